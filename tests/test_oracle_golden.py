@@ -1,0 +1,131 @@
+"""Pins the CPU oracle (oracle/) to fixtures produced by the REAL reference
+(tests/golden/make_golden.py, run in the dev container).  CPU only."""
+import numpy as np
+import torch
+
+from oracle import regularizers_ref as R
+from oracle import vgg_ref
+
+TINY = [16, "M", 16, "M", 32, 32, "M", 32, 32, "M"]
+T = lambda a: torch.from_numpy(np.asarray(a))  # noqa: E731
+
+
+def close(a, b, rtol=1e-5, atol=1e-6):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    scale = max(np.abs(b).max(), 1e-30)
+    assert a.shape == b.shape
+    err = np.abs(a - b).max()
+    assert err <= atol * scale + rtol * scale, (err, scale)
+
+
+def tiny_params(g, prefix="p", n=18):
+    return [T(g["%s%d" % (prefix, i)]) for i in range(n)]
+
+
+def test_g1_tiny_fwd_bwd(golden):
+    g = golden("G1_vgg_fwd_bwd")
+    params = tiny_params(g, "tiny_p")
+    x, y = T(g["tiny_x"]), T(g["tiny_y"])
+    for kind in ("ce_mean", "ce_sum", "mse_sum_zero"):
+        logits, loss, grads, _ = vgg_ref.loss_and_grads(params, TINY, x, y, kind)
+        close(logits, g["tiny_%s_logits" % kind])
+        close(loss, g["tiny_%s_loss" % kind])
+        for i, gr in enumerate(grads):
+            close(gr, g["tiny_%s_g%d" % (kind, i)])
+
+
+def test_g1_small_fwd_bwd(golden):
+    g = golden("G1_vgg_fwd_bwd")
+    cfg = vgg_ref.CFGS["small_VGG9"]
+    params = vgg_ref.init_params(cfg, (128, 128), 20, 64, np.random.RandomState(21))
+    gen = np.random.RandomState(22)
+    x = T(gen.standard_normal((4, 3, 64, 64)).astype(np.float32))
+    y = T(gen.randint(0, 20, size=(4,)).astype(np.int64))
+    logits, loss, grads, _ = vgg_ref.loss_and_grads(params, cfg, x, y, "ce_mean")
+    close(logits, g["small_logits"])
+    close(loss, g["small_loss"])
+    assert sum(p.numel() for p in params) == 615380  # small_VGG9_cl_128_128
+    for i, gr in enumerate(grads):
+        gd = gr.double()
+        st = np.array([gd.sum().item(), gd.abs().sum().item(), gd.pow(2).sum().sqrt().item()])
+        np.testing.assert_allclose(st[1:], g["small_g%d_stats" % i][1:], rtol=1e-5)
+        close(gr.flatten()[:64], g["small_g%d_head" % i], rtol=1e-4)
+
+
+def test_g2_ewc_fisher(golden):
+    g = golden("G2_ewc_fisher")
+    params = tiny_params(g)
+    prev = [torch.zeros_like(p) for p in params]
+    for task in range(2):
+        batches = [(T(g["t%d_x%d" % (task, b)]), T(g["t%d_y%d" % (task, b)])) for b in range(3)]
+        new = R.diag_fisher(params, TINY, batches, 24)
+        acc = [a + b for a, b in zip(prev, new)]   # accumelate_reg_params main_EWC.py:205-232
+        for i, o in enumerate(acc):
+            close(o, g["t%d_omega%d" % (task, i)], rtol=2e-5)
+        prev = acc
+
+
+def test_g3_mas_omega_short_last_batch(golden):
+    g = golden("G3_mas_omega")
+    params = tiny_params(g)
+    batches = [(T(g["x%d" % b]), T(g["y%d" % b])) for b in range(3)]
+    assert [b[0].shape[0] for b in batches] == [8, 8, 5]
+    omega = R.mas_importance(params, TINY, batches)
+    for i, o in enumerate(omega):
+        close(o, g["omega%d" % i], rtol=2e-5)
+
+
+def test_g4_si_steps_and_consolidation(golden):
+    g = golden("G4_si")
+    for tag, wd in (("wd0", 0.0), ("wd1", 1e-4)):
+        theta = tiny_params(g, tag + "_p")
+        omega = tiny_params(g, tag + "_omega")
+        init = tiny_params(g, tag + "_init")
+        w = [torch.zeros_like(t) for t in theta]
+        buf = [None] * len(theta)
+        for s in range(3):
+            x, y = T(g["%s_x%d" % (tag, s)]), T(g["%s_y%d" % (tag, s)])
+            _, _, grads, _ = vgg_ref.loss_and_grads(theta, TINY, x, y, "ce_mean")
+            for i in range(len(theta)):
+                theta[i], buf[i], w[i] = R.si_step(theta[i], grads[i], omega[i], init[i], w[i], buf[i],
+                                                   400, 1e-2, 0.9, wd, s == 0)
+        for i in range(len(theta)):
+            close(theta[i], g["%s_s2_theta%d" % (tag, i)], rtol=2e-5)
+            close(buf[i], g["%s_s2_buf%d" % (tag, i)], rtol=2e-4)
+            close(w[i], g["%s_s2_w%d" % (tag, i)], rtol=2e-4)
+            o, w0, iv = R.si_consolidate(omega[i], w[i], theta[i], init[i])
+            close(o, g["%s_cons_omega%d" % (tag, i)], rtol=2e-4)
+            close(iv, g["%s_cons_init%d" % (tag, i)], rtol=2e-5)
+            assert float(T(g["%s_cons_w%d" % (tag, i)]).abs().max()) == 0.0
+
+
+def test_g5_penalised_sgd(golden):
+    g = golden("G5_reg_sgd")
+    for tag, lam, wd in (("ewc", 400, 0.0), ("mas", 3, 5e-4)):
+        theta = tiny_params(g, tag + "_p")
+        n = len(theta)
+        omega = [T(g["%s_omega%d" % (tag, i)]) if i < n - 2 else None for i in range(n)]
+        init = [T(g["%s_init%d" % (tag, i)]) if i < n - 2 else None for i in range(n)]
+        buf = [None] * n
+        for s in range(3):
+            x, y = T(g["%s_x%d" % (tag, s)]), T(g["%s_y%d" % (tag, s)])
+            _, loss, grads, _ = vgg_ref.loss_and_grads(theta, TINY, x, y, "ce_mean")
+            close(loss, g["%s_s%d_loss" % (tag, s)], rtol=2e-5)
+            for i in range(n):
+                theta[i], buf[i] = R.reg_sgd_step(theta[i], grads[i], omega[i], init[i], buf[i],
+                                                  lam, 1e-2, 0.9, wd, s == 0)
+        for i in range(n):
+            close(theta[i], g["%s_s2_theta%d" % (tag, i)], rtol=2e-5)
+            close(buf[i], g["%s_s2_buf%d" % (tag, i)], rtol=2e-4)
+
+
+def test_g9_set_lr_traces(golden):
+    g = golden("G9_schedules")
+    for tag in ("ewc", "si"):
+        for case in range(3):
+            tr = R.set_lr_trace(list(g["%s_c%d_improved" % (tag, case)]), 0.01, tag)
+            ref = g["%s_c%d_trace" % (tag, case)]
+            assert len(tr) == len(ref)
+            for (ep, lr, cont), r in zip(tr, ref):
+                assert ep == int(r[0]) and cont == bool(r[2])
+                assert abs(lr - r[1]) <= 1e-12 * max(1.0, r[1])
