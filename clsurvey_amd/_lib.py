@@ -1,0 +1,85 @@
+"""ctypes binding of libclhip.so (include/clhip.h).  The product path has NO CPU fallback:
+if the library is missing or a call fails this raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libclhip.so")
+
+_p = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+_z = C.c_size_t
+_l = C.c_long
+
+
+class LayerDesc(C.Structure):
+    _fields_ = [("type", _i), ("cin", _i), ("cout", _i), ("relu", _i), ("pool", _i),
+                ("w_off", _l), ("b_off", _l)]
+
+
+# name -> (restype, argtypes); mirrors include/clhip.h one to one
+SIGNATURES = {
+    "clhip_version": (_i, []),
+    "clhip_arch": (C.c_char_p, []),
+    "clhip_conv3x3_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "clhip_conv3x3_bwd_data": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "clhip_conv3x3_bwd_weight_ws": (_z, [_i, _i, _i, _i, _i]),
+    "clhip_conv3x3_bwd_weight": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "clhip_maxpool2_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "clhip_maxpool2_bwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "clhip_fc_ws": (_z, [_i, _i, _i]),
+    "clhip_fc_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _z, _p]),
+    "clhip_fc_bwd_data": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
+    "clhip_fc_bwd_weight": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "clhip_relu_bwd": (_i, [_p, _p, _p, _z, _p]),
+    "clhip_softmax_ce": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p]),
+    "clhip_mse_zero_sum": (_i, [_p, _z, _p, _p, _p]),
+    "clhip_reg_sgd_step": (_i, [_p, _p, _p, _p, _p, _z, _f, _f, _f, _f, _i, _p]),
+    "clhip_fisher_accum": (_i, [_p, _p, _z, _f, _p]),
+    "clhip_mas_accum": (_i, [_p, _p, _z, _f, _f, _p]),
+    "clhip_si_step": (_i, [_p, _p, _p, _p, _p, _p, _z, _f, _f, _f, _f, _i, _p]),
+    "clhip_si_consolidate": (_i, [_p, _p, _p, _p, _z, _f, _p]),
+    "clhip_net_create": (_i, [C.POINTER(LayerDesc), _i, _i, _i, _i, _i, C.POINTER(_p)]),
+    "clhip_net_destroy": (None, [_p]),
+    "clhip_net_workspace_bytes": (_z, [_p]),
+    "clhip_net_num_classes": (_i, [_p]),
+    "clhip_net_forward": (_i, [_p, _p, _p, _i, _p, _p, _p]),
+    "clhip_net_backward": (_i, [_p, _p, _p, _p, _i, _p, _p, _p]),
+    "clhip_net_loss_step": (_i, [_p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p]),
+    "clhip_dbg_conv3x3_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "clhip_dbg_conv3x3_bwd_data": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "clhip_dbg_conv3x3_bwd_weight": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "clhip_dbg_mfma_probe": (_i, [_p, _p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle. Raises if the HIP library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "clsurvey_amd: %s not found. Build it with `python clsurvey_amd/build.py` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)      # AttributeError => symbol missing: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+class ClhipError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        if rc > 0:
+            raise ClhipError("%s: HIP error %d" % (what, rc))
+        names = {-1: "CLHIP_EINVAL", -2: "CLHIP_ENOSPC", -3: "CLHIP_ENOTSUP"}
+        raise ClhipError("%s: %s" % (what, names.get(rc, rc)))

@@ -1,0 +1,268 @@
+// 3x3 pad-1 stride-1 convolution for gfx950: implicit GEMM on v_mfma_f32_32x32x2_f32.
+//
+//   forward      y[n][k][h][w]  = relu?(b[k] + sum_{c,r,s} x[n][c][h+r-1][w+s-1] * wt[k][c][r][s])
+//   bwd (data)   dx[n][c][h][w] = mask * sum_{k,r',s'} dy[n][k][h+r'-1][w+s'-1] * wt[k][c][2-r'][2-s']
+//   bwd (weight) dw[k][c][r][s] = sum_{n,h,w} dy[n][k][h][w] * x[n][c][h+r-1][w+s-1]   (conv3x3_wgrad.hip)
+//
+// Layout is torch's own NCHW / KCRS: no repacking passes, and an NCHW plane row is what a
+// wave stores (32 consecutive pixels of one channel per accumulator register => 128 B lines).
+//
+// GEMM view (D = A.B per MFMA, 32x32 output, K = 2):
+//   D rows  (A operand, from LDS weight tile)      : 32 output channels
+//   D cols  (B operand, from LDS activation tile)  : 32 pixels of the block's spatial tile
+//   K pair                                         : two input channels (c, c+1), same tap (r,s)
+// The activation tile is staged ONCE per channel chunk with its 1-pixel halo, so the nine taps
+// read the same LDS plane at nine immediate offsets (no im2col buffer, 9x less HBM/L2 traffic).
+//
+// Block = 256 threads = 4 waves = (2 halves of 64 output channels) x (2 halves of BP pixels).
+// LDS per buffer: weights [CK*9][65] + activations [CK][PLANE]; two buffers, register-staged
+// prefetch of chunk t+1 while chunk t feeds the matrix pipe (one barrier per chunk).
+#include "common.hpp"
+
+namespace {
+
+constexpr int KT = 64;     // output channels per block
+constexpr int LDW = 65;    // weight-tile row stride (odd: conflict-free transposing ds_write)
+
+template <int TW, int TH, int NB>
+struct Geo {
+    static constexpr int BP = TW * TH * NB;          // pixels per block tile
+    static constexpr int TWP = TW + 2;               // halo row length
+    static constexpr int PLANE = NB * (TH + 2) * TWP;  // floats per staged channel plane
+    static constexpr int NT = BP / 64;               // 32-pixel subtiles per wave
+    static_assert(BP == 64 || BP == 128, "block tile must hold 64 or 128 pixels");
+    static_assert(32 % TW == 0 || TW == 32, "TW must divide 32");
+};
+
+// MODE 0: forward (wt used as is, bias+relu epilogue)
+// MODE 1: backward-data (in = dy with Kw channels, out = dx with Cw channels, taps flipped)
+template <int TW, int TH, int NB, int CK, int MODE>
+__global__ __launch_bounds__(256) void conv3x3_mfma_kernel(
+    const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
+    const float* __restrict__ mask_src, float* __restrict__ out,
+    int N, int Cin, int Cout, int H, int W, int Kw, int Cw, int relu,
+    int tiles_w, int tiles_h, int n_pix_tiles) {
+    using G = Geo<TW, TH, NB>;
+    constexpr int WS_FLOATS = CK * 9 * LDW;
+    constexpr int XS_FLOATS = CK * G::PLANE;
+    constexpr int BUF_FLOATS = WS_FLOATS + XS_FLOATS;
+    __shared__ float lds[2 * BUF_FLOATS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wk = wave & 1;        // which 32 output channels
+    const int wp = wave >> 1;       // which half of the pixels
+    const int li = lane & 31;
+    const int kk = lane >> 5;
+
+    // block -> (output-channel tile, pixel tile); pixel tile fastest so concurrently resident
+    // blocks share one weight slice in L2.
+    const int bid = blockIdx.x;
+    const int kt = bid / n_pix_tiles;
+    const int pt = bid - kt * n_pix_tiles;
+    const int tw_i = pt % tiles_w;
+    const int th_i = (pt / tiles_w) % tiles_h;
+    const int ng = pt / (tiles_w * tiles_h);
+    const int n0 = ng * NB, h0 = th_i * TH, w0 = tw_i * TW;
+    const int ko0 = kt * KT;        // first output channel of this block
+
+    // per-lane LDS offsets of this wave's pixel subtiles (pixel q -> halo-plane address)
+    int pixoff[G::NT];
+#pragma unroll
+    for (int t = 0; t < G::NT; ++t) {
+        int q = (wp * G::NT + t) * 32 + li;
+        int tw = q % TW, th = (q / TW) % TH, nb = q / (TW * TH);
+        pixoff[t] = (nb * (TH + 2) + th) * G::TWP + tw;
+    }
+    const int a_lane = kk * 9 * LDW + wk * 32 + li;   // weight-tile read offset
+    const int b_lane = kk * G::PLANE;                 // activation-plane read offset
+
+    floatx16 acc[G::NT];
+#pragma unroll
+    for (int t = 0; t < G::NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    constexpr int W_ELEMS = KT * CK * 9;
+    constexpr int W_ITERS = (W_ELEMS + 255) / 256;
+    constexpr int X_ITERS = (XS_FLOATS + 255) / 256;
+    float wreg[W_ITERS];
+    float xreg[X_ITERS];
+
+    const size_t in_img = (size_t)Cin * H * W;
+    const int n_chunks = (Cin + CK - 1) / CK;
+
+    auto load_chunk = [&](int chunk) {
+        const int c0 = chunk * CK;
+        // ---- weights
+#pragma unroll
+        for (int j = 0; j < W_ITERS; ++j) {
+            int e = tid + 256 * j;
+            float v = 0.f;
+            if (e < W_ELEMS) {
+                if (MODE == 0) {
+                    int kl = e / (CK * 9), kidx = e - kl * (CK * 9);
+                    int c = c0 + kidx / 9;
+                    int k = ko0 + kl;
+                    if (k < Kw && c < Cw) v = wt[((size_t)k * Cw) * 9 + (size_t)c0 * 9 + kidx];
+                } else {
+                    // out-channel role = c (Cw), in-channel role = k (Kw); e runs (kl, cl, rs)
+                    int kl = e / (KT * 9), rem = e - kl * (KT * 9);
+                    int cl = rem / 9;
+                    int k = c0 + kl, c = ko0 + cl;
+                    if (k < Kw && c < Cw) v = wt[((size_t)k * Cw + ko0) * 9 + rem];
+                }
+            }
+            wreg[j] = v;
+        }
+        // ---- activations (with halo, zero padded)
+#pragma unroll
+        for (int j = 0; j < X_ITERS; ++j) {
+            int e = tid + 256 * j;
+            float v = 0.f;
+            if (e < XS_FLOATS) {
+                int cl = e / G::PLANE, rem = e - cl * G::PLANE;
+                int col = rem % G::TWP;
+                int rr = rem / G::TWP;
+                int row = rr % (TH + 2), nb = rr / (TH + 2);
+                int c = c0 + cl, n = n0 + nb, h = h0 - 1 + row, w = w0 - 1 + col;
+                if (c < Cin && n < N && h >= 0 && h < H && w >= 0 && w < W)
+                    v = in[(size_t)n * in_img + ((size_t)c * H + h) * W + w];
+            }
+            xreg[j] = v;
+        }
+    };
+
+    auto store_chunk = [&](int buf) {
+        float* ws = lds + buf * BUF_FLOATS;
+        float* xs = ws + WS_FLOATS;
+#pragma unroll
+        for (int j = 0; j < W_ITERS; ++j) {
+            int e = tid + 256 * j;
+            if (e < W_ELEMS) {
+                if (MODE == 0) {
+                    int kl = e / (CK * 9), kidx = e - kl * (CK * 9);
+                    ws[kidx * LDW + kl] = wreg[j];
+                } else {
+                    int kl = e / (KT * 9), rem = e - kl * (KT * 9);
+                    int cl = rem / 9, rs = rem - cl * 9;
+                    ws[(kl * 9 + (8 - rs)) * LDW + cl] = wreg[j];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < X_ITERS; ++j) {
+            int e = tid + 256 * j;
+            if (e < XS_FLOATS) xs[e] = xreg[j];
+        }
+    };
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        const int buf = chunk & 1;
+        if (chunk + 1 < n_chunks) load_chunk(chunk + 1);
+
+        const float* ws = lds + buf * BUF_FLOATS + a_lane;
+        const float* xs = lds + buf * BUF_FLOATS + WS_FLOATS + b_lane;
+#pragma unroll
+        for (int cp = 0; cp < CK / 2; ++cp) {
+#pragma unroll
+            for (int rs = 0; rs < 9; ++rs) {
+                const int r = rs / 3, s = rs - 3 * (rs / 3);
+                float a = ws[((2 * cp) * 9 + rs) * LDW];
+#pragma unroll
+                for (int t = 0; t < G::NT; ++t) {
+                    float b = xs[(2 * cp) * G::PLANE + pixoff[t] + r * G::TWP + s];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+                }
+            }
+        }
+
+        if (chunk + 1 < n_chunks) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: reg r of lane l = D[row = out-channel][col = pixel li]
+    const size_t out_img = (size_t)Cout * H * W;
+#pragma unroll
+    for (int t = 0; t < G::NT; ++t) {
+        int q = (wp * G::NT + t) * 32 + li;
+        int tw = q % TW, th = (q / TW) % TH, nb = q / (TW * TH);
+        int n = n0 + nb, h = h0 + th, w = w0 + tw;
+        bool pix_ok = (n < N) && (h < H) && (w < W);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int ko = ko0 + wk * 32 + mfma32_row(r, lane);
+            if (pix_ok && ko < Cout) {
+                size_t o = (size_t)n * out_img + ((size_t)ko * H + h) * W + w;
+                float v = acc[t][r];
+                if (MODE == 0) {
+                    if (bias) v += bias[ko];
+                    if (relu) v = fmaxf(v, 0.f);
+                } else {
+                    if (mask_src) v = mask_src[o] > 0.f ? v : 0.f;
+                }
+                out[o] = v;
+            }
+        }
+    }
+}
+
+template <int TW, int TH, int NB, int CK, int MODE>
+int launch_geo(const float* in, const float* wt, const float* bias, const float* mask_src, float* out,
+               int N, int Cin, int Cout, int H, int W, int Kw, int Cw, int relu, hipStream_t s) {
+    int tiles_w = (W + TW - 1) / TW, tiles_h = (H + TH - 1) / TH, ngrp = (N + NB - 1) / NB;
+    int n_pix_tiles = tiles_w * tiles_h * ngrp;
+    int kts = (Cout + KT - 1) / KT;
+    long long blocks = (long long)n_pix_tiles * kts;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return CLHIP_EINVAL;
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<TW, TH, NB, CK, MODE>), dim3((unsigned)blocks), dim3(256), 0, s,
+                       in, wt, bias, mask_src, out, N, Cin, Cout, H, W, Kw, Cw, relu, tiles_w, tiles_h, n_pix_tiles);
+    CLHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// Tile geometry choice: full 128-pixel tiles while they still give >= ~2 blocks per CU,
+// otherwise 64-pixel tiles (deep layers at 8x8 / 16x16 have few pixels).
+template <int CK, int MODE>
+int launch_conv(const float* in, const float* wt, const float* bias, const float* mask_src, float* out,
+                int N, int Cin, int Cout, int H, int W, int Kw, int Cw, int relu, hipStream_t s) {
+    const int kts = (Cout + KT - 1) / KT;
+    const long long pix = (long long)N * H * W;
+    const bool big = (pix / 128) * kts >= 512;
+    if (W >= 32 || W > 16) {
+        if (big) return launch_geo<32, 4, 1, CK, MODE>(in, wt, bias, mask_src, out, N, Cin, Cout, H, W, Kw, Cw, relu, s);
+        return launch_geo<32, 2, 1, CK, MODE>(in, wt, bias, mask_src, out, N, Cin, Cout, H, W, Kw, Cw, relu, s);
+    } else if (W > 8) {
+        if (big) return launch_geo<16, 8, 1, CK, MODE>(in, wt, bias, mask_src, out, N, Cin, Cout, H, W, Kw, Cw, relu, s);
+        return launch_geo<16, 4, 1, CK, MODE>(in, wt, bias, mask_src, out, N, Cin, Cout, H, W, Kw, Cw, relu, s);
+    } else {
+        if (big && H > 4) return launch_geo<8, 8, 2, CK, MODE>(in, wt, bias, mask_src, out, N, Cin, Cout, H, W, Kw, Cw, relu, s);
+        return launch_geo<8, 8, 1, CK, MODE>(in, wt, bias, mask_src, out, N, Cin, Cout, H, W, Kw, Cw, relu, s);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int clhip_conv3x3_fwd(const float* x, const float* w, const float* b, float* y,
+                      int N, int C, int K, int H, int W, int relu, void* stream) {
+    if (!x || !w || !y || N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0) return CLHIP_EINVAL;
+    hipStream_t s = as_stream(stream);
+    if (C <= 4) return launch_conv<4, 0>(x, w, b, nullptr, y, N, C, K, H, W, K, C, relu, s);
+    return launch_conv<8, 0>(x, w, b, nullptr, y, N, C, K, H, W, K, C, relu, s);
+}
+
+int clhip_conv3x3_bwd_data(const float* dy, const float* w, const float* relu_src, float* dx,
+                           int N, int C, int K, int H, int W, void* stream) {
+    if (!dy || !w || !dx || N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0) return CLHIP_EINVAL;
+    // in = dy (K channels), out = dx (C channels)
+    return launch_conv<8, 1>(dy, w, nullptr, relu_src, dx, N, K, C, H, W, K, C, 0, as_stream(stream));
+}
+
+}  // extern "C"

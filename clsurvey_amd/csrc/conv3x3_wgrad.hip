@@ -1,0 +1,327 @@
+// Weight/bias gradient of the 3x3 pad-1 convolution on v_mfma_f32_32x32x2_f32.
+//
+//   dw[k][c][r][s] = sum_{n,h,w} dy[n][k][h][w] * x[n][c][h+r-1][w+s-1]     db[k] = sum dy[n][k][h][w]
+//
+// GEMM view: D rows = 32 output channels k (A operand = dy), D cols = 32 input channels c
+// (B operand = x shifted by the tap), reduction (MFMA K) = pixels, two per instruction.
+// One A fragment feeds NINE MFMAs (one accumulator per tap): 10 ds_read_b32 per 9 MFMAs.
+//
+// The reduction dimension (N*H*W, up to 819 200) is split across blocks; every block writes a
+// partial [9][K][C] slab into the caller's workspace and a second kernel sums the slabs in a
+// fixed order => bitwise run-to-run deterministic (the reference seeds everything and sets
+// cudnn.deterministic, utilities/utils.py:52-58).
+//
+// First layer (C <= 3): the 27 (c,r,s) combinations become the D columns of ONE accumulator
+// (84 % of the MFMA columns useful instead of 9 %).
+#include "common.hpp"
+
+namespace {
+
+constexpr int KT = 64, CT = 64;
+
+template <int TW, int TH>
+struct WGeo {
+    static constexpr int BP = TW * TH;                 // 64 pixels per stage, one image
+    static constexpr int TWP = TW + 2;
+    static constexpr int PLANE = (TH + 2) * TWP;
+    static constexpr int PLANEP = PLANE | 1;           // odd stride: conflict-free lane-per-channel reads
+    static constexpr int LDP = BP + 1;                 // dy tile row stride (odd)
+    static_assert(BP == 64, "stage is 64 pixels");
+};
+
+__device__ __forceinline__ void decode_stage(int st, int tiles_w, int tiles_h, int TW, int TH,
+                                             int& n, int& h0, int& w0) {
+    int tw_i = st % tiles_w;
+    int t = st / tiles_w;
+    int th_i = t % tiles_h;
+    n = t / tiles_h;
+    h0 = th_i * TH;
+    w0 = tw_i * TW;
+}
+
+// grid.x = n_tiles(k,c) * splits ; block 256 = 4 waves = (2 k-halves) x (2 c-halves)
+template <int TW, int TH>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part_dw,
+    float* __restrict__ part_db, int N, int C, int K, int H, int W, int tiles_w, int tiles_h,
+    int total_stages, int splits, int c_tiles) {
+    using G = WGeo<TW, TH>;
+    __shared__ float dys[KT * G::LDP];
+    __shared__ float xs[CT * G::PLANEP];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave & 1, wc = wave >> 1;
+    const int li = lane & 31, kk = lane >> 5;
+
+    const int split = blockIdx.x % splits;
+    const int tile = blockIdx.x / splits;
+    const int ct = tile % c_tiles, kt = tile / c_tiles;
+    const int k0 = kt * KT, c0 = ct * CT;
+
+    // contiguous, balanced stage range of this split
+    const int per = total_stages / splits, extra = total_stages % splits;
+    const int st_begin = split * per + min(split, extra);
+    const int st_end = st_begin + per + (split < extra ? 1 : 0);
+
+    floatx16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bsum = 0.f;
+
+    const float* a_ptr = dys + (wk * 32 + li) * G::LDP + kk;
+    const float* b_ptr = xs + (wc * 32 + li) * G::PLANEP + kk;
+    const size_t plane_hw = (size_t)H * W;
+
+    for (int st = st_begin; st < st_end; ++st) {
+        int n, h0, w0;
+        decode_stage(st, tiles_w, tiles_h, TW, TH, n, h0, w0);
+        __syncthreads();   // previous stage's LDS reads are done
+        // ---- dy tile: [64 k][64 px]
+        constexpr int DY_ITERS = KT * G::BP / 256;
+#pragma unroll
+        for (int j = 0; j < DY_ITERS; ++j) {
+            int e = tid + 256 * j;
+            int kl = e / G::BP, q = e - kl * G::BP;
+            int th = q / TW, tw = q - th * TW;
+            int k = k0 + kl, h = h0 + th, w = w0 + tw;
+            float v = 0.f;
+            if (k < K && h < H && w < W) v = dy[((size_t)n * K + k) * plane_hw + (size_t)h * W + w];
+            dys[kl * G::LDP + q] = v;
+        }
+        // ---- x halo tile: [64 c][PLANE]
+        constexpr int X_ELEMS = CT * G::PLANE;
+        constexpr int X_ITERS = (X_ELEMS + 255) / 256;
+#pragma unroll 4
+        for (int j = 0; j < X_ITERS; ++j) {
+            int e = tid + 256 * j;
+            if (e < X_ELEMS) {
+                int cl = e / G::PLANE, rem = e - cl * G::PLANE;
+                int row = rem / G::TWP, col = rem - row * G::TWP;
+                int c = c0 + cl, h = h0 - 1 + row, w = w0 - 1 + col;
+                float v = 0.f;
+                if (c < C && h >= 0 && h < H && w >= 0 && w < W)
+                    v = x[((size_t)n * C + c) * plane_hw + (size_t)h * W + w];
+                xs[cl * G::PLANEP + rem] = v;
+            }
+        }
+        __syncthreads();
+        // ---- 32 pixel pairs x 9 taps
+#pragma unroll
+        for (int pp = 0; pp < G::BP / 2; ++pp) {
+            constexpr int dummy = 0; (void)dummy;
+            const int q0 = 2 * pp;
+            const int th = q0 / TW, tw = q0 - (q0 / TW) * TW;
+            float a = a_ptr[q0];
+            bsum += a;
+#pragma unroll
+            for (int rs = 0; rs < 9; ++rs) {
+                const int r = rs / 3, s = rs - 3 * (rs / 3);
+                float b = b_ptr[(th + r) * G::TWP + tw + s];
+                acc[rs] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[rs], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- partial slab [split][9][K][C]: reg r of lane l = D[row = k][col = c]
+    float* slab = part_dw + (size_t)split * 9 * K * C;
+    const int c = c0 + wc * 32 + li;
+#pragma unroll
+    for (int rs = 0; rs < 9; ++rs)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int k = k0 + wk * 32 + mfma32_row(r, lane);
+            if (k < K && c < C) slab[((size_t)rs * K + k) * C + c] = acc[rs][r];
+        }
+    if (part_db && ct == 0 && wc == 0) {
+        bsum += __shfl_xor(bsum, 32, 64);
+        int k = k0 + wk * 32 + li;
+        if (kk == 0 && k < K) part_db[(size_t)split * K + k] = bsum;
+    }
+}
+
+// First-layer variant: C*9 <= 32 columns in one accumulator. Block = 128 threads = 2 waves
+// (k halves of a 64-channel tile).
+template <int TW, int TH>
+__global__ __launch_bounds__(128) void conv3x3_wgrad_smallc_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part_dw,
+    float* __restrict__ part_db, int N, int C, int K, int H, int W, int tiles_w, int tiles_h,
+    int total_stages, int splits) {
+    using G = WGeo<TW, TH>;
+    __shared__ float dys[KT * G::LDP];
+    __shared__ float xs[3 * G::PLANE + 8];
+
+    const int tid = threadIdx.x, lane = tid & 63, wk = tid >> 6;
+    const int li = lane & 31, kk = lane >> 5;
+    const int split = blockIdx.x % splits;
+    const int kt = blockIdx.x / splits;
+    const int k0 = kt * KT;
+    const int per = total_stages / splits, extra = total_stages % splits;
+    const int st_begin = split * per + min(split, extra);
+    const int st_end = st_begin + per + (split < extra ? 1 : 0);
+
+    floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float bsum = 0.f;
+
+    // column li -> (c, r, s); columns >= C*9 read a valid dummy address, never stored
+    const int ncol = C * 9;
+    int col_off = 0;
+    if (li < ncol) {
+        int cc = li / 9, rs = li - cc * 9;
+        col_off = cc * G::PLANE + (rs / 3) * G::TWP + (rs % 3);
+    }
+    const float* a_ptr = dys + (wk * 32 + li) * G::LDP + kk;
+    const float* b_ptr = xs + col_off + kk;
+    const size_t plane_hw = (size_t)H * W;
+
+    for (int st = st_begin; st < st_end; ++st) {
+        int n, h0, w0;
+        decode_stage(st, tiles_w, tiles_h, TW, TH, n, h0, w0);
+        __syncthreads();
+        constexpr int DY_ITERS = KT * G::BP / 128;
+#pragma unroll 8
+        for (int j = 0; j < DY_ITERS; ++j) {
+            int e = tid + 128 * j;
+            int kl = e / G::BP, q = e - kl * G::BP;
+            int th = q / TW, tw = q - th * TW;
+            int k = k0 + kl, h = h0 + th, w = w0 + tw;
+            float v = 0.f;
+            if (k < K && h < H && w < W) v = dy[((size_t)n * K + k) * plane_hw + (size_t)h * W + w];
+            dys[kl * G::LDP + q] = v;
+        }
+        constexpr int X_ELEMS = 3 * G::PLANE;
+        constexpr int X_ITERS = (X_ELEMS + 127) / 128;
+#pragma unroll
+        for (int j = 0; j < X_ITERS; ++j) {
+            int e = tid + 128 * j;
+            if (e < X_ELEMS) {
+                int cl = e / G::PLANE, rem = e - cl * G::PLANE;
+                int row = rem / G::TWP, col = rem - row * G::TWP;
+                int h = h0 - 1 + row, w = w0 - 1 + col;
+                float v = 0.f;
+                if (cl < C && h >= 0 && h < H && w >= 0 && w < W)
+                    v = x[((size_t)n * C + cl) * plane_hw + (size_t)h * W + w];
+                xs[e] = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pp = 0; pp < G::BP / 2; ++pp) {
+            const int q0 = 2 * pp;
+            const int th = q0 / TW, tw = q0 - (q0 / TW) * TW;
+            float a = a_ptr[q0];
+            bsum += a;
+            float b = b_ptr[th * G::TWP + tw];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+    }
+    // slab layout [split][9][K][C] like the general kernel
+    float* slab = part_dw + (size_t)split * 9 * K * C;
+    if (li < ncol) {
+        int cc = li / 9, rs = li - cc * 9;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int k = k0 + wk * 32 + mfma32_row(r, lane);
+            if (k < K) slab[((size_t)rs * K + k) * C + cc] = acc[r];
+        }
+    }
+    if (part_db) {
+        bsum += __shfl_xor(bsum, 32, 64);
+        int k = k0 + wk * 32 + li;
+        if (kk == 0 && k < K) part_db[(size_t)split * K + k] = bsum;
+    }
+}
+
+// dw[k][c][rs] = sum_s slab[s][rs][k][c] (fixed order); db likewise.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part_dw,
+                                                           const float* __restrict__ part_db,
+                                                           float* __restrict__ dw, float* __restrict__ db,
+                                                           int K, int C, int splits) {
+    const size_t kc = (size_t)K * C, total = 9 * kc;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total + (db ? K : 0); e += stride) {
+        if (e < total) {
+            float s = 0.f;
+            for (int sp = 0; sp < splits; ++sp) s += part_dw[(size_t)sp * total + e];
+            size_t rs = e / kc, rem = e - rs * kc;     // rem = k*C + c
+            dw[rem * 9 + rs] = s;
+        } else {
+            size_t k = e - total;
+            float s = 0.f;
+            for (int sp = 0; sp < splits; ++sp) s += part_db[(size_t)sp * K + k];
+            db[k] = s;
+        }
+    }
+}
+
+struct WPlan {
+    int TW, TH, tiles_w, tiles_h, total_stages, splits, k_tiles, c_tiles;
+    size_t ws_floats;
+};
+
+WPlan make_plan(int N, int C, int K, int H, int W) {
+    WPlan p;
+    if (W > 16) { p.TW = 32; p.TH = 2; }
+    else if (W > 8) { p.TW = 16; p.TH = 4; }
+    else { p.TW = 8; p.TH = 8; }
+    p.tiles_w = (W + p.TW - 1) / p.TW;
+    p.tiles_h = (H + p.TH - 1) / p.TH;
+    p.total_stages = p.tiles_w * p.tiles_h * N;
+    p.k_tiles = (K + KT - 1) / KT;
+    p.c_tiles = (C * 9 <= 32) ? 1 : (C + CT - 1) / CT;
+    int tiles = p.k_tiles * p.c_tiles;
+    int target = (C * 9 <= 32) ? 2048 : 512;           // blocks wanted in flight
+    int splits = (target + tiles - 1) / tiles;
+    if (splits > p.total_stages) splits = p.total_stages;
+    // keep the partial slabs under 96 MiB
+    size_t slab = (size_t)9 * K * C + K;
+    size_t max_splits = ((size_t)96 << 20) / (slab * sizeof(float));
+    if (max_splits < 1) max_splits = 1;
+    if ((size_t)splits > max_splits) splits = (int)max_splits;
+    if (splits < 1) splits = 1;
+    p.splits = splits;
+    p.ws_floats = slab * (size_t)splits;
+    return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t clhip_conv3x3_bwd_weight_ws(int N, int C, int K, int H, int W) {
+    if (N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0) return 0;
+    return make_plan(N, C, K, H, W).ws_floats * sizeof(float);
+}
+
+int clhip_conv3x3_bwd_weight(const float* x, const float* dy, float* dw, float* db,
+                             int N, int C, int K, int H, int W, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !dy || !dw || !ws || N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0) return CLHIP_EINVAL;
+    WPlan p = make_plan(N, C, K, H, W);
+    if (ws_bytes < p.ws_floats * sizeof(float)) return CLHIP_ENOSPC;
+    hipStream_t s = as_stream(stream);
+    float* part_dw = static_cast<float*>(ws);
+    float* part_db = part_dw + (size_t)p.splits * 9 * K * C;
+    const bool smallc = (C * 9 <= 32);
+    unsigned grid = (unsigned)(p.k_tiles * p.c_tiles * p.splits);
+#define WG_ARGS x, dy, part_dw, part_db, N, C, K, H, W, p.tiles_w, p.tiles_h, p.total_stages, p.splits
+    if (smallc) {
+        if (p.TW == 32) hipLaunchKernelGGL((conv3x3_wgrad_smallc_kernel<32, 2>), dim3(grid), dim3(128), 0, s, WG_ARGS);
+        else if (p.TW == 16) hipLaunchKernelGGL((conv3x3_wgrad_smallc_kernel<16, 4>), dim3(grid), dim3(128), 0, s, WG_ARGS);
+        else hipLaunchKernelGGL((conv3x3_wgrad_smallc_kernel<8, 8>), dim3(grid), dim3(128), 0, s, WG_ARGS);
+    } else {
+        if (p.TW == 32) hipLaunchKernelGGL((conv3x3_wgrad_kernel<32, 2>), dim3(grid), dim3(256), 0, s, WG_ARGS, p.c_tiles);
+        else if (p.TW == 16) hipLaunchKernelGGL((conv3x3_wgrad_kernel<16, 4>), dim3(grid), dim3(256), 0, s, WG_ARGS, p.c_tiles);
+        else hipLaunchKernelGGL((conv3x3_wgrad_kernel<8, 8>), dim3(grid), dim3(256), 0, s, WG_ARGS, p.c_tiles);
+    }
+#undef WG_ARGS
+    CLHIP_LAUNCH_CHECK();
+    size_t total = (size_t)9 * K * C + (db ? K : 0);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, s, part_dw, part_db, dw, db, K, C, p.splits);
+    CLHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

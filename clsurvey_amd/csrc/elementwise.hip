@@ -1,0 +1,198 @@
+// HBM-bound fused optimizer / importance-weight kernels (one pass over the parameter arena).
+// Reference arithmetic restated per kernel; algorithmic bytes per parameter in DESIGN.md.
+#include "common.hpp"
+
+namespace {
+
+constexpr int EW_BLOCK = 256;
+
+// Generic driver: applies F to n elements, float4-vectorised when every pointer is 16B aligned.
+template <class F>
+__global__ __launch_bounds__(EW_BLOCK) void ew_kernel(size_t n, size_t n4, F f) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (size_t i = tid; i < n4; i += stride) f.vec(i);
+    for (size_t i = n4 * 4 + tid; i < n; i += stride) f.scalar(i);
+}
+
+template <class F>
+int ew_launch(size_t n, bool vec_ok, F f, hipStream_t s) {
+    if (n == 0) return 0;
+    size_t n4 = vec_ok ? n / 4 : 0;
+    size_t items = vec_ok ? (n4 > 0 ? n4 : 1) : n;
+    hipLaunchKernelGGL(ew_kernel<F>, dim3(ew_grid(items, EW_BLOCK)), dim3(EW_BLOCK), 0, s, n, n4, f);
+    CLHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+struct RegSgd {
+    float* theta; const float* grad; const float* omega; const float* init; float* buf;
+    float two_lambda, lr, momentum, wd; int first;
+    __device__ __forceinline__ float one(float th, float g, float om, float iv, float& b) const {
+        float d = g + (th - iv) * (two_lambda * om);   // train_EWC.py:62-65
+        d = d + wd * th;                               // :70-71
+        b = first ? d : (b * momentum + d);            // :72-78
+        return th - lr * b;                            // :83
+    }
+    __device__ __forceinline__ void scalar(size_t i) const {
+        float b = first ? 0.f : buf[i];
+        float om = omega ? omega[i] : 0.f, iv = omega ? init[i] : 0.f;
+        float t = one(theta[i], grad[i], om, iv, b);
+        buf[i] = b; theta[i] = t;
+    }
+    __device__ __forceinline__ void vec(size_t i) const {
+        float4 th = reinterpret_cast<const float4*>(theta)[i];
+        float4 g = reinterpret_cast<const float4*>(grad)[i];
+        float4 om = omega ? reinterpret_cast<const float4*>(omega)[i] : make_float4(0, 0, 0, 0);
+        float4 iv = omega ? reinterpret_cast<const float4*>(init)[i] : make_float4(0, 0, 0, 0);
+        float4 b = first ? make_float4(0, 0, 0, 0) : reinterpret_cast<const float4*>(buf)[i];
+        th.x = one(th.x, g.x, om.x, iv.x, b.x); th.y = one(th.y, g.y, om.y, iv.y, b.y);
+        th.z = one(th.z, g.z, om.z, iv.z, b.z); th.w = one(th.w, g.w, om.w, iv.w, b.w);
+        reinterpret_cast<float4*>(buf)[i] = b;
+        reinterpret_cast<float4*>(theta)[i] = th;
+    }
+};
+
+struct FisherAcc {
+    float* omega; const float* grad; float data_len;
+    __device__ __forceinline__ void scalar(size_t i) const { float g = grad[i]; omega[i] += g * g / data_len; }
+    __device__ __forceinline__ void vec(size_t i) const {
+        float4 o = reinterpret_cast<float4*>(omega)[i];
+        float4 g = reinterpret_cast<const float4*>(grad)[i];
+        o.x += g.x * g.x / data_len; o.y += g.y * g.y / data_len;
+        o.z += g.z * g.z / data_len; o.w += g.w * g.w / data_len;
+        reinterpret_cast<float4*>(omega)[i] = o;
+    }
+};
+
+struct MasAcc {
+    float* omega; const float* grad; float prev, curr;
+    __device__ __forceinline__ float one(float o, float g) const { return (o * prev + fabsf(g)) / curr; }
+    __device__ __forceinline__ void scalar(size_t i) const { omega[i] = one(omega[i], grad[i]); }
+    __device__ __forceinline__ void vec(size_t i) const {
+        float4 o = reinterpret_cast<float4*>(omega)[i];
+        float4 g = reinterpret_cast<const float4*>(grad)[i];
+        o.x = one(o.x, g.x); o.y = one(o.y, g.y); o.z = one(o.z, g.z); o.w = one(o.w, g.w);
+        reinterpret_cast<float4*>(omega)[i] = o;
+    }
+};
+
+struct SiStep {
+    float* theta; const float* grad; const float* omega; const float* init; float* w; float* buf;
+    float two_lambda, lr, momentum, wd; int first;
+    __device__ __forceinline__ float one(float th, float g, float om, float iv, float& b, float& wv) const {
+        float d = g + (th - iv) * (two_lambda * om);   // train_SI.py:69-73
+        d = d + wd * th;                               // :82-83
+        b = first ? d : (b * momentum + d);            // :85-96
+        float tn = th - lr * b;                        // :98
+        wv = wv + ((tn - th) * g) * -1.f;              // :99-120 (unregularised g, actual step)
+        return tn;
+    }
+    __device__ __forceinline__ void scalar(size_t i) const {
+        float b = first ? 0.f : buf[i]; float wv = w[i];
+        float t = one(theta[i], grad[i], omega[i], init[i], b, wv);
+        buf[i] = b; w[i] = wv; theta[i] = t;
+    }
+    __device__ __forceinline__ void vec(size_t i) const {
+        float4 th = reinterpret_cast<const float4*>(theta)[i];
+        float4 g = reinterpret_cast<const float4*>(grad)[i];
+        float4 om = reinterpret_cast<const float4*>(omega)[i];
+        float4 iv = reinterpret_cast<const float4*>(init)[i];
+        float4 wv = reinterpret_cast<const float4*>(w)[i];
+        float4 b = first ? make_float4(0, 0, 0, 0) : reinterpret_cast<const float4*>(buf)[i];
+        th.x = one(th.x, g.x, om.x, iv.x, b.x, wv.x); th.y = one(th.y, g.y, om.y, iv.y, b.y, wv.y);
+        th.z = one(th.z, g.z, om.z, iv.z, b.z, wv.z); th.w = one(th.w, g.w, om.w, iv.w, b.w, wv.w);
+        reinterpret_cast<float4*>(buf)[i] = b;
+        reinterpret_cast<float4*>(w)[i] = wv;
+        reinterpret_cast<float4*>(theta)[i] = th;
+    }
+};
+
+struct SiCons {
+    float* omega; float* w; const float* theta; float* init; float slack;
+    __device__ __forceinline__ float one(float o, float wv, float th, float iv) const {
+        float pd = th - iv;
+        float t = wv / (pd * pd + slack);              // train_SI.py:331-334
+        return o + fmaxf(t, 0.f);                      // :346-350
+    }
+    __device__ __forceinline__ void scalar(size_t i) const {
+        float th = theta[i];
+        omega[i] = one(omega[i], w[i], th, init[i]); w[i] = 0.f; init[i] = th;
+    }
+    __device__ __forceinline__ void vec(size_t i) const {
+        float4 th = reinterpret_cast<const float4*>(theta)[i];
+        float4 o = reinterpret_cast<float4*>(omega)[i];
+        float4 wv = reinterpret_cast<float4*>(w)[i];
+        float4 iv = reinterpret_cast<float4*>(init)[i];
+        o.x = one(o.x, wv.x, th.x, iv.x); o.y = one(o.y, wv.y, th.y, iv.y);
+        o.z = one(o.z, wv.z, th.z, iv.z); o.w = one(o.w, wv.w, th.w, iv.w);
+        reinterpret_cast<float4*>(omega)[i] = o;
+        reinterpret_cast<float4*>(w)[i] = make_float4(0, 0, 0, 0);
+        reinterpret_cast<float4*>(init)[i] = th;
+    }
+};
+
+struct ReluBwd {
+    const float* dy; const float* y; float* dx;
+    __device__ __forceinline__ void scalar(size_t i) const { dx[i] = y[i] > 0.f ? dy[i] : 0.f; }
+    __device__ __forceinline__ void vec(size_t i) const {
+        float4 a = reinterpret_cast<const float4*>(dy)[i];
+        float4 b = reinterpret_cast<const float4*>(y)[i];
+        a.x = b.x > 0.f ? a.x : 0.f; a.y = b.y > 0.f ? a.y : 0.f;
+        a.z = b.z > 0.f ? a.z : 0.f; a.w = b.w > 0.f ? a.w : 0.f;
+        reinterpret_cast<float4*>(dx)[i] = a;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int clhip_reg_sgd_step(float* theta, const float* grad, const float* omega, const float* init_val,
+                       float* buf, size_t n, float reg_lambda, float lr, float momentum, float wd,
+                       int first, void* stream) {
+    if (!theta || !grad || !buf || (omega && !init_val)) return CLHIP_EINVAL;
+    RegSgd f{theta, grad, omega, init_val, buf, 2.f * reg_lambda, lr, momentum, wd, first};
+    bool v = aligned16(theta) && aligned16(grad) && aligned16(buf) && (!omega || (aligned16(omega) && aligned16(init_val)));
+    return ew_launch(n, v, f, as_stream(stream));
+}
+
+int clhip_fisher_accum(float* omega, const float* grad, size_t n, float data_len, void* stream) {
+    if (!omega || !grad || data_len <= 0.f) return CLHIP_EINVAL;
+    FisherAcc f{omega, grad, data_len};
+    return ew_launch(n, aligned16(omega) && aligned16(grad), f, as_stream(stream));
+}
+
+int clhip_mas_accum(float* omega, const float* grad, size_t n, float prev_size, float curr_size, void* stream) {
+    if (!omega || !grad || curr_size <= 0.f) return CLHIP_EINVAL;
+    MasAcc f{omega, grad, prev_size, curr_size};
+    return ew_launch(n, aligned16(omega) && aligned16(grad), f, as_stream(stream));
+}
+
+int clhip_si_step(float* theta, const float* grad, const float* omega, const float* init_val, float* w,
+                  float* buf, size_t n, float reg_lambda, float lr, float momentum, float wd, int first,
+                  void* stream) {
+    if (!theta || !grad || !omega || !init_val || !w || !buf) return CLHIP_EINVAL;
+    SiStep f{theta, grad, omega, init_val, w, buf, 2.f * reg_lambda, lr, momentum, wd, first};
+    bool v = aligned16(theta) && aligned16(grad) && aligned16(omega) && aligned16(init_val) && aligned16(w) && aligned16(buf);
+    return ew_launch(n, v, f, as_stream(stream));
+}
+
+int clhip_si_consolidate(float* omega, float* w, const float* theta, float* init_val, size_t n, float slack,
+                         void* stream) {
+    if (!omega || !w || !theta || !init_val) return CLHIP_EINVAL;
+    SiCons f{omega, w, theta, init_val, slack};
+    bool v = aligned16(omega) && aligned16(w) && aligned16(theta) && aligned16(init_val);
+    return ew_launch(n, v, f, as_stream(stream));
+}
+
+int clhip_relu_bwd(const float* dy, const float* y, float* dx, size_t n, void* stream) {
+    if (!dy || !y || !dx) return CLHIP_EINVAL;
+    ReluBwd f{dy, y, dx};
+    return ew_launch(n, aligned16(dy) && aligned16(y) && aligned16(dx), f, as_stream(stream));
+}
+
+int clhip_version(void) { return 100; }
+const char* clhip_arch(void) { return "gfx950"; }
+
+}  // extern "C"

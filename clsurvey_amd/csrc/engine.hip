@@ -1,0 +1,226 @@
+// Static-plan executor for VGG-style nets ([conv3x3+ReLU (+maxpool2)]* -> [Linear(+ReLU)]*).
+//
+// The reference trains through nn.Sequential + autograd, one Python dispatch per op per batch
+// (EWC/train_EWC.py:181-189).  At N=200 a small_VGG9 step is < 1 ms of MFMA work, so the op
+// sequence is planned once and every forward / loss / backward pass is ONE call that enqueues
+// ~35 kernels on the caller's stream with all ReLU backward passes fused into the producing
+// backward-data kernels.  The plan holds only shapes and offsets; parameters, gradients and
+// the activation workspace are caller-owned device memory (torch allocations).
+#include <vector>
+#include <new>
+#include "common.hpp"
+
+namespace {
+
+struct LayerPlan {
+    int type;              // 0 conv3x3, 1 fc
+    int cin, cout, relu, pool;
+    long w_off, b_off;     // float offsets into the parameter / gradient arenas
+    int h, w;              // conv: input spatial size
+    size_t in_elems, out_elems, pool_elems;   // per image
+    size_t act_off;        // float offset of this layer's OUTPUT (post-ReLU, pre-pool) in ws
+    size_t pool_off;       // float offset of pooled output
+    size_t idx_off;        // byte offset of pool argmax
+};
+
+struct NetPlan {
+    std::vector<LayerPlan> layers;
+    int max_batch, in_c, in_h, in_w, n_classes;
+    size_t in_elems;
+    size_t acts_floats;      // saved activations
+    size_t idx_bytes;
+    size_t grad_floats;      // one ping-pong gradient buffer
+    size_t scratch_bytes;    // wgrad / fc split-K scratch
+    size_t total_bytes;
+    // derived offsets (bytes) inside ws
+    size_t off_acts, off_idx, off_g0, off_g1, off_scratch, off_dlogits, off_loss;
+};
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+extern "C" {
+
+int clhip_net_create(const clhip_layer_desc* descs, int n_layers, int max_batch, int in_c, int in_h, int in_w,
+                     void** out_handle) {
+    if (!descs || n_layers <= 0 || max_batch <= 0 || !out_handle) return CLHIP_EINVAL;
+    NetPlan* p = new (std::nothrow) NetPlan();
+    if (!p) return CLHIP_ENOSPC;
+    p->max_batch = max_batch; p->in_c = in_c; p->in_h = in_h; p->in_w = in_w;
+    p->in_elems = (size_t)in_c * in_h * in_w;
+    int c = in_c, h = in_h, w = in_w;
+    size_t feat = p->in_elems;
+    size_t acts = 0, idxb = 0, gmax = 0, scratch = 0;
+    bool seen_fc = false;
+    for (int i = 0; i < n_layers; ++i) {
+        LayerPlan L{};
+        L.type = descs[i].type; L.cin = descs[i].cin; L.cout = descs[i].cout;
+        L.relu = descs[i].relu; L.pool = descs[i].pool; L.w_off = descs[i].w_off; L.b_off = descs[i].b_off;
+        if (L.type == 0) {
+            if (seen_fc || L.cin != c) { delete p; return CLHIP_EINVAL; }
+            L.h = h; L.w = w;
+            L.in_elems = (size_t)c * h * w;
+            L.out_elems = (size_t)L.cout * h * w;
+            L.act_off = acts; acts += L.out_elems * max_batch;
+            if (L.pool) {
+                if ((h & 1) || (w & 1)) { delete p; return CLHIP_EINVAL; }
+                L.pool_elems = L.out_elems / 4;
+                L.pool_off = acts; acts += L.pool_elems * max_batch;
+                L.idx_off = idxb; idxb += align_up(L.pool_elems * max_batch, 256);
+                h /= 2; w /= 2;
+            }
+            size_t s = clhip_conv3x3_bwd_weight_ws(max_batch, L.cin, L.cout, L.h, L.w);
+            if (s > scratch) scratch = s;
+            if (L.out_elems > gmax) gmax = L.out_elems;
+            c = L.cout;
+            feat = (size_t)c * h * w;
+        } else if (L.type == 1) {
+            seen_fc = true;
+            if ((size_t)L.cin != feat) { delete p; return CLHIP_EINVAL; }
+            L.in_elems = feat; L.out_elems = (size_t)L.cout;
+            L.act_off = acts; acts += L.out_elems * max_batch;
+            size_t s = clhip_fc_ws(max_batch, L.cin, L.cout);
+            if (s > scratch) scratch = s;
+            if (L.in_elems > gmax) gmax = L.in_elems;
+            if (L.out_elems > gmax) gmax = L.out_elems;
+            feat = L.out_elems;
+        } else { delete p; return CLHIP_EINVAL; }
+        p->layers.push_back(L);
+    }
+    p->n_classes = (int)feat;
+    p->acts_floats = acts; p->idx_bytes = idxb; p->grad_floats = gmax * max_batch; p->scratch_bytes = scratch;
+    size_t off = 0;
+    p->off_acts = off; off += align_up(acts * 4, 256);
+    p->off_idx = off; off += align_up(idxb, 256);
+    p->off_g0 = off; off += align_up(p->grad_floats * 4, 256);
+    p->off_g1 = off; off += align_up(p->grad_floats * 4, 256);
+    p->off_scratch = off; off += align_up(scratch, 256);
+    p->off_dlogits = off; off += align_up((size_t)max_batch * p->n_classes * 4, 256);
+    p->off_loss = off; off += 256;
+    p->total_bytes = off;
+    *out_handle = p;
+    return 0;
+}
+
+void clhip_net_destroy(void* handle) { delete static_cast<NetPlan*>(handle); }
+
+size_t clhip_net_workspace_bytes(void* handle) { return handle ? static_cast<NetPlan*>(handle)->total_bytes : 0; }
+int clhip_net_num_classes(void* handle) { return handle ? static_cast<NetPlan*>(handle)->n_classes : 0; }
+
+// Forward pass; activations are kept in ws for a following backward. logits_out (optional) receives
+// a copy of the [N][classes] logits.
+int clhip_net_forward(void* handle, const float* params, const float* x, int N, void* ws, float* logits_out,
+                      void* stream) {
+    NetPlan* p = static_cast<NetPlan*>(handle);
+    if (!p || !params || !x || !ws || N <= 0 || N > p->max_batch) return CLHIP_EINVAL;
+    char* base = static_cast<char*>(ws);
+    float* acts = reinterpret_cast<float*>(base + p->off_acts);
+    uint8_t* idx = reinterpret_cast<uint8_t*>(base + p->off_idx);
+    void* scratch = base + p->off_scratch;
+    const float* cur = x;
+    int rc;
+    for (const LayerPlan& L : p->layers) {
+        float* y = acts + L.act_off;
+        if (L.type == 0) {
+            rc = clhip_conv3x3_fwd(cur, params + L.w_off, params + L.b_off, y, N, L.cin, L.cout, L.h, L.w, L.relu, stream);
+            if (rc) return rc;
+            cur = y;
+            if (L.pool) {
+                float* pl = acts + L.pool_off;
+                rc = clhip_maxpool2_fwd(y, pl, idx + L.idx_off, N * L.cout, L.h, L.w, stream);
+                if (rc) return rc;
+                cur = pl;
+            }
+        } else {
+            rc = clhip_fc_fwd(cur, params + L.w_off, params + L.b_off, y, N, L.cin, L.cout, L.relu, scratch,
+                              p->scratch_bytes, stream);
+            if (rc) return rc;
+            cur = y;
+        }
+    }
+    if (logits_out) {
+        hipError_t e = hipMemcpyAsync(logits_out, cur, (size_t)N * p->n_classes * sizeof(float),
+                                      hipMemcpyDeviceToDevice, as_stream(stream));
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+// Backward pass from dlogits[N][classes] (device) through the activations saved by the last
+// clhip_net_forward on the same ws.  Writes every parameter gradient into `grads` (same offsets
+// as params; overwritten, not accumulated).
+int clhip_net_backward(void* handle, const float* params, float* grads, const float* x, int N, void* ws,
+                       const float* dlogits, void* stream) {
+    NetPlan* p = static_cast<NetPlan*>(handle);
+    if (!p || !params || !grads || !x || !ws || !dlogits || N <= 0 || N > p->max_batch) return CLHIP_EINVAL;
+    char* base = static_cast<char*>(ws);
+    float* acts = reinterpret_cast<float*>(base + p->off_acts);
+    uint8_t* idx = reinterpret_cast<uint8_t*>(base + p->off_idx);
+    float* g[2] = {reinterpret_cast<float*>(base + p->off_g0), reinterpret_cast<float*>(base + p->off_g1)};
+    void* scratch = base + p->off_scratch;
+    const float* gin = dlogits;      // gradient w.r.t. the current layer's output (already ReLU-masked)
+    int flip = 0;
+    int rc;
+    for (int i = (int)p->layers.size() - 1; i >= 0; --i) {
+        const LayerPlan& L = p->layers[i];
+        // input of layer i = (pooled) output of layer i-1, or the image batch
+        const float* xin = x;
+        if (i > 0) {
+            const LayerPlan& P = p->layers[i - 1];
+            xin = acts + ((P.type == 0 && P.pool) ? P.pool_off : P.act_off);
+        }
+        if (L.type == 1) {
+            rc = clhip_fc_bwd_weight(xin, gin, grads + L.w_off, grads + L.b_off, N, L.cin, L.cout, stream);
+            if (rc) return rc;
+            if (i > 0) {
+                float* gout = g[flip]; flip ^= 1;
+                // mask with (xin > 0): xin is a ReLU (or pooled ReLU) output
+                rc = clhip_fc_bwd_data(gin, params + L.w_off, xin, gout, N, L.cin, L.cout, scratch, p->scratch_bytes, stream);
+                if (rc) return rc;
+                gin = gout;
+            }
+        } else {
+            const float* gy = gin;
+            if (L.pool) {
+                float* gout = g[flip]; flip ^= 1;
+                rc = clhip_maxpool2_bwd(gin, idx + L.idx_off, gout, N * L.cout, L.h, L.w, stream);
+                if (rc) return rc;
+                gy = gout;
+            }
+            rc = clhip_conv3x3_bwd_weight(xin, gy, grads + L.w_off, grads + L.b_off, N, L.cin, L.cout, L.h, L.w,
+                                          scratch, p->scratch_bytes, stream);
+            if (rc) return rc;
+            if (i > 0) {
+                float* gout = g[flip]; flip ^= 1;
+                rc = clhip_conv3x3_bwd_data(gy, params + L.w_off, xin, gout, N, L.cin, L.cout, L.h, L.w, stream);
+                if (rc) return rc;
+                gin = gout;
+            }
+        }
+    }
+    return 0;
+}
+
+// forward + loss (+ backward when grads != NULL) in one call.
+//   loss_kind 0: CrossEntropy mean   1: CrossEntropy sum   2: sum of squared logits (MAS)
+int clhip_net_loss_step(void* handle, const float* params, float* grads, const float* x, const int64_t* labels,
+                        int N, int loss_kind, void* ws, float* loss_out, double* stats, float* logits_out,
+                        void* stream) {
+    NetPlan* p = static_cast<NetPlan*>(handle);
+    if (!p || !ws || (loss_kind != 2 && !labels)) return CLHIP_EINVAL;
+    char* base = static_cast<char*>(ws);
+    float* dlogits = reinterpret_cast<float*>(base + p->off_dlogits);
+    float* loss_dev = loss_out ? loss_out : reinterpret_cast<float*>(base + p->off_loss);
+    int rc = clhip_net_forward(handle, params, x, N, ws, logits_out, stream);
+    if (rc) return rc;
+    const LayerPlan& last = p->layers.back();
+    const float* logits = reinterpret_cast<float*>(base + p->off_acts) + last.act_off;
+    if (loss_kind == 2) rc = clhip_mse_zero_sum(logits, (size_t)N * p->n_classes, dlogits, loss_dev, stream);
+    else rc = clhip_softmax_ce(logits, labels, N, p->n_classes, loss_kind, dlogits, loss_dev, stats, stream);
+    if (rc) return rc;
+    if (grads) rc = clhip_net_backward(handle, params, grads, x, N, ws, dlogits, stream);
+    return rc;
+}
+
+}  // extern "C"

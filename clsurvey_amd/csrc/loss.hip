@@ -1,0 +1,107 @@
+// Loss kernels: softmax cross-entropy (mean / sum) and the MAS sum-of-squares objective.
+// Tiny tensors ([N<=~1k][C<=1k]); one block, fixed reduction order => deterministic.
+#include "common.hpp"
+
+namespace {
+
+constexpr int LOSS_BLOCK = 1024;  // 16 waves
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// One wave per row, rows strided over the 16 waves of the single block.
+__global__ __launch_bounds__(LOSS_BLOCK) void softmax_ce_kernel(
+    const float* __restrict__ logits, const int64_t* __restrict__ labels, int N, int C, int reduction,
+    float* __restrict__ dlogits, float* __restrict__ loss_out, double* __restrict__ stats) {
+    __shared__ float s_loss[16];
+    __shared__ int s_corr[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float scale = reduction == 0 ? 1.f / (float)N : 1.f;
+    float wl = 0.f;   // this wave's loss sum (rows in increasing order)
+    int wc = 0;
+    for (int row = wave; row < N; row += 16) {
+        const float* z = logits + (size_t)row * C;
+        const int y = (int)labels[row];
+        float m = -INFINITY;
+        int am = 0x7fffffff;
+        for (int c = lane; c < C; c += 64) {
+            float v = z[c];
+            if (v > m) { m = v; am = c; }
+        }
+        float gm = wave_max(m);
+        // first index attaining the max (torch.max tie rule: lowest index)
+        int cand = (m == gm) ? am : 0x7fffffff;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+        float se = 0.f;
+        for (int c = lane; c < C; c += 64) se += expf(z[c] - gm);
+        se = wave_sum(se);
+        const float lse = logf(se);
+        for (int c = lane; c < C; c += 64) {
+            float p = expf(z[c] - gm - lse);
+            dlogits[(size_t)row * C + c] = (p - (c == y ? 1.f : 0.f)) * scale;
+        }
+        float zy = z[y];
+        wl += -(zy - gm - lse);
+        wc += (cand == y) ? 1 : 0;
+    }
+    if (lane == 0) { s_loss[wave] = wl; s_corr[wave] = wc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f; int c = 0;
+        for (int i = 0; i < 16; ++i) { t += s_loss[i]; c += s_corr[i]; }
+        t *= scale;
+        loss_out[0] = t;
+        if (stats) { stats[0] += (double)t; stats[1] += (double)c; }
+    }
+}
+
+__global__ __launch_bounds__(LOSS_BLOCK) void mse_zero_sum_kernel(const float* __restrict__ z, size_t n,
+                                                                  float* __restrict__ dz, float* __restrict__ loss_out) {
+    __shared__ float s_part[16];
+    float acc = 0.f;
+    for (size_t i = threadIdx.x; i < n; i += LOSS_BLOCK) {
+        float v = z[i];
+        acc += v * v;
+        dz[i] = 2.f * v;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < 16; ++i) t += s_part[i];
+        loss_out[0] = t;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int clhip_softmax_ce(const float* logits, const int64_t* labels_i64, int N, int C, int reduction,
+                     float* dlogits, float* loss_out, double* stats, void* stream) {
+    if (!logits || !labels_i64 || !dlogits || !loss_out || N <= 0 || C <= 0) return CLHIP_EINVAL;
+    if (reduction != 0 && reduction != 1) return CLHIP_EINVAL;
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3(1), dim3(LOSS_BLOCK), 0, as_stream(stream), logits, labels_i64, N, C,
+                       reduction, dlogits, loss_out, stats);
+    CLHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+int clhip_mse_zero_sum(const float* logits, size_t n, float* dlogits, float* loss_out, void* stream) {
+    if (!logits || !dlogits || !loss_out || n == 0) return CLHIP_EINVAL;
+    hipLaunchKernelGGL(mse_zero_sum_kernel, dim3(1), dim3(LOSS_BLOCK), 0, as_stream(stream), logits, n, dlogits, loss_out);
+    CLHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,181 @@
+"""ParamArena + NetEngine: the MI355X execution model for a VGG-style net.
+
+* ParamArena lays all parameters of a model out in ONE contiguous fp32 HBM buffer (16-byte
+  aligned slots, module order) and re-points every nn.Parameter's .data / .grad at views of it.
+  The Parameter OBJECTS are untouched, so the reference's `reg_params` dict (keyed by Parameter
+  identity, pickled with the model: EWC/main_EWC.py:160-232) keeps working.  Every optimizer /
+  importance update then is a single HBM-bound kernel over the arena instead of ~8 eager ops
+  x 16 tensors (EWC/train_EWC.py:46-84).
+* NetEngine parses model.features / model.classifier (the structure of models/VGGSlim.py:27-76)
+  into a static plan executed by libclhip's clhip_net_* entry points: one call per pass.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import check, LayerDesc
+
+
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+class ParamArena:
+    def __init__(self, params, device=None):
+        self.params = list(params)
+        if device is None:
+            device = self.params[0].device
+        self.device = torch.device(device)
+        self.offsets = []
+        off = 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += _pad4(p.numel())
+        self.numel = off
+        self.theta = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.aux = {}
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                v = self.theta[o:o + p.numel()].view(p.shape)
+                v.copy_(p.data.to(self.device, torch.float32))
+                p.data = v
+                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+        self._index = {id(p): i for i, p in enumerate(self.params)}
+
+    def slot(self, p):
+        i = self._index[id(p)]
+        return self.offsets[i], p.numel()
+
+    def buffer(self, name, zero=True):
+        """Named auxiliary arena (omega, init_val, momentum buffer, w, ...)."""
+        if name not in self.aux:
+            self.aux[name] = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
+        elif zero:
+            pass
+        return self.aux[name]
+
+    def view(self, name, p):
+        o, n = self.slot(p)
+        buf = self.theta if name == "theta" else self.grad if name == "grad" else self.buffer(name, zero=False)
+        return buf[o:o + n].view(p.shape)
+
+    def load(self, name, per_param):
+        """Fill aux arena `name` from {Parameter: tensor}; params missing from the dict get zeros
+        (e.g. omega of a fresh head that is 'not in reg_params')."""
+        buf = self.buffer(name)
+        buf.zero_()
+        for p in self.params:
+            t = per_param.get(p)
+            if t is not None:
+                self.view(name, p).copy_(t.to(self.device, torch.float32))
+        return buf
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+
+def parse_vgg(model):
+    """[(kind, module, relu, pool)] from a VGGSlim-structured module. Raises on anything the
+    static plan does not cover (BatchNorm / Dropout variants are SURVEY §8f 'next')."""
+    layers = []
+    feats = list(model.features.children())
+    i = 0
+    while i < len(feats):
+        m = feats[i]
+        if isinstance(m, nn.Conv2d):
+            if m.kernel_size != (3, 3) or m.padding != (1, 1) or m.stride != (1, 1) or m.groups != 1:
+                raise NotImplementedError("NetEngine: only 3x3 pad-1 stride-1 convolutions")
+            relu = i + 1 < len(feats) and isinstance(feats[i + 1], nn.ReLU)
+            j = i + (2 if relu else 1)
+            pool = j < len(feats) and isinstance(feats[j], nn.MaxPool2d)
+            if pool:
+                mp = feats[j]
+                ks = mp.kernel_size if isinstance(mp.kernel_size, tuple) else (mp.kernel_size,) * 2
+                st = mp.stride if isinstance(mp.stride, tuple) else (mp.stride,) * 2
+                if ks != (2, 2) or st != (2, 2):
+                    raise NotImplementedError("NetEngine: only 2x2 stride-2 max-pool")
+                j += 1
+            layers.append(("conv", m, relu, pool))
+            i = j
+        else:
+            raise NotImplementedError("NetEngine: unsupported feature module %r" % (m,))
+    cls = list(model.classifier.children())
+    i = 0
+    while i < len(cls):
+        m = cls[i]
+        if isinstance(m, nn.Linear):
+            relu = i + 1 < len(cls) and isinstance(cls[i + 1], nn.ReLU)
+            layers.append(("fc", m, relu, False))
+            i += 2 if relu else 1
+        else:
+            raise NotImplementedError("NetEngine: unsupported classifier module %r" % (m,))
+    return layers
+
+
+class NetEngine:
+    LOSS = {"ce_mean": 0, "ce_sum": 1, "mse_sum_zero": 2}
+
+    def __init__(self, model, max_batch, in_shape, device="cuda"):
+        self.model = model
+        self.device = torch.device(device)
+        self.layers = parse_vgg(model)
+        params = list(model.parameters())
+        self.arena = ParamArena(params, self.device)
+        descs = (LayerDesc * len(self.layers))()
+        for d, (kind, m, relu, pool) in zip(descs, self.layers):
+            d.type = 0 if kind == "conv" else 1
+            d.cin = m.in_channels if kind == "conv" else m.in_features
+            d.cout = m.out_channels if kind == "conv" else m.out_features
+            d.relu, d.pool = int(relu), int(pool)
+            d.w_off = self.arena.slot(m.weight)[0]
+            if m.bias is None:
+                raise NotImplementedError("NetEngine: layers without bias")
+            d.b_off = self.arena.slot(m.bias)[0]
+        self.max_batch = int(max_batch)
+        self.in_shape = tuple(in_shape)
+        h = C.c_void_p()
+        L = _lib.lib()
+        check(L.clhip_net_create(descs, len(self.layers), self.max_batch, *self.in_shape, C.byref(h)),
+              "clhip_net_create")
+        self._h = h
+        self.n_classes = L.clhip_net_num_classes(h)
+        self.ws = torch.empty(L.clhip_net_workspace_bytes(h), dtype=torch.uint8, device=self.device)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _lib.lib().clhip_net_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _check_x(self, x):
+        if not x.is_cuda or x.dtype != torch.float32 or not x.is_contiguous():
+            raise RuntimeError("NetEngine needs contiguous fp32 HIP tensors")
+        if tuple(x.shape[1:]) != self.in_shape or x.shape[0] > self.max_batch:
+            raise RuntimeError("NetEngine: bad input shape %s" % (tuple(x.shape),))
+
+    def forward(self, x):
+        self._check_x(x)
+        logits = torch.empty((x.shape[0], self.n_classes), dtype=torch.float32, device=self.device)
+        check(_lib.lib().clhip_net_forward(self._h, self.arena.theta.data_ptr(), x.data_ptr(), x.shape[0],
+                                           self.ws.data_ptr(), logits.data_ptr(),
+                                           torch.cuda.current_stream().cuda_stream), "clhip_net_forward")
+        return logits
+
+    def loss_step(self, x, y, kind="ce_mean", backward=True, stats=None, want_logits=False):
+        """forward + loss (+ backward into arena.grad). Returns (loss[1] device tensor, logits|None).
+        No host synchronisation happens here."""
+        self._check_x(x)
+        logits = torch.empty((x.shape[0], self.n_classes), dtype=torch.float32, device=self.device) if want_logits else None
+        check(_lib.lib().clhip_net_loss_step(
+            self._h, self.arena.theta.data_ptr(), self.arena.grad.data_ptr() if backward else None, x.data_ptr(),
+            y.data_ptr() if y is not None else None, x.shape[0], self.LOSS[kind], self.ws.data_ptr(),
+            self.loss.data_ptr(), stats.data_ptr() if stats is not None else None,
+            logits.data_ptr() if logits is not None else None, torch.cuda.current_stream().cuda_stream),
+            "clhip_net_loss_step")
+        return self.loss, logits

@@ -1,0 +1,284 @@
+"""Thin torch-facing wrappers over the C ABI (include/clhip.h).
+
+Every function takes contiguous fp32 CUDA(HIP) tensors, passes raw device pointers and the
+current HIP stream to libclhip, and returns torch tensors.  There is no CPU path: a CPU tensor
+raises.  The autograd.Function classes at the bottom make the kernels usable from ordinary
+nn.Module code (HAT / GEM wrappers); the hot loops use clsurvey_amd.net.NetEngine instead.
+"""
+import torch
+
+from . import _lib
+from ._lib import check
+
+_ws_cache = {}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("clsurvey_amd ops need HIP device tensors (no CPU fallback)")
+        if not t.is_contiguous():
+            raise RuntimeError("clsurvey_amd ops need contiguous tensors")
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def workspace(nbytes, device, tag="default"):
+    """Grow-only scratch buffer per (device, tag)."""
+    key = (str(device), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+# ------------------------------------------------------------------ convolution
+def conv3x3_fwd(x, w, b, relu=True):
+    _chk(x, w, b)
+    N, C, H, W = x.shape
+    K = w.shape[0]
+    assert w.shape == (K, C, 3, 3) and x.dtype == torch.float32
+    y = torch.empty((N, K, H, W), dtype=torch.float32, device=x.device)
+    check(_lib.lib().clhip_conv3x3_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(y), N, C, K, H, W, int(relu), _stream()),
+          "clhip_conv3x3_fwd")
+    return y
+
+
+def conv3x3_bwd_data(dy, w, relu_src=None):
+    _chk(dy, w, relu_src)
+    N, K, H, W = dy.shape
+    C = w.shape[1]
+    dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device)
+    check(_lib.lib().clhip_conv3x3_bwd_data(_ptr(dy), _ptr(w), _ptr(relu_src), _ptr(dx), N, C, K, H, W, _stream()),
+          "clhip_conv3x3_bwd_data")
+    return dx
+
+
+def conv3x3_bwd_weight(x, dy, need_bias=True):
+    _chk(x, dy)
+    N, C, H, W = x.shape
+    K = dy.shape[1]
+    L = _lib.lib()
+    nbytes = L.clhip_conv3x3_bwd_weight_ws(N, C, K, H, W)
+    ws = workspace(nbytes, x.device, "wgrad")
+    dw = torch.empty((K, C, 3, 3), dtype=torch.float32, device=x.device)
+    db = torch.empty((K,), dtype=torch.float32, device=x.device) if need_bias else None
+    check(L.clhip_conv3x3_bwd_weight(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), N, C, K, H, W, _ptr(ws), ws.numel(),
+                                     _stream()), "clhip_conv3x3_bwd_weight")
+    return dw, db
+
+
+# ------------------------------------------------------------------ pooling
+def maxpool2_fwd(x):
+    _chk(x)
+    N, C, H, W = x.shape
+    y = torch.empty((N, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    idx = torch.empty((N, C, H // 2, W // 2), dtype=torch.uint8, device=x.device)
+    check(_lib.lib().clhip_maxpool2_fwd(_ptr(x), _ptr(y), _ptr(idx), N * C, H, W, _stream()), "clhip_maxpool2_fwd")
+    return y, idx
+
+
+def maxpool2_bwd(dy, idx):
+    _chk(dy, idx)
+    N, C, OH, OW = dy.shape
+    dx = torch.empty((N, C, OH * 2, OW * 2), dtype=torch.float32, device=dy.device)
+    check(_lib.lib().clhip_maxpool2_bwd(_ptr(dy), _ptr(idx), _ptr(dx), N * C, OH * 2, OW * 2, _stream()),
+          "clhip_maxpool2_bwd")
+    return dx
+
+
+# ------------------------------------------------------------------ fully connected
+def fc_fwd(x, w, b, relu=False):
+    _chk(x, w, b)
+    M, I = x.shape
+    O = w.shape[0]
+    L = _lib.lib()
+    ws = workspace(L.clhip_fc_ws(M, I, O), x.device, "fc")
+    y = torch.empty((M, O), dtype=torch.float32, device=x.device)
+    check(L.clhip_fc_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(y), M, I, O, int(relu), _ptr(ws), ws.numel(), _stream()),
+          "clhip_fc_fwd")
+    return y
+
+
+def fc_bwd_data(dy, w, relu_src=None):
+    _chk(dy, w, relu_src)
+    M, O = dy.shape
+    I = w.shape[1]
+    L = _lib.lib()
+    ws = workspace(L.clhip_fc_ws(M, I, O), dy.device, "fc")
+    dx = torch.empty((M, I), dtype=torch.float32, device=dy.device)
+    check(L.clhip_fc_bwd_data(_ptr(dy), _ptr(w), _ptr(relu_src), _ptr(dx), M, I, O, _ptr(ws), ws.numel(), _stream()),
+          "clhip_fc_bwd_data")
+    return dx
+
+
+def fc_bwd_weight(x, dy, need_bias=True):
+    _chk(x, dy)
+    M, I = x.shape
+    O = dy.shape[1]
+    dw = torch.empty((O, I), dtype=torch.float32, device=x.device)
+    db = torch.empty((O,), dtype=torch.float32, device=x.device) if need_bias else None
+    check(_lib.lib().clhip_fc_bwd_weight(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), M, I, O, _stream()),
+          "clhip_fc_bwd_weight")
+    return dw, db
+
+
+def relu_bwd(dy, y):
+    _chk(dy, y)
+    dx = torch.empty_like(dy)
+    check(_lib.lib().clhip_relu_bwd(_ptr(dy), _ptr(y), _ptr(dx), dy.numel(), _stream()), "clhip_relu_bwd")
+    return dx
+
+
+# ------------------------------------------------------------------ losses
+def softmax_ce(logits, labels, reduction="mean", stats=None):
+    """returns (loss[1], dlogits). stats: optional float64[2] device tensor accumulating
+    (sum of batch losses, #correct)."""
+    _chk(logits, labels, stats)
+    N, Cc = logits.shape
+    assert labels.dtype == torch.int64
+    dl = torch.empty_like(logits)
+    loss = torch.empty((1,), dtype=torch.float32, device=logits.device)
+    red = {"mean": 0, "sum": 1}[reduction]
+    check(_lib.lib().clhip_softmax_ce(_ptr(logits), _ptr(labels), N, Cc, red, _ptr(dl), _ptr(loss), _ptr(stats),
+                                      _stream()), "clhip_softmax_ce")
+    return loss, dl
+
+
+def mse_zero_sum(logits):
+    _chk(logits)
+    dl = torch.empty_like(logits)
+    loss = torch.empty((1,), dtype=torch.float32, device=logits.device)
+    check(_lib.lib().clhip_mse_zero_sum(_ptr(logits), logits.numel(), _ptr(dl), _ptr(loss), _stream()),
+          "clhip_mse_zero_sum")
+    return loss, dl
+
+
+# ------------------------------------------------------------------ optimizers / importance (in place)
+def reg_sgd_step(theta, grad, omega, init_val, buf, reg_lambda, lr, momentum, wd, first):
+    _chk(theta, grad, omega, init_val, buf)
+    check(_lib.lib().clhip_reg_sgd_step(_ptr(theta), _ptr(grad), _ptr(omega), _ptr(init_val), _ptr(buf), theta.numel(),
+                                        float(reg_lambda), float(lr), float(momentum), float(wd), int(first), _stream()),
+          "clhip_reg_sgd_step")
+
+
+def fisher_accum(omega, grad, data_len):
+    _chk(omega, grad)
+    check(_lib.lib().clhip_fisher_accum(_ptr(omega), _ptr(grad), omega.numel(), float(data_len), _stream()),
+          "clhip_fisher_accum")
+
+
+def mas_accum(omega, grad, batch_index, batch_size):
+    _chk(omega, grad)
+    prev = float(batch_index * batch_size)
+    curr = float((batch_index + 1) * batch_size)
+    check(_lib.lib().clhip_mas_accum(_ptr(omega), _ptr(grad), omega.numel(), prev, curr, _stream()), "clhip_mas_accum")
+
+
+def si_step(theta, grad, omega, init_val, w, buf, reg_lambda, lr, momentum, wd, first):
+    _chk(theta, grad, omega, init_val, w, buf)
+    check(_lib.lib().clhip_si_step(_ptr(theta), _ptr(grad), _ptr(omega), _ptr(init_val), _ptr(w), _ptr(buf),
+                                   theta.numel(), float(reg_lambda), float(lr), float(momentum), float(wd), int(first),
+                                   _stream()), "clhip_si_step")
+
+
+def si_consolidate(omega, w, theta, init_val, slack=1e-3):
+    _chk(omega, w, theta, init_val)
+    check(_lib.lib().clhip_si_consolidate(_ptr(omega), _ptr(w), _ptr(theta), _ptr(init_val), omega.numel(), float(slack),
+                                          _stream()), "clhip_si_consolidate")
+
+
+# ------------------------------------------------------------------ autograd bridges
+class Conv3x3ReLUFn(torch.autograd.Function):
+    """relu(conv3x3(x, w) + b) — nn.Conv2d + nn.ReLU(inplace) pair of VGGSlim.py:34-38."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu):
+        x = x.contiguous()
+        y = conv3x3_fwd(x, w.contiguous(), b.contiguous() if b is not None else None, relu)
+        ctx.relu = relu
+        ctx.save_for_backward(x, w, y)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        if ctx.relu:
+            dy = relu_bwd(dy, y)
+        dx = conv3x3_bwd_data(dy, w) if ctx.needs_input_grad[0] else None
+        dw, db = conv3x3_bwd_weight(x, dy, ctx.has_bias)
+        return dx, dw, db, None
+
+
+class MaxPool2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y, idx = maxpool2_fwd(x.contiguous())
+        ctx.save_for_backward(idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        return maxpool2_bwd(dy.contiguous(), idx)
+
+
+class LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, relu):
+        x = x.contiguous()
+        y = fc_fwd(x, w.contiguous(), b.contiguous() if b is not None else None, relu)
+        ctx.relu = relu
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        if ctx.relu:
+            dy = relu_bwd(dy, y)
+        dx = fc_bwd_data(dy, w) if ctx.needs_input_grad[0] else None
+        dw, db = fc_bwd_weight(x, dy, ctx.has_bias)
+        return dx, dw, db, None
+
+
+class SoftmaxCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, reduction):
+        loss, dl = softmax_ce(logits.contiguous(), labels, reduction)
+        ctx.save_for_backward(dl)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g, None, None
+
+
+def conv3x3_relu(x, w, b, relu=True):
+    return Conv3x3ReLUFn.apply(x, w, b, relu)
+
+
+def maxpool2(x):
+    return MaxPool2Fn.apply(x)
+
+
+def linear(x, w, b, relu=False):
+    return LinearFn.apply(x, w, b, relu)
+
+
+def cross_entropy(logits, labels, reduction="mean"):
+    return SoftmaxCEFn.apply(logits, labels, reduction)

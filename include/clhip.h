@@ -1,0 +1,154 @@
+/*
+ * clhip.h — C ABI of libclhip.so: MI355X (gfx950 / CDNA4) kernels for the CLsurvey
+ * per-task training + importance-weight hot path.
+ *
+ * The reference (Mattdl/CLsurvey) is pure Python on torch; every "kernel" it runs is an ATen
+ * op reached from the files cited per entry point below (paths relative to /root/reference/src).
+ * A maintainer binds this header with ctypes; no torch types cross it.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (fp32 unless the name says _u8 / _i64 / _f64)
+ *   - tensors are dense NCHW / row-major exactly as torch lays them out (weights [K][C][3][3])
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous
+ *   - return value: 0 on success, a positive hipError_t from the launch, or a negative
+ *     CLHIP_E* argument error. Kernels never allocate; scratch comes in through `ws`.
+ */
+#ifndef CLHIP_H
+#define CLHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLHIP_EINVAL (-1)   /* bad shape / null pointer */
+#define CLHIP_ENOSPC (-2)   /* workspace too small */
+#define CLHIP_ENOTSUP (-3)  /* shape not supported by this build */
+
+/* Library version (major*10000 + minor*100 + patch) and the gfx arch it was built for. */
+int clhip_version(void);
+const char* clhip_arch(void);
+
+/* ------------------------------------------------------------------ convolution (MFMA fp32)
+ * nn.Conv2d(C, K, 3, padding=1) (+ fused bias, ReLU) — models/VGGSlim.py:34-38.
+ * y[N][K][H][W] = relu?(conv(x[N][C][H][W], w[K][C][3][3]) + b[K])                      */
+int clhip_conv3x3_fwd(const float* x, const float* w, const float* b, float* y,
+                      int N, int C, int K, int H, int W, int relu, void* stream);
+
+/* autograd convolution_backward, data part. dx[N][C][H][W] from dy[N][K][H][W].
+ * If relu_src != NULL: dx is multiplied by (relu_src > 0) — the fused ReLU backward
+ * (threshold_backward) of the layer that PRODUCED this conv's input (VGGSlim.py:38).      */
+int clhip_conv3x3_bwd_data(const float* dy, const float* w, const float* relu_src, float* dx,
+                           int N, int C, int K, int H, int W, void* stream);
+
+/* convolution_backward, weight + bias part. dw[K][C][3][3], db[K] (db may be NULL).
+ * Deterministic: split partial sums live in `ws` (>= clhip_conv3x3_bwd_weight_ws bytes)
+ * and are reduced in a fixed order (utils.set_random contract, utilities/utils.py:52-58).  */
+size_t clhip_conv3x3_bwd_weight_ws(int N, int C, int K, int H, int W);
+int clhip_conv3x3_bwd_weight(const float* x, const float* dy, float* dw, float* db,
+                             int N, int C, int K, int H, int W, void* ws, size_t ws_bytes,
+                             void* stream);
+
+/* ------------------------------------------------------------------ max-pool 2x2 stride 2
+ * nn.MaxPool2d(2, 2) — models/VGGSlim.py:32. idx_u8 holds the argmax (0..3, row-major in the
+ * window, first maximum wins as in ATen).  H, W are the INPUT sizes (even).                */
+int clhip_maxpool2_fwd(const float* x, float* y, uint8_t* idx_u8, int NC, int H, int W, void* stream);
+int clhip_maxpool2_bwd(const float* dy, const uint8_t* idx_u8, float* dx, int NC, int H, int W,
+                       void* stream);
+
+/* ------------------------------------------------------------------ fully connected (MFMA fp32)
+ * nn.Linear — models/VGGSlim.py:68-74.  x[M][I], w[O][I], b[O], y[M][O].                   */
+/* ws: optional split-K scratch (>= clhip_fc_ws(M,I,O) bytes); NULL => no K split (slower, same result
+ * up to summation order).                                                                   */
+size_t clhip_fc_ws(int M, int I, int O);
+int clhip_fc_fwd(const float* x, const float* w, const float* b, float* y,
+                 int M, int I, int O, int relu, void* ws, size_t ws_bytes, void* stream);
+/* dx[M][I] = dy[M][O] . w[O][I], optionally masked by (relu_src[M][I] > 0). */
+int clhip_fc_bwd_data(const float* dy, const float* w, const float* relu_src, float* dx,
+                      int M, int I, int O, void* ws, size_t ws_bytes, void* stream);
+/* dw[O][I] = dy^T . x ; db[O] = column sums of dy (db may be NULL). */
+int clhip_fc_bwd_weight(const float* x, const float* dy, float* dw, float* db,
+                        int M, int I, int O, void* stream);
+/* y = relu(x) backward helper for non-fused callers: dx = dy * (y > 0). */
+int clhip_relu_bwd(const float* dy, const float* y, float* dx, size_t n, void* stream);
+
+/* ------------------------------------------------------------------ losses
+ * CrossEntropyLoss (mean, reduction=0) — EWC/train_EWC.py:183; nll_loss(log_softmax, sum,
+ * reduction=1) — EWC/main_EWC.py:148.  Writes loss_out[0], dlogits[N][C] (already scaled by
+ * 1/N for mean) and, if stats != NULL, accumulates stats[0] += loss, stats[1] += #correct
+ * (argmax == label; the running_loss / running_corrects of train_EWC.py:196-197) so the
+ * host needs no per-batch .item() sync.  C <= 1024.                                         */
+int clhip_softmax_ce(const float* logits, const int64_t* labels_i64, int N, int C, int reduction,
+                     float* dlogits, float* loss_out, double* stats, void* stream);
+/* MSELoss(size_average=False) against zeros — MAS/train_MAS.py:556-560: loss = sum(z^2),
+ * dlogits = 2 z.                                                                            */
+int clhip_mse_zero_sum(const float* logits, size_t n, float* dlogits, float* loss_out, void* stream);
+
+/* ------------------------------------------------------------------ penalised optimizers
+ * Weight_Regularized_SGD.step — EWC/train_EWC.py:23-86 == MAS/train_MAS.py:32-95.
+ *   d = g + 2*lambda*omega*(theta - init);  d += wd*theta;
+ *   buf = first ? d : momentum*buf + d;  theta -= lr*buf
+ * omega == NULL  <=>  "p not in reg_params" (plain SGD, e.g. the fresh head).               */
+int clhip_reg_sgd_step(float* theta, const float* grad, const float* omega, const float* init_val,
+                       float* buf, size_t n, float reg_lambda, float lr, float momentum, float wd,
+                       int first, void* stream);
+/* diag_fisher accumulation — EWC/main_EWC.py:155: omega += grad^2 / data_len.               */
+int clhip_fisher_accum(float* omega, const float* grad, size_t n, float data_len, void* stream);
+/* Objective_After_SGD.step — MAS/train_MAS.py:167-173: omega = (omega*prev + |g|) / curr.   */
+int clhip_mas_accum(float* omega, const float* grad, size_t n, float prev_size, float curr_size,
+                    void* stream);
+/* Elastic_SGD.step — SI/train_SI.py:28-126 (penalised momentum SGD + path integral w).      */
+int clhip_si_step(float* theta, const float* grad, const float* omega, const float* init_val,
+                  float* w, float* buf, size_t n, float reg_lambda, float lr, float momentum,
+                  float wd, int first, void* stream);
+/* update_reg_params — SI/train_SI.py:301-351: omega += max(w/((theta-init)^2+slack),0);
+ * w = 0; init = theta.                                                                      */
+int clhip_si_consolidate(float* omega, float* w, const float* theta, float* init_val, size_t n,
+                         float slack, void* stream);
+
+/* ------------------------------------------------------------------ static-plan net executor
+ * One call per pass for VGG-style nets instead of one Python dispatch per op
+ * (replaces `outputs = model(inputs); loss.backward()` of EWC/train_EWC.py:181-187,
+ * EWC/main_EWC.py:147-149, MAS/train_MAS.py:549-560, framework/inference.py:52-68).
+ * params / grads are flat fp32 arenas; w_off / b_off are float offsets into them.          */
+typedef struct {
+    int type;            /* 0: conv3x3 pad 1 (+ReLU) (+2x2 max-pool)   1: Linear (+ReLU) */
+    int cin, cout;       /* channels (conv) or in/out features (fc) */
+    int relu, pool;
+    long w_off, b_off;
+} clhip_layer_desc;
+
+int clhip_net_create(const clhip_layer_desc* layers, int n_layers, int max_batch, int in_c, int in_h,
+                     int in_w, void** out_handle);
+void clhip_net_destroy(void* handle);
+size_t clhip_net_workspace_bytes(void* handle);
+int clhip_net_num_classes(void* handle);
+int clhip_net_forward(void* handle, const float* params, const float* x, int N, void* ws,
+                      float* logits_out, void* stream);
+int clhip_net_backward(void* handle, const float* params, float* grads, const float* x, int N, void* ws,
+                       const float* dlogits, void* stream);
+/* loss_kind 0: CE mean, 1: CE sum, 2: sum of squared logits.  grads == NULL => forward + loss only
+ * (validation / test).  stats as in clhip_softmax_ce.                                        */
+int clhip_net_loss_step(void* handle, const float* params, float* grads, const float* x,
+                        const int64_t* labels_i64, int N, int loss_kind, void* ws, float* loss_out,
+                        double* stats, float* logits_out, void* stream);
+
+/* ------------------------------------------------------------------ debug reference kernels
+ * Direct (one thread per output, no MFMA/LDS) convolutions used only by tests to triage the
+ * MFMA kernels on the device.  Same signatures as the production entry points.              */
+int clhip_dbg_conv3x3_fwd(const float* x, const float* w, const float* b, float* y,
+                          int N, int C, int K, int H, int W, int relu, void* stream);
+int clhip_dbg_conv3x3_bwd_data(const float* dy, const float* w, const float* relu_src, float* dx,
+                               int N, int C, int K, int H, int W, void* stream);
+int clhip_dbg_conv3x3_bwd_weight(const float* x, const float* dy, float* dw, float* db,
+                                 int N, int C, int K, int H, int W, void* stream);
+/* MFMA fragment-layout probe: out[2][32][32]: D of the 32x32x2 f32 MFMA for rank-1 A,B patterns per k slice,
+ * stored through the documented fragment map (see csrc/debug_naive.hip).                   */
+int clhip_dbg_mfma_probe(float* out_2048, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLHIP_H */

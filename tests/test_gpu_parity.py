@@ -1,0 +1,368 @@
+"""GPU parity tests: HIP kernels (through the C ABI via clsurvey_amd.ops / NetEngine) against
+the CPU oracle on the same seeded inputs, plus the golden fixtures generated from the reference.
+Tolerance: north_star says 1e-3 relative for fp32; we assert 2e-4 of the tensor's max magnitude
+(fp32 accumulation-order noise is ~1e-6)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import regularizers_ref as R
+from oracle import vgg_ref
+
+pytestmark = pytest.mark.gpu
+
+TINY = [16, "M", 16, "M", 32, 32, "M", 32, 32, "M"]
+RTOL = 2e-4
+
+
+def dev():
+    assert torch.cuda.is_available(), "needs the MI355X"
+    return torch.device("cuda:0")
+
+
+def rel_err(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-30))
+
+
+def assert_close(a, b, tol=RTOL, what=""):
+    e = rel_err(a, b)
+    assert e <= tol, "%s rel err %.3e > %.1e" % (what, e, tol)
+
+
+def rnd(gen, *shape, scale=1.0):
+    return torch.from_numpy((gen.standard_normal(shape) * scale).astype(np.float32))
+
+
+def test_mfma_fragment_layout_probe():
+    from clsurvey_amd import _lib
+    out = torch.zeros(2048, device=dev())
+    assert _lib.lib().clhip_dbg_mfma_probe(out.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    o = out.cpu().view(2, 32, 32)
+    i = torch.arange(1, 33, dtype=torch.float32)
+    exp = i[:, None] * 100.0 * i[None, :]
+    assert torch.equal(o[0], exp) and torch.equal(o[1], exp)
+
+
+CONV_SHAPES = [  # N, C, K, H, W
+    (2, 3, 16, 32, 32), (3, 16, 16, 16, 16), (2, 32, 32, 8, 8), (5, 32, 24, 4, 4), (2, 8, 40, 12, 20),
+    (4, 3, 64, 64, 64), (4, 64, 64, 32, 32), (6, 64, 128, 8, 8), (3, 128, 128, 8, 8), (1, 70, 70, 10, 10),
+]
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+@pytest.mark.parametrize("impl", ["mfma", "naive"])
+def test_conv3x3_fwd_bwd(shape, impl):
+    import torch.nn.functional as F
+    from clsurvey_amd import ops, _lib
+    N, C, K, H, W = shape
+    gen = np.random.RandomState(hash(shape) % 2**31)
+    x, w, b = rnd(gen, N, C, H, W), rnd(gen, K, C, 3, 3, scale=0.2), rnd(gen, K, scale=0.1)
+    dy = rnd(gen, N, K, H, W)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    y_ref = F.relu(F.conv2d(xr, wr, br, padding=1))
+    y_ref.backward(dy)
+    dpre = dy * (y_ref.detach() > 0)
+    d = dev()
+    xd, wd, bd, dpd = x.to(d), w.to(d), b.to(d), dpre.to(d)
+    if impl == "mfma":
+        y = ops.conv3x3_fwd(xd, wd, bd, relu=True)
+        dx = ops.conv3x3_bwd_data(dpd, wd)
+        dw, db = ops.conv3x3_bwd_weight(xd, dpd)
+        # fused relu mask variant: masking with a random sign tensor
+        msrc = rnd(gen, N, C, H, W).to(d)
+        dxm = ops.conv3x3_bwd_data(dpd, wd, msrc)
+        assert_close(dxm, xr.grad * (msrc.cpu() > 0), what="bwd_data+mask")
+    else:
+        L = _lib.lib()
+        y = torch.empty(N, K, H, W, device=d)
+        dx = torch.empty(N, C, H, W, device=d)
+        dw = torch.empty(K, C, 3, 3, device=d)
+        db = torch.empty(K, device=d)
+        assert L.clhip_dbg_conv3x3_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), N, C, K, H, W, 1, None) == 0
+        assert L.clhip_dbg_conv3x3_bwd_data(dpd.data_ptr(), wd.data_ptr(), None, dx.data_ptr(), N, C, K, H, W, None) == 0
+        assert L.clhip_dbg_conv3x3_bwd_weight(xd.data_ptr(), dpd.data_ptr(), dw.data_ptr(), db.data_ptr(), N, C, K, H, W, None) == 0
+    torch.cuda.synchronize()
+    assert_close(y, y_ref, what="fwd")
+    assert_close(dx, xr.grad, what="bwd_data")
+    assert_close(dw, wr.grad, what="bwd_weight")
+    assert_close(db, br.grad, what="bwd_bias")
+
+
+def test_conv_bwd_weight_is_deterministic():
+    from clsurvey_amd import ops
+    gen = np.random.RandomState(5)
+    d = dev()
+    x, dy = rnd(gen, 8, 64, 16, 16).to(d), rnd(gen, 8, 64, 16, 16).to(d)
+    a = ops.conv3x3_bwd_weight(x, dy)
+    b = ops.conv3x3_bwd_weight(x, dy)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 8, 8), (3, 5, 64, 64), (1, 128, 2, 2)])
+def test_maxpool(shape):
+    import torch.nn.functional as F
+    from clsurvey_amd import ops
+    gen = np.random.RandomState(3)
+    x = rnd(gen, *shape)
+    x[0, 0, :2, :2] = 0.0   # tie: first index must win
+    xr = x.clone().requires_grad_(True)
+    y_ref, i_ref = F.max_pool2d(xr, 2, 2, return_indices=True)
+    g = rnd(gen, *y_ref.shape)
+    y_ref.backward(g)
+    d = dev()
+    y, idx = ops.maxpool2_fwd(x.to(d))
+    dx = ops.maxpool2_bwd(g.to(d), idx)
+    assert torch.equal(y.cpu(), y_ref.detach())
+    assert torch.equal(dx.cpu(), xr.grad)
+    H, W = shape[2], shape[3]
+    oh = torch.arange(H // 2).view(-1, 1) * 2
+    ow = torch.arange(W // 2).view(1, -1) * 2
+    flat = (oh + (idx.cpu().long() // 2)) * W + ow + (idx.cpu().long() % 2)
+    assert torch.equal(flat, i_ref)
+
+
+@pytest.mark.parametrize("shape", [(7, 50, 33), (200, 2048, 128), (200, 128, 20), (64, 512, 512), (200, 24, 5)])
+def test_fc(shape):
+    import torch.nn.functional as F
+    from clsurvey_amd import ops
+    M, I, O = shape
+    gen = np.random.RandomState(M + I + O)
+    x, w, b, dy = rnd(gen, M, I), rnd(gen, O, I, scale=0.05), rnd(gen, O, scale=0.1), rnd(gen, M, O)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    y_ref = F.relu(F.linear(xr, wr, br))
+    y_ref.backward(dy)
+    dpre = dy * (y_ref.detach() > 0)
+    d = dev()
+    y = ops.fc_fwd(x.to(d), w.to(d), b.to(d), relu=True)
+    dx = ops.fc_bwd_data(dpre.to(d), w.to(d))
+    dw, db = ops.fc_bwd_weight(x.to(d), dpre.to(d))
+    assert_close(y, y_ref, what="fc fwd")
+    assert_close(dx, xr.grad, what="fc bwd_data")
+    assert_close(dw, wr.grad, what="fc bwd_weight")
+    assert_close(db, br.grad, what="fc bwd_bias")
+    msrc = rnd(gen, M, I)
+    assert_close(ops.fc_bwd_data(dpre.to(d), w.to(d), msrc.to(d)), xr.grad * (msrc > 0), what="fc mask")
+
+
+@pytest.mark.parametrize("red", ["mean", "sum"])
+def test_softmax_ce(red):
+    import torch.nn.functional as F
+    from clsurvey_amd import ops
+    gen = np.random.RandomState(9)
+    z = rnd(gen, 200, 20, scale=3.0)
+    y = torch.from_numpy(gen.randint(0, 20, size=(200,)).astype(np.int64))
+    zr = z.clone().requires_grad_(True)
+    l_ref = F.cross_entropy(zr, y, reduction=red)
+    l_ref.backward()
+    d = dev()
+    stats = torch.zeros(2, dtype=torch.float64, device=d)
+    loss, dl = ops.softmax_ce(z.to(d), y.to(d), red, stats)
+    loss2, _ = ops.softmax_ce(z.to(d), y.to(d), red, stats)
+    assert_close(loss, l_ref.detach().view(1), tol=1e-5, what="loss")
+    assert_close(dl, zr.grad, tol=1e-5, what="dlogits")
+    s = stats.cpu()
+    assert abs(s[0].item() - 2 * l_ref.item()) < 1e-4 * abs(l_ref.item())
+    assert int(s[1].item()) == 2 * int((z.argmax(1) == y).sum())
+    l3, d3 = ops.mse_zero_sum(z.to(d))
+    assert_close(l3, (z ** 2).sum().view(1), tol=1e-5)
+    assert_close(d3, 2 * z, tol=1e-6)
+
+
+def test_elementwise_regularizers_match_oracle():
+    from clsurvey_amd import ops
+    gen = np.random.RandomState(17)
+    d = dev()
+    for n in (1, 5, 1023, 4096, 615380):
+        th, g = rnd(gen, n), rnd(gen, n, scale=0.1)
+        om, iv = rnd(gen, n).abs() * 1e-2, rnd(gen, n)
+        buf0, w0 = rnd(gen, n, scale=0.1), rnd(gen, n, scale=0.01)
+        for first in (True, False):
+            for use_reg in (True, False):
+                t_ref, b_ref = R.reg_sgd_step(th, g, om if use_reg else None, iv if use_reg else None,
+                                              None if first else buf0, 400, 1e-2, 0.9, 5e-4, first)
+                t, b = th.clone().to(d), buf0.clone().to(d)
+                ops.reg_sgd_step(t, g.to(d), om.to(d) if use_reg else None, iv.to(d) if use_reg else None, b,
+                                 400, 1e-2, 0.9, 5e-4, first)
+                assert_close(t, t_ref, tol=1e-6, what="reg_sgd theta")
+                assert_close(b, b_ref, tol=1e-6, what="reg_sgd buf")
+            t_ref, b_ref, w_ref = R.si_step(th, g, om, iv, w0, None if first else buf0, 400, 1e-2, 0.9, 1e-4, first)
+            t, b, w = th.clone().to(d), buf0.clone().to(d), w0.clone().to(d)
+            ops.si_step(t, g.to(d), om.to(d), iv.to(d), w, b, 400, 1e-2, 0.9, 1e-4, first)
+            assert_close(t, t_ref, tol=1e-6)
+            assert_close(b, b_ref, tol=1e-6)
+            assert_close(w, w_ref, tol=1e-5)
+        o = om.clone().to(d)
+        ops.fisher_accum(o, g.to(d), 8000)
+        assert_close(o, R.fisher_accum(om, g, 8000), tol=1e-6)
+        o = om.clone().to(d)
+        ops.mas_accum(o, g.to(d), 3, 200)
+        assert_close(o, R.mas_accum(om, g, 3, 200), tol=1e-6)
+        o, w, i2 = om.clone().to(d), w0.clone().to(d), iv.clone().to(d)
+        ops.si_consolidate(o, w, th.to(d), i2)
+        o_ref, w_ref, i_ref = R.si_consolidate(om, w0, th, iv)
+        assert_close(o, o_ref, tol=1e-5)
+        assert float(w.abs().max()) == 0.0 and torch.equal(i2.cpu(), th)
+    # unaligned views (scalar path)
+    base = rnd(gen, 1001).to(d)
+    g = rnd(gen, 1000).to(d)
+    o = base[1:]
+    ref = R.fisher_accum(o.cpu(), g.cpu(), 10)
+    ops.fisher_accum(o, g, 10)
+    assert_close(o, ref, tol=1e-6)
+
+
+def build_engine(cfg, fc, ncls, hw, params, max_batch):
+    from clsurvey_amd import models, net
+    last = [v for v in cfg if v != "M"][-1]
+    m = models.VGGSlim(cfg=cfg, num_classes=ncls, classifier_inputdim=last * (hw // 16) ** 2,
+                       classifier_dim1=fc[0], classifier_dim2=fc[1])
+    with torch.no_grad():
+        for p, q in zip(m.parameters(), params):
+            p.copy_(q)
+    eng = net.NetEngine(m, max_batch, (3, hw, hw), dev())
+    return m, eng
+
+
+@pytest.mark.parametrize("kind", ["ce_mean", "ce_sum", "mse_sum_zero"])
+def test_engine_matches_reference_golden_g1(golden, kind):
+    g = golden("G1_vgg_fwd_bwd")
+    params = [torch.from_numpy(g["tiny_p%d" % i]) for i in range(18)]
+    m, eng = build_engine(TINY, (24, 24), 5, 32, params, 8)
+    x, y = torch.from_numpy(g["tiny_x"]).to(dev()), torch.from_numpy(g["tiny_y"]).to(dev())
+    loss, logits = eng.loss_step(x, y, kind, backward=True, want_logits=True)
+    assert_close(logits, torch.from_numpy(g["tiny_%s_logits" % kind]), what="logits")
+    assert_close(loss, torch.from_numpy(g["tiny_%s_loss" % kind]).view(1), what="loss")
+    for i, p in enumerate(m.parameters()):
+        assert_close(p.grad, torch.from_numpy(g["tiny_%s_g%d" % (kind, i)]), what="grad %d" % i)
+
+
+def test_autograd_path_matches_engine_and_golden(golden):
+    from clsurvey_amd import ops
+    g = golden("G1_vgg_fwd_bwd")
+    params = [torch.from_numpy(g["tiny_p%d" % i]) for i in range(18)]
+    m, eng = build_engine(TINY, (24, 24), 5, 32, params, 8)
+    x, y = torch.from_numpy(g["tiny_x"]).to(dev()), torch.from_numpy(g["tiny_y"]).to(dev())
+    for p in m.parameters():
+        p.grad = None
+    logits = m(x)
+    loss = ops.cross_entropy(logits, y, "mean")
+    loss.backward()
+    assert_close(logits, torch.from_numpy(g["tiny_ce_mean_logits"]), what="logits")
+    for i, p in enumerate(m.parameters()):
+        assert_close(p.grad, torch.from_numpy(g["tiny_ce_mean_g%d" % i]), what="grad %d" % i)
+
+
+@pytest.mark.parametrize("name,N", [("small_VGG9", 200), ("base_VGG9", 32)])
+def test_engine_full_size_vs_oracle(name, N):
+    cfg = vgg_ref.CFGS[name]
+    fc = (128, 128) if name == "small_VGG9" else (512, 512)
+    params = vgg_ref.init_params(cfg, fc, 20, 64, np.random.RandomState(21))
+    gen = np.random.RandomState(22)
+    x = rnd(gen, N, 3, 64, 64)
+    y = torch.from_numpy(gen.randint(0, 20, size=(N,)).astype(np.int64))
+    m, eng = build_engine(cfg, fc, 20, 64, params, N)
+    logits_ref, loss_ref, grads_ref, _ = vgg_ref.loss_and_grads(params, cfg, x, y, "ce_sum")
+    loss, logits = eng.loss_step(x.to(dev()), y.to(dev()), "ce_sum", True, want_logits=True)
+    assert_close(logits, logits_ref, what="logits")
+    assert_close(loss, loss_ref.view(1), what="loss")
+    for i, (p, gr) in enumerate(zip(m.parameters(), grads_ref)):
+        assert_close(p.grad, gr, what="grad %d" % i)
+    # eval-only pass leaves gradients untouched and reproduces the logits bit for bit
+    before = eng.arena.grad.clone()
+    _, logits2 = eng.loss_step(x.to(dev()), y.to(dev()), "ce_mean", False, want_logits=True)
+    assert torch.equal(before, eng.arena.grad) and torch.equal(logits, logits2)
+
+
+def test_ewc_fisher_golden_g2(golden):
+    """diag_fisher (EWC/main_EWC.py:138-157) over 3 batches x 2 tasks through NetEngine +
+    clhip_fisher_accum, against the reference's own Omega."""
+    from clsurvey_amd import ops
+    g = golden("G2_ewc_fisher")
+    params = [torch.from_numpy(g["p%d" % i]) for i in range(18)]
+    m, eng = build_engine(TINY, (24, 24), 5, 32, params, 8)
+    A = eng.arena
+    omega = A.buffer("omega")
+    prev = torch.zeros_like(omega)
+    for task in range(2):
+        omega.zero_()
+        for b in range(3):
+            x = torch.from_numpy(g["t%d_x%d" % (task, b)]).to(dev())
+            y = torch.from_numpy(g["t%d_y%d" % (task, b)]).to(dev())
+            eng.loss_step(x, y, "ce_sum", True)
+            ops.fisher_accum(omega, A.grad, 24)
+        prev = prev + omega
+        for i, p in enumerate(m.parameters()):
+            o, n = A.slot(p)
+            assert_close(prev[o:o + n].view(p.shape), torch.from_numpy(g["t%d_omega%d" % (task, i)]), tol=5e-4,
+                         what="omega t%d p%d" % (task, i))
+
+
+def test_mas_omega_golden_g3(golden):
+    from clsurvey_amd import ops
+    g = golden("G3_mas_omega")
+    params = [torch.from_numpy(g["p%d" % i]) for i in range(18)]
+    m, eng = build_engine(TINY, (24, 24), 5, 32, params, 8)
+    A = eng.arena
+    omega = A.buffer("omega")
+    omega.zero_()
+    for b in range(3):
+        x = torch.from_numpy(g["x%d" % b]).to(dev())
+        eng.loss_step(x, None, "mse_sum_zero", True)
+        ops.mas_accum(omega, A.grad, b, x.shape[0])
+    for i, p in enumerate(m.parameters()):
+        assert_close(A.view("omega", p), torch.from_numpy(g["omega%d" % i]), tol=5e-4, what="omega %d" % i)
+
+
+def test_penalised_sgd_golden_g5(golden):
+    """3 steps of Weight_Regularized_SGD (EWC and MAS classes) incl. an unpenalised head."""
+    from clsurvey_amd import ops
+    g = golden("G5_reg_sgd")
+    for tag, lam, wd in (("ewc", 400, 0.0), ("mas", 3, 5e-4)):
+        params = [torch.from_numpy(g["%s_p%d" % (tag, i)]) for i in range(18)]
+        m, eng = build_engine(TINY, (24, 24), 5, 32, params, 8)
+        A = eng.arena
+        plist = list(m.parameters())
+        A.load("omega", {p: torch.from_numpy(g["%s_omega%d" % (tag, i)]) for i, p in enumerate(plist[:-2])})
+        A.load("init_val", {p: torch.from_numpy(g["%s_init%d" % (tag, i)]) for i, p in enumerate(plist[:-2])})
+        buf = A.buffer("buf")
+        for s in range(3):
+            x = torch.from_numpy(g["%s_x%d" % (tag, s)]).to(dev())
+            y = torch.from_numpy(g["%s_y%d" % (tag, s)]).to(dev())
+            loss, _ = eng.loss_step(x, y, "ce_mean", True)
+            assert_close(loss, torch.from_numpy(g["%s_s%d_loss" % (tag, s)]).view(1), what="loss")
+            ops.reg_sgd_step(A.theta, A.grad, A.aux["omega"], A.aux["init_val"], buf, lam, 1e-2, 0.9, wd, s == 0)
+        for i, p in enumerate(plist):
+            assert_close(p.data, torch.from_numpy(g["%s_s2_theta%d" % (tag, i)]), what="theta %d" % i)
+            assert_close(A.view("buf", p), torch.from_numpy(g["%s_s2_buf%d" % (tag, i)]), tol=1e-3, what="buf %d" % i)
+
+
+def test_si_golden_g4(golden):
+    from clsurvey_amd import ops
+    g = golden("G4_si")
+    for tag, wd in (("wd0", 0.0), ("wd1", 1e-4)):
+        params = [torch.from_numpy(g["%s_p%d" % (tag, i)]) for i in range(18)]
+        m, eng = build_engine(TINY, (24, 24), 5, 32, params, 8)
+        A = eng.arena
+        plist = list(m.parameters())
+        A.load("omega", {p: torch.from_numpy(g["%s_omega%d" % (tag, i)]) for i, p in enumerate(plist)})
+        A.load("init_val", {p: torch.from_numpy(g["%s_init%d" % (tag, i)]) for i, p in enumerate(plist)})
+        buf, w = A.buffer("buf"), A.buffer("w")
+        w.zero_()
+        for s in range(3):
+            x = torch.from_numpy(g["%s_x%d" % (tag, s)]).to(dev())
+            y = torch.from_numpy(g["%s_y%d" % (tag, s)]).to(dev())
+            eng.loss_step(x, y, "ce_mean", True)
+            ops.si_step(A.theta, A.grad, A.aux["omega"], A.aux["init_val"], w, buf, 400, 1e-2, 0.9, wd, s == 0)
+        for i, p in enumerate(plist):
+            assert_close(p.data, torch.from_numpy(g["%s_s2_theta%d" % (tag, i)]), what="theta %d" % i)
+            assert_close(A.view("w", p), torch.from_numpy(g["%s_s2_w%d" % (tag, i)]), tol=2e-3, what="w %d" % i)
+        ops.si_consolidate(A.aux["omega"], w, A.theta, A.aux["init_val"])
+        for i, p in enumerate(plist):
+            assert_close(A.view("omega", p), torch.from_numpy(g["%s_cons_omega%d" % (tag, i)]), tol=2e-3, what="omega %d" % i)
+            assert_close(A.view("init_val", p), torch.from_numpy(g["%s_cons_init%d" % (tag, i)]), what="init %d" % i)
