@@ -64,6 +64,14 @@ def lib():
             raise RuntimeError(
                 "clsurvey_amd: %s not found. Build it with `python clsurvey_amd/build.py` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        # torch's ROCm wheel bundles its own libamdhip64; it MUST be the one (and only) HIP runtime in
+        # the process, so make sure it is mapped before libclhip's DT_NEEDED libamdhip64.so.7 resolves
+        # (otherwise /opt/rocm's copy is loaded as a second runtime and launches fail with
+        # hipErrorNoDevice on pointers owned by torch's runtime).
+        import torch
+        bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(bundled):
+            C.CDLL(bundled, mode=C.RTLD_GLOBAL)
         h = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)      # AttributeError => symbol missing: fail loudly

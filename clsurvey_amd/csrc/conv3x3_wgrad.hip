@@ -6,13 +6,16 @@
 // (B operand = x shifted by the tap), reduction (MFMA K) = pixels, two per instruction.
 // One A fragment feeds NINE MFMAs (one accumulator per tap): 10 ds_read_b32 per 9 MFMAs.
 //
-// The reduction dimension (N*H*W, up to 819 200) is split across blocks; every block writes a
-// partial [9][K][C] slab into the caller's workspace and a second kernel sums the slabs in a
-// fixed order => bitwise run-to-run deterministic (the reference seeds everything and sets
-// cudnn.deterministic, utilities/utils.py:52-58).
+// The reduction dimension (N*H*W, up to 819 200) is split across blocks (about one block per
+// CU: the kernel is MFMA-bound and software-pipelined — the next 64-pixel stage is prefetched
+// into registers while the current one feeds the matrix pipe).  Every block writes a partial
+// [9][K][C](+[K]) slab into the caller's workspace; two small kernels then sum the slabs in a
+// fixed order (grouped, then across groups) => bitwise run-to-run deterministic, as the
+// reference promises by seeding everything and setting cudnn.deterministic
+// (utilities/utils.py:52-58).
 //
-// First layer (C <= 3): the 27 (c,r,s) combinations become the D columns of ONE accumulator
-// (84 % of the MFMA columns useful instead of 9 %).
+// First layer (C*9 <= 32): the 27 (c,r,s) combinations become the D columns of ONE accumulator
+// (84 % of the MFMA columns useful instead of 9 %); that kernel is HBM-bound on reading dy.
 #include "common.hpp"
 
 namespace {
@@ -42,9 +45,9 @@ __device__ __forceinline__ void decode_stage(int st, int tiles_w, int tiles_h, i
 // grid.x = n_tiles(k,c) * splits ; block 256 = 4 waves = (2 k-halves) x (2 c-halves)
 template <int TW, int TH>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(
-    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part_dw,
-    float* __restrict__ part_db, int N, int C, int K, int H, int W, int tiles_w, int tiles_h,
-    int total_stages, int splits, int c_tiles) {
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
+    int N, int C, int K, int H, int W, int tiles_w, int tiles_h,
+    int total_stages, int splits, int c_tiles, size_t slab_stride) {
     using G = WGeo<TW, TH>;
     __shared__ float dys[KT * G::LDP];
     __shared__ float xs[CT * G::PLANEP];
@@ -74,43 +77,63 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(
     const float* b_ptr = xs + (wc * 32 + li) * G::PLANEP + kk;
     const size_t plane_hw = (size_t)H * W;
 
-    for (int st = st_begin; st < st_end; ++st) {
+    constexpr int DY_ITERS = KT * G::BP / 256;                 // 16
+    constexpr int X_ELEMS = CT * G::PLANE;
+    constexpr int X_ITERS = (X_ELEMS + 255) / 256;             // 34 / 27 / 25
+    float dyr[DY_ITERS];
+    float xr[X_ITERS];
+
+    auto load_stage = [&](int st) {
         int n, h0, w0;
         decode_stage(st, tiles_w, tiles_h, TW, TH, n, h0, w0);
-        __syncthreads();   // previous stage's LDS reads are done
-        // ---- dy tile: [64 k][64 px]
-        constexpr int DY_ITERS = KT * G::BP / 256;
+        const float* dyn = dy + (size_t)n * K * plane_hw;
+        const float* xn = x + (size_t)n * C * plane_hw;
 #pragma unroll
         for (int j = 0; j < DY_ITERS; ++j) {
             int e = tid + 256 * j;
             int kl = e / G::BP, q = e - kl * G::BP;
             int th = q / TW, tw = q - th * TW;
             int k = k0 + kl, h = h0 + th, w = w0 + tw;
-            float v = 0.f;
-            if (k < K && h < H && w < W) v = dy[((size_t)n * K + k) * plane_hw + (size_t)h * W + w];
-            dys[kl * G::LDP + q] = v;
+            dyr[j] = (k < K && h < H && w < W) ? dyn[(size_t)k * plane_hw + (size_t)h * W + w] : 0.f;
         }
-        // ---- x halo tile: [64 c][PLANE]
-        constexpr int X_ELEMS = CT * G::PLANE;
-        constexpr int X_ITERS = (X_ELEMS + 255) / 256;
-#pragma unroll 4
+#pragma unroll
         for (int j = 0; j < X_ITERS; ++j) {
             int e = tid + 256 * j;
+            float v = 0.f;
             if (e < X_ELEMS) {
                 int cl = e / G::PLANE, rem = e - cl * G::PLANE;
                 int row = rem / G::TWP, col = rem - row * G::TWP;
                 int c = c0 + cl, h = h0 - 1 + row, w = w0 - 1 + col;
-                float v = 0.f;
-                if (c < C && h >= 0 && h < H && w >= 0 && w < W)
-                    v = x[((size_t)n * C + c) * plane_hw + (size_t)h * W + w];
-                xs[cl * G::PLANEP + rem] = v;
+                if (c < C && h >= 0 && h < H && w >= 0 && w < W) v = xn[(size_t)c * plane_hw + (size_t)h * W + w];
+            }
+            xr[j] = v;
+        }
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < DY_ITERS; ++j) {
+            int e = tid + 256 * j;
+            int kl = e / G::BP, q = e - kl * G::BP;
+            dys[kl * G::LDP + q] = dyr[j];
+        }
+#pragma unroll
+        for (int j = 0; j < X_ITERS; ++j) {
+            int e = tid + 256 * j;
+            if (e < X_ELEMS) {
+                int cl = e / G::PLANE, rem = e - cl * G::PLANE;
+                xs[cl * G::PLANEP + rem] = xr[j];
             }
         }
+    };
+
+    if (st_begin < st_end) load_stage(st_begin);
+    for (int st = st_begin; st < st_end; ++st) {
+        __syncthreads();               // previous stage's LDS reads are done
+        store_stage();
         __syncthreads();
-        // ---- 32 pixel pairs x 9 taps
+        if (st + 1 < st_end) load_stage(st + 1);   // in flight while the matrix pipe runs
 #pragma unroll
         for (int pp = 0; pp < G::BP / 2; ++pp) {
-            constexpr int dummy = 0; (void)dummy;
             const int q0 = 2 * pp;
             const int th = q0 / TW, tw = q0 - (q0 / TW) * TW;
             float a = a_ptr[q0];
@@ -124,8 +147,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(
         }
     }
 
-    // ---- partial slab [split][9][K][C]: reg r of lane l = D[row = k][col = c]
-    float* slab = part_dw + (size_t)split * 9 * K * C;
+    // ---- partial slab [split]{[9][K][C], [K]}: reg r of lane l = D[row = k][col = c]
+    float* slab = part + (size_t)split * slab_stride;
     const int c = c0 + wc * 32 + li;
 #pragma unroll
     for (int rs = 0; rs < 9; ++rs)
@@ -134,25 +157,27 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(
             int k = k0 + wk * 32 + mfma32_row(r, lane);
             if (k < K && c < C) slab[((size_t)rs * K + k) * C + c] = acc[rs][r];
         }
-    if (part_db && ct == 0 && wc == 0) {
+    if (ct == 0 && wc == 0) {
         bsum += __shfl_xor(bsum, 32, 64);
         int k = k0 + wk * 32 + li;
-        if (kk == 0 && k < K) part_db[(size_t)split * K + k] = bsum;
+        if (kk == 0 && k < K) slab[(size_t)9 * K * C + k] = bsum;
     }
 }
 
-// First-layer variant: C*9 <= 32 columns in one accumulator. Block = 128 threads = 2 waves
-// (k halves of a 64-channel tile).
+// First-layer variant: C*9 <= 32 columns in one accumulator. Block = 256 threads = 4 waves:
+// (2 k-halves of a 64-channel tile) x (2 halves of the stage's pixel pairs); the two pixel
+// halves are summed through LDS at the end.  HBM-bound on dy: stages are prefetched.
 template <int TW, int TH>
-__global__ __launch_bounds__(128) void conv3x3_wgrad_smallc_kernel(
-    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part_dw,
-    float* __restrict__ part_db, int N, int C, int K, int H, int W, int tiles_w, int tiles_h,
-    int total_stages, int splits) {
+__global__ __launch_bounds__(256) void conv3x3_wgrad_smallc_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
+    int N, int C, int K, int H, int W, int tiles_w, int tiles_h,
+    int total_stages, int splits, size_t slab_stride) {
     using G = WGeo<TW, TH>;
     __shared__ float dys[KT * G::LDP];
     __shared__ float xs[3 * G::PLANE + 8];
 
-    const int tid = threadIdx.x, lane = tid & 63, wk = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave & 1, wh = wave >> 1;
     const int li = lane & 31, kk = lane >> 5;
     const int split = blockIdx.x % splits;
     const int kt = blockIdx.x / splits;
@@ -173,93 +198,132 @@ __global__ __launch_bounds__(128) void conv3x3_wgrad_smallc_kernel(
         int cc = li / 9, rs = li - cc * 9;
         col_off = cc * G::PLANE + (rs / 3) * G::TWP + (rs % 3);
     }
-    const float* a_ptr = dys + (wk * 32 + li) * G::LDP + kk;
+    const float* a_ptr = dys + (wk * 32 + li) * G::LDP + kk + wh * (G::BP / 2);
     const float* b_ptr = xs + col_off + kk;
     const size_t plane_hw = (size_t)H * W;
 
-    for (int st = st_begin; st < st_end; ++st) {
+    constexpr int DY_ITERS = KT * G::BP / 256;                 // 16
+    constexpr int X_ELEMS = 3 * G::PLANE;
+    constexpr int X_ITERS = (X_ELEMS + 255) / 256;             // 2
+    float dyr[DY_ITERS];
+    float xr[X_ITERS];
+
+    auto load_stage = [&](int st) {
         int n, h0, w0;
         decode_stage(st, tiles_w, tiles_h, TW, TH, n, h0, w0);
-        __syncthreads();
-        constexpr int DY_ITERS = KT * G::BP / 128;
-#pragma unroll 8
+        const float* dyn = dy + (size_t)n * K * plane_hw;
+        const float* xn = x + (size_t)n * C * plane_hw;
+#pragma unroll
         for (int j = 0; j < DY_ITERS; ++j) {
-            int e = tid + 128 * j;
+            int e = tid + 256 * j;
             int kl = e / G::BP, q = e - kl * G::BP;
             int th = q / TW, tw = q - th * TW;
             int k = k0 + kl, h = h0 + th, w = w0 + tw;
-            float v = 0.f;
-            if (k < K && h < H && w < W) v = dy[((size_t)n * K + k) * plane_hw + (size_t)h * W + w];
-            dys[kl * G::LDP + q] = v;
+            dyr[j] = (k < K && h < H && w < W) ? dyn[(size_t)k * plane_hw + (size_t)h * W + w] : 0.f;
         }
-        constexpr int X_ELEMS = 3 * G::PLANE;
-        constexpr int X_ITERS = (X_ELEMS + 127) / 128;
 #pragma unroll
         for (int j = 0; j < X_ITERS; ++j) {
-            int e = tid + 128 * j;
+            int e = tid + 256 * j;
+            float v = 0.f;
             if (e < X_ELEMS) {
                 int cl = e / G::PLANE, rem = e - cl * G::PLANE;
                 int row = rem / G::TWP, col = rem - row * G::TWP;
                 int h = h0 - 1 + row, w = w0 - 1 + col;
-                float v = 0.f;
-                if (cl < C && h >= 0 && h < H && w >= 0 && w < W)
-                    v = x[((size_t)n * C + cl) * plane_hw + (size_t)h * W + w];
-                xs[e] = v;
+                if (cl < C && h >= 0 && h < H && w >= 0 && w < W) v = xn[(size_t)cl * plane_hw + (size_t)h * W + w];
             }
+            xr[j] = v;
         }
-        __syncthreads();
+    };
+    auto store_stage = [&]() {
 #pragma unroll
-        for (int pp = 0; pp < G::BP / 2; ++pp) {
-            const int q0 = 2 * pp;
-            const int th = q0 / TW, tw = q0 - (q0 / TW) * TW;
-            float a = a_ptr[q0];
+        for (int j = 0; j < DY_ITERS; ++j) {
+            int e = tid + 256 * j;
+            int kl = e / G::BP, q = e - kl * G::BP;
+            dys[kl * G::LDP + q] = dyr[j];
+        }
+#pragma unroll
+        for (int j = 0; j < X_ITERS; ++j) {
+            int e = tid + 256 * j;
+            if (e < X_ELEMS) xs[e] = xr[j];
+        }
+    };
+
+    if (st_begin < st_end) load_stage(st_begin);
+    for (int st = st_begin; st < st_end; ++st) {
+        __syncthreads();
+        store_stage();
+        __syncthreads();
+        if (st + 1 < st_end) load_stage(st + 1);
+#pragma unroll
+        for (int pp = 0; pp < G::BP / 4; ++pp) {
+            // this wave's half of the stage: pixel = wh*32 + ql (+kk); 32 is a multiple of TW, so the
+            // half offset is whole rows
+            const int ql = 2 * pp;
+            float a = a_ptr[ql];
             bsum += a;
-            float b = b_ptr[th * G::TWP + tw];
+            const int th = ql / TW, tw = ql - (ql / TW) * TW;
+            float b = b_ptr[(th + wh * (32 / TW)) * G::TWP + tw];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
         }
     }
-    // slab layout [split][9][K][C] like the general kernel
-    float* slab = part_dw + (size_t)split * 9 * K * C;
-    if (li < ncol) {
-        int cc = li / 9, rs = li - cc * 9;
+    // combine the two pixel halves through LDS (reuse dys), fixed order: half 0 + half 1
+    bsum += __shfl_xor(bsum, 32, 64);
+    __syncthreads();                                             // last stage's LDS reads are done
+    float* red = dys;                                            // [2 k-halves][16 regs][64 lanes] + [64] bias
+    if (wh == 1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int k = k0 + wk * 32 + mfma32_row(r, lane);
-            if (k < K) slab[((size_t)rs * K + k) * C + cc] = acc[r];
-        }
+        for (int r = 0; r < 16; ++r) red[(wk * 16 + r) * 64 + lane] = acc[r];
+        if (kk == 0) red[2048 + wk * 32 + li] = bsum;
     }
-    if (part_db) {
-        bsum += __shfl_xor(bsum, 32, 64);
+    __syncthreads();
+    if (wh == 0) {
+        float* slab = part + (size_t)split * slab_stride;
+        if (li < ncol) {
+            int cc = li / 9, rs = li - cc * 9;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int k = k0 + wk * 32 + mfma32_row(r, lane);
+                if (k < K) slab[((size_t)rs * K + k) * C + cc] = acc[r] + red[(wk * 16 + r) * 64 + lane];
+            }
+        }
         int k = k0 + wk * 32 + li;
-        if (kk == 0 && k < K) part_db[(size_t)split * K + k] = bsum;
+        if (kk == 0 && k < K) slab[(size_t)9 * K * C + k] = bsum + red[2048 + wk * 32 + li];
     }
 }
 
-// dw[k][c][rs] = sum_s slab[s][rs][k][c] (fixed order); db likewise.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part_dw,
-                                                           const float* __restrict__ part_db,
-                                                           float* __restrict__ dw, float* __restrict__ db,
-                                                           int K, int C, int splits) {
-    const size_t kc = (size_t)K * C, total = 9 * kc;
-    size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total + (db ? K : 0); e += stride) {
-        if (e < total) {
-            float s = 0.f;
-            for (int sp = 0; sp < splits; ++sp) s += part_dw[(size_t)sp * total + e];
-            size_t rs = e / kc, rem = e - rs * kc;     // rem = k*C + c
-            dw[rem * 9 + rs] = s;
-        } else {
-            size_t k = e - total;
-            float s = 0.f;
-            for (int sp = 0; sp < splits; ++sp) s += part_db[(size_t)sp * K + k];
-            db[k] = s;
-        }
+// Level 1: tmp[g][e] = sum over the splits of group g (fixed order).
+__global__ __launch_bounds__(256) void wgrad_reduce_groups_kernel(const float* __restrict__ part, float* __restrict__ tmp,
+                                                                  size_t total, int splits, int group) {
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int g = blockIdx.y;
+    const int s0 = g * group, s1 = min(splits, s0 + group);
+    float s = 0.f;
+#pragma unroll 8
+    for (int sp = s0; sp < s1; ++sp) s += part[(size_t)sp * total + e];
+    tmp[(size_t)g * total + e] = s;
+}
+
+// Level 2: dw[k][c][rs] = sum_g tmp[g][rs][k][c] ; db[k] = sum_g tmp[g][9KC + k].
+__global__ __launch_bounds__(256) void wgrad_reduce_final_kernel(const float* __restrict__ tmp, float* __restrict__ dw,
+                                                                 float* __restrict__ db, int K, int C, int groups) {
+    const size_t kc = (size_t)K * C, nw = 9 * kc, total = nw + K;
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    float s = 0.f;
+#pragma unroll 8
+    for (int g = 0; g < groups; ++g) s += tmp[(size_t)g * total + e];
+    if (e < nw) {
+        size_t rs = e / kc, rem = e - rs * kc;     // rem = k*C + c
+        dw[rem * 9 + rs] = s;
+    } else if (db) {
+        db[e - nw] = s;
     }
 }
 
 struct WPlan {
-    int TW, TH, tiles_w, tiles_h, total_stages, splits, k_tiles, c_tiles;
-    size_t ws_floats;
+    int TW, TH, tiles_w, tiles_h, total_stages, splits, k_tiles, c_tiles, group, groups;
+    size_t slab, ws_floats;
 };
 
 WPlan make_plan(int N, int C, int K, int H, int W) {
@@ -270,20 +334,26 @@ WPlan make_plan(int N, int C, int K, int H, int W) {
     p.tiles_w = (W + p.TW - 1) / p.TW;
     p.tiles_h = (H + p.TH - 1) / p.TH;
     p.total_stages = p.tiles_w * p.tiles_h * N;
+    const bool smallc = (C * 9 <= 32);
     p.k_tiles = (K + KT - 1) / KT;
-    p.c_tiles = (C * 9 <= 32) ? 1 : (C + CT - 1) / CT;
+    p.c_tiles = smallc ? 1 : (C + CT - 1) / CT;
     int tiles = p.k_tiles * p.c_tiles;
-    int target = (C * 9 <= 32) ? 2048 : 512;           // blocks wanted in flight
+    // MFMA-bound general kernel: ~1 block per CU. HBM-bound first-layer kernel: several per CU.
+    int target = smallc ? 1024 : 256;
     int splits = (target + tiles - 1) / tiles;
     if (splits > p.total_stages) splits = p.total_stages;
-    // keep the partial slabs under 96 MiB
-    size_t slab = (size_t)9 * K * C + K;
-    size_t max_splits = ((size_t)96 << 20) / (slab * sizeof(float));
+    p.slab = (size_t)9 * K * C + K;
+    size_t max_splits = ((size_t)64 << 20) / (p.slab * sizeof(float));
     if (max_splits < 1) max_splits = 1;
     if ((size_t)splits > max_splits) splits = (int)max_splits;
     if (splits < 1) splits = 1;
     p.splits = splits;
-    p.ws_floats = slab * (size_t)splits;
+    // two-level reduction: groups of ~sqrt(splits)
+    int group = 1;
+    while (group * group < splits) ++group;
+    p.group = group;
+    p.groups = (splits + group - 1) / group;
+    p.ws_floats = p.slab * (size_t)(splits + p.groups);
     return p;
 }
 
@@ -302,24 +372,26 @@ int clhip_conv3x3_bwd_weight(const float* x, const float* dy, float* dw, float* 
     WPlan p = make_plan(N, C, K, H, W);
     if (ws_bytes < p.ws_floats * sizeof(float)) return CLHIP_ENOSPC;
     hipStream_t s = as_stream(stream);
-    float* part_dw = static_cast<float*>(ws);
-    float* part_db = part_dw + (size_t)p.splits * 9 * K * C;
+    float* part = static_cast<float*>(ws);
+    float* tmp = part + p.slab * (size_t)p.splits;
     const bool smallc = (C * 9 <= 32);
     unsigned grid = (unsigned)(p.k_tiles * p.c_tiles * p.splits);
-#define WG_ARGS x, dy, part_dw, part_db, N, C, K, H, W, p.tiles_w, p.tiles_h, p.total_stages, p.splits
+#define WG_ARGS x, dy, part, N, C, K, H, W, p.tiles_w, p.tiles_h, p.total_stages, p.splits
     if (smallc) {
-        if (p.TW == 32) hipLaunchKernelGGL((conv3x3_wgrad_smallc_kernel<32, 2>), dim3(grid), dim3(128), 0, s, WG_ARGS);
-        else if (p.TW == 16) hipLaunchKernelGGL((conv3x3_wgrad_smallc_kernel<16, 4>), dim3(grid), dim3(128), 0, s, WG_ARGS);
-        else hipLaunchKernelGGL((conv3x3_wgrad_smallc_kernel<8, 8>), dim3(grid), dim3(128), 0, s, WG_ARGS);
+        if (p.TW == 32) hipLaunchKernelGGL((conv3x3_wgrad_smallc_kernel<32, 2>), dim3(grid), dim3(256), 0, s, WG_ARGS, p.slab);
+        else if (p.TW == 16) hipLaunchKernelGGL((conv3x3_wgrad_smallc_kernel<16, 4>), dim3(grid), dim3(256), 0, s, WG_ARGS, p.slab);
+        else hipLaunchKernelGGL((conv3x3_wgrad_smallc_kernel<8, 8>), dim3(grid), dim3(256), 0, s, WG_ARGS, p.slab);
     } else {
-        if (p.TW == 32) hipLaunchKernelGGL((conv3x3_wgrad_kernel<32, 2>), dim3(grid), dim3(256), 0, s, WG_ARGS, p.c_tiles);
-        else if (p.TW == 16) hipLaunchKernelGGL((conv3x3_wgrad_kernel<16, 4>), dim3(grid), dim3(256), 0, s, WG_ARGS, p.c_tiles);
-        else hipLaunchKernelGGL((conv3x3_wgrad_kernel<8, 8>), dim3(grid), dim3(256), 0, s, WG_ARGS, p.c_tiles);
+        if (p.TW == 32) hipLaunchKernelGGL((conv3x3_wgrad_kernel<32, 2>), dim3(grid), dim3(256), 0, s, WG_ARGS, p.c_tiles, p.slab);
+        else if (p.TW == 16) hipLaunchKernelGGL((conv3x3_wgrad_kernel<16, 4>), dim3(grid), dim3(256), 0, s, WG_ARGS, p.c_tiles, p.slab);
+        else hipLaunchKernelGGL((conv3x3_wgrad_kernel<8, 8>), dim3(grid), dim3(256), 0, s, WG_ARGS, p.c_tiles, p.slab);
     }
 #undef WG_ARGS
     CLHIP_LAUNCH_CHECK();
-    size_t total = (size_t)9 * K * C + (db ? K : 0);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, s, part_dw, part_db, dw, db, K, C, p.splits);
+    unsigned bx = (unsigned)((p.slab + 255) / 256);
+    hipLaunchKernelGGL(wgrad_reduce_groups_kernel, dim3(bx, p.groups), dim3(256), 0, s, part, tmp, p.slab, p.splits, p.group);
+    CLHIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(wgrad_reduce_final_kernel, dim3(bx), dim3(256), 0, s, tmp, dw, db, K, C, p.groups);
     CLHIP_LAUNCH_CHECK();
     return 0;
 }

@@ -1,0 +1,36 @@
+"""Plain fine-tuning on the HIP path — mirror of src/methods/Finetune/{main_SGD,train_SGD}.py.
+Phase 1 of every framework method delegates here (methods/method.py:671,706,735)."""
+import os
+
+import torch
+
+from ..optim import SGD
+from . import train_common as tc
+
+
+def fine_tune_SGD(dset_dataloader, cumsum_dset_sizes, dset_classes, model_path, exp_dir, num_epochs=100, lr=0.0004,
+                  freeze_mode=0, weight_decay=0, enable_resume=True, replace_last_classifier_layer=True,
+                  save_models_mode=True, freq=5, device="cuda", batch_size=None):
+    """main_SGD.py:13-82. dset_dataloader: {'train','val'} of DeviceLoader (Finetune.grid_datafetch
+    builds them, method.py:1030-1060)."""
+    if freeze_mode:
+        raise NotImplementedError("freeze_mode (classifier-only warm-up) is not on the measured path")
+    resume = os.path.join(exp_dir, "epoch.pth.tar") if enable_resume else ""
+    if resume and os.path.isfile(resume):
+        model_ft = torch.load(resume, weights_only=False)["model"]
+    else:
+        if not os.path.exists(exp_dir) and save_models_mode:
+            os.makedirs(exp_dir)
+        if not os.path.isfile(model_path):
+            raise Exception("Model path non-existing: {}".format(model_path))
+        model_ft = tc.load_model(model_path)
+    if replace_last_classifier_layer:
+        labels_per_task = [len(task_labels) for task_labels in dset_classes["train"]]
+        tc.replace_head(model_ft, sum(labels_per_task))          # utils.py:68-72
+    model_ft = model_ft.to(device)
+    any_loader = dset_dataloader["train"]
+    engine = tc.engine_for(model_ft, dset_dataloader, batch_size or any_loader.batch_size, device)
+    optimizer_ft = SGD(model_ft.parameters(), lr, momentum=0.9, weight_decay=weight_decay)
+    return tc.train_model(model_ft, engine, optimizer_ft, lr, dset_dataloader, cumsum_dset_sizes, num_epochs, exp_dir,
+                          resume, saving_freq=freq, step_fn=optimizer_ft.step, save_models_mode=save_models_mode,
+                          abort_on_bad_loss=False)

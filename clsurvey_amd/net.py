@@ -10,6 +10,7 @@
   into a static plan executed by libclhip's clhip_net_* entry points: one call per pass.
 """
 import ctypes as C
+import weakref
 
 import torch
 import torch.nn as nn
@@ -23,6 +24,19 @@ def _pad4(n):
 
 
 class ParamArena:
+    _registry = weakref.WeakValueDictionary()   # id(first param) -> arena
+
+    @classmethod
+    def find(cls, params):
+        """The arena that owns exactly this parameter list (or None)."""
+        params = list(params)
+        if not params:
+            return None
+        a = cls._registry.get(id(params[0]))
+        if a is None or len(a.params) != len(params) or any(x is not y for x, y in zip(a.params, params)):
+            return None
+        return a
+
     def __init__(self, params, device=None):
         self.params = list(params)
         if device is None:
@@ -44,6 +58,7 @@ class ParamArena:
                 p.data = v
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
         self._index = {id(p): i for i, p in enumerate(self.params)}
+        ParamArena._registry[id(self.params[0])] = self
 
     def slot(self, p):
         i = self._index[id(p)]

@@ -50,6 +50,7 @@ def test_mfma_fragment_layout_probe():
 CONV_SHAPES = [  # N, C, K, H, W
     (2, 3, 16, 32, 32), (3, 16, 16, 16, 16), (2, 32, 32, 8, 8), (5, 32, 24, 4, 4), (2, 8, 40, 12, 20),
     (4, 3, 64, 64, 64), (4, 64, 64, 32, 32), (6, 64, 128, 8, 8), (3, 128, 128, 8, 8), (1, 70, 70, 10, 10),
+    (96, 3, 64, 64, 64), (40, 64, 64, 32, 32), (300, 64, 64, 16, 16), (700, 128, 64, 8, 8), (64, 2, 32, 16, 16),
 ]
 
 
@@ -59,6 +60,8 @@ def test_conv3x3_fwd_bwd(shape, impl):
     import torch.nn.functional as F
     from clsurvey_amd import ops, _lib
     N, C, K, H, W = shape
+    if impl == "naive" and N * C * K * H * W > 4 * 64 * 64 * 32 * 32:
+        pytest.skip("naive triage kernels only run on the small shapes")
     gen = np.random.RandomState(hash(shape) % 2**31)
     x, w, b = rnd(gen, N, C, H, W), rnd(gen, K, C, 3, 3, scale=0.2), rnd(gen, K, scale=0.1)
     dy = rnd(gen, N, K, H, W)
@@ -267,12 +270,20 @@ def test_engine_full_size_vs_oracle(name, N):
     x = rnd(gen, N, 3, 64, 64)
     y = torch.from_numpy(gen.randint(0, 20, size=(N,)).astype(np.int64))
     m, eng = build_engine(cfg, fc, 20, 64, params, N)
+    # fp32 CPU sums of up to 819 200 cancelling terms (conv1 dW) are themselves ~3e-3 off the exact
+    # value, so the judge is an fp64 evaluation of the same oracle; the fp32 oracle's own distance to
+    # it is the yardstick for what "fp32 parity" can mean on each tensor.
     logits_ref, loss_ref, grads_ref, _ = vgg_ref.loss_and_grads(params, cfg, x, y, "ce_sum")
+    p64 = [p.double() for p in params]
+    _, loss64, grads64, _ = vgg_ref.loss_and_grads(p64, cfg, x.double(), y, "ce_sum")
     loss, logits = eng.loss_step(x.to(dev()), y.to(dev()), "ce_sum", True, want_logits=True)
     assert_close(logits, logits_ref, what="logits")
     assert_close(loss, loss_ref.view(1), what="loss")
-    for i, (p, gr) in enumerate(zip(m.parameters(), grads_ref)):
-        assert_close(p.grad, gr, what="grad %d" % i)
+    for i, (p, g32, g64) in enumerate(zip(m.parameters(), grads_ref, grads64)):
+        cpu32 = rel_err(g32, g64)
+        gpu = rel_err(p.grad, g64)
+        assert gpu <= max(RTOL, 1.5 * cpu32), "grad %d: gpu-vs-fp64 %.3e, cpu-fp32-vs-fp64 %.3e" % (i, gpu, cpu32)
+        assert rel_err(p.grad, g32) <= 1e-2, "grad %d vs fp32 oracle" % i
     # eval-only pass leaves gradients untouched and reproduces the logits bit for bit
     before = eng.arena.grad.clone()
     _, logits2 = eng.loss_step(x.to(dev()), y.to(dev()), "ce_mean", False, want_logits=True)
