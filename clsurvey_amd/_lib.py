@@ -31,7 +31,7 @@ SIGNATURES = {
     "clhip_fc_ws": (_z, [_i, _i, _i]),
     "clhip_fc_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _z, _p]),
     "clhip_fc_bwd_data": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
-    "clhip_fc_bwd_weight": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "clhip_fc_bwd_weight": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
     "clhip_relu_bwd": (_i, [_p, _p, _p, _z, _p]),
     "clhip_softmax_ce": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p]),
     "clhip_mse_zero_sum": (_i, [_p, _z, _p, _p, _p]),
@@ -60,10 +60,11 @@ def lib():
     """Load (once) and return the ctypes handle. Raises if the HIP library is absent."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get("CLHIP_LIB", LIB_PATH)     # CLHIP_LIB: experimental variants (tools/)
+        if not os.path.exists(path):
             raise RuntimeError(
                 "clsurvey_amd: %s not found. Build it with `python clsurvey_amd/build.py` "
-                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
         # torch's ROCm wheel bundles its own libamdhip64; it MUST be the one (and only) HIP runtime in
         # the process, so make sure it is mapped before libclhip's DT_NEEDED libamdhip64.so.7 resolves
         # (otherwise /opt/rocm's copy is loaded as a second runtime and launches fail with
@@ -72,7 +73,7 @@ def lib():
         bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
         if os.path.exists(bundled):
             C.CDLL(bundled, mode=C.RTLD_GLOBAL)
-        h = C.CDLL(LIB_PATH)
+        h = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)      # AttributeError => symbol missing: fail loudly
             fn.restype = res

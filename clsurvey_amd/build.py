@@ -41,5 +41,21 @@ def build(force=False, verbose=True):
     return OUT
 
 
+def build_variant(name, src, defines, verbose=True):
+    """Experimental variant: recompile ONE source with extra -D flags and link libclhip_<name>.so.
+    Selected at run time with CLHIP_LIB=<path> (tools/ only; the product always loads libclhip.so)."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    build(verbose=verbose)
+    o = os.path.join(CSRC, src.replace(".hip", ".%s.o" % name))
+    cmd = [hipcc] + FLAGS + ["-D" + d for d in defines] + ["-c", os.path.join(CSRC, src), "-o", o]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    objs = [os.path.join(CSRC, x.replace(".hip", ".o")) if x != src else o for x in SOURCES]
+    out = os.path.join(HERE, "libclhip_%s.so" % name)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    return out
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)

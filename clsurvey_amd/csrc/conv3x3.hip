@@ -36,8 +36,11 @@ struct Geo {
 
 // MODE 0: forward (wt used as is, bias+relu epilogue)
 // MODE 1: backward-data (in = dy with Kw channels, out = dx with Cw channels, taps flipped)
+#ifndef CLHIP_CONV_MIN_WAVES
+#define CLHIP_CONV_MIN_WAVES 1
+#endif
 template <int TW, int TH, int NB, int CK, int MODE>
-__global__ __launch_bounds__(256) void conv3x3_mfma_kernel(
+__global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel(
     const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
     const float* __restrict__ mask_src, float* __restrict__ out,
     int N, int Cin, int Cout, int H, int W, int Kw, int Cw, int relu,

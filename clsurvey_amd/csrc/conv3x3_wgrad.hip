@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    float bsum = 0.f;
+    double bsum = 0.0;      // bias sums cancel heavily: accumulate in f64 (VALU has slack)
 
     const float* a_ptr = dys + (wk * 32 + li) * G::LDP + kk;
     const float* b_ptr = xs + (wc * 32 + li) * G::PLANEP + kk;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(
             const int q0 = 2 * pp;
             const int th = q0 / TW, tw = q0 - (q0 / TW) * TW;
             float a = a_ptr[q0];
-            bsum += a;
+            bsum += (double)a;
 #pragma unroll
             for (int rs = 0; rs < 9; ++rs) {
                 const int r = rs / 3, s = rs - 3 * (rs / 3);
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(
     if (ct == 0 && wc == 0) {
         bsum += __shfl_xor(bsum, 32, 64);
         int k = k0 + wk * 32 + li;
-        if (kk == 0 && k < K) slab[(size_t)9 * K * C + k] = bsum;
+        if (kk == 0 && k < K) slab[(size_t)9 * K * C + k] = (float)bsum;
     }
 }
 
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_smallc_kernel(
     floatx16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    float bsum = 0.f;
+    double bsum = 0.0;      // bias sums cancel heavily: accumulate in f64 (VALU has slack)
 
     // column li -> (c, r, s); columns >= C*9 read a valid dummy address, never stored
     const int ncol = C * 9;
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_smallc_kernel(
             // half offset is whole rows
             const int ql = 2 * pp;
             float a = a_ptr[ql];
-            bsum += a;
+            bsum += (double)a;
             const int th = ql / TW, tw = ql - (ql / TW) * TW;
             float b = b_ptr[(th + wh * (32 / TW)) * G::TWP + tw];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_smallc_kernel(
     if (wh == 1) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[(wk * 16 + r) * 64 + lane] = acc[r];
-        if (kk == 0) red[2048 + wk * 32 + li] = bsum;
+        if (kk == 0) red[2048 + wk * 32 + li] = (float)bsum;
     }
     __syncthreads();
     if (wh == 0) {
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_smallc_kernel(
             }
         }
         int k = k0 + wk * 32 + li;
-        if (kk == 0 && k < K) slab[(size_t)9 * K * C + k] = bsum + red[2048 + wk * 32 + li];
+        if (kk == 0 && k < K) slab[(size_t)9 * K * C + k] = (float)(bsum + (double)red[2048 + wk * 32 + li]);
     }
 }
 
@@ -298,10 +298,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_groups_kernel(const float* _
     if (e >= total) return;
     const int g = blockIdx.y;
     const int s0 = g * group, s1 = min(splits, s0 + group);
-    float s = 0.f;
+    double s = 0.0;
 #pragma unroll 8
-    for (int sp = s0; sp < s1; ++sp) s += part[(size_t)sp * total + e];
-    tmp[(size_t)g * total + e] = s;
+    for (int sp = s0; sp < s1; ++sp) s += (double)part[(size_t)sp * total + e];
+    tmp[(size_t)g * total + e] = (float)s;
 }
 
 // Level 2: dw[k][c][rs] = sum_g tmp[g][rs][k][c] ; db[k] = sum_g tmp[g][9KC + k].
@@ -310,14 +310,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_final_kernel(const float* __
     const size_t kc = (size_t)K * C, nw = 9 * kc, total = nw + K;
     size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
-    float s = 0.f;
+    double s = 0.0;
 #pragma unroll 8
-    for (int g = 0; g < groups; ++g) s += tmp[(size_t)g * total + e];
+    for (int g = 0; g < groups; ++g) s += (double)tmp[(size_t)g * total + e];
     if (e < nw) {
         size_t rs = e / kc, rem = e - rs * kc;     // rem = k*C + c
-        dw[rem * 9 + rs] = s;
+        dw[rem * 9 + rs] = (float)s;
     } else if (db) {
-        db[e - nw] = s;
+        db[e - nw] = (float)s;
     }
 }
 

@@ -171,7 +171,7 @@ int clhip_net_backward(void* handle, const float* params, float* grads, const fl
             xin = acts + ((P.type == 0 && P.pool) ? P.pool_off : P.act_off);
         }
         if (L.type == 1) {
-            rc = clhip_fc_bwd_weight(xin, gin, grads + L.w_off, grads + L.b_off, N, L.cin, L.cout, stream);
+            rc = clhip_fc_bwd_weight(xin, gin, grads + L.w_off, grads + L.b_off, N, L.cin, L.cout, scratch, p->scratch_bytes, stream);
             if (rc) return rc;
             if (i > 0) {
                 float* gout = g[flip]; flip ^= 1;

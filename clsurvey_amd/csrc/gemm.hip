@@ -8,7 +8,7 @@
 
 namespace {
 
-constexpr int TM = 64, TN = 64, BK = 16, LD = 65;
+constexpr int TM = 64, TN = 64, BK = 32, LD = 65;
 
 // AK: A is contiguous along k (sak == 1); BKc: B is contiguous along k (sbk == 1)
 template <bool AK, bool BKc>
@@ -31,27 +31,49 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-        __syncthreads();
+    // register-staged software pipeline: chunk t+1 is in flight while chunk t feeds the MFMAs
+    constexpr int A_IT = (TM * BK) / 256, B_IT = (TN * BK) / 256;
+    float ar[A_IT], br[B_IT];
+    auto load_chunk = [&](int k0) {
 #pragma unroll
-        for (int j = 0; j < (TM * BK) / 256; ++j) {
+        for (int j = 0; j < A_IT; ++j) {
             int e = tid + 256 * j;
             int ml, kl;
             if (AK) { ml = e / BK; kl = e - ml * BK; } else { kl = e / TM; ml = e - kl * TM; }
             int m = m0 + ml, k = k0 + kl;
-            float v = (m < M && k < k_end) ? a[(long)m * sam + (long)k * sak] : 0.f;
-            as[kl * LD + ml] = v;
+            ar[j] = (m < M && k < k_end) ? a[(long)m * sam + (long)k * sak] : 0.f;
         }
 #pragma unroll
-        for (int j = 0; j < (TN * BK) / 256; ++j) {
+        for (int j = 0; j < B_IT; ++j) {
             int e = tid + 256 * j;
             int nl, kl;
             if (BKc) { nl = e / BK; kl = e - nl * BK; } else { kl = e / TN; nl = e - kl * TN; }
             int n = n0 + nl, k = k0 + kl;
-            float v = (n < N && k < k_end) ? b[(long)k * sbk + (long)n * sbn] : 0.f;
-            bs[kl * LD + nl] = v;
+            br[j] = (n < N && k < k_end) ? b[(long)k * sbk + (long)n * sbn] : 0.f;
         }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int j = 0; j < A_IT; ++j) {
+            int e = tid + 256 * j;
+            int ml, kl;
+            if (AK) { ml = e / BK; kl = e - ml * BK; } else { kl = e / TM; ml = e - kl * TM; }
+            as[kl * LD + ml] = ar[j];
+        }
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j) {
+            int e = tid + 256 * j;
+            int nl, kl;
+            if (BKc) { nl = e / BK; kl = e - nl * BK; } else { kl = e / TN; nl = e - kl * TN; }
+            bs[kl * LD + nl] = br[j];
+        }
+    };
+    if (k_begin < k_end) load_chunk(k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
         __syncthreads();
+        store_chunk();
+        __syncthreads();
+        if (k0 + BK < k_end) load_chunk(k0 + BK);
 #pragma unroll
         for (int k2 = 0; k2 < BK; k2 += 2) {
             float av = as[(k2 + kk) * LD + wm * 32 + li];
@@ -93,19 +115,26 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
     }
 }
 
-// db[o] = sum_m dy[m][o]  (fixed order)
+// db[o] = sum_m dy[m][o]: 64 columns x 4 row-groups per block; each thread sums its rows in order
+// (double accumulator), the 4 groups are combined in fixed order through LDS.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dy, float* __restrict__ db, int M, int O) {
-    int o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= O) return;
-    float s = 0.f;
-    for (int m = 0; m < M; ++m) s += dy[(size_t)m * O + o];
-    db[o] = s;
+    __shared__ double part[4][64];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int o = blockIdx.x * 64 + c;
+    const int per = (M + 3) / 4;
+    const int m0 = g * per, m1 = min(M, m0 + per);
+    double s = 0.0;
+    if (o < O)
+        for (int m = m0; m < m1; ++m) s += (double)dy[(size_t)m * O + o];
+    part[g][c] = s;
+    __syncthreads();
+    if (g == 0 && o < O) db[o] = (float)(((part[0][c] + part[1][c]) + part[2][c]) + part[3][c]);
 }
 
 int choose_splits(int M, int N, int K) {
     int tiles = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
     int s = 512 / tiles;
-    int max_by_k = K / 128;          // keep >= 128 of K per split
+    int max_by_k = K / 64;           // keep >= 64 of K per split
     if (s > max_by_k) s = max_by_k;
     if (s > 32) s = 32;
     if (s < 1) s = 1;
@@ -141,7 +170,9 @@ size_t clhip_fc_ws(int M, int I, int O) {
     if (M <= 0 || I <= 0 || O <= 0) return 0;
     size_t a = (size_t)M * O * choose_splits(M, O, I);   // forward
     size_t b = (size_t)M * I * choose_splits(M, I, O);   // backward-data
-    return (a > b ? a : b) * sizeof(float);
+    size_t c = (size_t)O * I * choose_splits(O, I, M);   // backward-weight
+    size_t m = a > b ? a : b;
+    return (m > c ? m : c) * sizeof(float);
 }
 
 int clhip_fc_fwd(const float* x, const float* w, const float* b, float* y, int M, int I, int O, int relu,
@@ -158,14 +189,15 @@ int clhip_fc_bwd_data(const float* dy, const float* w, const float* relu_src, fl
     return gemm_launch<true, false>(dy, w, dx, M, I, O, O, 1, I, 1, nullptr, relu_src, 0, ws, ws_bytes, as_stream(stream));
 }
 
-int clhip_fc_bwd_weight(const float* x, const float* dy, float* dw, float* db, int M, int I, int O, void* stream) {
+int clhip_fc_bwd_weight(const float* x, const float* dy, float* dw, float* db, int M, int I, int O,
+                        void* ws, size_t ws_bytes, void* stream) {
     if (!x || !dy || !dw || M <= 0 || I <= 0 || O <= 0) return CLHIP_EINVAL;
     hipStream_t s = as_stream(stream);
     // C[O][I]: A(m = o, k = batch) = dy[k][m] (m contiguous), B(k = batch, n = i) = x[k][n] (n contiguous)
-    int rc = gemm_launch<false, false>(dy, x, dw, O, I, M, 1, O, I, 1, nullptr, nullptr, 0, nullptr, 0, s);
+    int rc = gemm_launch<false, false>(dy, x, dw, O, I, M, 1, O, I, 1, nullptr, nullptr, 0, ws, ws_bytes, s);
     if (rc) return rc;
     if (db) {
-        hipLaunchKernelGGL(colsum_kernel, dim3((O + 255) / 256), dim3(256), 0, s, dy, db, M, O);
+        hipLaunchKernelGGL(colsum_kernel, dim3((O + 63) / 64), dim3(256), 0, s, dy, db, M, O);
         CLHIP_LAUNCH_CHECK();
     }
     return 0;

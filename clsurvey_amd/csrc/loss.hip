@@ -17,7 +17,10 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// One wave per row, rows strided over the 16 waves of the single block.
+// One wave per row, rows strided over the 16 waves of the single block.  The tensor is tiny, so
+// the kernel is pure latency: rows are fetched RB at a time per wave (all loads in flight
+// together) before any arithmetic, instead of one dependent round trip per row.
+template <int RB>
 __global__ __launch_bounds__(LOSS_BLOCK) void softmax_ce_kernel(
     const float* __restrict__ logits, const int64_t* __restrict__ labels, int N, int C, int reduction,
     float* __restrict__ dlogits, float* __restrict__ loss_out, double* __restrict__ stats) {
@@ -27,31 +30,57 @@ __global__ __launch_bounds__(LOSS_BLOCK) void softmax_ce_kernel(
     const float scale = reduction == 0 ? 1.f / (float)N : 1.f;
     float wl = 0.f;   // this wave's loss sum (rows in increasing order)
     int wc = 0;
-    for (int row = wave; row < N; row += 16) {
-        const float* z = logits + (size_t)row * C;
-        const int y = (int)labels[row];
-        float m = -INFINITY;
-        int am = 0x7fffffff;
-        for (int c = lane; c < C; c += 64) {
-            float v = z[c];
-            if (v > m) { m = v; am = c; }
-        }
-        float gm = wave_max(m);
-        // first index attaining the max (torch.max tie rule: lowest index)
-        int cand = (m == gm) ? am : 0x7fffffff;
+    const bool narrow = C <= 64;
+    for (int row0 = wave; row0 < N; row0 += 16 * RB) {
+        float zr[RB];
+        int yr[RB];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
-        float se = 0.f;
-        for (int c = lane; c < C; c += 64) se += expf(z[c] - gm);
-        se = wave_sum(se);
-        const float lse = logf(se);
-        for (int c = lane; c < C; c += 64) {
-            float p = expf(z[c] - gm - lse);
-            dlogits[(size_t)row * C + c] = (p - (c == y ? 1.f : 0.f)) * scale;
+        for (int b = 0; b < RB; ++b) {
+            int row = row0 + 16 * b;
+            zr[b] = (narrow && row < N && lane < C) ? logits[(size_t)row * C + lane] : -INFINITY;
+            yr[b] = (row < N) ? (int)labels[row] : 0;
         }
-        float zy = z[y];
-        wl += -(zy - gm - lse);
-        wc += (cand == y) ? 1 : 0;
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+            int row = row0 + 16 * b;
+            if (row >= N) break;
+            const float* z = logits + (size_t)row * C;
+            const int y = yr[b];
+            float m = -INFINITY;
+            int am = 0x7fffffff;
+            if (narrow) {
+                m = zr[b];
+                am = lane < C ? lane : 0x7fffffff;
+            } else {
+                for (int c = lane; c < C; c += 64) {
+                    float v = z[c];
+                    if (v > m) { m = v; am = c; }
+                }
+            }
+            float gm = wave_max(m);
+            // first index attaining the max (torch.max tie rule: lowest index)
+            int cand = (m == gm) ? am : 0x7fffffff;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+            float se = 0.f, zy;
+            if (narrow) {
+                float ex = lane < C ? expf(zr[b] - gm) : 0.f;
+                se = wave_sum(ex);
+                const float lse = logf(se);
+                if (lane < C) dlogits[(size_t)row * C + lane] = (expf(zr[b] - gm - lse) - (lane == y ? 1.f : 0.f)) * scale;
+                zy = __shfl(zr[b], y, 64);
+                wl += -(zy - gm - lse);
+            } else {
+                for (int c = lane; c < C; c += 64) se += expf(z[c] - gm);
+                se = wave_sum(se);
+                const float lse = logf(se);
+                for (int c = lane; c < C; c += 64)
+                    dlogits[(size_t)row * C + c] = (expf(z[c] - gm - lse) - (c == y ? 1.f : 0.f)) * scale;
+                zy = z[y];
+                wl += -(zy - gm - lse);
+            }
+            wc += (cand == y) ? 1 : 0;
+        }
     }
     if (lane == 0) { s_loss[wave] = wl; s_corr[wave] = wc; }
     __syncthreads();
@@ -91,7 +120,7 @@ int clhip_softmax_ce(const float* logits, const int64_t* labels_i64, int N, int 
                      float* dlogits, float* loss_out, double* stats, void* stream) {
     if (!logits || !labels_i64 || !dlogits || !loss_out || N <= 0 || C <= 0) return CLHIP_EINVAL;
     if (reduction != 0 && reduction != 1) return CLHIP_EINVAL;
-    hipLaunchKernelGGL(softmax_ce_kernel, dim3(1), dim3(LOSS_BLOCK), 0, as_stream(stream), logits, labels_i64, N, C,
+    hipLaunchKernelGGL(softmax_ce_kernel<16>, dim3(1), dim3(LOSS_BLOCK), 0, as_stream(stream), logits, labels_i64, N, C,
                        reduction, dlogits, loss_out, stats);
     CLHIP_LAUNCH_CHECK();
     return 0;

@@ -1,0 +1,248 @@
+"""Method plugin surface — mirror of src/methods/method.py (Method ABC :81-111, parse :35,
+set_hyperparams :238-274, classes EWC :663, SI :695, MAS :726, Finetune :994).
+
+Same class attributes (name, eval_name, category, extra_hyperparams_count, hyperparams) and hooks
+(grid_train, train, inference_eval, get_output, grid_poststep, compose_dataset) as the reference,
+so the framework drivers only talk to `manager.method.<hook>(args, manager, ...)`.
+"""
+import copy
+import os
+from abc import ABC, abstractmethod
+from collections import OrderedDict
+from enum import Enum, auto
+
+import torch
+
+from ..data import DeviceLoader, TensorTaskDataset
+from . import ewc as trainEWC
+from . import finetune as trainFT
+from . import mas as trainMAS
+from . import si as trainSI
+from . import train_common as tc
+
+
+class Category(Enum):
+    MODEL_BASED = auto()
+    DATA_BASED = auto()
+    MASK_BASED = auto()
+    BASELINE = auto()
+    REHEARSAL_BASED = auto()
+
+
+class Method(ABC):
+    @property
+    @abstractmethod
+    def name(self): pass
+
+    @property
+    @abstractmethod
+    def eval_name(self): pass
+
+    @property
+    @abstractmethod
+    def category(self): pass
+
+    @property
+    @abstractmethod
+    def extra_hyperparams_count(self): pass
+
+    @property
+    @abstractmethod
+    def hyperparams(self): pass
+
+    @abstractmethod
+    def get_output(self, images, args): pass
+
+    @staticmethod
+    @abstractmethod
+    def inference_eval(args, manager): pass
+
+
+def get_output_def(model, heads, images, current_head_idx, final_layer_idx):
+    """method.py:230-235: swap in the task head, eval-mode forward (HIP kernels via model.forward)."""
+    head = heads[current_head_idx]
+    model.classifier._modules[final_layer_idx] = head
+    model.eval()
+    with torch.no_grad():
+        return model(images)
+
+
+def set_hyperparams(method, hyperparams, static_params=False):
+    """'a,b;c,d' grammar of method.py:238-274.  (The reference crashes on a single value such as
+    '400' — SURVEY §8 gotcha 10; here a single value is accepted as that value.)"""
+    assert isinstance(hyperparams, str)
+
+    def leave_default(x):
+        return x == "def" or x == ""
+    vals = []
+    split_lists = [x.strip() for x in hyperparams.split(";") if len(x) > 0]
+    for split_list in split_lists:
+        sp = [float(x) for x in split_list.split(",") if not leave_default(x)]
+        sp = sp[0] if len(sp) == 1 else sp
+        if len(split_lists) == 1:
+            vals = sp if isinstance(sp, list) else [sp]
+        else:
+            vals.append(sp)
+    target = getattr(method, "static_hyperparams", None) if static_params else method.hyperparams
+    if target is None:
+        return
+    for idx, (key, _) in enumerate(list(target.items())):
+        if idx < len(vals) and not leave_default(vals[idx]):
+            target[key] = vals[idx]
+    method.init_hyperparams = copy.deepcopy(target)
+
+
+class ConcatTasks(TensorTaskDataset):
+    """ConcatDatasetDynamicLabels (data/imgfolder.py): labels of task j are offset by the class
+    counts of tasks < j."""
+
+    def __init__(self, dsets, classes_len):
+        xs, ys, off = [], [], 0
+        for d, n in zip(dsets, classes_len):
+            xs.append(d.x)
+            ys.append(d.y + off)
+            off += n
+        super().__init__(torch.cat(xs), torch.cat(ys), sum((list(d.classes) for d in dsets), []))
+
+
+class Finetune(Method):
+    name = "finetuning"
+    eval_name = name
+    category = Category.BASELINE
+    extra_hyperparams_count = 0
+    hyperparams = {}
+    grid_chkpt = True
+    start_scratch = True
+    no_framework = True     # intended path (SURVEY §8 gotcha 12)
+
+    def get_output(self, images, args):
+        return get_output_def(args.model, args.heads, images, args.current_head_idx, args.final_layer_idx)
+
+    @staticmethod
+    def grid_train(args, manager, lr):
+        dataset_path = manager.current_task_dataset_path
+        if not isinstance(dataset_path, list):
+            dataset_path = [dataset_path]
+        dset_dataloader, cumsum_dset_sizes, dset_classes = Finetune.compose_dataset(dataset_path, args.batch_size,
+                                                                                     getattr(args, "device", "cuda"))
+        return trainFT.fine_tune_SGD(dset_dataloader, cumsum_dset_sizes, dset_classes,
+                                     model_path=manager.previous_task_model_path, exp_dir=manager.gridsearch_exp_dir,
+                                     num_epochs=args.num_epochs, lr=lr, weight_decay=args.weight_decay,
+                                     enable_resume=True, save_models_mode=True, replace_last_classifier_layer=True,
+                                     freq=args.saving_freq, device=getattr(args, "device", "cuda"),
+                                     batch_size=args.batch_size)
+
+    @staticmethod
+    def grid_poststep(args, manager):
+        manager.previous_task_model_path = os.path.join(manager.best_exp_grid_node_dirname, "best_model.pth.tar")
+        exp_dir = os.path.join(manager.parent_exp_dir, "task_" + str(args.task_counter), "TASK_TRAINING")
+        if os.path.islink(exp_dir) or os.path.exists(exp_dir):
+            os.unlink(exp_dir)
+        os.symlink(os.path.relpath(manager.best_exp_grid_node_dirname, os.path.dirname(exp_dir)), exp_dir)
+
+    @staticmethod
+    def compose_dataset(dataset_path, batch_size, device="cuda"):
+        """method.py:1057-1079 with DeviceLoader in place of DataLoader(num_workers=4)."""
+        imgf = {x: [] for x in ["train", "val"]}
+        classes = {x: [] for x in ["train", "val"]}
+        sizes = {x: [] for x in ["train", "val"]}
+        for p in dataset_path:
+            w = torch.load(p, weights_only=False) if isinstance(p, str) else p
+            for mode in ["train", "val"]:
+                imgf[mode].append(w[mode])
+                classes[mode].append(w[mode].classes)
+                sizes[mode].append(len(w[mode]))
+        cumsum = {m: sum(sizes[m]) for m in sizes}
+        clen = {m: [len(c) for c in classes[m]] for m in classes}
+        loaders = {x: DeviceLoader(ConcatTasks(imgf[x], clen[x]) if len(imgf[x]) > 1 else imgf[x][0],
+                                   batch_size, True, device) for x in ["train", "val"]}
+        return loaders, cumsum, classes
+
+    @staticmethod
+    def inference_eval(args, manager):
+        """method.py:1081-1103."""
+        from ..framework import inference as test_network
+        model = tc.load_model(args.eval_model_path)
+        if isinstance(model, dict):
+            model = model["model"]
+        head_layer_idx = str(len(model.classifier._modules) - 1)
+        assert isinstance(model.classifier._modules[head_layer_idx], torch.nn.Linear), "NO VALID HEAD IDX"
+        target_heads = test_network.get_prev_heads(args.head_paths, head_layer_idx, getattr(args, "device", "cuda"))
+        assert len(target_heads) == 1
+        return test_network.test_model(manager.method, model, args.dset_path, 0, subset=args.test_set,
+                                       target_head=target_heads, batch_size=args.batch_size,
+                                       task_idx=args.eval_dset_idx, device=getattr(args, "device", "cuda"))
+
+
+class _Regularised(Method):
+    category = Category.MODEL_BASED
+    extra_hyperparams_count = 1
+
+    @staticmethod
+    def grid_train(args, manager, lr):
+        return Finetune.grid_train(args, manager, lr)
+
+    def get_output(self, images, args):
+        return get_output_def(args.model, args.heads, images, args.current_head_idx, args.final_layer_idx)
+
+    @staticmethod
+    def inference_eval(args, manager):
+        return Finetune.inference_eval(args, manager)
+
+
+class EWC(_Regularised):
+    name = "EWC"
+    eval_name = name
+    hyperparams = OrderedDict({"lambda": 400})
+
+    def train(self, args, manager, hyperparams):
+        return trainEWC.fine_tune_EWC_acuumelation(
+            dataset_path=manager.current_task_dataset_path, previous_task_model_path=manager.previous_task_model_path,
+            exp_dir=manager.heuristic_exp_dir, data_dir=args.data_dir, reg_sets=manager.reg_sets,
+            reg_lambda=hyperparams["lambda"], batch_size=args.batch_size, num_epochs=args.num_epochs, lr=args.lr,
+            weight_decay=args.weight_decay, saving_freq=args.saving_freq, device=getattr(args, "device", "cuda"))
+
+
+class MAS(_Regularised):
+    name = "MAS"
+    eval_name = name
+    hyperparams = OrderedDict({"lambda": 3})
+
+    def train(self, args, manager, hyperparams):
+        return trainMAS.fine_tune_objective_based_acuumelation(
+            dataset_path=manager.current_task_dataset_path, previous_task_model_path=manager.previous_task_model_path,
+            init_model_path=args.init_model_path, exp_dir=manager.heuristic_exp_dir, data_dir=args.data_dir,
+            reg_sets=manager.reg_sets, reg_lambda=hyperparams["lambda"], batch_size=args.batch_size,
+            weight_decay=args.weight_decay, num_epochs=args.num_epochs, lr=args.lr, norm="L2", b1=False,
+            saving_freq=args.saving_freq, device=getattr(args, "device", "cuda"))
+
+
+class SI(_Regularised):
+    name = "SI"
+    eval_name = name
+    hyperparams = OrderedDict({"lambda": 400})
+
+    def train(self, args, manager, hyperparams):
+        return trainSI.fine_tune_elastic(
+            dataset_path=manager.current_task_dataset_path, num_epochs=args.num_epochs,
+            exp_dir=manager.heuristic_exp_dir, model_path=manager.previous_task_model_path,
+            reg_lambda=hyperparams["lambda"], batch_size=args.batch_size, lr=args.lr, init_freeze=0,
+            weight_decay=args.weight_decay, saving_freq=args.saving_freq, device=getattr(args, "device", "cuda"))
+
+
+_REGISTRY = {c.name: c for c in (EWC, MAS, SI, Finetune)}
+
+
+def parse(method_name):
+    """method.py:35-78 for the methods on the hot path (GEM / PackNet / HAT register themselves when
+    their modules are imported)."""
+    if method_name in _REGISTRY:
+        m = _REGISTRY[method_name]()
+        m.hyperparams = copy.deepcopy(type(m).hyperparams)
+        return m
+    raise NotImplementedError("Method not yet parseable: %r" % method_name)
+
+
+def register(cls):
+    _REGISTRY[cls.name] = cls
+    return cls

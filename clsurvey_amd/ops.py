@@ -125,9 +125,11 @@ def fc_bwd_weight(x, dy, need_bias=True):
     _chk(x, dy)
     M, I = x.shape
     O = dy.shape[1]
+    L = _lib.lib()
+    ws = workspace(L.clhip_fc_ws(M, I, O), x.device, "fc")
     dw = torch.empty((O, I), dtype=torch.float32, device=x.device)
     db = torch.empty((O,), dtype=torch.float32, device=x.device) if need_bias else None
-    check(_lib.lib().clhip_fc_bwd_weight(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), M, I, O, _stream()),
+    check(L.clhip_fc_bwd_weight(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), M, I, O, _ptr(ws), ws.numel(), _stream()),
           "clhip_fc_bwd_weight")
     return dw, db
 

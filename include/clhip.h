@@ -70,7 +70,7 @@ int clhip_fc_bwd_data(const float* dy, const float* w, const float* relu_src, fl
                       int M, int I, int O, void* ws, size_t ws_bytes, void* stream);
 /* dw[O][I] = dy^T . x ; db[O] = column sums of dy (db may be NULL). */
 int clhip_fc_bwd_weight(const float* x, const float* dy, float* dw, float* db,
-                        int M, int I, int O, void* stream);
+                        int M, int I, int O, void* ws, size_t ws_bytes, void* stream);
 /* y = relu(x) backward helper for non-fused callers: dx = dy * (y > 0). */
 int clhip_relu_bwd(const float* dy, const float* y, float* dx, size_t n, void* stream);
 
