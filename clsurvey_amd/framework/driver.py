@@ -1,0 +1,478 @@
+"""Continual Hyperparameter Framework driver — the build's own counterpart of
+src/framework/{main,framework_train,lr_grid_train,eval}.py (the reference cannot travel to the GPU
+box).  Pure control flow; every tensor op happens behind `manager.method.<hook>`.
+
+Reproduced semantics (file:line of the reference):
+  * CLI flags and defaults                                   main.py:17-74
+  * task loop, boot LR grid on task 1, Manager fields        main.py:158-220
+  * SI first-task model bootstrap path                       main.py:226-241, utils.py:146
+  * phase 1: per-LR x finetune_iterations grid, seeding by iteration index, mean-over-iterations
+    best-LR rule, StoragePolicy, grid checkpoint             lr_grid_train.py:9-176
+  * phase 2: threshold A_ft*(1-p), decay, max attempts, hyperparams.pth.tar + SUCCESS.FLAG
+                                                             framework_train.py:76-216
+  * eval: seq_res / seq_forgetting dict layout and file name  eval.py:146-247, utils.py:200-230
+The phase-1 grid can be sharded over ranks (clsurvey_amd.framework.shard); phase 2 stays sequential.
+"""
+import argparse
+import copy
+import operator
+import os
+import random
+import shutil
+import sys
+import time
+import traceback
+
+import numpy as np
+import torch
+
+from ..methods import method as methods
+from ..methods import train_common as tc
+
+RUNMODES = ["first_task_basemodel_dump", "timing_mode", "debug"]
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="Continual Hyperparameter Framework on MI355X")
+    p.add_argument("model_name", type=str)
+    p.add_argument("--method_name", type=str, default=None)
+    p.add_argument("--ds_name", type=str, default=None)
+    p.add_argument("--gridsearch_name", type=str, default="demo")
+    p.add_argument("--exp_name", type=str, default=None)
+    p.add_argument("--starting_task_count", type=int, default=1)
+    p.add_argument("--max_task_count", type=int, default=None)
+    p.add_argument("--finetune_iterations", type=int, default=1)
+    p.add_argument("--saving_freq", type=int, default=20)
+    p.add_argument("--save_models_FT_heuristic", action="store_true")
+    p.add_argument("--runmode", default=None, choices=RUNMODES)
+    p.add_argument("--cleanup_exp", action="store_true")
+    p.add_argument("--drop_margin", type=float, default=0.2)
+    p.add_argument("--decaying_factor", type=float, default=0.5)
+    p.add_argument("--max_attempts_per_task", type=int, default=10)
+    p.add_argument("--hyperparams", type=str, default="")
+    p.add_argument("--static_hyperparams", type=str, default="")
+    p.add_argument("--lr_grid", type=str, default="1e-2,5e-3,1e-3,5e-4,1e-4")
+    p.add_argument("--boot_lr_grid", type=str, default=None)
+    p.add_argument("--num_epochs", type=int, default=70)
+    p.add_argument("--weight_decay", type=float, default=0)
+    p.add_argument("--batch_size", type=int, default=200)
+    p.add_argument("--test", action="store_true")
+    p.add_argument("--test_max_task_count", type=int, default=None)
+    p.add_argument("--test_starting_task_count", type=int, default=1)
+    p.add_argument("--test_overwrite_mode", action="store_true")
+    p.add_argument("--test_set", choices=["test", "val", "train"], type=str, default="test")
+    # build-specific
+    p.add_argument("--results_root", type=str, default="./exp_results")
+    p.add_argument("--device", type=str, default="cuda")
+    return p
+
+
+def set_random(seed=7):
+    """utilities/utils.py:52-58."""
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+    random.seed(seed)
+    np.random.seed(seed)
+
+
+def float_to_scientific_str(v):
+    return "{:.1e}".format(v)
+
+
+class StoragePolicy(object):
+    """lr_grid_train.py:162-176."""
+
+    def __init__(self, mode):
+        assert mode in ("all", "only_keep_best", "keep_none")
+        self.only_keep_best = mode == "only_keep_best"
+        self.keep_none = mode == "keep_none"
+        self.keep_all = mode == "all"
+
+
+class Manager(object):
+    """main.py:181-220."""
+    token_name = "SUCCESS.FLAG"
+
+    def __init__(self, dataset, method, previous_task_model_path, parent_exp_dir, base_model):
+        self.dataset = dataset
+        self.method = method
+        self.previous_task_model_path = previous_task_model_path
+        self.parent_exp_dir = parent_exp_dir
+        self.base_model = base_model
+        self.current_task_dataset_path = None
+        self.best_finetuned_model_path = None
+        self.autoencoder_model_path = None
+        self.reg_sets = []
+
+    def set_dataset(self, args, rnd_transform=False):
+        if hasattr(self.method, "grid_datafetch"):
+            self.current_task_dataset_path = self.method.grid_datafetch(args, self.dataset)
+        else:
+            self.current_task_dataset_path = self.dataset.get_task_dataset_path(task_name=args.task_name,
+                                                                                rnd_transform=rnd_transform)
+
+    def save_hyperparams(self, output_dir, hyperparams):
+        os.makedirs(output_dir, exist_ok=True)
+        clean = {k: v for k, v in hyperparams.items() if k not in ("args", "manager")}
+        torch.save(clean, os.path.join(output_dir, "hyperparams.pth.tar"))
+
+    def get_success_token_path(self, exp_dir):
+        return os.path.join(exp_dir, self.token_name)
+
+    def create_success_token(self, exp_dir):
+        if not os.path.exists(self.get_success_token_path(exp_dir)):
+            torch.save("", self.get_success_token_path(exp_dir))
+
+
+class BaseModel(object):
+    """models/net.py model wrapper: .name, .path (pickled untrained model), .last_layer_idx."""
+
+    def __init__(self, root, name, input_size, num_classes):
+        from .. import models
+        self.name = name
+        self.path = os.path.join(root, name + ".pth.tar")
+        if not os.path.exists(self.path):
+            os.makedirs(root, exist_ok=True)
+            m = models.parse_model_name(name, input_size, num_classes)
+            torch.save(m, self.path)
+        m = torch.load(self.path, weights_only=False)
+        self.last_layer_idx = len(m.classifier._modules) - 1
+
+
+# ------------------------------------------------------------------ phase 1
+def lr_grid_single_task(args, manager, save_models_mode="keep_none", train_node=None):
+    """lr_grid_train.py:9-160. `train_node(lr, iteration) -> acc` lets the shard module run grid
+    nodes on other ranks; default runs them here."""
+    manager.store_policy = StoragePolicy(save_models_mode)
+    args.task_name = manager.dataset.get_taskname(args.task_counter)
+    manager.ft_parent_exp_dir = os.path.join(manager.parent_exp_dir, "task_" + str(args.task_counter),
+                                             "FT_LR_GRIDSEARCH")
+    os.makedirs(manager.ft_parent_exp_dir, exist_ok=True)
+    processed_lrs = {}
+    grid_checkpoint_file = os.path.join(manager.ft_parent_exp_dir, "grid_checkpoint.pth")
+    if os.path.exists(grid_checkpoint_file):
+        processed_lrs = torch.load(grid_checkpoint_file, weights_only=False)["processed_lrs"]
+    args.presteps_elapsed_time = 0
+    if hasattr(manager.method, "grid_prestep"):
+        manager.method.grid_prestep(args, manager)
+
+    def node_dir(lr, it):
+        d = "lr=" + str(float_to_scientific_str(lr))
+        if args.finetune_iterations > 1:
+            d += "_it" + str(it)
+        return os.path.join(manager.ft_parent_exp_dir, d)
+
+    if train_node is None:
+        def train_node(lr, it):
+            set_random(it)                                       # lr_grid_train.py:73,77
+            manager.gridsearch_exp_dir = node_dir(lr, it)
+            os.makedirs(manager.gridsearch_exp_dir, exist_ok=True)
+            _, acc = manager.method.grid_train(args, manager, lr)
+            return acc
+
+    best_acc, best_lr = 0, None
+    manager.best_exp_grid_node_dirname = None
+    best_iteration_batch_dirs = []
+    manager.grid_trace = []
+    for lr in args.lrs:
+        accum_acc, best_iteration_dir, best_iteration_acc = 0, None, 0
+        iteration_batch_dirs = []
+        if lr not in processed_lrs:
+            processed_lrs[lr] = {"acc": []}
+        for it in range(args.finetune_iterations):
+            manager.gridsearch_exp_dir = node_dir(lr, it)
+            iteration_batch_dirs.append(manager.gridsearch_exp_dir)
+            if it < len(processed_lrs[lr]["acc"]):
+                acc = processed_lrs[lr]["acc"][it]
+                set_random(it)
+            else:
+                acc = train_node(lr, it)
+                processed_lrs[lr]["acc"].append(acc)
+            manager.grid_trace.append((lr, it, acc))
+            if acc > best_iteration_acc:
+                best_iteration_acc, best_iteration_dir = acc, node_dir(lr, it)
+            accum_acc += acc
+            torch.save({"processed_lrs": processed_lrs}, grid_checkpoint_file)
+        avg_acc = accum_acc / args.finetune_iterations
+        if avg_acc > best_acc:
+            best_lr, best_acc = lr, avg_acc
+            manager.best_exp_grid_node_dirname = best_iteration_dir
+            if manager.store_policy.only_keep_best:
+                for d in best_iteration_batch_dirs:
+                    shutil.rmtree(d, ignore_errors=True)
+            best_iteration_batch_dirs = iteration_batch_dirs
+        elif manager.store_policy.only_keep_best:
+            for d in iteration_batch_dirs:
+                shutil.rmtree(d, ignore_errors=True)
+        if manager.store_policy.keep_none:
+            for d in iteration_batch_dirs:
+                shutil.rmtree(d, ignore_errors=True)
+    print("FINETUNE DONE: best_lr={}, best_acc={}".format(best_lr, best_acc))
+    if hasattr(manager.method, "grid_poststep"):
+        manager.method.grid_poststep(args, manager)
+    return best_lr, best_acc
+
+
+# ------------------------------------------------------------------ phase 2
+class HyperparameterFramework(object):
+    """framework_train.py:14-216."""
+
+    def __init__(self, method):
+        self.hyperparams = method.hyperparams
+        self.hyperparams_backup = copy.deepcopy(self.hyperparams)
+        self.hyperparam_idx = 0
+        self.attempts = 0
+        self.trace = []      # (hyperparams, acc, threshold) per attempt — parity observable
+
+    def _get_state(self):
+        return {"hyperparams": self.hyperparams, "hyperparams_backup": self.hyperparams_backup,
+                "hyperparam_idx": self.hyperparam_idx, "attempts": self.attempts}
+
+    def _restore_state(self, state):
+        for hkey in self.hyperparams.keys():
+            self.hyperparams[hkey] = state["hyperparams"][hkey]
+            self.hyperparams_backup[hkey] = state["hyperparams_backup"][hkey]
+        self.hyperparam_idx = state["hyperparam_idx"]
+        self.attempts = state["attempts"]
+
+    @staticmethod
+    def maximalPlasticitySearch(args, manager, train_node=None):
+        t0 = time.time()
+        lr, acc = lr_grid_single_task(args, manager, save_models_mode=args.save_models_mode, train_node=train_node)
+        args.phase1_elapsed_time = time.time() - t0
+        return lr, acc
+
+    def load_chkpt(self, manager):
+        os.makedirs(manager.heuristic_exp_dir, exist_ok=True)
+        path = os.path.join(manager.heuristic_exp_dir, "hyperparams.pth.tar")
+        try:
+            chkpt = torch.load(path, weights_only=False)
+        except Exception:
+            return False
+        self._restore_state(chkpt["state"])
+        return True
+
+    def stabilityDecay(self, args, manager, finetune_lr, finetune_acc):
+        args.lr = finetune_lr
+        manager.heuristic_exp_dir = os.path.join(manager.parent_exp_dir, "task_" + str(args.task_counter),
+                                                 "TASK_TRAINING")
+        if hasattr(manager.method, "train_init"):
+            manager.method.train_init(args, manager)
+        if not self.load_chkpt(manager):
+            self.attempts = 0
+            self.hyperparams_backup = copy.deepcopy(self.hyperparams)
+        if os.path.exists(manager.get_success_token_path(manager.heuristic_exp_dir)):
+            manager.best_model_path = os.path.join(manager.heuristic_exp_dir, "best_model.pth.tar")
+            return
+        args.presteps_elapsed_time = 0
+        if hasattr(manager.method, "prestep"):
+            manager.method.prestep(args, manager)
+        max_attempts = args.max_attempts_per_task
+        converged = False
+        while not converged and self.attempts < max_attempts:
+            print(" => ATTEMPT {}/{}: Hyperparams {}".format(self.attempts, max_attempts - 1, self.hyperparams))
+            t0 = time.time()
+            try:
+                manager.method.hyperparams = self.hyperparams
+                model, task_lr_acc = manager.method.train(args, manager, self.hyperparams)
+            except Exception:
+                traceback.print_exc()
+                sys.exit(1)
+            threshold = finetune_acc * args.inv_drop_margin          # A_ft * (1 - p)
+            self.trace.append((copy.deepcopy(dict(self.hyperparams)), task_lr_acc, threshold))
+            if task_lr_acc >= threshold:
+                converged = True
+                args.convergence_iteration_elapsed_time = time.time() - t0
+            else:
+                self.hyperparamDecay(args, manager)
+                self.attempts += 1
+                if self.attempts < max_attempts:
+                    shutil.rmtree(manager.heuristic_exp_dir, ignore_errors=True)
+                else:
+                    converged = True
+            manager.save_hyperparams(manager.heuristic_exp_dir,
+                                     {"acc_threshold": threshold, "val_acc": task_lr_acc, "state": self._get_state()})
+        manager.best_model_path = os.path.join(manager.heuristic_exp_dir, "best_model.pth.tar")
+        manager.create_success_token(manager.heuristic_exp_dir)
+
+    def hyperparamDecay(self, args, manager):
+        """framework_train.py:168-216 (single hyperparam; round-robin then joint decay for several)."""
+        op = manager.method.decay_operator if hasattr(manager.method, "decay_operator") else operator.mul
+        if len(self.hyperparams) == 1:
+            hkey = list(self.hyperparams.keys())[0]
+            self.hyperparams[hkey] = op(self.hyperparams[hkey], args.decaying_factor)
+        elif self.hyperparam_idx == len(self.hyperparams):
+            self.hyperparam_idx = 0
+            for hkey, hval in self.hyperparams_backup.items():
+                self.hyperparams[hkey] = op(hval, args.decaying_factor)
+            self.hyperparams_backup = copy.deepcopy(self.hyperparams)
+        else:
+            hlist = list(self.hyperparams.items())
+            hkey = hlist[self.hyperparam_idx][0]
+            self.hyperparams[hkey] = op(self.hyperparams_backup[hkey], args.decaying_factor)
+            for i, (other, _) in enumerate(hlist):
+                if i != self.hyperparam_idx:
+                    self.hyperparams[other] = self.hyperparams_backup[other]
+            self.hyperparam_idx += 1
+
+
+def framework_single_task(args, manager, train_node=None):
+    """framework_train.py:219-292."""
+    if args.task_counter == 1 and not args.train_first_task and not args.wrap_first_task_model:
+        print("USING SI AS MODEL FOR FIRST TASK: ", manager.previous_task_model_path)
+        return None
+    skip_to_post = args.wrap_first_task_model and args.task_counter == 1
+    hf = HyperparameterFramework(manager.method)
+    if args.save_models_FT_heuristic:
+        args.save_models_mode = "all"
+    elif manager.method.name == "PackNet":
+        args.save_models_mode = "only_keep_best"
+    else:
+        args.save_models_mode = "keep_none"
+    args.phase1_elapsed_time = args.presteps_elapsed_time = 0
+    args.convergence_iteration_elapsed_time = args.postprocess_time = 0
+    if args.task_counter > 1:
+        prev = manager.dataset.get_taskname(args.task_counter - 1)
+        args.previous_task_dataset_path = manager.dataset.get_task_dataset_path(task_name=prev, rnd_transform=False)
+        manager.reg_sets = [args.previous_task_dataset_path]
+    args.classifier_heads_starting_idx = manager.base_model.last_layer_idx
+    if not skip_to_post:
+        ft_lr, ft_acc = hf.maximalPlasticitySearch(args, manager, train_node)
+        hf.stabilityDecay(args, manager, ft_lr, ft_acc)
+    if hasattr(manager.method, "poststep"):
+        manager.method.poststep(args, manager)
+    if hasattr(manager.method, "init_next_task"):
+        manager.method.init_next_task(manager)
+    else:
+        manager.previous_task_model_path = manager.best_model_path
+    return hf
+
+
+# ------------------------------------------------------------------ eval
+def get_perf_output_filename(method_name, dataset_index):
+    return "test_method_performances" + method_name + str(dataset_index) + ".pth"      # utils.py:225-230
+
+
+def eval_all_models_all_tasks(args, manager, ds_paths, model_paths):
+    """eval.py:146-247: model j >= i evaluated on task i with task i's head; forgetting = acc_i(i) - acc_i(j)."""
+    out = {}
+    os.makedirs(args.out_path, exist_ok=True)
+    for dataset_index in range(args.test_starting_task_count - 1, args.test_max_task_count):
+        if dataset_index >= len(ds_paths):
+            break
+        args.eval_dset_idx = dataset_index
+        seq_acc, seq_forgetting = {dataset_index: []}, {dataset_index: []}
+        args.dset_path = ds_paths[dataset_index]
+        args.head_paths = model_paths[dataset_index]
+        for trained_model_idx in range(dataset_index, len(ds_paths)):
+            args.trained_model_idx = trained_model_idx
+            args.eval_model_path = model_paths[trained_model_idx]
+            accuracy = manager.method.inference_eval(args, manager)
+            seq_acc[dataset_index].append(accuracy)
+            if trained_model_idx > dataset_index:
+                seq_forgetting[dataset_index].append(seq_acc[dataset_index][0] - accuracy)
+        perf = {manager.method.eval_name: {"seq_res": seq_acc, "seq_forgetting": seq_forgetting, "seq_head_acc": []}}
+        torch.save(perf, os.path.join(args.out_path, get_perf_output_filename(manager.method.eval_name, dataset_index)))
+        out[dataset_index] = perf[manager.method.eval_name]
+    return out
+
+
+# ------------------------------------------------------------------ main
+def get_exp_name(args, method):
+    """utils.py:130-143."""
+    parts = ["dm={}".format(args.drop_margin), "df={}".format(args.decaying_factor), "e={}".format(args.num_epochs),
+             "bs={}".format(args.batch_size)]
+    if args.weight_decay != 0:
+        parts.append("L2={}".format(args.weight_decay))
+    for k, v in method.hyperparams.items():
+        parts.append("{}={}".format(k, v))
+    for k, v in getattr(method, "static_hyperparams", {}).items():
+        parts.append("{}={}".format(k, v))
+    return "_".join(parts)
+
+
+def first_task_modelname(args):
+    return "vanilla" if args.weight_decay == 0 else "L2={}".format(args.weight_decay)   # models/net.py get_init_modelname
+
+
+def main(argv=None, method=None, dataset=None, train_node_factory=None):
+    args = build_parser().parse_args(argv)
+    set_random(7)                                                 # utils.init -> set_random()
+    if method is None:
+        method = methods.parse(args.method_name)
+    assert dataset is not None, "pass a dataset object (clsurvey_amd.framework.tasks)"
+    base_model = BaseModel(os.path.join(args.results_root, "models"), args.model_name, dataset.input_size,
+                           len(next(iter(dataset.classes_per_task.values()))))
+    parse_floats = lambda s: [float(x) for x in s.split(",") if x]   # noqa: E731
+    args.lr_grid = parse_floats(args.lr_grid)
+    args.boot_lr_grid = parse_floats(args.boot_lr_grid) if args.boot_lr_grid else args.lr_grid
+    args.data_dir = None
+    args.init_model_path = None
+    args.max_task_count = dataset.task_count if args.max_task_count is None else args.max_task_count
+    args.inv_drop_margin = 1 - args.drop_margin
+    args.first_task_modelname = first_task_modelname(args)
+    args.train_first_task = bool(getattr(method, "start_scratch", False))
+    args.wrap_first_task_model = bool(getattr(method, "wrap_first_task_model", False))
+    args.no_framework = bool(getattr(method, "no_framework", False))
+    for option in RUNMODES:
+        setattr(args, option, args.runmode == option)
+    if args.first_task_basemodel_dump:
+        assert method.name == "SI", "Define SI method to train first task common model."
+        args.train_first_task = True
+        args.starting_task_count = args.max_task_count = 1
+        args.gridsearch_name = "first_task_basemodel"
+        args.exp_name = args.first_task_modelname
+    elif args.debug:
+        args.finetune_iterations, args.num_epochs, args.saving_freq = 1, 1, 200
+        args.lr_grid = args.boot_lr_grid = [0.01]
+    if hasattr(method, "train_args_overwrite"):
+        method.train_args_overwrite(args)
+    methods.set_hyperparams(method, args.hyperparams)
+    methods.set_hyperparams(method, args.static_hyperparams, static_params=True)
+    if args.exp_name is None:
+        args.exp_name = get_exp_name(args, method)
+    tr_root = os.path.join(args.results_root, "train")
+    parent_exp_dir = os.path.join(tr_root, dataset.train_exp_results_dir, method.name, base_model.name, "gridsearch",
+                                  args.gridsearch_name, args.exp_name)
+    if args.cleanup_exp and os.path.isdir(parent_exp_dir):
+        shutil.rmtree(parent_exp_dir)
+    # main.py:226-241
+    if args.starting_task_count == 1:
+        si_path = os.path.join(tr_root, dataset.train_exp_results_dir, "SI", base_model.name, "gridsearch",
+                               "first_task_basemodel", args.first_task_modelname, "task_1", "TASK_TRAINING",
+                               "best_model.pth.tar")
+        prev = base_model.path if (args.train_first_task or args.first_task_basemodel_dump) else si_path
+    else:
+        prev = os.path.join(parent_exp_dir, "task_{}".format(args.starting_task_count - 1), "TASK_TRAINING",
+                            "best_model.pth.tar")
+    if not os.path.exists(prev) and not args.first_task_basemodel_dump:
+        raise Exception("NOT EXISTING previous_task_model_path = " + prev)
+    manager = Manager(dataset, method, prev, parent_exp_dir, base_model)
+    ds_paths, model_paths, frameworks = [], [], []
+    for task_counter in range(args.starting_task_count, args.max_task_count + 1):
+        args.task_counter = task_counter
+        args.task_name = dataset.get_taskname(task_counter)
+        args.lrs = args.boot_lr_grid if task_counter == 1 else args.lr_grid
+        manager.set_dataset(args)
+        train_node = train_node_factory(args, manager) if train_node_factory else None
+        try:
+            if args.no_framework:
+                lr_grid_single_task(args, manager, save_models_mode="all", train_node=train_node)
+            else:
+                frameworks.append(framework_single_task(args, manager, train_node))
+            ds_paths.append(manager.current_task_dataset_path)
+            model_paths.append(manager.previous_task_model_path)
+        except RuntimeError as e:
+            print("ERROR:", e)
+            traceback.print_exc()
+            break
+    results = None
+    if args.test:
+        args.test_max_task_count = dataset.task_count if args.test_max_task_count is None else args.test_max_task_count
+        exp = args.exp_name if args.test_set == "test" else "{}_{}".format(args.exp_name, args.test_set)
+        args.out_path = os.path.join(args.results_root, "test", "results", dataset.test_results_dir, method.eval_name,
+                                     base_model.name, args.gridsearch_name, exp)
+        results = eval_all_models_all_tasks(args, manager, ds_paths, model_paths)
+    return {"manager": manager, "frameworks": frameworks, "ds_paths": ds_paths, "model_paths": model_paths,
+            "results": results, "args": args}

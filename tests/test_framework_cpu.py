@@ -1,0 +1,117 @@
+"""CPU tests of the host logic: framework control flow (grid search, stability decay, eval dict
+layout) with a fake Method — no tensors, no GPU."""
+import copy
+import os
+from collections import OrderedDict
+
+import torch
+
+from clsurvey_amd.framework import driver
+
+
+class FakeDataset:
+    name = argname = test_results_dir = train_exp_results_dir = "fake"
+    task_count = 3
+    input_size = (32, 32)
+    classes_per_task = OrderedDict((str(i), ["a", "b"]) for i in range(1, 4))
+
+    def get_taskname(self, i):
+        return str(i)
+
+    def get_task_dataset_path(self, task_name=None, rnd_transform=False):
+        return "ds_" + str(task_name)
+
+
+class FakeMethod:
+    """acc of phase 1 depends on lr; phase 2 acc rises as lambda decays."""
+    name = eval_name = "EWC"
+    hyperparams = OrderedDict({"lambda": 400})
+    calls = []
+
+    def grid_train(self, args, manager, lr):
+        os.makedirs(manager.gridsearch_exp_dir, exist_ok=True)
+        return None, {1e-2: 0.5, 5e-3: 0.8, 1e-3: 0.6}.get(lr, 0.1)
+
+    def grid_poststep(self, args, manager):
+        pass
+
+    def train(self, args, manager, hyperparams):
+        FakeMethod.calls.append((args.task_counter, hyperparams["lambda"], args.lr))
+        os.makedirs(manager.heuristic_exp_dir, exist_ok=True)
+        torch.save({"lam": hyperparams["lambda"]}, os.path.join(manager.heuristic_exp_dir, "best_model.pth.tar"))
+        return None, 0.8 - hyperparams["lambda"] / 1000.0      # 0.4, 0.6, 0.7 ...
+
+    def inference_eval(self, args, manager):
+        return 90.0 - 10.0 * (args.trained_model_idx - args.eval_dset_idx)
+
+    def get_output(self, images, args):
+        raise NotImplementedError
+
+
+def test_two_phase_framework_and_eval(tmp_path):
+    FakeMethod.calls = []
+    m = FakeMethod()
+    m.hyperparams = copy.deepcopy(FakeMethod.hyperparams)
+    root = str(tmp_path)
+    # task 1 model comes from the SI bootstrap path (main.py:226-233): create the file it expects
+    si = os.path.join(root, "train", "fake", "SI", "small_VGG9_cl_128_128", "gridsearch", "first_task_basemodel",
+                      "vanilla", "task_1", "TASK_TRAINING")
+    os.makedirs(si)
+    torch.save({}, os.path.join(si, "best_model.pth.tar"))
+    out = driver.main(["small_VGG9_cl_128_128", "--method_name", "EWC", "--results_root", root, "--lr_grid",
+                       "1e-2,5e-3,1e-3", "--test", "--num_epochs", "1"], method=m, dataset=FakeDataset())
+    # task 1 skipped (SI model), tasks 2 and 3: best lr 5e-3 (acc .8) -> threshold .64
+    # lambda 400 -> .4 (<.64) decay 200 -> .6 (<.64) decay 100 -> .7 ok; task 3 starts from lambda 100
+    assert FakeMethod.calls == [(2, 400, 5e-3), (2, 200.0, 5e-3), (2, 100.0, 5e-3), (3, 100.0, 5e-3)]
+    hf2, hf3 = out["frameworks"][1], out["frameworks"][2]
+    assert [round(t[2], 6) for t in hf2.trace] == [0.64, 0.64, 0.64]
+    assert [t[0]["lambda"] for t in hf2.trace] == [400, 200.0, 100.0]
+    assert len(hf3.trace) == 1
+    tdir = os.path.join(out["manager"].parent_exp_dir, "task_2", "TASK_TRAINING")
+    assert os.path.exists(os.path.join(tdir, "SUCCESS.FLAG"))
+    st = torch.load(os.path.join(tdir, "hyperparams.pth.tar"), weights_only=False)
+    assert st["state"]["attempts"] == 2 and st["state"]["hyperparams"]["lambda"] == 100.0
+    res = out["results"]
+    assert res[0]["seq_res"][0] == [90.0, 80.0, 70.0] and res[0]["seq_forgetting"][0] == [10.0, 20.0]
+    assert res[2]["seq_res"][2] == [90.0]
+    f = os.path.join(out["args"].out_path, "test_method_performancesEWC1.pth")
+    assert "seq_head_acc" in torch.load(f, weights_only=False)["EWC"]
+
+
+def test_multi_hyperparam_decay_order():
+    """framework_train.py:176-184 worked example."""
+    class M:
+        hyperparams = OrderedDict([("lambda", 5.0), ("alpha", 2.0)])
+    hf = driver.HyperparameterFramework(M())
+
+    class A:
+        decaying_factor = 0.5
+
+    class Mgr:
+        method = M()
+    seq = []
+    for _ in range(5):
+        hf.hyperparamDecay(A(), Mgr())
+        seq.append((hf.hyperparams["lambda"], hf.hyperparams["alpha"]))
+    assert seq == [(2.5, 2.0), (5.0, 1.0), (2.5, 1.0), (1.25, 1.0), (2.5, 0.5)]
+
+
+def test_set_hyperparams_grammar():
+    from clsurvey_amd.methods import method as M
+    m = M.parse("EWC")
+    M.set_hyperparams(m, "200")
+    assert m.hyperparams["lambda"] == 200.0
+    M.set_hyperparams(m, "def")
+    assert m.hyperparams["lambda"] == 200.0
+    assert M.parse("MAS").hyperparams["lambda"] == 3 and M.parse("SI").hyperparams["lambda"] == 400
+
+
+def test_device_loader_reproduces_dataloader_order():
+    from torch.utils.data import DataLoader
+    from clsurvey_amd.data import DeviceLoader, TensorTaskDataset
+    ds = TensorTaskDataset(torch.arange(23).float().view(23, 1, 1, 1).expand(23, 3, 2, 2), torch.arange(23), list(range(5)))
+    torch.manual_seed(7)
+    ref = [b[1].tolist() for _ in range(2) for b in DataLoader(ds, batch_size=5, shuffle=True)]
+    torch.manual_seed(7)
+    dl = DeviceLoader(ds, 5, True, "cpu")
+    assert [b[1].tolist() for _ in range(2) for b in dl] == ref and len(dl) == 5
