@@ -171,18 +171,32 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
 
         const float* ws = lds + buf * BUF_FLOATS + a_lane;
         const float* xs = lds + buf * BUF_FLOATS + WS_FLOATS + b_lane;
-#pragma unroll
-        for (int cp = 0; cp < CK / 2; ++cp) {
+        // Explicit register double-buffering of the MFMA operands: the 9 + 9*NT LDS reads of channel
+        // pair cp+1 are issued BEFORE the 9*NT MFMAs of pair cp, so every MFMA block runs with all
+        // operands already in VGPRs (hipcc otherwise schedules ds_read -> lgkmcnt(0) -> mfma chains
+        // that expose the LDS latency once per two MFMAs; measured 50 % MFMA busy).
+        float af[2][9], bf[2][G::NT][9];
+        auto load_frag = [&](int cp, int slot) {
 #pragma unroll
             for (int rs = 0; rs < 9; ++rs) {
                 const int r = rs / 3, s = rs - 3 * (rs / 3);
-                float a = ws[((2 * cp) * 9 + rs) * LDW];
+                af[slot][rs] = ws[((2 * cp) * 9 + rs) * LDW];
 #pragma unroll
-                for (int t = 0; t < G::NT; ++t) {
-                    float b = xs[(2 * cp) * G::PLANE + pixoff[t] + r * G::TWP + s];
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
-                }
+                for (int t = 0; t < G::NT; ++t)
+                    bf[slot][t][rs] = xs[(2 * cp) * G::PLANE + pixoff[t] + r * G::TWP + s];
             }
+        };
+        load_frag(0, 0);
+#pragma unroll
+        for (int cp = 0; cp < CK / 2; ++cp) {
+            if (cp + 1 < CK / 2) load_frag(cp + 1, (cp + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int rs = 0; rs < 9; ++rs)
+#pragma unroll
+                for (int t = 0; t < G::NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cp & 1][rs], bf[cp & 1][t][rs], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
 
         if (chunk + 1 < n_chunks) store_chunk(buf ^ 1);

@@ -132,18 +132,29 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(
         store_stage();
         __syncthreads();
         if (st + 1 < st_end) load_stage(st + 1);   // in flight while the matrix pipe runs
-#pragma unroll
-        for (int pp = 0; pp < G::BP / 2; ++pp) {
+        // operands of pixel pair pp+1 are read while the 9 MFMAs of pair pp run (explicit register
+        // double buffering; see conv3x3.hip)
+        float af[2], bf[2][9];
+        auto load_frag = [&](int pp, int slot) {
             const int q0 = 2 * pp;
             const int th = q0 / TW, tw = q0 - (q0 / TW) * TW;
-            float a = a_ptr[q0];
-            bsum += (double)a;
+            af[slot] = a_ptr[q0];
 #pragma unroll
             for (int rs = 0; rs < 9; ++rs) {
                 const int r = rs / 3, s = rs - 3 * (rs / 3);
-                float b = b_ptr[(th + r) * G::TWP + tw + s];
-                acc[rs] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[rs], 0, 0, 0);
+                bf[slot][rs] = b_ptr[(th + r) * G::TWP + tw + s];
             }
+        };
+        load_frag(0, 0);
+#pragma unroll
+        for (int pp = 0; pp < G::BP / 2; ++pp) {
+            if (pp + 1 < G::BP / 2) load_frag(pp + 1, (pp + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            bsum += (double)af[pp & 1];
+#pragma unroll
+            for (int rs = 0; rs < 9; ++rs)
+                acc[rs] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[pp & 1], bf[pp & 1][rs], acc[rs], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 

@@ -4,10 +4,10 @@ set -u
 mkdir -p gpurun_out
 TAG=${1:-t1}
 export TMPDIR=/tmp
-echo "== tests"; timeout 900 python -m pytest tests -m gpu -q -x -p no:cacheprovider 2>&1 | tail -15 | tee gpurun_out/${TAG}_tests.log
+echo "== tests"; timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | grep -v "Loss:\|^Epoch\|lr is\|Accuracy\|Training complete\|ATTEMPT\|FINETUNE\|USING SI\|^$" | tail -40 | tee gpurun_out/${TAG}_tests.log
 echo "== smoke"; timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -3 | tee gpurun_out/${TAG}_smoke.log
 echo "== bench"; timeout 600 python bench.py --steps 100 --warmup 10 2> gpurun_out/${TAG}_bench.err | tee gpurun_out/${TAG}_bench.json | cut -c1-400
-for v in "" occ2 occ3; do
+for v in ""; do
   if [ -z "$v" ]; then unset CLHIP_LIB; else export CLHIP_LIB=$PWD/clsurvey_amd/libclhip_$v.so; fi
   echo "== conv_bench ${v:-default}"; timeout 300 python tools/conv_bench.py small 200 20 2>&1 | tail -12 | tee gpurun_out/${TAG}_convbench_${v:-default}.log
 done
