@@ -40,6 +40,13 @@ SIGNATURES = {
     "clhip_mas_accum": (_i, [_p, _p, _z, _f, _f, _p]),
     "clhip_si_step": (_i, [_p, _p, _p, _p, _p, _p, _z, _f, _f, _f, _f, _i, _p]),
     "clhip_si_consolidate": (_i, [_p, _p, _p, _p, _z, _f, _p]),
+    "clhip_packnet_finetune_mask": (_i, [_p, _z, _i, _p]),
+    "clhip_packnet_kth_ws": (_z, []),
+    "clhip_packnet_kth_abs": (_i, [_p, _p, _z, _i, _z, _p, _p, _z, _p]),
+    "clhip_packnet_prune": (_i, [_p, _p, _z, _i, _p, _p]),
+    "clhip_mask_grad_zero": (_i, [_p, _p, _z, _i, _p]),
+    "clhip_mask_weight_zero": (_i, [_p, _p, _z, _i, _i, _p]),
+    "clhip_packnet_sgd_step": (_i, [_p, _p, _p, _p, _z, _i, _f, _f, _f, _i, _p]),
     "clhip_net_create": (_i, [C.POINTER(LayerDesc), _i, _i, _i, _i, _i, C.POINTER(_p)]),
     "clhip_net_destroy": (None, [_p]),
     "clhip_net_workspace_bytes": (_z, [_p]),

@@ -93,47 +93,66 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
     float wreg[W_ITERS];
     float xreg[X_ITERS];
 
-    const size_t in_img = (size_t)Cin * H * W;
+    const size_t plane_hw = (size_t)H * W;
     const int n_chunks = (Cin + CK - 1) / CK;
+
+    // Staging addresses are computed ONCE per block: per chunk only the base pointers move (all the
+    // div/mod index math per element otherwise runs on the VALU in series with the MFMAs of the
+    // same wave: measured 50 % MFMA busy before this change).
+    //   wmeta: LDS destination | (channel-in-chunk << 16) | (valid << 24) ;  woff: global offset
+    //   xmeta: (channel-in-chunk << 1) | valid                            ;  xoff: global offset
+    int woff[W_ITERS], wmeta[W_ITERS], xoff[X_ITERS], xmeta[X_ITERS];
+#pragma unroll
+    for (int j = 0; j < W_ITERS; ++j) {
+        int e = tid + 256 * j;
+        woff[j] = 0; wmeta[j] = 0;
+        if (e < W_ELEMS) {
+            if (MODE == 0) {
+                int kl = e / (CK * 9), kidx = e - kl * (CK * 9);
+                woff[j] = (ko0 + kl) * Cw * 9 + kidx;
+                wmeta[j] = (kidx * LDW + kl) | ((kidx / 9) << 16) | ((ko0 + kl < Kw ? 1 : 0) << 24);
+            } else {
+                // out-channel role = c (Cw), in-channel role = k (Kw); e runs (kl, cl, rs)
+                int kl = e / (KT * 9), rem = e - kl * (KT * 9);
+                int cl = rem / 9, rs = rem - cl * 9;
+                woff[j] = (kl * Cw + ko0) * 9 + rem;
+                wmeta[j] = ((kl * 9 + (8 - rs)) * LDW + cl) | (kl << 16) | ((ko0 + cl < Cw ? 1 : 0) << 24);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < X_ITERS; ++j) {
+        int e = tid + 256 * j;
+        xoff[j] = 0; xmeta[j] = 0;
+        if (e < XS_FLOATS) {
+            int cl = e / G::PLANE, rem = e - cl * G::PLANE;
+            int col = rem % G::TWP;
+            int rr = rem / G::TWP;
+            int row = rr % (TH + 2), nb = rr / (TH + 2);
+            int n = n0 + nb, h = h0 - 1 + row, w = w0 - 1 + col;
+            bool ok = n < N && h >= 0 && h < H && w >= 0 && w < W;
+            xoff[j] = ok ? (int)(((size_t)nb * Cin + cl) * plane_hw) + h * W + w : 0;
+            xmeta[j] = (cl << 1) | (ok ? 1 : 0);
+        }
+    }
+    const float* in_blk = in + (size_t)n0 * Cin * plane_hw;
 
     auto load_chunk = [&](int chunk) {
         const int c0 = chunk * CK;
-        // ---- weights
+        const int cleft = Cin - c0;                      // channels left (>= CK except in the tail chunk)
+        const float* wb = wt + (MODE == 0 ? (size_t)c0 * 9 : (size_t)c0 * Cw * 9);
+        const float* xb = in_blk + (size_t)c0 * plane_hw;
 #pragma unroll
         for (int j = 0; j < W_ITERS; ++j) {
-            int e = tid + 256 * j;
-            float v = 0.f;
-            if (e < W_ELEMS) {
-                if (MODE == 0) {
-                    int kl = e / (CK * 9), kidx = e - kl * (CK * 9);
-                    int c = c0 + kidx / 9;
-                    int k = ko0 + kl;
-                    if (k < Kw && c < Cw) v = wt[((size_t)k * Cw) * 9 + (size_t)c0 * 9 + kidx];
-                } else {
-                    // out-channel role = c (Cw), in-channel role = k (Kw); e runs (kl, cl, rs)
-                    int kl = e / (KT * 9), rem = e - kl * (KT * 9);
-                    int cl = rem / 9;
-                    int k = c0 + kl, c = ko0 + cl;
-                    if (k < Kw && c < Cw) v = wt[((size_t)k * Cw + ko0) * 9 + rem];
-                }
-            }
-            wreg[j] = v;
+            const int mt = wmeta[j];
+            const bool ok = (mt >> 24) && (((mt >> 16) & 0xff) < cleft);
+            wreg[j] = ok ? wb[woff[j]] : 0.f;
         }
-        // ---- activations (with halo, zero padded)
 #pragma unroll
         for (int j = 0; j < X_ITERS; ++j) {
-            int e = tid + 256 * j;
-            float v = 0.f;
-            if (e < XS_FLOATS) {
-                int cl = e / G::PLANE, rem = e - cl * G::PLANE;
-                int col = rem % G::TWP;
-                int rr = rem / G::TWP;
-                int row = rr % (TH + 2), nb = rr / (TH + 2);
-                int c = c0 + cl, n = n0 + nb, h = h0 - 1 + row, w = w0 - 1 + col;
-                if (c < Cin && n < N && h >= 0 && h < H && w >= 0 && w < W)
-                    v = in[(size_t)n * in_img + ((size_t)c * H + h) * W + w];
-            }
-            xreg[j] = v;
+            const int mt = xmeta[j];
+            const bool ok = (mt & 1) && ((mt >> 1) < cleft);
+            xreg[j] = ok ? xb[xoff[j]] : 0.f;
         }
     };
 
@@ -141,24 +160,11 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
         float* ws = lds + buf * BUF_FLOATS;
         float* xs = ws + WS_FLOATS;
 #pragma unroll
-        for (int j = 0; j < W_ITERS; ++j) {
-            int e = tid + 256 * j;
-            if (e < W_ELEMS) {
-                if (MODE == 0) {
-                    int kl = e / (CK * 9), kidx = e - kl * (CK * 9);
-                    ws[kidx * LDW + kl] = wreg[j];
-                } else {
-                    int kl = e / (KT * 9), rem = e - kl * (KT * 9);
-                    int cl = rem / 9, rs = rem - cl * 9;
-                    ws[(kl * 9 + (8 - rs)) * LDW + cl] = wreg[j];
-                }
-            }
-        }
+        for (int j = 0; j < W_ITERS; ++j)
+            if (tid + 256 * j < W_ELEMS) ws[wmeta[j] & 0xffff] = wreg[j];
 #pragma unroll
-        for (int j = 0; j < X_ITERS; ++j) {
-            int e = tid + 256 * j;
-            if (e < XS_FLOATS) xs[e] = xreg[j];
-        }
+        for (int j = 0; j < X_ITERS; ++j)
+            if (tid + 256 * j < XS_FLOATS) xs[tid + 256 * j] = xreg[j];
     };
 
     load_chunk(0);

@@ -83,47 +83,50 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(
     float dyr[DY_ITERS];
     float xr[X_ITERS];
 
+    // Staging index math is hoisted out of the stage loop (it would otherwise run on the VALU in
+    // series with this wave's MFMAs — there is one wave per SIMD here).
+    //  dy tile: element e = tid + 256 j -> (k = wave + 4 j, pixel q = tid & 63): per-thread constants
+    //  x halo : xoff[j] = cl*HW + (row-1)*W + (col-1);  xmeta[j] = row | col<<4 | cl<<10 | ldsdst<<17
+    const int q_t = tid & 63;
+    const int th_t = q_t / TW, tw_t = q_t - th_t * TW;
+    const int dy_lds = wave * G::LDP + q_t;
+    int xoff[X_ITERS], xmeta[X_ITERS];
+#pragma unroll
+    for (int j = 0; j < X_ITERS; ++j) {
+        int e = tid + 256 * j;
+        xoff[j] = 0; xmeta[j] = 0;
+        if (e < X_ELEMS) {
+            int cl = e / G::PLANE, rem = e - cl * G::PLANE;
+            int row = rem / G::TWP, col = rem - row * G::TWP;
+            xoff[j] = cl * (int)plane_hw + (row - 1) * W + (col - 1);
+            xmeta[j] = row | (col << 4) | (cl << 10) | ((cl * G::PLANEP + rem) << 17);
+        }
+    }
+
     auto load_stage = [&](int st) {
         int n, h0, w0;
         decode_stage(st, tiles_w, tiles_h, TW, TH, n, h0, w0);
-        const float* dyn = dy + (size_t)n * K * plane_hw;
-        const float* xn = x + (size_t)n * C * plane_hw;
+        const bool pix_ok = (h0 + th_t < H) && (w0 + tw_t < W);
+        const float* dyp = dy + ((size_t)n * K + k0 + wave) * plane_hw + (size_t)(h0 + th_t) * W + (w0 + tw_t);
+        const float* xp = x + ((size_t)n * C + c0) * plane_hw + (size_t)h0 * W + w0;
 #pragma unroll
-        for (int j = 0; j < DY_ITERS; ++j) {
-            int e = tid + 256 * j;
-            int kl = e / G::BP, q = e - kl * G::BP;
-            int th = q / TW, tw = q - th * TW;
-            int k = k0 + kl, h = h0 + th, w = w0 + tw;
-            dyr[j] = (k < K && h < H && w < W) ? dyn[(size_t)k * plane_hw + (size_t)h * W + w] : 0.f;
-        }
+        for (int j = 0; j < DY_ITERS; ++j)
+            dyr[j] = (pix_ok && (k0 + wave + 4 * j < K)) ? dyp[(size_t)(4 * j) * plane_hw] : 0.f;
 #pragma unroll
         for (int j = 0; j < X_ITERS; ++j) {
-            int e = tid + 256 * j;
-            float v = 0.f;
-            if (e < X_ELEMS) {
-                int cl = e / G::PLANE, rem = e - cl * G::PLANE;
-                int row = rem / G::TWP, col = rem - row * G::TWP;
-                int c = c0 + cl, h = h0 - 1 + row, w = w0 - 1 + col;
-                if (c < C && h >= 0 && h < H && w >= 0 && w < W) v = xn[(size_t)c * plane_hw + (size_t)h * W + w];
-            }
-            xr[j] = v;
+            const int mt = xmeta[j];
+            const int h = h0 - 1 + (mt & 15), w = w0 - 1 + ((mt >> 4) & 63);
+            const bool ok = (tid + 256 * j < X_ELEMS) && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W &&
+                            (c0 + ((mt >> 10) & 127) < C);
+            xr[j] = ok ? xp[xoff[j]] : 0.f;
         }
     };
     auto store_stage = [&]() {
 #pragma unroll
-        for (int j = 0; j < DY_ITERS; ++j) {
-            int e = tid + 256 * j;
-            int kl = e / G::BP, q = e - kl * G::BP;
-            dys[kl * G::LDP + q] = dyr[j];
-        }
+        for (int j = 0; j < DY_ITERS; ++j) dys[dy_lds + 4 * j * G::LDP] = dyr[j];
 #pragma unroll
-        for (int j = 0; j < X_ITERS; ++j) {
-            int e = tid + 256 * j;
-            if (e < X_ELEMS) {
-                int cl = e / G::PLANE, rem = e - cl * G::PLANE;
-                xs[cl * G::PLANEP + rem] = xr[j];
-            }
-        }
+        for (int j = 0; j < X_ITERS; ++j)
+            if (tid + 256 * j < X_ELEMS) xs[xmeta[j] >> 17] = xr[j];
     };
 
     if (st_begin < st_end) load_stage(st_begin);
@@ -219,44 +222,46 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_smallc_kernel(
     float dyr[DY_ITERS];
     float xr[X_ITERS];
 
+    const int q_t = tid & 63;
+    const int th_t = q_t / TW, tw_t = q_t - th_t * TW;
+    const int dy_lds = wave * G::LDP + q_t;
+    int xoff[X_ITERS], xmeta[X_ITERS];
+#pragma unroll
+    for (int j = 0; j < X_ITERS; ++j) {
+        int e = tid + 256 * j;
+        xoff[j] = 0; xmeta[j] = 0;
+        if (e < X_ELEMS) {
+            int cl = e / G::PLANE, rem = e - cl * G::PLANE;
+            int row = rem / G::TWP, col = rem - row * G::TWP;
+            xoff[j] = cl * (int)plane_hw + (row - 1) * W + (col - 1);
+            xmeta[j] = row | (col << 4) | (cl << 10);
+        }
+    }
+
     auto load_stage = [&](int st) {
         int n, h0, w0;
         decode_stage(st, tiles_w, tiles_h, TW, TH, n, h0, w0);
-        const float* dyn = dy + (size_t)n * K * plane_hw;
-        const float* xn = x + (size_t)n * C * plane_hw;
+        const bool pix_ok = (h0 + th_t < H) && (w0 + tw_t < W);
+        const float* dyp = dy + ((size_t)n * K + k0 + wave) * plane_hw + (size_t)(h0 + th_t) * W + (w0 + tw_t);
+        const float* xp = x + (size_t)n * C * plane_hw + (size_t)h0 * W + w0;
 #pragma unroll
-        for (int j = 0; j < DY_ITERS; ++j) {
-            int e = tid + 256 * j;
-            int kl = e / G::BP, q = e - kl * G::BP;
-            int th = q / TW, tw = q - th * TW;
-            int k = k0 + kl, h = h0 + th, w = w0 + tw;
-            dyr[j] = (k < K && h < H && w < W) ? dyn[(size_t)k * plane_hw + (size_t)h * W + w] : 0.f;
-        }
+        for (int j = 0; j < DY_ITERS; ++j)
+            dyr[j] = (pix_ok && (k0 + wave + 4 * j < K)) ? dyp[(size_t)(4 * j) * plane_hw] : 0.f;
 #pragma unroll
         for (int j = 0; j < X_ITERS; ++j) {
-            int e = tid + 256 * j;
-            float v = 0.f;
-            if (e < X_ELEMS) {
-                int cl = e / G::PLANE, rem = e - cl * G::PLANE;
-                int row = rem / G::TWP, col = rem - row * G::TWP;
-                int h = h0 - 1 + row, w = w0 - 1 + col;
-                if (cl < C && h >= 0 && h < H && w >= 0 && w < W) v = xn[(size_t)cl * plane_hw + (size_t)h * W + w];
-            }
-            xr[j] = v;
+            const int mt = xmeta[j];
+            const int h = h0 - 1 + (mt & 15), w = w0 - 1 + ((mt >> 4) & 63);
+            const bool ok = (tid + 256 * j < X_ELEMS) && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W &&
+                            (((mt >> 10) & 127) < C);
+            xr[j] = ok ? xp[xoff[j]] : 0.f;
         }
     };
     auto store_stage = [&]() {
 #pragma unroll
-        for (int j = 0; j < DY_ITERS; ++j) {
-            int e = tid + 256 * j;
-            int kl = e / G::BP, q = e - kl * G::BP;
-            dys[kl * G::LDP + q] = dyr[j];
-        }
+        for (int j = 0; j < DY_ITERS; ++j) dys[dy_lds + 4 * j * G::LDP] = dyr[j];
 #pragma unroll
-        for (int j = 0; j < X_ITERS; ++j) {
-            int e = tid + 256 * j;
-            if (e < X_ELEMS) xs[e] = xr[j];
-        }
+        for (int j = 0; j < X_ITERS; ++j)
+            if (tid + 256 * j < X_ELEMS) xs[tid + 256 * j] = xr[j];
     };
 
     if (st_begin < st_end) load_stage(st_begin);

@@ -108,6 +108,28 @@ int clhip_si_step(float* theta, const float* grad, const float* omega, const flo
 int clhip_si_consolidate(float* omega, float* w, const float* theta, float* init_val, size_t n,
                          float slack, void* stream);
 
+/* ------------------------------------------------------------------ PackNet masks (uint8, bit-exact)
+ * methods/packnet/prune.py: mask value = owning task (1-based), 0 = free/pruned.
+ *   finetune_mask  (:141-155)  mask[mask==0] = cur
+ *   kth_abs        (:30-39)    cutoff = k-th smallest |w| over {mask==cur} (exact radix select;
+ *                               k = round(prune_perc*numel) computed by the caller, k >= 1)
+ *   prune          (:43-47,:64-71) mask[(|w|<=cutoff)&(mask==cur)] = 0 ; w[mask==0] = 0
+ *   mask_grad_zero (:73-97)    grad[mask != cur] = 0
+ *   mask_weight_zero mode 0 (:99-106 make_pruned_zero): w[mask==0]=0 ;
+ *                    mode 1 (:108-118 apply_mask(idx)): w[mask==0 or mask>idx]=0
+ *   packnet_sgd_step           fused do_batch tail (packnet/main.py:187-193): grads of foreign weights
+ *                               -> 0, PacknetSGD.step (packnetSGD.py:35-56: weight decay masked by
+ *                               grad != 0), pruned weights -> 0.  mask_u8 == NULL => plain PacknetSGD. */
+int clhip_packnet_finetune_mask(uint8_t* mask_u8, size_t n, int cur, void* stream);
+size_t clhip_packnet_kth_ws(void);
+int clhip_packnet_kth_abs(const float* w, const uint8_t* mask_u8, size_t n, int cur, size_t k,
+                          float* out_cutoff, void* ws, size_t ws_bytes, void* stream);
+int clhip_packnet_prune(float* w, uint8_t* mask_u8, size_t n, int cur, const float* cutoff_dev, void* stream);
+int clhip_mask_grad_zero(float* grad, const uint8_t* mask_u8, size_t n, int cur, void* stream);
+int clhip_mask_weight_zero(float* w, const uint8_t* mask_u8, size_t n, int mode, int idx, void* stream);
+int clhip_packnet_sgd_step(float* theta, float* grad, float* buf, const uint8_t* mask_u8, size_t n, int cur,
+                           float lr, float momentum, float wd, int first, void* stream);
+
 /* ------------------------------------------------------------------ static-plan net executor
  * One call per pass for VGG-style nets instead of one Python dispatch per op
  * (replaces `outputs = model(inputs); loss.backward()` of EWC/train_EWC.py:181-187,
