@@ -39,7 +39,7 @@ struct Geo {
 #ifndef CLHIP_CONV_MIN_WAVES
 #define CLHIP_CONV_MIN_WAVES 1
 #endif
-template <int TW, int TH, int NB, int CK, int MODE>
+template <int TW, int TH, int NB, int CK, int MODE, bool VEC>
 __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel(
     const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
     const float* __restrict__ mask_src, float* __restrict__ out,
@@ -88,83 +88,193 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     constexpr int W_ELEMS = KT * CK * 9;
-    constexpr int W_ITERS = (W_ELEMS + 255) / 256;
-    constexpr int X_ITERS = (XS_FLOATS + 255) / 256;
-    float wreg[W_ITERS];
-    float xreg[X_ITERS];
-
     const size_t plane_hw = (size_t)H * W;
     const int n_chunks = (Cin + CK - 1) / CK;
+    const float* in_blk = in + (size_t)n0 * Cin * plane_hw;
 
-    // Staging addresses are computed ONCE per block: per chunk only the base pointers move (all the
-    // div/mod index math per element otherwise runs on the VALU in series with the MFMAs of the
-    // same wave: measured 50 % MFMA busy before this change).
-    //   wmeta: LDS destination | (channel-in-chunk << 16) | (valid << 24) ;  woff: global offset
-    //   xmeta: (channel-in-chunk << 1) | valid                            ;  xoff: global offset
-    int woff[W_ITERS], wmeta[W_ITERS], xoff[X_ITERS], xmeta[X_ITERS];
+    // ------------------------------------------------------------------ staging
+    // All index math is done ONCE per block; per chunk only base pointers move.  Every load is
+    // unconditional from an always-mapped address + a select (no exec-mask branches): measured, the
+    // per-element bounds-check branches cost ~20 VALU/SALU instructions per 4-byte load and ran in
+    // series with this wave's MFMAs.
+    //  VEC (aligned shapes: Cin % 8 == 0, W % 4 == 0, W % TW == 0, Cw % 4 == 0): 16-byte global loads
+    //      — weights 4.5 / activations 1.5-2 (+halo columns) instructions per thread per chunk;
+    //  scalar path: first layer (C = 3) and odd shapes.
+    constexpr int W_IT = VEC ? (W_ELEMS / 4 + 255) / 256 : (W_ELEMS + 255) / 256;
+    constexpr int XROWS = CK * NB * (TH + 2);                 // halo-plane rows per chunk
+    constexpr int XV_ELEMS = XROWS * (TW / 4);                // interior float4 per chunk
+    constexpr int X_IT = VEC ? (XV_ELEMS + 255) / 256 : (XS_FLOATS + 255) / 256;
+    constexpr int H_IT = VEC ? (XROWS * 2 + 255) / 256 : 0;   // halo-column scalars
+    float4 wv[VEC ? W_IT : 1];
+    float4 xv[VEC ? X_IT : 1];
+    float hv[VEC ? (H_IT > 0 ? H_IT : 1) : 1];
+    float wreg[VEC ? 1 : W_IT];
+    float xreg[VEC ? 1 : X_IT];
+    int woff[W_IT], wdst[VEC ? W_IT * (MODE == 0 ? 1 : 4) : W_IT];
+    int xoff[X_IT], xdst[VEC ? X_IT : 1];
+    int hoff[H_IT > 0 ? H_IT : 1], hdst[H_IT > 0 ? H_IT : 1];
+    unsigned wok = 0, xok = 0, hok = 0;                        // validity bit per iteration
+    int wch[VEC ? 1 : W_IT], xch[VEC ? 1 : X_IT];             // scalar path: channel-in-chunk (tail chunks)
+
+    if constexpr (VEC) {
 #pragma unroll
-    for (int j = 0; j < W_ITERS; ++j) {
-        int e = tid + 256 * j;
-        woff[j] = 0; wmeta[j] = 0;
-        if (e < W_ELEMS) {
+        for (int j = 0; j < W_IT; ++j) {
+            const int e = tid + 256 * j;
+            woff[j] = 0;
             if (MODE == 0) {
-                int kl = e / (CK * 9), kidx = e - kl * (CK * 9);
-                woff[j] = (ko0 + kl) * Cw * 9 + kidx;
-                wmeta[j] = (kidx * LDW + kl) | ((kidx / 9) << 16) | ((ko0 + kl < Kw ? 1 : 0) << 24);
+                // row kl: CK*9 contiguous floats = CK*9/4 float4; LDS dst of float t: (4f+t)*LDW + kl
+                const int kl = e / (CK * 9 / 4), f = e - kl * (CK * 9 / 4);
+                wdst[j] = (4 * f) * LDW + kl;
+                if (e < W_ELEMS / 4 && ko0 + kl < Kw) { woff[j] = (ko0 + kl) * Cw * 9 + 4 * f; wok |= 1u << j; }
             } else {
-                // out-channel role = c (Cw), in-channel role = k (Kw); e runs (kl, cl, rs)
-                int kl = e / (KT * 9), rem = e - kl * (KT * 9);
-                int cl = rem / 9, rs = rem - cl * 9;
-                woff[j] = (kl * Cw + ko0) * 9 + rem;
-                wmeta[j] = ((kl * 9 + (8 - rs)) * LDW + cl) | (kl << 16) | ((ko0 + cl < Cw ? 1 : 0) << 24);
+                // in-channel row kl: KT*9 contiguous floats (c = ko0.., rs); dst of float t individually
+                const int kl = e / (KT * 9 / 4), f = e - kl * (KT * 9 / 4);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int rem = 4 * f + t, cl = rem / 9, rs = rem - cl * 9;
+                    wdst[j * 4 + t] = (kl * 9 + (8 - rs)) * LDW + cl;
+                }
+                if (e < W_ELEMS / 4 && 4 * f < (Cw - ko0) * 9) { woff[j] = (kl * Cw + ko0) * 9 + 4 * f; wok |= 1u << j; }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < X_IT; ++j) {
+            const int e = tid + 256 * j;
+            const int rowid = e / (TW / 4), f = e - rowid * (TW / 4);
+            const int cl = rowid / (NB * (TH + 2)), rr = rowid - cl * (NB * (TH + 2));
+            const int nb = rr / (TH + 2), row = rr - nb * (TH + 2);
+            const int n = n0 + nb, h = h0 - 1 + row;
+            xdst[j] = cl * G::PLANE + (nb * (TH + 2) + row) * G::TWP + 1 + 4 * f;
+            xoff[j] = 0;
+            if (e < XV_ELEMS && n < N && h >= 0 && h < H) {
+                xoff[j] = (int)(((size_t)nb * Cin + cl) * plane_hw) + h * W + w0 + 4 * f;
+                xok |= 1u << j;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < H_IT; ++j) {
+            const int e = tid + 256 * j;
+            const int rowid = e >> 1, side = e & 1;
+            const int cl = rowid / (NB * (TH + 2)), rr = rowid - cl * (NB * (TH + 2));
+            const int nb = rr / (TH + 2), row = rr - nb * (TH + 2);
+            const int n = n0 + nb, h = h0 - 1 + row, w = side ? w0 + TW : w0 - 1;
+            hdst[j] = cl * G::PLANE + (nb * (TH + 2) + row) * G::TWP + (side ? TW + 1 : 0);
+            hoff[j] = 0;
+            if (e < XROWS * 2 && n < N && h >= 0 && h < H && w >= 0 && w < W) {
+                hoff[j] = (int)(((size_t)nb * Cin + cl) * plane_hw) + h * W + w;
+                hok |= 1u << j;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < W_IT; ++j) {
+            const int e = tid + 256 * j;
+            woff[j] = 0; wdst[j] = 0; wch[j] = 0;
+            if (e < W_ELEMS) {
+                if (MODE == 0) {
+                    const int kl = e / (CK * 9), kidx = e - kl * (CK * 9);
+                    wdst[j] = kidx * LDW + kl; wch[j] = kidx / 9;
+                    if (ko0 + kl < Kw) { woff[j] = (ko0 + kl) * Cw * 9 + kidx; wok |= 1u << j; }
+                } else {
+                    const int kl = e / (KT * 9), rem = e - kl * (KT * 9);
+                    const int cl = rem / 9, rs = rem - cl * 9;
+                    wdst[j] = (kl * 9 + (8 - rs)) * LDW + cl; wch[j] = kl;
+                    if (ko0 + cl < Cw) { woff[j] = (kl * Cw + ko0) * 9 + rem; wok |= 1u << j; }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < X_IT; ++j) {
+            const int e = tid + 256 * j;
+            xoff[j] = 0; xch[j] = 0;
+            if (e < XS_FLOATS) {
+                const int cl = e / G::PLANE, rem = e - cl * G::PLANE;
+                const int col = rem % G::TWP, rr = rem / G::TWP;
+                const int row = rr % (TH + 2), nb = rr / (TH + 2);
+                const int n = n0 + nb, h = h0 - 1 + row, w = w0 - 1 + col;
+                xch[j] = cl;
+                if (n < N && h >= 0 && h < H && w >= 0 && w < W) {
+                    xoff[j] = (int)(((size_t)nb * Cin + cl) * plane_hw) + h * W + w;
+                    xok |= 1u << j;
+                }
             }
         }
     }
-#pragma unroll
-    for (int j = 0; j < X_ITERS; ++j) {
-        int e = tid + 256 * j;
-        xoff[j] = 0; xmeta[j] = 0;
-        if (e < XS_FLOATS) {
-            int cl = e / G::PLANE, rem = e - cl * G::PLANE;
-            int col = rem % G::TWP;
-            int rr = rem / G::TWP;
-            int row = rr % (TH + 2), nb = rr / (TH + 2);
-            int n = n0 + nb, h = h0 - 1 + row, w = w0 - 1 + col;
-            bool ok = n < N && h >= 0 && h < H && w >= 0 && w < W;
-            xoff[j] = ok ? (int)(((size_t)nb * Cin + cl) * plane_hw) + h * W + w : 0;
-            xmeta[j] = (cl << 1) | (ok ? 1 : 0);
-        }
-    }
-    const float* in_blk = in + (size_t)n0 * Cin * plane_hw;
 
     auto load_chunk = [&](int chunk) {
         const int c0 = chunk * CK;
-        const int cleft = Cin - c0;                      // channels left (>= CK except in the tail chunk)
         const float* wb = wt + (MODE == 0 ? (size_t)c0 * 9 : (size_t)c0 * Cw * 9);
         const float* xb = in_blk + (size_t)c0 * plane_hw;
+        if constexpr (VEC) {
 #pragma unroll
-        for (int j = 0; j < W_ITERS; ++j) {
-            const int mt = wmeta[j];
-            const bool ok = (mt >> 24) && (((mt >> 16) & 0xff) < cleft);
-            wreg[j] = ok ? wb[woff[j]] : 0.f;
-        }
+            for (int j = 0; j < W_IT; ++j) {
+                const bool ok = (wok >> j) & 1u;
+                float4 v = *reinterpret_cast<const float4*>(ok ? wb + woff[j] : wt);
+                wv[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
 #pragma unroll
-        for (int j = 0; j < X_ITERS; ++j) {
-            const int mt = xmeta[j];
-            const bool ok = (mt & 1) && ((mt >> 1) < cleft);
-            xreg[j] = ok ? xb[xoff[j]] : 0.f;
+            for (int j = 0; j < X_IT; ++j) {
+                const bool ok = (xok >> j) & 1u;
+                float4 v = *reinterpret_cast<const float4*>(ok ? xb + xoff[j] : in);
+                xv[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < H_IT; ++j) {
+                const bool ok = (hok >> j) & 1u;
+                float v = *(ok ? xb + hoff[j] : in);
+                hv[j] = ok ? v : 0.f;
+            }
+        } else {
+            const int cleft = Cin - c0;                  // channels left (>= CK except in the tail chunk)
+#pragma unroll
+            for (int j = 0; j < W_IT; ++j) {
+                const bool ok = ((wok >> j) & 1u) && wch[j] < cleft;
+                float v = *(ok ? wb + woff[j] : wt);
+                wreg[j] = ok ? v : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < X_IT; ++j) {
+                const bool ok = ((xok >> j) & 1u) && xch[j] < cleft;
+                float v = *(ok ? xb + xoff[j] : in);
+                xreg[j] = ok ? v : 0.f;
+            }
         }
     };
 
     auto store_chunk = [&](int buf) {
         float* ws = lds + buf * BUF_FLOATS;
         float* xs = ws + WS_FLOATS;
+        if constexpr (VEC) {
 #pragma unroll
-        for (int j = 0; j < W_ITERS; ++j)
-            if (tid + 256 * j < W_ELEMS) ws[wmeta[j] & 0xffff] = wreg[j];
+            for (int j = 0; j < W_IT; ++j) {
+                if (tid + 256 * j < W_ELEMS / 4) {
+                    if (MODE == 0) {
+                        float* d = ws + wdst[j];
+                        d[0] = wv[j].x; d[LDW] = wv[j].y; d[2 * LDW] = wv[j].z; d[3 * LDW] = wv[j].w;
+                    } else {
+                        ws[wdst[4 * j]] = wv[j].x; ws[wdst[4 * j + 1]] = wv[j].y;
+                        ws[wdst[4 * j + 2]] = wv[j].z; ws[wdst[4 * j + 3]] = wv[j].w;
+                    }
+                }
+            }
 #pragma unroll
-        for (int j = 0; j < X_ITERS; ++j)
-            if (tid + 256 * j < XS_FLOATS) xs[tid + 256 * j] = xreg[j];
+            for (int j = 0; j < X_IT; ++j) {
+                if (tid + 256 * j < XV_ELEMS) {
+                    float* d = xs + xdst[j];
+                    d[0] = xv[j].x; d[1] = xv[j].y; d[2] = xv[j].z; d[3] = xv[j].w;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < H_IT; ++j)
+                if (tid + 256 * j < XROWS * 2) xs[hdst[j]] = hv[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < W_IT; ++j)
+                if (tid + 256 * j < W_ELEMS) ws[wdst[j]] = wreg[j];
+#pragma unroll
+            for (int j = 0; j < X_IT; ++j)
+                if (tid + 256 * j < XS_FLOATS) xs[tid + 256 * j] = xreg[j];
+        }
     };
 
     load_chunk(0);
@@ -235,7 +345,7 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
     }
 }
 
-template <int TW, int TH, int NB, int CK, int MODE>
+template <int TW, int TH, int NB, int CK, int MODE, bool VEC>
 int launch_geo(const float* in, const float* wt, const float* bias, const float* mask_src, float* out,
                int N, int Cin, int Cout, int H, int W, int Kw, int Cw, int relu, hipStream_t s) {
     int tiles_w = (W + TW - 1) / TW, tiles_h = (H + TH - 1) / TH, ngrp = (N + NB - 1) / NB;
@@ -243,7 +353,7 @@ int launch_geo(const float* in, const float* wt, const float* bias, const float*
     int kts = (Cout + KT - 1) / KT;
     long long blocks = (long long)n_pix_tiles * kts;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return CLHIP_EINVAL;
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<TW, TH, NB, CK, MODE>), dim3((unsigned)blocks), dim3(256), 0, s,
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<TW, TH, NB, CK, MODE, VEC>), dim3((unsigned)blocks), dim3(256), 0, s,
                        in, wt, bias, mask_src, out, N, Cin, Cout, H, W, Kw, Cw, relu, tiles_w, tiles_h, n_pix_tiles);
     CLHIP_LAUNCH_CHECK();
     return 0;
@@ -251,22 +361,23 @@ int launch_geo(const float* in, const float* wt, const float* bias, const float*
 
 // Tile geometry choice: full 128-pixel tiles while they still give >= ~2 blocks per CU,
 // otherwise 64-pixel tiles (deep layers at 8x8 / 16x16 have few pixels).
-template <int CK, int MODE>
+template <int CK, int MODE, bool VEC>
 int launch_conv(const float* in, const float* wt, const float* bias, const float* mask_src, float* out,
                 int N, int Cin, int Cout, int H, int W, int Kw, int Cw, int relu, hipStream_t s) {
     const int kts = (Cout + KT - 1) / KT;
     const long long pix = (long long)N * H * W;
     const bool big = (pix / 128) * kts >= 512;
-    if (W >= 32 || W > 16) {
-        if (big) return launch_geo<32, 4, 1, CK, MODE>(in, wt, bias, mask_src, out, N, Cin, Cout, H, W, Kw, Cw, relu, s);
-        return launch_geo<32, 2, 1, CK, MODE>(in, wt, bias, mask_src, out, N, Cin, Cout, H, W, Kw, Cw, relu, s);
-    } else if (W > 8) {
-        if (big) return launch_geo<16, 8, 1, CK, MODE>(in, wt, bias, mask_src, out, N, Cin, Cout, H, W, Kw, Cw, relu, s);
-        return launch_geo<16, 4, 1, CK, MODE>(in, wt, bias, mask_src, out, N, Cin, Cout, H, W, Kw, Cw, relu, s);
-    } else {
-        if (big && H > 4) return launch_geo<8, 8, 2, CK, MODE>(in, wt, bias, mask_src, out, N, Cin, Cout, H, W, Kw, Cw, relu, s);
-        return launch_geo<8, 8, 1, CK, MODE>(in, wt, bias, mask_src, out, N, Cin, Cout, H, W, Kw, Cw, relu, s);
-    }
+#define GEO(TW_, TH_, NB_) launch_geo<TW_, TH_, NB_, CK, MODE, VEC>(in, wt, bias, mask_src, out, N, Cin, Cout, H, W, Kw, Cw, relu, s)
+    if (W > 16) return big ? GEO(32, 4, 1) : GEO(32, 2, 1);
+    if (W > 8) return big ? GEO(16, 8, 1) : GEO(16, 4, 1);
+    return (big && H > 4) ? GEO(8, 8, 2) : GEO(8, 8, 1);
+#undef GEO
+}
+
+// 16-byte staging needs aligned rows and whole tiles along w.
+bool vec_ok(const float* in, const float* wt, int Cin, int H, int W, int Cw) {
+    const int TW = W > 16 ? 32 : (W > 8 ? 16 : 8);
+    return (Cin % 8 == 0) && (Cw % 4 == 0) && (W % 4 == 0) && (W % TW == 0) && aligned16(in) && aligned16(wt);
 }
 
 }  // namespace
@@ -277,15 +388,18 @@ int clhip_conv3x3_fwd(const float* x, const float* w, const float* b, float* y,
                       int N, int C, int K, int H, int W, int relu, void* stream) {
     if (!x || !w || !y || N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0) return CLHIP_EINVAL;
     hipStream_t s = as_stream(stream);
-    if (C <= 4) return launch_conv<4, 0>(x, w, b, nullptr, y, N, C, K, H, W, K, C, relu, s);
-    return launch_conv<8, 0>(x, w, b, nullptr, y, N, C, K, H, W, K, C, relu, s);
+    if (C <= 4) return launch_conv<4, 0, false>(x, w, b, nullptr, y, N, C, K, H, W, K, C, relu, s);
+    if (vec_ok(x, w, C, H, W, C)) return launch_conv<8, 0, true>(x, w, b, nullptr, y, N, C, K, H, W, K, C, relu, s);
+    return launch_conv<8, 0, false>(x, w, b, nullptr, y, N, C, K, H, W, K, C, relu, s);
 }
 
 int clhip_conv3x3_bwd_data(const float* dy, const float* w, const float* relu_src, float* dx,
                            int N, int C, int K, int H, int W, void* stream) {
     if (!dy || !w || !dx || N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0) return CLHIP_EINVAL;
     // in = dy (K channels), out = dx (C channels)
-    return launch_conv<8, 1>(dy, w, nullptr, relu_src, dx, N, K, C, H, W, K, C, 0, as_stream(stream));
+    if (vec_ok(dy, w, K, H, W, C))
+        return launch_conv<8, 1, true>(dy, w, nullptr, relu_src, dx, N, K, C, H, W, K, C, 0, as_stream(stream));
+    return launch_conv<8, 1, false>(dy, w, nullptr, relu_src, dx, N, K, C, H, W, K, C, 0, as_stream(stream));
 }
 
 }  // extern "C"

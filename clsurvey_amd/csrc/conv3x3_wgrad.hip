@@ -16,6 +16,7 @@
 //
 // First layer (C*9 <= 32): the 27 (c,r,s) combinations become the D columns of ONE accumulator
 // (84 % of the MFMA columns useful instead of 9 %); that kernel is HBM-bound on reading dy.
+#include <cstdlib>
 #include "common.hpp"
 
 namespace {
@@ -43,7 +44,7 @@ __device__ __forceinline__ void decode_stage(int st, int tiles_w, int tiles_h, i
 }
 
 // grid.x = n_tiles(k,c) * splits ; block 256 = 4 waves = (2 k-halves) x (2 c-halves)
-template <int TW, int TH>
+template <int TW, int TH, bool VEC>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
     int N, int C, int K, int H, int W, int tiles_w, int tiles_h,
@@ -77,56 +78,140 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(
     const float* b_ptr = xs + (wc * 32 + li) * G::PLANEP + kk;
     const size_t plane_hw = (size_t)H * W;
 
-    constexpr int DY_ITERS = KT * G::BP / 256;                 // 16
+    // ------------------------------------------------------------------ staging
+    // Index math hoisted out of the stage loop; loads are unconditional from always-mapped addresses
+    // + a select (no exec-mask branches), 16 bytes wide on aligned shapes (VEC): 14 load instructions
+    // per thread per stage instead of 50 four-byte loads with ~20 VALU/SALU instructions of bounds
+    // logic each — this wave is alone on its SIMD, so all of that ran with the matrix pipe idle.
+    constexpr int XROWS = CT * (TH + 2);
+    constexpr int DY_IT = VEC ? (KT * G::BP / 4) / 256 : KT * G::BP / 256;          // 4 | 16
     constexpr int X_ELEMS = CT * G::PLANE;
-    constexpr int X_ITERS = (X_ELEMS + 255) / 256;             // 34 / 27 / 25
-    float dyr[DY_ITERS];
-    float xr[X_ITERS];
-
-    // Staging index math is hoisted out of the stage loop (it would otherwise run on the VALU in
-    // series with this wave's MFMAs — there is one wave per SIMD here).
-    //  dy tile: element e = tid + 256 j -> (k = wave + 4 j, pixel q = tid & 63): per-thread constants
-    //  x halo : xoff[j] = cl*HW + (row-1)*W + (col-1);  xmeta[j] = row | col<<4 | cl<<10 | ldsdst<<17
+    constexpr int XV_ELEMS = XROWS * (TW / 4);
+    constexpr int X_IT = VEC ? (XV_ELEMS + 255) / 256 : (X_ELEMS + 255) / 256;      // 8|5|5 | 34|27|25
+    constexpr int H_IT = VEC ? (XROWS * 2 + 255) / 256 : 0;                          // 2|2|3
+    float4 dyv[VEC ? DY_IT : 1], xv[VEC ? X_IT : 1];
+    float hv[H_IT > 0 ? H_IT : 1];
+    float dyr[VEC ? 1 : DY_IT], xr[VEC ? 1 : X_IT];
+    int dyoff[VEC ? DY_IT : 1], dydst[VEC ? DY_IT : 1], dyrow[VEC ? DY_IT : 1];
+    int xoff[X_IT], xmeta[X_IT];           // VEC: row | ldsdst<<8 | cl<<24 ; scalar: row | col<<4 | cl<<10 | ldsdst<<17
+    int hoff[H_IT > 0 ? H_IT : 1], hmeta[H_IT > 0 ? H_IT : 1];   // row | side<<4 | ldsdst<<8 | cl<<24
     const int q_t = tid & 63;
     const int th_t = q_t / TW, tw_t = q_t - th_t * TW;
     const int dy_lds = wave * G::LDP + q_t;
-    int xoff[X_ITERS], xmeta[X_ITERS];
+
+    if constexpr (VEC) {
 #pragma unroll
-    for (int j = 0; j < X_ITERS; ++j) {
-        int e = tid + 256 * j;
-        xoff[j] = 0; xmeta[j] = 0;
-        if (e < X_ELEMS) {
-            int cl = e / G::PLANE, rem = e - cl * G::PLANE;
-            int row = rem / G::TWP, col = rem - row * G::TWP;
-            xoff[j] = cl * (int)plane_hw + (row - 1) * W + (col - 1);
-            xmeta[j] = row | (col << 4) | (cl << 10) | ((cl * G::PLANEP + rem) << 17);
+        for (int j = 0; j < DY_IT; ++j) {
+            const int e = tid + 256 * j;                     // float4 index: (kl, 16 float4 per k)
+            const int kl = e / (G::BP / 4), f = e - kl * (G::BP / 4);
+            const int q = 4 * f, th = q / TW, tw = q - th * TW;
+            dyoff[j] = kl * (int)plane_hw + th * W + tw;
+            dydst[j] = kl * G::LDP + q;
+            dyrow[j] = th | (kl << 8);
+        }
+#pragma unroll
+        for (int j = 0; j < X_IT; ++j) {
+            const int e = tid + 256 * j;
+            const int rowid = e / (TW / 4), f = e - rowid * (TW / 4);
+            const int cl = rowid / (TH + 2), row = rowid - cl * (TH + 2);
+            xoff[j] = cl * (int)plane_hw + (row - 1) * W + 4 * f;
+            xmeta[j] = row | ((cl * G::PLANEP + row * G::TWP + 1 + 4 * f) << 8) | (cl << 24);
+        }
+#pragma unroll
+        for (int j = 0; j < H_IT; ++j) {
+            const int e = tid + 256 * j;
+            const int rowid = e >> 1, side = e & 1;
+            const int cl = rowid / (TH + 2), row = rowid - cl * (TH + 2);
+            hoff[j] = cl * (int)plane_hw + (row - 1) * W + (side ? TW : -1);
+            hmeta[j] = row | (side << 4) | ((cl * G::PLANEP + row * G::TWP + (side ? TW + 1 : 0)) << 8) | (cl << 24);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < X_IT; ++j) {
+            const int e = tid + 256 * j;
+            xoff[j] = 0; xmeta[j] = 0;
+            if (e < X_ELEMS) {
+                const int cl = e / G::PLANE, rem = e - cl * G::PLANE;
+                const int row = rem / G::TWP, col = rem - row * G::TWP;
+                xoff[j] = cl * (int)plane_hw + (row - 1) * W + (col - 1);
+                xmeta[j] = row | (col << 4) | (cl << 10) | ((cl * G::PLANEP + rem) << 17);
+            }
         }
     }
 
     auto load_stage = [&](int st) {
         int n, h0, w0;
         decode_stage(st, tiles_w, tiles_h, TW, TH, n, h0, w0);
-        const bool pix_ok = (h0 + th_t < H) && (w0 + tw_t < W);
-        const float* dyp = dy + ((size_t)n * K + k0 + wave) * plane_hw + (size_t)(h0 + th_t) * W + (w0 + tw_t);
         const float* xp = x + ((size_t)n * C + c0) * plane_hw + (size_t)h0 * W + w0;
+        if constexpr (VEC) {
+            const float* dyp = dy + ((size_t)n * K + k0) * plane_hw + (size_t)h0 * W + w0;
 #pragma unroll
-        for (int j = 0; j < DY_ITERS; ++j)
-            dyr[j] = (pix_ok && (k0 + wave + 4 * j < K)) ? dyp[(size_t)(4 * j) * plane_hw] : 0.f;
+            for (int j = 0; j < DY_IT; ++j) {
+                const bool ok = (h0 + (dyrow[j] & 255) < H) && (k0 + (dyrow[j] >> 8) < K);
+                float4 v = *reinterpret_cast<const float4*>(ok ? dyp + dyoff[j] : dy);
+                dyv[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
 #pragma unroll
-        for (int j = 0; j < X_ITERS; ++j) {
-            const int mt = xmeta[j];
-            const int h = h0 - 1 + (mt & 15), w = w0 - 1 + ((mt >> 4) & 63);
-            const bool ok = (tid + 256 * j < X_ELEMS) && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W &&
-                            (c0 + ((mt >> 10) & 127) < C);
-            xr[j] = ok ? xp[xoff[j]] : 0.f;
+            for (int j = 0; j < X_IT; ++j) {
+                const int mt = xmeta[j];
+                const int h = h0 - 1 + (mt & 255);
+                const bool ok = (tid + 256 * j < XV_ELEMS) && (unsigned)h < (unsigned)H && (c0 + (mt >> 24) < C);
+                float4 v = *reinterpret_cast<const float4*>(ok ? xp + xoff[j] : x);
+                xv[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < H_IT; ++j) {
+                const int mt = hmeta[j];
+                const int h = h0 - 1 + (mt & 15), w = ((mt >> 4) & 1) ? w0 + TW : w0 - 1;
+                const bool ok = (tid + 256 * j < XROWS * 2) && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W &&
+                                (c0 + (mt >> 24) < C);
+                float v = *(ok ? xp + hoff[j] : x);
+                hv[j] = ok ? v : 0.f;
+            }
+        } else {
+            const bool pix_ok = (h0 + th_t < H) && (w0 + tw_t < W);
+            const float* dyp = dy + ((size_t)n * K + k0 + wave) * plane_hw + (size_t)(h0 + th_t) * W + (w0 + tw_t);
+#pragma unroll
+            for (int j = 0; j < DY_IT; ++j) {
+                const bool ok = pix_ok && (k0 + wave + 4 * j < K);
+                float v = *(ok ? dyp + (size_t)(4 * j) * plane_hw : dy);
+                dyr[j] = ok ? v : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < X_IT; ++j) {
+                const int mt = xmeta[j];
+                const int h = h0 - 1 + (mt & 15), w = w0 - 1 + ((mt >> 4) & 63);
+                const bool ok = (tid + 256 * j < X_ELEMS) && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W &&
+                                (c0 + ((mt >> 10) & 127) < C);
+                float v = *(ok ? xp + xoff[j] : x);
+                xr[j] = ok ? v : 0.f;
+            }
         }
     };
     auto store_stage = [&]() {
+        if constexpr (VEC) {
 #pragma unroll
-        for (int j = 0; j < DY_ITERS; ++j) dys[dy_lds + 4 * j * G::LDP] = dyr[j];
+            for (int j = 0; j < DY_IT; ++j) {
+                float* d = dys + dydst[j];
+                d[0] = dyv[j].x; d[1] = dyv[j].y; d[2] = dyv[j].z; d[3] = dyv[j].w;
+            }
 #pragma unroll
-        for (int j = 0; j < X_ITERS; ++j)
-            if (tid + 256 * j < X_ELEMS) xs[xmeta[j] >> 17] = xr[j];
+            for (int j = 0; j < X_IT; ++j) {
+                if (tid + 256 * j < XV_ELEMS) {
+                    float* d = xs + ((xmeta[j] >> 8) & 0xffff);
+                    d[0] = xv[j].x; d[1] = xv[j].y; d[2] = xv[j].z; d[3] = xv[j].w;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < H_IT; ++j)
+                if (tid + 256 * j < XROWS * 2) xs[(hmeta[j] >> 8) & 0xffff] = hv[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < DY_IT; ++j) dys[dy_lds + 4 * j * G::LDP] = dyr[j];
+#pragma unroll
+            for (int j = 0; j < X_IT; ++j)
+                if (tid + 256 * j < X_ELEMS) xs[xmeta[j] >> 17] = xr[j];
+        }
     };
 
     if (st_begin < st_end) load_stage(st_begin);
@@ -398,9 +483,14 @@ int clhip_conv3x3_bwd_weight(const float* x, const float* dy, float* dw, float* 
         else if (p.TW == 16) hipLaunchKernelGGL((conv3x3_wgrad_smallc_kernel<16, 4>), dim3(grid), dim3(256), 0, s, WG_ARGS, p.slab);
         else hipLaunchKernelGGL((conv3x3_wgrad_smallc_kernel<8, 8>), dim3(grid), dim3(256), 0, s, WG_ARGS, p.slab);
     } else {
-        if (p.TW == 32) hipLaunchKernelGGL((conv3x3_wgrad_kernel<32, 2>), dim3(grid), dim3(256), 0, s, WG_ARGS, p.c_tiles, p.slab);
-        else if (p.TW == 16) hipLaunchKernelGGL((conv3x3_wgrad_kernel<16, 4>), dim3(grid), dim3(256), 0, s, WG_ARGS, p.c_tiles, p.slab);
-        else hipLaunchKernelGGL((conv3x3_wgrad_kernel<8, 8>), dim3(grid), dim3(256), 0, s, WG_ARGS, p.c_tiles, p.slab);
+        // 16-byte staging needs aligned rows and whole tiles along w
+        const bool vec = (W % 4 == 0) && (W % p.TW == 0) && aligned16(x) && aligned16(dy);
+#define WG_LAUNCH(TW_, TH_) do { if (vec) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TW_, TH_, true>), dim3(grid), dim3(256), 0, s, WG_ARGS, p.c_tiles, p.slab); \
+                                 else hipLaunchKernelGGL((conv3x3_wgrad_kernel<TW_, TH_, false>), dim3(grid), dim3(256), 0, s, WG_ARGS, p.c_tiles, p.slab); } while (0)
+        if (p.TW == 32) WG_LAUNCH(32, 2);
+        else if (p.TW == 16) WG_LAUNCH(16, 4);
+        else WG_LAUNCH(8, 8);
+#undef WG_LAUNCH
     }
 #undef WG_ARGS
     CLHIP_LAUNCH_CHECK();
