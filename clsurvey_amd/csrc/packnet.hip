@@ -98,13 +98,13 @@ __global__ __launch_bounds__(PB) void packnet_step_kernel(float* __restrict__ th
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         float g = grad[i], th = theta[i];
         uint8_t mi = m ? m[i] : cur;
-        if (mi != cur) { g = 0.f; grad[i] = 0.f; }
+        if (m && mi != cur) { g = 0.f; grad[i] = 0.f; }
         float d = g;
         if (wd != 0.f) d = g + (wd * th) * (g != 0.f ? 1.f : 0.f);        // packnetSGD.py:40-43
         float b = first ? d : (buf[i] * momentum + d);
         buf[i] = b;
         th = th - lr * b;
-        if (mi == 0) th = 0.f;
+        if (m && mi == 0) th = 0.f;
         theta[i] = th;
     }
 }

@@ -246,7 +246,74 @@ def g9():
     save("G9_schedules", **out)
 
 
+
+
+# ------------------------------------------- G7 PackNet masks (bit-exact)
+def g7():
+    import methods.packnet.prune as PP
+    import methods.packnet.packnetSGD as PS
+    gen = np.random.RandomState(71)
+
+    class M(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.shared = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.ReLU(), nn.Conv2d(8, 12, 3, padding=1),
+                                        nn.ReLU(), nn.Linear(48, 40), nn.ReLU(), nn.Linear(40, 24))
+    m = M()
+    layers = [(i, mod) for i, mod in enumerate(m.shared.modules()) if isinstance(mod, (nn.Conv2d, nn.Linear))]
+    with torch.no_grad():
+        for _, mod in layers:
+            mod.weight.copy_(torch.from_numpy(gen.standard_normal(tuple(mod.weight.shape)).astype(np.float32) * 0.1))
+            mod.bias.copy_(torch.from_numpy(gen.standard_normal(tuple(mod.bias.shape)).astype(np.float32) * 0.1))
+        # exact ties around the cutoff and exact zeros, to pin the <= / kthvalue semantics
+        w0 = layers[0][1].weight
+        w0.view(-1)[:20] = 0.05
+        w0.view(-1)[20:30] = -0.05
+        w0.view(-1)[30:34] = 0.0
+    out = {"layer_idx": np.array([i for i, _ in layers])}
+    masks = {i: torch.zeros(mod.weight.shape, dtype=torch.uint8) for i, mod in layers}
+
+    def snap(tag):
+        for i, mod in layers:
+            out["%s_w%d" % (tag, i)] = np_(mod.weight)
+            out["%s_b%d" % (tag, i)] = np_(mod.bias)
+            if mod.weight.grad is not None:
+                out["%s_g%d" % (tag, i)] = np_(mod.weight.grad)
+                out["%s_gb%d" % (tag, i)] = np_(mod.bias.grad)
+
+    def snap_masks(tag, md):
+        for i, _ in layers:
+            out["%s_m%d" % (tag, i)] = md[i].numpy().copy()
+
+    snap("init")
+    for task, perc in ((1, 0.75), (2, 0.5)):
+        pr = PP.SparsePruner(m, perc, masks, False, False, task)
+        pr.make_finetuning_mask()
+        snap_masks("t%d_ft" % task, pr.current_masks)
+        opt = PS.PacknetSGD(m.parameters(), lr=0.05, momentum=0.9, weight_decay=5e-4)
+        for s in range(2):
+            for _, mod in layers:
+                mod.weight.grad = torch.from_numpy(gen.standard_normal(tuple(mod.weight.shape)).astype(np.float32))
+                mod.bias.grad = torch.from_numpy(gen.standard_normal(tuple(mod.bias.shape)).astype(np.float32))
+            for i, mod in layers:
+                out["t%d_s%d_rawg%d" % (task, s, i)] = np_(mod.weight.grad)
+                out["t%d_s%d_rawgb%d" % (task, s, i)] = np_(mod.bias.grad)
+            pr.make_grads_zero()
+            opt.step()
+            pr.make_pruned_zero()
+            snap("t%d_s%d" % (task, s))
+        pr.current_masks = None
+        pr.prune()
+        snap("t%d_pruned" % task)
+        snap_masks("t%d_pruned" % task, pr.current_masks)
+        masks = pr.current_masks
+    pr = PP.SparsePruner(m, 0.5, masks, False, False, 2)
+    pr.apply_mask(1)
+    snap("apply1")
+    save("G7_packnet", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g7", "g9"]
     for w in which:
         globals()[w]()

@@ -384,3 +384,87 @@ def test_si_golden_g4(golden):
         for i, p in enumerate(plist):
             assert_close(A.view("omega", p), torch.from_numpy(g["%s_cons_omega%d" % (tag, i)]), tol=2e-3, what="omega %d" % i)
             assert_close(A.view("init_val", p), torch.from_numpy(g["%s_cons_init%d" % (tag, i)]), what="init %d" % i)
+
+
+def test_packnet_masks_bit_exact_g7(golden):
+    """SparsePruner / PacknetSGD on the device vs the reference's own masks & weights (bit-exact masks)."""
+    import torch.nn as nn
+    from clsurvey_amd.methods import packnet as PK
+    g = golden("G7_packnet")
+
+    class M(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.shared = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.ReLU(), nn.Conv2d(8, 12, 3, padding=1),
+                                        nn.ReLU(), nn.Linear(48, 40), nn.ReLU(), nn.Linear(40, 24))
+    m = M().to(dev())
+    layers = [(i, mod) for i, mod in enumerate(m.shared.modules()) if isinstance(mod, (nn.Conv2d, nn.Linear))]
+    assert [i for i, _ in layers] == [int(i) for i in g["layer_idx"]]
+    with torch.no_grad():
+        for i, mod in layers:
+            mod.weight.copy_(torch.from_numpy(g["init_w%d" % i]))
+            mod.bias.copy_(torch.from_numpy(g["init_b%d" % i]))
+    masks = {i: torch.zeros(mod.weight.shape, dtype=torch.uint8, device=dev()) for i, mod in layers}
+    for task, perc in ((1, 0.75), (2, 0.5)):
+        pr = PK.SparsePruner(m, perc, masks, False, False, task)
+        pr.make_finetuning_mask()
+        for i, _ in layers:
+            assert torch.equal(pr.current_masks[i].cpu(), torch.from_numpy(g["t%d_ft_m%d" % (task, i)]))
+        opt = PK.PacknetSGD(m.parameters(), lr=0.05, momentum=0.9, weight_decay=5e-4)
+        for s in range(2):
+            for i, mod in layers:
+                mod.weight.grad = torch.from_numpy(g["t%d_s%d_rawg%d" % (task, s, i)]).to(dev())
+                mod.bias.grad = torch.from_numpy(g["t%d_s%d_rawgb%d" % (task, s, i)]).to(dev())
+            pr.make_grads_zero()
+            opt.step()
+            pr.make_pruned_zero()
+            for i, mod in layers:
+                assert_close(mod.weight.data, torch.from_numpy(g["t%d_s%d_w%d" % (task, s, i)]), tol=1e-6, what="w")
+                assert torch.equal(mod.bias.data.cpu(), torch.from_numpy(g["t%d_s%d_b%d" % (task, s, i)]))
+                assert torch.equal(mod.weight.data.cpu() == 0, torch.from_numpy(g["t%d_s%d_w%d" % (task, s, i)]) == 0)
+            with torch.no_grad():     # stay bit-aligned with the fixture for the exact mask comparison below
+                for i, mod in layers:
+                    mod.weight.copy_(torch.from_numpy(g["t%d_s%d_w%d" % (task, s, i)]))
+        pr.current_masks = None
+        pr.prune()
+        for i, mod in layers:
+            assert torch.equal(pr.current_masks[i].cpu(), torch.from_numpy(g["t%d_pruned_m%d" % (task, i)])), \
+                "mask layer %d task %d" % (i, task)
+            assert torch.equal(mod.weight.data.cpu(), torch.from_numpy(g["t%d_pruned_w%d" % (task, i)]))
+        masks = pr.current_masks
+    pr = PK.SparsePruner(m, 0.5, masks, False, False, 2)
+    pr.apply_mask(1)
+    for i, mod in layers:
+        assert torch.equal(mod.weight.data.cpu(), torch.from_numpy(g["apply1_w%d" % i]))
+
+
+def test_packnet_kth_abs_large_and_fused_tail():
+    """radix select == numpy partition on 4.7M weights (wide_VGG9 conv size); fused do_batch tail ==
+    the three separate reference steps."""
+    from clsurvey_amd.methods import packnet as PK
+    from oracle import packnet_ref as P
+    gen = np.random.RandomState(3)
+    n = 512 * 512 * 9 * 2
+    w = (gen.standard_normal(n) * 0.05).astype(np.float32)
+    w[::1000] = 0.0
+    mask = gen.randint(0, 4, size=n).astype(np.uint8)
+    wd_, md_ = torch.from_numpy(w).to(dev()), torch.from_numpy(mask).to(dev())
+    for k in (1, 17, (mask == 2).sum() // 2, (mask == 2).sum()):
+        ref = np.partition(np.abs(w[mask == 2]), k - 1)[k - 1]
+        got = PK.kth_abs(wd_, md_, 2, int(k)).item()
+        assert got == float(ref), (k, got, ref)
+    # fused tail
+    n = 100003
+    th, gr = (gen.standard_normal(n) * 0.1).astype(np.float32), gen.standard_normal(n).astype(np.float32)
+    mk = gen.randint(0, 4, size=n).astype(np.uint8)
+    buf0 = (gen.standard_normal(n) * 0.01).astype(np.float32)
+    for first in (True, False):
+        g2 = P.make_grads_zero(gr, mk, 2)
+        t_ref, b_ref = P.packnet_sgd_step(th, g2, None if first else buf0, 0.05, 0.9, 5e-4, first)
+        t_ref = P.make_pruned_zero(t_ref, mk)
+        t, g_, b = (torch.from_numpy(a.copy()).to(dev()) for a in (th, gr, buf0))
+        PK.fused_batch_tail(t, g_, b, torch.from_numpy(mk).to(dev()), 2, 0.05, 0.9, 5e-4, first)
+        assert_close(t, torch.from_numpy(t_ref), tol=1e-6)
+        assert_close(b, torch.from_numpy(b_ref), tol=1e-6)
+        assert torch.equal(g_.cpu(), torch.from_numpy(g2))
+        assert torch.equal(t.cpu() == 0, torch.from_numpy(t_ref) == 0)

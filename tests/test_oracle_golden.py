@@ -129,3 +129,41 @@ def test_g9_set_lr_traces(golden):
             for (ep, lr, cont), r in zip(tr, ref):
                 assert ep == int(r[0]) and cont == bool(r[2])
                 assert abs(lr - r[1]) <= 1e-12 * max(1.0, r[1])
+
+
+def test_g7_packnet_masks_bit_exact(golden):
+    """SparsePruner / PacknetSGD (reference) vs oracle/packnet_ref.py: masks bit-exact, weights exact."""
+    from oracle import packnet_ref as P
+    g = golden("G7_packnet")
+    layers = [int(i) for i in g["layer_idx"]]
+    w = {i: g["init_w%d" % i].copy() for i in layers}
+    b = {i: g["init_b%d" % i].copy() for i in layers}
+    masks = {i: np.zeros(w[i].shape, dtype=np.uint8) for i in layers}
+    for task, perc in ((1, 0.75), (2, 0.5)):
+        masks = {i: P.make_finetuning_mask(masks[i], task) for i in layers}
+        for i in layers:
+            assert np.array_equal(masks[i], g["t%d_ft_m%d" % (task, i)])
+        buf = {i: None for i in layers}
+        bbuf = {i: None for i in layers}
+        for s in range(2):
+            for i in layers:
+                gr = P.make_grads_zero(g["t%d_s%d_rawg%d" % (task, s, i)], masks[i], task)
+                # the reference adds the weight-decay term to .grad in place (d_p.add_) before we could
+                # snapshot it, so compare the exact zero set here and the weights below
+                assert np.array_equal(gr == 0, g["t%d_s%d_g%d" % (task, s, i)] == 0)
+                w[i], buf[i] = P.packnet_sgd_step(w[i], gr, buf[i], 0.05, 0.9, 5e-4, s == 0)
+                w[i] = P.make_pruned_zero(w[i], masks[i])
+                np.testing.assert_allclose(w[i], g["t%d_s%d_w%d" % (task, s, i)], rtol=1e-6, atol=1e-8)
+                # biases: train_bias=False -> grads zeroed -> wd term masked out too -> unchanged
+                gb = np.zeros_like(b[i])
+                b[i], bbuf[i] = P.packnet_sgd_step(b[i], gb, bbuf[i], 0.05, 0.9, 5e-4, s == 0)
+                assert np.array_equal(b[i], g["t%d_s%d_b%d" % (task, s, i)])
+            w = {i: g["t%d_s%d_w%d" % (task, s, i)].copy() for i in layers}   # stay bit-aligned with the fixture
+        for i in layers:
+            w[i], masks[i], cutoff, k = P.prune(w[i], masks[i], task, perc)
+            assert np.array_equal(masks[i], g["t%d_pruned_m%d" % (task, i)]), "mask layer %d task %d" % (i, task)
+            assert np.array_equal(w[i], g["t%d_pruned_w%d" % (task, i)])
+    for i in layers:
+        assert np.array_equal(P.apply_mask(w[i], masks[i], 1), g["apply1_w%d" % i])
+    # banker's rounding of the cutoff rank (prune.py:32)
+    assert P.cutoff_rank(0.5, 5) == 2 and P.cutoff_rank(0.5, 7) == 4 and P.cutoff_rank(0.9, 215) == 194
