@@ -47,6 +47,15 @@ SIGNATURES = {
     "clhip_mask_grad_zero": (_i, [_p, _p, _z, _i, _p]),
     "clhip_mask_weight_zero": (_i, [_p, _p, _z, _i, _i, _p]),
     "clhip_packnet_sgd_step": (_i, [_p, _p, _p, _p, _z, _i, _f, _f, _f, _i, _p]),
+    "clhip_hat_gate": (_i, [_p, _i, _f, _p, _p]),
+    "clhip_hat_scale_weight": (_i, [_p, _p, _p, _z, _z, _z, _p]),
+    "clhip_hat_weight_grad": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "clhip_hat_emb_grad": (_i, [_p, _p, _p, _i, _f, _f, _p, _p]),
+    "clhip_hat_reg_sums": (_i, [_p, _p, _i, _p, _p]),
+    "clhip_hat_backmask": (_i, [_p, _p, _p, _z, _z, _z, _p]),
+    "clhip_hat_sgd_ws": (_z, []),
+    "clhip_hat_sgd_step": (_i, [_p, _p, _p, _p, _z, _f, _f, _f, _i, _i, _f, _f, _f, _f, _i, _p, _z, _p]),
+    "clhip_clamp": (_i, [_p, _z, _f, _f, _p]),
     "clhip_net_create": (_i, [C.POINTER(LayerDesc), _i, _i, _i, _i, _i, C.POINTER(_p)]),
     "clhip_net_destroy": (None, [_p]),
     "clhip_net_workspace_bytes": (_z, [_p]),

@@ -1,0 +1,224 @@
+"""HAT on the HIP path — mirror of src/methods/HAT/networks/vgg_hat.py (Net), approaches/hat.py (Appr:
+init_masks, criterion, train_epoch step) and HAT_utils.py (HAT_SGD).
+
+The per-channel gates are folded into the NEXT layer's weights (see csrc/hat.hip), so the un-gated
+activations flow through the ordinary NetEngine plan; only parameter-sized kernels are HAT specific.
+"""
+import copy
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from .._lib import check
+from ..net import NetEngine
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class HatNet(nn.Module):
+    """Same parameter tree as vgg_hat.Net (vgg_hat.py:14-81): convs, conv_embs, fcs, fc_embs, classifier."""
+
+    def __init__(self, rawmodel, inputsize, taskcla, uniform_init=True):
+        super().__init__()
+        self.taskcla = taskcla
+        self.convs, self.conv_embs = nn.ModuleList(), nn.ModuleList()
+        self.fcs, self.fc_embs = nn.ModuleList(), nn.ModuleList()
+        self.classifier = nn.ModuleList()
+        self.maxpool_idxs = []
+        conv_idx = 0
+        for mod in rawmodel.features.children():
+            if isinstance(mod, nn.Conv2d):
+                self.convs.append(copy.deepcopy(mod))
+                self.conv_embs.append(nn.Embedding(len(taskcla), mod.out_channels))
+                conv_idx += 1
+            elif isinstance(mod, nn.MaxPool2d):
+                self.maxpool_idxs.append(conv_idx - 1)
+        fcs = [m for m in rawmodel.classifier.children() if isinstance(m, nn.Linear)]
+        for i, mod in enumerate(fcs):
+            if i < len(fcs) - 1:
+                self.fcs.append(copy.deepcopy(mod))
+                self.fc_embs.append(nn.Embedding(len(taskcla), mod.out_features))
+            else:
+                self.classifier.append(copy.deepcopy(mod))
+        smid_sq = self.fcs[0].in_features / self.convs[-1].out_channels
+        self.smid = int(smid_sq ** 0.5)
+        assert self.convs[-1].out_channels * self.smid * self.smid == self.fcs[0].in_features
+        self.enable_warmup = True
+        self.smax = None
+        self.lamb = None
+        if uniform_init:
+            for emb in list(self.conv_embs) + list(self.fc_embs):
+                emb.weight.data.uniform_(0, 2)
+
+    def plain_view(self):
+        """features / classifier Sequentials over the SAME Conv2d / Linear modules (for NetEngine)."""
+        feats = []
+        for i, c in enumerate(self.convs):
+            feats += [c, nn.ReLU(inplace=True)]
+            if i in self.maxpool_idxs:
+                feats.append(nn.MaxPool2d(2, 2))
+        cls = []
+        for f in self.fcs:
+            cls += [f, nn.ReLU(True)]
+        cls.append(self.classifier[0])
+        view = nn.Module()
+        view.features = nn.Sequential(*feats)
+        view.classifier = nn.Sequential(*cls)
+        return view
+
+
+class HatEngine:
+    """forward / criterion / backward of vgg_hat.Net.forward + Appr.criterion for one batch."""
+
+    def __init__(self, net, max_batch, in_shape, device="cuda"):
+        self.net = net.to(device)
+        self.device = torch.device(device)
+        self.view = net.plain_view()
+        self.engine = NetEngine(self.view, max_batch, in_shape, device)
+        self.A = self.engine.arena
+        self.scaled = torch.zeros_like(self.A.theta)
+        self.layers = list(net.convs) + list(net.fcs) + [net.classifier[0]]          # in plan order
+        self.embs = list(net.conv_embs) + list(net.fc_embs)                           # gate l follows layer l
+        self.nc = len(net.convs)
+        self.gate = [torch.zeros(e.weight.shape[1], device=self.device) for e in self.embs]
+        self.dgate = [torch.zeros_like(g) for g in self.gate]
+        self.reg_sums = torch.zeros(2, dtype=torch.float64, device=self.device)
+        self.ws = torch.zeros(_lib.lib().clhip_hat_sgd_ws(), dtype=torch.uint8, device=self.device)
+        for e in self.embs:
+            e.weight.grad = torch.zeros_like(e.weight.data)
+
+    def _R(self, li):
+        """inner repeat of layer li's input-channel index in its weight layout [K][C][R]."""
+        if li < self.nc:
+            return 9
+        if li == self.nc:
+            return self.net.smid * self.net.smid
+        return 1
+
+    def gates(self, t, s):
+        L = _lib.lib()
+        for e, g in zip(self.embs, self.gate):
+            row = e.weight.data[t]
+            check(L.clhip_hat_gate(row.data_ptr(), row.numel(), float(s), g.data_ptr(), _stream()), "clhip_hat_gate")
+        return self.gate
+
+    def masks_at(self, t, s):
+        return [g.clone() for g in self.gates(t, s)]
+
+    def _scale_weights(self):
+        L = _lib.lib()
+        self.scaled.copy_(self.A.theta)                      # biases (and layer 0) as they are
+        for li in range(1, len(self.layers)):
+            w = self.layers[li].weight.data
+            off, n = self.A.slot(self.layers[li].weight)
+            gin = self.gate[li - 1]
+            R = self._R(li)
+            K, Cg = w.shape[0], gin.numel()
+            check(L.clhip_hat_scale_weight(w.data_ptr(), gin.data_ptr(), self.scaled[off:off + n].data_ptr(), K, Cg, R,
+                                           _stream()), "clhip_hat_scale_weight")
+
+    def step(self, t, x, y, s, mask_pre=None, lamb=0.0, count=None, backward=True, stats=None, want_logits=False):
+        """Returns (ce_loss[1] device, reg device scalar (lamb*reg), logits|None). With backward=True all
+        .grad fields (convs, fcs, head in the arena; embeddings dense with row t filled) are set."""
+        L = _lib.lib()
+        self.gates(t, s)
+        self._scale_weights()
+        ce, logits = self.engine.loss_step(x, y, "ce_mean", backward, stats, want_logits, params=self.scaled)
+        self.reg_sums.zero_()
+        for l, g in enumerate(self.gate):
+            mp = mask_pre[l] if mask_pre is not None else None
+            check(L.clhip_hat_reg_sums(g.data_ptr(), mp.data_ptr() if mp is not None else None, g.numel(),
+                                       self.reg_sums.data_ptr(), _stream()), "clhip_hat_reg_sums")
+        reg = lamb * self.reg_sums[0] / self.reg_sums[1]
+        if backward:
+            if count is None:
+                count = float(self.reg_sums[1].item())
+            for li in range(1, len(self.layers)):
+                wmod = self.layers[li]
+                off, n = self.A.slot(wmod.weight)
+                gw = self.A.grad[off:off + n]
+                gin = self.gate[li - 1]
+                check(L.clhip_hat_weight_grad(gw.data_ptr(), wmod.weight.data.data_ptr(), gin.data_ptr(), gw.data_ptr(),
+                                              self.dgate[li - 1].data_ptr(), wmod.weight.shape[0], gin.numel(),
+                                              self._R(li), _stream()), "clhip_hat_weight_grad")
+            for l, e in enumerate(self.embs):
+                e.weight.grad.zero_()
+                mp = mask_pre[l] if mask_pre is not None else None
+                row = e.weight.grad[t]
+                check(L.clhip_hat_emb_grad(self.dgate[l].data_ptr(), self.gate[l].data_ptr(),
+                                           mp.data_ptr() if mp is not None else None, row.numel(), float(s),
+                                           float(lamb) / count, row.data_ptr(), _stream()), "clhip_hat_emb_grad")
+        return ce, reg, logits
+
+
+def init_masks(hat, current_task, smax):
+    """hat.py:58-89 on the device: (mask_pre list, mask_back {param name: tensor})."""
+    L = _lib.lib()
+    mask_pre = None
+    for t in range(current_task):
+        m = hat.masks_at(t, smax)
+        mask_pre = m if mask_pre is None else [torch.max(a, b) for a, b in zip(mask_pre, m)]
+    mask_back = {}
+    if mask_pre is None:
+        return None, mask_back
+    net, nc = hat.net, hat.nc
+
+    def bm(post, pre, shape, C, R):
+        out = torch.empty(shape, dtype=torch.float32, device=hat.device)
+        check(L.clhip_hat_backmask(post.data_ptr(), pre.data_ptr() if pre is not None else None, out.data_ptr(),
+                                   shape[0], C, R, _stream()), "clhip_hat_backmask")
+        return out
+    for i, conv in enumerate(net.convs):
+        pre = mask_pre[i - 1] if i > 0 else None
+        mask_back["convs.%d.weight" % i] = bm(mask_pre[i], pre, tuple(conv.weight.shape), conv.in_channels, 9)
+        if i > 0:          # vgg_hat.py:268-276: convs.0.bias falls through to None
+            mask_back["convs.%d.bias" % i] = bm(mask_pre[i], None, tuple(conv.bias.shape), 1, 1)
+    for i, fc in enumerate(net.fcs):
+        pre = mask_pre[nc + i - 1] if i > 0 else mask_pre[nc - 1]
+        R = net.smid * net.smid if i == 0 else 1
+        mask_back["fcs.%d.weight" % i] = bm(mask_pre[nc + i], pre, tuple(fc.weight.shape), pre.numel(), R)
+        if i > 0:          # fcs.0.bias falls through to None as well (vgg_hat.py:278-293)
+            mask_back["fcs.%d.bias" % i] = bm(mask_pre[nc + i], None, tuple(fc.bias.shape), 1, 1)
+    return mask_pre, mask_back
+
+
+class HAT_SGD(torch.optim.Optimizer):
+    """HAT_utils.py:185-250."""
+
+    def __init__(self, params, lr, momentum=0, dampening=0, weight_decay=0, nesterov=False):
+        super().__init__(params, dict(lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay,
+                                      nesterov=nesterov))
+        self._ws = None
+
+    def step(self, model, mask_back, t, s=None, thres_cosh=None, smax=None, clipgrad=None, finetune=False, closure=None):
+        L = _lib.lib()
+        for group in self.param_groups:
+            for p, (name, modp) in zip(group["params"], model.named_parameters()):
+                assert modp is p
+                if p.grad is None:
+                    continue
+                if self._ws is None:
+                    self._ws = torch.zeros(L.clhip_hat_sgd_ws(), dtype=torch.uint8, device=p.device)
+                st = self.state[p]
+                first = "momentum_buffer" not in st
+                if first:
+                    st["momentum_buffer"] = torch.zeros_like(p.data)
+                mb = mask_back.get(name) if t > 0 else None
+                check(L.clhip_hat_sgd_step(p.data.data_ptr(), p.grad.data.data_ptr(), st["momentum_buffer"].data_ptr(),
+                                           mb.data_ptr() if mb is not None else None, p.numel(), float(group["lr"]),
+                                           float(group["momentum"]), float(group["weight_decay"]), int("embs" in name),
+                                           int(finetune), float(s), float(smax), float(thres_cosh), float(clipgrad),
+                                           int(first), self._ws.data_ptr(), self._ws.numel(), _stream()),
+                      "clhip_hat_sgd_step")
+        return None
+
+
+def clamp_embeddings(net, thres_emb=6.0):
+    """hat.py:238-240."""
+    L = _lib.lib()
+    for n, p in net.named_parameters():
+        if "embs" in n:
+            check(L.clhip_clamp(p.data.data_ptr(), p.numel(), -thres_emb, thres_emb, _stream()), "clhip_clamp")

@@ -130,6 +130,33 @@ int clhip_mask_weight_zero(float* w, const uint8_t* mask_u8, size_t n, int mode,
 int clhip_packnet_sgd_step(float* theta, float* grad, float* buf, const uint8_t* mask_u8, size_t n, int cur,
                            float lr, float momentum, float wd, int first, void* stream);
 
+/* ------------------------------------------------------------------ HAT gates / back-masks / HAT_SGD
+ * methods/HAT/networks/vgg_hat.py, approaches/hat.py, HAT_utils.py.  Gates multiply layer outputs in the
+ * reference (vgg_hat.py:104-116); here they are folded into the NEXT layer's weights
+ * (W'[k][c][r] = W[k][c][r]*gate[c]) so the conv/FC kernels run unchanged on un-gated activations.
+ *   hat_gate        (:121-127)  gate = sigmoid(s * emb_row)
+ *   hat_scale_weight            out = w * gate_in[c]   (w viewed as [K][C][R]; gate_in NULL => copy)
+ *   hat_weight_grad             dw = g_wprime * gate_in[c] ; dgate_in[c] = sum_{k,r} g_wprime * w
+ *   hat_emb_grad                demb = (dgate + lamb_over_count*(1-mask_pre)) * s*a*(1-a)   (hat.py:285-299)
+ *   hat_reg_sums                sums2[0] += sum gate*(1-mask_pre); sums2[1] += sum (1-mask_pre)
+ *   hat_backmask    (:258-295)  out[k][c][r] = 1 - min(a_post[k], a_pre[c])   (a_pre NULL => 1 - a_post[k])
+ *   hat_sgd_step    (HAT_utils.py:192-250) wd (not on embs), grad *= mask_back, embedding compensation
+ *                   (smax/s)*(cosh(clamp(s*e,+-thres))+1)/(cosh(e)+1), clip_grad_norm(p, clipgrad), momentum SGD
+ *   clamp           (hat.py:238-240) embeddings to +-6                                               */
+int clhip_hat_gate(const float* emb_row, int n, float s, float* gate, void* stream);
+int clhip_hat_scale_weight(const float* w, const float* gate_in, float* out, size_t K, size_t C, size_t R, void* stream);
+int clhip_hat_weight_grad(const float* g_wprime, const float* w, const float* gate_in, float* dw, float* dgate_in,
+                          int K, int C, int R, void* stream);
+int clhip_hat_emb_grad(const float* dgate, const float* gate, const float* mask_pre, int n, float s,
+                       float lamb_over_count, float* demb, void* stream);
+int clhip_hat_reg_sums(const float* gate, const float* mask_pre, int n, double* sums2, void* stream);
+int clhip_hat_backmask(const float* a_post, const float* a_pre, float* out, size_t K, size_t C, size_t R, void* stream);
+size_t clhip_hat_sgd_ws(void);
+int clhip_hat_sgd_step(float* theta, float* grad, float* buf, const float* mask_back, size_t n, float lr,
+                       float momentum, float wd, int is_emb, int finetune, float s, float smax, float thres_cosh,
+                       float clipgrad, int first, void* ws, size_t ws_bytes, void* stream);
+int clhip_clamp(float* x, size_t n, float lo, float hi, void* stream);
+
 /* ------------------------------------------------------------------ static-plan net executor
  * One call per pass for VGG-style nets instead of one Python dispatch per op
  * (replaces `outputs = model(inputs); loss.backward()` of EWC/train_EWC.py:181-187,

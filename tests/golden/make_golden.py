@@ -313,7 +313,61 @@ def g7():
     save("G7_packnet", **out)
 
 
+# ------------------------------------------- G8 HAT gates / criterion / HAT_SGD
+def g8():
+    import methods.HAT.networks.vgg_hat as VH
+    import methods.HAT.approaches.hat as HA
+    import methods.HAT.HAT_utils as HU
+    torch.cuda.LongTensor = torch.LongTensor
+    raw, params = build("tiny_VGG9", TINY, (24, 24), 5, 32, seed=81)
+    gen = np.random.RandomState(82)
+    taskcla = [(0, 5), (1, 5), (2, 5)]
+    net = VH.Net(raw, (3, 32, 32), taskcla, uniform_init=True)
+    with torch.no_grad():
+        for emb in list(net.conv_embs) + list(net.fc_embs):
+            emb.weight.copy_(torch.from_numpy(gen.uniform(-1.5, 2.0, size=tuple(emb.weight.shape)).astype(np.float32)))
+    out = {}
+    names = [n for n, _ in net.named_parameters()]
+    out["param_names"] = np.array(names)
+    for n, p in net.named_parameters():
+        out["p_" + n] = np_(p)
+    smax, lamb, t = 50.0, 0.75, 1
+    mask_pre, mask_back = HA.Appr.init_masks(t, net, smax)
+    for i, mp in enumerate(mask_pre):
+        out["mask_pre%d" % i] = np_(mp)
+    for n, v in mask_back.items():
+        out["mask_back_" + n] = np_(v)
+    appr = HA.Appr.__new__(HA.Appr)
+    appr.mask_pre, appr.lamb, appr.ce = mask_pre, lamb, torch.nn.CrossEntropyLoss()
+    opt = HU.HAT_SGD(net.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
+    task = torch.LongTensor([t])
+    net.train()
+    for step, s in enumerate((7.3, 23.0)):
+        x, y = data(gen, 8, 32, 5)
+        out["x%d" % step], out["y%d" % step] = np_(x), np_(y)
+        output, masks = net.forward(task, x, s=s)
+        loss, reg = appr.criterion(output, y, masks)
+        opt.zero_grad()
+        loss.backward()
+        out["s%d_logits" % step], out["s%d_loss" % step], out["s%d_reg" % step] = np_(output), np_(loss), np_(reg)
+        for i, mk in enumerate(masks):
+            out["s%d_mask%d" % (step, i)] = np_(mk)
+        for n, p in net.named_parameters():
+            if p.grad is not None:
+                out["s%d_rawgrad_%s" % (step, n)] = np_(p.grad)
+        opt.step(net, mask_back, t, s, 50, smax, 10000)
+        for n, p in net.named_parameters():
+            if "embs" in n:
+                p.data = torch.clamp(p.data, -6, 6)
+        for n, p in net.named_parameters():
+            out["s%d_theta_%s" % (step, n)] = np_(p)
+            if p in opt.state and "momentum_buffer" in opt.state[p]:
+                out["s%d_buf_%s" % (step, n)] = np_(opt.state[p]["momentum_buffer"])
+    out["hyper"] = np.array([smax, lamb, t, 0.05, 0.9, 1e-4])
+    save("G8_hat", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g7", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g7", "g8", "g9"]
     for w in which:
         globals()[w]()

@@ -468,3 +468,44 @@ def test_packnet_kth_abs_large_and_fused_tail():
         assert_close(b, torch.from_numpy(b_ref), tol=1e-6)
         assert torch.equal(g_.cpu(), torch.from_numpy(g2))
         assert torch.equal(t.cpu() == 0, torch.from_numpy(t_ref) == 0)
+
+
+def test_hat_step_golden_g8(golden):
+    """vgg_hat.Net.forward + Appr.criterion + backward + HAT_SGD.step (x2) + clamp vs the reference (G8)."""
+    import torch.nn as nn
+    from clsurvey_amd import models
+    from clsurvey_amd.methods import hat as HT
+    g = golden("G8_hat")
+    smax, lamb, t, lr, mom, wd = [float(v) for v in g["hyper"]]
+    t = int(t)
+    raw = models.VGGSlim(cfg=TINY, num_classes=5, classifier_inputdim=32 * 2 * 2, classifier_dim1=24, classifier_dim2=24)
+    net = HT.HatNet(raw, (3, 32, 32), [(0, 5), (1, 5), (2, 5)])
+    names = [str(n) for n in g["param_names"]]
+    assert [n for n, _ in net.named_parameters()] == names
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            p.copy_(torch.from_numpy(g["p_" + n]))
+    hat = HT.HatEngine(net, 8, (3, 32, 32), dev())
+    mask_pre, mask_back = HT.init_masks(hat, t, smax)
+    for i, mp in enumerate(mask_pre):
+        assert_close(mp, torch.from_numpy(g["mask_pre%d" % i]).view(-1), tol=1e-6, what="mask_pre")
+    gold_mb = {k[len("mask_back_"):] for k in g.files if k.startswith("mask_back_")}
+    assert set(mask_back) == gold_mb
+    for n, v in mask_back.items():
+        assert_close(v, torch.from_numpy(g["mask_back_" + n]), tol=1e-6, what="mask_back " + n)
+    opt = HT.HAT_SGD(net.parameters(), lr=lr, momentum=mom, weight_decay=wd)
+    count = None
+    for step, s in enumerate((7.3, 23.0)):
+        x, y = torch.from_numpy(g["x%d" % step]).to(dev()), torch.from_numpy(g["y%d" % step]).to(dev())
+        ce, reg, logits = hat.step(t, x, y, s, mask_pre, lamb, count, True, want_logits=True)
+        assert_close(logits, torch.from_numpy(g["s%d_logits" % step]), what="logits")
+        assert_close((ce + reg.float()).view(1), torch.from_numpy(g["s%d_loss" % step]).view(1), what="loss")
+        assert_close(reg.float().view(1), torch.from_numpy(g["s%d_reg" % step]).view(1), tol=1e-5, what="reg")
+        for n, p in net.named_parameters():
+            key = "s%d_rawgrad_%s" % (step, n)
+            if key in g.files:
+                assert_close(p.grad, torch.from_numpy(g[key]), tol=5e-4, what="grad " + n)
+        opt.step(net, mask_back, t, s, 50, smax, 10000)
+        HT.clamp_embeddings(net)
+        for n, p in net.named_parameters():
+            assert_close(p.data, torch.from_numpy(g["s%d_theta_%s" % (step, n)]), tol=5e-4, what="theta " + n)

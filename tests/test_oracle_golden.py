@@ -167,3 +167,40 @@ def test_g7_packnet_masks_bit_exact(golden):
         assert np.array_equal(P.apply_mask(w[i], masks[i], 1), g["apply1_w%d" % i])
     # banker's rounding of the cutoff rank (prune.py:32)
     assert P.cutoff_rank(0.5, 5) == 2 and P.cutoff_rank(0.5, 7) == 4 and P.cutoff_rank(0.9, 215) == 194
+
+
+def _hat_params(g, prefix="p_"):
+    return {str(n): T(g[prefix + str(n)]) for n in g["param_names"]}
+
+
+def test_g8_hat_oracle(golden):
+    from oracle import hat_ref as H
+    g = golden("G8_hat")
+    smax, lamb, t, lr, mom, wd = [float(v) for v in g["hyper"]]
+    t = int(t)
+    P = _hat_params(g)
+    pool_after = {0, 1, 3, 5}        # TINY = [16,'M',16,'M',32,32,'M',32,32,'M']
+    mask_pre, mask_back = H.init_masks(P, t, smax)
+    for i, mp in enumerate(mask_pre):
+        close(mp, g["mask_pre%d" % i].reshape(-1), rtol=1e-6)
+    for n, v in mask_back.items():
+        close(v, g["mask_back_" + n], rtol=1e-6)
+    assert set(mask_back) == {k[len("mask_back_"):] for k in g.files if k.startswith("mask_back_")}
+    bufs = {n: None for n in P}
+    for step, s in enumerate((7.3, 23.0)):
+        x, y = T(g["x%d" % step]), T(g["y%d" % step])
+        leaf = {n: v.clone().requires_grad_(True) for n, v in P.items()}
+        logits, mk = H.forward(leaf, pool_after, t, x, s)
+        loss, reg = H.criterion(logits, y, mk, mask_pre, lamb)
+        loss.backward()
+        close(logits.detach(), g["s%d_logits" % step], rtol=2e-5)
+        close(loss.detach(), g["s%d_loss" % step], rtol=2e-5)
+        close(reg.detach(), g["s%d_reg" % step], rtol=2e-5)
+        for n in P:
+            if leaf[n].grad is None:
+                continue
+            P[n], bufs[n], _ = H.hat_sgd_step(n, P[n], leaf[n].grad, bufs[n], mask_back, t, s, smax, lr, mom, wd,
+                                              first=(step == 0))
+            if "embs" in n:
+                P[n] = torch.clamp(P[n], -6, 6)
+            close(P[n], g["s%d_theta_%s" % (step, n)], rtol=5e-5)
