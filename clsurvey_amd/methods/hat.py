@@ -174,14 +174,12 @@ def init_masks(hat, current_task, smax):
     for i, conv in enumerate(net.convs):
         pre = mask_pre[i - 1] if i > 0 else None
         mask_back["convs.%d.weight" % i] = bm(mask_pre[i], pre, tuple(conv.weight.shape), conv.in_channels, 9)
-        if i > 0:          # vgg_hat.py:268-276: convs.0.bias falls through to None
-            mask_back["convs.%d.bias" % i] = bm(mask_pre[i], None, tuple(conv.bias.shape), 1, 1)
+        mask_back["convs.%d.bias" % i] = bm(mask_pre[i], None, tuple(conv.bias.shape), 1, 1)      # :275-276
     for i, fc in enumerate(net.fcs):
         pre = mask_pre[nc + i - 1] if i > 0 else mask_pre[nc - 1]
         R = net.smid * net.smid if i == 0 else 1
         mask_back["fcs.%d.weight" % i] = bm(mask_pre[nc + i], pre, tuple(fc.weight.shape), pre.numel(), R)
-        if i > 0:          # fcs.0.bias falls through to None as well (vgg_hat.py:278-293)
-            mask_back["fcs.%d.bias" % i] = bm(mask_pre[nc + i], None, tuple(fc.bias.shape), 1, 1)
+        mask_back["fcs.%d.bias" % i] = bm(mask_pre[nc + i], None, tuple(fc.bias.shape), 1, 1)     # :292-293
     return mask_pre, mask_back
 
 
