@@ -56,6 +56,12 @@ SIGNATURES = {
     "clhip_hat_sgd_ws": (_z, []),
     "clhip_hat_sgd_step": (_i, [_p, _p, _p, _p, _z, _f, _f, _f, _i, _i, _f, _f, _f, _f, _i, _p, _z, _p]),
     "clhip_clamp": (_i, [_p, _z, _f, _f, _p]),
+    "clhip_softmax_ce_slice": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "clhip_net_loss_step_slice": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
+    "clhip_axpy": (_i, [_p, _p, _z, _f, _i, _p]),
+    "clhip_gem_gram_ws": (_z, [_i]),
+    "clhip_gem_gram": (_i, [_p, _z, C.POINTER(_i), _i, _z, _p, _p, _z, _p]),
+    "clhip_gem_project": (_i, [_p, _z, C.POINTER(_i), C.POINTER(_f), _i, _p, _p, _z, _p]),
     "clhip_net_create": (_i, [C.POINTER(LayerDesc), _i, _i, _i, _i, _i, C.POINTER(_p)]),
     "clhip_net_destroy": (None, [_p]),
     "clhip_net_workspace_bytes": (_z, [_p]),

@@ -204,9 +204,9 @@ int clhip_net_backward(void* handle, const float* params, float* grads, const fl
 
 // forward + loss (+ backward when grads != NULL) in one call.
 //   loss_kind 0: CrossEntropy mean   1: CrossEntropy sum   2: sum of squared logits (MAS)
-int clhip_net_loss_step(void* handle, const float* params, float* grads, const float* x, const int64_t* labels,
-                        int N, int loss_kind, void* ws, float* loss_out, double* stats, float* logits_out,
-                        void* stream) {
+int clhip_net_loss_step_slice(void* handle, const float* params, float* grads, const float* x, const int64_t* labels,
+                              int N, int loss_kind, int col_off, int ncols, void* ws, float* loss_out, double* stats,
+                              float* logits_out, void* stream) {
     NetPlan* p = static_cast<NetPlan*>(handle);
     if (!p || !ws || (loss_kind != 2 && !labels)) return CLHIP_EINVAL;
     char* base = static_cast<char*>(ws);
@@ -217,10 +217,18 @@ int clhip_net_loss_step(void* handle, const float* params, float* grads, const f
     const LayerPlan& last = p->layers.back();
     const float* logits = reinterpret_cast<float*>(base + p->off_acts) + last.act_off;
     if (loss_kind == 2) rc = clhip_mse_zero_sum(logits, (size_t)N * p->n_classes, dlogits, loss_dev, stream);
-    else rc = clhip_softmax_ce(logits, labels, N, p->n_classes, loss_kind, dlogits, loss_dev, stats, stream);
+    else rc = clhip_softmax_ce_slice(logits, labels, N, p->n_classes, col_off, ncols > 0 ? ncols : p->n_classes - col_off,
+                                     loss_kind, dlogits, loss_dev, stats, stream);
     if (rc) return rc;
     if (grads) rc = clhip_net_backward(handle, params, grads, x, N, ws, dlogits, stream);
     return rc;
+}
+
+int clhip_net_loss_step(void* handle, const float* params, float* grads, const float* x, const int64_t* labels,
+                        int N, int loss_kind, void* ws, float* loss_out, double* stats, float* logits_out,
+                        void* stream) {
+    return clhip_net_loss_step_slice(handle, params, grads, x, labels, N, loss_kind, 0, 0, ws, loss_out, stats,
+                                     logits_out, stream);
 }
 
 }  // extern "C"

@@ -22,8 +22,18 @@ __device__ __forceinline__ float wave_sum(float v) {
 // together) before any arithmetic, instead of one dependent round trip per row.
 template <int RB>
 __global__ __launch_bounds__(LOSS_BLOCK) void softmax_ce_kernel(
-    const float* __restrict__ logits, const int64_t* __restrict__ labels, int N, int C, int reduction,
-    float* __restrict__ dlogits, float* __restrict__ loss_out, double* __restrict__ stats) {
+    const float* __restrict__ logits_full, const int64_t* __restrict__ labels, int N, int C, int reduction,
+    float* __restrict__ dlogits_full, float* __restrict__ loss_out, double* __restrict__ stats, int ld, int col_off) {
+    // logits_full is [N][ld]; the loss is taken over columns [col_off, col_off + C) (labels are relative to
+    // the slice); dlogits outside the slice are written as 0.
+    const float* logits = logits_full + col_off;
+    float* dlogits = dlogits_full + col_off;
+    if (ld != C) {
+        for (size_t i = threadIdx.x; i < (size_t)N * ld; i += LOSS_BLOCK) {
+            int c = (int)(i % ld);
+            if (c < col_off || c >= col_off + C) dlogits_full[i] = 0.f;
+        }
+    }
     __shared__ float s_loss[16];
     __shared__ int s_corr[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -37,14 +47,14 @@ __global__ __launch_bounds__(LOSS_BLOCK) void softmax_ce_kernel(
 #pragma unroll
         for (int b = 0; b < RB; ++b) {
             int row = row0 + 16 * b;
-            zr[b] = (narrow && row < N && lane < C) ? logits[(size_t)row * C + lane] : -INFINITY;
+            zr[b] = (narrow && row < N && lane < C) ? logits[(size_t)row * ld + lane] : -INFINITY;
             yr[b] = (row < N) ? (int)labels[row] : 0;
         }
 #pragma unroll
         for (int b = 0; b < RB; ++b) {
             int row = row0 + 16 * b;
             if (row >= N) break;
-            const float* z = logits + (size_t)row * C;
+            const float* z = logits + (size_t)row * ld;
             const int y = yr[b];
             float m = -INFINITY;
             int am = 0x7fffffff;
@@ -67,7 +77,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void softmax_ce_kernel(
                 float ex = lane < C ? expf(zr[b] - gm) : 0.f;
                 se = wave_sum(ex);
                 const float lse = logf(se);
-                if (lane < C) dlogits[(size_t)row * C + lane] = (expf(zr[b] - gm - lse) - (lane == y ? 1.f : 0.f)) * scale;
+                if (lane < C) dlogits[(size_t)row * ld + lane] = (expf(zr[b] - gm - lse) - (lane == y ? 1.f : 0.f)) * scale;
                 zy = __shfl(zr[b], y, 64);
                 wl += -(zy - gm - lse);
             } else {
@@ -75,7 +85,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void softmax_ce_kernel(
                 se = wave_sum(se);
                 const float lse = logf(se);
                 for (int c = lane; c < C; c += 64)
-                    dlogits[(size_t)row * C + c] = (expf(z[c] - gm - lse) - (c == y ? 1.f : 0.f)) * scale;
+                    dlogits[(size_t)row * ld + c] = (expf(z[c] - gm - lse) - (c == y ? 1.f : 0.f)) * scale;
                 zy = z[y];
                 wl += -(zy - gm - lse);
             }
@@ -116,14 +126,20 @@ __global__ __launch_bounds__(LOSS_BLOCK) void mse_zero_sum_kernel(const float* _
 
 extern "C" {
 
-int clhip_softmax_ce(const float* logits, const int64_t* labels_i64, int N, int C, int reduction,
-                     float* dlogits, float* loss_out, double* stats, void* stream) {
-    if (!logits || !labels_i64 || !dlogits || !loss_out || N <= 0 || C <= 0) return CLHIP_EINVAL;
+int clhip_softmax_ce_slice(const float* logits, const int64_t* labels_i64, int N, int ld, int col_off, int ncols,
+                           int reduction, float* dlogits, float* loss_out, double* stats, void* stream) {
+    if (!logits || !labels_i64 || !dlogits || !loss_out || N <= 0 || ncols <= 0 || col_off < 0 || col_off + ncols > ld)
+        return CLHIP_EINVAL;
     if (reduction != 0 && reduction != 1) return CLHIP_EINVAL;
-    hipLaunchKernelGGL(softmax_ce_kernel<16>, dim3(1), dim3(LOSS_BLOCK), 0, as_stream(stream), logits, labels_i64, N, C,
-                       reduction, dlogits, loss_out, stats);
+    hipLaunchKernelGGL(softmax_ce_kernel<16>, dim3(1), dim3(LOSS_BLOCK), 0, as_stream(stream), logits, labels_i64, N, ncols,
+                       reduction, dlogits, loss_out, stats, ld, col_off);
     CLHIP_LAUNCH_CHECK();
     return 0;
+}
+
+int clhip_softmax_ce(const float* logits, const int64_t* labels_i64, int N, int C, int reduction,
+                     float* dlogits, float* loss_out, double* stats, void* stream) {
+    return clhip_softmax_ce_slice(logits, labels_i64, N, C, 0, C, reduction, dlogits, loss_out, stats, stream);
 }
 
 int clhip_mse_zero_sum(const float* logits, size_t n, float* dlogits, float* loss_out, void* stream) {

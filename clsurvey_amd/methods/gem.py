@@ -1,0 +1,153 @@
+"""GEM on the HIP path — mirror of src/methods/rehearsal/model/gem.py (Net.observe / forward /
+fill_buffer / manage_memory) with the exemplar ring buffer held as TENSORS in HBM.
+
+The reference stores exemplar *paths* and re-decodes n_memories JPEGs for every past task on every
+training batch (gem.py:233-235); here memory[t] is a device tensor and a past-task pass is
+ceil(n_memories / batch) engine calls.  Gradients of a task are one contiguous row of G (the
+ParamArena gradient is flat), the QP inputs come from ONE Gram-matrix pass, the tiny QP runs on the
+host in float64 (clsurvey_amd.methods.qp, restating quadprog's Goldfarb-Idnani).
+"""
+import copy
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from .._lib import check
+from ..data import DeviceLoader, TensorTaskDataset
+from ..net import NetEngine
+from ..optim import SGD
+from . import qp
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def compute_offsets(task_idx, cum_nc_per_task):
+    """rehearsal/model/common.py:106-118."""
+    o1 = 0 if task_idx == 0 else int(cum_nc_per_task[task_idx - 1])
+    return o1, int(cum_nc_per_task[task_idx])
+
+
+def extend_head(model, n_outputs):
+    """gem.py:99-113: replace the head by an n_outputs-way Linear whose first rows are the old head."""
+    last = str(len(model.classifier._modules) - 1)
+    old = copy.deepcopy(model.classifier._modules[last])
+    new = nn.Linear(old.in_features, n_outputs)
+    with torch.no_grad():
+        new.weight[:old.out_features].copy_(old.weight)
+        new.bias[:old.out_features].copy_(old.bias)
+    model.classifier._modules[last] = new
+    return model
+
+
+class GemNet:
+    def __init__(self, model, n_outputs, n_tasks, nc_per_task, n_memories, lr, weight_decay=0.0, memory_strength=1.0,
+                 batch_size=200, in_shape=(3, 64, 64), device="cuda"):
+        self.net = model.to(device)
+        self.device = torch.device(device)
+        self.n_outputs, self.n_tasks, self.n_memories = n_outputs, n_tasks, n_memories
+        self.batch_size = batch_size
+        self.engine = NetEngine(self.net, max(batch_size, 1), in_shape, device)
+        self.A = self.engine.arena
+        self.G = torch.zeros((n_tasks, self.A.numel), dtype=torch.float32, device=self.device)   # gem.py:131
+        self.memory_x = torch.zeros((n_tasks, n_memories) + tuple(in_shape), dtype=torch.float32, device=self.device)
+        self.memory_labels = torch.zeros((n_tasks, n_memories), dtype=torch.int64, device=self.device)
+        self.cum_nc_per_task = [sum(nc_per_task[:i + 1]) for i in range(len(nc_per_task))]
+        self.observed_tasks, self.old_task, self.mem_cnt = [], -1, 0
+        self.margin = memory_strength
+        self.opt = SGD(self.net.parameters(), lr, momentum=0.9, weight_decay=weight_decay)       # gem.py:151
+        L = _lib.lib()
+        self._gram_ws = torch.zeros(L.clhip_gem_gram_ws(16), dtype=torch.uint8, device=self.device)
+        self._gram = torch.zeros(16 * 16, dtype=torch.float64, device=self.device)
+        self.stats = torch.zeros(2, dtype=torch.float64, device=self.device)
+
+    # ------------------------------------------------------------------ memory
+    def init_new_task(self, t):
+        self.observed_tasks.append(t)
+        self.old_task = t
+
+    def fill_buffer(self, t, x, y):
+        """gem.py:322-345 (ring buffer; exemplar tensors instead of paths)."""
+        bsz = y.shape[0]
+        endcnt = min(self.mem_cnt + bsz, self.n_memories)
+        eff = endcnt - self.mem_cnt
+        self.memory_x[t, self.mem_cnt:endcnt] = x[:eff]
+        self.memory_labels[t, self.mem_cnt:endcnt] = y[:eff]
+        self.mem_cnt += eff
+        if self.mem_cnt == self.n_memories:
+            self.mem_cnt = 0
+            return True
+        return False
+
+    def manage_memory(self, t, loader):
+        """gem.py:347-368: fill the buffer from the first-task training set."""
+        for x, y in loader:
+            if t != self.old_task:
+                self.init_new_task(t)
+            if self.fill_buffer(t, x, y):
+                return True
+        return False
+
+    # ------------------------------------------------------------------ kernels
+    def _axpy(self, row, assign):
+        check(_lib.lib().clhip_axpy(row.data_ptr(), self.A.grad.data_ptr(), self.A.numel, 1.0, int(assign), _stream()),
+              "clhip_axpy")
+
+    def gram(self, rows):
+        m = len(rows)
+        idx = (C.c_int * m)(*rows)
+        check(_lib.lib().clhip_gem_gram(self.G.data_ptr(), self.G.shape[1], idx, m, self.A.numel, self._gram.data_ptr(),
+                                        self._gram_ws.data_ptr(), self._gram_ws.numel(), _stream()), "clhip_gem_gram")
+        return self._gram[:m * m].cpu().numpy().reshape(m, m)
+
+    def project(self, rows, v, t):
+        m = len(rows)
+        idx = (C.c_int * m)(*rows)
+        vv = (C.c_float * m)(*[float(a) for a in v])
+        check(_lib.lib().clhip_gem_project(self.G.data_ptr(), self.G.shape[1], idx, vv, m, self.G[t].data_ptr(),
+                                           self.A.grad.data_ptr(), self.A.numel, _stream()), "clhip_gem_project")
+
+    # ------------------------------------------------------------------ gem.py:206-287
+    def observe(self, x, t, y):
+        batch_stats = {"projected_grads": [0]}
+        if t != self.old_task:
+            self.init_new_task(t)
+        self.fill_buffer(t, x, y)
+        if len(self.observed_tasks) > 1:
+            for past in self.observed_tasks[:-1]:
+                sl = compute_offsets(past, self.cum_nc_per_task)
+                mem = TensorTaskDataset.__new__(TensorTaskDataset)
+                mem.x, mem.y, mem.classes = self.memory_x[past], self.memory_labels[past], []
+                first = True
+                for xb, yb in DeviceLoader(mem, self.batch_size, True, self.device):
+                    self.engine.loss_step(xb.contiguous(), yb.contiguous(), "ce_mean", True, class_slice=sl)
+                    self._axpy(self.G[past], assign=first)          # grads accumulate over batches (:237-256)
+                    first = False
+        sl = compute_offsets(t, self.cum_nc_per_task)
+        self.stats.zero_()
+        loss, _ = self.engine.loss_step(x, y, "ce_mean", True, self.stats, class_slice=sl)
+        loss = loss.clone()
+        if len(self.observed_tasks) > 1:
+            self._axpy(self.G[t], assign=True)                       # store_grad (:272)
+            rows = list(self.observed_tasks[:-1]) + [t]
+            gram = self.gram(rows)
+            dotp = gram[-1, :-1]                                      # g . G_tt (:275-276)
+            viol = int((dotp < 0).sum())
+            if viol != 0:
+                batch_stats["projected_grads"] = [viol]
+                v = qp.project2cone2_coefficients(gram, len(rows) - 1, list(range(len(rows) - 1)), self.margin)
+                self.project(rows[:-1], v, t)                         # project2cone2 + overwrite_grad (:278-283)
+        self.opt.step()
+        return loss, self.stats[1], batch_stats
+
+    def forward(self, x, t):
+        """gem.py:169-204 (eval): logits with everything outside the task slice at -1e11."""
+        logits = self.engine.forward(x)
+        o1, o2 = compute_offsets(t, self.cum_nc_per_task)
+        out = torch.full_like(logits, -10e10)
+        out[:, o1:o2] = logits[:, o1:o2]
+        return out

@@ -182,16 +182,18 @@ class NetEngine:
                                            torch.cuda.current_stream().cuda_stream), "clhip_net_forward")
         return logits
 
-    def loss_step(self, x, y, kind="ce_mean", backward=True, stats=None, want_logits=False, params=None):
+    def loss_step(self, x, y, kind="ce_mean", backward=True, stats=None, want_logits=False, params=None,
+                  class_slice=None):
         """forward + loss (+ backward into arena.grad). Returns (loss[1] device tensor, logits|None).
         No host synchronisation happens here."""
         self._check_x(x)
         logits = torch.empty((x.shape[0], self.n_classes), dtype=torch.float32, device=self.device) if want_logits else None
-        check(_lib.lib().clhip_net_loss_step(
+        o1, nc = (class_slice[0], class_slice[1] - class_slice[0]) if class_slice is not None else (0, 0)
+        check(_lib.lib().clhip_net_loss_step_slice(
             self._h, (params if params is not None else self.arena.theta).data_ptr(),
             self.arena.grad.data_ptr() if backward else None, x.data_ptr(),
-            y.data_ptr() if y is not None else None, x.shape[0], self.LOSS[kind], self.ws.data_ptr(),
+            y.data_ptr() if y is not None else None, x.shape[0], self.LOSS[kind], int(o1), int(nc), self.ws.data_ptr(),
             self.loss.data_ptr(), stats.data_ptr() if stats is not None else None,
             logits.data_ptr() if logits is not None else None, torch.cuda.current_stream().cuda_stream),
-            "clhip_net_loss_step")
+            "clhip_net_loss_step_slice")
         return self.loss, logits

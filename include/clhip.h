@@ -82,6 +82,10 @@ int clhip_relu_bwd(const float* dy, const float* y, float* dx, size_t n, void* s
  * host needs no per-batch .item() sync.  C <= 1024.                                         */
 int clhip_softmax_ce(const float* logits, const int64_t* labels_i64, int N, int C, int reduction,
                      float* dlogits, float* loss_out, double* stats, void* stream);
+/* Same over a column slice [col_off, col_off+ncols) of logits[N][ld] (labels relative to the slice; dlogits
+ * outside the slice = 0): GEM's shared 200-way head, rehearsal/model/gem.py:259-263.          */
+int clhip_softmax_ce_slice(const float* logits, const int64_t* labels_i64, int N, int ld, int col_off, int ncols,
+                           int reduction, float* dlogits, float* loss_out, double* stats, void* stream);
 /* MSELoss(size_average=False) against zeros — MAS/train_MAS.py:556-560: loss = sum(z^2),
  * dlogits = 2 z.                                                                            */
 int clhip_mse_zero_sum(const float* logits, size_t n, float* dlogits, float* loss_out, void* stream);
@@ -183,6 +187,24 @@ int clhip_net_backward(void* handle, const float* params, float* grads, const fl
 int clhip_net_loss_step(void* handle, const float* params, float* grads, const float* x,
                         const int64_t* labels_i64, int N, int loss_kind, void* ws, float* loss_out,
                         double* stats, float* logits_out, void* stream);
+
+/* cross-entropy over the class slice [col_off, col_off+ncols) of the shared head (ncols 0 => to the end) */
+int clhip_net_loss_step_slice(void* handle, const float* params, float* grads, const float* x,
+                              const int64_t* labels_i64, int N, int loss_kind, int col_off, int ncols, void* ws,
+                              float* loss_out, double* stats, float* logits_out, void* stream);
+
+/* ------------------------------------------------------------------ GEM memory gradients
+ * rehearsal/model/gem.py:20-80,275-277.  G[n_tasks][ld]: one contiguous row per task.
+ *   axpy        y = (assign ? 0 : y) + alpha*x : store_grad (:20-35) / accumulation over memory batches (:237-255)
+ *   gem_gram    out_f64[m*m] = rows(row_idx) . rows(row_idx)^T in f64, one pass (the MM^T and M g of :70-73;
+ *               its last row/column also carries the violation test g.G_tt of :275-277)
+ *   gem_project out = g + sum_i v[i]*G[row_idx[i]]   (:79, written straight into the gradient arena = overwrite_grad) */
+int clhip_axpy(float* y, const float* x, size_t n, float alpha, int assign, void* stream);
+size_t clhip_gem_gram_ws(int m);
+int clhip_gem_gram(const float* G, size_t ld, const int* row_idx_host, int m, size_t n, double* out_f64, void* ws,
+                   size_t ws_bytes, void* stream);
+int clhip_gem_project(const float* G, size_t ld, const int* row_idx_host, const float* v_host, int m, const float* g,
+                      float* out, size_t n, void* stream);
 
 /* ------------------------------------------------------------------ debug reference kernels
  * Direct (one thread per output, no MFMA/LDS) convolutions used only by tests to triage the

@@ -367,7 +367,42 @@ def g8():
     save("G8_hat", **out)
 
 
+# ------------------------------------------- G6 GEM gradient memory + projection
+def g6():
+    """store_grad / overwrite_grad / project2cone2 of the real gem.py. quadprog is NOT installed: the QP inside
+    project2cone2 is solved by the scipy stand-in in tests/golden/harness/quadprog.py (SLSQP, ftol 1e-15), so
+    the projected vectors pin gem.py's own arithmetic around the QP, not quadprog's."""
+    import methods.rehearsal.model.gem as GEM
+    gen = np.random.RandomState(61)
+    out = {}
+    shapes = [(4, 3, 3, 3), (4,), (6, 4), (6,)]
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+    dims = [p.numel() for p in params]
+    G = torch.zeros(sum(dims), 5)
+    for tid in (0, 2, 3):
+        for pi, p in enumerate(params):
+            p.grad = torch.from_numpy(gen.standard_normal(tuple(p.shape)).astype(np.float32))
+            out["grad_t%d_%d" % (tid, pi)] = np_(p.grad)
+        GEM.store_grad(lambda: params, G, dims, tid)
+    out["G"] = np_(G)
+    GEM.overwrite_grad(lambda: params, G[:, 2] * 2.0, dims)
+    for i, p in enumerate(params):
+        out["overwritten_%d" % i] = np_(p.grad)
+    for case in range(6):
+        t = [1, 2, 3, 5, 7, 9][case]
+        P_ = 200 + 37 * case
+        mem = torch.from_numpy(gen.standard_normal((P_, t)).astype(np.float32))
+        g = torch.from_numpy(gen.standard_normal((P_, 1)).astype(np.float32))
+        if case % 2 == 0:      # make sure some constraints are violated
+            g = g - 0.5 * mem[:, :1]
+        margin = [0.5, 1.0, 0.0, 1.0, 0.5, 1.0][case]
+        out["qp%d_mem" % case], out["qp%d_g" % case], out["qp%d_margin" % case] = np_(mem), np_(g), np.array(margin)
+        GEM.project2cone2(g, mem, margin)
+        out["qp%d_x" % case] = np_(g)
+    save("G6_gem", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     for w in which:
         globals()[w]()

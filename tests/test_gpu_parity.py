@@ -509,3 +509,94 @@ def test_hat_step_golden_g8(golden):
         HT.clamp_embeddings(net)
         for n, p in net.named_parameters():
             assert_close(p.data, torch.from_numpy(g["s%d_theta_%s" % (step, n)]), tol=5e-4, what="theta " + n)
+
+
+def test_gem_gram_and_project_kernels():
+    import ctypes as C
+    from clsurvey_amd import _lib
+    gen = np.random.RandomState(5)
+    n, ld, nt = 100003, 100008, 10
+    Gh = gen.standard_normal((nt, ld)).astype(np.float32)
+    G = torch.from_numpy(Gh).to(dev())
+    L = _lib.lib()
+    ws = torch.zeros(L.clhip_gem_gram_ws(16), dtype=torch.uint8, device=dev())
+    for rows in ([3], [0, 2, 9], list(range(10)), [7, 1, 4, 8, 2, 6]):
+        m = len(rows)
+        out = torch.zeros(m * m, dtype=torch.float64, device=dev())
+        idx = (C.c_int * m)(*rows)
+        assert L.clhip_gem_gram(G.data_ptr(), ld, idx, m, n, out.data_ptr(), ws.data_ptr(), ws.numel(), None) == 0
+        ref = Gh[rows, :n].astype(np.float64) @ Gh[rows, :n].astype(np.float64).T
+        got = out.cpu().numpy().reshape(m, m)
+        assert np.abs(got - ref).max() <= 1e-10 * np.abs(ref).max()
+    rows, v = [0, 2, 9], [0.5, 1.25, -0.75]
+    g = torch.from_numpy(gen.standard_normal(n).astype(np.float32)).to(dev())
+    o = torch.empty(n, device=dev())
+    assert L.clhip_gem_project(G.data_ptr(), ld, (C.c_int * 3)(*rows), (C.c_float * 3)(*v), 3, g.data_ptr(), o.data_ptr(),
+                               n, None) == 0
+    ref = (np.array(v, dtype=np.float32).astype(np.float64) @ Gh[rows, :n].astype(np.float64) + g.cpu().numpy()).astype(np.float32)
+    assert_close(o, torch.from_numpy(ref), tol=1e-6)
+
+
+def test_gem_observe_step_vs_oracle():
+    """gem.Net.observe (gem.py:206-287) for the third task: two memory-gradient passes (batches of the ring
+    buffer in DataLoader order, grads summed over batch means), violation test, QP projection, SGD step."""
+    from clsurvey_amd import models
+    from clsurvey_amd.methods import gem as GM
+    from clsurvey_amd.data import DeviceLoader, TensorTaskDataset
+    from oracle import gem_ref as GR
+    gen = np.random.RandomState(13)
+    ncls, ntask, nmem, bs = 4, 3, 10, 4
+    params = vgg_ref.init_params(TINY, (24, 24), ncls * ntask, 32, gen)
+    m = models.VGGSlim(cfg=TINY, num_classes=ncls * ntask, classifier_inputdim=32 * 2 * 2, classifier_dim1=24, classifier_dim2=24)
+    with torch.no_grad():
+        for p, q in zip(m.parameters(), params):
+            p.copy_(q)
+    gem = GM.GemNet(m, ncls * ntask, ntask, [ncls] * ntask, nmem, lr=0.05, memory_strength=1.0, batch_size=bs,
+                    in_shape=(3, 32, 32), device=dev())
+    mem_x = [rnd(gen, nmem, 3, 32, 32) for _ in range(2)]
+    mem_y = [torch.from_numpy(gen.randint(0, ncls, size=(nmem,)).astype(np.int64)) for _ in range(2)]
+    for t in range(2):          # tasks 0 and 1 were seen before: fill their memories
+        gem.observed_tasks.append(t)
+        gem.memory_x[t] = mem_x[t].to(dev())
+        gem.memory_labels[t] = mem_y[t].to(dev())
+    gem.old_task = 1
+    x = rnd(gen, bs, 3, 32, 32)
+    y = torch.from_numpy(gen.randint(0, ncls, size=(bs,)).astype(np.int64))
+    # ---- oracle: same loader order (same global RNG state), float64 projection
+    torch.manual_seed(123)
+    P = sum(p.numel() for p in params)
+    Gref = np.zeros((P, ntask), dtype=np.float32)
+    for past in (0, 1):
+        ds = TensorTaskDataset(mem_x[past], mem_y[past], [])
+        acc = [torch.zeros_like(p) for p in params]
+        for xb, yb in DeviceLoader(ds, bs, True, "cpu"):
+            logits, _, _, _ = vgg_ref.loss_and_grads(params, TINY, xb, yb, "ce_mean")   # only to reuse forward
+            ps = [p.detach().clone().requires_grad_(True) for p in params]
+            out = vgg_ref.forward(ps, TINY, xb)[:, past * ncls:(past + 1) * ncls]
+            grads = torch.autograd.grad(torch.nn.functional.cross_entropy(out, yb), ps)
+            acc = [a + g_ for a, g_ in zip(acc, grads)]
+        Gref = GR.store_grad([a.numpy() for a in acc], Gref, past)
+    ps = [p.detach().clone().requires_grad_(True) for p in params]
+    out = vgg_ref.forward(ps, TINY, x)[:, 2 * ncls:3 * ncls]
+    loss_ref = torch.nn.functional.cross_entropy(out, y)
+    grads = torch.autograd.grad(loss_ref, ps)
+    Gref = GR.store_grad([g_.numpy() for g_ in grads], Gref, 2)
+    dotp, viol = GR.violations(Gref, 2, [0, 1])
+    gflat = Gref[:, 2].copy()
+    if viol:
+        gflat, _ = GR.project2cone2(Gref[:, 2], Gref[:, [0, 1]], 1.0)
+    new = [p - 0.05 * torch.from_numpy(gi) for p, gi in zip(params, GR.overwrite_grad(gflat, [tuple(p.shape) for p in params]))]
+    # ---- device
+    torch.manual_seed(123)
+    loss, correct, stats = gem.observe(x.to(dev()), 2, y.to(dev()))
+    assert gem.observed_tasks == [0, 1, 2]
+    assert_close(loss, loss_ref.detach().view(1), what="loss")
+    assert stats["projected_grads"] == [viol]
+    assert int(correct.item()) == int((out.argmax(1) == y).sum())
+    for past in (0, 1, 2):
+        row = torch.cat([gem.G[past][o:o + p.numel()] for p, o in zip(m.parameters(), gem.A.offsets)])
+        assert_close(row, torch.from_numpy(Gref[:, past]), tol=5e-4, what="G row %d" % past)
+    for i, (p, q) in enumerate(zip(m.parameters(), new)):
+        assert_close(p.data, q, tol=5e-4, what="theta %d" % i)
+    # ring buffer took the new batch
+    assert torch.equal(gem.memory_x[2, :bs].cpu(), x) and gem.mem_cnt == bs

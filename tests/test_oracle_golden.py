@@ -204,3 +204,36 @@ def test_g8_hat_oracle(golden):
             if "embs" in n:
                 P[n] = torch.clamp(P[n], -6, 6)
             close(P[n], g["s%d_theta_%s" % (step, n)], rtol=5e-5)
+
+
+def test_g6_gem_oracle_and_product_qp(golden):
+    """gem.py store/overwrite/project2cone2 (reference, QP via scipy stand-in) vs the oracle (active-set
+    enumeration) and the product's Goldfarb-Idnani solver.  quadprog parity itself is unpinned."""
+    from oracle import gem_ref as GR
+    from clsurvey_amd.methods import qp
+    g = golden("G6_gem")
+    shapes = [(4, 3, 3, 3), (4,), (6, 4), (6,)]
+    G = np.zeros_like(g["G"])
+    for tid in (0, 2, 3):
+        G = GR.store_grad([g["grad_t%d_%d" % (tid, i)] for i in range(4)], G, tid)
+    assert np.array_equal(G, g["G"])
+    for i, a in enumerate(GR.overwrite_grad(G[:, 2] * 2.0, shapes)):
+        assert np.array_equal(a, g["overwritten_%d" % i])
+    for case in range(6):
+        mem, gr, margin = g["qp%d_mem" % case], g["qp%d_g" % case], float(g["qp%d_margin" % case])
+        x, v = GR.project2cone2(gr, mem, margin)
+        scale = np.abs(g["qp%d_x" % case]).max()
+        assert np.abs(x - g["qp%d_x" % case].reshape(-1)).max() <= 2e-5 * scale     # SLSQP stand-in tolerance
+        # product solver from the Gram matrix (what the device computes)
+        rows = np.concatenate([mem.T, gr.reshape(1, -1)]).astype(np.float64)
+        gram = rows @ rows.T
+        t = mem.shape[1]
+        v2 = qp.project2cone2_coefficients(gram, t, list(range(t)), margin)
+        assert np.abs(v2 - v).max() <= 1e-9 * max(1.0, np.abs(v).max())
+        # KKT of the product solution
+        M = mem.T.astype(np.float64)
+        Pm = M @ M.T
+        Pm = 0.5 * (Pm + Pm.T) + 1e-3 * np.eye(t)
+        grad = Pm @ v2 + M @ gr.reshape(-1).astype(np.float64)
+        assert np.all(v2 >= margin - 1e-10) and np.all(grad >= -1e-8)
+        assert abs(((v2 - margin) * grad).sum()) <= 1e-7 * max(1.0, np.abs(grad).max())
