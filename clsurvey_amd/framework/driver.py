@@ -393,7 +393,11 @@ def get_exp_name(args, method):
 
 
 def first_task_modelname(args):
-    return "vanilla" if args.weight_decay == 0 else "L2={}".format(args.weight_decay)   # models/net.py get_init_modelname
+    """models/net.py:39-53 (get_init_modelname)."""
+    name = ["e={}".format(args.num_epochs), "bs={}".format(args.batch_size), "lr={}".format(sorted(args.lr_grid))]
+    if args.weight_decay != 0:
+        name.append("L2={}".format(args.weight_decay))
+    return "_".join(name)
 
 
 def main(argv=None, method=None, dataset=None, train_node_factory=None):

@@ -1,0 +1,107 @@
+"""G10: end-to-end fixture from the reference's UNCHANGED framework/main.py (dev container only).
+
+Runs, on CPU, SI `first_task_basemodel_dump` and then a 3-task EWC sweep with --test on tiny synthetic
+tasks (clsurvey_amd.framework.tasks.SyntheticTaskSequence, tensor-backed), starting from deterministic
+weights, and records what the build's own driver must reproduce on the GPU with the same seeds:
+per-LR validation accuracies of every phase-1 grid, the phase-2 (lambda, acc, threshold) state, the
+seq_res / seq_forgetting dictionaries and checksums of the final Omega.
+"""
+import os
+import shutil
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "harness"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import harness  # noqa: E402
+
+torch = harness.install()
+import utilities.utils as utils  # noqa: E402
+
+MODEL = "small_VGG9_cl_128_128"
+COMMON = [MODEL, "--lr_grid", "1e-2,3e-3", "--num_epochs", "8", "--batch_size", "40", "--saving_freq", "100"]
+
+
+from g10_weights import det_weights  # noqa: E402
+
+
+def main():
+    root = tempfile.mkdtemp(prefix="g10_")
+    with open(os.path.join(root, "config.init"), "w") as f:
+        f.write("[DEFAULT]\ntest_results_root_path='./results/test'\ntr_results_root_path='./results/train'\n"
+                "models_root_path='./data/models'\nds_root_path='./data/datasets'\n")
+    utils.get_root_src_path = lambda: root
+    torch.cuda.is_available = lambda: False
+    import torch.utils.data as tud
+    _DL = tud.DataLoader
+
+    class DL(_DL):      # no worker processes / pinning in the container; order semantics unchanged
+        def __init__(self, *a, **k):
+            k["num_workers"] = 0
+            k["pin_memory"] = False
+            super().__init__(*a, **k)
+    tud.DataLoader = DL
+    torch.utils.data.DataLoader = DL
+
+    import framework.main as ref_main
+    import methods.method as ref_methods
+    import models.VGGSlim as V
+    from clsurvey_amd.framework.tasks import SyntheticTaskSequence
+    ds = SyntheticTaskSequence(os.path.join(root, "data", "datasets"), task_count=3, classes_per_task=4,
+                               sizes=(160, 40, 40), hw=32, noise=0.4, name="tiny3")
+    # base model file the reference would otherwise create (models/net.py:158-169)
+    mdir = os.path.join(root, "data", "models", "customVGG_input=32x32")
+    os.makedirs(mdir)
+    m = V.VGGSlim(config="small_VGG9", num_classes=4, classifier_inputdim=128 * 2 * 2, classifier_dim1=128,
+                  classifier_dim2=128)
+    with torch.no_grad():
+        for p, w in zip(m.parameters(), det_weights()):
+            p.copy_(torch.from_numpy(w))
+    torch.save(m, os.path.join(mdir, MODEL + ".pth.tar"))
+
+    out = {}
+    sys.argv = ["main.py"] + COMMON + ["--method_name", "SI", "--runmode", "first_task_basemodel_dump"]
+    ref_main.main(method=ref_methods.parse("SI"), dataset=ds)
+    sys.argv = ["main.py"] + COMMON + ["--method_name", "EWC", "--test"]
+    ref_main.main(method=ref_methods.parse("EWC"), dataset=ds)
+
+    tr = os.path.join(root, "results", "train", "tiny3")
+    si_root = os.path.join(tr, "SI", MODEL, "gridsearch", "first_task_basemodel")
+    si_name = os.listdir(si_root)[0]
+    out["si_first_task_modelname"] = np.array(si_name)
+    si_grid = torch.load(os.path.join(si_root, si_name, "task_1", "FT_LR_GRIDSEARCH", "grid_checkpoint.pth"))
+    for lr, d in si_grid["processed_lrs"].items():
+        out["si_t1_lr%g" % lr] = np.array(d["acc"], dtype=np.float64)
+    si_h = torch.load(os.path.join(si_root, si_name, "task_1", "TASK_TRAINING", "hyperparams.pth.tar"))
+    out["si_t1_val_acc"] = np.array(float(si_h["val_acc"]))
+    exp = [d for d in os.listdir(os.path.join(tr, "EWC", MODEL, "gridsearch", "demo"))][0]
+    out["ewc_exp_name"] = np.array(exp)
+    base = os.path.join(tr, "EWC", MODEL, "gridsearch", "demo", exp)
+    for t in (2, 3):
+        g = torch.load(os.path.join(base, "task_%d" % t, "FT_LR_GRIDSEARCH", "grid_checkpoint.pth"))
+        for lr, d in g["processed_lrs"].items():
+            out["ewc_t%d_lr%g" % (t, lr)] = np.array(d["acc"], dtype=np.float64)
+        h = torch.load(os.path.join(base, "task_%d" % t, "TASK_TRAINING", "hyperparams.pth.tar"))
+        out["ewc_t%d_val_acc" % t] = np.array(float(h["val_acc"]))
+        out["ewc_t%d_threshold" % t] = np.array(float(h["acc_threshold"]))
+        out["ewc_t%d_attempts" % t] = np.array(int(h["state"]["attempts"]))
+        out["ewc_t%d_lambda" % t] = np.array(float(h["state"]["hyperparams"]["lambda"]))
+        mt = torch.load(os.path.join(base, "task_%d" % t, "TASK_TRAINING", "best_model.pth.tar"))
+        om = [mt.reg_params[p]["omega"].double() for p in mt.parameters() if p in mt.reg_params]
+        out["ewc_t%d_omega_stats" % t] = np.array([[float(o.sum()), float(o.max()), float(o.pow(2).sum().sqrt())] for o in om])
+    te = os.path.join(root, "results", "test", "results", "tiny3", "EWC", MODEL, "demo", exp)
+    for i in range(3):
+        r = torch.load(os.path.join(te, "test_method_performancesEWC%d.pth" % i))["EWC"]
+        out["seq_res%d" % i] = np.array(r["seq_res"][i], dtype=np.float64)
+        out["seq_forgetting%d" % i] = np.array(r["seq_forgetting"][i], dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "G10_framework_ewc.npz"), **out)
+    for k, v in out.items():
+        print(k, v if v.size < 8 else v.shape)
+    shutil.rmtree(root, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -75,3 +75,63 @@ def test_si_first_task_dump_then_methods(workdir):
                 assert any(float(o.abs().max()) > 0 for o in om), "%s task %d: omega all zero" % (name, t)
         hf = out["frameworks"][1]
         assert len(hf.trace) >= 1 and hf.trace[-1][1] >= 0.0
+
+
+def test_end_to_end_matches_reference_driver_g10(tmp_path, golden):
+    """Same tiny 3-task sequence, same deterministic start weights, same CLI flags and seeds as the run of the
+    reference's UNCHANGED framework/main.py recorded in tests/golden/G10 (make_g10.py): SI first-task dump, then
+    EWC with --test.  The build's driver + HIP path must reproduce the per-LR grid accuracies, the phase-2
+    state (attempts, lambda, threshold), seq_res / seq_forgetting and the Omega statistics."""
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from g10_weights import det_weights
+    from clsurvey_amd import models
+    from clsurvey_amd.framework import driver
+    from clsurvey_amd.framework.tasks import SyntheticTaskSequence
+    from clsurvey_amd.methods import method as M
+    g = golden("G10_framework_ewc")
+    root = str(tmp_path)
+    ds = SyntheticTaskSequence(os.path.join(root, "data"), task_count=3, classes_per_task=4, sizes=(160, 40, 40),
+                               hw=32, noise=0.4, name="tiny3")
+    m = models.parse_model_name("small_VGG9_cl_128_128", (32, 32), 4)
+    with torch.no_grad():
+        for p, w in zip(m.parameters(), det_weights()):
+            p.copy_(torch.from_numpy(w))
+    os.makedirs(os.path.join(root, "models"))
+    torch.save(m, os.path.join(root, "models", "small_VGG9_cl_128_128.pth.tar"))
+    out = driver.main(COMMON + ["--method_name", "SI", "--results_root", root, "--runmode", "first_task_basemodel_dump"],
+                      method=M.parse("SI"), dataset=ds)
+    one = 1.0 / 40 + 1e-9          # one validation sample
+    trace = {lr: acc for lr, it, acc in out["manager"].grid_trace}
+    for lr in (1e-2, 3e-3):
+        assert abs(trace[lr] - float(g["si_t1_lr%g" % lr][0])) <= one, ("SI grid", lr, trace[lr], g["si_t1_lr%g" % lr])
+    assert abs(out["frameworks"][0].trace[-1][1] - float(g["si_t1_val_acc"])) <= one
+    assert os.path.basename(os.path.dirname(os.path.dirname(os.path.dirname(out["manager"].best_model_path)))) == \
+        str(g["si_first_task_modelname"])
+
+    out = driver.main(COMMON + ["--method_name", "EWC", "--results_root", root, "--test"], method=M.parse("EWC"), dataset=ds)
+    assert out["args"].exp_name == str(g["ewc_exp_name"])
+    for t, hf in zip((2, 3), out["frameworks"][1:]):
+        assert abs(hf.trace[-1][1] - float(g["ewc_t%d_val_acc" % t])) <= one, (t, hf.trace)
+        assert abs(hf.trace[-1][2] - float(g["ewc_t%d_threshold" % t])) <= 0.8 * one
+        assert hf.attempts == int(g["ewc_t%d_attempts" % t]), (t, hf.trace)
+        assert hf.hyperparams["lambda"] == float(g["ewc_t%d_lambda" % t])
+        tdir = os.path.join(out["manager"].parent_exp_dir, "task_%d" % t)
+        grid = torch.load(os.path.join(tdir, "FT_LR_GRIDSEARCH", "grid_checkpoint.pth"), weights_only=False)["processed_lrs"]
+        for lr in (1e-2, 3e-3):
+            assert abs(grid[lr]["acc"][0] - float(g["ewc_t%d_lr%g" % (t, lr)][0])) <= one, (t, lr, grid[lr])
+        mt = torch.load(os.path.join(tdir, "TASK_TRAINING", "best_model.pth.tar"), weights_only=False)
+        om = [mt.reg_params[p]["omega"].double() for p in mt.parameters() if p in mt.reg_params]
+        ref = g["ewc_t%d_omega_stats" % t]
+        assert len(om) == ref.shape[0]
+        for o, r in zip(om, ref):
+            st = np.array([float(o.sum()), float(o.max()), float(o.pow(2).sum().sqrt())])
+            assert np.all(np.abs(st - r) <= 0.05 * np.abs(r) + 1e-12), (t, st, r)    # training trajectories are chaotic
+    res = out["results"]
+    two = 100.0 * 2 / 40 + 1e-9     # two test samples, in percent
+    for i in range(3):
+        got, ref = np.array(res[i]["seq_res"][i]), g["seq_res%d" % i]
+        assert got.shape == ref.shape and np.all(np.abs(got - ref) <= two), (i, got, ref)
+        gf, rf = np.array(res[i]["seq_forgetting"][i]), g["seq_forgetting%d" % i]
+        assert gf.shape == rf.shape and np.all(np.abs(gf - rf) <= 2 * two), (i, gf, rf)
