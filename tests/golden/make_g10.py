@@ -22,7 +22,9 @@ torch = harness.install()
 import utilities.utils as utils  # noqa: E402
 
 MODEL = "small_VGG9_cl_128_128"
-COMMON = [MODEL, "--lr_grid", "1e-2,3e-3", "--num_epochs", "8", "--batch_size", "40", "--saving_freq", "100"]
+ATTEMPTS = []
+LAMBDA0 = 2.0
+COMMON = [MODEL, "--lr_grid", "1e-2,3e-3", "--num_epochs", "8", "--batch_size", "40", "--saving_freq", "100", "--drop_margin", "0.05"]
 
 
 from g10_weights import det_weights  # noqa: E402
@@ -66,7 +68,23 @@ def main():
     sys.argv = ["main.py"] + COMMON + ["--method_name", "SI", "--runmode", "first_task_basemodel_dump"]
     ref_main.main(method=ref_methods.parse("SI"), dataset=ds)
     sys.argv = ["main.py"] + COMMON + ["--method_name", "EWC", "--test"]
-    ref_main.main(method=ref_methods.parse("EWC"), dataset=ds)
+    global ATTEMPTS
+
+    class LoggedEWC(ref_methods.EWC):       # instrumentation only: record EVERY phase-2 attempt
+        def train(self, args, manager, hyperparams):
+            model, acc = super().train(args, manager, hyperparams)
+            ATTEMPTS.append((args.task_counter, float(hyperparams["lambda"]), float(acc)))
+            return model, acc
+    globals()["LoggedEWC"] = LoggedEWC       # picklable by reference (the framework pickles vars(manager))
+    LoggedEWC.__qualname__ = "LoggedEWC"
+    ewc = LoggedEWC()
+    import collections
+    # lambda 400 (method.py:668) makes lr*2*lambda*Omega > 2 on these tiny tasks: the reference's own run diverges
+    # (loss 6e20) and the early-return accuracy is chaotic. Pin the framework in its stable regime instead.
+    ewc.hyperparams = collections.OrderedDict({"lambda": LAMBDA0})
+    ref_main.main(method=ewc, dataset=ds)
+    out["ewc_attempts"] = np.array(ATTEMPTS, dtype=np.float64)
+    out["ewc_lambda0"] = np.array(float(LAMBDA0))
 
     tr = os.path.join(root, "results", "train", "tiny3")
     si_root = os.path.join(tr, "SI", MODEL, "gridsearch", "first_task_basemodel")

@@ -100,7 +100,8 @@ def test_end_to_end_matches_reference_driver_g10(tmp_path, golden):
             p.copy_(torch.from_numpy(w))
     os.makedirs(os.path.join(root, "models"))
     torch.save(m, os.path.join(root, "models", "small_VGG9_cl_128_128.pth.tar"))
-    out = driver.main(COMMON + ["--method_name", "SI", "--results_root", root, "--runmode", "first_task_basemodel_dump"],
+    G10 = COMMON + ["--drop_margin", "0.05"]
+    out = driver.main(G10 + ["--method_name", "SI", "--results_root", root, "--runmode", "first_task_basemodel_dump"],
                       method=M.parse("SI"), dataset=ds)
     one = 1.0 / 40 + 1e-9          # one validation sample
     trace = {lr: acc for lr, it, acc in out["manager"].grid_trace}
@@ -110,11 +111,18 @@ def test_end_to_end_matches_reference_driver_g10(tmp_path, golden):
     assert os.path.basename(os.path.dirname(os.path.dirname(os.path.dirname(out["manager"].best_model_path)))) == \
         str(g["si_first_task_modelname"])
 
-    out = driver.main(COMMON + ["--method_name", "EWC", "--results_root", root, "--test"], method=M.parse("EWC"), dataset=ds)
+    ewc = M.parse("EWC")
+    ewc.hyperparams["lambda"] = float(g["ewc_lambda0"])      # stable regime, see make_g10.py
+    out = driver.main(G10 + ["--method_name", "EWC", "--results_root", root, "--test"], method=ewc, dataset=ds)
     assert out["args"].exp_name == str(g["ewc_exp_name"])
+    ref_attempts = g["ewc_attempts"]
+    mine = [(t, tr[0]["lambda"], tr[1]) for t, hf in zip((2, 3), out["frameworks"][1:]) for tr in hf.trace]
+    assert len(mine) == len(ref_attempts), (mine, ref_attempts)
+    for a, b in zip(mine, ref_attempts):
+        assert a[0] == int(b[0]) and a[1] == float(b[1]) and abs(a[2] - float(b[2])) <= one, (mine, ref_attempts)
     for t, hf in zip((2, 3), out["frameworks"][1:]):
         assert abs(hf.trace[-1][1] - float(g["ewc_t%d_val_acc" % t])) <= one, (t, hf.trace)
-        assert abs(hf.trace[-1][2] - float(g["ewc_t%d_threshold" % t])) <= 0.8 * one
+        assert abs(hf.trace[-1][2] - float(g["ewc_t%d_threshold" % t])) <= one
         assert hf.attempts == int(g["ewc_t%d_attempts" % t]), (t, hf.trace)
         assert hf.hyperparams["lambda"] == float(g["ewc_t%d_lambda" % t])
         tdir = os.path.join(out["manager"].parent_exp_dir, "task_%d" % t)
