@@ -23,7 +23,7 @@ import utilities.utils as utils  # noqa: E402
 
 MODEL = "small_VGG9_cl_128_128"
 ATTEMPTS = []
-LAMBDA0 = 2.0
+LAMBDA0 = 40.0
 COMMON = [MODEL, "--lr_grid", "1e-2,3e-3", "--num_epochs", "8", "--batch_size", "40", "--saving_freq", "100", "--drop_margin", "0.05"]
 
 
