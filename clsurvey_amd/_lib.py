@@ -23,6 +23,8 @@ SIGNATURES = {
     "clhip_version": (_i, []),
     "clhip_arch": (C.c_char_p, []),
     "clhip_conv3x3_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "clhip_conv3x3_relu_pool_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "clhip_conv3x3_bwd_weight_unpool": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
     "clhip_conv3x3_bwd_data": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "clhip_conv3x3_bwd_weight_ws": (_z, [_i, _i, _i, _i, _i]),
     "clhip_conv3x3_bwd_weight": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),

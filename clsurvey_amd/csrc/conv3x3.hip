@@ -34,6 +34,20 @@ struct Geo {
     static_assert(32 % TW == 0 || TW == 32, "TW must divide 32");
 };
 
+// Subtile s (32 pixels) / lane li -> pixel of the block tile.  With a fused 2x2 max-pool every 2x2 window must
+// sit inside ONE 32-pixel subtile so the four candidates are in four lanes of the same accumulator register:
+// the natural mapping already does that for TW = 16 (2 rows x 16) and TW = 8 (4 rows x 8); for TW = 32 the
+// pooled mapping uses 2 rows x 16 columns per subtile instead of 1 row x 32.
+template <int TW, int TH>
+__device__ __forceinline__ void tile_pixel(int s, int li, bool pool, int& nb, int& th, int& tw) {
+    if (pool && TW == 32) {
+        nb = 0; th = 2 * (s >> 1) + (li >> 4); tw = 16 * (s & 1) + (li & 15);
+    } else {
+        const int q = 32 * s + li;
+        tw = q % TW; th = (q / TW) % TH; nb = q / (TW * TH);
+    }
+}
+
 // MODE 0: forward (wt used as is, bias+relu epilogue)
 // MODE 1: backward-data (in = dy with Kw channels, out = dx with Cw channels, taps flipped)
 #ifndef CLHIP_CONV_MIN_WAVES
@@ -44,8 +58,9 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
     const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
     const float* __restrict__ mask_src, float* __restrict__ out,
     int N, int Cin, int Cout, int H, int W, int Kw, int Cw, int relu,
-    int tiles_w, int tiles_h, int n_pix_tiles) {
+    int tiles_w, int tiles_h, int n_pix_tiles, uint8_t* __restrict__ pool_idx) {
     using G = Geo<TW, TH, NB>;
+    const bool pool = pool_idx != nullptr;     // MODE 0 only: out = 2x2-max-pooled relu(conv), idx = argmax
     constexpr int WS_FLOATS = CK * 9 * LDW;
     constexpr int XS_FLOATS = CK * G::PLANE;
     constexpr int BUF_FLOATS = WS_FLOATS + XS_FLOATS;
@@ -74,8 +89,8 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
     int pixoff[G::NT];
 #pragma unroll
     for (int t = 0; t < G::NT; ++t) {
-        int q = (wp * G::NT + t) * 32 + li;
-        int tw = q % TW, th = (q / TW) % TH, nb = q / (TW * TH);
+        int nb, th, tw;
+        tile_pixel<TW, TH>(wp * G::NT + t, li, pool, nb, th, tw);
         pixoff[t] = (nb * (TH + 2) + th) * G::TWP + tw;
     }
     const int a_lane = kk * 9 * LDW + wk * 32 + li;   // weight-tile read offset
@@ -321,10 +336,45 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
 
     // ---- epilogue: reg r of lane l = D[row = out-channel][col = pixel li]
     const size_t out_img = (size_t)Cout * H * W;
+    if (MODE == 0 && pool) {
+        // fused ReLU + 2x2/2 max-pool (VGGSlim.py:32,38): the window's candidates are lanes li, li^1 (right),
+        // li^VX (below), li^1^VX; the top-left lane writes the maximum and the 2-bit argmax (first maximum in
+        // ATen's scan order wins).  The pre-pool activation never goes to HBM.
+        constexpr int VX = TW == 8 ? 8 : 16;
+        const int OH = H >> 1, OW = W >> 1;
+        const bool writer = !(li & 1) && !(li & VX);
+#pragma unroll
+        for (int t = 0; t < G::NT; ++t) {
+            int nb, th, tw;
+            tile_pixel<TW, TH>(wp * G::NT + t, li, true, nb, th, tw);
+            const int n = n0 + nb, h = h0 + th, w = w0 + tw;
+            const bool pix_ok = (n < N) && (h < H) && (w < W);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ko = ko0 + wk * 32 + mfma32_row(r, lane);
+                float v = acc[t][r];
+                if (bias && ko < Cout) v += bias[ko];
+                v = fmaxf(v, 0.f);
+                const float tr = __shfl_xor(v, 1, 64);
+                const float bl = __shfl_xor(v, VX, 64);
+                const float br = __shfl_xor(tr, VX, 64);
+                if (writer && pix_ok && ko < Cout) {
+                    float m = v; int a = 0;
+                    if (tr > m) { m = tr; a = 1; }
+                    if (bl > m) { m = bl; a = 2; }
+                    if (br > m) { m = br; a = 3; }
+                    const size_t o = (((size_t)n * Cout + ko) * OH + (h >> 1)) * OW + (w >> 1);
+                    out[o] = m;
+                    pool_idx[o] = (uint8_t)a;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < G::NT; ++t) {
-        int q = (wp * G::NT + t) * 32 + li;
-        int tw = q % TW, th = (q / TW) % TH, nb = q / (TW * TH);
+        int nb, th, tw;
+        tile_pixel<TW, TH>(wp * G::NT + t, li, false, nb, th, tw);
         int n = n0 + nb, h = h0 + th, w = w0 + tw;
         bool pix_ok = (n < N) && (h < H) && (w < W);
 #pragma unroll
@@ -347,14 +397,14 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
 
 template <int TW, int TH, int NB, int CK, int MODE, bool VEC>
 int launch_geo(const float* in, const float* wt, const float* bias, const float* mask_src, float* out,
-               int N, int Cin, int Cout, int H, int W, int Kw, int Cw, int relu, hipStream_t s) {
+               int N, int Cin, int Cout, int H, int W, int Kw, int Cw, int relu, hipStream_t s, uint8_t* pool_idx) {
     int tiles_w = (W + TW - 1) / TW, tiles_h = (H + TH - 1) / TH, ngrp = (N + NB - 1) / NB;
     int n_pix_tiles = tiles_w * tiles_h * ngrp;
     int kts = (Cout + KT - 1) / KT;
     long long blocks = (long long)n_pix_tiles * kts;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return CLHIP_EINVAL;
     hipLaunchKernelGGL((conv3x3_mfma_kernel<TW, TH, NB, CK, MODE, VEC>), dim3((unsigned)blocks), dim3(256), 0, s,
-                       in, wt, bias, mask_src, out, N, Cin, Cout, H, W, Kw, Cw, relu, tiles_w, tiles_h, n_pix_tiles);
+                       in, wt, bias, mask_src, out, N, Cin, Cout, H, W, Kw, Cw, relu, tiles_w, tiles_h, n_pix_tiles, pool_idx);
     CLHIP_LAUNCH_CHECK();
     return 0;
 }
@@ -363,11 +413,12 @@ int launch_geo(const float* in, const float* wt, const float* bias, const float*
 // otherwise 64-pixel tiles (deep layers at 8x8 / 16x16 have few pixels).
 template <int CK, int MODE, bool VEC>
 int launch_conv(const float* in, const float* wt, const float* bias, const float* mask_src, float* out,
-                int N, int Cin, int Cout, int H, int W, int Kw, int Cw, int relu, hipStream_t s) {
+                int N, int Cin, int Cout, int H, int W, int Kw, int Cw, int relu, hipStream_t s,
+                uint8_t* pool_idx = nullptr) {
     const int kts = (Cout + KT - 1) / KT;
     const long long pix = (long long)N * H * W;
     const bool big = (pix / 128) * kts >= 512;
-#define GEO(TW_, TH_, NB_) launch_geo<TW_, TH_, NB_, CK, MODE, VEC>(in, wt, bias, mask_src, out, N, Cin, Cout, H, W, Kw, Cw, relu, s)
+#define GEO(TW_, TH_, NB_) launch_geo<TW_, TH_, NB_, CK, MODE, VEC>(in, wt, bias, mask_src, out, N, Cin, Cout, H, W, Kw, Cw, relu, s, pool_idx)
     if (W > 16) return big ? GEO(32, 4, 1) : GEO(32, 2, 1);
     if (W > 8) return big ? GEO(16, 8, 1) : GEO(16, 4, 1);
     return (big && H > 4) ? GEO(8, 8, 2) : GEO(8, 8, 1);
@@ -391,6 +442,16 @@ int clhip_conv3x3_fwd(const float* x, const float* w, const float* b, float* y,
     if (C <= 4) return launch_conv<4, 0, false>(x, w, b, nullptr, y, N, C, K, H, W, K, C, relu, s);
     if (vec_ok(x, w, C, H, W, C)) return launch_conv<8, 0, true>(x, w, b, nullptr, y, N, C, K, H, W, K, C, relu, s);
     return launch_conv<8, 0, false>(x, w, b, nullptr, y, N, C, K, H, W, K, C, relu, s);
+}
+
+int clhip_conv3x3_relu_pool_fwd(const float* x, const float* w, const float* b, float* y_pool, uint8_t* idx_u8,
+                                int N, int C, int K, int H, int W, void* stream) {
+    if (!x || !w || !y_pool || !idx_u8 || N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1))
+        return CLHIP_EINVAL;
+    hipStream_t s = as_stream(stream);
+    if (C <= 4) return launch_conv<4, 0, false>(x, w, b, nullptr, y_pool, N, C, K, H, W, K, C, 1, s, idx_u8);
+    if (vec_ok(x, w, C, H, W, C)) return launch_conv<8, 0, true>(x, w, b, nullptr, y_pool, N, C, K, H, W, K, C, 1, s, idx_u8);
+    return launch_conv<8, 0, false>(x, w, b, nullptr, y_pool, N, C, K, H, W, K, C, 1, s, idx_u8);
 }
 
 int clhip_conv3x3_bwd_data(const float* dy, const float* w, const float* relu_src, float* dx,

@@ -270,7 +270,10 @@ template <int TW, int TH>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_smallc_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
     int N, int C, int K, int H, int W, int tiles_w, int tiles_h,
-    int total_stages, int splits, size_t slab_stride) {
+    int total_stages, int splits, size_t slab_stride, const uint8_t* __restrict__ unpool_idx) {
+    // unpool_idx != NULL: `dy` is the gradient w.r.t. the 2x2-max-POOLED output [N][K][H/2][W/2] and the
+    // un-pooled gradient tile is rebuilt on the fly from the 2-bit argmax (fused maxpool backward: the
+    // 4x larger dy tensor of the first layer is never written nor read).
     using G = WGeo<TW, TH>;
     __shared__ float dys[KT * G::LDP];
     __shared__ float xs[3 * G::PLANE + 8];
@@ -306,6 +309,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_smallc_kernel(
     constexpr int X_ITERS = (X_ELEMS + 255) / 256;             // 2
     float dyr[DY_ITERS];
     float xr[X_ITERS];
+    int upa[4];
 
     const int q_t = tid & 63;
     const int th_t = q_t / TW, tw_t = q_t - th_t * TW;
@@ -329,9 +333,26 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_smallc_kernel(
         const bool pix_ok = (h0 + th_t < H) && (w0 + tw_t < W);
         const float* dyp = dy + ((size_t)n * K + k0 + wave) * plane_hw + (size_t)(h0 + th_t) * W + (w0 + tw_t);
         const float* xp = x + (size_t)n * C * plane_hw + (size_t)h0 * W + w0;
+        if (unpool_idx) {
+            const int OH = H >> 1, OW = W >> 1;
 #pragma unroll
-        for (int j = 0; j < DY_ITERS; ++j)
-            dyr[j] = (pix_ok && (k0 + wave + 4 * j < K)) ? dyp[(size_t)(4 * j) * plane_hw] : 0.f;
+            for (int j = 0; j < 4; ++j) {
+                const int e = tid + 256 * j;                          // 64 k x 16 pooled windows
+                const int kl = e >> 4, pwin = e & 15;
+                const int ph = pwin / (TW / 2), pw = pwin - ph * (TW / 2);
+                const int k = k0 + kl, hh = (h0 >> 1) + ph, ww = (w0 >> 1) + pw;
+                const bool ok = k < K && hh < OH && ww < OW;
+                const size_t o = (((size_t)n * K + k) * OH + hh) * OW + ww;
+                float g = *(ok ? dy + o : dy);
+                uint8_t a = *(ok ? unpool_idx + o : unpool_idx);
+                dyr[j] = ok ? g : 0.f;
+                upa[j] = ok ? (int)a : 255;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < DY_ITERS; ++j)
+                dyr[j] = (pix_ok && (k0 + wave + 4 * j < K)) ? dyp[(size_t)(4 * j) * plane_hw] : 0.f;
+        }
 #pragma unroll
         for (int j = 0; j < X_ITERS; ++j) {
             const int mt = xmeta[j];
@@ -342,8 +363,22 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_smallc_kernel(
         }
     };
     auto store_stage = [&]() {
+        if (unpool_idx) {
 #pragma unroll
-        for (int j = 0; j < DY_ITERS; ++j) dys[dy_lds + 4 * j * G::LDP] = dyr[j];
+            for (int j = 0; j < 4; ++j) {
+                const int e = tid + 256 * j;
+                const int kl = e >> 4, pwin = e & 15;
+                const int ph = pwin / (TW / 2), pw = pwin - ph * (TW / 2);
+                float* d = dys + kl * G::LDP + (2 * ph) * TW + 2 * pw;
+                const float g = dyr[j];
+                const int a = upa[j];
+                d[0] = a == 0 ? g : 0.f; d[1] = a == 1 ? g : 0.f;
+                d[TW] = a == 2 ? g : 0.f; d[TW + 1] = a == 3 ? g : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < DY_ITERS; ++j) dys[dy_lds + 4 * j * G::LDP] = dyr[j];
+        }
 #pragma unroll
         for (int j = 0; j < X_ITERS; ++j)
             if (tid + 256 * j < X_ELEMS) xs[tid + 256 * j] = xr[j];
@@ -467,9 +502,10 @@ size_t clhip_conv3x3_bwd_weight_ws(int N, int C, int K, int H, int W) {
     return make_plan(N, C, K, H, W).ws_floats * sizeof(float);
 }
 
-int clhip_conv3x3_bwd_weight(const float* x, const float* dy, float* dw, float* db,
-                             int N, int C, int K, int H, int W, void* ws, size_t ws_bytes, void* stream) {
+static int bwd_weight_impl(const float* x, const float* dy, const uint8_t* unpool_idx, float* dw, float* db,
+                           int N, int C, int K, int H, int W, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !dy || !dw || !ws || N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0) return CLHIP_EINVAL;
+    if (unpool_idx && (C * 9 > 32 || (H & 1) || (W & 1))) return CLHIP_ENOTSUP;
     WPlan p = make_plan(N, C, K, H, W);
     if (ws_bytes < p.ws_floats * sizeof(float)) return CLHIP_ENOSPC;
     hipStream_t s = as_stream(stream);
@@ -479,9 +515,9 @@ int clhip_conv3x3_bwd_weight(const float* x, const float* dy, float* dw, float* 
     unsigned grid = (unsigned)(p.k_tiles * p.c_tiles * p.splits);
 #define WG_ARGS x, dy, part, N, C, K, H, W, p.tiles_w, p.tiles_h, p.total_stages, p.splits
     if (smallc) {
-        if (p.TW == 32) hipLaunchKernelGGL((conv3x3_wgrad_smallc_kernel<32, 2>), dim3(grid), dim3(256), 0, s, WG_ARGS, p.slab);
-        else if (p.TW == 16) hipLaunchKernelGGL((conv3x3_wgrad_smallc_kernel<16, 4>), dim3(grid), dim3(256), 0, s, WG_ARGS, p.slab);
-        else hipLaunchKernelGGL((conv3x3_wgrad_smallc_kernel<8, 8>), dim3(grid), dim3(256), 0, s, WG_ARGS, p.slab);
+        if (p.TW == 32) hipLaunchKernelGGL((conv3x3_wgrad_smallc_kernel<32, 2>), dim3(grid), dim3(256), 0, s, WG_ARGS, p.slab, unpool_idx);
+        else if (p.TW == 16) hipLaunchKernelGGL((conv3x3_wgrad_smallc_kernel<16, 4>), dim3(grid), dim3(256), 0, s, WG_ARGS, p.slab, unpool_idx);
+        else hipLaunchKernelGGL((conv3x3_wgrad_smallc_kernel<8, 8>), dim3(grid), dim3(256), 0, s, WG_ARGS, p.slab, unpool_idx);
     } else {
         // 16-byte staging needs aligned rows and whole tiles along w
         const bool vec = (W % 4 == 0) && (W % p.TW == 0) && aligned16(x) && aligned16(dy);
@@ -500,6 +536,19 @@ int clhip_conv3x3_bwd_weight(const float* x, const float* dy, float* dw, float* 
     hipLaunchKernelGGL(wgrad_reduce_final_kernel, dim3(bx), dim3(256), 0, s, tmp, dw, db, K, C, p.groups);
     CLHIP_LAUNCH_CHECK();
     return 0;
+}
+
+int clhip_conv3x3_bwd_weight(const float* x, const float* dy, float* dw, float* db,
+                             int N, int C, int K, int H, int W, void* ws, size_t ws_bytes, void* stream) {
+    return bwd_weight_impl(x, dy, nullptr, dw, db, N, C, K, H, W, ws, ws_bytes, stream);
+}
+
+// dy_pool[N][K][H/2][W/2] + idx: weight gradient of a conv whose ReLU output was 2x2-max-pooled, without
+// materialising the un-pooled gradient.  Supported for the first-layer kernel (C*9 <= 32); others: ENOTSUP.
+int clhip_conv3x3_bwd_weight_unpool(const float* x, const float* dy_pool, const uint8_t* idx_u8, float* dw, float* db,
+                                    int N, int C, int K, int H, int W, void* ws, size_t ws_bytes, void* stream) {
+    if (!idx_u8) return CLHIP_EINVAL;
+    return bwd_weight_impl(x, dy_pool, idx_u8, dw, db, N, C, K, H, W, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -123,14 +123,23 @@ int clhip_net_forward(void* handle, const float* params, const float* x, int N, 
     for (const LayerPlan& L : p->layers) {
         float* y = acts + L.act_off;
         if (L.type == 0) {
-            rc = clhip_conv3x3_fwd(cur, params + L.w_off, params + L.b_off, y, N, L.cin, L.cout, L.h, L.w, L.relu, stream);
-            if (rc) return rc;
-            cur = y;
-            if (L.pool) {
+            if (L.pool && L.relu) {
+                // conv + bias + ReLU + max-pool in one kernel; the pre-pool tensor is never materialised
                 float* pl = acts + L.pool_off;
-                rc = clhip_maxpool2_fwd(y, pl, idx + L.idx_off, N * L.cout, L.h, L.w, stream);
+                rc = clhip_conv3x3_relu_pool_fwd(cur, params + L.w_off, params + L.b_off, pl, idx + L.idx_off, N, L.cin,
+                                                 L.cout, L.h, L.w, stream);
                 if (rc) return rc;
                 cur = pl;
+            } else {
+                rc = clhip_conv3x3_fwd(cur, params + L.w_off, params + L.b_off, y, N, L.cin, L.cout, L.h, L.w, L.relu, stream);
+                if (rc) return rc;
+                cur = y;
+                if (L.pool) {
+                    float* pl = acts + L.pool_off;
+                    rc = clhip_maxpool2_fwd(y, pl, idx + L.idx_off, N * L.cout, L.h, L.w, stream);
+                    if (rc) return rc;
+                    cur = pl;
+                }
             }
         } else {
             rc = clhip_fc_fwd(cur, params + L.w_off, params + L.b_off, y, N, L.cin, L.cout, L.relu, scratch,
@@ -182,15 +191,26 @@ int clhip_net_backward(void* handle, const float* params, float* grads, const fl
             }
         } else {
             const float* gy = gin;
-            if (L.pool) {
+            bool wdone = false;
+            if (L.pool && i == 0) {
+                // no backward-data below the first layer: take the weight gradient straight from the pooled
+                // gradient + argmax (fused max-pool backward), when the kernel supports the shape
+                rc = clhip_conv3x3_bwd_weight_unpool(xin, gin, idx + L.idx_off, grads + L.w_off, grads + L.b_off, N, L.cin,
+                                                     L.cout, L.h, L.w, scratch, p->scratch_bytes, stream);
+                if (rc == 0) wdone = true;
+                else if (rc != CLHIP_ENOTSUP) return rc;
+            }
+            if (L.pool && !wdone) {
                 float* gout = g[flip]; flip ^= 1;
                 rc = clhip_maxpool2_bwd(gin, idx + L.idx_off, gout, N * L.cout, L.h, L.w, stream);
                 if (rc) return rc;
                 gy = gout;
             }
-            rc = clhip_conv3x3_bwd_weight(xin, gy, grads + L.w_off, grads + L.b_off, N, L.cin, L.cout, L.h, L.w,
-                                          scratch, p->scratch_bytes, stream);
-            if (rc) return rc;
+            if (!wdone) {
+                rc = clhip_conv3x3_bwd_weight(xin, gy, grads + L.w_off, grads + L.b_off, N, L.cin, L.cout, L.h, L.w,
+                                              scratch, p->scratch_bytes, stream);
+                if (rc) return rc;
+            }
             if (i > 0) {
                 float* gout = g[flip]; flip ^= 1;
                 rc = clhip_conv3x3_bwd_data(gy, params + L.w_off, xin, gout, N, L.cin, L.cout, L.h, L.w, stream);

@@ -53,6 +53,31 @@ def conv3x3_fwd(x, w, b, relu=True):
     return y
 
 
+def conv3x3_relu_pool_fwd(x, w, b):
+    """fused conv + bias + ReLU + 2x2 max-pool: returns (y_pool, idx_u8)."""
+    _chk(x, w, b)
+    N, C, H, W = x.shape
+    K = w.shape[0]
+    y = torch.empty((N, K, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    idx = torch.empty((N, K, H // 2, W // 2), dtype=torch.uint8, device=x.device)
+    check(_lib.lib().clhip_conv3x3_relu_pool_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(y), _ptr(idx), N, C, K, H, W, _stream()),
+          "clhip_conv3x3_relu_pool_fwd")
+    return y, idx
+
+
+def conv3x3_bwd_weight_unpool(x, dy_pool, idx, need_bias=True):
+    _chk(x, dy_pool, idx)
+    N, C, H, W = x.shape
+    K = dy_pool.shape[1]
+    L = _lib.lib()
+    ws = workspace(L.clhip_conv3x3_bwd_weight_ws(N, C, K, H, W), x.device, "wgrad")
+    dw = torch.empty((K, C, 3, 3), dtype=torch.float32, device=x.device)
+    db = torch.empty((K,), dtype=torch.float32, device=x.device) if need_bias else None
+    check(L.clhip_conv3x3_bwd_weight_unpool(_ptr(x), _ptr(dy_pool), _ptr(idx), _ptr(dw), _ptr(db), N, C, K, H, W,
+                                            _ptr(ws), ws.numel(), _stream()), "clhip_conv3x3_bwd_weight_unpool")
+    return dw, db
+
+
 def conv3x3_bwd_data(dy, w, relu_src=None):
     _chk(dy, w, relu_src)
     N, K, H, W = dy.shape

@@ -37,6 +37,11 @@ const char* clhip_arch(void);
 int clhip_conv3x3_fwd(const float* x, const float* w, const float* b, float* y,
                       int N, int C, int K, int H, int W, int relu, void* stream);
 
+/* Fused conv + bias + ReLU + 2x2/2 max-pool (VGGSlim.py:32-38): y_pool[N][K][H/2][W/2], idx_u8 = argmax
+ * (0..3).  The pre-pool activation is never written (the first layer's would be 210 MB per batch).      */
+int clhip_conv3x3_relu_pool_fwd(const float* x, const float* w, const float* b, float* y_pool, uint8_t* idx_u8,
+                                int N, int C, int K, int H, int W, void* stream);
+
 /* autograd convolution_backward, data part. dx[N][C][H][W] from dy[N][K][H][W].
  * If relu_src != NULL: dx is multiplied by (relu_src > 0) — the fused ReLU backward
  * (threshold_backward) of the layer that PRODUCED this conv's input (VGGSlim.py:38).      */
@@ -50,6 +55,12 @@ size_t clhip_conv3x3_bwd_weight_ws(int N, int C, int K, int H, int W);
 int clhip_conv3x3_bwd_weight(const float* x, const float* dy, float* dw, float* db,
                              int N, int C, int K, int H, int W, void* ws, size_t ws_bytes,
                              void* stream);
+
+/* Same from the gradient w.r.t. the POOLED output + argmax (fused max_pool2d backward). Implemented for the
+ * first-layer kernel (C*9 <= 32); returns CLHIP_ENOTSUP otherwise (callers then un-pool with
+ * clhip_maxpool2_bwd first).                                                                             */
+int clhip_conv3x3_bwd_weight_unpool(const float* x, const float* dy_pool, const uint8_t* idx_u8, float* dw, float* db,
+                                    int N, int C, int K, int H, int W, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ max-pool 2x2 stride 2
  * nn.MaxPool2d(2, 2) — models/VGGSlim.py:32. idx_u8 holds the argmax (0..3, row-major in the

@@ -600,3 +600,36 @@ def test_gem_observe_step_vs_oracle():
         assert_close(p.data, q, tol=5e-4, what="theta %d" % i)
     # ring buffer took the new batch
     assert torch.equal(gem.memory_x[2, :bs].cpu(), x) and gem.mem_cnt == bs
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 16, 32, 32), (3, 16, 16, 16, 16), (5, 32, 24, 8, 8), (9, 3, 64, 64, 64),
+                                   (4, 64, 64, 32, 32), (40, 64, 64, 16, 16), (33, 64, 128, 8, 8), (2, 8, 40, 12, 20)])
+def test_fused_conv_relu_pool(shape):
+    """fused conv+ReLU+maxpool == separate kernels, bit for bit (same accumulation order), and the argmax is ATen's."""
+    import torch.nn.functional as F
+    from clsurvey_amd import ops
+    N, C, K, H, W = shape
+    gen = np.random.RandomState(sum(shape))
+    x, w, b = rnd(gen, N, C, H, W).to(dev()), (rnd(gen, K, C, 3, 3, scale=0.2)).to(dev()), rnd(gen, K, scale=0.1).to(dev())
+    y = ops.conv3x3_fwd(x, w, b, relu=True)
+    yp_ref, idx_ref = ops.maxpool2_fwd(y)
+    yp, idx = ops.conv3x3_relu_pool_fwd(x, w, b)
+    assert torch.equal(yp, yp_ref)
+    assert torch.equal(idx, idx_ref)
+    y_cpu = F.max_pool2d(F.relu(F.conv2d(x.cpu(), w.cpu(), b.cpu(), padding=1)), 2, 2)
+    assert_close(yp, y_cpu, what="pooled")
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 16, 32, 32), (9, 3, 64, 64, 64), (200, 3, 64, 64, 64), (7, 2, 8, 16, 16), (3, 1, 70, 8, 8)])
+def test_wgrad_fused_unpool(shape):
+    from clsurvey_amd import ops
+    N, C, K, H, W = shape
+    gen = np.random.RandomState(sum(shape) + 1)
+    x = rnd(gen, N, C, H, W).to(dev())
+    gp = rnd(gen, N, K, H // 2, W // 2).to(dev())
+    idx = torch.from_numpy(gen.randint(0, 4, size=(N, K, H // 2, W // 2)).astype(np.uint8)).to(dev())
+    dy = ops.maxpool2_bwd(gp, idx)
+    dw_ref, db_ref = ops.conv3x3_bwd_weight(x, dy)
+    dw, db = ops.conv3x3_bwd_weight_unpool(x, gp, idx)
+    assert_close(dw, dw_ref, tol=1e-5, what="dw")
+    assert_close(db, db_ref, tol=1e-5, what="db")
