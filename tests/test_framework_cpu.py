@@ -55,7 +55,7 @@ def test_two_phase_framework_and_eval(tmp_path):
     root = str(tmp_path)
     # task 1 model comes from the SI bootstrap path (main.py:226-233): create the file it expects
     si = os.path.join(root, "train", "fake", "SI", "small_VGG9_cl_128_128", "gridsearch", "first_task_basemodel",
-                      "vanilla", "task_1", "TASK_TRAINING")
+                      "e=1_bs=200_lr=[0.001, 0.005, 0.01]", "task_1", "TASK_TRAINING")     # models/net.py:39-53 naming
     os.makedirs(si)
     torch.save({}, os.path.join(si, "best_model.pth.tar"))
     out = driver.main(["small_VGG9_cl_128_128", "--method_name", "EWC", "--results_root", root, "--lr_grid",
