@@ -115,26 +115,30 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
     }
 }
 
-// db[o] = sum_m dy[m][o]: 64 columns x 4 row-groups per block; each thread sums its rows in order
-// (double accumulator), the 4 groups are combined in fixed order through LDS.
+// db[o] = sum_m dy[m][o]: 16 columns x 16 row-groups per block; each thread sums its rows in order
+// (double accumulator), the 16 groups are combined in fixed order through LDS.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dy, float* __restrict__ db, int M, int O) {
-    __shared__ double part[4][64];
-    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int o = blockIdx.x * 64 + c;
-    const int per = (M + 3) / 4;
+    __shared__ double part[16][17];
+    const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int o = blockIdx.x * 16 + c;
+    const int per = (M + 15) / 16;
     const int m0 = g * per, m1 = min(M, m0 + per);
     double s = 0.0;
     if (o < O)
         for (int m = m0; m < m1; ++m) s += (double)dy[(size_t)m * O + o];
     part[g][c] = s;
     __syncthreads();
-    if (g == 0 && o < O) db[o] = (float)(((part[0][c] + part[1][c]) + part[2][c]) + part[3][c]);
+    if (g == 0 && o < O) {
+        double t = 0.0;
+        for (int i = 0; i < 16; ++i) t += part[i][c];
+        db[o] = (float)t;
+    }
 }
 
 int choose_splits(int M, int N, int K) {
     int tiles = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
     int s = 512 / tiles;
-    int max_by_k = K / 64;           // keep >= 64 of K per split
+    int max_by_k = K / 96;           // keep >= 96 of K per split (a split costs an extra reduce launch)
     if (s > max_by_k) s = max_by_k;
     if (s > 32) s = 32;
     if (s < 1) s = 1;
@@ -197,7 +201,7 @@ int clhip_fc_bwd_weight(const float* x, const float* dy, float* dw, float* db, i
     int rc = gemm_launch<false, false>(dy, x, dw, O, I, M, 1, O, I, 1, nullptr, nullptr, 0, ws, ws_bytes, s);
     if (rc) return rc;
     if (db) {
-        hipLaunchKernelGGL(colsum_kernel, dim3((O + 63) / 64), dim3(256), 0, s, dy, db, M, O);
+        hipLaunchKernelGGL(colsum_kernel, dim3((O + 15) / 16), dim3(256), 0, s, dy, db, M, O);
         CLHIP_LAUNCH_CHECK();
     }
     return 0;

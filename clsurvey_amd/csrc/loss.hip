@@ -103,6 +103,55 @@ __global__ __launch_bounds__(LOSS_BLOCK) void softmax_ce_kernel(
     }
 }
 
+// Narrow heads (C <= 64, the 20-way task heads): one THREAD per row, no cross-lane traffic; rows are
+// summed in index order by thread 0 afterwards (deterministic).  N <= 1024.
+__global__ __launch_bounds__(LOSS_BLOCK) void softmax_ce_rows_kernel(
+    const float* __restrict__ logits_full, const int64_t* __restrict__ labels, int N, int C, int reduction,
+    float* __restrict__ dlogits_full, float* __restrict__ loss_out, double* __restrict__ stats, int ld, int col_off) {
+    __shared__ float s_loss[LOSS_BLOCK];
+    __shared__ unsigned char s_corr[LOSS_BLOCK];
+    const int row = threadIdx.x;
+    const float scale = reduction == 0 ? 1.f / (float)N : 1.f;
+    float li = 0.f;
+    int ok = 0;
+    if (row < N) {
+        const float* z = logits_full + (size_t)row * ld + col_off;
+        float* dz = dlogits_full + (size_t)row * ld;
+        const int y = (int)labels[row];
+        float m = -INFINITY;
+        int am = 0;
+#pragma unroll 4
+        for (int c = 0; c < C; ++c) {
+            float v = z[c];
+            if (v > m) { m = v; am = c; }
+        }
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += expf(z[c] - m);
+        const float lse = logf(se);
+        for (int c = 0; c < ld; ++c) {
+            const int cc = c - col_off;
+            dz[c] = (cc >= 0 && cc < C) ? (expf(z[cc] - m - lse) - (cc == y ? 1.f : 0.f)) * scale : 0.f;
+        }
+        li = -(z[y] - m - lse);
+        ok = (am == y);
+    }
+    s_loss[row] = li;
+    s_corr[row] = (unsigned char)ok;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // same summation order as the wave-per-row kernel: rows w, w+16, ... per wave, then waves 0..15
+        float t = 0.f; int c = 0;
+        for (int w = 0; w < 16; ++w) {
+            float wl = 0.f;
+            for (int r = w; r < N; r += 16) { wl += s_loss[r]; c += s_corr[r]; }
+            t += wl;
+        }
+        t *= scale;
+        loss_out[0] = t;
+        if (stats) { stats[0] += (double)t; stats[1] += (double)c; }
+    }
+}
+
 __global__ __launch_bounds__(LOSS_BLOCK) void mse_zero_sum_kernel(const float* __restrict__ z, size_t n,
                                                                   float* __restrict__ dz, float* __restrict__ loss_out) {
     __shared__ float s_part[16];
@@ -131,8 +180,12 @@ int clhip_softmax_ce_slice(const float* logits, const int64_t* labels_i64, int N
     if (!logits || !labels_i64 || !dlogits || !loss_out || N <= 0 || ncols <= 0 || col_off < 0 || col_off + ncols > ld)
         return CLHIP_EINVAL;
     if (reduction != 0 && reduction != 1) return CLHIP_EINVAL;
-    hipLaunchKernelGGL(softmax_ce_kernel<16>, dim3(1), dim3(LOSS_BLOCK), 0, as_stream(stream), logits, labels_i64, N, ncols,
-                       reduction, dlogits, loss_out, stats, ld, col_off);
+    if (ncols <= 64 && N <= LOSS_BLOCK && ld <= 4096)
+        hipLaunchKernelGGL(softmax_ce_rows_kernel, dim3(1), dim3(LOSS_BLOCK), 0, as_stream(stream), logits, labels_i64, N, ncols,
+                           reduction, dlogits, loss_out, stats, ld, col_off);
+    else
+        hipLaunchKernelGGL(softmax_ce_kernel<16>, dim3(1), dim3(LOSS_BLOCK), 0, as_stream(stream), logits, labels_i64, N, ncols,
+                           reduction, dlogits, loss_out, stats, ld, col_off);
     CLHIP_LAUNCH_CHECK();
     return 0;
 }
