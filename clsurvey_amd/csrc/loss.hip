@@ -138,14 +138,18 @@ __global__ __launch_bounds__(LOSS_BLOCK) void softmax_ce_rows_kernel(
     s_loss[row] = li;
     s_corr[row] = (unsigned char)ok;
     __syncthreads();
+    // fixed-order reduction: wave w sums rows w*64 .. w*64+63 with a butterfly, thread 0 adds the 16 wave sums
+    __shared__ float w_loss[16];
+    __shared__ int w_corr[16];
+    float v = s_loss[row];
+    int cc = s_corr[row];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { v += __shfl_xor(v, o, 64); cc += __shfl_xor(cc, o, 64); }
+    if ((threadIdx.x & 63) == 0) { w_loss[threadIdx.x >> 6] = v; w_corr[threadIdx.x >> 6] = cc; }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        // same summation order as the wave-per-row kernel: rows w, w+16, ... per wave, then waves 0..15
         float t = 0.f; int c = 0;
-        for (int w = 0; w < 16; ++w) {
-            float wl = 0.f;
-            for (int r = w; r < N; r += 16) { wl += s_loss[r]; c += s_corr[r]; }
-            t += wl;
-        }
+        for (int w = 0; w < 16; ++w) { t += w_loss[w]; c += w_corr[w]; }
         t *= scale;
         loss_out[0] = t;
         if (stats) { stats[0] += (double)t; stats[1] += (double)c; }
