@@ -23,6 +23,12 @@ static inline int ew_grid(size_t work_items, int block) {
     return (int)g;
 }
 
+// 16 zero bytes in device memory. Out-of-range / halo elements are loaded FROM HERE (address select) instead
+// of "load, then select 0": the select would consume the loaded register at once and make hipcc put an
+// s_waitcnt vmcnt(0) right behind every global load, i.e. serialise each load's full latency in front of the
+// MFMA loop (measured: conv kernels at ~55 % of what the same MFMA loop sustains in isolation).
+static __device__ __attribute__((aligned(16))) float clhip_zero16[4] = {0.f, 0.f, 0.f, 0.f};   // non-const: stays in the global address space (a const would be addrspace(4) and turn the selected load into flat_load)
+
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 

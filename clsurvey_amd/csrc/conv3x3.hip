@@ -224,34 +224,29 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
 #pragma unroll
             for (int j = 0; j < W_IT; ++j) {
                 const bool ok = (wok >> j) & 1u;
-                float4 v = *reinterpret_cast<const float4*>(ok ? wb + woff[j] : wt);
-                wv[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+                wv[j] = *reinterpret_cast<const float4*>(ok ? wb + woff[j] : clhip_zero16);
             }
 #pragma unroll
             for (int j = 0; j < X_IT; ++j) {
                 const bool ok = (xok >> j) & 1u;
-                float4 v = *reinterpret_cast<const float4*>(ok ? xb + xoff[j] : in);
-                xv[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+                xv[j] = *reinterpret_cast<const float4*>(ok ? xb + xoff[j] : clhip_zero16);
             }
 #pragma unroll
             for (int j = 0; j < H_IT; ++j) {
                 const bool ok = (hok >> j) & 1u;
-                float v = *(ok ? xb + hoff[j] : in);
-                hv[j] = ok ? v : 0.f;
+                hv[j] = *(ok ? xb + hoff[j] : clhip_zero16);
             }
         } else {
             const int cleft = Cin - c0;                  // channels left (>= CK except in the tail chunk)
 #pragma unroll
             for (int j = 0; j < W_IT; ++j) {
                 const bool ok = ((wok >> j) & 1u) && wch[j] < cleft;
-                float v = *(ok ? wb + woff[j] : wt);
-                wreg[j] = ok ? v : 0.f;
+                wreg[j] = *(ok ? wb + woff[j] : clhip_zero16);
             }
 #pragma unroll
             for (int j = 0; j < X_IT; ++j) {
                 const bool ok = ((xok >> j) & 1u) && xch[j] < cleft;
-                float v = *(ok ? xb + xoff[j] : in);
-                xreg[j] = ok ? v : 0.f;
+                xreg[j] = *(ok ? xb + xoff[j] : clhip_zero16);
             }
         }
     };

@@ -148,16 +148,14 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(
 #pragma unroll
             for (int j = 0; j < DY_IT; ++j) {
                 const bool ok = (h0 + (dyrow[j] & 255) < H) && (k0 + (dyrow[j] >> 8) < K);
-                float4 v = *reinterpret_cast<const float4*>(ok ? dyp + dyoff[j] : dy);
-                dyv[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+                dyv[j] = *reinterpret_cast<const float4*>(ok ? dyp + dyoff[j] : clhip_zero16);
             }
 #pragma unroll
             for (int j = 0; j < X_IT; ++j) {
                 const int mt = xmeta[j];
                 const int h = h0 - 1 + (mt & 255);
                 const bool ok = (tid + 256 * j < XV_ELEMS) && (unsigned)h < (unsigned)H && (c0 + (mt >> 24) < C);
-                float4 v = *reinterpret_cast<const float4*>(ok ? xp + xoff[j] : x);
-                xv[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+                xv[j] = *reinterpret_cast<const float4*>(ok ? xp + xoff[j] : clhip_zero16);
             }
 #pragma unroll
             for (int j = 0; j < H_IT; ++j) {
@@ -165,8 +163,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(
                 const int h = h0 - 1 + (mt & 15), w = ((mt >> 4) & 1) ? w0 + TW : w0 - 1;
                 const bool ok = (tid + 256 * j < XROWS * 2) && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W &&
                                 (c0 + (mt >> 24) < C);
-                float v = *(ok ? xp + hoff[j] : x);
-                hv[j] = ok ? v : 0.f;
+                hv[j] = *(ok ? xp + hoff[j] : clhip_zero16);
             }
         } else {
             const bool pix_ok = (h0 + th_t < H) && (w0 + tw_t < W);
@@ -174,8 +171,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(
 #pragma unroll
             for (int j = 0; j < DY_IT; ++j) {
                 const bool ok = pix_ok && (k0 + wave + 4 * j < K);
-                float v = *(ok ? dyp + (size_t)(4 * j) * plane_hw : dy);
-                dyr[j] = ok ? v : 0.f;
+                dyr[j] = *(ok ? dyp + (size_t)(4 * j) * plane_hw : clhip_zero16);
             }
 #pragma unroll
             for (int j = 0; j < X_IT; ++j) {
@@ -183,8 +179,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(
                 const int h = h0 - 1 + (mt & 15), w = w0 - 1 + ((mt >> 4) & 63);
                 const bool ok = (tid + 256 * j < X_ELEMS) && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W &&
                                 (c0 + ((mt >> 10) & 127) < C);
-                float v = *(ok ? xp + xoff[j] : x);
-                xr[j] = ok ? v : 0.f;
+                xr[j] = *(ok ? xp + xoff[j] : clhip_zero16);
             }
         }
     };
@@ -343,15 +338,13 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_smallc_kernel(
                 const int k = k0 + kl, hh = (h0 >> 1) + ph, ww = (w0 >> 1) + pw;
                 const bool ok = k < K && hh < OH && ww < OW;
                 const size_t o = (((size_t)n * K + k) * OH + hh) * OW + ww;
-                float g = *(ok ? dy + o : dy);
-                uint8_t a = *(ok ? unpool_idx + o : unpool_idx);
-                dyr[j] = ok ? g : 0.f;
-                upa[j] = ok ? (int)a : 255;
+                dyr[j] = *(ok ? dy + o : clhip_zero16);              // zero gradient => all four window slots 0
+                upa[j] = (int)*(ok ? unpool_idx + o : reinterpret_cast<const uint8_t*>(clhip_zero16));
             }
         } else {
 #pragma unroll
             for (int j = 0; j < DY_ITERS; ++j)
-                dyr[j] = (pix_ok && (k0 + wave + 4 * j < K)) ? dyp[(size_t)(4 * j) * plane_hw] : 0.f;
+                dyr[j] = *((pix_ok && (k0 + wave + 4 * j < K)) ? dyp + (size_t)(4 * j) * plane_hw : clhip_zero16);
         }
 #pragma unroll
         for (int j = 0; j < X_ITERS; ++j) {
@@ -359,7 +352,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_smallc_kernel(
             const int h = h0 - 1 + (mt & 15), w = w0 - 1 + ((mt >> 4) & 63);
             const bool ok = (tid + 256 * j < X_ELEMS) && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W &&
                             (((mt >> 10) & 127) < C);
-            xr[j] = ok ? xp[xoff[j]] : 0.f;
+            xr[j] = *(ok ? xp + xoff[j] : clhip_zero16);
         }
     };
     auto store_stage = [&]() {

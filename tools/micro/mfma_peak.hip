@@ -45,6 +45,13 @@ void run(const char* name, int blocks) {
 }
 
 int main() {
+    run<1, false>("1acc pure", 256);
+    run<2, false>("2acc pure", 256);
+    run<3, false>("3acc pure", 256);
+    run<1, false>("1acc pure", 512);
+    run<2, false>("2acc pure", 512);
+    run<4, true>("4acc + 5 lds reads", 256);
+    run<4, true>("4acc + 5 lds reads", 512);
     run<4, false>("4acc pure", 256);
     run<9, false>("9acc pure", 256);
     run<9, true>("9acc + 10 lds reads", 256);
