@@ -217,6 +217,9 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
     }
 
     auto load_chunk = [&](int chunk) {
+#ifdef CLHIP_ABL_NOGLOAD
+        if (chunk > 0) return;
+#endif
         const int c0 = chunk * CK;
         const float* wb = wt + (MODE == 0 ? (size_t)c0 * 9 : (size_t)c0 * Cw * 9);
         const float* xb = in_blk + (size_t)c0 * plane_hw;
@@ -252,6 +255,9 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
     };
 
     auto store_chunk = [&](int buf) {
+#ifdef CLHIP_ABL_NOLSTORE
+        if (buf == 1 && lds[0] != 12345.f) return;
+#endif
         float* ws = lds + buf * BUF_FLOATS;
         float* xs = ws + WS_FLOATS;
         if constexpr (VEC) {
@@ -326,8 +332,15 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
         }
 
         if (chunk + 1 < n_chunks) store_chunk(buf ^ 1);
+#ifndef CLHIP_ABL_NOSYNC
         __syncthreads();
+#endif
     }
+#ifdef CLHIP_ABL_NOEPI
+    { float sacc = 0.f;
+      for (int t = 0; t < G::NT; ++t) for (int r = 0; r < 16; ++r) sacc += acc[t][r];
+      if (sacc != 1.2345e30f) return; }
+#endif
 
     // ---- epilogue: reg r of lane l = D[row = out-channel][col = pixel li]
     const size_t out_img = (size_t)Cout * H * W;

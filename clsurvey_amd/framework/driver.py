@@ -326,7 +326,7 @@ def framework_single_task(args, manager, train_node=None):
     hf = HyperparameterFramework(manager.method)
     if args.save_models_FT_heuristic:
         args.save_models_mode = "all"
-    elif manager.method.name == "PackNet":
+    elif manager.method.name == "packnet":
         args.save_models_mode = "only_keep_best"
     else:
         args.save_models_mode = "keep_none"

@@ -7,6 +7,7 @@ so the framework drivers only talk to `manager.method.<hook>(args, manager, ...)
 """
 import copy
 import os
+import warnings
 from abc import ABC, abstractmethod
 from collections import OrderedDict
 from enum import Enum, auto
@@ -17,6 +18,7 @@ from ..data import DeviceLoader, TensorTaskDataset
 from . import ewc as trainEWC
 from . import finetune as trainFT
 from . import mas as trainMAS
+from . import packnet_main as trainPacknet
 from . import si as trainSI
 from . import train_common as tc
 
@@ -230,7 +232,103 @@ class SI(_Regularised):
             weight_decay=args.weight_decay, saving_freq=args.saving_freq, device=getattr(args, "device", "cuda"))
 
 
-_REGISTRY = {c.name: c for c in (EWC, MAS, SI, Finetune)}
+
+class PackNet(Method):
+    """method.py:415-556 (MASK_BASED): phase 1 = finetune on the free weights per LR, phase 2 = prune +
+    post-prune finetune; one wrapped model with a head per task and uint8 ownership masks."""
+    name = "packnet"
+    eval_name = name
+    category = Category.MASK_BASED
+    extra_hyperparams_count = 1
+    hyperparams = OrderedDict({"prune_perc_per_layer": 0.9})
+    grid_chkpt = True
+    start_scratch = True
+
+    def __init__(self):
+        self.pruned_savename = None
+        self.grid_batch_size = 200          # method.py:524 hardcodes 200 for phase 1 (tests shrink it)
+
+    @staticmethod
+    def get_dataset_name(task_name):
+        return "survey_TASK_" + task_name
+
+    def train_init(self, args, manager):
+        self.pruned_savename = os.path.join(manager.heuristic_exp_dir, "best_model_PRUNED")
+
+    def train(self, args, manager, hyperparams):
+        prune_lr = args.lr * 0.1            # method.py:437
+        manager.overwrite_args = {
+            "weight_decay": args.weight_decay, "train_path": manager.current_task_dataset_path,
+            "test_path": manager.current_task_dataset_path, "mode": "prune",
+            "dataset": self.get_dataset_name(args.task_name), "loadname": manager.best_finetuned_model_path,
+            "post_prune_epochs": 10, "prune_perc_per_layer": hyperparams["prune_perc_per_layer"], "lr": prune_lr,
+            "finetune_epochs": args.num_epochs, "cuda": True, "save_prefix": self.pruned_savename,
+            "train_bn": args.train_bn, "saving_freq": args.saving_freq, "current_dataset_idx": args.task_counter,
+            "batch_size": args.batch_size,
+        }
+        task_lr_acc = trainPacknet.main(manager.overwrite_args, device=getattr(args, "device", "cuda"))
+        return None, task_lr_acc
+
+    def get_output(self, images, args):
+        return get_output_def(args.model, args.heads, images, args.current_head_idx, args.final_layer_idx)
+
+    def init_next_task(self, manager):
+        assert self.pruned_savename is not None
+        if os.path.exists(self.pruned_savename + "_final.pth.tar"):
+            manager.previous_task_model_path = self.pruned_savename + "_final.pth.tar"
+        elif os.path.exists(self.pruned_savename + "_postprune.pth.tar"):
+            warnings.warn("Final file not found(no final file saved if finetune gives no improvement)! Using postprune")
+            manager.previous_task_model_path = self.pruned_savename + "_postprune.pth.tar"
+        else:
+            raise Exception("Previous task pruned model final/postprune non-existing: {}".format(self.pruned_savename))
+
+    def grid_prestep(self, args, manager):
+        manager.dataset_name = self.get_dataset_name(args.task_name)
+        manager.disable_pruning_mask = False
+        if args.task_counter == 1:
+            init_wrapper_model_name = os.path.join(manager.ft_parent_exp_dir, manager.base_model.name + "_INIT_WRAPPED.pth")
+            if not os.path.exists(init_wrapper_model_name):
+                arch = "alexnet" if "alexnet" in manager.base_model.name.lower() else "VGGslim_nopretrain"
+                trainPacknet.main({
+                    "arch": arch, "init_dump": True, "cuda": True, "loadname": manager.previous_task_model_path,
+                    "save_prefix": init_wrapper_model_name, "last_layer_idx": manager.base_model.last_layer_idx,
+                    "current_dataset_idx": args.task_counter})
+            manager.previous_task_model_path = init_wrapper_model_name
+            manager.disable_pruning_mask = True        # method.py:505: task 1 trains every weight
+
+    def grid_train(self, args, manager, lr):
+        ft_savename = os.path.join(manager.gridsearch_exp_dir, "best_model")
+        overwrite_args = {
+            "weight_decay": args.weight_decay, "disable_pruning_mask": manager.disable_pruning_mask,
+            "train_path": manager.current_task_dataset_path, "test_path": manager.current_task_dataset_path,
+            "mode": "finetune", "dataset": manager.dataset_name,
+            "num_outputs": len(manager.dataset.classes_per_task[args.task_name]),
+            "loadname": manager.previous_task_model_path, "lr": lr, "finetune_epochs": args.num_epochs, "cuda": True,
+            "save_prefix": ft_savename, "batch_size": self.grid_batch_size,
+            "train_bn": args.train_bn, "saving_freq": args.saving_freq, "current_dataset_idx": args.task_counter,
+        }
+        acc = trainPacknet.main(overwrite_args, device=getattr(args, "device", "cuda"))
+        return None, acc
+
+    def grid_poststep(self, args, manager):
+        manager.best_finetuned_model_path = os.path.join(manager.best_exp_grid_node_dirname, "best_model.pth.tar")
+
+    @staticmethod
+    def train_args_overwrite(args):
+        args.train_bn = "BN" in args.model_name         # ModelRegularization.batchnorm
+        print("TRAINING BN PARAMS = ", str(args.train_bn))
+
+    @staticmethod
+    def inference_eval(args, manager):
+        task_name = manager.dataset.get_taskname(args.eval_dset_idx + 1)
+        return trainPacknet.main({
+            "train_path": args.dset_path, "test_path": args.dset_path, "mode": "eval",
+            "dataset": PackNet.get_dataset_name(task_name), "loadname": args.eval_model_path, "cuda": True,
+            "batch_size": args.batch_size, "current_dataset_idx": args.eval_dset_idx + 1},
+            device=getattr(args, "device", "cuda"))
+
+
+_REGISTRY = {c.name: c for c in (EWC, MAS, SI, Finetune, PackNet)}
 
 
 def parse(method_name):

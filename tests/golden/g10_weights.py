@@ -6,11 +6,11 @@ import numpy as np
 SMALL = [64, "M", 64, "M", 64, 64, "M", 128, 128, "M"]
 
 
-def det_weights(seed=5):
+def det_weights(seed=5, cfg=None, fc=(128, 128), ncls=4, hw=32):
     """deterministic, quickly-trainable start weights (kaiming for conv AND linear), numpy-driven."""
     gen = np.random.RandomState(seed)
-    cfg = SMALL
-    ws, c, hw = [], 3, 32
+    cfg = SMALL if cfg is None else cfg
+    ws, c = [], 3
     for v in cfg:
         if v == "M":
             hw //= 2
@@ -19,7 +19,7 @@ def det_weights(seed=5):
         ws.append(np.zeros(v, dtype=np.float32))
         c = v
     d = c * hw * hw
-    for o in (128, 128, 4):
+    for o in (fc[0], fc[1], ncls):
         ws.append((gen.standard_normal((o, d)) * (2.0 / d) ** 0.5).astype(np.float32))
         ws.append(np.zeros(o, dtype=np.float32))
         d = o
