@@ -120,6 +120,16 @@ class HatEngine:
             check(L.clhip_hat_scale_weight(w.data_ptr(), gin.data_ptr(), self.scaled[off:off + n].data_ptr(), K, Cg, R,
                                            _stream()), "clhip_hat_scale_weight")
 
+    def forward(self, t, x, s):
+        """vgg_hat.Net.forward logits for task t at gate slope s (inference: s = smax)."""
+        self.gates(t, s)
+        self._scale_weights()
+        return self.engine.forward(x, params=self.scaled)
+
+    def plain_step(self, x, y, backward=True, stats=None):
+        """hat_finetune.py:133-137: forward with every gate forced to 1 (masks=ft_mask) + CE (+ backward)."""
+        return self.engine.loss_step(x, y, "ce_mean", backward, stats)
+
     def step(self, t, x, y, s, mask_pre=None, lamb=0.0, count=None, backward=True, stats=None, want_logits=False):
         """Returns (ce_loss[1] device, reg device scalar (lamb*reg), logits|None). With backward=True all
         .grad fields (convs, fcs, head in the arena; embeddings dense with row t filled) are set."""
@@ -208,7 +218,8 @@ class HAT_SGD(torch.optim.Optimizer):
                 check(L.clhip_hat_sgd_step(p.data.data_ptr(), p.grad.data.data_ptr(), st["momentum_buffer"].data_ptr(),
                                            mb.data_ptr() if mb is not None else None, p.numel(), float(group["lr"]),
                                            float(group["momentum"]), float(group["weight_decay"]), int("embs" in name),
-                                           int(finetune), float(s), float(smax), float(thres_cosh), float(clipgrad),
+                                           int(finetune), float(s or 0.0), float(smax or 0.0), float(thres_cosh or 0.0),
+                                           float(clipgrad or 0.0),
                                            int(first), self._ws.data_ptr(), self._ws.numel(), _stream()),
                       "clhip_hat_sgd_step")
         return None

@@ -17,6 +17,7 @@ import torch
 from ..data import DeviceLoader, TensorTaskDataset
 from . import ewc as trainEWC
 from . import finetune as trainFT
+from . import hat_main as trainHAT
 from . import mas as trainMAS
 from . import packnet_main as trainPacknet
 from . import si as trainSI
@@ -328,7 +329,56 @@ class PackNet(Method):
             device=getattr(args, "device", "cuda"))
 
 
-_REGISTRY = {c.name: c for c in (EWC, MAS, SI, Finetune, PackNet)}
+
+def _modular_accespoint(args, manager, parameter, method_arg, save_path=None, prev_model_path=None, finetune=False):
+    """method.py:630-660."""
+    nc_per_task = [len(v) for v in manager.dataset.classes_per_task.values()]       # dataset_utils.get_nc_per_task
+    save_path = manager.heuristic_exp_dir if save_path is None else save_path
+    prev_model_path = manager.previous_task_model_path if prev_model_path is None else prev_model_path
+    manager.overwrite_args = {
+        "weight_decay": args.weight_decay, "task_name": args.task_name, "task_count": args.task_counter,
+        "prev_model_path": prev_model_path, "model_name": args.model_name, "output": save_path,
+        "nepochs": args.num_epochs, "parameter": parameter, "cuda": True,
+        "dataset_path": manager.current_task_dataset_path, "dataset": manager.dataset,
+        "n_tasks": manager.dataset.task_count, "batch_size": args.batch_size, "lr": args.lr,
+        "is_scratch_model": args.task_counter == 1, "approach": method_arg, "nc_per_task": nc_per_task,
+        "finetune_mode": finetune, "save_freq": args.saving_freq,
+    }
+    return trainHAT.main(manager.overwrite_args, device=getattr(args, "device", "cuda"))
+
+
+class HAT(Method):
+    """method.py:600-627 (MASK_BASED): hard attention to the task; accuracies are fractions in [0, 1]."""
+    name = "HAT"
+    eval_name = name
+    category = Category.MASK_BASED
+    extra_hyperparams_count = 2
+    hyperparams = OrderedDict({"smax": 800, "c": 2.5})
+    start_scratch = True
+
+    def grid_train(self, args, manager, lr):
+        args.lr = lr
+        return _modular_accespoint(args, manager, list(self.hyperparams.values()), "hat",
+                                   save_path=manager.gridsearch_exp_dir, finetune=True)
+
+    def train(self, args, manager, hyperparams):
+        return _modular_accespoint(args, manager, list(hyperparams.values()), "hat")
+
+    def get_output(self, images, args):
+        from . import hat as H
+        head = args.heads[args.current_head_idx]
+        eng = getattr(args, "_hat_engine", None)
+        if eng is None or eng.net is not args.model or eng.net.classifier[0] is not head:
+            args.model.classifier = torch.nn.ModuleList([head])
+            eng = args._hat_engine = H.HatEngine(args.model, args.batch_size, tuple(images.shape[1:]), images.device)
+        return eng.forward(args.task_idx, images, args.model.smax)
+
+    @staticmethod
+    def inference_eval(args, manager):
+        return Finetune.inference_eval(args, manager)
+
+
+_REGISTRY = {c.name: c for c in (EWC, MAS, SI, Finetune, PackNet, HAT)}
 
 
 def parse(method_name):

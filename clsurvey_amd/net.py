@@ -174,10 +174,11 @@ class NetEngine:
         if tuple(x.shape[1:]) != self.in_shape or x.shape[0] > self.max_batch:
             raise RuntimeError("NetEngine: bad input shape %s" % (tuple(x.shape),))
 
-    def forward(self, x):
+    def forward(self, x, params=None):
         self._check_x(x)
         logits = torch.empty((x.shape[0], self.n_classes), dtype=torch.float32, device=self.device)
-        check(_lib.lib().clhip_net_forward(self._h, self.arena.theta.data_ptr(), x.data_ptr(), x.shape[0],
+        check(_lib.lib().clhip_net_forward(self._h, (params if params is not None else self.arena.theta).data_ptr(),
+                                           x.data_ptr(), x.shape[0],
                                            self.ws.data_ptr(), logits.data_ptr(),
                                            torch.cuda.current_stream().cuda_stream), "clhip_net_forward")
         return logits
