@@ -340,6 +340,12 @@ def framework_single_task(args, manager, train_node=None):
     if not skip_to_post:
         ft_lr, ft_acc = hf.maximalPlasticitySearch(args, manager, train_node)
         hf.stabilityDecay(args, manager, ft_lr, ft_acc)
+    else:
+        # The reference reads manager.best_model_path in GEM.poststep (method.py:307) without ever setting it on
+        # this path; the evident intent ("save wrapped SI model in first task best_model_path") is task_1's slot.
+        manager.heuristic_exp_dir = os.path.join(manager.parent_exp_dir, "task_" + str(args.task_counter),
+                                                 "TASK_TRAINING")
+        manager.best_model_path = os.path.join(manager.heuristic_exp_dir, "best_model.pth.tar")
     if hasattr(manager.method, "poststep"):
         manager.method.poststep(args, manager)
     if hasattr(manager.method, "init_next_task"):

@@ -45,25 +45,63 @@ def extend_head(model, n_outputs):
 
 
 class GemNet:
+    """gem.Net (gem.py:83-387). Picklable like the reference's nn.Module (torch.save(model) /
+    copy.deepcopy(model) in train_rehearsal.py:176-180): the pickle carries the wrapped net, the exemplar
+    tensors and the counters; engine / workspaces are rebuilt on load (init_setup)."""
+
     def __init__(self, model, n_outputs, n_tasks, nc_per_task, n_memories, lr, weight_decay=0.0, memory_strength=1.0,
                  batch_size=200, in_shape=(3, 64, 64), device="cuda"):
         self.net = model.to(device)
         self.device = torch.device(device)
         self.n_outputs, self.n_tasks, self.n_memories = n_outputs, n_tasks, n_memories
         self.batch_size = batch_size
-        self.engine = NetEngine(self.net, max(batch_size, 1), in_shape, device)
-        self.A = self.engine.arena
-        self.G = torch.zeros((n_tasks, self.A.numel), dtype=torch.float32, device=self.device)   # gem.py:131
-        self.memory_x = torch.zeros((n_tasks, n_memories) + tuple(in_shape), dtype=torch.float32, device=self.device)
+        self.in_shape = tuple(in_shape)
+        self.memory_x = torch.zeros((n_tasks, n_memories) + self.in_shape, dtype=torch.float32, device=self.device)
         self.memory_labels = torch.zeros((n_tasks, n_memories), dtype=torch.int64, device=self.device)
         self.cum_nc_per_task = [sum(nc_per_task[:i + 1]) for i in range(len(nc_per_task))]
         self.observed_tasks, self.old_task, self.mem_cnt = [], -1, 0
-        self.margin = memory_strength
-        self.opt = SGD(self.net.parameters(), lr, momentum=0.9, weight_decay=weight_decay)       # gem.py:151
+        self._bind()
+        self.init_setup(lr=lr, weight_decay=weight_decay, memory_strength=memory_strength)
+
+    def _bind(self):
+        self.engine = NetEngine(self.net, max(self.batch_size, 1), self.in_shape, self.device)
+        self.A = self.engine.arena
+        self.G = torch.zeros((self.n_tasks, self.A.numel), dtype=torch.float32, device=self.device)   # gem.py:131
         L = _lib.lib()
         self._gram_ws = torch.zeros(L.clhip_gem_gram_ws(16), dtype=torch.uint8, device=self.device)
         self._gram = torch.zeros(16 * 16, dtype=torch.float64, device=self.device)
         self.stats = torch.zeros(2, dtype=torch.float64, device=self.device)
+
+    def init_setup(self, args=None, lr=None, weight_decay=None, memory_strength=None):
+        """gem.py:146-155: fresh SGD(momentum 0.9) and margin; called after construction and after torch.load."""
+        if args is not None:
+            lr, weight_decay, memory_strength = args.lr, args.weight_decay, args.memory_strength
+        self.opt = SGD(self.net.parameters(), lr, momentum=0.9, weight_decay=weight_decay)       # gem.py:151
+        self.margin = memory_strength
+
+    _TRANSIENT = ("engine", "A", "G", "_gram_ws", "_gram", "stats", "opt")
+
+    def __getstate__(self):
+        return {k: v for k, v in self.__dict__.items() if k not in self._TRANSIENT}
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self.device = torch.device(self.device)
+        self.net = self.net.to(self.device)
+        self._bind()
+        self.opt = None
+
+    def compute_offsets(self, task_idx, cum_nc_per_task):
+        return compute_offsets(task_idx, cum_nc_per_task)
+
+    def parameters(self):
+        return self.net.parameters()
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        return self
 
     # ------------------------------------------------------------------ memory
     def init_new_task(self, t):
@@ -143,6 +181,22 @@ class GemNet:
                 self.project(rows[:-1], v, t)                         # project2cone2 + overwrite_grad (:278-283)
         self.opt.step()
         return loss, self.stats[1], batch_stats
+
+    def observe_FT(self, x, t, y):
+        """gem.py:289-309: plain SGD step on the task's output slice (phase-1 grid; no memory)."""
+        sl = compute_offsets(t, self.cum_nc_per_task)
+        self.stats.zero_()
+        loss, _ = self.engine.loss_step(x, y, "ce_mean", True, self.stats, class_slice=sl)
+        self.opt.step()
+        return loss, self.stats[1]
+
+    def eval_batch(self, x, y, t, stats):
+        """main_rehearsal.py:18-35: CE and hits on the task slice (accumulated into stats on the device)."""
+        sl = compute_offsets(t, self.cum_nc_per_task)
+        return self.engine.loss_step(x, y, "ce_mean", False, stats, class_slice=sl)[0]
+
+    def __call__(self, x, t, **kw):
+        return self.forward(x, t)
 
     def forward(self, x, t):
         """gem.py:169-204 (eval): logits with everything outside the task slice at -1e11."""

@@ -7,6 +7,7 @@ so the framework drivers only talk to `manager.method.<hook>(args, manager, ...)
 """
 import copy
 import os
+import time
 import warnings
 from abc import ABC, abstractmethod
 from collections import OrderedDict
@@ -17,6 +18,7 @@ import torch
 from ..data import DeviceLoader, TensorTaskDataset
 from . import ewc as trainEWC
 from . import finetune as trainFT
+from . import gem_main as trainRehearsal
 from . import hat_main as trainHAT
 from . import mas as trainMAS
 from . import packnet_main as trainPacknet
@@ -378,7 +380,71 @@ class HAT(Method):
         return Finetune.inference_eval(args, manager)
 
 
-_REGISTRY = {c.name: c for c in (EWC, MAS, SI, Finetune, PackNet, HAT)}
+
+def _rehearsal_accespoint(args, manager, memory_strength, mem_per_task, method_arg, save_path=None, prev_model_path=None,
+                          finetune=False, postprocess=False):
+    """method.py:381-412."""
+    nc_per_task = [len(v) for v in manager.dataset.classes_per_task.values()]
+    total_outputs = sum(nc_per_task)
+    save_path = manager.heuristic_exp_dir if save_path is None else save_path
+    prev_model_path = manager.previous_task_model_path if prev_model_path is None else prev_model_path
+    manager.overwrite_args = {
+        "weight_decay": args.weight_decay, "task_name": args.task_name, "task_count": args.task_counter,
+        "prev_model_path": prev_model_path, "save_path": save_path, "n_outputs": total_outputs, "method": method_arg,
+        "n_memories": mem_per_task, "n_epochs": args.num_epochs, "memory_strength": memory_strength, "cuda": True,
+        "dataset_path": manager.current_task_dataset_path, "n_tasks": manager.dataset.task_count,
+        "batch_size": args.batch_size, "lr": args.lr, "finetune": finetune,
+        "is_scratch_model": args.task_counter == 1, "postprocess": postprocess,
+    }
+    return trainRehearsal.main(manager.overwrite_args, nc_per_task, device=getattr(args, "device", "cuda"))
+
+
+class GEM(Method):
+    """method.py:281-327 (REHEARSAL_BASED). Task 1 only wraps the shared SI model with its exemplars."""
+    name = "GEM"
+    eval_name = name
+    category = Category.REHEARSAL_BASED
+    extra_hyperparams_count = 1
+    hyperparams = OrderedDict({"margin": 1})
+    static_hyperparams = OrderedDict({"mem_per_task": 1024})
+    wrap_first_task_model = True
+
+    def train(self, args, manager, hyperparams):
+        return _rehearsal_accespoint(args, manager, hyperparams["margin"], self.static_hyperparams["mem_per_task"], "gem")
+
+    def get_output(self, images, args):
+        offset1, offset2 = args.model.compute_offsets(args.current_head_idx, args.model.cum_nc_per_task)
+        return args.model(images, args.current_head_idx)[:, offset1:offset2]
+
+    def poststep(self, args, manager):
+        if args.task_counter > 1:
+            return
+        start_time = time.time()
+        save_path = manager.best_model_path
+        prev_model_path = manager.previous_task_model_path
+        if not os.path.exists(save_path):
+            args.lr = getattr(args, "lr", None) or 0.0           # the wrapper's optimizer is rebuilt at the next task
+            _rehearsal_accespoint(args, manager, self.hyperparams["margin"], self.static_hyperparams["mem_per_task"],
+                                  "gem", save_path, prev_model_path, postprocess=args.task_counter == 1)
+        args.postprocess_time = time.time() - start_time
+        manager.best_model_path = save_path
+
+    def grid_train(self, args, manager, lr):
+        args.lr = lr
+        return _rehearsal_accespoint(args, manager, 0, self.static_hyperparams["mem_per_task"], "gem",
+                                     save_path=manager.gridsearch_exp_dir, finetune=True)
+
+    @staticmethod
+    def inference_eval(args, manager):
+        """FinetuneRehearsalFullMem.inference_eval (method.py:1172-1182)."""
+        from ..framework import inference as test_network
+        model = tc.load_model(args.eval_model_path)
+        return test_network.test_model(manager.method, model, args.dset_path, args.eval_dset_idx, subset=args.test_set,
+                                       target_head=None, batch_size=args.batch_size, task_idx=args.eval_dset_idx,
+                                       device=getattr(args, "device", "cuda"))
+
+
+_REGISTRY = {c.name: c for c in (EWC, MAS, SI, Finetune, PackNet, HAT, GEM)}
 
 
 def parse(method_name):

@@ -539,3 +539,36 @@ def test_hat_through_driver(tmp_path):
     for t in (1, 2, 3):
         tdir = os.path.join(out["manager"].parent_exp_dir, "task_%d" % t, "TASK_TRAINING")
         assert os.path.exists(os.path.join(tdir, "best_model.pth.tar")) and os.path.exists(os.path.join(tdir, "SUCCESS.FLAG"))
+
+
+# --------------------------------------------------------------------------- GEM trainer (a13-a16)
+def test_gem_through_driver(tmp_path):
+    """GEM Method class through the driver on three tiny tasks with --test: task 1 = the shared SI model wrapped
+    with its exemplars (postprocess), tasks 2-3 = phase-1 observe_FT grid + phase-2 observe with memory passes,
+    Gram, QP and projection.  Checks the wire files, the exemplar buffers and that the pickled wrapper reloads."""
+    from clsurvey_amd.framework import driver
+    from clsurvey_amd.methods import method as M
+    root = str(tmp_path)
+    ds = _dataset(root)
+    _friendly_base_model(root)
+    driver.main(COMMON + ["--method_name", "SI", "--results_root", root, "--runmode", "first_task_basemodel_dump"],
+                method=M.parse("SI"), dataset=ds)
+    gem = M.parse("GEM")
+    gem.static_hyperparams = {"mem_per_task": 64}
+    out = driver.main(COMMON + ["--method_name", "GEM", "--results_root", root, "--test"], method=gem, dataset=ds)
+    res = out["results"]
+    assert sorted(res) == [0, 1, 2]
+    accs = [a for i in res for a in res[i]["seq_res"][i]]
+    assert all(0.0 <= a <= 100.0 for a in accs)
+    assert res[0]["seq_res"][0][0] > 40.0 and res[2]["seq_res"][2][0] > 30.0, res
+    wrapped = torch.load(out["model_paths"][0], weights_only=False)
+    assert wrapped.observed_tasks == [0] and wrapped.n_memories == 64 and wrapped.n_outputs == 12
+    assert float(wrapped.memory_x[0].abs().sum()) > 0 and float(wrapped.memory_x[1].abs().sum()) == 0
+    last = torch.load(out["model_paths"][-1], weights_only=False)
+    assert last.observed_tasks == [0, 1, 2] and last.cum_nc_per_task == [4, 8, 12]
+    assert all(float(last.memory_x[t].abs().sum()) > 0 for t in range(3))
+    x = torch.randn(5, 3, 32, 32, device="cuda")
+    lo = last(x, 1)
+    assert lo.shape == (5, 12) and bool((lo[:, :4] < -1e10).all()) and bool((lo[:, 8:] < -1e10).all())
+    hf = out["frameworks"][-1]
+    assert len(hf.trace) >= 1
