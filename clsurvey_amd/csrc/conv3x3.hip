@@ -217,9 +217,6 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
     }
 
     auto load_chunk = [&](int chunk) {
-#ifdef CLHIP_ABL_NOGLOAD
-        if (chunk > 0) return;
-#endif
         const int c0 = chunk * CK;
         const float* wb = wt + (MODE == 0 ? (size_t)c0 * 9 : (size_t)c0 * Cw * 9);
         const float* xb = in_blk + (size_t)c0 * plane_hw;
@@ -255,9 +252,6 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
     };
 
     auto store_chunk = [&](int buf) {
-#ifdef CLHIP_ABL_NOLSTORE
-        if (buf == 1 && lds[0] != 12345.f) return;
-#endif
         float* ws = lds + buf * BUF_FLOATS;
         float* xs = ws + WS_FLOATS;
         if constexpr (VEC) {
@@ -332,15 +326,8 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
         }
 
         if (chunk + 1 < n_chunks) store_chunk(buf ^ 1);
-#ifndef CLHIP_ABL_NOSYNC
         __syncthreads();
-#endif
     }
-#ifdef CLHIP_ABL_NOEPI
-    { float sacc = 0.f;
-      for (int t = 0; t < G::NT; ++t) for (int r = 0; r < 16; ++r) sacc += acc[t][r];
-      if (sacc != 1.2345e30f) return; }
-#endif
 
     // ---- epilogue: reg r of lane l = D[row = out-channel][col = pixel li]
     const size_t out_img = (size_t)Cout * H * W;
@@ -433,6 +420,218 @@ int launch_conv(const float* in, const float* wt, const float* bias, const float
 #undef GEO
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// First layer (C = 3) with fused bias + ReLU + 2x2 max-pool (VGGSlim.py:27-40: conv(3->64), ReLU, 'M').
+//
+// K = 27 (padded to 28 = 14 MFMA k-pairs) is far too short for the chunked kernel above: one chunk, no
+// pipelining, a block lives ~10 us and most of that is prologue / epilogue latency (measured 24 TFLOP/s).
+// Here the block is persistent: the 64x27 weight slice lives in 28 VGPRs per lane for the whole kernel (A
+// operand straight from registers), tiles of 8 rows x 32 columns stream through two 4 KB LDS halo buffers
+// (register-staged prefetch of tile i+1 during tile i), and each wave owns two image rows h, h+1 so the
+// vertical pool partner is the SAME lane of the other accumulator and the horizontal one is lane^1 (one DPP
+// quad_perm) — no cross-row shuffles, the pre-pool activation never leaves registers.
+//   per wave and tile: 28 ds_read_b32, 56 MFMA (2 rows x 2 channel halves x 14 k-pairs).
+constexpr int C3_TW = 32, C3_TH = 8, C3_TWP = C3_TW + 2;
+constexpr int C3_WROWS = 4;                         // halo rows a wave stages for ITS two image rows
+constexpr int C3_PLANE = C3_WROWS * C3_TWP;         // 136 floats per channel
+constexpr int C3_HALO = 3 * C3_PLANE;               // 408 floats per wave and buffer
+constexpr int C3_PLD = 20;     // pooled-slab row stride: 16-byte aligned rows, kk halves (4 rows apart) on disjoint banks
+
+__device__ __forceinline__ float dpp_xor1(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true));
+}
+
+// Every wave is an independent worker: it stages the 4-row halo of its own two image rows into a private,
+// double-buffered LDS slab, so the tile loop has NO block barrier and the waves of a SIMD drift apart —
+// one wave's MFMA phase overlaps another's epilogue (VALU + LDS) instead of all four marching in lock step.
+__global__ __launch_bounds__(256, 2) void conv3x3_c3_relu_pool_kernel(
+    const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
+    float* __restrict__ out, uint8_t* __restrict__ pool_idx, int N, int Cout, int H, int W,
+    int tiles_w, int tiles_h, int ntiles) {
+    __shared__ float halo_s[4 * 2 * C3_HALO];
+    __shared__ float bias_s[KT];
+    __shared__ __attribute__((aligned(16))) float pool_s[4 * KT * C3_PLD];     // per wave: [64 channels][16 pooled px] (+4 pad)
+    __shared__ __attribute__((aligned(16))) uint8_t idx_s[4 * KT * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kk = lane >> 5;
+    const int ko0 = blockIdx.y * KT;
+
+    if (tid < KT) bias_s[tid] = (bias && ko0 + tid < Cout) ? bias[ko0 + tid] : 0.f;
+
+    // K order: the 27 taps (+1 zero pad) are paired so that the two taps of a pair differ by a FIXED LDS offset
+    // (kk selects the tap): 9 pairs (c, r=0, s)/(c, r=1, s) [+1 halo row], 3 pairs (c, 2, 0)/(c, 2, 1) [+1 column],
+    // (0, 2, 2)/(1, 2, 2) [+1 channel plane] and (2, 2, 2)/pad.  Three per-lane base registers + immediates address
+    // every B operand; the A fragments (weights, in registers for the whole kernel) follow the same order.
+    float a[2][14];
+    auto tap = [&](int j, int& c, int& r, int& s) -> bool {        // tap of k-pair j for this lane's kk; false = zero pad
+        if (j < 9) { c = j / 3; s = j - 3 * c; r = kk; return true; }
+        if (j < 12) { c = j - 9; r = 2; s = kk; return true; }
+        if (j == 12) { c = kk; r = 2; s = 2; return true; }
+        c = 2; r = 2; s = 2; return kk == 0;
+    };
+#pragma unroll
+    for (int j = 0; j < 14; ++j) {
+        int c, r, s2;
+        const bool real = tap(j, c, r, s2);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int ch = ko0 + 32 * half + li;
+            a[half][j] = (real && ch < Cout) ? wt[(size_t)ch * 27 + c * 9 + r * 3 + s2] : 0.f;
+        }
+    }
+    const int b_row = li + kk * C3_TWP, b_col = li + kk, b_pln = li + kk * C3_PLANE;
+    auto b_addr = [&](int j) -> int {               // LDS offset of tap (j, kk) for image row 0 of the wave
+        if (j < 9) return b_row + (j / 3) * C3_PLANE + (j % 3);
+        if (j < 12) return b_col + (j - 9) * C3_PLANE + 2 * C3_TWP;
+        if (j == 12) return b_pln + 2 * C3_TWP + 2;
+        return li + 2 * C3_PLANE + 2 * C3_TWP + 2;                 // kk = 1 reads the same finite value; its A is 0
+    };
+
+    // staging of this wave's [3][4][34] halo: six loads cover columns 1..32 of two rows each (lanes 0-31 row 2i,
+    // lanes 32-63 row 2i+1 of the 12 (channel, row) lines), a seventh the two border columns of all 12 lines.
+    float sv[7];
+    const size_t plane_hw = (size_t)H * W;
+    const int st_src = kk * W + li;                                 // + (c*plane_hw + (rr-1)*W) per load
+    const int st_dst = kk * C3_TWP + li + 1;
+    const int e_line = lane >> 1, e_side = lane & 1;                // border columns: 24 lanes
+    const int e_c = e_line >> 2, e_rr = e_line & 3;
+    const int st_esrc = e_c * (int)plane_hw + (e_rr - 1) * W + (e_side ? C3_TW : -1);
+    const int st_edst = e_c * C3_PLANE + e_rr * C3_TWP + (e_side ? C3_TW + 1 : 0);
+    auto tile_coords = [&](int t, int& n, int& h, int& w0) {
+        const int tw = t % tiles_w, q = t / tiles_w;
+        const int th = q % tiles_h;
+        n = q / tiles_h; h = th * C3_TH + 2 * wave; w0 = tw * C3_TW;
+    };
+    auto load_tile = [&](int t) {
+        int n, h, w0;
+        tile_coords(t, n, h, w0);
+        const float* xb = x + (size_t)n * 3 * plane_hw + (size_t)h * W + w0;
+        bool rok[2];                                 // halo rows h-1+kk and h+1+kk
+        rok[0] = (unsigned)(h - 1 + kk) < (unsigned)H;
+        rok[1] = (unsigned)(h + 1 + kk) < (unsigned)H;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const float* p = xb + (i >> 1) * (ptrdiff_t)plane_hw + (2 * (i & 1) - 1) * W + st_src;
+            sv[i] = *(rok[i & 1] ? p : clhip_zero16);
+        }
+        const bool eok = lane < 24 && (unsigned)(h - 1 + e_rr) < (unsigned)H &&
+                         (unsigned)(w0 + (e_side ? C3_TW : -1)) < (unsigned)W;
+        const float* pe = xb + st_esrc;
+        sv[6] = *(eok ? pe : clhip_zero16);
+    };
+    float* hw_s = halo_s + wave * (2 * C3_HALO);
+    auto store_tile = [&](int buf) {
+        float* d = hw_s + buf * C3_HALO;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) d[(i >> 1) * C3_PLANE + 2 * (i & 1) * C3_TWP + st_dst] = sv[i];
+        if (lane < 24) d[st_edst] = sv[6];
+    };
+
+    const int OH = H >> 1, OW = W >> 1;          // OW % 16 == 0 (W % 32 == 0): every 16-pixel pooled run is 64-byte aligned
+    int tile = blockIdx.x, buf = 0;
+    if (tile < ntiles) { load_tile(tile); store_tile(0); }
+    // the weight fragments must be complete BEFORE the loop: otherwise hipcc's waitcnt pass, merging the loop
+    // back-edge with this preheader, puts s_waitcnt vmcnt(0) in front of the first MFMA of every tile and the
+    // prefetch of tile i+1 stops overlapping the MFMAs of tile i
+    __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0), expcnt / lgkmcnt untouched
+    __syncthreads();                                // bias_s
+    float* pw = pool_s + wave * (KT * C3_PLD);
+    uint8_t* iw = idx_s + wave * (KT * 16);
+    // one lane-dependent base per array, everything else is an immediate offset of the LDS instruction
+    float* pw_l = pw + 4 * kk * C3_PLD + (li >> 1);
+    uint8_t* iw_l = iw + 4 * kk * 16 + (li >> 1);
+    const float* bias_k = bias_s + 4 * kk;
+    for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+        const int next = tile + gridDim.x;
+        if (next < ntiles) load_tile(next);
+
+        floatx16 acc[2][2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int row = 0; row < 2; ++row)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[half][row][r] = 0.f;
+        const float* xs = hw_s + buf * C3_HALO;
+        float b0[14], b1[14];
+#pragma unroll
+        for (int j = 0; j < 14; ++j) { b0[j] = xs[b_addr(j)]; b1[j] = xs[b_addr(j) + C3_TWP]; }
+        __builtin_amdgcn_sched_barrier(0);          // all 28 LDS reads in flight before the first MFMA
+#pragma unroll
+        for (int j = 0; j < 14; ++j) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][j], b0[j], acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][j], b0[j], acc[1][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][j], b1[j], acc[0][1], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][j], b1[j], acc[1][1], 0, 0, 0);
+        }
+
+        // stage tile i+1 now: its loads had the whole MFMA phase to land, and doing it BEFORE the global stores keeps
+        // the vmcnt wait from also draining those. The other buffer was last read one iteration ago by this same wave.
+        if (next < ntiles) store_tile(buf ^ 1);
+
+        // epilogue: window = {(h, w), (h, w+1), (h+1, w), (h+1, w+1)} = {acc row 0 lane, lane^1, acc row 1 lane, lane^1};
+        // first maximum in that scan order wins (ATen max_pool2d).  The even lanes put value and 2-bit argmax into this
+        // wave's LDS slab [64 channels][16 pooled pixels]; the slab then leaves as 16-byte stores (4 + 1 store
+        // instructions per wave and tile instead of 64 quarter-filled ones — the VMEM issue rate, not the matrix
+        // pipe, was the limiter with direct stores: measured 61 us for the layer).
+        int n, h, w0;
+        tile_coords(tile, n, h, w0);
+        asm volatile("" ::: "memory");              // keep the 32 bias reads in the loop (hoisted they cost 32 VGPRs -> scratch spills)
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float bv = bias_k[32 * half + (r & 3) + 8 * (r >> 2)];
+                const float tl = fmaxf(acc[half][0][r] + bv, 0.f), bl = fmaxf(acc[half][1][r] + bv, 0.f);
+                const float tr = dpp_xor1(tl), br = dpp_xor1(bl);
+                float m = tl; int am = 0;
+                if (tr > m) { m = tr; am = 1; }
+                if (bl > m) { m = bl; am = 2; }
+                if (br > m) { m = br; am = 3; }
+                acc[half][0][r] = m;                           // results stay in the accumulator registers ...
+                acc[half][1][r] = __int_as_float(am);
+            }
+        if (!(li & 1)) {                                        // ... and ONE exec-masked region writes them out
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c0 = 32 * half + (r & 3) + 8 * (r >> 2);      // + 4*kk: in the lane bases
+                    pw_l[c0 * C3_PLD] = acc[half][0][r];
+                    iw_l[c0 * 16] = (uint8_t)__float_as_int(acc[half][1][r]);
+                }
+        }
+        __builtin_amdgcn_wave_barrier();            // LDS ops of one wave execute in order; keep the compiler's order too
+        if (h < H) {
+            const size_t chw = (size_t)OH * OW;
+            const size_t obase = (size_t)n * Cout * chw + (size_t)(h >> 1) * OW + (w0 >> 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = lane + 64 * i, cl = q >> 2, part = q & 3;
+                const float4 v = *reinterpret_cast<const float4*>(pw + cl * C3_PLD + 4 * part);
+                if (ko0 + cl < Cout) *reinterpret_cast<float4*>(out + obase + (size_t)(ko0 + cl) * chw + 4 * part) = v;
+            }
+            const uint4 iv = *reinterpret_cast<const uint4*>(iw + lane * 16);
+            if (ko0 + lane < Cout) *reinterpret_cast<uint4*>(pool_idx + obase + (size_t)(ko0 + lane) * chw) = iv;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+int launch_c3_pool(const float* x, const float* wt, const float* bias, float* out, uint8_t* idx,
+                   int N, int Cout, int H, int W, hipStream_t s) {
+    const int tiles_w = W / C3_TW, tiles_h = (H + C3_TH - 1) / C3_TH;
+    const long long ntiles = (long long)tiles_w * tiles_h * N;
+    const int kts = (Cout + KT - 1) / KT;
+    if (ntiles <= 0 || ntiles > 0x7fffffffLL) return CLHIP_EINVAL;
+    long long gx = 512 / kts;                       // 2 resident blocks per CU over all channel tiles
+    if (gx < 1) gx = 1;
+    if (gx > ntiles) gx = ntiles;
+    hipLaunchKernelGGL(conv3x3_c3_relu_pool_kernel, dim3((unsigned)gx, (unsigned)kts), dim3(256), 0, s,
+                       x, wt, bias, out, idx, N, Cout, H, W, tiles_w, tiles_h, (int)ntiles);
+    CLHIP_LAUNCH_CHECK();
+    return 0;
+}
+
 // 16-byte staging needs aligned rows and whole tiles along w.
 bool vec_ok(const float* in, const float* wt, int Cin, int H, int W, int Cw) {
     const int TW = W > 16 ? 32 : (W > 8 ? 16 : 8);
@@ -457,6 +656,7 @@ int clhip_conv3x3_relu_pool_fwd(const float* x, const float* w, const float* b, 
     if (!x || !w || !y_pool || !idx_u8 || N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1))
         return CLHIP_EINVAL;
     hipStream_t s = as_stream(stream);
+    if (C == 3 && W % C3_TW == 0) return launch_c3_pool(x, w, b, y_pool, idx_u8, N, K, H, W, s);
     if (C <= 4) return launch_conv<4, 0, false>(x, w, b, nullptr, y_pool, N, C, K, H, W, K, C, 1, s, idx_u8);
     if (vec_ok(x, w, C, H, W, C)) return launch_conv<8, 0, true>(x, w, b, nullptr, y_pool, N, C, K, H, W, K, C, 1, s, idx_u8);
     return launch_conv<8, 0, false>(x, w, b, nullptr, y_pool, N, C, K, H, W, K, C, 1, s, idx_u8);

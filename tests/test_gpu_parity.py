@@ -605,7 +605,8 @@ def test_gem_observe_step_vs_oracle():
 @pytest.mark.parametrize("shape", [(2, 3, 16, 32, 32), (3, 16, 16, 16, 16), (5, 32, 24, 8, 8), (9, 3, 64, 64, 64),
                                    (4, 64, 64, 32, 32), (40, 64, 64, 16, 16), (33, 64, 128, 8, 8), (2, 8, 40, 12, 20)])
 def test_fused_conv_relu_pool(shape):
-    """fused conv+ReLU+maxpool == separate kernels, bit for bit (same accumulation order), and the argmax is ATen's."""
+    """fused conv+ReLU+maxpool == separate kernels (bit for bit where the accumulation order is the same), and the
+    argmax is ATen's."""
     import torch.nn.functional as F
     from clsurvey_amd import ops
     N, C, K, H, W = shape
@@ -614,8 +615,17 @@ def test_fused_conv_relu_pool(shape):
     y = ops.conv3x3_fwd(x, w, b, relu=True)
     yp_ref, idx_ref = ops.maxpool2_fwd(y)
     yp, idx = ops.conv3x3_relu_pool_fwd(x, w, b)
-    assert torch.equal(yp, yp_ref)
-    assert torch.equal(idx, idx_ref)
+    if C == 3 and W % 32 == 0:
+        # dedicated first-layer kernel: K is ordered (c, r, s) instead of (tap, channel pair), so the fp32 sums differ
+        # in the last bits; the argmax may only differ where the window has a near-tie
+        assert_close(yp, yp_ref, tol=1e-5, what="pooled vs unfused")
+        win = y.view(N, K, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(N, K, H // 2, W // 2, 4)
+        picked = win.gather(4, idx.long().unsqueeze(-1)).squeeze(-1)
+        assert float((picked - yp_ref).abs().max()) <= 1e-5 * max(1.0, float(yp_ref.abs().max()))
+        assert float((idx != idx_ref).float().mean()) < 1e-2
+    else:
+        assert torch.equal(yp, yp_ref)
+        assert torch.equal(idx, idx_ref)
     y_cpu = F.max_pool2d(F.relu(F.conv2d(x.cpu(), w.cpu(), b.cpu(), padding=1)), 2, 2)
     assert_close(yp, y_cpu, what="pooled")
 

@@ -45,11 +45,21 @@ while i < len(cfg):
          "bwd_weight": timed(lambda: ops.conv3x3_bwd_weight(x, dy))}
     if c > 3:
         t["bwd_data"] = timed(lambda: ops.conv3x3_bwd_data(dy, w, x))
+    pooled = i + 1 < len(cfg) and cfg[i + 1] == "M"
+    if pooled:
+        t["fwd+pool"] = timed(lambda: ops.conv3x3_relu_pool_fwd(x, w, b))
+        if c == 3:
+            yp, idx = ops.conv3x3_relu_pool_fwd(x, w, b)
+            dyp = torch.randn_like(yp)
+            t["wgrad_unpool"] = timed(lambda: ops.conv3x3_bwd_weight_unpool(x, dyp, idx))
     line = "%4dx%-4d@%-3d" % (c, k, hw)
     for kk in ("fwd", "bwd_data", "bwd_weight"):
         if kk in t:
             tot[kk] += t[kk]
             flt[kk] += fl
+            line += "  %s %7.1f us %6.1f TF" % (kk, t[kk] * 1e6, fl / t[kk] / 1e12)
+    for kk in ("fwd+pool", "wgrad_unpool"):
+        if kk in t:
             line += "  %s %7.1f us %6.1f TF" % (kk, t[kk] * 1e6, fl / t[kk] / 1e12)
     print(line)
     c = k

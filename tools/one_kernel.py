@@ -1,0 +1,24 @@
+#!/usr/bin/env python
+"""Run ONE conv entry point a few times (for rocprofv3 --pmc passes).
+usage: python tools/one_kernel.py {c3pool|fwd|dgrad|wgrad} N C K HW [iters]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from clsurvey_amd import ops  # noqa: E402
+
+kind = sys.argv[1]
+N, C, K, HW = (int(v) for v in sys.argv[2:6])
+iters = int(sys.argv[6]) if len(sys.argv) > 6 else 5
+dev = torch.device("cuda:0")
+x = torch.randn(N, C, HW, HW, device=dev)
+w = torch.randn(K, C, 3, 3, device=dev) * 0.05
+b = torch.zeros(K, device=dev)
+dy = torch.randn(N, K, HW, HW, device=dev)
+fn = {"c3pool": lambda: ops.conv3x3_relu_pool_fwd(x, w, b), "fwd": lambda: ops.conv3x3_fwd(x, w, b, True),
+      "dgrad": lambda: ops.conv3x3_bwd_data(dy, w, x), "wgrad": lambda: ops.conv3x3_bwd_weight(x, dy)}[kind]
+for _ in range(iters):
+    fn()
+torch.cuda.synchronize()
