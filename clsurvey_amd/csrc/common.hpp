@@ -29,6 +29,30 @@ static inline int ew_grid(size_t work_items, int block) {
 // MFMA loop (measured: conv kernels at ~55 % of what the same MFMA loop sustains in isolation).
 static __device__ __attribute__((aligned(16))) float clhip_zero16[4] = {0.f, 0.f, 0.f, 0.f};   // non-const: stays in the global address space (a const would be addrspace(4) and turn the selected load into flat_load)
 
+// Raw buffer access (gfx9 buffer resource: base, stride 0, num_records in bytes, DATA_FORMAT_32): the hardware range
+// check (voffset >= num_records; the scalar offset is NOT part of it) returns 0 for loads and drops stores, so a
+// predicate costs one v_cndmask on the 32-bit offset instead of a select on the value (which waits for the load) or
+// an exec-mask branch.  num_records is clipped so that CLHIP_OOB is always out of range.
+constexpr int CLHIP_OOB = (int)0x80000000;
+typedef unsigned int clhip_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t clhip_rsrc(const void* p, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes > 0x7fffffffull ? 0x7fffffff : (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float clhip_buf_load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ float4 clhip_buf_load4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    const clhip_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ void clhip_buf_store(float v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+}
+__device__ __forceinline__ void clhip_buf_store_u8(uint8_t v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b8(v, r, voff, soff, 0);
+}
+__device__ __forceinline__ size_t out_img_of(int C, int hw) { return (size_t)C * hw; }
+
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
@@ -37,3 +61,4 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 //   B operand: lane l supplies B[k = l >> 5][j = l & 31]
 //   D: reg r of lane l holds D[row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][col = l & 31]
 __device__ __forceinline__ int mfma32_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+

@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
     constexpr int XS_FLOATS = CK * G::PLANE;
     constexpr int BUF_FLOATS = WS_FLOATS + XS_FLOATS;
     __shared__ float lds[2 * BUF_FLOATS];
+    __shared__ float bias_s[KT];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
     const int ng = pt / (tiles_w * tiles_h);
     const int n0 = ng * NB, h0 = th_i * TH, w0 = tw_i * TW;
     const int ko0 = kt * KT;        // first output channel of this block
+    if (MODE == 0 && threadIdx.x < KT) bias_s[threadIdx.x] = (bias && ko0 + (int)threadIdx.x < Cout) ? bias[ko0 + threadIdx.x] : 0.f;
 
     // per-lane LDS offsets of this wave's pixel subtiles (pixel q -> halo-plane address)
     int pixoff[G::NT];
@@ -216,38 +218,41 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
         }
     }
 
+    // Raw buffer loads: out-of-range / halo elements get voffset = CLHIP_OOB and read back as 0 from the hardware
+    // range check (no select on the loaded value, so nothing waits on the load), the per-chunk base is the scalar
+    // offset of the instruction (not range-checked, never VALU) and an element costs at most one v_cndmask.
+    const __amdgpu_buffer_rsrc_t rs_w = clhip_rsrc(wt, (size_t)Kw * Cw * 9 * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rs_x = clhip_rsrc(in_blk, (size_t)(N - n0) * Cin * plane_hw * sizeof(float));
+    if constexpr (VEC) {
+#pragma unroll
+        for (int j = 0; j < W_IT; ++j) woff[j] = ((wok >> j) & 1u) ? woff[j] * 4 : CLHIP_OOB;
+#pragma unroll
+        for (int j = 0; j < X_IT; ++j) xoff[j] = ((xok >> j) & 1u) ? xoff[j] * 4 : CLHIP_OOB;
+#pragma unroll
+        for (int j = 0; j < H_IT; ++j) hoff[j] = ((hok >> j) & 1u) ? hoff[j] * 4 : CLHIP_OOB;
+    } else {
+#pragma unroll
+        for (int j = 0; j < W_IT; ++j) woff[j] = ((wok >> j) & 1u) ? woff[j] * 4 : CLHIP_OOB;
+#pragma unroll
+        for (int j = 0; j < X_IT; ++j) xoff[j] = ((xok >> j) & 1u) ? xoff[j] * 4 : CLHIP_OOB;
+    }
     auto load_chunk = [&](int chunk) {
         const int c0 = chunk * CK;
-        const float* wb = wt + (MODE == 0 ? (size_t)c0 * 9 : (size_t)c0 * Cw * 9);
-        const float* xb = in_blk + (size_t)c0 * plane_hw;
+        const int wb = (MODE == 0 ? c0 * 9 : c0 * Cw * 9) * (int)sizeof(float);
+        const int xb = c0 * (int)plane_hw * (int)sizeof(float);
         if constexpr (VEC) {
 #pragma unroll
-            for (int j = 0; j < W_IT; ++j) {
-                const bool ok = (wok >> j) & 1u;
-                wv[j] = *reinterpret_cast<const float4*>(ok ? wb + woff[j] : clhip_zero16);
-            }
+            for (int j = 0; j < W_IT; ++j) wv[j] = clhip_buf_load4(rs_w, woff[j], wb);
 #pragma unroll
-            for (int j = 0; j < X_IT; ++j) {
-                const bool ok = (xok >> j) & 1u;
-                xv[j] = *reinterpret_cast<const float4*>(ok ? xb + xoff[j] : clhip_zero16);
-            }
+            for (int j = 0; j < X_IT; ++j) xv[j] = clhip_buf_load4(rs_x, xoff[j], xb);
 #pragma unroll
-            for (int j = 0; j < H_IT; ++j) {
-                const bool ok = (hok >> j) & 1u;
-                hv[j] = *(ok ? xb + hoff[j] : clhip_zero16);
-            }
+            for (int j = 0; j < H_IT; ++j) hv[j] = clhip_buf_load(rs_x, hoff[j], xb);
         } else {
             const int cleft = Cin - c0;                  // channels left (>= CK except in the tail chunk)
 #pragma unroll
-            for (int j = 0; j < W_IT; ++j) {
-                const bool ok = ((wok >> j) & 1u) && wch[j] < cleft;
-                wreg[j] = *(ok ? wb + woff[j] : clhip_zero16);
-            }
+            for (int j = 0; j < W_IT; ++j) wreg[j] = clhip_buf_load(rs_w, wch[j] < cleft ? woff[j] : CLHIP_OOB, wb);
 #pragma unroll
-            for (int j = 0; j < X_IT; ++j) {
-                const bool ok = ((xok >> j) & 1u) && xch[j] < cleft;
-                xreg[j] = *(ok ? xb + xoff[j] : clhip_zero16);
-            }
+            for (int j = 0; j < X_IT; ++j) xreg[j] = clhip_buf_load(rs_x, xch[j] < cleft ? xoff[j] : CLHIP_OOB, xb);
         }
     };
 
@@ -330,61 +335,74 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
     }
 
     // ---- epilogue: reg r of lane l = D[row = out-channel][col = pixel li]
-    const size_t out_img = (size_t)Cout * H * W;
+    // Buffer stores: the lane's pixel/channel-base offset is one VGPR per subtile (CLHIP_OOB drops the store), the
+    // channel of register r is a scalar offset.  Bias comes from LDS (a global load per register, each waited for,
+    // used to cost ~10 % of the kernel).
+    const int kb = ko0 + wk * 32 + 4 * kk;               // channel of register r: kb + (r & 3) + 8 * (r >> 2)
+    const bool kfull = ko0 + KT <= Cout;                 // uniform: no per-register channel test
+    auto rch = [](int r) { return (r & 3) + 8 * (r >> 2); };
     if (MODE == 0 && pool) {
         // fused ReLU + 2x2/2 max-pool (VGGSlim.py:32,38): the window's candidates are lanes li, li^1 (right),
         // li^VX (below), li^1^VX; the top-left lane writes the maximum and the 2-bit argmax (first maximum in
         // ATen's scan order wins).  The pre-pool activation never goes to HBM.
         constexpr int VX = TW == 8 ? 8 : 16;
         const int OH = H >> 1, OW = W >> 1;
+        const int chw = OH * OW;
+        const __amdgpu_buffer_rsrc_t rs_o = clhip_rsrc(out + (size_t)n0 * Cout * chw, (size_t)(N - n0) * Cout * chw * sizeof(float));
+        const __amdgpu_buffer_rsrc_t rs_i = clhip_rsrc(pool_idx + (size_t)n0 * Cout * chw, (size_t)(N - n0) * Cout * chw);
         const bool writer = !(li & 1) && !(li & VX);
 #pragma unroll
         for (int t = 0; t < G::NT; ++t) {
             int nb, th, tw;
             tile_pixel<TW, TH>(wp * G::NT + t, li, true, nb, th, tw);
-            const int n = n0 + nb, h = h0 + th, w = w0 + tw;
-            const bool pix_ok = (n < N) && (h < H) && (w < W);
+            const int h = h0 + th, w = w0 + tw;
+            const bool ok = writer && (n0 + nb < N) && (h < H) && (w < W);
+            const int eoff = (nb * Cout + kb) * chw + (h >> 1) * OW + (w >> 1);      // element offset of channel kb
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int ko = ko0 + wk * 32 + mfma32_row(r, lane);
-                float v = acc[t][r];
-                if (bias && ko < Cout) v += bias[ko];
-                v = fmaxf(v, 0.f);
+                float v = fmaxf(acc[t][r] + bias_s[wk * 32 + 4 * kk + rch(r)], 0.f);
                 const float tr = __shfl_xor(v, 1, 64);
                 const float bl = __shfl_xor(v, VX, 64);
                 const float br = __shfl_xor(tr, VX, 64);
-                if (writer && pix_ok && ko < Cout) {
-                    float m = v; int a = 0;
-                    if (tr > m) { m = tr; a = 1; }
-                    if (bl > m) { m = bl; a = 2; }
-                    if (br > m) { m = br; a = 3; }
-                    const size_t o = (((size_t)n * Cout + ko) * OH + (h >> 1)) * OW + (w >> 1);
-                    out[o] = m;
-                    pool_idx[o] = (uint8_t)a;
-                }
+                float m = v; int a = 0;
+                if (tr > m) { m = tr; a = 1; }
+                if (bl > m) { m = bl; a = 2; }
+                if (br > m) { m = br; a = 3; }
+                const bool okr = ok && (kfull || kb + rch(r) < Cout);
+                clhip_buf_store(m, rs_o, okr ? eoff * 4 : CLHIP_OOB, rch(r) * chw * 4);
+                clhip_buf_store_u8((uint8_t)a, rs_i, okr ? eoff : CLHIP_OOB, rch(r) * chw);
             }
         }
         return;
     }
+    {
+        const int chw = (int)plane_hw;
+        const __amdgpu_buffer_rsrc_t rs_o = clhip_rsrc(out + (size_t)n0 * out_img_of(Cout, chw), (size_t)(N - n0) * Cout * chw * sizeof(float));
+        const __amdgpu_buffer_rsrc_t rs_m = clhip_rsrc(MODE == 1 && mask_src ? mask_src + (size_t)n0 * out_img_of(Cout, chw) : out,
+                                                       (size_t)(N - n0) * Cout * chw * sizeof(float));
 #pragma unroll
-    for (int t = 0; t < G::NT; ++t) {
-        int nb, th, tw;
-        tile_pixel<TW, TH>(wp * G::NT + t, li, false, nb, th, tw);
-        int n = n0 + nb, h = h0 + th, w = w0 + tw;
-        bool pix_ok = (n < N) && (h < H) && (w < W);
+        for (int t = 0; t < G::NT; ++t) {
+            int nb, th, tw;
+            tile_pixel<TW, TH>(wp * G::NT + t, li, false, nb, th, tw);
+            const int h = h0 + th, w = w0 + tw;
+            const bool ok = (n0 + nb < N) && (h < H) && (w < W);
+            const int boff = ok ? ((nb * Cout + kb) * chw + h * W + w) * 4 : CLHIP_OOB;
+            float mk[16];
+            if (MODE == 1 && mask_src) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int ko = ko0 + wk * 32 + mfma32_row(r, lane);
-            if (pix_ok && ko < Cout) {
-                size_t o = (size_t)n * out_img + ((size_t)ko * H + h) * W + w;
+                for (int r = 0; r < 16; ++r)
+                    mk[r] = clhip_buf_load(rs_m, (kfull || kb + rch(r) < Cout) ? boff : CLHIP_OOB, rch(r) * chw * 4);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
                 float v = acc[t][r];
                 if (MODE == 0) {
-                    if (bias) v += bias[ko];
+                    if (bias) v += bias_s[wk * 32 + 4 * kk + rch(r)];
                     if (relu) v = fmaxf(v, 0.f);
                 } else {
-                    if (mask_src) v = mask_src[o] > 0.f ? v : 0.f;
+                    if (mask_src) v = mk[r] > 0.f ? v : 0.f;
                 }
-                out[o] = v;
+                clhip_buf_store(v, rs_o, (kfull || kb + rch(r) < Cout) ? boff : CLHIP_OOB, rch(r) * chw * 4);
             }
         }
     }
@@ -657,6 +675,7 @@ int clhip_conv3x3_relu_pool_fwd(const float* x, const float* w, const float* b, 
         return CLHIP_EINVAL;
     hipStream_t s = as_stream(stream);
     if (C == 3 && W % C3_TW == 0) return launch_c3_pool(x, w, b, y_pool, idx_u8, N, K, H, W, s);
+
     if (C <= 4) return launch_conv<4, 0, false>(x, w, b, nullptr, y_pool, N, C, K, H, W, K, C, 1, s, idx_u8);
     if (vec_ok(x, w, C, H, W, C)) return launch_conv<8, 0, true>(x, w, b, nullptr, y_pool, N, C, K, H, W, K, C, 1, s, idx_u8);
     return launch_conv<8, 0, false>(x, w, b, nullptr, y_pool, N, C, K, H, W, K, C, 1, s, idx_u8);
