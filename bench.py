@@ -75,8 +75,26 @@ def parse():
     return ap.parse_args()
 
 
+def conv_instance(C, H, W, N, K, mode, pool):
+    """Name of the kernel the library launches for this layer (mirrors launch_conv / clhip_conv3x3_relu_pool_fwd in
+    csrc/conv3x3.hip), so that the roofline entry can be matched against the rocprofv3 kernel stats in profiles/."""
+    if mode == 0 and pool and C == 3 and W % 32 == 0:
+        return "conv3x3_c3_relu_pool_kernel"
+    kts = (K + 63) // 64
+    big = (N * H * W // 128) * kts >= 512
+    if W > 16:
+        geo = (32, 4, 1) if big else (32, 2, 1)
+    elif W > 8:
+        geo = (16, 8, 1) if big else (16, 4, 1)
+    else:
+        geo = (8, 8, 2) if (big and H > 4) else (8, 8, 1)
+    ck, vec = (4, "false") if C <= 4 else (8, "true" if (C % 8 == 0 and W % 4 == 0 and W % geo[0] == 0) else "false")
+    return "conv3x3_mfma_kernel<%d, %d, %d, %d, %d, %s>" % (geo[0], geo[1], geo[2], ck, mode, vec)
+
+
 def time_kernels(eng, x, N, iters):
-    """Per-layer HIP-event timing of the three conv kernels (same shapes as the step)."""
+    """Per-layer HIP-event timing of the conv launches of one pass, as the plan executor issues them (fused
+    ReLU+pool forward on pooled layers, first-layer weight gradient straight from the pooled gradient)."""
     from clsurvey_amd import ops
     rows = []
     stream = torch.cuda.current_stream()
@@ -102,15 +120,46 @@ def time_kernels(eng, x, N, iters):
             return e0.elapsed_time(e1) / iters * 1e-3
 
         xin = cur
-        t_f = timed(lambda: ops.conv3x3_fwd(xin, m.weight.data, m.bias.data, True))
-        t_w = timed(lambda: ops.conv3x3_bwd_weight(xin, dy))
-        rows.append(dict(kernel="conv3x3_fwd", layer="%dx%d@%d" % (C, K, H), flops=fl, sec=t_f))
-        rows.append(dict(kernel="conv3x3_bwd_weight", layer="%dx%d@%d" % (C, K, H), flops=fl, sec=t_w))
+        layer = "%dx%d@%d" % (C, K, H)
+        if pool:
+            yp, idx = ops.conv3x3_relu_pool_fwd(xin, m.weight.data, m.bias.data)
+            t_f = timed(lambda: ops.conv3x3_relu_pool_fwd(xin, m.weight.data, m.bias.data))
+            rows.append(dict(kernel="conv3x3_relu_pool_fwd", layer=layer, flops=fl, sec=t_f,
+                             instance=conv_instance(C, H, W, N, K, 0, True),
+                             alg_bytes=4.0 * N * H * W * (C + K / 4.0) + 1.0 * N * K * H * W / 4))
+        else:
+            t_f = timed(lambda: ops.conv3x3_fwd(xin, m.weight.data, m.bias.data, True))
+            rows.append(dict(kernel="conv3x3_fwd", layer=layer, flops=fl, sec=t_f,
+                             instance=conv_instance(C, H, W, N, K, 0, False), alg_bytes=4.0 * N * H * W * (C + K)))
+        if C == 3 and pool:
+            dyp = torch.randn_like(yp)
+            t_w = timed(lambda: ops.conv3x3_bwd_weight_unpool(xin, dyp, idx))
+            rows.append(dict(kernel="conv3x3_bwd_weight_unpool", layer=layer, flops=fl, sec=t_w,
+                             instance="conv3x3_wgrad_smallc_kernel", alg_bytes=4.0 * N * H * W * (C + K / 4.0)))
+        else:
+            t_w = timed(lambda: ops.conv3x3_bwd_weight(xin, dy))
+            rows.append(dict(kernel="conv3x3_bwd_weight", layer=layer, flops=fl, sec=t_w,
+                             instance="conv3x3_wgrad_kernel (+ fixed-order reduce)", alg_bytes=4.0 * N * H * W * (C + K)))
         if C > 3:
             t_d = timed(lambda: ops.conv3x3_bwd_data(dy, m.weight.data, xin))
-            rows.append(dict(kernel="conv3x3_bwd_data", layer="%dx%d@%d" % (C, K, H), flops=fl, sec=t_d))
+            rows.append(dict(kernel="conv3x3_bwd_data", layer=layer, flops=fl, sec=t_d,
+                             instance=conv_instance(K, H, W, N, C, 1, False), alg_bytes=4.0 * N * H * W * (2 * C + K)))
         cur = ops.maxpool2_fwd(y)[0] if pool else y
     return rows
+
+
+def measured_traffic(kernel, layer, N):
+    """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (tools/gpu_traffic.sh: FETCH_SIZE
+    and WRITE_SIZE in separate passes; FETCH_SIZE doubled for 16-byte-per-lane reads as MI355X_MICROARCH.md
+    prescribes for gfx950).  None when no measurement for this kernel/shape is on file."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+    except Exception:
+        return None
+    e = t.get("%s %s N=%d" % (kernel, layer, N))
+    return None if e is None else float(e["hbm_bytes_per_launch"])
 
 
 def cpu_baseline(batch, steps):
@@ -247,15 +296,19 @@ def main():
         for r in rows:
             a = agg.setdefault(r["kernel"], dict(flops=0.0, sec=0.0, launches=0))
             a["flops"] += r["flops"]; a["sec"] += r["sec"]; a["launches"] += 1
-        dom = max(agg.items(), key=lambda kv: kv[1]["sec"])
-        ach = dom[1]["flops"] / dom[1]["sec"] / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": dom[0], "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-                           "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                           "avg_launch_us": dom[1]["sec"] / dom[1]["launches"] * 1e6,
+        dom = max(rows, key=lambda r: r["sec"])          # the single launch that costs most per pass
+        ach = dom["flops"] / dom["sec"] / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": "%s [%s, layer %s, N=%d]" % (dom["instance"], dom["kernel"], dom["layer"], N),
+                           "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+                           "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                           "traffic": measured_traffic(dom["kernel"], dom["layer"], N),
+                           "algorithmic_gflop_per_launch": dom["flops"] / 1e9,
+                           "algorithmic_bytes_per_launch": dom["alg_bytes"],
+                           "avg_launch_us": dom["sec"] * 1e6,
                            "per_kernel": {k: {"tflops": v["flops"] / v["sec"] / 1e12, "us_per_step_pass": v["sec"] * 1e6}
                                           for k, v in agg.items()},
-                           "per_layer": [{"kernel": r["kernel"], "layer": r["layer"], "us": r["sec"] * 1e6,
-                                          "tflops": r["flops"] / r["sec"] / 1e12} for r in rows]}
+                           "per_layer": [{"kernel": r["kernel"], "layer": r["layer"], "instance": r["instance"],
+                                          "us": r["sec"] * 1e6, "tflops": r["flops"] / r["sec"] / 1e12} for r in rows]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, args.cpu_steps)
             out["config"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
