@@ -420,33 +420,37 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_smallc_kernel(
     }
 }
 
-// Level 1: tmp[g][e] = sum over the splits of group g (fixed order).
-__global__ __launch_bounds__(256) void wgrad_reduce_groups_kernel(const float* __restrict__ part, float* __restrict__ tmp,
-                                                                  size_t total, int splits, int group) {
-    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total) return;
-    const int g = blockIdx.y;
-    const int s0 = g * group, s1 = min(splits, s0 + group);
-    double s = 0.0;
-#pragma unroll 8
-    for (int sp = s0; sp < s1; ++sp) s += (double)part[(size_t)sp * total + e];
-    tmp[(size_t)g * total + e] = (float)s;
-}
-
-// Level 2: dw[k][c][rs] = sum_g tmp[g][rs][k][c] ; db[k] = sum_g tmp[g][9KC + k].
-__global__ __launch_bounds__(256) void wgrad_reduce_final_kernel(const float* __restrict__ tmp, float* __restrict__ dw,
-                                                                 float* __restrict__ db, int K, int C, int groups) {
+// Fixed-order reduction of the partial slabs in ONE launch (the two tiny launches it replaces were launch-latency
+// bound: 12 us per layer and pass).  Block = 64 consecutive elements x 16 split-lanes: lane j sums its contiguous
+// range of splits in order (f64), the 16 partials meet in LDS and are added in order j = 0..15 — the same two-level
+// association for every run, every grid size: bitwise run-to-run deterministic.
+//   dw[k][c][rs] = sum_s part[s][rs][k][c] ; db[k] = sum_s part[s][9KC + k]
+constexpr int RED_EL = 64, RED_J = 16;
+__global__ __launch_bounds__(RED_EL * RED_J) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                      float* __restrict__ db, int K, int C, int splits) {
+    __shared__ double partial[RED_J][RED_EL];
     const size_t kc = (size_t)K * C, nw = 9 * kc, total = nw + K;
-    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total) return;
+    const int el = threadIdx.x & (RED_EL - 1), j = threadIdx.x / RED_EL;
+    const size_t e = (size_t)blockIdx.x * RED_EL + el;
+    const int q = (splits + RED_J - 1) / RED_J;
+    const int s0 = j * q, s1 = min(splits, s0 + q);
     double s = 0.0;
+    if (e < total) {
 #pragma unroll 8
-    for (int g = 0; g < groups; ++g) s += (double)tmp[(size_t)g * total + e];
-    if (e < nw) {
-        size_t rs = e / kc, rem = e - rs * kc;     // rem = k*C + c
-        dw[rem * 9 + rs] = (float)s;
-    } else if (db) {
-        db[e - nw] = (float)s;
+        for (int sp = s0; sp < s1; ++sp) s += (double)part[(size_t)sp * total + e];
+    }
+    partial[j][el] = s;
+    __syncthreads();
+    if (j == 0 && e < total) {
+        double t = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < RED_J; ++jj) t += partial[jj][el];
+        if (e < nw) {
+            const size_t rs = e / kc, rem = e - rs * kc;     // rem = k*C + c
+            dw[rem * 9 + rs] = (float)t;
+        } else if (db) {
+            db[e - nw] = (float)t;
+        }
     }
 }
 
@@ -503,7 +507,6 @@ static int bwd_weight_impl(const float* x, const float* dy, const uint8_t* unpoo
     if (ws_bytes < p.ws_floats * sizeof(float)) return CLHIP_ENOSPC;
     hipStream_t s = as_stream(stream);
     float* part = static_cast<float*>(ws);
-    float* tmp = part + p.slab * (size_t)p.splits;
     const bool smallc = (C * 9 <= 32);
     unsigned grid = (unsigned)(p.k_tiles * p.c_tiles * p.splits);
 #define WG_ARGS x, dy, part, N, C, K, H, W, p.tiles_w, p.tiles_h, p.total_stages, p.splits
@@ -523,10 +526,8 @@ static int bwd_weight_impl(const float* x, const float* dy, const uint8_t* unpoo
     }
 #undef WG_ARGS
     CLHIP_LAUNCH_CHECK();
-    unsigned bx = (unsigned)((p.slab + 255) / 256);
-    hipLaunchKernelGGL(wgrad_reduce_groups_kernel, dim3(bx, p.groups), dim3(256), 0, s, part, tmp, p.slab, p.splits, p.group);
-    CLHIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(wgrad_reduce_final_kernel, dim3(bx), dim3(256), 0, s, tmp, dw, db, K, C, p.groups);
+    const unsigned bx = (unsigned)((p.slab + RED_EL - 1) / RED_EL);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(bx), dim3(RED_EL * RED_J), 0, s, part, dw, db, K, C, p.splits);
     CLHIP_LAUNCH_CHECK();
     return 0;
 }
