@@ -62,3 +62,17 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 //   D: reg r of lane l holds D[row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][col = l & 31]
 __device__ __forceinline__ int mfma32_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+
+// fc_chain.hip: weight/bias gradients of the whole Linear stack in one launch. Offsets are float offsets:
+// w_off / b_off into the parameter (and gradient) arena, act_off into the activation workspace, dz_off into the
+// gradient scratch of the hidden layers.
+#define CLHIP_FC_MAX 4
+struct clhip_fc_chain {
+    int n;
+    long w_off[CLHIP_FC_MAX], b_off[CLHIP_FC_MAX];
+    int din[CLHIP_FC_MAX], dout[CLHIP_FC_MAX], relu[CLHIP_FC_MAX];
+    size_t act_off[CLHIP_FC_MAX], dz_off[CLHIP_FC_MAX];
+};
+int clhip_internal_fc_chain_ok(const clhip_fc_chain* d);
+int clhip_internal_fc_chain_wgrad(const clhip_fc_chain* d, float* grads, const float* x, int N, const float* acts,
+                                  const float* dlogits, const float* dz, hipStream_t s);

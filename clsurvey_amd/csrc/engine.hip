@@ -33,7 +33,11 @@ struct NetPlan {
     size_t scratch_bytes;    // wgrad / fc split-K scratch
     size_t total_bytes;
     // derived offsets (bytes) inside ws
-    size_t off_acts, off_idx, off_g0, off_g1, off_scratch, off_dlogits, off_loss;
+    size_t off_acts, off_idx, off_g0, off_g1, off_scratch, off_dlogits, off_loss, off_fcdz;
+    // classifier = trailing Linear layers [fc_first, end): fused into three launches when it fits fc_chain.hip
+    int fc_first;
+    bool fc_fused;
+    clhip_fc_chain chain;
 };
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -98,6 +102,28 @@ int clhip_net_create(const clhip_layer_desc* descs, int n_layers, int max_batch,
     p->off_scratch = off; off += align_up(scratch, 256);
     p->off_dlogits = off; off += align_up((size_t)max_batch * p->n_classes * 4, 256);
     p->off_loss = off; off += 256;
+    // fused classifier
+    p->fc_first = n_layers;
+    for (int i = 0; i < n_layers; ++i) if (p->layers[i].type == 1) { p->fc_first = i; break; }
+    p->fc_fused = false;
+    p->off_fcdz = off;
+    const int nfc = n_layers - p->fc_first;
+    if (nfc >= 1 && nfc <= CLHIP_FC_MAX) {
+        clhip_fc_chain& ch = p->chain;
+        ch.n = nfc;
+        size_t dzf = 0;
+        for (int l = 0; l < nfc; ++l) {
+            const LayerPlan& L = p->layers[p->fc_first + l];
+            ch.w_off[l] = L.w_off; ch.b_off[l] = L.b_off; ch.din[l] = L.cin; ch.dout[l] = L.cout; ch.relu[l] = L.relu;
+            ch.act_off[l] = L.act_off;
+            ch.dz_off[l] = dzf;
+            if (l < nfc - 1) dzf += (size_t)L.cout * max_batch;
+        }
+        if (clhip_internal_fc_chain_ok(&ch)) {
+            p->fc_fused = true;
+            off += align_up(dzf * 4 + 256, 256);
+        }
+    }
     p->total_bytes = off;
     *out_handle = p;
     return 0;
@@ -120,7 +146,8 @@ int clhip_net_forward(void* handle, const float* params, const float* x, int N, 
     void* scratch = base + p->off_scratch;
     const float* cur = x;
     int rc;
-    for (const LayerPlan& L : p->layers) {
+    for (size_t li = 0; li < p->layers.size(); ++li) {
+        const LayerPlan& L = p->layers[li];
         float* y = acts + L.act_off;
         if (L.type == 0) {
             if (L.pool && L.relu) {
@@ -171,7 +198,9 @@ int clhip_net_backward(void* handle, const float* params, float* grads, const fl
     const float* gin = dlogits;      // gradient w.r.t. the current layer's output (already ReLU-masked)
     int flip = 0;
     int rc;
-    for (int i = (int)p->layers.size() - 1; i >= 0; --i) {
+    const int top = (int)p->layers.size() - 1;
+    float* fcdz = reinterpret_cast<float*>(base + p->off_fcdz);
+    for (int i = top; i >= 0; --i) {
         const LayerPlan& L = p->layers[i];
         // input of layer i = (pooled) output of layer i-1, or the image batch
         const float* xin = x;
@@ -180,14 +209,23 @@ int clhip_net_backward(void* handle, const float* params, float* grads, const fl
             xin = acts + ((P.type == 0 && P.pool) ? P.pool_off : P.act_off);
         }
         if (L.type == 1) {
-            rc = clhip_fc_bwd_weight(xin, gin, grads + L.w_off, grads + L.b_off, N, L.cin, L.cout, scratch, p->scratch_bytes, stream);
-            if (rc) return rc;
+            if (!p->fc_fused) {
+                rc = clhip_fc_bwd_weight(xin, gin, grads + L.w_off, grads + L.b_off, N, L.cin, L.cout, scratch, p->scratch_bytes, stream);
+                if (rc) return rc;
+            }
             if (i > 0) {
-                float* gout = g[flip]; flip ^= 1;
+                // fused weight gradients (below) read the hidden layers' dz after the chain: keep them in their own slots
+                float* gout = (p->fc_fused && i > p->fc_first) ? fcdz + p->chain.dz_off[i - p->fc_first - 1] : g[flip];
+                if (gout == g[flip]) flip ^= 1;
                 // mask with (xin > 0): xin is a ReLU (or pooled ReLU) output
                 rc = clhip_fc_bwd_data(gin, params + L.w_off, xin, gout, N, L.cin, L.cout, scratch, p->scratch_bytes, stream);
                 if (rc) return rc;
                 gin = gout;
+            }
+            if (p->fc_fused && i == p->fc_first) {
+                // all dz_l are in place: dW_l, db_l of every Linear layer in one launch
+                rc = clhip_internal_fc_chain_wgrad(&p->chain, grads, xin, N, acts, dlogits, fcdz, as_stream(stream));
+                if (rc) return rc;
             }
         } else {
             const float* gy = gin;

@@ -7,7 +7,7 @@ mkdir -p gpurun_out
 P=$PWD
 pass() {  # name counters...
   n=$1; shift
-  ( cd /tmp && timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $P/gpurun_out/${TAG}_$n -- python $P/tools/one_kernel.py $ARGS > $P/gpurun_out/${TAG}_$n.log 2>&1 )
+  ( cd /tmp && timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $P/gpurun_out/${TAG}_$n -- python $P/tools/${PMC_SCRIPT:-one_kernel.py} $ARGS > $P/gpurun_out/${TAG}_$n.log 2>&1 )
   f=$(find gpurun_out/${TAG}_$n -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python - "$f" <<'PY'
 import csv, sys, collections
@@ -18,7 +18,7 @@ for r in rows:
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
 for k in agg:
     n = len({r["Dispatch_Id"] for r in rows if r["Kernel_Name"][:60] == k})
-    if "conv3x3" in k or "wgrad" in k:
+    if "conv3x3" in k or "wgrad" in k or "fc_chain" in k:
         print(k, "dispatches", n, {c: round(v / n) for c, v in agg[k].items()})
 PY
 }
