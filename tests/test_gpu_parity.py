@@ -245,6 +245,27 @@ def test_engine_matches_reference_golden_g1(golden, kind):
         assert_close(p.grad, torch.from_numpy(g["tiny_%s_g%d" % (kind, i)]), what="grad %d" % i)
 
 
+@pytest.mark.parametrize("N,fc,ncls", [(5, (40, 24), 7), (33, (96, 64), 20), (200, (128, 128), 150)])
+def test_engine_classifier_gradients_vs_oracle(N, fc, ncls):
+    """fc_chain_wgrad_kernel (all Linear dW / db in one launch) on odd batch sizes, widths that are not multiples of 32
+    and a wide head, against the fp64 CPU oracle (the tiny goldens only cover 24-wide layers at N=8)."""
+    from oracle import vgg_ref
+    gen = np.random.RandomState(N + ncls)
+    params = vgg_ref.init_params(TINY, fc, ncls, 32, gen)
+    with torch.no_grad():
+        for i in (-6, -4, -2):
+            params[i] *= 30.0                      # N(0, .01) classifier init would leave every gradient at 1e-6
+    m, eng = build_engine(TINY, fc, ncls, 32, params, N)
+    x = rnd(gen, N, 3, 32, 32).to(dev())
+    y = torch.from_numpy(gen.randint(0, ncls, size=(N,)).astype(np.int64)).to(dev())
+    loss, logits = eng.loss_step(x, y, "ce_sum", backward=True, want_logits=True)
+    p64 = [p.double() for p in params]
+    lo_ref, loss_ref, gr, _ = vgg_ref.loss_and_grads(p64, TINY, x.cpu().double(), y.cpu(), "ce_sum")
+    assert_close(logits, lo_ref.float(), tol=2e-4, what="logits")
+    for i, p in enumerate(m.parameters()):
+        assert_close(p.grad, gr[i].float(), tol=1e-3, what="grad %d" % i)
+
+
 def test_autograd_path_matches_engine_and_golden(golden):
     from clsurvey_amd import ops
     g = golden("G1_vgg_fwd_bwd")
@@ -603,7 +624,8 @@ def test_gem_observe_step_vs_oracle():
 
 
 @pytest.mark.parametrize("shape", [(2, 3, 16, 32, 32), (3, 16, 16, 16, 16), (5, 32, 24, 8, 8), (9, 3, 64, 64, 64),
-                                   (4, 64, 64, 32, 32), (40, 64, 64, 16, 16), (33, 64, 128, 8, 8), (2, 8, 40, 12, 20)])
+                                   (4, 64, 64, 32, 32), (40, 64, 64, 16, 16), (33, 64, 128, 8, 8), (2, 8, 40, 12, 20),
+                                   (3, 3, 40, 20, 32), (2, 3, 70, 12, 64), (700, 3, 8, 8, 32), (1, 3, 130, 64, 96)])
 def test_fused_conv_relu_pool(shape):
     """fused conv+ReLU+maxpool == separate kernels (bit for bit where the accumulation order is the same), and the
     argmax is ATen's."""
