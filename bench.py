@@ -81,7 +81,7 @@ def conv_instance(C, H, W, N, K, mode, pool):
     if mode == 0 and pool and C == 3 and W % 32 == 0:
         return "conv3x3_c3_relu_pool_kernel"
     kts = (K + 63) // 64
-    big = (N * H * W // 128) * kts >= 512
+    big = (N * H * W // 128) * kts >= 300
     if W > 16:
         geo = (32, 4, 1) if big else (32, 2, 1)
     elif W > 8:

@@ -422,15 +422,17 @@ int launch_geo(const float* in, const float* wt, const float* bias, const float*
     return 0;
 }
 
-// Tile geometry choice: full 128-pixel tiles while they still give >= ~2 blocks per CU,
-// otherwise 64-pixel tiles (deep layers at 8x8 / 16x16 have few pixels).
+// Tile geometry choice: full 128-pixel tiles while they still give more blocks than CUs,
+// otherwise 64-pixel tiles (deep layers at 8x8 have few pixels).
 template <int CK, int MODE, bool VEC>
 int launch_conv(const float* in, const float* wt, const float* bias, const float* mask_src, float* out,
                 int N, int Cin, int Cout, int H, int W, int Kw, int Cw, int relu, hipStream_t s,
                 uint8_t* pool_idx = nullptr) {
     const int kts = (Cout + KT - 1) / KT;
     const long long pix = (long long)N * H * W;
-    const bool big = (pix / 128) * kts >= 512;
+    // measured on small_VGG9 at N=200: 400 blocks of 128 pixels beat 800 of 64 (47 vs 51 us at 16x16: one A fragment
+    // feeds two MFMAs), 200 of 128 lose to 400 of 64 at 8x8 (too few blocks for 256 CUs)
+    const bool big = (pix / 128) * kts >= 300;
 #define GEO(TW_, TH_, NB_) launch_geo<TW_, TH_, NB_, CK, MODE, VEC>(in, wt, bias, mask_src, out, N, Cin, Cout, H, W, Kw, Cw, relu, s, pool_idx)
     if (W > 16) return big ? GEO(32, 4, 1) : GEO(32, 2, 1);
     if (W > 8) return big ? GEO(16, 8, 1) : GEO(16, 4, 1);
