@@ -132,6 +132,33 @@ struct SiCons {
     }
 };
 
+// IMM merge (methods/IMM/merge.py:185-242), one parameter tensor of up to 32 task models per launch:
+//   mean-IMM: out = (theta_0 + ... + theta_{M-1}) / M                      (:222-232)
+//   mode-IMM: out = sum_m (F_m / S) * theta_m,  S = sum of the precisions  (:226-228)
+// Same operation order as the reference's per-tensor torch ops (running sum from zero, divide last), so the merged
+// weights agree with it to the last bit.
+constexpr int IMM_MAX = 32;
+struct ImmPtrs { const float* theta[IMM_MAX]; const float* prec[IMM_MAX]; };
+struct ImmMerge {
+    ImmPtrs p; const float* sum_prec; float* out; int n_models; int mean_mode;
+    __device__ __forceinline__ void scalar(size_t i) const {
+        float acc = 0.f;
+        if (mean_mode) {
+            for (int m = 0; m < n_models; ++m) acc = __fadd_rn(acc, p.theta[m][i]);
+            acc = __fdiv_rn(acc, (float)n_models);
+        } else {
+            const float sp = sum_prec[i];
+            // separate, correctly rounded div / mul / add like the reference's three torch ops (no fma contraction)
+            for (int m = 0; m < n_models; ++m) acc = __fadd_rn(acc, __fmul_rn(__fdiv_rn(p.prec[m][i], sp), p.theta[m][i]));
+        }
+        out[i] = acc;
+    }
+    __device__ __forceinline__ void vec(size_t i) const {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) scalar(4 * i + t);
+    }
+};
+
 struct ReluBwd {
     const float* dy; const float* y; float* dx;
     __device__ __forceinline__ void scalar(size_t i) const { dx[i] = y[i] > 0.f ? dy[i] : 0.f; }
@@ -190,6 +217,20 @@ int clhip_relu_bwd(const float* dy, const float* y, float* dx, size_t n, void* s
     if (!dy || !y || !dx) return CLHIP_EINVAL;
     ReluBwd f{dy, y, dx};
     return ew_launch(n, aligned16(dy) && aligned16(y) && aligned16(dx), f, as_stream(stream));
+}
+
+int clhip_imm_merge(const float* const* thetas, const float* const* precisions, const float* sum_precision, int n_models,
+                    size_t n, float* out, void* stream) {
+    if (!thetas || !out || n_models < 1 || n_models > IMM_MAX) return CLHIP_EINVAL;
+    if (precisions && !sum_precision) return CLHIP_EINVAL;
+    ImmMerge f{};
+    for (int m = 0; m < n_models; ++m) {
+        if (!thetas[m] || (precisions && !precisions[m])) return CLHIP_EINVAL;
+        f.p.theta[m] = thetas[m];
+        f.p.prec[m] = precisions ? precisions[m] : nullptr;
+    }
+    f.sum_prec = sum_precision; f.out = out; f.n_models = n_models; f.mean_mode = precisions ? 0 : 1;
+    return ew_launch(n, false, f, as_stream(stream));
 }
 
 int clhip_version(void) { return 100; }

@@ -483,6 +483,9 @@ def main(argv=None, method=None, dataset=None, train_node_factory=None):
         exp = args.exp_name if args.test_set == "test" else "{}_{}".format(args.exp_name, args.test_set)
         args.out_path = os.path.join(args.results_root, "test", "results", dataset.test_results_dir, method.eval_name,
                                      base_model.name, args.gridsearch_name, exp)
+        if hasattr(method, "eval_model_preprocessing"):          # eval.py:45-46 (IMM: merged models)
+            args.models_path, args.datasets_path = model_paths, ds_paths
+            model_paths = method.eval_model_preprocessing(args)
         results = eval_all_models_all_tasks(args, manager, ds_paths, model_paths)
     return {"manager": manager, "frameworks": frameworks, "ds_paths": ds_paths, "model_paths": model_paths,
             "results": results, "args": args}

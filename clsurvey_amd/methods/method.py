@@ -20,6 +20,7 @@ from . import ewc as trainEWC
 from . import finetune as trainFT
 from . import gem_main as trainRehearsal
 from . import hat_main as trainHAT
+from . import imm as trainIMM
 from . import mas as trainMAS
 from . import packnet_main as trainPacknet
 from . import si as trainSI
@@ -444,12 +445,64 @@ class GEM(Method):
                                        device=getattr(args, "device", "cuda"))
 
 
-_REGISTRY = {c.name: c for c in (EWC, MAS, SI, Finetune, PackNet, HAT, GEM)}
+
+class IMM(Method):
+    """method.py:760-819 (MODEL_BASED, no_framework): L2-transfer training per task, mean / mode merge before eval."""
+    name = "IMM"
+    eval_name = name
+    modes = ["mean", "mode"]
+    category = Category.MODEL_BASED
+    extra_hyperparams_count = 1
+    hyperparams = OrderedDict({"lambda": 0.01})
+    grid_chkpt = True
+    no_framework = True
+
+    def __init__(self, mode="mode"):
+        if mode not in self.modes:
+            raise Exception("NO EXISTING IMM MODE: '{}'".format(mode))
+        self.mode = mode
+        self.eval_name = self.name + "_" + self.mode
+
+    def set_mode(self, mode):
+        if mode not in self.modes:
+            raise Exception("TRY TO SET NON EXISTING IMM MODE: ", mode)
+        self.mode = mode
+        self.eval_name = self.name + "_" + self.mode
+
+    def grid_train(self, args, manager, lr):
+        return trainIMM.fine_tune_l2transfer(dataset_path=manager.current_task_dataset_path,
+                                             model_path=manager.previous_task_model_path,
+                                             exp_dir=manager.gridsearch_exp_dir, reg_lambda=self.hyperparams["lambda"],
+                                             batch_size=args.batch_size, num_epochs=args.num_epochs, lr=lr,
+                                             weight_decay=args.weight_decay, saving_freq=args.saving_freq,
+                                             device=getattr(args, "device", "cuda"))
+
+    def get_output(self, images, args):
+        return get_output_def(args.model, args.heads, images, args.current_head_idx, args.final_layer_idx)
+
+    @staticmethod
+    def grid_poststep(args, manager):
+        Finetune.grid_poststep(args, manager)
+
+    def eval_model_preprocessing(self, args):
+        return trainIMM.preprocess_merge_IMM(self, args.models_path, args.datasets_path, args.batch_size, overwrite=True,
+                                             device=getattr(args, "device", "cuda"))
+
+    @staticmethod
+    def inference_eval(args, manager):
+        return Finetune.inference_eval(args, manager)
+
+
+_REGISTRY = {c.name: c for c in (EWC, MAS, SI, Finetune, PackNet, HAT, GEM, IMM)}
 
 
 def parse(method_name):
     """method.py:35-78 for the methods on the hot path (GEM / PackNet / HAT register themselves when
     their modules are imported)."""
+    if IMM.name in method_name:                               # method.py:40-42: modeIMM, meanIMM, IMM_mode, IMM_mean
+        m = IMM(method_name.replace("_", "").replace(IMM.name, "").strip())
+        m.hyperparams = copy.deepcopy(IMM.hyperparams)
+        return m
     if method_name in _REGISTRY:
         m = _REGISTRY[method_name]()
         m.hyperparams = copy.deepcopy(type(m).hyperparams)

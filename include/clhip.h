@@ -123,6 +123,13 @@ int clhip_si_step(float* theta, const float* grad, const float* omega, const flo
 int clhip_si_consolidate(float* omega, float* w, const float* theta, float* init_val, size_t n,
                          float slack, void* stream);
 
+/* IMM_merge_models — IMM/merge.py:185-242, one parameter tensor of n_models (<= 32) task models:
+ * precisions == NULL: mean-IMM  out = (sum_m theta_m) / n_models
+ * else               mode-IMM  out = sum_m (precisions[m] / sum_precision) * theta_m
+ * thetas / precisions are HOST arrays of device pointers.                                           */
+int clhip_imm_merge(const float* const* thetas, const float* const* precisions, const float* sum_precision,
+                    int n_models, size_t n, float* out, void* stream);
+
 /* ------------------------------------------------------------------ PackNet masks (uint8, bit-exact)
  * methods/packnet/prune.py: mask value = owning task (1-based), 0 = free/pruned.
  *   finetune_mask  (:141-155)  mask[mask==0] = cur

@@ -577,3 +577,38 @@ def test_gem_through_driver(tmp_path):
     assert lo.shape == (5, 12) and bool((lo[:, :4] < -1e10).all()) and bool((lo[:, 8:] < -1e10).all())
     hf = out["frameworks"][-1]
     assert len(hf.trace) >= 1
+
+
+# --------------------------------------------------------------------------- IMM
+@pytest.mark.parametrize("mode", ["mean", "mode"])
+def test_imm_through_driver(tmp_path, mode):
+    """IMM (no_framework: L2-transfer LR grid per task, merge before evaluation) through the driver with --test."""
+    from clsurvey_amd.framework import driver
+    from clsurvey_amd.methods import method as M
+    root = str(tmp_path)
+    ds = _dataset(root)
+    _friendly_base_model(root)
+    driver.main(COMMON + ["--method_name", "SI", "--results_root", root, "--runmode", "first_task_basemodel_dump"],
+                method=M.parse("SI"), dataset=ds)
+    imm = M.parse("IMM_" + mode)
+    assert imm.eval_name == "IMM_" + mode
+    out = driver.main(COMMON + ["--method_name", "IMM", "--results_root", root, "--test"], method=imm, dataset=ds)
+    res = out["results"]
+    assert sorted(res) == [0, 1, 2]
+    accs = [a for i in res for a in res[i]["seq_res"][i]]
+    assert all(0.0 <= a <= 100.0 for a in accs) and res[0]["seq_res"][0][0] > 40.0
+    tdir = os.path.dirname(out["model_paths"][-1])
+    merged = os.path.join(tdir, "best_model_%s_merge.pth.tar" % mode)
+    assert os.path.exists(merged)
+    assert out["model_paths"][-1] == merged and out["model_paths"][0].endswith("best_model.pth.tar")
+    mm = torch.load(merged, weights_only=False)
+    last = torch.load(os.path.join(tdir, "best_model.pth.tar"), weights_only=False)
+    same = all(torch.equal(a.detach().cpu(), b.detach().cpu()) for a, b in zip(mm.parameters(), last.parameters()))
+    if mode == "mean":
+        assert same, "the reference's mean-IMM leaves the task model unmerged (merge.py:223-239)"
+    else:
+        assert not same
+        assert os.path.exists(os.path.join(tdir, "precision_mode.pth.tar"))
+        assert os.path.exists(os.path.join(tdir, "sum_precision_mode.pth.tar"))
+        rp = last.reg_params
+        assert all(bool((rp[p]["omega"] == 1).all()) for p in last.parameters() if p in rp)

@@ -665,3 +665,77 @@ def test_wgrad_fused_unpool(shape):
     dw, db = ops.conv3x3_bwd_weight_unpool(x, gp, idx)
     assert_close(dw, dw_ref, tol=1e-5, what="dw")
     assert_close(db, db_ref, tol=1e-5, what="db")
+
+
+# --------------------------------------------------------------------------- IMM
+def _g13_model(seed):
+    from clsurvey_amd import models
+    from oracle import vgg_ref
+    ps = vgg_ref.init_params(TINY, (24, 24), 5, 32, np.random.RandomState(int(seed)))
+    for i in (-6, -4, -2):
+        ps[i] = ps[i] * 20.0
+    m = models.VGGSlim(cfg=TINY, num_classes=5, classifier_inputdim=32 * 2 * 2, classifier_dim1=24, classifier_dim2=24)
+    with torch.no_grad():
+        for p, q in zip(m.parameters(), ps):
+            p.copy_(q)
+    return m, ps
+
+
+def test_imm_merge_and_precision_golden_g13(golden):
+    """IMM_merge_models (mean as the reference executes it, mode through clhip_imm_merge), the intended mean, and
+    diag_fisher with argmax 'sampling' against the reference run recorded in G13."""
+    from clsurvey_amd.methods import imm as IM
+    from clsurvey_amd.data import TensorTaskDataset, DeviceLoader
+    from oracle import imm_ref as I
+    g = golden("G13_imm")
+    built = [_g13_model(s) for s in g["model_seeds"]]
+    models = [b[0] for b in built]
+    names = [str(n) for n in g["param_names"]]
+    head = ["classifier.4.weight", "classifier.4.bias"]
+    keep = (0, 1, 6, 7, 12, 13)
+    prec = [{names[j]: torch.from_numpy(g["prec%d_p%d" % (i, j)]) for j in keep} for i in range(3)]
+    for idx in (1, 2):
+        mean_m = IM.IMM_merge_models(models, idx, head, mean_mode=True, device=dev())
+        for j, p in enumerate(mean_m.parameters()):
+            if j in keep or j >= 16:
+                assert torch.equal(p.detach().cpu(), torch.from_numpy(g["mean%d_p%d" % (idx, j)])), ("mean", idx, j)
+        fixed = IM.IMM_merge_models(models, idx, head, mean_mode=True, device=dev(), fix_mean=True)
+        for j, p in enumerate(fixed.parameters()):
+            if j < 16:
+                assert torch.equal(p.detach().cpu(), I.merge_mean_intended([b[1][j] for b in built[:idx + 1]])), ("mean*", idx, j)
+        # mode: only the stored tensors have precisions in the fixture -> merge those through the kernel directly
+        s = {n: sum(prec[i][n] for i in range(1, idx + 1)) + prec[0][n] for n in prec[0]}
+        s = None
+        for i in range(idx + 1):
+            s = prec[i] if s is None else {n: p + prec[i][n] for n, p in s.items()}
+        for j in keep:
+            n = names[j]
+            thetas = [b[1][j].to(dev()).contiguous() for b in built[:idx + 1]]
+            out = torch.empty_like(thetas[0])
+            IM._merge_tensor(thetas, [prec[i][n].to(dev()) for i in range(idx + 1)], s[n].to(dev()), out)
+            # fp32: the device division is not bit-identical to the host's; 1e-6 relative (the CPU oracle is bit-exact)
+            assert_close(out, torch.from_numpy(g["mode%d_p%d" % (idx, j)]), tol=1e-6, what="mode %d %d" % (idx, j))
+    # precision estimate: two phases, argmax instead of multinomial (the fixture's choice), head excluded
+    loaders = {}
+    for ph, nb in (("train", 2), ("val", 3)):
+        x = torch.cat([torch.from_numpy(g["fx_%s%d" % (ph, b)]) for b in range(nb)])
+        bs = g["fx_%s0" % ph].shape[0]
+        loaders[ph] = DeviceLoader(TensorTaskDataset(x, torch.zeros(x.shape[0], dtype=torch.int64), list("01234")), bs, False, dev())
+    fisher = IM.diag_fisher(models[0].to(dev()), loaders, exclude_params=head, sampler=lambda z: z.argmax(1))
+    assert sorted(fisher) == sorted(n for n in names if n not in head)
+    for j in range(16):
+        ref = torch.from_numpy(g["fisher_p%d" % j])
+        assert_close(fisher[names[j]], ref, tol=5e-4, what="fisher %d" % j)
+
+
+def test_imm_update_reg_params_and_sampler():
+    from clsurvey_amd.methods import imm as IM
+    m, _ = _g13_model(140)
+    m.reg_params = {p: {"omega": torch.zeros_like(p), "init_val": torch.zeros_like(p)} for p in m.parameters()}
+    rp = IM.update_reg_params(m)
+    assert len([p for p in m.parameters() if p in rp]) == 18
+    assert all(bool((rp[p]["omega"] == 1).all()) and torch.equal(rp[p]["init_val"], p.data) for p in m.parameters())
+    torch.manual_seed(0)
+    z = torch.tensor([[10.0, -10.0, -10.0], [-10.0, -10.0, 10.0]], device=dev()).repeat(50, 1)
+    t = IM.sample_targets(z)
+    assert t.shape == (100,) and bool((t[0::2] == 0).all()) and bool((t[1::2] == 2).all())

@@ -237,3 +237,42 @@ def test_g6_gem_oracle_and_product_qp(golden):
         grad = Pm @ v2 + M @ gr.reshape(-1).astype(np.float64)
         assert np.all(v2 >= margin - 1e-10) and np.all(grad >= -1e-8)
         assert abs(((v2 - margin) * grad).sum()) <= 1e-7 * max(1.0, np.abs(grad).max())
+
+
+def _g13_models(g):
+    out = []
+    for seed in g["model_seeds"]:
+        ps = vgg_ref.init_params(TINY, (24, 24), 5, 32, np.random.RandomState(int(seed)))
+        for i in (-6, -4, -2):
+            ps[i] = ps[i] * 20.0
+        out.append(ps)
+    return out
+
+
+def test_g13_imm_merge_and_precision(golden):
+    """oracle/imm_ref.py vs the reference's IMM_merge_models (mean / mode) and diag_fisher (G13, make_g13.py)."""
+    from oracle import imm_ref as I
+    g = golden("G13_imm")
+    models = _g13_models(g)
+    keep = (0, 1, 6, 7, 12, 13)
+    for idx in (1, 2):
+        for j in keep:
+            thetas = [m[j] for m in models[:idx + 1]]
+            assert torch.equal(I.merge_mean(thetas), torch.from_numpy(g["mean%d_p%d" % (idx, j)])), ("mean", idx, j)
+            precs = [torch.from_numpy(g["prec%d_p%d" % (i, j)]) for i in range(idx + 1)]
+            s = precs[0]
+            for p in precs[1:]:
+                s = s + p
+            np.testing.assert_allclose(I.merge_mode(thetas, precs, s).numpy(), g["mode%d_p%d" % (idx, j)], rtol=1e-6, atol=1e-7)
+        for j in (16, 17):      # heads are not merged: the task's own head
+            assert torch.equal(models[idx][j], torch.from_numpy(g["mean%d_p%d" % (idx, j)]))
+            assert torch.equal(models[idx][j], torch.from_numpy(g["mode%d_p%d" % (idx, j)]))
+    phases = [[torch.from_numpy(g["fx_train%d" % b]) for b in range(2)], [torch.from_numpy(g["fx_val%d" % b]) for b in range(3)]]
+    with torch.no_grad():
+        targets = [[vgg_ref.forward(models[0], TINY, x).argmax(1) for x in ph] for ph in phases]
+    prec = I.diag_fisher(models[0], TINY, phases, targets, exclude=(16, 17))
+    for j in range(16):
+        ref = g["fisher_p%d" % j]
+        np.testing.assert_allclose(prec[j].numpy(), ref, rtol=2e-4, atol=2e-4 * float(np.abs(ref).max()))
+    assert "fisher_p16" not in g.files and prec[16] is None
+    assert int(g["urp_count"]) == 18 and bool(g["urp_omega_all_ones"]) and bool(g["urp_init_equals_theta"])
