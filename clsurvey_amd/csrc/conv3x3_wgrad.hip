@@ -43,24 +43,33 @@ __device__ __forceinline__ void decode_stage(int st, int tiles_w, int tiles_h, i
     w0 = tw_i * TW;
 }
 
-// grid.x = n_tiles(k,c) * splits ; block 256 = 4 waves = (2 k-halves) x (2 c-halves)
-template <int TW, int TH, bool VEC>
-__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(
+// grid.x = n_tiles(k,c) * splits ; block 256 = 4 waves.
+//   PS = false: 64x64 (k,c) tile, waves = (2 k-halves) x (2 c-halves), every wave sees all 64 pixels of a stage;
+//   PS = true ("pixel split", deep layers with few pixels): 32x32 tile, the four waves take a quarter of each stage's
+//        pixels and their accumulators are added through LDS in wave order at the end.  A 4x smaller slab per block and
+//        4x more stages per block: at 16x16 / 8x8 the 64x64 form left 1.5-3 stages per block (20-30 % lost to the
+//        whole-stage quantisation) and moved 38 MB of partial slabs per layer.
+#ifndef CLHIP_WGRAD_MINBLK
+#define CLHIP_WGRAD_MINBLK 1
+#endif
+template <int TW, int TH, bool VEC, bool PS>
+__global__ __launch_bounds__(256, PS ? 2 : CLHIP_WGRAD_MINBLK) void conv3x3_wgrad_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
     int N, int C, int K, int H, int W, int tiles_w, int tiles_h,
     int total_stages, int splits, int c_tiles, size_t slab_stride) {
     using G = WGeo<TW, TH>;
-    __shared__ float dys[KT * G::LDP];
-    __shared__ float xs[CT * G::PLANEP];
+    constexpr int KTt = PS ? 32 : 64, CTt = PS ? 32 : 64;
+    __shared__ float dys[KTt * G::LDP];
+    __shared__ float xs[(CTt * G::PLANEP > 3 * 1024 + 64) ? CTt * G::PLANEP : 3 * 1024 + 64];   // PS: reused as the 12 KB reduction pad
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wk = wave & 1, wc = wave >> 1;
+    const int wk = PS ? 0 : (wave & 1), wc = PS ? 0 : (wave >> 1);
     const int li = lane & 31, kk = lane >> 5;
 
     const int split = blockIdx.x % splits;
     const int tile = blockIdx.x / splits;
     const int ct = tile % c_tiles, kt = tile / c_tiles;
-    const int k0 = kt * KT, c0 = ct * CT;
+    const int k0 = kt * KTt, c0 = ct * CTt;
 
     // contiguous, balanced stage range of this split
     const int per = total_stages / splits, extra = total_stages % splits;
@@ -83,9 +92,9 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(
     // + a select (no exec-mask branches), 16 bytes wide on aligned shapes (VEC): 14 load instructions
     // per thread per stage instead of 50 four-byte loads with ~20 VALU/SALU instructions of bounds
     // logic each — this wave is alone on its SIMD, so all of that ran with the matrix pipe idle.
-    constexpr int XROWS = CT * (TH + 2);
-    constexpr int DY_IT = VEC ? (KT * G::BP / 4) / 256 : KT * G::BP / 256;          // 4 | 16
-    constexpr int X_ELEMS = CT * G::PLANE;
+    constexpr int XROWS = CTt * (TH + 2);
+    constexpr int DY_IT = VEC ? (KTt * G::BP / 4) / 256 : KTt * G::BP / 256;        // 4 | 16 (PS: 2 | 8)
+    constexpr int X_ELEMS = CTt * G::PLANE;
     constexpr int XV_ELEMS = XROWS * (TW / 4);
     constexpr int X_IT = VEC ? (XV_ELEMS + 255) / 256 : (X_ELEMS + 255) / 256;      // 8|5|5 | 34|27|25
     constexpr int H_IT = VEC ? (XROWS * 2 + 255) / 256 : 0;                          // 2|2|3
@@ -139,9 +148,19 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(
         }
     }
 
-    auto load_stage = [&](int st) {
-        int n, h0, w0;
-        decode_stage(st, tiles_w, tiles_h, TW, TH, n, h0, w0);
+    // stages are visited in order: decode the first one with divisions, then step (tile column, tile row, image) —
+    // the ~135 scalar instructions of a full decode per stage sat in front of every stage's MFMAs of this lone wave
+    int cur_n, cur_th, cur_tw;
+    {
+        const int st0 = st_begin < st_end ? st_begin : 0;
+        cur_tw = st0 % tiles_w;
+        const int t0 = st0 / tiles_w;
+        cur_th = t0 % tiles_h;
+        cur_n = t0 / tiles_h;
+    }
+    auto load_stage = [&](int) {
+        const int n = cur_n, h0 = cur_th * TH, w0 = cur_tw * TW;
+        if (++cur_tw == tiles_w) { cur_tw = 0; if (++cur_th == tiles_h) { cur_th = 0; ++cur_n; } }
         const float* xp = x + ((size_t)n * C + c0) * plane_hw + (size_t)h0 * W + w0;
         if constexpr (VEC) {
             const float* dyp = dy + ((size_t)n * K + k0) * plane_hw + (size_t)h0 * W + w0;
@@ -218,20 +237,25 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(
         // operands of pixel pair pp+1 are read while the 9 MFMAs of pair pp run (explicit register
         // double buffering; see conv3x3.hip)
         float af[2], bf[2][9];
+        // PS: this wave's quarter of the stage starts at pixel 16*wave (whole rows or half rows for every TW)
+        constexpr int NPP = PS ? G::BP / 8 : G::BP / 2;
+        const int pb = PS ? 16 * wave : 0;
+        const float* a_w = a_ptr + pb;
+        const float* b_w = b_ptr + (pb / TW) * G::TWP + (pb % TW);
         auto load_frag = [&](int pp, int slot) {
             const int q0 = 2 * pp;
             const int th = q0 / TW, tw = q0 - (q0 / TW) * TW;
-            af[slot] = a_ptr[q0];
+            af[slot] = a_w[q0];
 #pragma unroll
             for (int rs = 0; rs < 9; ++rs) {
                 const int r = rs / 3, s = rs - 3 * (rs / 3);
-                bf[slot][rs] = b_ptr[(th + r) * G::TWP + tw + s];
+                bf[slot][rs] = b_w[(th + r) * G::TWP + tw + s];
             }
         };
         load_frag(0, 0);
 #pragma unroll
-        for (int pp = 0; pp < G::BP / 2; ++pp) {
-            if (pp + 1 < G::BP / 2) load_frag(pp + 1, (pp + 1) & 1);
+        for (int pp = 0; pp < NPP; ++pp) {
+            if (pp + 1 < NPP) load_frag(pp + 1, (pp + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
             bsum += (double)af[pp & 1];
 #pragma unroll
@@ -241,8 +265,48 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(
         }
     }
 
-    // ---- partial slab [split]{[9][K][C], [K]}: reg r of lane l = D[row = k][col = c]
     float* slab = part + (size_t)split * slab_stride;
+    if constexpr (PS) {
+        // add the four pixel quarters in wave order 0 + 1 + 2 + 3 (fixed => deterministic), one tap per round through a
+        // 12 KB pad in xs; wave 0 then owns the tile
+        __syncthreads();                                   // the last stage's LDS reads are done
+        float* pad = xs;                                   // [3 waves][16 regs][64 lanes]
+        double* bpad = reinterpret_cast<double*>(dys);     // [3 waves][64 lanes]
+        bsum += __shfl_xor(bsum, 32, 64);                  // even + odd pixels of this wave
+        if (wave > 0) bpad[(wave - 1) * 64 + lane] = bsum;
+#pragma unroll
+        for (int rs = 0; rs < 9; ++rs) {
+            if (wave > 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pad[((wave - 1) * 16 + r) * 64 + lane] = acc[rs][r];
+            }
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[rs][r] = ((acc[rs][r] + pad[(0 * 16 + r) * 64 + lane]) + pad[(1 * 16 + r) * 64 + lane]) + pad[(2 * 16 + r) * 64 + lane];
+            }
+            __syncthreads();
+        }
+        if (wave == 0) {
+            const int c = c0 + li;
+#pragma unroll
+            for (int rs = 0; rs < 9; ++rs)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int k = k0 + mfma32_row(r, lane);
+                    if (k < K && c < C) slab[((size_t)rs * K + k) * C + c] = acc[rs][r];
+                }
+            if (ct == 0) {
+                const double tot = ((bsum + bpad[0 * 64 + lane]) + bpad[1 * 64 + lane]) + bpad[2 * 64 + lane];
+                const int k = k0 + li;
+                if (kk == 0 && k < K) slab[(size_t)9 * K * C + k] = (float)tot;
+            }
+        }
+        return;
+    }
+
+    // ---- partial slab [split]{[9][K][C], [K]}: reg r of lane l = D[row = k][col = c]
     const int c = c0 + wc * 32 + li;
 #pragma unroll
     for (int rs = 0; rs < 9; ++rs)
@@ -322,9 +386,19 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_smallc_kernel(
         }
     }
 
-    auto load_stage = [&](int st) {
-        int n, h0, w0;
-        decode_stage(st, tiles_w, tiles_h, TW, TH, n, h0, w0);
+    // stages are visited in order: decode the first one with divisions, then step (tile column, tile row, image) —
+    // the ~135 scalar instructions of a full decode per stage sat in front of every stage's MFMAs of this lone wave
+    int cur_n, cur_th, cur_tw;
+    {
+        const int st0 = st_begin < st_end ? st_begin : 0;
+        cur_tw = st0 % tiles_w;
+        const int t0 = st0 / tiles_w;
+        cur_th = t0 % tiles_h;
+        cur_n = t0 / tiles_h;
+    }
+    auto load_stage = [&](int) {
+        const int n = cur_n, h0 = cur_th * TH, w0 = cur_tw * TW;
+        if (++cur_tw == tiles_w) { cur_tw = 0; if (++cur_th == tiles_h) { cur_th = 0; ++cur_n; } }
         const bool pix_ok = (h0 + th_t < H) && (w0 + tw_t < W);
         const float* dyp = dy + ((size_t)n * K + k0 + wave) * plane_hw + (size_t)(h0 + th_t) * W + (w0 + tw_t);
         const float* xp = x + (size_t)n * C * plane_hw + (size_t)h0 * W + w0;
@@ -455,7 +529,7 @@ __global__ __launch_bounds__(RED_EL * RED_J) void wgrad_reduce_kernel(const floa
 }
 
 struct WPlan {
-    int TW, TH, tiles_w, tiles_h, total_stages, splits, k_tiles, c_tiles, group, groups;
+    int TW, TH, tiles_w, tiles_h, total_stages, splits, k_tiles, c_tiles, group, groups, ps;
     size_t slab, ws_floats;
 };
 
@@ -470,9 +544,20 @@ WPlan make_plan(int N, int C, int K, int H, int W) {
     const bool smallc = (C * 9 <= 32);
     p.k_tiles = (K + KT - 1) / KT;
     p.c_tiles = smallc ? 1 : (C + CT - 1) / CT;
+    p.ps = 0;
+    if (!smallc) {
+        // few stages per 64x64 block (deep layers): 32x32 tiles with the pixels of a stage split over the waves
+        const int t64 = p.k_tiles * p.c_tiles;
+        const int splits64 = (256 + t64 - 1) / t64;
+        if (p.total_stages / (splits64 > 0 ? splits64 : 1) < 8) {
+            p.ps = 1;
+            p.k_tiles = (K + 31) / 32;
+            p.c_tiles = (C + 31) / 32;
+        }
+    }
     int tiles = p.k_tiles * p.c_tiles;
     // MFMA-bound general kernel: ~1 block per CU. HBM-bound first-layer kernel: several per CU.
-    int target = smallc ? 1024 : 256;
+    int target = smallc ? 1024 : 256;       // (512 PS blocks, two per CU, measured slower: 44 vs 39 us at 8x8)
     int splits = (target + tiles - 1) / tiles;
     if (splits > p.total_stages) splits = p.total_stages;
     p.slab = (size_t)9 * K * C + K;
@@ -517,12 +602,14 @@ static int bwd_weight_impl(const float* x, const float* dy, const uint8_t* unpoo
     } else {
         // 16-byte staging needs aligned rows and whole tiles along w
         const bool vec = (W % 4 == 0) && (W % p.TW == 0) && aligned16(x) && aligned16(dy);
-#define WG_LAUNCH(TW_, TH_) do { if (vec) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TW_, TH_, true>), dim3(grid), dim3(256), 0, s, WG_ARGS, p.c_tiles, p.slab); \
-                                 else hipLaunchKernelGGL((conv3x3_wgrad_kernel<TW_, TH_, false>), dim3(grid), dim3(256), 0, s, WG_ARGS, p.c_tiles, p.slab); } while (0)
+#define WG_LAUNCH1(TW_, TH_, PS_) do { if (vec) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TW_, TH_, true, PS_>), dim3(grid), dim3(256), 0, s, WG_ARGS, p.c_tiles, p.slab); \
+                                      else hipLaunchKernelGGL((conv3x3_wgrad_kernel<TW_, TH_, false, PS_>), dim3(grid), dim3(256), 0, s, WG_ARGS, p.c_tiles, p.slab); } while (0)
+#define WG_LAUNCH(TW_, TH_) do { if (p.ps) WG_LAUNCH1(TW_, TH_, true); else WG_LAUNCH1(TW_, TH_, false); } while (0)
         if (p.TW == 32) WG_LAUNCH(32, 2);
         else if (p.TW == 16) WG_LAUNCH(16, 4);
         else WG_LAUNCH(8, 8);
 #undef WG_LAUNCH
+#undef WG_LAUNCH1
     }
 #undef WG_ARGS
     CLHIP_LAUNCH_CHECK();
