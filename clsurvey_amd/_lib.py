@@ -43,6 +43,7 @@ SIGNATURES = {
     "clhip_si_step": (_i, [_p, _p, _p, _p, _p, _p, _z, _f, _f, _f, _f, _i, _p]),
     "clhip_si_consolidate": (_i, [_p, _p, _p, _p, _z, _f, _p]),
     "clhip_imm_merge": (_i, [_p, _p, _p, _i, _z, _p, _p]),
+    "clhip_lwf_loss": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _i, _p, _p, _p, _p]),
     "clhip_packnet_finetune_mask": (_i, [_p, _z, _i, _p]),
     "clhip_packnet_kth_ws": (_z, []),
     "clhip_packnet_kth_abs": (_i, [_p, _p, _z, _i, _z, _p, _p, _z, _p]),

@@ -175,6 +175,79 @@ __global__ __launch_bounds__(LOSS_BLOCK) void mse_zero_sum_kernel(const float* _
     }
 }
 
+
+// LwF objective over stacked heads (methods/LwF/main_LWF.py:47-76,184-202): logits [N][ld] hold H heads side by side
+// (head h = columns off[h] .. off[h] + size[h]); the LAST head is the new task (CrossEntropy, mean), every earlier head
+// h is distilled towards teacher [N][ld_t] (same column layout, the old heads only):
+//   L_h = 1/N sum_rows [ log sum_j exp((y_j - max y)/T) - sum_j p_j (y_j - max y)/T ],
+//   p = softmax(t - max t)^(1/T) / sum(...)                                  (distillation_loss, :47-76)
+//   total = task + lambda * sum_h L_h ;  d total / d y_j = lambda / (N T) (softmax((y - max)/T)_j - p_j) on old heads.
+// One thread per row (N <= 1024); rows are summed in a fixed order.  loss_out[0] = task loss (what the reference logs),
+// loss_out[1] = lambda * sum_h L_h; stats += (task loss, #correct on the new head).
+constexpr int LWF_MAX_HEADS = 32;
+struct LwfHeads { int n; int off[LWF_MAX_HEADS]; int size[LWF_MAX_HEADS]; };
+
+__global__ __launch_bounds__(LOSS_BLOCK) void lwf_loss_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                              const float* __restrict__ teacher, LwfHeads hd, int N, int ld, int ld_t,
+                                                              float T, float lam, int distill, float* __restrict__ dlogits,
+                                                              float* __restrict__ loss_out, double* __restrict__ stats) {
+    __shared__ float s_task[LOSS_BLOCK], s_dist[LOSS_BLOCK];
+    __shared__ unsigned char s_corr[LOSS_BLOCK];
+    const int row = threadIdx.x;
+    float task = 0.f, dist = 0.f;
+    int ok = 0;
+    if (row < N) {
+        const float* z = logits + (size_t)row * ld;
+        float* dz = dlogits + (size_t)row * ld;
+        const float invN = 1.f / (float)N;
+        for (int h = 0; h < hd.n; ++h) {
+            const int o = hd.off[h], C = hd.size[h];
+            float m = -INFINITY; int am = 0;
+            for (int c = 0; c < C; ++c) { const float v = z[o + c]; if (v > m) { m = v; am = c; } }
+            if (h == hd.n - 1) {
+                const int y = (int)labels[row];
+                float se = 0.f;
+                for (int c = 0; c < C; ++c) se += expf(z[o + c] - m);
+                const float lse = logf(se);
+                for (int c = 0; c < C; ++c) dz[o + c] = (expf(z[o + c] - m - lse) - (c == y ? 1.f : 0.f)) * invN;
+                task = -(z[o + y] - m - lse);
+                ok = (am == y);
+            } else if (distill) {
+                const float* t = teacher + (size_t)row * ld_t + o;
+                float mt = -INFINITY;
+                for (int c = 0; c < C; ++c) mt = fmaxf(mt, t[c]);
+                float st = 0.f;
+                for (int c = 0; c < C; ++c) st += expf(t[c] - mt);
+                const float invT = 1.f / T;
+                float sp = 0.f;                                   // sum_j softmax(t)_j^(1/T)
+                for (int c = 0; c < C; ++c) sp += powf(expf(t[c] - mt) / st, invT);
+                float sumex = 0.f;
+                for (int c = 0; c < C; ++c) sumex += expf((z[o + c] - m) * invT);
+                float cross = 0.f;
+                const float g = lam * invN * invT;
+                for (int c = 0; c < C; ++c) {
+                    const float p = powf(expf(t[c] - mt) / st, invT) / sp;
+                    const float ys = (z[o + c] - m) * invT;
+                    cross += p * ys;
+                    dz[o + c] = g * (expf(ys) / sumex - p);
+                }
+                dist += logf(sumex) - cross;
+            } else {
+                for (int c = 0; c < C; ++c) dz[o + c] = 0.f;
+            }
+        }
+    }
+    s_task[row] = task; s_dist[row] = dist; s_corr[row] = (unsigned char)ok;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f, d = 0.f; int c = 0;
+        for (int i = 0; i < N; ++i) { t += s_task[i]; d += s_dist[i]; c += s_corr[i]; }       // fixed order
+        t /= (float)N; d = lam * d / (float)N;
+        loss_out[0] = t; loss_out[1] = d;
+        if (stats) { stats[0] += (double)t; stats[1] += (double)c; }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -197,6 +270,21 @@ int clhip_softmax_ce_slice(const float* logits, const int64_t* labels_i64, int N
 int clhip_softmax_ce(const float* logits, const int64_t* labels_i64, int N, int C, int reduction,
                      float* dlogits, float* loss_out, double* stats, void* stream) {
     return clhip_softmax_ce_slice(logits, labels_i64, N, C, 0, C, reduction, dlogits, loss_out, stats, stream);
+}
+
+int clhip_lwf_loss(const float* logits, const int64_t* labels_i64, const float* teacher, const int* head_sizes, int n_heads,
+                   int N, int ld, int ld_teacher, float T, float reg_lambda, int distill, float* dlogits, float* loss_out2,
+                   double* stats, void* stream) {
+    if (!logits || !labels_i64 || !head_sizes || !dlogits || !loss_out2 || n_heads < 1 || n_heads > LWF_MAX_HEADS) return CLHIP_EINVAL;
+    if (N <= 0 || N > LOSS_BLOCK || (distill && n_heads > 1 && !teacher) || T <= 0.f) return CLHIP_EINVAL;
+    LwfHeads hd; hd.n = n_heads;
+    int off = 0;
+    for (int h = 0; h < n_heads; ++h) { if (head_sizes[h] <= 0) return CLHIP_EINVAL; hd.off[h] = off; hd.size[h] = head_sizes[h]; off += head_sizes[h]; }
+    if (off > ld || (distill && n_heads > 1 && off - head_sizes[n_heads - 1] > ld_teacher)) return CLHIP_EINVAL;
+    hipLaunchKernelGGL(lwf_loss_kernel, dim3(1), dim3(LOSS_BLOCK), 0, as_stream(stream), logits, labels_i64, teacher, hd, N, ld,
+                       ld_teacher, T, reg_lambda, distill, dlogits, loss_out2, stats);
+    CLHIP_LAUNCH_CHECK();
+    return 0;
 }
 
 int clhip_mse_zero_sum(const float* logits, size_t n, float* dlogits, float* loss_out, void* stream) {

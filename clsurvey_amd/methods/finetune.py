@@ -24,6 +24,12 @@ def fine_tune_SGD(dset_dataloader, cumsum_dset_sizes, dset_classes, model_path, 
         if not os.path.isfile(model_path):
             raise Exception("Model path non-existing: {}".format(model_path))
         model_ft = tc.load_model(model_path)
+    # main_SGD.py:50-53: an LwF wrapper is unwrapped to its VGG with the stacked heads cut down to the first one
+    from .lwf import AlexNet_LwF
+    if isinstance(model_ft, AlexNet_LwF):
+        model_ft.model.classifier = torch.nn.Sequential(
+            *list(model_ft.model.classifier.children())[:model_ft.last_layer_name + 1])
+        model_ft = model_ft.model
     if replace_last_classifier_layer:
         labels_per_task = [len(task_labels) for task_labels in dset_classes["train"]]
         tc.replace_head(model_ft, sum(labels_per_task))          # utils.py:68-72

@@ -21,6 +21,7 @@ from . import finetune as trainFT
 from . import gem_main as trainRehearsal
 from . import hat_main as trainHAT
 from . import imm as trainIMM
+from . import lwf as trainLWF
 from . import mas as trainMAS
 from . import packnet_main as trainPacknet
 from . import si as trainSI
@@ -493,7 +494,50 @@ class IMM(Method):
         return Finetune.inference_eval(args, manager)
 
 
-_REGISTRY = {c.name: c for c in (EWC, MAS, SI, Finetune, PackNet, HAT, GEM, IMM)}
+
+class LWF(Method):
+    """method.py:940-989 (DATA_BASED): new head per task, old heads distilled from the previous model."""
+    name = "LWF"
+    eval_name = name
+    category = Category.DATA_BASED
+    extra_hyperparams_count = 1
+    hyperparams = OrderedDict({"lambda": 10})
+
+    def __init__(self, warmup_step=False):
+        if warmup_step:
+            raise NotImplementedError("LwF head warm-up (fine_tune_freeze) is not on the HIP path")
+        self.warmup_step = warmup_step
+
+    @staticmethod
+    def grid_train(args, manager, lr):
+        return Finetune.grid_train(args, manager, lr)
+
+    def train(self, args, manager, hyperparams):
+        return trainLWF.fine_tune_SGD_LwF(dataset_path=manager.current_task_dataset_path,
+                                          previous_task_model_path=manager.previous_task_model_path,
+                                          init_model_path=getattr(args, "init_model_path", ""),
+                                          exp_dir=manager.heuristic_exp_dir, batch_size=args.batch_size,
+                                          num_epochs=args.num_epochs, lr=args.lr, init_freeze=0,
+                                          weight_decay=args.weight_decay,
+                                          last_layer_name=args.classifier_heads_starting_idx,
+                                          saving_freq=args.saving_freq, reg_lambda=hyperparams["lambda"],
+                                          device=getattr(args, "device", "cuda"))
+
+    def get_output(self, images, args):
+        with torch.no_grad():
+            outputs = args.model(images)
+        if isinstance(outputs, list):
+            outputs = outputs[args.current_head_idx]
+        return outputs
+
+    @staticmethod
+    def inference_eval(args, manager):
+        if args.trained_model_idx > 0:
+            return GEM.inference_eval(args, manager)        # FinetuneRehearsalFullMem.inference_eval: model as is, head idx
+        return Finetune.inference_eval(args, manager)        # the shared SI first-task model
+
+
+_REGISTRY = {c.name: c for c in (EWC, MAS, SI, Finetune, PackNet, HAT, GEM, IMM, LWF)}
 
 
 def parse(method_name):

@@ -133,27 +133,34 @@ def parse_vgg(model):
 class NetEngine:
     LOSS = {"ce_mean": 0, "ce_sum": 1, "mse_sum_zero": 2}
 
-    def __init__(self, model, max_batch, in_shape, device="cuda"):
+    def __init__(self, model, max_batch, in_shape, device="cuda", layers=None, params=None):
+        """layers / params (optional): an explicit plan [(kind, weight, bias, cin, cout, relu, pool)] and the parameter
+        order of the arena, for models whose module tree is not plain VGGSlim (e.g. LwF's stacked heads run as ONE
+        Linear over head parameters laid out back to back)."""
         self.model = model
         self.device = torch.device(device)
-        self.layers = parse_vgg(model)
-        params = list(model.parameters())
-        self.arena = ParamArena(params, self.device)
-        descs = (LayerDesc * len(self.layers))()
-        for d, (kind, m, relu, pool) in zip(descs, self.layers):
+        if layers is None:
+            self.layers = parse_vgg(model)
+            specs = [(kind, m.weight, m.bias, m.in_channels if kind == "conv" else m.in_features,
+                      m.out_channels if kind == "conv" else m.out_features, relu, pool) for kind, m, relu, pool in self.layers]
+        else:
+            specs = list(layers)
+            self.layers = specs
+        if any(b is None for _, _, b, _, _, _, _ in specs):
+            raise NotImplementedError("NetEngine: layers without bias")
+        self.arena = ParamArena(list(model.parameters()) if params is None else list(params), self.device)
+        descs = (LayerDesc * len(specs))()
+        for d, (kind, w, b, cin, cout, relu, pool) in zip(descs, specs):
             d.type = 0 if kind == "conv" else 1
-            d.cin = m.in_channels if kind == "conv" else m.in_features
-            d.cout = m.out_channels if kind == "conv" else m.out_features
+            d.cin, d.cout = int(cin), int(cout)
             d.relu, d.pool = int(relu), int(pool)
-            d.w_off = self.arena.slot(m.weight)[0]
-            if m.bias is None:
-                raise NotImplementedError("NetEngine: layers without bias")
-            d.b_off = self.arena.slot(m.bias)[0]
+            d.w_off = self.arena.slot(w)[0]
+            d.b_off = self.arena.slot(b)[0]
         self.max_batch = int(max_batch)
         self.in_shape = tuple(in_shape)
         h = C.c_void_p()
         L = _lib.lib()
-        check(L.clhip_net_create(descs, len(self.layers), self.max_batch, *self.in_shape, C.byref(h)),
+        check(L.clhip_net_create(descs, len(specs), self.max_batch, *self.in_shape, C.byref(h)),
               "clhip_net_create")
         self._h = h
         self.n_classes = L.clhip_net_num_classes(h)
@@ -182,6 +189,13 @@ class NetEngine:
                                            self.ws.data_ptr(), logits.data_ptr(),
                                            torch.cuda.current_stream().cuda_stream), "clhip_net_forward")
         return logits
+
+    def backward(self, x, dlogits):
+        """Backward of the last forward() on this engine from dlogits [N][classes] into arena.grad."""
+        self._check_x(x)
+        check(_lib.lib().clhip_net_backward(self._h, self.arena.theta.data_ptr(), self.arena.grad.data_ptr(), x.data_ptr(),
+                                            x.shape[0], self.ws.data_ptr(), dlogits.data_ptr(),
+                                            torch.cuda.current_stream().cuda_stream), "clhip_net_backward")
 
     def loss_step(self, x, y, kind="ce_mean", backward=True, stats=None, want_logits=False, params=None,
                   class_slice=None):

@@ -101,6 +101,16 @@ int clhip_softmax_ce_slice(const float* logits, const int64_t* labels_i64, int N
  * dlogits = 2 z.                                                                            */
 int clhip_mse_zero_sum(const float* logits, size_t n, float* dlogits, float* loss_out, void* stream);
 
+/* LwF objective over stacked heads — LwF/main_LWF.py:47-76 (distillation_loss) and :184-202 (train_model_lwf):
+ * logits [N][ld] = n_heads heads side by side (head_sizes, host array); last head = new task, CrossEntropy(mean);
+ * every earlier head is distilled (temperature T) towards teacher [N][ld_teacher] (same column layout).
+ * dlogits = d(task + reg_lambda * sum dist)/dlogits; loss_out2[0] = task loss, [1] = reg_lambda * sum of the
+ * distillation terms; stats (optional, f64[2]) += (task loss, #correct on the new head). distill = 0: validation
+ * (task loss / accuracy only, zero gradient on the old heads). N <= 1024.                                      */
+int clhip_lwf_loss(const float* logits, const int64_t* labels_i64, const float* teacher, const int* head_sizes, int n_heads,
+                   int N, int ld, int ld_teacher, float T, float reg_lambda, int distill, float* dlogits, float* loss_out2,
+                   double* stats, void* stream);
+
 /* ------------------------------------------------------------------ penalised optimizers
  * Weight_Regularized_SGD.step — EWC/train_EWC.py:23-86 == MAS/train_MAS.py:32-95.
  *   d = g + 2*lambda*omega*(theta - init);  d += wd*theta;

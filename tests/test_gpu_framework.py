@@ -612,3 +612,30 @@ def test_imm_through_driver(tmp_path, mode):
         assert os.path.exists(os.path.join(tdir, "sum_precision_mode.pth.tar"))
         rp = last.reg_params
         assert all(bool((rp[p]["omega"] == 1).all()) for p in last.parameters() if p in rp)
+
+
+# --------------------------------------------------------------------------- LwF
+def test_lwf_through_driver(tmp_path):
+    """LWF through the two-phase driver with --test: task >= 2 models are AlexNet_LwF wrappers with one head per task,
+    phase 1 unwraps them (main_SGD.py:50-53), evaluation picks the task's head."""
+    from clsurvey_amd.framework import driver
+    from clsurvey_amd.methods import method as M
+    from clsurvey_amd.methods.lwf import AlexNet_LwF
+    root = str(tmp_path)
+    ds = _dataset(root)
+    _friendly_base_model(root)
+    driver.main(COMMON + ["--method_name", "SI", "--results_root", root, "--runmode", "first_task_basemodel_dump"],
+                method=M.parse("SI"), dataset=ds)
+    lwf = M.parse("LWF")
+    lwf.hyperparams["lambda"] = 1.0
+    out = driver.main(COMMON + ["--method_name", "LWF", "--results_root", root, "--test"], method=lwf, dataset=ds)
+    res = out["results"]
+    assert sorted(res) == [0, 1, 2]
+    accs = [a for i in res for a in res[i]["seq_res"][i]]
+    assert all(0.0 <= a <= 100.0 for a in accs)
+    assert res[0]["seq_res"][0][0] > 40.0 and res[2]["seq_res"][2][0] > 30.0, res
+    last = torch.load(out["model_paths"][-1], weights_only=False)
+    assert isinstance(last, AlexNet_LwF) and last.last_layer_name == 4
+    heads = list(last.model.classifier.children())[4:]
+    assert len(heads) == 3 and all(h.out_features == 4 for h in heads)
+    assert last.reg_params["reg_lambda"] == out["frameworks"][-1].hyperparams["lambda"]

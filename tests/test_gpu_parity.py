@@ -739,3 +739,67 @@ def test_imm_update_reg_params_and_sampler():
     z = torch.tensor([[10.0, -10.0, -10.0], [-10.0, -10.0, 10.0]], device=dev()).repeat(50, 1)
     t = IM.sample_targets(z)
     assert t.shape == (100,) and bool((t[0::2] == 0).all()) and bool((t[1::2] == 2).all())
+
+
+# --------------------------------------------------------------------------- LwF
+def _g14_wrapper(g):
+    import torch.nn as nn
+    from clsurvey_amd import models
+    from clsurvey_amd.methods import lwf as LF
+    from oracle import vgg_ref
+    ps = vgg_ref.init_params(TINY, (24, 24), 4, 32, np.random.RandomState(141))
+    for i in (-6, -4, -2):
+        ps[i] = ps[i] * 20.0
+    m = models.VGGSlim(cfg=TINY, num_classes=4, classifier_inputdim=32 * 2 * 2, classifier_dim1=24, classifier_dim2=24)
+    with torch.no_grad():
+        for p, q in zip(m.parameters(), ps):
+            p.copy_(q)
+    w = LF.AlexNet_LwF(m, last_layer_name=4)
+    for i, nc in enumerate((8, 4)):
+        h = nn.Linear(24, nc)
+        with torch.no_grad():
+            h.weight.copy_(torch.from_numpy(g["head%d_w" % (i + 1)]))
+            h.bias.copy_(torch.from_numpy(g["head%d_b" % (i + 1)]))
+        w.model.classifier.add_module(str(5 + i), h)
+    return w
+
+
+def test_lwf_loss_kernel_and_engine_golden_g14(golden):
+    """clhip_lwf_loss (value, gradient) on bare logits, the stacked-heads-as-one-Linear plan (head outputs), and the
+    full LwF objective's parameter gradients against the reference run recorded in G14."""
+    import ctypes as C
+    from clsurvey_amd import _lib
+    from clsurvey_amd.methods import lwf as LF
+    g = golden("G14_lwf")
+    L = _lib.lib()
+    for tag in ("a", "b"):
+        y = torch.from_numpy(g["d%s_y" % tag])
+        n, c = y.shape
+        z = torch.cat([y, torch.zeros(n, 4)], 1).contiguous().to(dev())      # one distilled head + a dummy new head
+        t = torch.from_numpy(g["d%s_t" % tag]).to(dev())
+        lab = torch.zeros(n, dtype=torch.int64, device=dev())
+        dz = torch.zeros_like(z)
+        loss2 = torch.zeros(2, device=dev())
+        sizes = (C.c_int * 2)(c, 4)
+        _lib.check(L.clhip_lwf_loss(z.data_ptr(), lab.data_ptr(), t.data_ptr(), sizes, 2, n, c + 4, c, float(g["d%s_T" % tag]), 1.0, 1,
+                                    dz.data_ptr(), loss2.data_ptr(), None, torch.cuda.current_stream().cuda_stream), "lwf")
+        assert_close(loss2[1:2], torch.from_numpy(g["d%s_loss" % tag]).view(1), tol=1e-5, what="distillation loss")
+        assert_close(dz[:, :c], torch.from_numpy(g["d%s_grad" % tag]), tol=1e-4, what="distillation grad")
+    w = _g14_wrapper(g).to(dev())
+    assert [n for n, _ in w.named_parameters()] == [str(n) for n in g["param_names"]]
+    x, y = torch.from_numpy(g["x"]).to(dev()), torch.from_numpy(g["y"]).to(dev())
+    outs = w(x)                                                       # autograd-bridge forward (evaluation path)
+    for i, o in enumerate(outs):
+        assert_close(o, torch.from_numpy(g["out%d" % i]), tol=2e-4, what="head %d output" % i)
+    eng = LF.LwfEngine(w, 8, (3, 32, 32), dev())
+    z = eng.logits(x)
+    assert eng.sizes == [4, 8, 4]
+    assert_close(z, torch.cat([torch.from_numpy(g["out%d" % i]) for i in range(3)], 1), tol=2e-4, what="stacked logits")
+    teacher = torch.cat([torch.from_numpy(g["teacher0"]), torch.from_numpy(g["teacher1"])], 1).contiguous().to(dev())
+    stats = torch.zeros(2, dtype=torch.float64, device=dev())
+    loss2 = eng.step(x, y, teacher, 2.0, 10.0, backward=True, stats=stats)
+    assert_close(loss2[0:1], torch.from_numpy(g["task_loss"]).view(1), tol=1e-4, what="task loss")
+    assert_close(loss2[1:2], torch.from_numpy(g["dist_loss"]).view(1), tol=1e-4, what="lambda * distillation")
+    assert int(stats[1].item()) == int((torch.from_numpy(g["out2"]).argmax(1) == torch.from_numpy(g["y"])).sum())
+    for j, (n, p) in enumerate(w.named_parameters()):
+        assert_close(p.grad, torch.from_numpy(g["g%d" % j]), tol=1e-3, what="grad " + n)

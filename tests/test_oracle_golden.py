@@ -276,3 +276,19 @@ def test_g13_imm_merge_and_precision(golden):
         np.testing.assert_allclose(prec[j].numpy(), ref, rtol=2e-4, atol=2e-4 * float(np.abs(ref).max()))
     assert "fisher_p16" not in g.files and prec[16] is None
     assert int(g["urp_count"]) == 18 and bool(g["urp_omega_all_ones"]) and bool(g["urp_init_equals_theta"])
+
+
+def test_g14_lwf_distillation(golden):
+    """oracle/lwf_ref.py vs the reference's distillation_loss value + gradient (G14, make_g14.py)."""
+    from oracle import lwf_ref as LW
+    g = golden("G14_lwf")
+    for tag in ("a", "b"):
+        y = torch.from_numpy(g["d%s_y" % tag]).requires_grad_(True)
+        loss = LW.distillation_loss(y, torch.from_numpy(g["d%s_t" % tag]), float(g["d%s_T" % tag]))
+        loss.backward()
+        np.testing.assert_allclose(loss.detach().numpy(), g["d%s_loss" % tag], rtol=1e-5)
+        np.testing.assert_allclose(y.grad.numpy(), g["d%s_grad" % tag], rtol=1e-4, atol=1e-7)
+    outs = [torch.from_numpy(g["out%d" % i]) for i in range(3)]
+    task, dist = LW.lwf_objective(outs, torch.from_numpy(g["y"]), [torch.from_numpy(g["teacher0"]), torch.from_numpy(g["teacher1"])], 2.0, 10.0)
+    np.testing.assert_allclose(task.numpy(), g["task_loss"], rtol=1e-5)
+    np.testing.assert_allclose(dist.numpy(), g["dist_loss"], rtol=1e-5)
