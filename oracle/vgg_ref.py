@@ -15,6 +15,8 @@ CFGS = {  # models/VGGSlim.py:19-23
     "small_VGG9": [64, "M", 64, "M", 64, 64, "M", 128, 128, "M"],
     "base_VGG9": [64, "M", 64, "M", 128, 128, "M", 256, 256, "M"],
     "wide_VGG9": [64, "M", 128, "M", 256, 256, "M", 512, 512, "M"],
+    "deep_VGG22": [64, "M", 64, 64, 64, 64, 64, 64, "M", 128, 128, 128, 128, 128, 128, "M",
+                   256, 256, 256, 256, 256, 256, "M"],
 }
 
 

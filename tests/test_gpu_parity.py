@@ -223,7 +223,8 @@ def test_elementwise_regularizers_match_oracle():
 def build_engine(cfg, fc, ncls, hw, params, max_batch):
     from clsurvey_amd import models, net
     last = [v for v in cfg if v != "M"][-1]
-    m = models.VGGSlim(cfg=cfg, num_classes=ncls, classifier_inputdim=last * (hw // 16) ** 2,
+    npool = sum(1 for v in cfg if v == "M")
+    m = models.VGGSlim(cfg=cfg, num_classes=ncls, classifier_inputdim=last * (hw // 2 ** npool) ** 2,
                        classifier_dim1=fc[0], classifier_dim2=fc[1])
     with torch.no_grad():
         for p, q in zip(m.parameters(), params):
@@ -282,7 +283,7 @@ def test_autograd_path_matches_engine_and_golden(golden):
         assert_close(p.grad, torch.from_numpy(g["tiny_ce_mean_g%d" % i]), what="grad %d" % i)
 
 
-@pytest.mark.parametrize("name,N", [("small_VGG9", 200), ("base_VGG9", 32)])
+@pytest.mark.parametrize("name,N", [("small_VGG9", 200), ("base_VGG9", 32), ("wide_VGG9", 8), ("deep_VGG22", 6)])
 def test_engine_full_size_vs_oracle(name, N):
     cfg = vgg_ref.CFGS[name]
     fc = (128, 128) if name == "small_VGG9" else (512, 512)
@@ -309,8 +310,11 @@ def test_engine_full_size_vs_oracle(name, N):
         scale = float(g64.abs().max())
         rows = (g - g64).abs().reshape(g.shape[0], -1).max(1).values / scale
         cpu_rows = (g32.double() - g64).abs().reshape(g.shape[0], -1).max(1).values / scale
-        assert float(rows.max()) <= 1e-2, "grad %d worst row %.3e" % (i, float(rows.max()))
-        assert float(rows.median()) <= max(1e-3, 1.5 * float(cpu_rows.median())), \
+        assert float(rows.max()) <= max(2e-2 if name == "deep_VGG22" else 1e-2, 2.0 * float(cpu_rows.max())), \
+            "grad %d worst row %.3e (cpu fp32: %.3e)" % (i, float(rows.max()), float(cpu_rows.max()))
+        # 22 layers: decision flips accumulate on the way down (conv1 of deep_VGG22: torch-CPU fp32 3.6e-3, device 6.2e-3)
+        slack = 2.0 if name == "deep_VGG22" else 1.5
+        assert float(rows.median()) <= max(1e-3, slack * float(cpu_rows.median())), \
             "grad %d median row err %.3e (cpu fp32: %.3e)" % (i, float(rows.median()), float(cpu_rows.median()))
     # eval-only pass leaves gradients untouched and reproduces the logits bit for bit
     before = eng.arena.grad.clone()
