@@ -47,6 +47,51 @@ __global__ __launch_bounds__(PB) void maxpool2_bwd_kernel(const float* __restric
     }
 }
 
+// General k x k / stride s max-pool without padding (AlexNet's overlapping 3x3 stride 2, torchvision alexnet
+// features[2,5,12]): forward keeps the window position of the first maximum (ATen scan order), backward is a GATHER
+// over the <= ceil(k/s)^2 windows that cover an input pixel (overlapping windows; no atomics => deterministic).
+__global__ __launch_bounds__(PB) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         uint8_t* __restrict__ idx, size_t total, int H, int W, int OH, int OW,
+                                                         int k, int s) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += stride) {
+        const int ow = (int)(o % OW);
+        const size_t t = o / OW;
+        const int oh = (int)(t % OH);
+        const size_t nc = t / OH;
+        const float* p = x + (nc * H + (size_t)oh * s) * W + (size_t)ow * s;
+        float m = p[0]; int a = 0;
+        for (int r = 0; r < k; ++r)
+            for (int c = 0; c < k; ++c) {
+                const float v = p[(size_t)r * W + c];
+                if (v > m || v != v) { m = v; a = r * k + c; }
+            }
+        y[o] = m;
+        idx[o] = (uint8_t)a;
+    }
+}
+
+__global__ __launch_bounds__(PB) void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                                         float* __restrict__ dx, size_t total_in, int H, int W, int OH, int OW,
+                                                         int k, int s) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total_in; e += stride) {
+        const int w = (int)(e % W);
+        const size_t t = e / W;
+        const int h = (int)(t % H);
+        const size_t nc = t / H;
+        const int oh_lo = h - k + 1 > 0 ? (h - k + 1 + s - 1) / s : 0, oh_hi = min(OH - 1, h / s);
+        const int ow_lo = w - k + 1 > 0 ? (w - k + 1 + s - 1) / s : 0, ow_hi = min(OW - 1, w / s);
+        float g = 0.f;
+        for (int oh = oh_lo; oh <= oh_hi; ++oh)
+            for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+                const size_t o = (nc * OH + oh) * OW + ow;
+                if ((int)idx[o] == (h - oh * s) * k + (w - ow * s)) g += dy[o];
+            }
+        dx[e] = g;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -63,6 +108,24 @@ int clhip_maxpool2_bwd(const float* dy, const uint8_t* idx_u8, float* dx, int NC
     if (!dy || !dx || !idx_u8 || NC <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return CLHIP_EINVAL;
     size_t total = (size_t)NC * (H / 2) * (W / 2);
     hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_grid(total, PB)), dim3(PB), 0, as_stream(stream), dy, idx_u8, dx, total, H, W);
+    CLHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+int clhip_maxpool_fwd(const float* x, float* y, uint8_t* idx_u8, int NC, int H, int W, int k, int stride, void* stream) {
+    if (!x || !y || !idx_u8 || NC <= 0 || k < 1 || k > 15 || stride < 1 || H < k || W < k) return CLHIP_EINVAL;
+    const int OH = (H - k) / stride + 1, OW = (W - k) / stride + 1;
+    const size_t total = (size_t)NC * OH * OW;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(total, PB)), dim3(PB), 0, as_stream(stream), x, y, idx_u8, total, H, W, OH, OW, k, stride);
+    CLHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+int clhip_maxpool_bwd(const float* dy, const uint8_t* idx_u8, float* dx, int NC, int H, int W, int k, int stride, void* stream) {
+    if (!dy || !dx || !idx_u8 || NC <= 0 || k < 1 || k > 15 || stride < 1 || H < k || W < k) return CLHIP_EINVAL;
+    const int OH = (H - k) / stride + 1, OW = (W - k) / stride + 1;
+    const size_t total_in = (size_t)NC * H * W;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(total_in, PB)), dim3(PB), 0, as_stream(stream), dy, idx_u8, dx, total_in, H, W, OH, OW, k, stride);
     CLHIP_LAUNCH_CHECK();
     return 0;
 }

@@ -102,7 +102,65 @@ def conv3x3_bwd_weight(x, dy, need_bias=True):
     return dw, db
 
 
+def _out_hw(H, W, R, S, stride, pad):
+    return (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+
+
+def conv2d_fwd(x, w, b, stride=1, pad=0, relu=False):
+    """General convolution (AlexNet layers); the 3x3 pad-1 stride-1 case belongs to conv3x3_fwd."""
+    _chk(x, w, b)
+    N, C, H, W = x.shape
+    K, _, R, S = w.shape
+    OH, OW = _out_hw(H, W, R, S, stride, pad)
+    y = torch.empty((N, K, OH, OW), dtype=torch.float32, device=x.device)
+    check(_lib.lib().clhip_conv2d_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(y), N, C, H, W, K, R, S, int(stride), int(pad), int(relu),
+                                      _stream()), "clhip_conv2d_fwd")
+    return y
+
+
+def conv2d_bwd_data(dy, w, x_shape, stride=1, pad=0, relu_src=None):
+    _chk(dy, w, relu_src)
+    N, C, H, W = x_shape
+    K, _, R, S = w.shape
+    dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device)
+    check(_lib.lib().clhip_conv2d_bwd_data(_ptr(dy), _ptr(w), _ptr(relu_src), _ptr(dx), N, C, H, W, K, R, S, int(stride), int(pad),
+                                           _stream()), "clhip_conv2d_bwd_data")
+    return dx
+
+
+def conv2d_bwd_weight(x, dy, ksize, stride=1, pad=0, need_bias=True):
+    _chk(x, dy)
+    N, C, H, W = x.shape
+    K = dy.shape[1]
+    R, S = ksize
+    L = _lib.lib()
+    ws = workspace(L.clhip_conv2d_bwd_weight_ws(N, C, H, W, K, R, S, int(stride), int(pad)), x.device, "wgrad2d")
+    dw = torch.empty((K, C, R, S), dtype=torch.float32, device=x.device)
+    db = torch.empty((K,), dtype=torch.float32, device=x.device) if need_bias else None
+    check(L.clhip_conv2d_bwd_weight(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), N, C, H, W, K, R, S, int(stride), int(pad), _ptr(ws),
+                                    ws.numel(), _stream()), "clhip_conv2d_bwd_weight")
+    return dw, db
+
+
 # ------------------------------------------------------------------ pooling
+def maxpool_fwd(x, k, stride):
+    _chk(x)
+    N, C, H, W = x.shape
+    OH, OW = (H - k) // stride + 1, (W - k) // stride + 1
+    y = torch.empty((N, C, OH, OW), dtype=torch.float32, device=x.device)
+    idx = torch.empty((N, C, OH, OW), dtype=torch.uint8, device=x.device)
+    check(_lib.lib().clhip_maxpool_fwd(_ptr(x), _ptr(y), _ptr(idx), N * C, H, W, int(k), int(stride), _stream()), "clhip_maxpool_fwd")
+    return y, idx
+
+
+def maxpool_bwd(dy, idx, x_shape, k, stride):
+    _chk(dy, idx)
+    N, C, H, W = x_shape
+    dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device)
+    check(_lib.lib().clhip_maxpool_bwd(_ptr(dy), _ptr(idx), _ptr(dx), N * C, H, W, int(k), int(stride), _stream()), "clhip_maxpool_bwd")
+    return dx
+
+
 def maxpool2_fwd(x):
     _chk(x)
     N, C, H, W = x.shape
@@ -248,6 +306,45 @@ class Conv3x3ReLUFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class Conv2dReLUFn(torch.autograd.Function):
+    """relu?(conv2d(x, w, stride, pad) + b) for the non-3x3 layers (torchvision alexnet features)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, relu):
+        x = x.contiguous()
+        y = conv2d_fwd(x, w.contiguous(), b.contiguous() if b is not None else None, stride, pad, relu)
+        ctx.cfg = (stride, pad, relu, b is not None)
+        ctx.save_for_backward(x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        stride, pad, relu, has_bias = ctx.cfg
+        dy = dy.contiguous()
+        if relu:
+            dy = relu_bwd(dy, y)
+        dx = conv2d_bwd_data(dy, w, tuple(x.shape), stride, pad) if ctx.needs_input_grad[0] else None
+        dw, db = conv2d_bwd_weight(x, dy, tuple(w.shape[2:]), stride, pad, has_bias)
+        return dx, dw, db, None, None, None
+
+
+class MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k, stride):
+        x = x.contiguous()
+        y, idx = maxpool_fwd(x, k, stride)
+        ctx.cfg = (tuple(x.shape), k, stride)
+        ctx.save_for_backward(idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        shape, k, stride = ctx.cfg
+        return maxpool_bwd(dy.contiguous(), idx, shape, k, stride), None, None
+
+
 class MaxPool2Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -301,6 +398,14 @@ def conv3x3_relu(x, w, b, relu=True):
 
 def maxpool2(x):
     return MaxPool2Fn.apply(x)
+
+
+def conv2d_relu(x, w, b, stride=1, pad=0, relu=True):
+    return Conv2dReLUFn.apply(x, w, b, stride, pad, relu)
+
+
+def maxpool(x, k, stride):
+    return MaxPoolFn.apply(x, k, stride)
 
 
 def linear(x, w, b, relu=False):

@@ -69,6 +69,23 @@ int clhip_maxpool2_fwd(const float* x, float* y, uint8_t* idx_u8, int NC, int H,
 int clhip_maxpool2_bwd(const float* dy, const uint8_t* idx_u8, float* dx, int NC, int H, int W,
                        void* stream);
 
+/* General k x k / stride max-pool, no padding (torchvision alexnet features[2,5,12]: MaxPool2d(3, 2), models/net.py:96-125).
+ * idx = window position r*k + c of the first maximum (ATen scan order); backward gathers over the overlapping windows. */
+int clhip_maxpool_fwd(const float* x, float* y, uint8_t* idx_u8, int NC, int H, int W, int k, int stride, void* stream);
+int clhip_maxpool_bwd(const float* dy, const uint8_t* idx_u8, float* dx, int NC, int H, int W, int k, int stride, void* stream);
+
+/* General convolution (AlexNet: Conv2d(3,64,11,4,2), Conv2d(64,192,5,1,2), 3x3 pad 1 with 192/384/256 channels —
+ * models/net.py:96-125 via torchvision.models.alexnet), NCHW / KCRS, zero padding `pad`, stride `stride`:
+ * forward (+bias, optional ReLU), backward-data (optional ReLU mask relu_src > 0), backward-weight (+ db) with
+ * caller-provided workspace of clhip_conv2d_bwd_weight_ws bytes. CLHIP_ENOTSUP if R*S > 256. */
+size_t clhip_conv2d_bwd_weight_ws(int N, int C, int H, int W, int K, int R, int S, int stride, int pad);
+int clhip_conv2d_fwd(const float* x, const float* w, const float* b, float* y, int N, int C, int H, int W, int K, int R, int S,
+                     int stride, int pad, int relu, void* stream);
+int clhip_conv2d_bwd_data(const float* dy, const float* w, const float* relu_src, float* dx, int N, int C, int H, int W, int K,
+                          int R, int S, int stride, int pad, void* stream);
+int clhip_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* db, int N, int C, int H, int W, int K, int R,
+                            int S, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------ fully connected (MFMA fp32)
  * nn.Linear — models/VGGSlim.py:68-74.  x[M][I], w[O][I], b[O], y[M][O].                   */
 /* ws: optional split-K scratch (>= clhip_fc_ws(M,I,O) bytes); NULL => no K split (slower, same result

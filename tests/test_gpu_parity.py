@@ -813,3 +813,61 @@ def test_lwf_loss_kernel_and_engine_golden_g14(golden):
     assert int(stats[1].item()) == int((torch.from_numpy(g["out2"]).argmax(1) == torch.from_numpy(g["y"])).sum())
     for j, (n, p) in enumerate(w.named_parameters()):
         assert_close(p.grad, torch.from_numpy(g["g%d" % j]), tol=1e-3, what="grad " + n)
+
+
+# --------------------------------------------------------------------------- general conv / pool (AlexNet, config 4)
+@pytest.mark.parametrize("shape", [
+    # N, C, H, W, K, R, stride, pad
+    (3, 3, 67, 67, 64, 11, 4, 2),      # alexnet conv1 geometry (224 -> 55) at 67 -> 15
+    (2, 64, 15, 15, 192, 5, 1, 2),     # conv2
+    (2, 192, 7, 7, 384, 3, 1, 1),      # conv3 (3x3, but through the general kernel)
+    (5, 7, 9, 13, 10, 3, 2, 0),        # odd everything, stride 2, no padding
+    (2, 16, 12, 12, 33, 4, 3, 1),
+])
+def test_conv2d_general(shape):
+    import torch.nn.functional as F
+    from clsurvey_amd import ops
+    N, C, H, W, K, R, st, pad = shape
+    gen = np.random.RandomState(sum(shape))
+    x = rnd(gen, N, C, H, W)
+    w = rnd(gen, K, C, R, R, scale=1.0 / np.sqrt(C * R * R))
+    b = rnd(gen, K, scale=0.1)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y_ref = F.relu(F.conv2d(xr, wr, br, stride=st, padding=pad))
+    dy = rnd(gen, *y_ref.shape)
+    y_ref.backward(dy)
+    y = ops.conv2d_fwd(x.to(dev()), w.to(dev()), b.to(dev()), st, pad, relu=True)
+    assert_close(y, y_ref.detach(), what="fwd")
+    dym = (dy * (y_ref.detach() > 0)).contiguous().to(dev())
+    dx = ops.conv2d_bwd_data(dym, w.to(dev()), (N, C, H, W), st, pad)
+    assert_close(dx, xr.grad, what="bwd_data")
+    dxm = ops.conv2d_bwd_data(dym, w.to(dev()), (N, C, H, W), st, pad, relu_src=x.to(dev()))
+    assert_close(dxm, xr.grad * (x > 0), what="bwd_data+mask")
+    dw, db = ops.conv2d_bwd_weight(x.to(dev()), dym, (R, R), st, pad)
+    assert_close(dw, wr.grad, what="bwd_weight")
+    assert_close(db, br.grad, what="bias grad")
+    dw2, _ = ops.conv2d_bwd_weight(x.to(dev()), dym, (R, R), st, pad)
+    assert torch.equal(dw, dw2), "bwd_weight must be run-to-run deterministic"
+
+
+@pytest.mark.parametrize("shape", [(3, 8, 15, 15, 3, 2), (2, 5, 13, 13, 3, 2), (2, 4, 9, 11, 2, 2), (1, 3, 10, 10, 3, 1), (2, 6, 55, 55, 3, 2)])
+def test_maxpool_general(shape):
+    import torch.nn.functional as F
+    from clsurvey_amd import ops
+    N, C, H, W, k, st = shape
+    gen = np.random.RandomState(sum(shape))
+    x = rnd(gen, N, C, H, W)
+    x[0, 0, :4, :4] = 0.5                        # ties: the first maximum in scan order must win
+    xr = x.clone().requires_grad_(True)
+    y_ref, i_ref = F.max_pool2d(xr, k, st, return_indices=True)
+    dy = rnd(gen, *y_ref.shape)
+    y_ref.backward(dy)
+    y, idx = ops.maxpool_fwd(x.to(dev()), k, st)
+    assert torch.equal(y.cpu(), y_ref.detach())
+    OH, OW = y_ref.shape[2:]
+    oh = torch.arange(OH).view(1, 1, OH, 1) * st
+    ow = torch.arange(OW).view(1, 1, 1, OW) * st
+    flat = (oh + idx.cpu().long() // k) * W + ow + idx.cpu().long() % k
+    assert torch.equal(flat, i_ref), "argmax positions differ from ATen"
+    dx = ops.maxpool_bwd(dy.to(dev()), idx, (N, C, H, W), k, st)
+    assert_close(dx, xr.grad, tol=1e-6, what="pool bwd")
