@@ -17,10 +17,16 @@ struct LayerPlan {
     int cin, cout, relu, pool;
     long w_off, b_off;     // float offsets into the parameter / gradient arenas
     int h, w;              // conv: input spatial size
+    int ks, st, pd;        // conv kernel / stride / pad (3,1,1 = the conv3x3.hip fast path)
+    int oh, ow;            // conv output size
+    int pk, ps;            // pool window / stride (2,2 = pool.hip's 2-bit fast path)
+    int ph, pw;            // pooled size
     size_t in_elems, out_elems, pool_elems;   // per image
     size_t act_off;        // float offset of this layer's OUTPUT (post-ReLU, pre-pool) in ws
     size_t pool_off;       // float offset of pooled output
     size_t idx_off;        // byte offset of pool argmax
+    const float* drop;     // dropout mask applied to this layer's INPUT (NULL = none); see clhip_net_set_dropout
+    long drop_stride;      // floats between the mask rows of consecutive samples (0 = one row shared by the batch)
 };
 
 struct NetPlan {
@@ -41,6 +47,22 @@ struct NetPlan {
 };
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// h[n][f] *= mask[n * stride + f]: nn.Dropout in training mode with a caller-drawn mask (already divided by the
+// retain probability), or GEM's one-row-per-observe masks (stride 0).  HBM-bound, in place.
+__global__ void drop_scale_kernel(float* __restrict__ h, const float* __restrict__ mask, long stride, int feat, size_t total) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t n = i / feat, f = i - n * feat;
+        h[i] *= mask[n * stride + f];
+    }
+}
+
+int drop_scale(float* h, const float* mask, long stride, size_t feat, int N, hipStream_t s) {
+    const size_t total = feat * N;
+    hipLaunchKernelGGL(drop_scale_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, s, h, mask, stride, (int)feat, total);
+    CLHIP_LAUNCH_CHECK();
+    return 0;
+}
 
 }  // namespace
 
@@ -64,19 +86,34 @@ int clhip_net_create(const clhip_layer_desc* descs, int n_layers, int max_batch,
         if (L.type == 0) {
             if (seen_fc || L.cin != c) { delete p; return CLHIP_EINVAL; }
             L.h = h; L.w = w;
+            L.ks = descs[i].ksize > 0 ? descs[i].ksize : 3;
+            L.st = descs[i].ksize > 0 ? descs[i].stride : 1;
+            L.pd = descs[i].ksize > 0 ? descs[i].pad : 1;
+            if (L.st < 1 || L.pd < 0) { delete p; return CLHIP_EINVAL; }
+            L.oh = (h + 2 * L.pd - L.ks) / L.st + 1; L.ow = (w + 2 * L.pd - L.ks) / L.st + 1;
+            if (L.oh <= 0 || L.ow <= 0) { delete p; return CLHIP_EINVAL; }
+            const bool vgg = L.ks == 3 && L.st == 1 && L.pd == 1;
             L.in_elems = (size_t)c * h * w;
-            L.out_elems = (size_t)L.cout * h * w;
+            L.out_elems = (size_t)L.cout * L.oh * L.ow;
             L.act_off = acts; acts += L.out_elems * max_batch;
+            int oh = L.oh, ow = L.ow;
             if (L.pool) {
-                if ((h & 1) || (w & 1)) { delete p; return CLHIP_EINVAL; }
-                L.pool_elems = L.out_elems / 4;
+                L.pk = descs[i].pool_k > 0 ? descs[i].pool_k : 2;
+                L.ps = descs[i].pool_k > 0 ? descs[i].pool_s : 2;
+                if (L.ps < 1 || oh < L.pk || ow < L.pk) { delete p; return CLHIP_EINVAL; }
+                if (L.pk == 2 && L.ps == 2 && ((oh & 1) || (ow & 1))) { delete p; return CLHIP_EINVAL; }
+                L.ph = (oh - L.pk) / L.ps + 1; L.pw = (ow - L.pk) / L.ps + 1;
+                L.pool_elems = (size_t)L.cout * L.ph * L.pw;
                 L.pool_off = acts; acts += L.pool_elems * max_batch;
                 L.idx_off = idxb; idxb += align_up(L.pool_elems * max_batch, 256);
-                h /= 2; w /= 2;
+                oh = L.ph; ow = L.pw;
             }
-            size_t s = clhip_conv3x3_bwd_weight_ws(max_batch, L.cin, L.cout, L.h, L.w);
+            size_t s = vgg ? clhip_conv3x3_bwd_weight_ws(max_batch, L.cin, L.cout, L.h, L.w)
+                           : clhip_conv2d_bwd_weight_ws(max_batch, L.cin, L.h, L.w, L.cout, L.ks, L.ks, L.st, L.pd);
             if (s > scratch) scratch = s;
             if (L.out_elems > gmax) gmax = L.out_elems;
+            if (L.in_elems > gmax) gmax = L.in_elems;
+            h = oh; w = ow;
             c = L.cout;
             feat = (size_t)c * h * w;
         } else if (L.type == 1) {
@@ -129,6 +166,17 @@ int clhip_net_create(const clhip_layer_desc* descs, int n_layers, int max_batch,
     return 0;
 }
 
+// Dropout in front of layer `layer` (> 0): mask is device memory, [N][in_elems] with row_stride floats between samples
+// (row_stride 0: one row for the whole batch), values 0 or 1/p_retain.  NULL switches it off (eval mode).  The mask must
+// stay valid and unchanged from a forward to its backward.
+int clhip_net_set_dropout(void* handle, int layer, const float* mask, long row_stride) {
+    NetPlan* p = static_cast<NetPlan*>(handle);
+    if (!p || layer <= 0 || layer >= (int)p->layers.size() || row_stride < 0) return CLHIP_EINVAL;
+    p->layers[layer].drop = mask;
+    p->layers[layer].drop_stride = row_stride;
+    return 0;
+}
+
 void clhip_net_destroy(void* handle) { delete static_cast<NetPlan*>(handle); }
 
 size_t clhip_net_workspace_bytes(void* handle) { return handle ? static_cast<NetPlan*>(handle)->total_bytes : 0; }
@@ -149,7 +197,26 @@ int clhip_net_forward(void* handle, const float* params, const float* x, int N, 
     for (size_t li = 0; li < p->layers.size(); ++li) {
         const LayerPlan& L = p->layers[li];
         float* y = acts + L.act_off;
-        if (L.type == 0) {
+        if (L.drop) {       // li > 0: cur is the previous layer's saved output; masked in place so that backward sees h * m
+            rc = drop_scale(const_cast<float*>(cur), L.drop, L.drop_stride, L.in_elems, N, as_stream(stream));
+            if (rc) return rc;
+        }
+        const bool vgg = L.type == 0 && L.ks == 3 && L.st == 1 && L.pd == 1;
+        const bool pool22 = L.pool && L.pk == 2 && L.ps == 2;
+        if (L.type == 0 && !(vgg && (!L.pool || pool22))) {
+            // general geometry (AlexNet): separate conv (+bias, ReLU) and k x k / stride pool kernels
+            rc = vgg ? clhip_conv3x3_fwd(cur, params + L.w_off, params + L.b_off, y, N, L.cin, L.cout, L.h, L.w, L.relu, stream)
+                     : clhip_conv2d_fwd(cur, params + L.w_off, params + L.b_off, y, N, L.cin, L.h, L.w, L.cout, L.ks, L.ks, L.st,
+                                        L.pd, L.relu, stream);
+            if (rc) return rc;
+            cur = y;
+            if (L.pool) {
+                float* pl = acts + L.pool_off;
+                rc = clhip_maxpool_fwd(y, pl, idx + L.idx_off, N * L.cout, L.oh, L.ow, L.pk, L.ps, stream);
+                if (rc) return rc;
+                cur = pl;
+            }
+        } else if (L.type == 0) {
             if (L.pool && L.relu) {
                 // conv + bias + ReLU + max-pool in one kernel; the pre-pool tensor is never materialised
                 float* pl = acts + L.pool_off;
@@ -221,11 +288,42 @@ int clhip_net_backward(void* handle, const float* params, float* grads, const fl
                 rc = clhip_fc_bwd_data(gin, params + L.w_off, xin, gout, N, L.cin, L.cout, scratch, p->scratch_bytes, stream);
                 if (rc) return rc;
                 gin = gout;
+                if (L.drop) {
+                    rc = drop_scale(gout, L.drop, L.drop_stride, L.in_elems, N, as_stream(stream));
+                    if (rc) return rc;
+                }
             }
             if (p->fc_fused && i == p->fc_first) {
                 // all dz_l are in place: dW_l, db_l of every Linear layer in one launch
                 rc = clhip_internal_fc_chain_wgrad(&p->chain, grads, xin, N, acts, dlogits, fcdz, as_stream(stream));
                 if (rc) return rc;
+            }
+        } else if (!(L.ks == 3 && L.st == 1 && L.pd == 1 && (!L.pool || (L.pk == 2 && L.ps == 2)))) {
+            // general geometry (AlexNet)
+            const bool vgg = L.ks == 3 && L.st == 1 && L.pd == 1;
+            const float* gy = gin;
+            if (L.pool) {
+                float* gout = g[flip]; flip ^= 1;
+                rc = clhip_maxpool_bwd(gin, idx + L.idx_off, gout, N * L.cout, L.oh, L.ow, L.pk, L.ps, stream);
+                if (rc) return rc;
+                gy = gout;
+            }
+            rc = vgg ? clhip_conv3x3_bwd_weight(xin, gy, grads + L.w_off, grads + L.b_off, N, L.cin, L.cout, L.h, L.w, scratch,
+                                                p->scratch_bytes, stream)
+                     : clhip_conv2d_bwd_weight(xin, gy, grads + L.w_off, grads + L.b_off, N, L.cin, L.h, L.w, L.cout, L.ks, L.ks,
+                                               L.st, L.pd, scratch, p->scratch_bytes, stream);
+            if (rc) return rc;
+            if (i > 0) {
+                float* gout = g[flip]; flip ^= 1;
+                rc = vgg ? clhip_conv3x3_bwd_data(gy, params + L.w_off, xin, gout, N, L.cin, L.cout, L.h, L.w, stream)
+                         : clhip_conv2d_bwd_data(gy, params + L.w_off, xin, gout, N, L.cin, L.h, L.w, L.cout, L.ks, L.ks, L.st, L.pd,
+                                                 stream);
+                if (rc) return rc;
+                gin = gout;
+                if (L.drop) {
+                    rc = drop_scale(gout, L.drop, L.drop_stride, L.in_elems, N, as_stream(stream));
+                    if (rc) return rc;
+                }
             }
         } else {
             const float* gy = gin;
@@ -254,6 +352,10 @@ int clhip_net_backward(void* handle, const float* params, float* grads, const fl
                 rc = clhip_conv3x3_bwd_data(gy, params + L.w_off, xin, gout, N, L.cin, L.cout, L.h, L.w, stream);
                 if (rc) return rc;
                 gin = gout;
+                if (L.drop) {
+                    rc = drop_scale(gout, L.drop, L.drop_stride, L.in_elems, N, as_stream(stream));
+                    if (rc) return rc;
+                }
             }
         }
     }

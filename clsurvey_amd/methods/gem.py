@@ -65,6 +65,8 @@ class GemNet:
 
     def _bind(self):
         self.engine = NetEngine(self.net, max(self.batch_size, 1), self.in_shape, self.device)
+        self.engine.auto_dropout = False        # Dropout masks are GEM's own (below), not nn.Dropout's
+        self.dropout_masks = {}
         self.A = self.engine.arena
         self.G = torch.zeros((self.n_tasks, self.A.numel), dtype=torch.float32, device=self.device)   # gem.py:131
         L = _lib.lib()
@@ -76,10 +78,29 @@ class GemNet:
         """gem.py:146-155: fresh SGD(momentum 0.9) and margin; called after construction and after torch.load."""
         if args is not None:
             lr, weight_decay, memory_strength = args.lr, args.weight_decay, args.memory_strength
-        self.opt = SGD(self.net.parameters(), lr, momentum=0.9, weight_decay=weight_decay)       # gem.py:151
+        self.dropout_masks = {}                                                                   # gem.py:152
+        self.opt = SGD(self.net.parameters(), lr, momentum=0.9, weight_decay=weight_decay)       # gem.py:153
         self.margin = memory_strength
 
-    _TRANSIENT = ("engine", "A", "G", "_gram_ws", "_gram", "stats", "opt")
+    # ------------------------------------------------------------------ gem.py:166-196 (manual dropout)
+    def reset_dropout_config(self):
+        self.dropout_masks = {}
+
+    def _dropout(self, train, p_retain_unit=0.5):
+        """Training mode: every Dropout of the plan multiplies its input by ONE mask row Bernoulli(p_retain)/p_retain of a
+        single sample's shape, drawn when first needed after a reset and shared by all samples and passes until the next
+        reset (gem.py:180-191; p_retain is the fixed 0.5 of the reference's signature, not module.p).  Eval: identity."""
+        for li in self.engine.drops:
+            if not train:
+                self.engine.set_dropout(li, None)
+                continue
+            if li not in self.dropout_masks:
+                n = self.engine.in_elems[li]
+                self.dropout_masks[li] = torch.full((n,), p_retain_unit, dtype=torch.float32,
+                                                    device=self.device).bernoulli_().div_(p_retain_unit)
+            self.engine.set_dropout(li, self.dropout_masks[li])
+
+    _TRANSIENT = ("engine", "A", "G", "_gram_ws", "_gram", "stats", "opt", "dropout_masks")
 
     def __getstate__(self):
         return {k: v for k, v in self.__dict__.items() if k not in self._TRANSIENT}
@@ -155,6 +176,8 @@ class GemNet:
         if t != self.old_task:
             self.init_new_task(t)
         self.fill_buffer(t, x, y)
+        self.reset_dropout_config()                                   # gem.py:214-215: net.train(); fresh masks per observe
+        self._dropout(True)
         if len(self.observed_tasks) > 1:
             for past in self.observed_tasks[:-1]:
                 sl = compute_offsets(past, self.cum_nc_per_task)
@@ -186,6 +209,7 @@ class GemNet:
         """gem.py:289-309: plain SGD step on the task's output slice (phase-1 grid; no memory)."""
         sl = compute_offsets(t, self.cum_nc_per_task)
         self.stats.zero_()
+        self._dropout(True)       # no reset here: the masks drawn after init_setup stay for the whole run, as in the reference
         loss, _ = self.engine.loss_step(x, y, "ce_mean", True, self.stats, class_slice=sl)
         self.opt.step()
         return loss, self.stats[1]
@@ -193,6 +217,7 @@ class GemNet:
     def eval_batch(self, x, y, t, stats):
         """main_rehearsal.py:18-35: CE and hits on the task slice (accumulated into stats on the device)."""
         sl = compute_offsets(t, self.cum_nc_per_task)
+        self._dropout(False)
         return self.engine.loss_step(x, y, "ce_mean", False, stats, class_slice=sl)[0]
 
     def __call__(self, x, t, **kw):
@@ -200,6 +225,7 @@ class GemNet:
 
     def forward(self, x, t):
         """gem.py:169-204 (eval): logits with everything outside the task slice at -1e11."""
+        self._dropout(False)
         logits = self.engine.forward(x)
         o1, o2 = compute_offsets(t, self.cum_nc_per_task)
         out = torch.full_like(logits, -10e10)

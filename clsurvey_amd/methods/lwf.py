@@ -70,15 +70,16 @@ class AlexNet_LwF(nn.Module):
 def lwf_plan(wrapper):
     """(layers, params, head_sizes) for NetEngine: conv / shared Linear layers as they are, all heads as ONE Linear whose
     rows are the heads' rows back to back (arena order: ..., head weights, head biases)."""
-    from ..net import parse_vgg
+    from ..net import parse_net, conv_geometry
     m = wrapper.model
     cls = list(m.classifier.children())
     shared = nn.Module()
     shared.features = m.features
     shared.classifier = nn.Sequential(*cls[:wrapper.last_layer_name])
-    base = parse_vgg(shared)
+    base, drops = parse_net(shared)
     layers = [(kind, mod.weight, mod.bias, mod.in_channels if kind == "conv" else mod.in_features,
-               mod.out_channels if kind == "conv" else mod.out_features, relu, pool) for kind, mod, relu, pool in base]
+               mod.out_channels if kind == "conv" else mod.out_features, relu, pool) +
+              ((conv_geometry(mod),) if kind == "conv" else ()) for kind, mod, relu, pool in base]
     heads = cls[wrapper.last_layer_name:]
     if not heads or any(not isinstance(h, nn.Linear) for h in heads):
         raise NotImplementedError("LwF: the modules from last_layer_name on must be Linear heads")
@@ -89,15 +90,15 @@ def lwf_plan(wrapper):
     sizes = [h.out_features for h in heads]
     layers.append(("fc", heads[0].weight, heads[0].bias, feat, sum(sizes), False, False))
     params = [p for _, w, b, *_ in layers[:-1] for p in (w, b)] + [h.weight for h in heads] + [h.bias for h in heads]
-    return layers, params, sizes
+    return layers, params, sizes, drops
 
 
 class LwfEngine:
     """forward of all heads + LwF loss + backward for one batch."""
 
     def __init__(self, wrapper, max_batch, in_shape, device="cuda"):
-        layers, params, self.sizes = lwf_plan(wrapper)
-        self.engine = NetEngine(wrapper, max_batch, in_shape, device, layers=layers, params=params)
+        layers, params, self.sizes, drops = lwf_plan(wrapper)
+        self.engine = NetEngine(wrapper, max_batch, in_shape, device, layers=layers, params=params, drops=drops)
         self.device = self.engine.device
         self.n_out = sum(self.sizes)
         self._sizes = (C.c_int * len(self.sizes))(*self.sizes)

@@ -92,27 +92,41 @@ class ParamArena:
         self.grad.zero_()
 
 
-def parse_vgg(model):
-    """[(kind, module, relu, pool)] from a VGGSlim-structured module. Raises on anything the
-    static plan does not cover (BatchNorm / Dropout variants are SURVEY §8f 'next')."""
-    layers = []
+def _pair(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+
+
+def parse_net(model):
+    """([(kind, module, relu, pool)], {plan index: nn.Dropout in front of that layer}) from a module with the
+    features / classifier structure of models/VGGSlim.py:27-76 or of torchvision's AlexNet (models/net.py:96-125).
+    pool is False, True (2x2 stride 2) or (k, stride).  Raises on anything the static plan does not cover (BatchNorm
+    variants are SURVEY §8f 'next')."""
+    layers, drops = [], {}
     feats = list(model.features.children())
     i = 0
+    pending = None
     while i < len(feats):
         m = feats[i]
-        if isinstance(m, nn.Conv2d):
-            if m.kernel_size != (3, 3) or m.padding != (1, 1) or m.stride != (1, 1) or m.groups != 1:
-                raise NotImplementedError("NetEngine: only 3x3 pad-1 stride-1 convolutions")
+        if isinstance(m, nn.Dropout):
+            pending = m
+            i += 1
+        elif isinstance(m, nn.Conv2d):
+            ks, st, pd = _pair(m.kernel_size), _pair(m.stride), _pair(m.padding)
+            if ks[0] != ks[1] or st[0] != st[1] or pd[0] != pd[1] or m.groups != 1 or _pair(m.dilation) != (1, 1):
+                raise NotImplementedError("NetEngine: square kernels, symmetric stride / padding, no groups / dilation")
             relu = i + 1 < len(feats) and isinstance(feats[i + 1], nn.ReLU)
             j = i + (2 if relu else 1)
-            pool = j < len(feats) and isinstance(feats[j], nn.MaxPool2d)
-            if pool:
+            pool = False
+            if j < len(feats) and isinstance(feats[j], nn.MaxPool2d):
                 mp = feats[j]
-                ks = mp.kernel_size if isinstance(mp.kernel_size, tuple) else (mp.kernel_size,) * 2
-                st = mp.stride if isinstance(mp.stride, tuple) else (mp.stride,) * 2
-                if ks != (2, 2) or st != (2, 2):
-                    raise NotImplementedError("NetEngine: only 2x2 stride-2 max-pool")
+                pk, ps = _pair(mp.kernel_size), _pair(mp.stride if mp.stride is not None else mp.kernel_size)
+                if pk[0] != pk[1] or ps[0] != ps[1] or _pair(mp.padding) != (0, 0) or mp.ceil_mode or _pair(mp.dilation) != (1, 1):
+                    raise NotImplementedError("NetEngine: square un-padded floor-mode max-pool only")
+                pool = True if (pk[0], ps[0]) == (2, 2) else (pk[0], ps[0])
                 j += 1
+            if pending is not None:
+                drops[len(layers)] = pending
+                pending = None
             layers.append(("conv", m, relu, pool))
             i = j
         else:
@@ -121,39 +135,65 @@ def parse_vgg(model):
     i = 0
     while i < len(cls):
         m = cls[i]
-        if isinstance(m, nn.Linear):
+        if isinstance(m, nn.Dropout):
+            pending = m
+            i += 1
+        elif isinstance(m, nn.Linear):
             relu = i + 1 < len(cls) and isinstance(cls[i + 1], nn.ReLU)
+            if pending is not None:
+                drops[len(layers)] = pending
+                pending = None
             layers.append(("fc", m, relu, False))
             i += 2 if relu else 1
         else:
             raise NotImplementedError("NetEngine: unsupported classifier module %r" % (m,))
-    return layers
+    if pending is not None or 0 in drops:
+        raise NotImplementedError("NetEngine: Dropout must sit in front of a layer other than the first")
+    return layers, drops
+
+
+def parse_vgg(model):
+    """The plan layers only (see parse_net)."""
+    return parse_net(model)[0]
+
+
+def conv_geometry(m):
+    """(ksize, stride, pad) of a Conv2d accepted by parse_net."""
+    return _pair(m.kernel_size)[0], _pair(m.stride)[0], _pair(m.padding)[0]
 
 
 class NetEngine:
     LOSS = {"ce_mean": 0, "ce_sum": 1, "mse_sum_zero": 2}
 
-    def __init__(self, model, max_batch, in_shape, device="cuda", layers=None, params=None):
+    def __init__(self, model, max_batch, in_shape, device="cuda", layers=None, params=None, drops=None):
         """layers / params (optional): an explicit plan [(kind, weight, bias, cin, cout, relu, pool)] and the parameter
         order of the arena, for models whose module tree is not plain VGGSlim (e.g. LwF's stacked heads run as ONE
         Linear over head parameters laid out back to back)."""
         self.model = model
         self.device = torch.device(device)
+        self.drops = {}
         if layers is None:
-            self.layers = parse_vgg(model)
+            self.layers, self.drops = parse_net(model)
             specs = [(kind, m.weight, m.bias, m.in_channels if kind == "conv" else m.in_features,
-                      m.out_channels if kind == "conv" else m.out_features, relu, pool) for kind, m, relu, pool in self.layers]
+                      m.out_channels if kind == "conv" else m.out_features, relu, pool) +
+                     ((conv_geometry(m),) if kind == "conv" else ()) for kind, m, relu, pool in self.layers]
         else:
             specs = list(layers)
             self.layers = specs
-        if any(b is None for _, _, b, _, _, _, _ in specs):
+            self.drops = dict(drops or {})
+        if any(sp[2] is None for sp in specs):
             raise NotImplementedError("NetEngine: layers without bias")
         self.arena = ParamArena(list(model.parameters()) if params is None else list(params), self.device)
         descs = (LayerDesc * len(specs))()
-        for d, (kind, w, b, cin, cout, relu, pool) in zip(descs, specs):
+        for d, sp in zip(descs, specs):
+            kind, w, b, cin, cout, relu, pool = sp[:7]
             d.type = 0 if kind == "conv" else 1
             d.cin, d.cout = int(cin), int(cout)
-            d.relu, d.pool = int(relu), int(pool)
+            d.relu, d.pool = int(relu), int(bool(pool))
+            if isinstance(pool, tuple):
+                d.pool_k, d.pool_s = int(pool[0]), int(pool[1])
+            if kind == "conv":
+                d.ksize, d.stride, d.pad = (int(v) for v in (sp[7] if len(sp) > 7 else (w.shape[2], 1, w.shape[2] // 2)))
             d.w_off = self.arena.slot(w)[0]
             d.b_off = self.arena.slot(b)[0]
         self.max_batch = int(max_batch)
@@ -166,6 +206,51 @@ class NetEngine:
         self.n_classes = L.clhip_net_num_classes(h)
         self.ws = torch.empty(L.clhip_net_workspace_bytes(h), dtype=torch.uint8, device=self.device)
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.in_elems = {}
+        shp = self.in_shape
+        if self.drops:
+            with torch.no_grad():       # input width of every layer with a Dropout in front (shape arithmetic only)
+                c, h, w = shp
+                for li, sp in enumerate(specs):
+                    self.in_elems[li] = c * h * w
+                    if sp[0] == "conv":
+                        ks, st, pd = sp[7] if len(sp) > 7 else (3, 1, 1)
+                        c, h, w = sp[4], (h + 2 * pd - ks) // st + 1, (w + 2 * pd - ks) // st + 1
+                        if sp[6]:
+                            pk, ps = sp[6] if isinstance(sp[6], tuple) else (2, 2)
+                            h, w = (h - pk) // ps + 1, (w - pk) // ps + 1
+                    else:
+                        c, h, w = sp[4], 1, 1
+        self.auto_dropout = True     # loss_step / forward draw nn.Dropout masks themselves while model.training
+        self._masks = {}
+
+    def set_dropout(self, layer, mask):
+        """mask: None (off), [in_elems] (one row for the whole batch: GEM) or [N][in_elems] device fp32, values 0 or
+        1/p_retain, multiplying the input of plan layer `layer`.  Stays in force until changed."""
+        if mask is None:
+            self._masks.pop(layer, None)
+            ptr, stride = None, 0
+        else:
+            if not mask.is_cuda or mask.dtype != torch.float32 or not mask.is_contiguous():
+                raise RuntimeError("dropout masks are contiguous fp32 HIP tensors")
+            if mask.shape[-1] != self.in_elems[layer] or (mask.dim() == 2 and mask.shape[0] < 1):
+                raise RuntimeError("dropout mask shape %s does not fit layer %d" % (tuple(mask.shape), layer))
+            self._masks[layer] = mask
+            ptr, stride = mask.data_ptr(), (mask.shape[-1] if mask.dim() == 2 else 0)
+        check(_lib.lib().clhip_net_set_dropout(self._h, int(layer), ptr, int(stride)), "clhip_net_set_dropout")
+
+    def _auto_drop(self, n):
+        """nn.Dropout semantics (fresh Bernoulli(1-p)/(1-p) mask per element per pass while model.training, identity in
+        eval mode) for the Dropout modules of the plan; drawn with torch's device generator."""
+        if not self.drops or not self.auto_dropout:
+            return
+        for li, m in self.drops.items():
+            if self.model.training and m.p > 0:
+                keep = 1.0 - m.p
+                mask = torch.empty((n, self.in_elems[li]), dtype=torch.float32, device=self.device).bernoulli_(keep).div_(keep)
+                self.set_dropout(li, mask)
+            elif li in self._masks:
+                self.set_dropout(li, None)
 
     def __del__(self):
         try:
@@ -183,6 +268,7 @@ class NetEngine:
 
     def forward(self, x, params=None):
         self._check_x(x)
+        self._auto_drop(x.shape[0])
         logits = torch.empty((x.shape[0], self.n_classes), dtype=torch.float32, device=self.device)
         check(_lib.lib().clhip_net_forward(self._h, (params if params is not None else self.arena.theta).data_ptr(),
                                            x.data_ptr(), x.shape[0],
@@ -202,6 +288,7 @@ class NetEngine:
         """forward + loss (+ backward into arena.grad). Returns (loss[1] device tensor, logits|None).
         No host synchronisation happens here."""
         self._check_x(x)
+        self._auto_drop(x.shape[0])
         logits = torch.empty((x.shape[0], self.n_classes), dtype=torch.float32, device=self.device) if want_logits else None
         o1, nc = (class_slice[0], class_slice[1] - class_slice[0]) if class_slice is not None else (0, 0)
         check(_lib.lib().clhip_net_loss_step_slice(

@@ -214,12 +214,19 @@ int clhip_clamp(float* x, size_t n, float lo, float hi, void* stream);
 typedef struct {
     int type;            /* 0: conv3x3 pad 1 (+ReLU) (+2x2 max-pool)   1: Linear (+ReLU) */
     int cin, cout;       /* channels (conv) or in/out features (fc) */
-    int relu, pool;
+    int relu, pool;      /* pool: 0 none, 1 = a max-pool follows (pool_k x pool_k, stride pool_s; 0/0 means 2x2 stride 2) */
     long w_off, b_off;
+    int ksize, stride, pad;   /* conv geometry; ksize 0 means the VGG default 3x3, stride 1, pad 1 */
+    int pool_k, pool_s;
 } clhip_layer_desc;
 
 int clhip_net_create(const clhip_layer_desc* layers, int n_layers, int max_batch, int in_c, int in_h,
                      int in_w, void** out_handle);
+/* nn.Dropout of the AlexNet classifier (torchvision alexnet: classifier[0], [3]) in training mode, and GEM's per-observe
+ * masks (methods/rehearsal/GEM/gem.py:166-196): the mask (values 0 or 1/p_retain, drawn by the caller) multiplies the
+ * INPUT of plan layer `layer` (> 0) in forward and the gradient w.r.t. it in backward.  mask [N][in_elems] with
+ * row_stride floats between samples, row_stride 0 = one row for the whole batch; NULL = off (eval mode). */
+int clhip_net_set_dropout(void* handle, int layer, const float* mask, long row_stride);
 void clhip_net_destroy(void* handle);
 size_t clhip_net_workspace_bytes(void* handle);
 int clhip_net_num_classes(void* handle);

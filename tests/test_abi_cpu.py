@@ -70,3 +70,25 @@ def test_plan_shapes_on_cpu():
     # wrong input feature count is rejected
     descs[6].cin = 1234
     assert lib.clhip_net_create(descs, len(layers), 200, 3, 64, 64, C.byref(h)) == -1
+
+
+def test_parse_alexnet_plan_on_cpu():
+    """torchvision-shaped AlexNet: geometry and the Dropout positions of the static plan; the oracle restatement agrees
+    with the nn.Sequential modules themselves in eval mode."""
+    import torch
+    from clsurvey_amd import models, net
+    from oracle import alexnet_ref
+    m = models.AlexNet(num_classes=10, widths=(8, 12, 16, 16, 8), fc=32, feat_hw=1)
+    layers, drops = net.parse_net(m)
+    assert [(k, p) for k, _, _, p in layers] == [("conv", (3, 2)), ("conv", (3, 2)), ("conv", False), ("conv", False),
+                                                ("conv", (3, 2)), ("fc", False), ("fc", False), ("fc", False)]
+    assert [net.conv_geometry(mod) for k, mod, _, _ in layers if k == "conv"] == [(11, 4, 2), (5, 1, 2), (3, 1, 1), (3, 1, 1), (3, 1, 1)]
+    assert sorted(drops) == [5, 6]
+    full = models.parse_model_name("alexnet_pretrained_imgnet", num_classes=None)
+    assert full.classifier[6].out_features == 1000 and full.classifier[1].in_features == 9216
+    x = torch.randn(2, 3, 67, 67)
+    m.eval()
+    with torch.no_grad():
+        want = m.classifier(torch.flatten(m.features(x), 1))
+        got = alexnet_ref.forward(m, x)
+    assert torch.allclose(got, want, atol=1e-6)

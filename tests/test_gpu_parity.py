@@ -871,3 +871,181 @@ def test_maxpool_general(shape):
     assert torch.equal(flat, i_ref), "argmax positions differ from ATen"
     dx = ops.maxpool_bwd(dy.to(dev()), idx, (N, C, H, W), k, st)
     assert_close(dx, xr.grad, tol=1e-6, what="pool bwd")
+
+
+# ---------------------------------------------------------------------------------------------- AlexNet (config 4)
+def _small_alexnet(ncls=10, seed=0):
+    import copy
+    from clsurvey_amd import models
+    torch.manual_seed(seed)
+    m = models.AlexNet(num_classes=ncls, widths=(16, 24, 32, 32, 16), fc=64, feat_hw=1)
+    with torch.no_grad():
+        for p in m.parameters():       # default torch init is tiny for these widths: make every layer matter
+            if p.dim() > 1:
+                torch.nn.init.kaiming_normal_(p, nonlinearity="relu")
+            else:
+                p.uniform_(-0.1, 0.1)
+    return m, copy.deepcopy(m)
+
+
+def _flip_aware_grads(eng, model, grads_ref, what, tol=2e-3):
+    """Per-tensor max-abs error relative to the tensor's max magnitude; a handful of ReLU / max-pool decisions may flip
+    between two fp32 summation orders, which moves single rows by ~1e-2 (see test_engine_full_size_vs_oracle)."""
+    worst = 0.0
+    for (name, p), g in zip(model.named_parameters(), grads_ref):
+        got = eng.arena.view("grad", p).cpu()
+        e = rel_err(got, g)
+        worst = max(worst, e)
+        assert e <= tol, "%s: grad %s rel err %.3e" % (what, name, e)
+    return worst
+
+
+@pytest.mark.parametrize("mode", ["eval", "per_sample", "shared_row"])
+def test_engine_alexnet_small_vs_oracle(mode):
+    """AlexNet-structured plan (11x11/4 conv, 5x5 conv, 3x3 convs, 3x3/2 max-pools, Dropout-Linear classifier) through
+    the static-plan executor vs torch CPU with the same dropout masks."""
+    from oracle import alexnet_ref
+    from clsurvey_amd.net import NetEngine
+    model, ref = _small_alexnet()
+    N = 6
+    gen = np.random.default_rng(5)
+    x = rnd(gen, N, 3, 67, 67)
+    y = torch.from_numpy(gen.integers(0, 10, N))
+    eng = NetEngine(model, N, (3, 67, 67), dev())
+    assert sorted(eng.drops) == [5, 6] and eng.in_elems[5] == 16 and eng.in_elems[6] == 64
+    eng.auto_dropout = False
+    masks = None
+    if mode != "eval":
+        rows = N if mode == "per_sample" else 1
+        m0 = torch.from_numpy((gen.random((rows, 16)) < 0.5).astype(np.float32) * 2)
+        m1 = torch.from_numpy((gen.random((rows, 64)) < 0.5).astype(np.float32) * 2)
+        masks = {0: m0, 1: m1}
+        d0, d1 = m0.to(dev()), m1.to(dev())
+        if mode == "shared_row":
+            d0, d1 = d0[0].contiguous(), d1[0].contiguous()
+        eng.set_dropout(5, d0)
+        eng.set_dropout(6, d1)
+    loss, logits = eng.loss_step(x.to(dev()), y.to(dev()), "ce_mean", True, want_logits=True)
+    rl, rlog, rg = alexnet_ref.loss_and_grads(ref, x, y, masks)
+    assert_close(logits.cpu(), rlog, what="logits")
+    assert abs(float(loss) - float(rl)) <= 2e-4 * max(1.0, abs(float(rl)))
+    _flip_aware_grads(eng, model, rg, mode)
+    # switching the masks off again gives the eval-mode logits
+    eng.set_dropout(5, None)
+    eng.set_dropout(6, None)
+    assert_close(eng.forward(x.to(dev())).cpu(), alexnet_ref.forward(ref, x).detach(), what="eval logits")
+
+
+def test_engine_auto_dropout_follows_module_mode():
+    """nn.Dropout semantics of the executor: fresh masks while model.training, identity in eval mode."""
+    from oracle import alexnet_ref
+    from clsurvey_amd.net import NetEngine
+    model, ref = _small_alexnet(seed=3)
+    N = 4
+    x = rnd(np.random.default_rng(2), N, 3, 67, 67)
+    eng = NetEngine(model, N, (3, 67, 67), dev())
+    model.eval()
+    a = eng.forward(x.to(dev())).cpu()
+    assert_close(a, alexnet_ref.forward(ref, x).detach(), what="eval")
+    model.train()
+    torch.manual_seed(0)
+    b = eng.forward(x.to(dev())).cpu()
+    m0, m1 = eng._masks[5].cpu(), eng._masks[6].cpu()
+    assert set(np.unique(m0.numpy())) <= {0.0, 2.0} and m0.shape == (N, 16) and m1.shape == (N, 64)
+    assert_close(b, alexnet_ref.forward(ref, x, {0: m0, 1: m1}).detach(), what="train")
+    c = eng.forward(x.to(dev())).cpu()
+    assert not torch.equal(eng._masks[6].cpu(), m1)          # redrawn per pass
+    model.eval()
+    assert_close(eng.forward(x.to(dev())).cpu(), a, tol=0, what="eval again")
+    del c
+
+
+def test_alexnet_full_size_vs_oracle():
+    """torchvision-shaped AlexNet at 224x224 (BASELINE.json configs[3]: 'GEM AlexNet'), N=2: executor and autograd-bridge
+    paths vs torch CPU."""
+    from oracle import alexnet_ref
+    import copy
+    from clsurvey_amd import models
+    from clsurvey_amd.net import NetEngine
+    torch.manual_seed(1)
+    model = models.parse_model_name("alexnet_scratch", num_classes=40)
+    ref = copy.deepcopy(model)
+    N = 2
+    gen = np.random.default_rng(9)
+    x = rnd(gen, N, 3, 224, 224)
+    y = torch.from_numpy(gen.integers(0, 40, N))
+    m0 = torch.from_numpy((gen.random((N, 9216)) < 0.5).astype(np.float32) * 2)
+    m1 = torch.from_numpy((gen.random((N, 4096)) < 0.5).astype(np.float32) * 2)
+    rl, rlog, rg = alexnet_ref.loss_and_grads(ref, x, y, {0: m0, 1: m1})
+    # autograd bridges (models.AlexNet.forward), eval mode, before the arena takes the parameters over
+    model = model.to(dev()).eval()
+    with torch.no_grad():
+        out = model(x.to(dev()))
+    assert_close(out.cpu(), alexnet_ref.forward(ref, x).detach(), what="ops forward")
+    eng = NetEngine(model, N, (3, 224, 224), dev())
+    eng.auto_dropout = False
+    eng.set_dropout(5, m0.to(dev()))
+    eng.set_dropout(6, m1.to(dev()))
+    loss, logits = eng.loss_step(x.to(dev()), y.to(dev()), "ce_mean", True, want_logits=True)
+    assert_close(logits.cpu(), rlog, what="logits")
+    assert abs(float(loss) - float(rl)) <= 2e-4 * max(1.0, abs(float(rl)))
+    _flip_aware_grads(eng, model, rg, "alexnet 224")
+
+
+def test_alexnet_autograd_bridge_gradients():
+    """models.AlexNet.forward (conv2d / max-pool / linear autograd bridges) backward vs torch CPU on the small net."""
+    from oracle import alexnet_ref
+    model, ref = _small_alexnet(seed=4)
+    N = 5
+    gen = np.random.default_rng(11)
+    x = rnd(gen, N, 3, 67, 67)
+    y = torch.from_numpy(gen.integers(0, 10, N))
+    model = model.to(dev()).eval()
+    loss = torch.nn.functional.cross_entropy(model(x.to(dev())), y.to(dev()))
+    grads = torch.autograd.grad(loss, list(model.parameters()))
+    rl, _, rg = alexnet_ref.loss_and_grads(ref, x, y)
+    assert abs(float(loss) - float(rl)) <= 2e-4 * max(1.0, abs(float(rl)))
+    for (name, _), g, r in zip(model.named_parameters(), grads, rg):
+        assert rel_err(g, r) <= 2e-3, name
+
+
+def test_gem_observe_alexnet_dropout_masks():
+    """GEM on an AlexNet-structured net: one mask row per Dropout per observe, shared by the batch (gem.py:166-215);
+    first-task observe = plain SGD step on the masked net."""
+    from oracle import alexnet_ref
+    from clsurvey_amd.methods.gem import GemNet
+    model, ref = _small_alexnet(ncls=8, seed=6)
+    N = 6
+    gen = np.random.default_rng(13)
+    x = rnd(gen, N, 3, 67, 67)
+    y = torch.from_numpy(gen.integers(0, 4, N))
+    gem = GemNet(model, 8, 2, [4, 4], 4, lr=0.05, batch_size=N, in_shape=(3, 67, 67), device=dev())
+    theta0 = gem.A.theta.clone()
+    loss, hits, _ = gem.observe(x.to(dev()), 0, y.to(dev()))
+    m0, m1 = gem.dropout_masks[5].cpu(), gem.dropout_masks[6].cpu()
+    assert m0.shape == (16,) and m1.shape == (64,) and set(np.unique(m1.numpy())) <= {0.0, 2.0}
+    # oracle: CE on the task's slice [0, 4) with the same masks
+    params = list(ref.parameters())
+    logits = alexnet_ref.forward(ref, x, {0: m0[None], 1: m1[None]})
+    rl = torch.nn.functional.cross_entropy(logits[:, 0:4], y)
+    rg = torch.autograd.grad(rl, params)
+    assert abs(float(loss) - float(rl)) <= 2e-4 * max(1.0, abs(float(rl)))
+    for p_dev, p_ref, g in zip(model.parameters(), params, rg):
+        o, n = gem.A.slot(p_dev)
+        step = (theta0[o:o + n] - gem.A.theta[o:o + n]).view(p_ref.shape).cpu() / 0.05
+        assert rel_err(step, g) <= 2e-3
+    # the next observe draws new masks; eval uses none
+    old = m1.clone()
+    gem.observe(x.to(dev()), 0, y.to(dev()))
+    assert not torch.equal(gem.dropout_masks[6].cpu(), old)
+    out = gem.forward(x.to(dev()), 0)
+    with torch.no_grad():
+        for p_dev, p_ref in zip(model.parameters(), params):
+            p_ref.copy_(p_dev.detach().cpu())
+    assert_close(out[:, :4].cpu(), alexnet_ref.forward(ref, x).detach()[:, :4], what="gem eval")
+    # observe_FT keeps its masks over calls
+    gem.init_setup(lr=0.05, weight_decay=0.0, memory_strength=1.0)
+    gem.observe_FT(x.to(dev()), 0, y.to(dev()))
+    keep = gem.dropout_masks[6].clone()
+    gem.observe_FT(x.to(dev()), 0, y.to(dev()))
+    assert torch.equal(gem.dropout_masks[6], keep)
