@@ -95,10 +95,12 @@ class GemNet:
                 self.engine.set_dropout(li, None)
                 continue
             if li not in self.dropout_masks:
-                n = self.engine.in_elems[li]
-                self.dropout_masks[li] = torch.full((n,), p_retain_unit, dtype=torch.float32,
-                                                    device=self.device).bernoulli_().div_(p_retain_unit)
+                self.dropout_masks[li] = self._draw_mask(li, self.engine.in_elems[li], p_retain_unit)
             self.engine.set_dropout(li, self.dropout_masks[li])
+
+    def _draw_mask(self, layer, n, p_retain_unit):
+        """gem.py:183-186: torch.bernoulli(fill(p_retain)) / p_retain over one sample's features (device generator)."""
+        return torch.full((n,), p_retain_unit, dtype=torch.float32, device=self.device).bernoulli_().div_(p_retain_unit)
 
     _TRANSIENT = ("engine", "A", "G", "_gram_ws", "_gram", "stats", "opt", "dropout_masks")
 

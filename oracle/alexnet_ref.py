@@ -60,3 +60,49 @@ def loss_and_grads(model, x, y, masks=None):
     loss = F.cross_entropy(logits, y)
     grads = torch.autograd.grad(loss, params)
     return loss.detach(), logits.detach(), [g.detach() for g in grads]
+
+
+def gem_observe(model, bufs, x, t, y, masks, memories, cum_nc, lr, margin, momentum=0.9):
+    """One gem.Net.observe (gem.py:206-287) on a Dropout net with the given mask rows (shared by the memory passes and
+    the current batch, gem.py:180-191), SGD(momentum, no weight decay) update included.
+
+    memories: [(past_task, [(xb, yb), ...])] in observed order; bufs: momentum buffers per parameter (None at first).
+    Returns (loss, hits, n_violations, G [P][len(memories)+1] float32 with the current task last)."""
+    import numpy as np
+    from . import gem_ref
+    params = list(model.parameters())
+
+    def offsets(task):
+        return (0 if task == 0 else cum_nc[task - 1]), cum_nc[task]
+
+    cols = []
+    for past, batches in memories:
+        o1, o2 = offsets(past)
+        acc = [torch.zeros_like(p) for p in params]
+        for xb, yb in batches:                       # gradients accumulate over the batches (sum of batch means)
+            loss = F.cross_entropy(forward(model, xb, masks)[:, o1:o2], yb)
+            acc = [a + g for a, g in zip(acc, torch.autograd.grad(loss, params))]
+        cols.append(np.concatenate([a.numpy().reshape(-1) for a in acc]))
+    o1, o2 = offsets(t)
+    out = forward(model, x, masks)[:, o1:o2]
+    loss = F.cross_entropy(out, y)
+    hits = int((out.argmax(1) == y).sum())
+    grads = [g.detach() for g in torch.autograd.grad(loss, params)]
+    gflat = np.concatenate([g.numpy().reshape(-1) for g in grads])
+    viol = 0
+    G = np.stack(cols + [gflat], axis=1).astype(np.float32) if cols else gflat[:, None].astype(np.float32)
+    if cols:
+        dotp, viol = gem_ref.violations(G, len(cols), list(range(len(cols))))
+        if viol:
+            gflat, _ = gem_ref.project2cone2(gflat, G[:, :len(cols)], margin)
+            grads = [torch.from_numpy(a.copy()) for a in gem_ref.overwrite_grad(gflat, [tuple(p.shape) for p in params])]
+    sgd_momentum_step(params, grads, bufs, lr, momentum)
+    return loss.detach(), hits, viol, G
+
+
+def sgd_momentum_step(params, grads, bufs, lr, momentum=0.9):
+    """torch.optim.SGD(momentum, dampening 0, weight_decay 0): buf = g at the first step, then momentum * buf + g."""
+    with torch.no_grad():
+        for i, (p, g) in enumerate(zip(params, grads)):
+            bufs[i] = g.clone() if bufs[i] is None else bufs[i] * momentum + g
+            p.sub_(lr * bufs[i])

@@ -1049,3 +1049,44 @@ def test_gem_observe_alexnet_dropout_masks():
     keep = gem.dropout_masks[6].clone()
     gem.observe_FT(x.to(dev()), 0, y.to(dev()))
     assert torch.equal(gem.dropout_masks[6], keep)
+
+
+def test_gem_alexnet_golden_g15(golden):
+    """GemNet on the AlexNet-structured net of G15 against the reference's own gem.Net run (make_g15.py): four observes
+    (the third one projected) and two observe_FT steps with the reference's mask rows injected."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import g15_inputs as I
+    from clsurvey_amd.methods.gem import GemNet
+    g = golden("G15_gem_alexnet")
+    m = I.SmallAlexNet(num_classes=I.N_OUT)
+    I.load_params(m, [g["p0_%d" % i] for i in range(len(list(m.parameters())))])
+    gem = GemNet(m, I.N_OUT, 2, I.NC_PER_TASK, I.N_MEM, lr=0.002, weight_decay=0.0, memory_strength=0.5,
+                 batch_size=I.BATCH, in_shape=(3, I.HW, I.HW), device=dev())
+    assert sorted(gem.engine.drops) == [5, 6]
+    key = {5: "mask0", 6: "mask3"}        # plan layer -> classifier index of its Dropout in the reference's dict
+    cur = {"step": 0}
+    gem._draw_mask = lambda li, n, p: torch.from_numpy(g["s%d_%s" % (cur["step"], key[li])]).to(dev())
+    data = [(torch.from_numpy(x).to(dev()), torch.from_numpy(y).to(dev())) for x, y in I.batches(steps=6)]
+    for step in range(4):
+        cur["step"] = step
+        loss, hits, stats = gem.observe(data[step][0], 0 if step < 2 else 1, data[step][1])
+        assert abs(float(loss) - float(g["s%d_loss" % step])) <= 3e-4 * abs(float(g["s%d_loss" % step])), step
+        assert int(hits) == int(g["s%d_hits" % step])
+        assert stats["projected_grads"] == [int(g["s%d_proj" % step])]
+        touched = 0 if step < 2 else 1
+        assert np.array_equal(gem.memory_labels[touched].cpu().numpy(), g["s%d_mem_labels" % step][touched])
+    for i, p in enumerate(m.parameters()):
+        assert rel_err(p.data, torch.from_numpy(g["p4_%d" % i])) <= 1e-3, i
+    gem.init_setup(lr=0.002, weight_decay=0.0, memory_strength=0.5)
+    for step in (4, 5):
+        cur["step"] = 4                   # drawn once after init_setup, kept for the whole FT run
+        loss, hits = gem.observe_FT(data[step][0], 1, data[step][1])
+        assert abs(float(loss) - float(g["s%d_loss" % step])) <= 3e-4 * abs(float(g["s%d_loss" % step])), step
+        assert int(hits) == int(g["s%d_hits" % step])
+    for i, p in enumerate(m.parameters()):
+        assert rel_err(p.data, torch.from_numpy(g["p6_%d" % i])) <= 1e-3, i
+    out = gem.forward(data[0][0], 1).cpu().numpy()
+    assert (out[:, :4] < -1e10).all()
+    np.testing.assert_allclose(out[:, 4:8], g["eval_logits_t1"][:, 4:8], rtol=1e-3, atol=1e-4)

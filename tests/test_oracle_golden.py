@@ -292,3 +292,53 @@ def test_g14_lwf_distillation(golden):
     task, dist = LW.lwf_objective(outs, torch.from_numpy(g["y"]), [torch.from_numpy(g["teacher0"]), torch.from_numpy(g["teacher1"])], 2.0, 10.0)
     np.testing.assert_allclose(task.numpy(), g["task_loss"], rtol=1e-5)
     np.testing.assert_allclose(dist.numpy(), g["dist_loss"], rtol=1e-5)
+
+
+def _g15_net(g, prefix="p0_"):
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import g15_inputs as I
+    m = I.SmallAlexNet(num_classes=I.N_OUT)
+    I.load_params(m, [g["%s%d" % (prefix, i)] for i in range(len(list(m.parameters())))])
+    return m, I
+
+
+def test_g15_gem_alexnet_dropout_observe(golden):
+    """oracle/alexnet_ref.py (manual dropout rows, memory pass + current batch under ONE mask set, violation test,
+    projection, momentum SGD) vs the reference's unchanged gem.Net on an AlexNet-structured net (G15, make_g15.py)."""
+    from oracle import alexnet_ref as AR
+    g = golden("G15_gem_alexnet")
+    m, I = _g15_net(g)
+    data = [(torch.from_numpy(x), torch.from_numpy(y)) for x, y in I.batches(steps=6)]
+    bufs = [None] * len(list(m.parameters()))
+    cum = [4, 8]
+    assert int(g["s2_proj"]) == 1                      # the fixture holds a projected step
+    for step in range(4):
+        t = 0 if step < 2 else 1
+        masks = {0: torch.from_numpy(g["s%d_mask0" % step])[None], 1: torch.from_numpy(g["s%d_mask3" % step])[None]}
+        # ring buffer of task 0 after two observes: the first n_memories samples of step 1 (gem.py:322-345)
+        mem = [(0, [(data[1][0][:I.N_MEM], data[1][1][:I.N_MEM])])] if t == 1 else []
+        x, y = data[step]
+        loss, hits, viol, G = AR.gem_observe(m, bufs, x, t, y, masks, mem, cum, 0.002, 0.5)
+        np.testing.assert_allclose(float(loss), float(g["s%d_loss" % step]), rtol=2e-5)
+        assert hits == int(g["s%d_hits" % step]) and viol == int(g["s%d_proj" % step])
+    np.testing.assert_array_equal(g["s1_mem_labels"][0], data[1][1][:I.N_MEM].numpy())
+    for i, p in enumerate(m.parameters()):
+        np.testing.assert_allclose(p.detach().numpy(), g["p4_%d" % i], rtol=2e-4, atol=2e-6)
+    # observe_FT after init_setup: fresh momentum, ONE mask set for both steps
+    np.testing.assert_array_equal(g["s4_mask3"], g["s5_mask3"])
+    assert not np.array_equal(g["s4_mask3"], g["s3_mask3"])
+    bufs = [None] * len(bufs)
+    masks = {0: torch.from_numpy(g["s4_mask0"])[None], 1: torch.from_numpy(g["s4_mask3"])[None]}
+    params = list(m.parameters())
+    for step in (4, 5):
+        x, y = data[step]
+        loss = torch.nn.functional.cross_entropy(AR.forward(m, x, masks)[:, 4:8], y)
+        np.testing.assert_allclose(float(loss), float(g["s%d_loss" % step]), rtol=2e-5)
+        AR.sgd_momentum_step(params, [gr.detach() for gr in torch.autograd.grad(loss, params)], bufs, 0.002)
+    for i, p in enumerate(params):
+        np.testing.assert_allclose(p.detach().numpy(), g["p6_%d" % i], rtol=2e-4, atol=2e-6)
+    with torch.no_grad():
+        np.testing.assert_allclose(AR.forward(m, data[0][0]).numpy()[:, 4:8], g["eval_logits_t1"][:, 4:8], rtol=1e-4, atol=1e-5)
+    assert (g["eval_logits_t1"][:, :4] < -1e10).all()
