@@ -246,23 +246,41 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_reduce_kernel(const float* _
     }
 }
 
-__global__ __launch_bounds__(256) void conv2d_bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db,
+// db[k] = sum over images and pixels of dy: BIAS_SPLIT blocks per channel (image ranges) write f64 partials, a second
+// tiny launch adds them in order (deterministic).  One block per channel was 340 us on AlexNet's conv1 (64 blocks, one
+// load in flight per thread).
+constexpr int BIAS_SPLIT = 16;
+
+__global__ __launch_bounds__(256) void conv2d_bias_grad_kernel(const float* __restrict__ dy, double* __restrict__ part,
                                                                int N, int K, int OHW) {
-    __shared__ double part[256];
-    const int k = blockIdx.x;
-    double s = 0.0;
-    const long total = (long)N * OHW;
-    for (long e = threadIdx.x; e < total; e += 256) {
-        const long img = e / OHW, pp = e - img * OHW;
-        s += (double)dy[((size_t)img * K + k) * OHW + pp];
+    __shared__ double red[256];
+    const int k = blockIdx.x, sp = blockIdx.y;
+    const int n0 = (int)((long)N * sp / BIAS_SPLIT), n1 = (int)((long)N * (sp + 1) / BIAS_SPLIT);
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int img = n0; img < n1; ++img) {
+        const float* row = dy + ((size_t)img * K + k) * OHW;
+        int e = threadIdx.x;
+        for (; e + 768 < OHW; e += 1024) {
+            const float a = row[e], b = row[e + 256], c = row[e + 512], d = row[e + 768];
+            s0 += a; s1 += b; s2 += c; s3 += d;
+        }
+        for (; e < OHW; e += 256) s0 += row[e];
     }
-    part[threadIdx.x] = s;
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) db[k] = (float)part[0];
+    if (threadIdx.x == 0) part[(size_t)k * BIAS_SPLIT + sp] = red[0];
+}
+
+__global__ void conv2d_bias_finish_kernel(const double* __restrict__ part, float* __restrict__ db, int K) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    double s = 0.0;
+    for (int i = 0; i < BIAS_SPLIT; ++i) s += part[(size_t)k * BIAS_SPLIT + i];
+    db[k] = (float)s;
 }
 
 bool conv_ok(int N, int C, int H, int W, int K, int R, int S, int st, int pad, int& OH, int& OW) {
@@ -291,7 +309,9 @@ extern "C" {
 size_t clhip_conv2d_bwd_weight_ws(int N, int C, int H, int W, int K, int R, int S, int stride, int pad) {
     int OH, OW;
     if (!conv_ok(N, C, H, W, K, R, S, stride, pad, OH, OW)) return 0;
-    return (size_t)K * C * R * S * wgrad_splits(K, C * R * S, (long)N * OH * OW) * sizeof(float);
+    const size_t slabs = (size_t)K * C * R * S * wgrad_splits(K, C * R * S, (long)N * OH * OW) * sizeof(float);
+    const size_t bias = (size_t)K * BIAS_SPLIT * sizeof(double);     // reused after the slab reduction (stream order)
+    return slabs > bias ? slabs : bias;
 }
 
 int clhip_conv2d_fwd(const float* x, const float* w, const float* b, float* y, int N, int C, int H, int W, int K, int R, int S,
@@ -331,7 +351,7 @@ int clhip_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* d
     const long Kd = (long)N * OH * OW;
     const int splits = wgrad_splits(M, Nn, Kd);
     const size_t mn = (size_t)M * Nn;
-    if (ws_bytes < mn * splits * sizeof(float)) return CLHIP_ENOSPC;
+    if (ws_bytes < mn * splits * sizeof(float) || (db && ws_bytes < (size_t)K * BIAS_SPLIT * sizeof(double))) return CLHIP_ENOSPC;
     const int k_per_split = (int)(((Kd + splits - 1) / splits + BK - 1) / BK * BK);
     const int n_tiles = (Nn + TN - 1) / TN, m_tiles = (M + TM - 1) / TM;
     hipStream_t s = as_stream(stream);
@@ -341,7 +361,10 @@ int clhip_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* d
     hipLaunchKernelGGL(conv2d_wgrad_reduce_kernel, dim3(ew_grid(mn, 256)), dim3(256), 0, s, static_cast<const float*>(ws), dw, mn, splits);
     CLHIP_LAUNCH_CHECK();
     if (db) {
-        hipLaunchKernelGGL(conv2d_bias_grad_kernel, dim3(K), dim3(256), 0, s, dy, db, N, K, OH * OW);
+        double* part = static_cast<double*>(ws);       // the slabs are consumed: same stream, after the reduction
+        hipLaunchKernelGGL(conv2d_bias_grad_kernel, dim3(K, BIAS_SPLIT), dim3(256), 0, s, dy, part, N, K, OH * OW);
+        CLHIP_LAUNCH_CHECK();
+        hipLaunchKernelGGL(conv2d_bias_finish_kernel, dim3((K + 255) / 256), dim3(256), 0, s, part, db, K);
         CLHIP_LAUNCH_CHECK();
     }
     return 0;
