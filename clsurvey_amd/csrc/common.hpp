@@ -76,3 +76,10 @@ struct clhip_fc_chain {
 int clhip_internal_fc_chain_ok(const clhip_fc_chain* d);
 int clhip_internal_fc_chain_wgrad(const clhip_fc_chain* d, float* grads, const float* x, int N, const float* acts,
                                   const float* dlogits, const float* dz, hipStream_t s);
+
+// conv3x3_wgrad.hip: deferred slab reduction (see clhip_internal_conv3x3_wgrad_partial)
+#define CLHIP_WGRAD_JOBS_MAX 32
+struct clhip_wgrad_job { const float* part; float* dw; float* db; int K, C, splits; };
+int clhip_internal_conv3x3_wgrad_partial(const float* x, const float* dy, const uint8_t* unpool_idx, float* dw, float* db, int N,
+                                         int C, int K, int H, int W, void* ws, size_t ws_bytes, void* stream, clhip_wgrad_job* job);
+int clhip_internal_wgrad_reduce_multi(const clhip_wgrad_job* jobs, int n, hipStream_t s);

@@ -528,6 +528,44 @@ __global__ __launch_bounds__(RED_EL * RED_J) void wgrad_reduce_kernel(const floa
     }
 }
 
+// The same reduction for the slabs of SEVERAL layers in one launch (the plan executor defers them to the end of the
+// backward pass: six ~6 us launches -> one).  Per job the arithmetic and its order are those of wgrad_reduce_kernel.
+struct RedJobs {
+    clhip_wgrad_job job[CLHIP_WGRAD_JOBS_MAX];
+    unsigned first[CLHIP_WGRAD_JOBS_MAX + 1];       // prefix sums of blocks
+    int n;
+};
+
+__global__ __launch_bounds__(RED_EL * RED_J) void wgrad_reduce_multi_kernel(RedJobs jobs) {
+    __shared__ double partial[RED_J][RED_EL];
+    int ji = 0;
+    while (ji + 1 < jobs.n && blockIdx.x >= jobs.first[ji + 1]) ++ji;
+    const clhip_wgrad_job J = jobs.job[ji];
+    const size_t kc = (size_t)J.K * J.C, nw = 9 * kc, total = nw + J.K;
+    const int el = threadIdx.x & (RED_EL - 1), j = threadIdx.x / RED_EL;
+    const size_t e = (size_t)(blockIdx.x - jobs.first[ji]) * RED_EL + el;
+    const int q = (J.splits + RED_J - 1) / RED_J;
+    const int s0 = j * q, s1 = min(J.splits, s0 + q);
+    double s = 0.0;
+    if (e < total) {
+#pragma unroll 8
+        for (int sp = s0; sp < s1; ++sp) s += (double)J.part[(size_t)sp * total + e];
+    }
+    partial[j][el] = s;
+    __syncthreads();
+    if (j == 0 && e < total) {
+        double t = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < RED_J; ++jj) t += partial[jj][el];
+        if (e < nw) {
+            const size_t rs = e / kc, rem = e - rs * kc;
+            J.dw[rem * 9 + rs] = (float)t;
+        } else if (J.db) {
+            J.db[e - nw] = (float)t;
+        }
+    }
+}
+
 struct WPlan {
     int TW, TH, tiles_w, tiles_h, total_stages, splits, k_tiles, c_tiles, group, groups, ps;
     size_t slab, ws_floats;
@@ -585,7 +623,8 @@ size_t clhip_conv3x3_bwd_weight_ws(int N, int C, int K, int H, int W) {
 }
 
 static int bwd_weight_impl(const float* x, const float* dy, const uint8_t* unpool_idx, float* dw, float* db,
-                           int N, int C, int K, int H, int W, void* ws, size_t ws_bytes, void* stream) {
+                           int N, int C, int K, int H, int W, void* ws, size_t ws_bytes, void* stream,
+                           clhip_wgrad_job* defer = nullptr) {
     if (!x || !dy || !dw || !ws || N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0) return CLHIP_EINVAL;
     if (unpool_idx && (C * 9 > 32 || (H & 1) || (W & 1))) return CLHIP_ENOTSUP;
     WPlan p = make_plan(N, C, K, H, W);
@@ -613,6 +652,10 @@ static int bwd_weight_impl(const float* x, const float* dy, const uint8_t* unpoo
     }
 #undef WG_ARGS
     CLHIP_LAUNCH_CHECK();
+    if (defer) {
+        *defer = clhip_wgrad_job{part, dw, db, K, C, p.splits};
+        return 0;
+    }
     const unsigned bx = (unsigned)((p.slab + RED_EL - 1) / RED_EL);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(bx), dim3(RED_EL * RED_J), 0, s, part, dw, db, K, C, p.splits);
     CLHIP_LAUNCH_CHECK();
@@ -633,3 +676,28 @@ int clhip_conv3x3_bwd_weight_unpool(const float* x, const float* dy_pool, const 
 }
 
 }  // extern "C"
+
+// Partial slabs only; the caller reduces several layers at once with clhip_internal_wgrad_reduce_multi (the slabs in
+// ws must stay untouched until then).  unpool_idx as in clhip_conv3x3_bwd_weight_unpool (may be NULL).
+int clhip_internal_conv3x3_wgrad_partial(const float* x, const float* dy, const uint8_t* unpool_idx, float* dw, float* db, int N,
+                                         int C, int K, int H, int W, void* ws, size_t ws_bytes, void* stream, clhip_wgrad_job* job) {
+    if (!job) return CLHIP_EINVAL;
+    return bwd_weight_impl(x, dy, unpool_idx, dw, db, N, C, K, H, W, ws, ws_bytes, stream, job);
+}
+
+int clhip_internal_wgrad_reduce_multi(const clhip_wgrad_job* jobs, int n, hipStream_t s) {
+    if (n <= 0) return 0;
+    if (!jobs || n > CLHIP_WGRAD_JOBS_MAX) return CLHIP_EINVAL;
+    RedJobs r;
+    r.n = n;
+    r.first[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        r.job[i] = jobs[i];
+        const size_t total = (size_t)9 * jobs[i].K * jobs[i].C + jobs[i].K;
+        r.first[i + 1] = r.first[i] + (unsigned)((total + RED_EL - 1) / RED_EL);
+    }
+    for (int i = n; i < CLHIP_WGRAD_JOBS_MAX; ++i) { r.job[i] = clhip_wgrad_job{nullptr, nullptr, nullptr, 0, 0, 0}; r.first[i + 1] = r.first[n]; }
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(r.first[n]), dim3(RED_EL * RED_J), 0, s, r);
+    CLHIP_LAUNCH_CHECK();
+    return 0;
+}

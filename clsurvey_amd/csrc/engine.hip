@@ -26,6 +26,7 @@ struct LayerPlan {
     size_t act_off;        // float offset of this layer's OUTPUT (post-ReLU, pre-pool) in ws
     size_t pool_off;       // float offset of pooled output
     size_t idx_off;        // byte offset of pool argmax
+    size_t wg_off, wg_bytes;   // this layer's own weight-gradient slabs (3x3 layers; reduced for all layers at once)
     const float* drop;     // dropout mask applied to this layer's INPUT (NULL = none); see clhip_net_set_dropout
     long drop_stride;      // floats between the mask rows of consecutive samples (0 = one row shared by the batch)
 };
@@ -40,7 +41,8 @@ struct NetPlan {
     size_t scratch_bytes;    // wgrad / fc split-K scratch
     size_t total_bytes;
     // derived offsets (bytes) inside ws
-    size_t off_acts, off_idx, off_g0, off_g1, off_scratch, off_dlogits, off_loss, off_fcdz;
+    size_t off_acts, off_idx, off_g0, off_g1, off_scratch, off_dlogits, off_loss, off_fcdz, off_wg;
+    int n_wg;                // 3x3 conv layers with deferred slab reduction (0: every layer reduces right away)
     // classifier = trailing Linear layers [fc_first, end): fused into three launches when it fits fc_chain.hip
     int fc_first;
     bool fc_fused;
@@ -88,7 +90,8 @@ int clhip_net_create(const clhip_layer_desc* descs, int n_layers, int max_batch,
     p->in_elems = (size_t)in_c * in_h * in_w;
     int c = in_c, h = in_h, w = in_w;
     size_t feat = p->in_elems;
-    size_t acts = 0, idxb = 0, gmax = 0, scratch = 0;
+    size_t acts = 0, idxb = 0, gmax = 0, scratch = 0, wg_total = 0;
+    int n_wg = 0;
     bool seen_fc = false;
     for (int i = 0; i < n_layers; ++i) {
         LayerPlan L{};
@@ -122,6 +125,7 @@ int clhip_net_create(const clhip_layer_desc* descs, int n_layers, int max_batch,
             size_t s = vgg ? clhip_conv3x3_bwd_weight_ws(max_batch, L.cin, L.cout, L.h, L.w)
                            : clhip_conv2d_bwd_weight_ws(max_batch, L.cin, L.h, L.w, L.cout, L.ks, L.ks, L.st, L.pd);
             if (s > scratch) scratch = s;
+            if (vgg) { L.wg_off = wg_total; L.wg_bytes = align_up(s, 256); wg_total += L.wg_bytes; ++n_wg; }
             if (L.out_elems > gmax) gmax = L.out_elems;
             if (L.in_elems > gmax) gmax = L.in_elems;
             h = oh; w = ow;
@@ -172,6 +176,10 @@ int clhip_net_create(const clhip_layer_desc* descs, int n_layers, int max_batch,
             off += align_up(dzf * 4 + 256, 256);
         }
     }
+    // own slabs per 3x3 layer so that ONE launch reduces them all at the end of backward (HBM is plentiful: 288 GB)
+    p->off_wg = off;
+    p->n_wg = (n_wg >= 2 && n_wg <= CLHIP_WGRAD_JOBS_MAX) ? n_wg : 0;
+    if (p->n_wg) off += align_up(wg_total, 256);
     p->total_bytes = off;
     p->overlap = false;
     p->side = nullptr;
@@ -303,6 +311,9 @@ int clhip_net_backward(void* handle, const float* params, float* grads, const fl
     hipEvent_t pending[2] = {nullptr, nullptr};      // side-stream reader of g[b] that must finish before g[b] is rewritten
     hipEvent_t last_side = nullptr;
     int taken = -1;
+    const bool defer = p->n_wg > 0 && !ov;
+    clhip_wgrad_job jobs[CLHIP_WGRAD_JOBS_MAX];
+    int n_jobs = 0;
     // next ping-pong buffer as an OUTPUT of a main-stream launch
     auto take = [&]() -> float* {
         const int bi = flip;
@@ -368,10 +379,14 @@ int clhip_net_backward(void* handle, const float* params, float* grads, const fl
             // no backward-data below the first layer: take the weight gradient straight from the pooled gradient +
             // argmax (fused max-pool backward), when the kernel supports the shape
             rc = on_side(i, gin_buf, [&](void* st) {
+                if (defer)
+                    return clhip_internal_conv3x3_wgrad_partial(xin, gin, idx + L.idx_off, grads + L.w_off, grads + L.b_off, N, L.cin,
+                                                                L.cout, L.h, L.w, base + p->off_wg + L.wg_off, L.wg_bytes, st,
+                                                                &jobs[n_jobs]);
                 return clhip_conv3x3_bwd_weight_unpool(xin, gin, idx + L.idx_off, grads + L.w_off, grads + L.b_off, N, L.cin, L.cout,
                                                        L.h, L.w, scratch, p->scratch_bytes, st);
             });
-            if (rc == 0) wdone = true;
+            if (rc == 0) { wdone = true; if (defer) ++n_jobs; }
             else if (rc != CLHIP_ENOTSUP) return rc;
         }
         if (L.pool && !wdone) {
@@ -383,12 +398,16 @@ int clhip_net_backward(void* handle, const float* params, float* grads, const fl
         }
         if (!wdone) {
             rc = on_side(i, gy_buf, [&](void* st) {
+                if (vgg && defer)
+                    return clhip_internal_conv3x3_wgrad_partial(xin, gy, nullptr, grads + L.w_off, grads + L.b_off, N, L.cin, L.cout, L.h,
+                                                                L.w, base + p->off_wg + L.wg_off, L.wg_bytes, st, &jobs[n_jobs]);
                 return vgg ? clhip_conv3x3_bwd_weight(xin, gy, grads + L.w_off, grads + L.b_off, N, L.cin, L.cout, L.h, L.w, scratch,
                                                       p->scratch_bytes, st)
                            : clhip_conv2d_bwd_weight(xin, gy, grads + L.w_off, grads + L.b_off, N, L.cin, L.h, L.w, L.cout, L.ks, L.ks,
                                                      L.st, L.pd, scratch, p->scratch_bytes, st);
             });
             if (rc) return rc;
+            if (vgg && defer) ++n_jobs;
         }
         if (i > 0) {
             float* gout = take();
@@ -401,6 +420,10 @@ int clhip_net_backward(void* handle, const float* params, float* grads, const fl
                 if (rc) return rc;
             }
         }
+    }
+    if (n_jobs) {
+        rc = clhip_internal_wgrad_reduce_multi(jobs, n_jobs, main_s);
+        if (rc) return rc;
     }
     if (last_side) {      // join: every gradient is complete on the caller's stream when this returns
         hipError_t e = hipStreamWaitEvent(main_s, last_side, 0);

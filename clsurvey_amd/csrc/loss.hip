@@ -156,6 +156,65 @@ __global__ __launch_bounds__(LOSS_BLOCK) void softmax_ce_rows_kernel(
     }
 }
 
+// Same arithmetic as softmax_ce_rows_kernel with the whole [N][ld] logit block staged through LDS: coalesced loads and
+// stores instead of three latency-serialised passes of row-strided global reads (11.7 us -> a few us at 200 x 20).
+constexpr int CE_LDS_FLOATS = 12288;
+__global__ __launch_bounds__(LOSS_BLOCK) void softmax_ce_rows_lds_kernel(
+    const float* __restrict__ logits_full, const int64_t* __restrict__ labels, int N, int C, int reduction,
+    float* __restrict__ dlogits_full, float* __restrict__ loss_out, double* __restrict__ stats, int ld, int col_off) {
+    __shared__ float zs[CE_LDS_FLOATS];
+    __shared__ float w_loss[16];
+    __shared__ int w_corr[16];
+    const int lds = ld | 1;                       // odd row stride: conflict-free per-row walks
+    const int total = N * ld;
+    for (int e = threadIdx.x; e < total; e += LOSS_BLOCK) {
+        const int r = e / ld, c = e - r * ld;
+        zs[r * lds + c] = logits_full[e];
+    }
+    __syncthreads();
+    const int row = threadIdx.x;
+    const float scale = reduction == 0 ? 1.f / (float)N : 1.f;
+    float li = 0.f;
+    int ok = 0;
+    if (row < N) {
+        float* z = zs + row * lds + col_off;
+        const int y = (int)labels[row];
+        float m = -INFINITY;
+        int am = 0;
+        for (int c = 0; c < C; ++c) {
+            float v = z[c];
+            if (v > m) { m = v; am = c; }
+        }
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += expf(z[c] - m);
+        const float lse = logf(se);
+        li = -(z[y] - m - lse);
+        ok = (am == y);
+        float* zr = zs + row * lds;
+        for (int c = 0; c < ld; ++c) {
+            const int cc = c - col_off;
+            zr[c] = (cc >= 0 && cc < C) ? (expf(zr[c] - m - lse) - (cc == y ? 1.f : 0.f)) * scale : 0.f;
+        }
+    }
+    float v = li;
+    int cc = ok;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { v += __shfl_xor(v, o, 64); cc += __shfl_xor(cc, o, 64); }
+    if ((threadIdx.x & 63) == 0) { w_loss[threadIdx.x >> 6] = v; w_corr[threadIdx.x >> 6] = cc; }
+    __syncthreads();
+    for (int e = threadIdx.x; e < total; e += LOSS_BLOCK) {
+        const int r = e / ld, c = e - r * ld;
+        dlogits_full[e] = zs[r * lds + c];
+    }
+    if (threadIdx.x == 0) {
+        float t = 0.f; int c = 0;
+        for (int w = 0; w < 16; ++w) { t += w_loss[w]; c += w_corr[w]; }
+        t *= scale;
+        loss_out[0] = t;
+        if (stats) { stats[0] += (double)t; stats[1] += (double)c; }
+    }
+}
+
 __global__ __launch_bounds__(LOSS_BLOCK) void mse_zero_sum_kernel(const float* __restrict__ z, size_t n,
                                                                   float* __restrict__ dz, float* __restrict__ loss_out) {
     __shared__ float s_part[16];
@@ -257,7 +316,10 @@ int clhip_softmax_ce_slice(const float* logits, const int64_t* labels_i64, int N
     if (!logits || !labels_i64 || !dlogits || !loss_out || N <= 0 || ncols <= 0 || col_off < 0 || col_off + ncols > ld)
         return CLHIP_EINVAL;
     if (reduction != 0 && reduction != 1) return CLHIP_EINVAL;
-    if (ncols <= 64 && N <= LOSS_BLOCK && ld <= 4096)
+    if (ncols <= 64 && N <= LOSS_BLOCK && (size_t)N * (ld | 1) <= (size_t)CE_LDS_FLOATS)
+        hipLaunchKernelGGL(softmax_ce_rows_lds_kernel, dim3(1), dim3(LOSS_BLOCK), 0, as_stream(stream), logits, labels_i64, N, ncols,
+                           reduction, dlogits, loss_out, stats, ld, col_off);
+    else if (ncols <= 64 && N <= LOSS_BLOCK && ld <= 4096)
         hipLaunchKernelGGL(softmax_ce_rows_kernel, dim3(1), dim3(LOSS_BLOCK), 0, as_stream(stream), logits, labels_i64, N, ncols,
                            reduction, dlogits, loss_out, stats, ld, col_off);
     else

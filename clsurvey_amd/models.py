@@ -33,14 +33,20 @@ def make_layers(cfg, in_channels=3):
 
 class VGGSlim(nn.Module):
     def __init__(self, config="small_VGG9", num_classes=20, init_weights=True, classifier_inputdim=128 * 4 * 4,
-                 classifier_dim1=128, classifier_dim2=128, cfg=None):
+                 classifier_dim1=128, classifier_dim2=128, cfg=None, dropout=False):
         super().__init__()
         self.features = make_layers(cfg if cfg is not None else CFG[config])
         self.avgpool = nn.Identity()
-        self.classifier = nn.Sequential(
-            nn.Linear(classifier_inputdim, classifier_dim1), nn.ReLU(True),
-            nn.Linear(classifier_dim1, classifier_dim2), nn.ReLU(True),
-            nn.Linear(classifier_dim2, num_classes))
+        if dropout:      # the '_DROP' models (VGGSlim.py:57-66): classifier indices 0..6, last_layer_idx = 6
+            self.classifier = nn.Sequential(
+                nn.Linear(classifier_inputdim, classifier_dim1), nn.ReLU(True), nn.Dropout(),
+                nn.Linear(classifier_dim1, classifier_dim2), nn.ReLU(True), nn.Dropout(),
+                nn.Linear(classifier_dim2, num_classes))
+        else:
+            self.classifier = nn.Sequential(
+                nn.Linear(classifier_inputdim, classifier_dim1), nn.ReLU(True),
+                nn.Linear(classifier_dim1, classifier_dim2), nn.ReLU(True),
+                nn.Linear(classifier_dim2, num_classes))
         if init_weights:
             self._initialize_weights()
 
@@ -55,31 +61,9 @@ class VGGSlim(nn.Module):
                 nn.init.constant_(m.bias, 0)
 
     def forward(self, x):
-        mods = list(self.features.children())
-        i = 0
-        while i < len(mods):
-            m = mods[i]
-            if isinstance(m, nn.Conv2d):
-                relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
-                x = ops.conv3x3_relu(x, m.weight, m.bias, relu)
-                i += 2 if relu else 1
-            elif isinstance(m, nn.MaxPool2d):
-                x = ops.maxpool2(x)
-                i += 1
-            else:
-                raise NotImplementedError(type(m))
+        x = _walk(x, list(self.features.children()), self.training, "VGGSlim.features")
         x = torch.flatten(x, 1)
-        mods = list(self.classifier.children())
-        i = 0
-        while i < len(mods):
-            m = mods[i]
-            if isinstance(m, nn.Linear):
-                relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
-                x = ops.linear(x, m.weight, m.bias, relu)
-                i += 2 if relu else 1
-            else:
-                raise NotImplementedError(type(m))
-        return x
+        return _walk(x, list(self.classifier.children()), self.training, "VGGSlim.classifier")
 
 
 def _walk(x, mods, training, what):
@@ -154,10 +138,13 @@ def parse_model_name(name, input_size=(64, 64), num_classes=20):
         return AlexNet(num_classes=1000 if num_classes is None else num_classes)
     base = name.split("_cl_")[0]
     dims = name.split("_cl_")[1].split("_") if "_cl_" in name else ["512", "512"]
+    flags = name.split("_")
+    if "BN" in flags:
+        raise NotImplementedError("BatchNorm model variants (models/net.py:152-156) are not built yet")
     d1, d2 = int(dims[0]), int(dims[1])
     cfg = CFG[base]
     last = [v for v in cfg if v != "M"][-1]
     npool = sum(1 for v in cfg if v == "M")
     feat = last * (input_size[0] // 2 ** npool) * (input_size[1] // 2 ** npool)
     return VGGSlim(config=base, num_classes=num_classes, classifier_inputdim=feat,
-                   classifier_dim1=d1, classifier_dim2=d2)
+                   classifier_dim1=d1, classifier_dim2=d2, dropout="DROP" in flags)
