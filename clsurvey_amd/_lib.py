@@ -15,7 +15,8 @@ _l = C.c_long
 
 class LayerDesc(C.Structure):
     _fields_ = [("type", _i), ("cin", _i), ("cout", _i), ("relu", _i), ("pool", _i),
-                ("w_off", _l), ("b_off", _l), ("ksize", _i), ("stride", _i), ("pad", _i), ("pool_k", _i), ("pool_s", _i)]
+                ("w_off", _l), ("b_off", _l), ("ksize", _i), ("stride", _i), ("pad", _i), ("pool_k", _i), ("pool_s", _i),
+                ("bn", _i), ("bn_w_off", _l), ("bn_b_off", _l)]
 
 
 # name -> (restype, argtypes); mirrors include/clhip.h one to one
@@ -74,6 +75,11 @@ SIGNATURES = {
     "clhip_gem_project": (_i, [_p, _z, C.POINTER(_i), C.POINTER(_f), _i, _p, _p, _z, _p]),
     "clhip_net_create": (_i, [C.POINTER(LayerDesc), _i, _i, _i, _i, _i, C.POINTER(_p)]),
     "clhip_net_set_dropout": (_i, [_p, _i, _p, _l]),
+    "clhip_net_set_bn": (_i, [_p, _i, _p, _p, _f, _f]),
+    "clhip_net_set_training": (_i, [_p, _i]),
+    "clhip_bn_ws": (_z, [_i]),
+    "clhip_bn_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _i, _p, _z, _p]),
+    "clhip_bn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
     "clhip_net_destroy": (None, [_p]),
     "clhip_net_workspace_bytes": (_z, [_p]),
     "clhip_net_num_classes": (_i, [_p]),

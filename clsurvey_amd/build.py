@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libclhip.so")
-SOURCES = ["elementwise.hip", "loss.hip", "pool.hip", "conv3x3.hip", "conv3x3_wgrad.hip", "conv2d.hip", "gemm.hip", "fc_chain.hip",
+SOURCES = ["elementwise.hip", "loss.hip", "pool.hip", "conv3x3.hip", "conv3x3_wgrad.hip", "conv2d.hip", "bn.hip", "gemm.hip", "fc_chain.hip",
            "packnet.hip", "hat.hip", "gem.hip", "engine.hip", "debug_naive.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

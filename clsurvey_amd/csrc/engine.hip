@@ -26,6 +26,11 @@ struct LayerPlan {
     size_t act_off;        // float offset of this layer's OUTPUT (post-ReLU, pre-pool) in ws
     size_t pool_off;       // float offset of pooled output
     size_t idx_off;        // byte offset of pool argmax
+    int bn;                // BatchNorm2d between conv and ReLU
+    long bn_w_off, bn_b_off;
+    size_t z_off;          // bn: float offset of the convolution output (pre-BatchNorm) in ws
+    size_t stat_off;       // bn: float offset of save_mean[cout], save_invstd[cout]
+    float* rmean; float* rvar; float bn_momentum, bn_eps;
     size_t wg_off, wg_bytes;   // this layer's own weight-gradient slabs (3x3 layers; reduced for all layers at once)
     const float* drop;     // dropout mask applied to this layer's INPUT (NULL = none); see clhip_net_set_dropout
     long drop_stride;      // floats between the mask rows of consecutive samples (0 = one row shared by the batch)
@@ -42,6 +47,7 @@ struct NetPlan {
     size_t total_bytes;
     // derived offsets (bytes) inside ws
     size_t off_acts, off_idx, off_g0, off_g1, off_scratch, off_dlogits, off_loss, off_fcdz, off_wg;
+    int training;            // BatchNorm: batch statistics (1) or running statistics (0)
     int n_wg;                // 3x3 conv layers with deferred slab reduction (0: every layer reduces right away)
     // classifier = trailing Linear layers [fc_first, end): fused into three launches when it fits fc_chain.hip
     int fc_first;
@@ -109,6 +115,14 @@ int clhip_net_create(const clhip_layer_desc* descs, int n_layers, int max_batch,
             const bool vgg = L.ks == 3 && L.st == 1 && L.pd == 1;
             L.in_elems = (size_t)c * h * w;
             L.out_elems = (size_t)L.cout * L.oh * L.ow;
+            L.bn = descs[i].bn ? 1 : 0; L.bn_w_off = descs[i].bn_w_off; L.bn_b_off = descs[i].bn_b_off;
+            L.bn_momentum = 0.1f; L.bn_eps = 1e-5f;
+            if (L.bn) {
+                L.z_off = acts; acts += L.out_elems * max_batch;
+                L.stat_off = acts; acts += align_up(2 * (size_t)L.cout, 4);
+                const size_t bs = clhip_bn_ws(L.cout);
+                if (bs > scratch) scratch = bs;
+            }
             L.act_off = acts; acts += L.out_elems * max_batch;
             int oh = L.oh, ow = L.ow;
             if (L.pool) {
@@ -181,13 +195,16 @@ int clhip_net_create(const clhip_layer_desc* descs, int n_layers, int max_batch,
     p->n_wg = (n_wg >= 2 && n_wg <= CLHIP_WGRAD_JOBS_MAX) ? n_wg : 0;
     if (p->n_wg) off += align_up(wg_total, 256);
     p->total_bytes = off;
+    p->training = 1;
     p->overlap = false;
     p->side = nullptr;
     // Measured on small_VGG9 (N = 200): 2.59 ms per bench step with the overlap against 2.45 ms without (the two
     // MFMA-bound kernels only take slots from each other); AlexNet N = 128: 9.65 vs 9.76 ms.  Hence off unless
     // CLHIP_WGRAD_OVERLAP=1; results are identical either way (same kernels, same order per stream).
     const char* ov = getenv("CLHIP_WGRAD_OVERLAP");
-    if (ov && ov[0] == '1') {
+    bool any_bn = false;
+    for (const LayerPlan& L : p->layers) any_bn = any_bn || L.bn;
+    if (ov && ov[0] == '1' && !any_bn) {      // BatchNorm backward shares `scratch` with the weight-gradient launches
         // needs a device: plans made on a host without one (shape tests) simply stay single-stream
         if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) == hipSuccess) {
             p->overlap = true;
@@ -212,6 +229,21 @@ int clhip_net_set_dropout(void* handle, int layer, const float* mask, long row_s
     if (!p || layer <= 0 || layer >= (int)p->layers.size() || row_stride < 0) return CLHIP_EINVAL;
     p->layers[layer].drop = mask;
     p->layers[layer].drop_stride = row_stride;
+    return 0;
+}
+
+int clhip_net_set_bn(void* handle, int layer, float* running_mean, float* running_var, float momentum, float eps) {
+    NetPlan* p = static_cast<NetPlan*>(handle);
+    if (!p || layer < 0 || layer >= (int)p->layers.size() || !p->layers[layer].bn || !(eps > 0.f)) return CLHIP_EINVAL;
+    LayerPlan& L = p->layers[layer];
+    L.rmean = running_mean; L.rvar = running_var; L.bn_momentum = momentum; L.bn_eps = eps;
+    return 0;
+}
+
+int clhip_net_set_training(void* handle, int training) {
+    NetPlan* p = static_cast<NetPlan*>(handle);
+    if (!p) return CLHIP_EINVAL;
+    p->training = training ? 1 : 0;
     return 0;
 }
 
@@ -241,16 +273,25 @@ int clhip_net_forward(void* handle, const float* params, const float* x, int N, 
         }
         const bool vgg = L.type == 0 && L.ks == 3 && L.st == 1 && L.pd == 1;
         const bool pool22 = L.pool && L.pk == 2 && L.ps == 2;
-        if (L.type == 0 && !(vgg && (!L.pool || pool22))) {
-            // general geometry (AlexNet): separate conv (+bias, ReLU) and k x k / stride pool kernels
-            rc = vgg ? clhip_conv3x3_fwd(cur, params + L.w_off, params + L.b_off, y, N, L.cin, L.cout, L.h, L.w, L.relu, stream)
-                     : clhip_conv2d_fwd(cur, params + L.w_off, params + L.b_off, y, N, L.cin, L.h, L.w, L.cout, L.ks, L.ks, L.st,
-                                        L.pd, L.relu, stream);
+        if (L.type == 0 && (L.bn || !(vgg && (!L.pool || pool22)))) {
+            // general geometry (AlexNet) and BatchNorm layers: separate conv (+bias, ReLU), BatchNorm and pool kernels
+            float* zc = L.bn ? acts + L.z_off : y;
+            const int crelu = L.bn ? 0 : L.relu;
+            rc = vgg ? clhip_conv3x3_fwd(cur, params + L.w_off, params + L.b_off, zc, N, L.cin, L.cout, L.h, L.w, crelu, stream)
+                     : clhip_conv2d_fwd(cur, params + L.w_off, params + L.b_off, zc, N, L.cin, L.h, L.w, L.cout, L.ks, L.ks, L.st,
+                                        L.pd, crelu, stream);
             if (rc) return rc;
+            if (L.bn) {
+                float* st = acts + L.stat_off;
+                rc = clhip_bn_fwd(zc, params + L.bn_w_off, params + L.bn_b_off, L.rmean, L.rvar, y, st, st + L.cout, N, L.cout,
+                                  L.oh * L.ow, p->training, L.bn_momentum, L.bn_eps, L.relu, scratch, p->scratch_bytes, stream);
+                if (rc) return rc;
+            }
             cur = y;
             if (L.pool) {
                 float* pl = acts + L.pool_off;
-                rc = clhip_maxpool_fwd(y, pl, idx + L.idx_off, N * L.cout, L.oh, L.ow, L.pk, L.ps, stream);
+                rc = pool22 ? clhip_maxpool2_fwd(y, pl, idx + L.idx_off, N * L.cout, L.oh, L.ow, stream)
+                            : clhip_maxpool_fwd(y, pl, idx + L.idx_off, N * L.cout, L.oh, L.ow, L.pk, L.ps, stream);
                 if (rc) return rc;
                 cur = pl;
             }
@@ -375,7 +416,7 @@ int clhip_net_backward(void* handle, const float* params, float* grads, const fl
         const float* gy = gin;
         int gy_buf = gin_buf;
         bool wdone = false;
-        if (vgg && pool22 && i == 0) {
+        if (vgg && pool22 && i == 0 && !L.bn) {
             // no backward-data below the first layer: take the weight gradient straight from the pooled gradient +
             // argmax (fused max-pool backward), when the kernel supports the shape
             rc = on_side(i, gin_buf, [&](void* st) {
@@ -395,6 +436,15 @@ int clhip_net_backward(void* handle, const float* params, float* grads, const fl
                         : clhip_maxpool_bwd(gin, idx + L.idx_off, gout, N * L.cout, L.oh, L.ow, L.pk, L.ps, stream);
             if (rc) return rc;
             gy = gout; gy_buf = taken;
+        }
+        if (L.bn) {
+            // dy (w.r.t. the ReLU output) -> dz (w.r.t. the convolution output), in place; dgamma, dbeta
+            const float* st = acts + L.stat_off;
+            float* dzb = const_cast<float*>(gy);
+            if (gy_buf < 0) return CLHIP_EINVAL;      // a conv layer's incoming gradient always lives in g[0..1]
+            rc = clhip_bn_bwd(gy, acts + L.act_off, acts + L.z_off, params + L.bn_w_off, st, st + L.cout, dzb, grads + L.bn_w_off,
+                              grads + L.bn_b_off, N, L.cout, L.oh * L.ow, p->training, L.relu, scratch, p->scratch_bytes, stream);
+            if (rc) return rc;
         }
         if (!wdone) {
             rc = on_side(i, gy_buf, [&](void* st) {

@@ -20,22 +20,23 @@ CFG = {  # models/VGGSlim.py:19-23
 }
 
 
-def make_layers(cfg, in_channels=3):
+def make_layers(cfg, in_channels=3, batch_norm=False):
     layers = []
     for v in cfg:
         if v == "M":
             layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
         else:
-            layers += [nn.Conv2d(in_channels, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+            conv = nn.Conv2d(in_channels, v, kernel_size=3, padding=1)
+            layers += [conv, nn.BatchNorm2d(v), nn.ReLU(inplace=True)] if batch_norm else [conv, nn.ReLU(inplace=True)]
             in_channels = v
     return nn.Sequential(*layers)
 
 
 class VGGSlim(nn.Module):
     def __init__(self, config="small_VGG9", num_classes=20, init_weights=True, classifier_inputdim=128 * 4 * 4,
-                 classifier_dim1=128, classifier_dim2=128, cfg=None, dropout=False):
+                 classifier_dim1=128, classifier_dim2=128, cfg=None, dropout=False, batch_norm=False):
         super().__init__()
-        self.features = make_layers(cfg if cfg is not None else CFG[config])
+        self.features = make_layers(cfg if cfg is not None else CFG[config], batch_norm=batch_norm)
         self.avgpool = nn.Identity()
         if dropout:      # the '_DROP' models (VGGSlim.py:57-66): classifier indices 0..6, last_layer_idx = 6
             self.classifier = nn.Sequential(
@@ -56,6 +57,9 @@ class VGGSlim(nn.Module):
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
                 nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
             elif isinstance(m, nn.Linear):
                 nn.init.normal_(m.weight, 0, 0.01)
                 nn.init.constant_(m.bias, 0)
@@ -74,9 +78,16 @@ def _walk(x, mods, training, what):
         relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
         if isinstance(m, nn.Conv2d):
             ks, st, pd = m.kernel_size[0], m.stride[0], m.padding[0]
+            bn = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm2d) else None
+            if bn is not None:
+                relu = False
             x = ops.conv3x3_relu(x, m.weight, m.bias, relu) if (ks, st, pd) == (3, 1, 1) else \
                 ops.conv2d_relu(x, m.weight, m.bias, st, pd, relu)
             i += 2 if relu else 1
+            if bn is not None:
+                relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                x = ops.batchnorm_relu(x, bn, relu)
+                i += 2 if relu else 1
         elif isinstance(m, nn.Linear):
             x = ops.linear(x, m.weight, m.bias, relu)
             i += 2 if relu else 1
@@ -139,12 +150,10 @@ def parse_model_name(name, input_size=(64, 64), num_classes=20):
     base = name.split("_cl_")[0]
     dims = name.split("_cl_")[1].split("_") if "_cl_" in name else ["512", "512"]
     flags = name.split("_")
-    if "BN" in flags:
-        raise NotImplementedError("BatchNorm model variants (models/net.py:152-156) are not built yet")
     d1, d2 = int(dims[0]), int(dims[1])
     cfg = CFG[base]
     last = [v for v in cfg if v != "M"][-1]
     npool = sum(1 for v in cfg if v == "M")
     feat = last * (input_size[0] // 2 ** npool) * (input_size[1] // 2 ** npool)
     return VGGSlim(config=base, num_classes=num_classes, classifier_inputdim=feat,
-                   classifier_dim1=d1, classifier_dim2=d2, dropout="DROP" in flags)
+                   classifier_dim1=d1, classifier_dim2=d2, dropout="DROP" in flags, batch_norm="BN" in flags)

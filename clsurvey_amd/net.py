@@ -96,12 +96,12 @@ def _pair(v):
     return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
 
 
-def parse_net(model):
+def parse_net(model, with_bn=False):
     """([(kind, module, relu, pool)], {plan index: nn.Dropout in front of that layer}) from a module with the
     features / classifier structure of models/VGGSlim.py:27-76 or of torchvision's AlexNet (models/net.py:96-125).
     pool is False, True (2x2 stride 2) or (k, stride).  Raises on anything the static plan does not cover (BatchNorm
-    variants are SURVEY §8f 'next')."""
-    layers, drops = [], {}
+    variants: only with with_bn=True, which appends {plan index: nn.BatchNorm2d behind that convolution} to the result)."""
+    layers, drops, bns = [], {}, {}
     feats = list(model.features.children())
     i = 0
     pending = None
@@ -114,8 +114,17 @@ def parse_net(model):
             ks, st, pd = _pair(m.kernel_size), _pair(m.stride), _pair(m.padding)
             if ks[0] != ks[1] or st[0] != st[1] or pd[0] != pd[1] or m.groups != 1 or _pair(m.dilation) != (1, 1):
                 raise NotImplementedError("NetEngine: square kernels, symmetric stride / padding, no groups / dilation")
-            relu = i + 1 < len(feats) and isinstance(feats[i + 1], nn.ReLU)
-            j = i + (2 if relu else 1)
+            j = i + 1
+            if j < len(feats) and isinstance(feats[j], nn.BatchNorm2d):
+                bn = feats[j]
+                if not with_bn:
+                    raise NotImplementedError("this caller does not handle BatchNorm2d layers")
+                if not bn.affine or not bn.track_running_stats or bn.momentum is None or bn.num_features != m.out_channels:
+                    raise NotImplementedError("NetEngine: BatchNorm2d must be affine with running statistics and a momentum")
+                bns[len(layers)] = bn
+                j += 1
+            relu = j < len(feats) and isinstance(feats[j], nn.ReLU)
+            j += 1 if relu else 0
             pool = False
             if j < len(feats) and isinstance(feats[j], nn.MaxPool2d):
                 mp = feats[j]
@@ -149,7 +158,7 @@ def parse_net(model):
             raise NotImplementedError("NetEngine: unsupported classifier module %r" % (m,))
     if pending is not None or 0 in drops:
         raise NotImplementedError("NetEngine: Dropout must sit in front of a layer other than the first")
-    return layers, drops
+    return (layers, drops, bns) if with_bn else (layers, drops)
 
 
 def parse_vgg(model):
@@ -171,9 +180,9 @@ class NetEngine:
         Linear over head parameters laid out back to back)."""
         self.model = model
         self.device = torch.device(device)
-        self.drops = {}
+        self.drops, self.bns = {}, {}
         if layers is None:
-            self.layers, self.drops = parse_net(model)
+            self.layers, self.drops, self.bns = parse_net(model, with_bn=True)
             specs = [(kind, m.weight, m.bias, m.in_channels if kind == "conv" else m.in_features,
                       m.out_channels if kind == "conv" else m.out_features, relu, pool) +
                      ((conv_geometry(m),) if kind == "conv" else ()) for kind, m, relu, pool in self.layers]
@@ -196,6 +205,10 @@ class NetEngine:
                 d.ksize, d.stride, d.pad = (int(v) for v in (sp[7] if len(sp) > 7 else (w.shape[2], 1, w.shape[2] // 2)))
             d.w_off = self.arena.slot(w)[0]
             d.b_off = self.arena.slot(b)[0]
+        for li, bn in self.bns.items():
+            descs[li].bn = 1
+            descs[li].bn_w_off = self.arena.slot(bn.weight)[0]
+            descs[li].bn_b_off = self.arena.slot(bn.bias)[0]
         self.max_batch = int(max_batch)
         self.in_shape = tuple(in_shape)
         h = C.c_void_p()
@@ -206,6 +219,13 @@ class NetEngine:
         self.n_classes = L.clhip_net_num_classes(h)
         self.ws = torch.empty(L.clhip_net_workspace_bytes(h), dtype=torch.uint8, device=self.device)
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        for li, bn in self.bns.items():      # running statistics stay module buffers (pickled with the model), on the device
+            for name in ("running_mean", "running_var", "num_batches_tracked"):
+                buf = getattr(bn, name)
+                buf.data = buf.data.to(self.device).contiguous()
+            check(L.clhip_net_set_bn(h, li, bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps)),
+                  "clhip_net_set_bn")
+        self._training = None
         self.in_elems = {}
         shp = self.in_shape
         if self.drops:
@@ -239,6 +259,18 @@ class NetEngine:
             ptr, stride = mask.data_ptr(), (mask.shape[-1] if mask.dim() == 2 else 0)
         check(_lib.lib().clhip_net_set_dropout(self._h, int(layer), ptr, int(stride)), "clhip_net_set_dropout")
 
+    def _mode(self):
+        """nn.Module.train / eval -> the plan's BatchNorm mode; num_batches_tracked as nn.BatchNorm2d.forward counts it."""
+        if not self.bns:
+            return
+        training = bool(self.model.training)
+        if training != self._training:
+            check(_lib.lib().clhip_net_set_training(self._h, int(training)), "clhip_net_set_training")
+            self._training = training
+        if training:
+            for bn in self.bns.values():
+                bn.num_batches_tracked += 1
+
     def _auto_drop(self, n):
         """nn.Dropout semantics (fresh Bernoulli(1-p)/(1-p) mask per element per pass while model.training, identity in
         eval mode) for the Dropout modules of the plan; drawn with torch's device generator."""
@@ -268,6 +300,7 @@ class NetEngine:
 
     def forward(self, x, params=None):
         self._check_x(x)
+        self._mode()
         self._auto_drop(x.shape[0])
         logits = torch.empty((x.shape[0], self.n_classes), dtype=torch.float32, device=self.device)
         check(_lib.lib().clhip_net_forward(self._h, (params if params is not None else self.arena.theta).data_ptr(),
@@ -288,6 +321,7 @@ class NetEngine:
         """forward + loss (+ backward into arena.grad). Returns (loss[1] device tensor, logits|None).
         No host synchronisation happens here."""
         self._check_x(x)
+        self._mode()
         self._auto_drop(x.shape[0])
         logits = torch.empty((x.shape[0], self.n_classes), dtype=torch.float32, device=self.device) if want_logits else None
         o1, nc = (class_slice[0], class_slice[1] - class_slice[0]) if class_slice is not None else (0, 0)

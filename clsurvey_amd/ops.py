@@ -142,6 +142,36 @@ def conv2d_bwd_weight(x, dy, ksize, stride=1, pad=0, need_bias=True):
     return dw, db
 
 
+# ------------------------------------------------------------------ batch norm
+def bn_fwd(z, gamma, beta, running_mean, running_var, training, momentum, eps, relu):
+    """nn.BatchNorm2d (+ReLU): returns (y, save_mean, save_invstd); training mode moves the running statistics in place."""
+    _chk(z, gamma, beta, running_mean, running_var)
+    N, C, H, W = z.shape
+    y = torch.empty_like(z)
+    mean = torch.empty(C, dtype=torch.float32, device=z.device)
+    invstd = torch.empty(C, dtype=torch.float32, device=z.device)
+    L = _lib.lib()
+    ws = workspace(L.clhip_bn_ws(C), z.device, "bn")
+    check(L.clhip_bn_fwd(_ptr(z), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), _ptr(y), _ptr(mean), _ptr(invstd),
+                         N, C, H * W, int(training), float(momentum), float(eps), int(relu), _ptr(ws), ws.numel(), _stream()),
+          "clhip_bn_fwd")
+    return y, mean, invstd
+
+
+def bn_bwd(dy, y, z, gamma, mean, invstd, training, relu):
+    """(dz, dgamma, dbeta) of bn_fwd."""
+    _chk(dy, y, z, gamma, mean, invstd)
+    N, C, H, W = z.shape
+    dz = torch.empty_like(z)
+    dgamma = torch.empty(C, dtype=torch.float32, device=z.device)
+    dbeta = torch.empty(C, dtype=torch.float32, device=z.device)
+    L = _lib.lib()
+    ws = workspace(L.clhip_bn_ws(C), z.device, "bn")
+    check(L.clhip_bn_bwd(_ptr(dy), _ptr(y), _ptr(z), _ptr(gamma), _ptr(mean), _ptr(invstd), _ptr(dz), _ptr(dgamma), _ptr(dbeta),
+                         N, C, H * W, int(training), int(relu), _ptr(ws), ws.numel(), _stream()), "clhip_bn_bwd")
+    return dz, dgamma, dbeta
+
+
 # ------------------------------------------------------------------ pooling
 def maxpool_fwd(x, k, stride):
     _chk(x)
@@ -329,6 +359,23 @@ class Conv2dReLUFn(torch.autograd.Function):
         return dx, dw, db, None, None, None
 
 
+class BatchNormReLUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, gamma, beta, running_mean, running_var, training, momentum, eps, relu):
+        z = z.contiguous()
+        y, mean, invstd = bn_fwd(z, gamma.contiguous(), beta.contiguous(), running_mean, running_var, training, momentum, eps, relu)
+        ctx.cfg = (bool(training), bool(relu))
+        ctx.save_for_backward(z, y, gamma, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, y, gamma, mean, invstd = ctx.saved_tensors
+        training, relu = ctx.cfg
+        dz, dgamma, dbeta = bn_bwd(dy.contiguous(), y, z, gamma.contiguous(), mean, invstd, training, relu)
+        return dz, dgamma, dbeta, None, None, None, None, None, None
+
+
 class MaxPoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, k, stride):
@@ -402,6 +449,13 @@ def maxpool2(x):
 
 def conv2d_relu(x, w, b, stride=1, pad=0, relu=True):
     return Conv2dReLUFn.apply(x, w, b, stride, pad, relu)
+
+
+def batchnorm_relu(z, bn, relu=True):
+    """nn.BatchNorm2d module `bn` (+ReLU) on the HIP kernels; follows bn.training like the module itself."""
+    if bn.training:
+        bn.num_batches_tracked += 1
+    return BatchNormReLUFn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum, bn.eps, relu)
 
 
 def maxpool(x, k, stride):

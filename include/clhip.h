@@ -74,6 +74,19 @@ int clhip_maxpool2_bwd(const float* dy, const uint8_t* idx_u8, float* dx, int NC
 int clhip_maxpool_fwd(const float* x, float* y, uint8_t* idx_u8, int NC, int H, int W, int k, int stride, void* stream);
 int clhip_maxpool_bwd(const float* dy, const uint8_t* idx_u8, float* dx, int NC, int H, int W, int k, int stride, void* stream);
 
+/* nn.BatchNorm2d (+ the ReLU behind it) of the '_BN' model variants (models/VGGSlim.py:27-40, models/net.py:152-156),
+ * NCHW, HW = H*W.  training != 0: batch mean / biased variance, running_mean / running_var (may be NULL) moved by
+ * `momentum` with the unbiased variance, as torch; training == 0: the running statistics.  save_mean / save_invstd [C]
+ * are what the backward needs.  ws: clhip_bn_ws(C) bytes.  Backward: dy is the gradient w.r.t. y (post-ReLU when relu),
+ * dz may alias dy; dgamma / dbeta (may be NULL) are overwritten. */
+size_t clhip_bn_ws(int C);
+int clhip_bn_fwd(const float* z, const float* gamma, const float* beta, float* running_mean, float* running_var, float* y,
+                 float* save_mean, float* save_invstd, int N, int C, int HW, int training, float momentum, float eps, int relu,
+                 void* ws, size_t ws_bytes, void* stream);
+int clhip_bn_bwd(const float* dy, const float* y, const float* z, const float* gamma, const float* save_mean,
+                 const float* save_invstd, float* dz, float* dgamma, float* dbeta, int N, int C, int HW, int training, int relu,
+                 void* ws, size_t ws_bytes, void* stream);
+
 /* General convolution (AlexNet: Conv2d(3,64,11,4,2), Conv2d(64,192,5,1,2), 3x3 pad 1 with 192/384/256 channels —
  * models/net.py:96-125 via torchvision.models.alexnet), NCHW / KCRS, zero padding `pad`, stride `stride`:
  * forward (+bias, optional ReLU), backward-data (optional ReLU mask relu_src > 0), backward-weight (+ db) with
@@ -218,6 +231,8 @@ typedef struct {
     long w_off, b_off;
     int ksize, stride, pad;   /* conv geometry; ksize 0 means the VGG default 3x3, stride 1, pad 1 */
     int pool_k, pool_s;
+    int bn;                   /* conv layers: 1 = BatchNorm2d between the convolution and the ReLU (clhip_net_set_bn) */
+    long bn_w_off, bn_b_off;  /* float offsets of the BatchNorm weight / bias in the parameter arena */
 } clhip_layer_desc;
 
 int clhip_net_create(const clhip_layer_desc* layers, int n_layers, int max_batch, int in_c, int in_h,
@@ -227,6 +242,11 @@ int clhip_net_create(const clhip_layer_desc* layers, int n_layers, int max_batch
  * INPUT of plan layer `layer` (> 0) in forward and the gradient w.r.t. it in backward.  mask [N][in_elems] with
  * row_stride floats between samples, row_stride 0 = one row for the whole batch; NULL = off (eval mode). */
 int clhip_net_set_dropout(void* handle, int layer, const float* mask, long row_stride);
+/* BatchNorm buffers of plan layer `layer` (device fp32 [cout]; updated in place by training-mode forwards) and the
+ * module's momentum / eps; clhip_net_set_training switches every BatchNorm layer between batch and running statistics
+ * (nn.Module.train / eval). */
+int clhip_net_set_bn(void* handle, int layer, float* running_mean, float* running_var, float momentum, float eps);
+int clhip_net_set_training(void* handle, int training);
 void clhip_net_destroy(void* handle);
 size_t clhip_net_workspace_bytes(void* handle);
 int clhip_net_num_classes(void* handle);

@@ -30,6 +30,8 @@ def forward(model, x, masks=None):
             di += 1
         elif isinstance(m, nn.Conv2d):
             x = F.conv2d(x, m.weight, m.bias, m.stride, m.padding)
+        elif isinstance(m, nn.BatchNorm2d):      # '_BN' variants (models/VGGSlim.py:35-36): the module's own semantics
+            x = F.batch_norm(x, m.running_mean, m.running_var, m.weight, m.bias, m.training, m.momentum, m.eps)
         elif isinstance(m, nn.ReLU):
             x = F.relu(x)
         elif isinstance(m, nn.MaxPool2d):

@@ -100,5 +100,9 @@ def test_parse_drop_variant_on_cpu():
     m = models.parse_model_name("base_VGG9_cl_512_512_DROP", (64, 64), 20)
     layers, drops = net.parse_net(m)
     assert len(layers) == 9 and sorted(drops) == [7, 8] and len(m.classifier._modules) - 1 == 6
+    bn = models.parse_model_name("base_VGG9_cl_512_512_DROP_BN", (64, 64), 20)
     with pytest.raises(NotImplementedError):
-        models.parse_model_name("base_VGG9_cl_512_512_DROP_BN", (64, 64), 20)
+        net.parse_net(bn)                     # callers that do not handle BatchNorm say so
+    layers, drops, bns = net.parse_net(bn, with_bn=True)
+    assert sorted(bns) == [0, 1, 2, 3, 4, 5] and sorted(drops) == [7, 8] and all(r for _, _, r, _ in layers[:6])
+    assert [k for k, *_ in layers] == ["conv"] * 6 + ["fc"] * 3
