@@ -127,8 +127,8 @@ __global__ __launch_bounds__(256) void conv2d_gemm_kernel(const float* __restric
             for (int j = 0; j < IT; ++j) {
                 const int e = tid + 256 * j, kl = e / TM, ml = e - kl * TM;
                 const int m = m0 + ml, k = k0 + kl;
-                int off = CLHIP_OOB;
-                if (m < M && k < k_end) { const int ko = k / RS, rs = k - ko * RS; off = ((ko * p.C + m) * RS + rs) * 4; }
+                // kl = tid / 64 + 4 j: the same reduction index as B element j, whose (channel, tap) is carried in registers
+                const int off = (m < M && k < k_end) ? ((bch[j] * p.C + m) * RS + brs[j]) * 4 : CLHIP_OOB;
                 ar[j] = clhip_buf_load(rs_w, off, 0);
             }
 #pragma unroll
@@ -138,7 +138,10 @@ __global__ __launch_bounds__(256) void conv2d_gemm_kernel(const float* __restric
                 if (k < k_end && pix_base != CLHIP_OOB) {
                     const int rs = tab_rs[brs[j]];
                     const int th = pix_h - (rs >> 8), tw = pix_w - (rs & 255);
-                    if (th >= 0 && tw >= 0) {
+                    if (p.st == 1) {                 // uniform branch: no integer divisions on the stride-1 layers
+                        if ((unsigned)th < (unsigned)p.OH && (unsigned)tw < (unsigned)p.OW)
+                            off = (pix_base + bch[j] * OHW + th * p.OW + tw) * 4;
+                    } else if (th >= 0 && tw >= 0) {
                         const int oh = th / p.st, ow = tw / p.st;
                         if (oh * p.st == th && ow * p.st == tw && oh < p.OH && ow < p.OW)
                             off = (pix_base + bch[j] * OHW + oh * p.OW + ow) * 4;
