@@ -77,6 +77,12 @@ SIGNATURES = {
     "clhip_net_set_dropout": (_i, [_p, _i, _p, _l]),
     "clhip_net_set_bn": (_i, [_p, _i, _p, _p, _f, _f]),
     "clhip_net_set_training": (_i, [_p, _i]),
+    "clhip_net_layer_input": (_i, [_p, _i, _p, _p]),
+    "clhip_net_set_input_grad": (_i, [_p, _i, _p]),
+    "clhip_sigmoid_fwd": (_i, [_p, _p, _z, _p]),
+    "clhip_sigmoid_bwd": (_i, [_p, _p, _p, _z, _p]),
+    "clhip_mse_mean": (_i, [_p, _p, _z, _f, _p, _p, _p]),
+    "clhip_adadelta_step": (_i, [_p, _p, _p, _p, _z, _f, _f, _f, _f, _p]),
     "clhip_bn_ws": (_z, [_i]),
     "clhip_bn_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _i, _p, _z, _p]),
     "clhip_bn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),

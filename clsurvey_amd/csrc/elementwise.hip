@@ -171,9 +171,90 @@ struct ReluBwd {
     }
 };
 
+// EBLL (methods/EBLL/AlexNet_EBLL.py:13-15: Linear + Sigmoid encoder; Finetune_SGD_EBLL.py:497: optim.Adadelta)
+struct SigmoidFwd {
+    const float* x; float* y;
+    __device__ __forceinline__ void scalar(size_t i) const { y[i] = 1.f / (1.f + expf(-x[i])); }
+    __device__ __forceinline__ void vec(size_t i) const {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) scalar(4 * i + t);
+    }
+};
+struct SigmoidBwd {
+    const float* dy; const float* y; float* dx;
+    __device__ __forceinline__ void scalar(size_t i) const { const float v = y[i]; dx[i] = dy[i] * v * (1.f - v); }
+    __device__ __forceinline__ void vec(size_t i) const {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) scalar(4 * i + t);
+    }
+};
+// torch.optim.Adadelta (rho, eps, lr, weight_decay): square_avg = rho sq + (1 - rho) g^2; delta = sqrt(acc_delta + eps) /
+// sqrt(square_avg + eps) * g; acc_delta = rho acc_delta + (1 - rho) delta^2; theta -= lr * delta
+struct Adadelta {
+    float* theta; const float* grad; float* sq; float* acc; float lr, rho, eps, wd;
+    __device__ __forceinline__ void scalar(size_t i) const {
+        float g = grad[i];
+        const float th = theta[i];
+        if (wd != 0.f) g = g + wd * th;
+        const float s = sq[i] * rho + (1.f - rho) * g * g;
+        const float a = acc[i];
+        const float delta = sqrtf(a + eps) / sqrtf(s + eps) * g;
+        sq[i] = s;
+        acc[i] = a * rho + (1.f - rho) * delta * delta;
+        theta[i] = th - lr * delta;
+    }
+    __device__ __forceinline__ void vec(size_t i) const {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) scalar(4 * i + t);
+    }
+};
+
+// nn.MSELoss() (mean over all elements) of a against b, with d loss / d a * scale; one block, fixed order
+__global__ __launch_bounds__(1024) void mse_mean_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n,
+                                                        float scale, float* __restrict__ da, float* __restrict__ loss_out) {
+    __shared__ double red[1024];
+    double s = 0.0;
+    const float g = 2.f * scale / (float)n;
+    for (size_t i = threadIdx.x; i < n; i += 1024) {
+        const float d = a[i] - b[i];
+        s += (double)d * (double)d;
+        if (da) da[i] = g * d;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss_out[0] = (float)(red[0] / (double)n);
+}
+
 }  // namespace
 
 extern "C" {
+
+int clhip_sigmoid_fwd(const float* x, float* y, size_t n, void* stream) {
+    if (!x || !y) return CLHIP_EINVAL;
+    return ew_launch(n, false, SigmoidFwd{x, y}, as_stream(stream));
+}
+
+int clhip_sigmoid_bwd(const float* dy, const float* y, float* dx, size_t n, void* stream) {
+    if (!dy || !y || !dx) return CLHIP_EINVAL;
+    return ew_launch(n, false, SigmoidBwd{dy, y, dx}, as_stream(stream));
+}
+
+int clhip_adadelta_step(float* theta, const float* grad, float* square_avg, float* acc_delta, size_t n, float lr, float rho,
+                        float eps, float weight_decay, void* stream) {
+    if (!theta || !grad || !square_avg || !acc_delta) return CLHIP_EINVAL;
+    return ew_launch(n, false, Adadelta{theta, grad, square_avg, acc_delta, lr, rho, eps, weight_decay}, as_stream(stream));
+}
+
+int clhip_mse_mean(const float* a, const float* b, size_t n, float grad_scale, float* da, float* loss_out, void* stream) {
+    if (!a || !b || !loss_out || n == 0) return CLHIP_EINVAL;
+    hipLaunchKernelGGL(mse_mean_kernel, dim3(1), dim3(1024), 0, as_stream(stream), a, b, n, grad_scale, da, loss_out);
+    CLHIP_LAUNCH_CHECK();
+    return 0;
+}
 
 int clhip_reg_sgd_step(float* theta, const float* grad, const float* omega, const float* init_val,
                        float* buf, size_t n, float reg_lambda, float lr, float momentum, float wd,

@@ -32,6 +32,7 @@ struct LayerPlan {
     size_t stat_off;       // bn: float offset of save_mean[cout], save_invstd[cout]
     float* rmean; float* rvar; float bn_momentum, bn_eps;
     size_t wg_off, wg_bytes;   // this layer's own weight-gradient slabs (3x3 layers; reduced for all layers at once)
+    const float* extra_grad;   // added to the gradient w.r.t. this layer's input (side branches: clhip_net_set_input_grad)
     const float* drop;     // dropout mask applied to this layer's INPUT (NULL = none); see clhip_net_set_dropout
     long drop_stride;      // floats between the mask rows of consecutive samples (0 = one row shared by the batch)
 };
@@ -74,6 +75,16 @@ __global__ void drop_scale_kernel(float* __restrict__ h, const float* __restrict
         const size_t n = i / feat, f = i - n * feat;
         h[i] *= mask[n * stride + f];
     }
+}
+
+__global__ void add_inplace_kernel(float* __restrict__ a, const float* __restrict__ b, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a[i] += b[i];
+}
+
+int add_inplace(float* a, const float* b, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, s, a, b, n);
+    CLHIP_LAUNCH_CHECK();
+    return 0;
 }
 
 int drop_scale(float* h, const float* mask, long stride, size_t feat, int N, hipStream_t s) {
@@ -240,6 +251,22 @@ int clhip_net_set_bn(void* handle, int layer, float* running_mean, float* runnin
     return 0;
 }
 
+int clhip_net_layer_input(void* handle, int layer, size_t* ws_float_off, size_t* in_elems) {
+    NetPlan* p = static_cast<NetPlan*>(handle);
+    if (!p || layer <= 0 || layer >= (int)p->layers.size() || !ws_float_off || !in_elems) return CLHIP_EINVAL;
+    const LayerPlan& P = p->layers[layer - 1];
+    *ws_float_off = p->off_acts / sizeof(float) + ((P.type == 0 && P.pool) ? P.pool_off : P.act_off);
+    *in_elems = p->layers[layer].in_elems;
+    return 0;
+}
+
+int clhip_net_set_input_grad(void* handle, int layer, const float* extra) {
+    NetPlan* p = static_cast<NetPlan*>(handle);
+    if (!p || layer <= 0 || layer >= (int)p->layers.size()) return CLHIP_EINVAL;
+    p->layers[layer].extra_grad = extra;
+    return 0;
+}
+
 int clhip_net_set_training(void* handle, int training) {
     NetPlan* p = static_cast<NetPlan*>(handle);
     if (!p) return CLHIP_EINVAL;
@@ -403,6 +430,10 @@ int clhip_net_backward(void* handle, const float* params, float* grads, const fl
                     rc = drop_scale(gout, L.drop, L.drop_stride, L.in_elems, N, main_s);
                     if (rc) return rc;
                 }
+                if (L.extra_grad) {
+                    rc = add_inplace(gout, L.extra_grad, L.in_elems * (size_t)N, main_s);
+                    if (rc) return rc;
+                }
             }
             if (p->fc_fused && i == p->fc_first) {
                 // all dz_l are in place: dW_l, db_l of every Linear layer in one launch
@@ -467,6 +498,10 @@ int clhip_net_backward(void* handle, const float* params, float* grads, const fl
             gin = gout; gin_buf = taken;
             if (L.drop) {
                 rc = drop_scale(gout, L.drop, L.drop_stride, L.in_elems, N, main_s);
+                if (rc) return rc;
+            }
+            if (L.extra_grad) {
+                rc = add_inplace(gout, L.extra_grad, L.in_elems * (size_t)N, main_s);
                 if (rc) return rc;
             }
         }

@@ -30,13 +30,27 @@ def fine_tune_SGD(dset_dataloader, cumsum_dset_sizes, dset_classes, model_path, 
         model_ft.model.classifier = torch.nn.Sequential(
             *list(model_ft.model.classifier.children())[:model_ft.last_layer_name + 1])
         model_ft = model_ft.model
+    from .ebll import AlexNet_EBLL
+    engine_params = None
+    if isinstance(model_ft, AlexNet_EBLL):                        # main_SGD.py:54-56: stays a wrapper, in finetune mode
+        model_ft.classifier = torch.nn.Sequential(*list(model_ft.classifier.children())[:model_ft.last_layer_name + 1])
+        model_ft.set_finetune_mode(True)
     if replace_last_classifier_layer:
         labels_per_task = [len(task_labels) for task_labels in dset_classes["train"]]
         tc.replace_head(model_ft, sum(labels_per_task))          # utils.py:68-72
     model_ft = model_ft.to(device)
     any_loader = dset_dataloader["train"]
-    engine = tc.engine_for(model_ft, dset_dataloader, batch_size or any_loader.batch_size, device)
-    optimizer_ft = SGD(model_ft.parameters(), lr, momentum=0.9, weight_decay=weight_decay)
+    if isinstance(model_ft, AlexNet_EBLL):
+        # the frozen encoders get no gradient in the reference (p.grad is None: SGD skips them, weight decay included):
+        # keep them out of the arena the fused SGD kernel sweeps
+        from ..net import NetEngine
+        engine_params = list(model_ft.features.parameters()) + list(model_ft.classifier.parameters())
+        engine = NetEngine(model_ft, batch_size or any_loader.batch_size, tuple(any_loader.x.shape[1:]), device,
+                           params=engine_params)
+    else:
+        engine = tc.engine_for(model_ft, dset_dataloader, batch_size or any_loader.batch_size, device)
+    optimizer_ft = SGD(engine_params if engine_params is not None else model_ft.parameters(), lr, momentum=0.9,
+                       weight_decay=weight_decay)
     return tc.train_model(model_ft, engine, optimizer_ft, lr, dset_dataloader, cumsum_dset_sizes, num_epochs, exp_dir,
                           resume, saving_freq=freq, step_fn=optimizer_ft.step, save_models_mode=save_models_mode,
                           abort_on_bad_loss=False)

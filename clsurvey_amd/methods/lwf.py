@@ -36,30 +36,11 @@ class AlexNet_LwF(nn.Module):
         self.finetune_mode = mode
 
     def forward(self, x):
-        mods = list(self.model.features.children())
-        i = 0
-        while i < len(mods):
-            m = mods[i]
-            if isinstance(m, nn.Conv2d):
-                relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
-                x = ops.conv3x3_relu(x, m.weight, m.bias, relu)
-                i += 2 if relu else 1
-            elif isinstance(m, nn.MaxPool2d):
-                x = ops.maxpool2(x)
-                i += 1
-            else:
-                raise NotImplementedError(type(m))
+        from ..models import _walk
+        x = _walk(x, list(self.model.features.children()), self.training, "LwF features")
         x = torch.flatten(x, 1)
         cls = list(self.model.classifier.children())
-        i = 0
-        while i < self.last_layer_name:
-            m = cls[i]
-            if isinstance(m, nn.Linear):
-                relu = i + 1 < self.last_layer_name and isinstance(cls[i + 1], nn.ReLU)
-                x = ops.linear(x, m.weight, m.bias, relu)
-                i += 2 if relu else 1
-            else:
-                raise NotImplementedError(type(m))
+        x = _walk(x, cls[:self.last_layer_name], self.training, "LwF classifier")
         outputs = [ops.linear(x, h.weight, h.bias, False) for h in cls[self.last_layer_name:]]
         if self.finetune_mode:
             assert len(outputs) == 1
@@ -71,7 +52,7 @@ def lwf_plan(wrapper):
     """(layers, params, head_sizes) for NetEngine: conv / shared Linear layers as they are, all heads as ONE Linear whose
     rows are the heads' rows back to back (arena order: ..., head weights, head biases)."""
     from ..net import parse_net, conv_geometry
-    m = wrapper.model
+    m = getattr(wrapper, "model", wrapper)          # AlexNet_LwF holds the net in .model, AlexNet_EBLL is the net
     cls = list(m.classifier.children())
     shared = nn.Module()
     shared.features = m.features
@@ -112,9 +93,11 @@ class LwfEngine:
     def logits(self, x):
         return self.engine.forward(x)
 
-    def step(self, x, y, teacher_logits, T, reg_lambda, backward=True, stats=None):
-        """Returns loss2 (device: [task CE, lambda * sum distillation]). teacher_logits: [N][sum of the OLD head sizes]."""
-        z = self.engine.forward(x)
+    def step(self, x, y, teacher_logits, T, reg_lambda, backward=True, stats=None, z=None):
+        """Returns loss2 (device: [task CE, lambda * sum distillation]). teacher_logits: [N][sum of the OLD head sizes];
+        z: the logits of a forward the caller has just run on this engine for the same x (else it runs here)."""
+        if z is None:
+            z = self.engine.forward(x)
         n = x.shape[0]
         dl = self.dlogits[:n]
         check(_lib.lib().clhip_lwf_loss(

@@ -16,6 +16,7 @@ from enum import Enum, auto
 import torch
 
 from ..data import DeviceLoader, TensorTaskDataset
+from . import ebll as trainEBLL
 from . import ewc as trainEWC
 from . import finetune as trainFT
 from . import gem_main as trainRehearsal
@@ -537,7 +538,91 @@ class LWF(Method):
         return Finetune.inference_eval(args, manager)        # the shared SI first-task model
 
 
-_REGISTRY = {c.name: c for c in (EWC, MAS, SI, Finetune, PackNet, HAT, GEM, IMM, LWF)}
+class EBLL(Method):
+    """method.py:822-936 (DATA_BASED): LwF + a code loss through one under-complete autoencoder per finished task."""
+    name = "EBLL"
+    eval_name = name
+    category = Category.DATA_BASED
+    extra_hyperparams_count = 2
+    hyperparams = OrderedDict({"reg_lambda": 10, "ebll_reg_alpha": 1})
+    static_hyperparams = OrderedDict({"autoencoder_lr": [0.01], "autoencoder_epochs": 50,
+                                      "encoder_alphas": [1e-1, 1e-2], "encoder_dims": [100, 300]})
+
+    @staticmethod
+    def grid_train(args, manager, lr):
+        return Finetune.grid_train(args, manager, lr)
+
+    def prestep(self, args, manager):
+        print("AUTOENCODER PHASE: for prev task ", args.task_counter - 1)
+        manager.autoencoder_model_path = self._autoencoder_grid(args, manager)
+        print("AUTOENCODER PHASE DONE")
+
+    def _autoencoder_grid(self, args, manager):
+        """method.py:842-908: (dim, alpha, lr) grid of autoencoders on the previous task, best by validation accuracy of
+        the previous model's classifier on the reconstructed features; checkpointed per grid node."""
+        import itertools
+        import shutil
+        parent = os.path.join(manager.parent_exp_dir, "task_" + str(args.task_counter - 1), "ENCODER_TRAINING")
+        processed = {"header": ("dim", "alpha", "lr")}
+        ckpt = os.path.join(parent, "grid_checkpoint.pth")
+        if os.path.exists(ckpt):
+            processed = torch.load(ckpt, weights_only=False)
+        best_path, best_acc = None, 0
+        for it in itertools.product(self.static_hyperparams["encoder_dims"], self.static_hyperparams["encoder_alphas"],
+                                    self.static_hyperparams["autoencoder_lr"]):
+            dim, alpha, lr = it
+            exp_dir = os.path.join(parent, "dim={}_alpha={}_lr={}".format(str(dim), str(alpha), lr))
+            if it in processed:
+                acc = processed[it]
+            else:
+                os.makedirs(exp_dir, exist_ok=True)
+                t0 = time.time()
+                _, acc = trainEBLL.fine_tune_Adam_Autoencoder(dataset_path=args.previous_task_dataset_path,
+                                                              previous_task_model_path=manager.previous_task_model_path,
+                                                              exp_dir=exp_dir, batch_size=args.batch_size,
+                                                              num_epochs=self.static_hyperparams["autoencoder_epochs"], lr=lr,
+                                                              alpha=alpha, last_layer_name=args.classifier_heads_starting_idx,
+                                                              auto_dim=dim, device=getattr(args, "device", "cuda"))
+                args.presteps_elapsed_time += time.time() - t0
+                processed[it] = acc
+                torch.save(processed, ckpt)
+            print("autoencoder acc={}".format(str(acc)))
+            if acc > best_acc:
+                if best_path is not None:
+                    shutil.rmtree(best_path, ignore_errors=True)
+                best_acc, best_path = acc, exp_dir
+            else:
+                shutil.rmtree(exp_dir, ignore_errors=True)
+        if best_acc < 0.40:
+            print("[WARNING] Auto-encoder grid not sufficient: max attainable acc = {}".format(str(best_acc)))
+        return os.path.join(best_path, "best_model.pth.tar")
+
+    def train(self, args, manager, hyperparams):
+        return trainEBLL.fine_tune_SGD_EBLL(dataset_path=manager.current_task_dataset_path,
+                                            previous_task_model_path=manager.previous_task_model_path,
+                                            autoencoder_model_path=manager.autoencoder_model_path,
+                                            init_model_path=getattr(args, "init_model_path", ""),
+                                            exp_dir=manager.heuristic_exp_dir, batch_size=args.batch_size,
+                                            num_epochs=args.num_epochs, lr=args.lr, init_freeze=0,
+                                            reg_alpha=hyperparams["ebll_reg_alpha"], weight_decay=args.weight_decay,
+                                            saving_freq=args.saving_freq, reg_lambda=hyperparams["reg_lambda"],
+                                            device=getattr(args, "device", "cuda"))
+
+    def get_output(self, images, args):
+        with torch.no_grad():
+            outputs = args.model(images)
+        if isinstance(outputs, tuple):                    # (head outputs, codes); the SI first-task model returns logits
+            outputs = outputs[0]
+        if isinstance(outputs, list):
+            outputs = outputs[args.current_head_idx]
+        return outputs
+
+    @staticmethod
+    def inference_eval(args, manager):
+        return LWF.inference_eval(args, manager)
+
+
+_REGISTRY = {c.name: c for c in (EWC, MAS, SI, Finetune, PackNet, HAT, GEM, IMM, LWF, EBLL)}
 
 
 def parse(method_name):

@@ -259,6 +259,22 @@ class NetEngine:
             ptr, stride = mask.data_ptr(), (mask.shape[-1] if mask.dim() == 2 else 0)
         check(_lib.lib().clhip_net_set_dropout(self._h, int(layer), ptr, int(stride)), "clhip_net_set_dropout")
 
+    def layer_input(self, layer, n):
+        """[n][in_elems] view (no copy) of the activation that feeds plan layer `layer` (> 0), valid after a forward."""
+        off, elems = C.c_size_t(), C.c_size_t()
+        check(_lib.lib().clhip_net_layer_input(self._h, int(layer), C.byref(off), C.byref(elems)), "clhip_net_layer_input")
+        lo = off.value * 4
+        return self.ws[lo:lo + n * elems.value * 4].view(torch.float32).view(n, elems.value)
+
+    def set_input_grad(self, layer, extra):
+        """extra [N][in_elems] (or None) is added to the gradient w.r.t. layer_input(layer) in the following backward
+        passes; if that activation is a ReLU output the caller masks extra with (activation > 0) first."""
+        if extra is not None and (not extra.is_cuda or extra.dtype != torch.float32 or not extra.is_contiguous()):
+            raise RuntimeError("set_input_grad needs a contiguous fp32 HIP tensor")
+        self._extra = extra          # keep it alive
+        check(_lib.lib().clhip_net_set_input_grad(self._h, int(layer), extra.data_ptr() if extra is not None else None),
+              "clhip_net_set_input_grad")
+
     def _mode(self):
         """nn.Module.train / eval -> the plan's BatchNorm mode; num_batches_tracked as nn.BatchNorm2d.forward counts it."""
         if not self.bns:

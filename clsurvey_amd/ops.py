@@ -376,6 +376,58 @@ class BatchNormReLUFn(torch.autograd.Function):
         return dz, dgamma, dbeta, None, None, None, None, None, None
 
 
+def sigmoid_fwd(x):
+    _chk(x)
+    y = torch.empty_like(x)
+    check(_lib.lib().clhip_sigmoid_fwd(_ptr(x), _ptr(y), x.numel(), _stream()), "clhip_sigmoid_fwd")
+    return y
+
+
+def sigmoid_bwd(dy, y):
+    _chk(dy, y)
+    dx = torch.empty_like(y)
+    check(_lib.lib().clhip_sigmoid_bwd(_ptr(dy), _ptr(y), _ptr(dx), y.numel(), _stream()), "clhip_sigmoid_bwd")
+    return dx
+
+
+def mse_mean(a, b, grad_scale=1.0, want_grad=True):
+    """nn.MSELoss()(a, b) -> (loss[1] device tensor, grad_scale * d loss / d a or None)."""
+    _chk(a, b)
+    assert a.shape == b.shape
+    loss = torch.empty(1, dtype=torch.float32, device=a.device)
+    da = torch.empty_like(a) if want_grad else None
+    check(_lib.lib().clhip_mse_mean(_ptr(a), _ptr(b), a.numel(), float(grad_scale), _ptr(da), _ptr(loss), _stream()), "clhip_mse_mean")
+    return loss, da
+
+
+class SigmoidFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = sigmoid_fwd(x.contiguous())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return sigmoid_bwd(dy.contiguous(), y)
+
+
+class MseMeanFn(torch.autograd.Function):
+    """nn.MSELoss()(a, target): gradient w.r.t. a only (the target is data)."""
+
+    @staticmethod
+    def forward(ctx, a, target):
+        loss, da = mse_mean(a.contiguous(), target.contiguous())
+        ctx.save_for_backward(da)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, dl):
+        (da,) = ctx.saved_tensors
+        return da * dl, None
+
+
 class MaxPoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, k, stride):
@@ -456,6 +508,14 @@ def batchnorm_relu(z, bn, relu=True):
     if bn.training:
         bn.num_batches_tracked += 1
     return BatchNormReLUFn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum, bn.eps, relu)
+
+
+def sigmoid(x):
+    return SigmoidFn.apply(x)
+
+
+def mse_loss(a, target):
+    return MseMeanFn.apply(a, target)
 
 
 def maxpool(x, k, stride):

@@ -184,3 +184,32 @@ def detach_reg_params(reg_params):
     """Drop the arena marker before pickling (the views stay valid tensors)."""
     reg_params.pop("__arena__", None)
     return reg_params
+
+
+class Adadelta(Optimizer):
+    """torch.optim.Adadelta(params, lr, rho=0.9, eps=1e-6, weight_decay=0) — the optimizer of EBLL's autoencoder
+    (EBLL/Finetune_SGD_EBLL.py:497) — one fused kernel per parameter tensor (an autoencoder has four)."""
+
+    def __init__(self, params, lr=1.0, rho=0.9, eps=1e-6, weight_decay=0):
+        super().__init__(params, dict(lr=lr, rho=rho, eps=eps, weight_decay=weight_decay))
+
+    def step(self, closure=None):
+        from ._lib import check, lib
+        loss = closure() if closure is not None else None
+        for g in self.param_groups:
+            for p in g["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["square_avg"] = torch.zeros_like(p.data)
+                    st["acc_delta"] = torch.zeros_like(p.data)
+                st["step"] += 1
+                if not (p.data.is_cuda and p.data.is_contiguous() and p.grad.is_contiguous()):
+                    raise RuntimeError("Adadelta needs contiguous HIP tensors (no CPU fallback)")
+                check(lib().clhip_adadelta_step(p.data.data_ptr(), p.grad.data_ptr(), st["square_avg"].data_ptr(),
+                                                st["acc_delta"].data_ptr(), p.numel(), float(g["lr"]), float(g["rho"]),
+                                                float(g["eps"]), float(g["weight_decay"]),
+                                                torch.cuda.current_stream().cuda_stream), "clhip_adadelta_step")
+        return loss

@@ -28,6 +28,14 @@ extern "C" {
 #define CLHIP_ENOTSUP (-3)  /* shape not supported by this build */
 
 /* Library version (major*10000 + minor*100 + patch) and the gfx arch it was built for. */
+/* EBLL (methods/EBLL): the code layer of AutoEncoder (AlexNet_EBLL.py:9-26: Linear + Sigmoid), nn.MSELoss() on codes /
+ * reconstructions (Finetune_SGD_EBLL.py:151, 297) with its gradient (times grad_scale) and optim.Adadelta (:497). */
+int clhip_sigmoid_fwd(const float* x, float* y, size_t n, void* stream);
+int clhip_sigmoid_bwd(const float* dy, const float* y, float* dx, size_t n, void* stream);
+int clhip_mse_mean(const float* a, const float* b, size_t n, float grad_scale, float* da, float* loss_out, void* stream);
+int clhip_adadelta_step(float* theta, const float* grad, float* square_avg, float* acc_delta, size_t n, float lr, float rho,
+                        float eps, float weight_decay, void* stream);
+
 int clhip_version(void);
 const char* clhip_arch(void);
 
@@ -247,6 +255,12 @@ int clhip_net_set_dropout(void* handle, int layer, const float* mask, long row_s
  * (nn.Module.train / eval). */
 int clhip_net_set_bn(void* handle, int layer, float* running_mean, float* running_var, float momentum, float eps);
 int clhip_net_set_training(void* handle, int training);
+/* Side branches off a plan (EBLL's code layers on the flattened features, AlexNet_EBLL.py:110-117): the INPUT activation
+ * of plan layer `layer` (> 0) lives at float offset *ws_float_off of the workspace after a forward (in_elems floats per
+ * sample); `extra` ([N][in_elems], device, may be NULL = none) is added to the gradient w.r.t. that activation in the
+ * following backward passes until changed. */
+int clhip_net_layer_input(void* handle, int layer, size_t* ws_float_off, size_t* in_elems);
+int clhip_net_set_input_grad(void* handle, int layer, const float* extra);
 void clhip_net_destroy(void* handle);
 size_t clhip_net_workspace_bytes(void* handle);
 int clhip_net_num_classes(void* handle);

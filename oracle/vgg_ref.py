@@ -48,6 +48,18 @@ def init_params(cfg, fc_dims, num_classes, in_hw, gen, in_ch=3):
     return params
 
 
+def features(params, cfg, x):
+    """The feature extractor alone (conv / ReLU / max-pool stack), un-flattened."""
+    i = 0
+    for v in cfg:
+        if v == "M":
+            x = F.max_pool2d(x, kernel_size=2, stride=2)
+        else:
+            x = F.relu(F.conv2d(x, params[i], params[i + 1], padding=1))
+            i += 2
+    return x
+
+
 def forward(params, cfg, x, gates=None):
     """params: flat list [conv_w, conv_b]*, [fc_w, fc_b]*3 in module order."""
     i = 0

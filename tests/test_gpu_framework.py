@@ -715,3 +715,30 @@ def test_drop_bn_variant_through_driver(tmp_path):
         mt = torch.load(out["model_paths"][-1], weights_only=False)
         b0 = [mod for mod in mt.modules() if isinstance(mod, torch.nn.BatchNorm2d)][0]
         assert float(mt.reg_params[b0.weight]["omega"].abs().max()) > 0
+
+
+# --------------------------------------------------------------------------- EBLL
+def test_ebll_through_driver(tmp_path):
+    """EBLL through the driver with --test: per task an autoencoder grid on the previous task (prestep), phase-1 finetune
+    (unwrapping the EBLL wrapper), phase-2 training with distillation + code loss; evaluation picks the task's head."""
+    from clsurvey_amd.framework import driver
+    from clsurvey_amd.methods import method as M
+    from clsurvey_amd.methods.ebll import AlexNet_EBLL
+    root = str(tmp_path)
+    ds = _dataset(root)
+    _friendly_base_model(root)
+    driver.main(COMMON + ["--method_name", "SI", "--results_root", root, "--runmode", "first_task_basemodel_dump"],
+                method=M.parse("SI"), dataset=ds)
+    ebll = M.parse("EBLL")
+    ebll.static_hyperparams = {"autoencoder_lr": [0.01], "autoencoder_epochs": 4, "encoder_alphas": [1e-1], "encoder_dims": [16, 8]}
+    out = driver.main(COMMON + ["--method_name", "EBLL", "--results_root", root, "--test"], method=ebll, dataset=ds)
+    res = out["results"]
+    assert sorted(res) == [0, 1, 2]
+    accs = [a for i in res for a in res[i]["seq_res"][i]]
+    assert all(0.0 <= a <= 100.0 for a in accs) and res[0]["seq_res"][0][0] > 40.0, res
+    last = torch.load(out["model_paths"][-1], weights_only=False)
+    assert isinstance(last, AlexNet_EBLL) and len(last.autoencoders._modules) == 2 and len(last.classifier._modules) == 7
+    assert set(last.reg_params) >= {"lambda", "reg_alpha"}
+    enc_dir = os.path.join(out["manager"].parent_exp_dir, "task_1", "ENCODER_TRAINING")
+    assert os.path.exists(os.path.join(enc_dir, "grid_checkpoint.pth"))
+    assert len([d for d in os.listdir(enc_dir) if d.startswith("dim=")]) == 1       # the losing grid node is removed

@@ -1245,3 +1245,107 @@ def test_autograd_bridge_bn_drop_net_train_mode():
     for (name, b), (_, rb) in zip(model.named_buffers(), ref.named_buffers()):
         if b.dtype == torch.float32:
             assert_close(b.cpu(), rb, tol=1e-4, what=name)
+
+
+# ---------------------------------------------------------------------------------------------- EBLL
+def _g16_model(seed):
+    from clsurvey_amd import models
+    params = vgg_ref.init_params(TINY, (24, 24), 4, 32, np.random.RandomState(seed))
+    m = models.VGGSlim(cfg=TINY, num_classes=4, classifier_inputdim=32 * 2 * 2, classifier_dim1=24, classifier_dim2=24)
+    with torch.no_grad():
+        for p, q in zip(m.parameters(), params):
+            p.copy_(q)
+        for mod in m.classifier:
+            if isinstance(mod, torch.nn.Linear):
+                mod.weight.mul_(20.0)
+    return m
+
+
+def _load_ae(ae, g, tag):
+    with torch.no_grad():
+        for name, p in ae.named_parameters():
+            p.copy_(torch.from_numpy(g["%s_%s" % (tag, name)]))
+
+
+def test_ebll_autoencoder_stage_golden_g16(golden):
+    """Stage 1 as fine_tune_Adam_Autoencoder / train_autoencoder run it (plan executor for the frozen features, autograd
+    bridges for autoencoder + classifier tail, Adadelta kernel) vs the reference's own numbers."""
+    from clsurvey_amd import ops
+    from clsurvey_amd.methods import ebll as E
+    from clsurvey_amd.net import NetEngine
+    from clsurvey_amd.optim import Adadelta
+    g = golden("G16_ebll")
+    x, y = torch.from_numpy(g["x"]).to(dev()), torch.from_numpy(g["y"]).to(dev())
+    model = E.AlexNet_ENCODER(_g16_model(161), dim=10, last_layer_name=4, num_ftrs=128)
+    _load_ae(model.autoencoder, g, "s1")
+    model = model.to(dev())
+    fe = NetEngine(E._FeatureNet(model.features), 6, (3, 32, 32), dev())
+    opt = Adadelta(model.autoencoder.parameters(), 0.01)
+    alpha = float(g["s1_alpha"])
+    for p in list(model.features.parameters()) + list(model.classifier.parameters()):
+        p.requires_grad_(False)
+    for step in range(3):
+        feat = fe.forward(x)
+        opt.zero_grad()
+        recon = model.autoencoder(feat)
+        out = E._classifier_tail(model.classifier, recon, 4, True)[-1]
+        task, enc = ops.cross_entropy(out, y), ops.mse_loss(recon, feat)
+        (alpha * enc + task).backward()
+        if step == 0:
+            assert_close(feat.cpu(), torch.from_numpy(g["s1_in"]), tol=1e-5, what="features")
+            assert_close(recon.detach().cpu(), torch.from_numpy(g["s1_recon"]), tol=1e-5, what="reconstruction")
+            assert_close(out.detach().cpu(), torch.from_numpy(g["s1_out"]), tol=1e-4, what="head output")
+            assert abs(float(task) - float(g["s1_task_loss"])) <= 1e-4 * abs(float(g["s1_task_loss"]))
+            assert abs(float(enc) - float(g["s1_enc_loss"])) <= 1e-4 * abs(float(g["s1_enc_loss"]))
+            for name, p in model.autoencoder.named_parameters():
+                assert_close(p.grad.cpu(), torch.from_numpy(g["s1_grad_" + name]), tol=2e-4, what="grad " + name)
+        opt.step()
+    for name, p in model.autoencoder.named_parameters():
+        assert_close(p.detach().cpu(), torch.from_numpy(g["s1_after3_" + name]), tol=1e-4, what="after 3 Adadelta steps: " + name)
+    # the wrapper's own forward (evaluation path) returns the reference's triple
+    with torch.no_grad():
+        _load_ae(model.autoencoder, g, "s1")
+        o, e_in, e_out = model(x)
+    assert_close(o.cpu(), torch.from_numpy(g["s1_out"]), tol=1e-4, what="wrapper out")
+    assert_close(e_out.cpu(), torch.from_numpy(g["s1_recon"]), tol=1e-5, what="wrapper recon")
+
+
+def test_ebll_objective_golden_g16(golden):
+    """Stage 2: EbllEngine.step (stacked heads on the plan executor, code layers as a side branch, clhip_lwf_loss) vs the
+    reference's objective and every feature-extractor / classifier gradient."""
+    from clsurvey_amd.methods import ebll as E
+    g = golden("G16_ebll")
+    x, y = torch.from_numpy(g["x"]).to(dev()), torch.from_numpy(g["y"]).to(dev())
+    ae0, ae1 = E.AutoEncoder(128, 10), E.AutoEncoder(128, 6)
+    _load_ae(ae0, g, "s2_ae0")
+    _load_ae(ae1, g, "s2_ae1")
+    w = E.AlexNet_EBLL(_g16_model(162), ae0, last_layer_name=4)
+    w.autoencoders.add_module("1", ae1.encode)
+    for i, nc in enumerate((8, 4)):
+        h = torch.nn.Linear(24, nc)
+        with torch.no_grad():
+            h.weight.copy_(torch.from_numpy(g["s2_head%d_w" % (i + 1)]))
+            h.bias.copy_(torch.from_numpy(g["s2_head%d_b" % (i + 1)]))
+        w.classifier.add_module(str(5 + i), h)
+    w = w.to(dev())
+    with torch.no_grad():
+        outs, codes = w(x)                                   # evaluation path of the wrapper
+    for i in range(3):
+        assert_close(outs[i].cpu(), torch.from_numpy(g["s2_out%d" % i]), tol=1e-4, what="out%d" % i)
+    for i in range(2):
+        assert_close(codes[i].cpu(), torch.from_numpy(g["s2_code%d" % i]), tol=1e-5, what="code%d" % i)
+    eng = E.EbllEngine(w, 6, (3, 32, 32), dev())
+    tl = torch.cat([torch.from_numpy(g["s2_tlogits%d" % i]) for i in (0, 1)], 1).contiguous().to(dev())
+    tc_ = [torch.from_numpy(g["s2_tcodes%d" % i]).to(dev()) for i in (0, 1)]
+    loss2, code_loss = eng.step(x, y, tl, tc_, 2.0, float(g["s2_lambda"]), float(g["s2_reg_alpha"]), backward=True)
+    assert abs(float(loss2[0]) - float(g["s2_task_loss"])) <= 1e-4 * abs(float(g["s2_task_loss"]))
+    assert abs(float(loss2[1]) - float(g["s2_dist_loss"])) <= 1e-4 * abs(float(g["s2_dist_loss"]))
+    assert abs(float(code_loss) - float(g["s2_code_loss"])) <= 1e-4 * abs(float(g["s2_code_loss"]))
+    named = dict(w.named_parameters())
+    for j, name in enumerate(g["s2_param_names"]):
+        got = eng.arena.view("grad", named[str(name)]).cpu()
+        assert_close(got, torch.from_numpy(g["s2_g%d" % j]), tol=1e-3, what="grad " + str(name))
+    # targets() of a teacher engine = the wrapper's own outputs / codes
+    t_logits, t_codes = eng.targets(x)
+    assert_close(t_logits.cpu(), torch.cat([torch.from_numpy(g["s2_out%d" % i]) for i in range(3)], 1), tol=1e-4, what="targets")
+    assert_close(t_codes[1].cpu(), torch.from_numpy(g["s2_code1"]), tol=1e-5, what="target codes")

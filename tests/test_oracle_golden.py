@@ -342,3 +342,72 @@ def test_g15_gem_alexnet_dropout_observe(golden):
     with torch.no_grad():
         np.testing.assert_allclose(AR.forward(m, data[0][0]).numpy()[:, 4:8], g["eval_logits_t1"][:, 4:8], rtol=1e-4, atol=1e-5)
     assert (g["eval_logits_t1"][:, :4] < -1e10).all()
+
+
+TINY16 = [16, "M", 16, "M", 32, 32, "M", 32, 32, "M"]
+
+
+def _g16_params(seed):
+    params = vgg_ref.init_params(TINY16, (24, 24), 4, 32, np.random.RandomState(seed))
+    for i in (12, 14, 16):               # make_g16.tiny_net scales the three Linear weights by 20
+        params[i] = params[i] * 20.0
+    return params
+
+
+def test_g16_ebll_objectives(golden):
+    """oracle/ebll_ref.py vs the reference's EBLL code (G16, make_g16.py): autoencoder stage (losses, the four
+    gradients, three Adadelta steps) and the EBLL objective with every feature-extractor / classifier gradient."""
+    from oracle import ebll_ref as EB
+    g = golden("G16_ebll")
+    x, y = torch.from_numpy(g["x"]), torch.from_numpy(g["y"])
+    # ---- stage 1
+    params = _g16_params(161)
+    feat = vgg_ref.features(params, TINY16, x).flatten(1)
+    np.testing.assert_allclose(feat.numpy(), g["s1_in"], rtol=1e-5, atol=1e-6)
+    ae = [torch.from_numpy(g["s1_" + n]).clone().requires_grad_(True)
+          for n in ("encode.0.weight", "encode.0.bias", "decode.0.weight", "decode.0.bias")]
+
+    def tail(r):
+        h = torch.relu(torch.nn.functional.linear(r, params[12], params[13]))
+        h = torch.relu(torch.nn.functional.linear(h, params[14], params[15]))
+        return torch.nn.functional.linear(h, params[16], params[17])
+
+    state = [(torch.zeros_like(p), torch.zeros_like(p)) for p in ae]
+    for step in range(3):
+        task, enc, recon = EB.stage1_objective(feat, y, ae, tail, float(g["s1_alpha"]))
+        grads = torch.autograd.grad(float(g["s1_alpha"]) * enc + task, ae)
+        if step == 0:
+            np.testing.assert_allclose(task.item(), g["s1_task_loss"], rtol=1e-5)
+            np.testing.assert_allclose(enc.item(), g["s1_enc_loss"], rtol=1e-5)
+            np.testing.assert_allclose(recon.detach().numpy(), g["s1_recon"], rtol=1e-5, atol=1e-6)
+            for p_grad, n in zip(grads, ("encode.0.weight", "encode.0.bias", "decode.0.weight", "decode.0.bias")):
+                np.testing.assert_allclose(p_grad.numpy(), g["s1_grad_" + n], rtol=1e-4, atol=1e-7)
+        EB.adadelta_step(ae, grads, state, 0.01)
+    for p, n in zip(ae, ("encode.0.weight", "encode.0.bias", "decode.0.weight", "decode.0.bias")):
+        np.testing.assert_allclose(p.detach().numpy(), g["s1_after3_" + n], rtol=1e-5, atol=1e-7)
+    # ---- stage 2
+    params = [p.clone().requires_grad_(True) for p in _g16_params(162)]
+    heads = [(torch.from_numpy(g["s2_head%d_w" % i]).requires_grad_(True), torch.from_numpy(g["s2_head%d_b" % i]).requires_grad_(True))
+             for i in (1, 2)]
+    feat = vgg_ref.features(params, TINY16, x).flatten(1)
+    h = torch.relu(torch.nn.functional.linear(feat, params[12], params[13]))
+    h = torch.relu(torch.nn.functional.linear(h, params[14], params[15]))
+    outs = [torch.nn.functional.linear(h, params[16], params[17])] + [torch.nn.functional.linear(h, w, b) for w, b in heads]
+    codes = [EB.encode(feat, torch.from_numpy(g["s2_ae%d_encode.0.weight" % i]), torch.from_numpy(g["s2_ae%d_encode.0.bias" % i]))
+             for i in (0, 1)]
+    for i in range(3):
+        np.testing.assert_allclose(outs[i].detach().numpy(), g["s2_out%d" % i], rtol=1e-4, atol=1e-5)
+    for i in range(2):
+        np.testing.assert_allclose(codes[i].detach().numpy(), g["s2_code%d" % i], rtol=1e-5, atol=1e-6)
+    task, dist, code = EB.stage2_objective(outs, codes, y, [torch.from_numpy(g["s2_tlogits%d" % i]) for i in (0, 1)],
+                                           [torch.from_numpy(g["s2_tcodes%d" % i]) for i in (0, 1)], 2.0,
+                                           float(g["s2_lambda"]), float(g["s2_reg_alpha"]))
+    np.testing.assert_allclose(task.item(), g["s2_task_loss"], rtol=1e-5)
+    np.testing.assert_allclose(dist.item(), g["s2_dist_loss"], rtol=1e-5)
+    np.testing.assert_allclose(code.item(), g["s2_code_loss"], rtol=1e-5)
+    leaves = params + [t for wb in heads for t in wb]
+    grads = torch.autograd.grad(task + dist + float(g["s2_reg_alpha"]) * code, leaves)
+    assert len(grads) == len(g["s2_param_names"])
+    for j, gr in enumerate(grads):
+        ref = g["s2_g%d" % j]
+        assert np.abs(gr.numpy() - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-6), g["s2_param_names"][j]
