@@ -499,71 +499,72 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_smallc_kernel(
 // range of splits in order (f64), the 16 partials meet in LDS and are added in order j = 0..15 — the same two-level
 // association for every run, every grid size: bitwise run-to-run deterministic.
 //   dw[k][c][rs] = sum_s part[s][rs][k][c] ; db[k] = sum_s part[s][9KC + k]
-constexpr int RED_EL = 64, RED_J = 16;
-__global__ __launch_bounds__(RED_EL * RED_J) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                                      float* __restrict__ db, int K, int C, int splits) {
-    __shared__ double partial[RED_J][RED_EL];
+constexpr int RED_EL = 64, RED_J = 16, RED_V = 4;          // 64 elements x 16 split-lanes per block, 4 elements per thread
+constexpr int RED_THREADS = RED_EL / RED_V * RED_J;
+
+// One block: elements [e0, e0 + 64) of the (9KC + K)-element slab.  Thread (j, v) sums splits [j q, (j + 1) q) of the 4
+// consecutive elements v (16-byte loads when the slab rows are 16-byte aligned), then lane j = 0 adds the 16 partial
+// sums in order: the order per element does not depend on the vector width.
+__device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db,
+                                                   int K, int C, int splits, size_t e0, double (*partial)[RED_EL]) {
     const size_t kc = (size_t)K * C, nw = 9 * kc, total = nw + K;
-    const int el = threadIdx.x & (RED_EL - 1), j = threadIdx.x / RED_EL;
-    const size_t e = (size_t)blockIdx.x * RED_EL + el;
+    const int v = threadIdx.x % (RED_EL / RED_V), j = threadIdx.x / (RED_EL / RED_V);
+    const size_t e = e0 + (size_t)v * RED_V;
     const int q = (splits + RED_J - 1) / RED_J;
     const int s0 = j * q, s1 = min(splits, s0 + q);
-    double s = 0.0;
-    if (e < total) {
-#pragma unroll 8
-        for (int sp = s0; sp < s1; ++sp) s += (double)part[(size_t)sp * total + e];
-    }
-    partial[j][el] = s;
-    __syncthreads();
-    if (j == 0 && e < total) {
-        double t = 0.0;
+    double s[RED_V] = {0.0, 0.0, 0.0, 0.0};
+    if ((total & 3) == 0 && e + RED_V <= total) {
+#pragma unroll 4
+        for (int sp = s0; sp < s1; ++sp) {
+            const float4 t = *reinterpret_cast<const float4*>(part + (size_t)sp * total + e);
+            s[0] += (double)t.x; s[1] += (double)t.y; s[2] += (double)t.z; s[3] += (double)t.w;
+        }
+    } else {
+        for (int sp = s0; sp < s1; ++sp)
 #pragma unroll
-        for (int jj = 0; jj < RED_J; ++jj) t += partial[jj][el];
-        if (e < nw) {
-            const size_t rs = e / kc, rem = e - rs * kc;     // rem = k*C + c
-            dw[rem * 9 + rs] = (float)t;
-        } else if (db) {
-            db[e - nw] = (float)t;
+            for (int t = 0; t < RED_V; ++t)
+                if (e + t < total) s[t] += (double)part[(size_t)sp * total + e + t];
+    }
+#pragma unroll
+    for (int t = 0; t < RED_V; ++t) partial[j][v * RED_V + t] = s[t];
+    __syncthreads();
+    if (threadIdx.x < RED_EL) {
+        const int el = threadIdx.x;
+        const size_t ee = e0 + el;
+        if (ee < total) {
+            double t = 0.0;
+#pragma unroll
+            for (int jj = 0; jj < RED_J; ++jj) t += partial[jj][el];
+            if (ee < nw) {
+                const size_t rs = ee / kc, rem = ee - rs * kc;     // rem = k*C + c
+                dw[rem * 9 + rs] = (float)t;
+            } else if (db) {
+                db[ee - nw] = (float)t;
+            }
         }
     }
 }
 
+__global__ __launch_bounds__(RED_THREADS) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                   float* __restrict__ db, int K, int C, int splits) {
+    __shared__ double partial[RED_J][RED_EL];
+    wgrad_reduce_block(part, dw, db, K, C, splits, (size_t)blockIdx.x * RED_EL, partial);
+}
+
 // The same reduction for the slabs of SEVERAL layers in one launch (the plan executor defers them to the end of the
-// backward pass: six ~6 us launches -> one).  Per job the arithmetic and its order are those of wgrad_reduce_kernel.
+// backward pass).  Per job the arithmetic and its order are those of wgrad_reduce_kernel.
 struct RedJobs {
     clhip_wgrad_job job[CLHIP_WGRAD_JOBS_MAX];
     unsigned first[CLHIP_WGRAD_JOBS_MAX + 1];       // prefix sums of blocks
     int n;
 };
 
-__global__ __launch_bounds__(RED_EL * RED_J) void wgrad_reduce_multi_kernel(RedJobs jobs) {
+__global__ __launch_bounds__(RED_THREADS) void wgrad_reduce_multi_kernel(RedJobs jobs) {
     __shared__ double partial[RED_J][RED_EL];
     int ji = 0;
     while (ji + 1 < jobs.n && blockIdx.x >= jobs.first[ji + 1]) ++ji;
     const clhip_wgrad_job J = jobs.job[ji];
-    const size_t kc = (size_t)J.K * J.C, nw = 9 * kc, total = nw + J.K;
-    const int el = threadIdx.x & (RED_EL - 1), j = threadIdx.x / RED_EL;
-    const size_t e = (size_t)(blockIdx.x - jobs.first[ji]) * RED_EL + el;
-    const int q = (J.splits + RED_J - 1) / RED_J;
-    const int s0 = j * q, s1 = min(J.splits, s0 + q);
-    double s = 0.0;
-    if (e < total) {
-#pragma unroll 8
-        for (int sp = s0; sp < s1; ++sp) s += (double)J.part[(size_t)sp * total + e];
-    }
-    partial[j][el] = s;
-    __syncthreads();
-    if (j == 0 && e < total) {
-        double t = 0.0;
-#pragma unroll
-        for (int jj = 0; jj < RED_J; ++jj) t += partial[jj][el];
-        if (e < nw) {
-            const size_t rs = e / kc, rem = e - rs * kc;
-            J.dw[rem * 9 + rs] = (float)t;
-        } else if (J.db) {
-            J.db[e - nw] = (float)t;
-        }
-    }
+    wgrad_reduce_block(J.part, J.dw, J.db, J.K, J.C, J.splits, (size_t)(blockIdx.x - jobs.first[ji]) * RED_EL, partial);
 }
 
 struct WPlan {
@@ -657,7 +658,7 @@ static int bwd_weight_impl(const float* x, const float* dy, const uint8_t* unpoo
         return 0;
     }
     const unsigned bx = (unsigned)((p.slab + RED_EL - 1) / RED_EL);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(bx), dim3(RED_EL * RED_J), 0, s, part, dw, db, K, C, p.splits);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(bx), dim3(RED_THREADS), 0, s, part, dw, db, K, C, p.splits);
     CLHIP_LAUNCH_CHECK();
     return 0;
 }
@@ -697,7 +698,7 @@ int clhip_internal_wgrad_reduce_multi(const clhip_wgrad_job* jobs, int n, hipStr
         r.first[i + 1] = r.first[i] + (unsigned)((total + RED_EL - 1) / RED_EL);
     }
     for (int i = n; i < CLHIP_WGRAD_JOBS_MAX; ++i) { r.job[i] = clhip_wgrad_job{nullptr, nullptr, nullptr, 0, 0, 0}; r.first[i + 1] = r.first[n]; }
-    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(r.first[n]), dim3(RED_EL * RED_J), 0, s, r);
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(r.first[n]), dim3(RED_THREADS), 0, s, r);
     CLHIP_LAUNCH_CHECK();
     return 0;
 }
