@@ -1349,3 +1349,43 @@ def test_ebll_objective_golden_g16(golden):
     t_logits, t_codes = eng.targets(x)
     assert_close(t_logits.cpu(), torch.cat([torch.from_numpy(g["s2_out%d" % i]) for i in range(3)], 1), tol=1e-4, what="targets")
     assert_close(t_codes[1].cpu(), torch.from_numpy(g["s2_code1"]), tol=1e-5, what="target codes")
+
+
+def test_gem_gram_and_project_alexnet_scale():
+    """The GEM gradient-memory kernels at AlexNet size (BASELINE configs[3]: P = 57.8 M parameters with a 200-way head,
+    10 task rows = 2.3 GB): one-pass f64 Gram and projection vs torch fp64 on the device, plus the achieved HBM rate."""
+    import ctypes as C
+    from clsurvey_amd import _lib
+    n, nt = 57_823_240, 10
+    ld = (n + 3) // 4 * 4
+    gen = torch.Generator(device=dev()).manual_seed(3)
+    G = torch.randn((nt, ld), generator=gen, device=dev(), dtype=torch.float32)
+    L = _lib.lib()
+    ws = torch.zeros(L.clhip_gem_gram_ws(16), dtype=torch.uint8, device=dev())
+    rows = [0, 3, 4, 7, 9]
+    m = len(rows)
+    out = torch.zeros(m * m, dtype=torch.float64, device=dev())
+    idx = (C.c_int * m)(*rows)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    assert L.clhip_gem_gram(G.data_ptr(), ld, idx, m, n, out.data_ptr(), ws.data_ptr(), ws.numel(), None) == 0
+    ev[0].record()
+    assert L.clhip_gem_gram(G.data_ptr(), ld, idx, m, n, out.data_ptr(), ws.data_ptr(), ws.numel(), None) == 0
+    ev[1].record()
+    torch.cuda.synchronize()
+    ref = torch.zeros((m, m), dtype=torch.float64, device=dev())
+    for a in range(m):                       # fp64 reference row by row (a [5][57.8M] fp64 copy would be 2.3 GB more)
+        ra = G[rows[a], :n].double()
+        for b in range(a, m):
+            ref[a, b] = ref[b, a] = torch.dot(ra, G[rows[b], :n].double())
+    got = out.view(m, m)
+    assert float((got - ref).abs().max()) <= 1e-9 * float(ref.abs().max())
+    print("gem_gram: %d rows x %.1f M: %.1f us, %.2f TB/s" % (m, n / 1e6, ev[0].elapsed_time(ev[1]) * 1e3,
+                                                             m * n * 4 / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e12))
+    v = [0.5, 1.25, -0.75, 0.1, 2.0]
+    g = torch.randn(n, generator=gen, device=dev())
+    o = torch.empty(n, device=dev())
+    assert L.clhip_gem_project(G.data_ptr(), ld, idx, (C.c_float * m)(*v), m, g.data_ptr(), o.data_ptr(), n, None) == 0
+    want = g.double()
+    for a in range(m):
+        want += float(np.float32(v[a])) * G[rows[a], :n].double()
+    assert float((o.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
