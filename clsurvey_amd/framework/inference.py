@@ -3,6 +3,7 @@
 import copy
 
 import torch
+from ..data import load_task_datasets
 
 from ..data import DeviceLoader
 from ..methods import train_common as tc
@@ -30,7 +31,7 @@ def test_model(method, model, dataset_path, target_task_head_idx, target_head=No
         final_layer_idx = str(len(model.classifier._modules) - 1)
     model.eval()
     model = model.to(device)
-    dsets = torch.load(dataset_path, weights_only=False) if isinstance(dataset_path, str) else dataset_path
+    dsets = load_task_datasets(dataset_path)
     if subset not in dsets:
         subset = "val"
     loader = DeviceLoader(dsets[subset], batch_size, True, device)

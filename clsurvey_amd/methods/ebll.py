@@ -21,6 +21,7 @@ import os
 import time
 
 import torch
+from ..data import load_task_datasets
 import torch.nn as nn
 
 from .. import ops
@@ -205,7 +206,7 @@ def get_first_FC_layer(seq_module):
 def fine_tune_Adam_Autoencoder(dataset_path, previous_task_model_path, exp_dir="", batch_size=200, num_epochs=100, lr=0.01,
                                pretrained=True, alpha=1e-6, auto_dim=100, last_layer_name=6, device="cuda"):
     """Finetune_SGD_EBLL.py:441-504. Returns (AlexNet_ENCODER, best validation accuracy)."""
-    dsets = torch.load(dataset_path, weights_only=False) if isinstance(dataset_path, str) else dataset_path
+    dsets = load_task_datasets(dataset_path)
     dset_loaders = tc.make_loaders(dsets, batch_size, device)
     dset_sizes = {x: len(dsets[x]) for x in ["train", "val"]}
     resume = os.path.join(exp_dir, "epoch.pth.tar")
@@ -347,7 +348,7 @@ def fine_tune_SGD_EBLL(dataset_path, previous_task_model_path, autoencoder_model
                        batch_size=200, num_epochs=100, lr=0.0004, init_freeze=1, weight_decay=0, reg_alpha=1e-6, saving_freq=5,
                        reg_lambda=1, device="cuda"):
     """Finetune_SGD_EBLL.py:507-518 + the model surgery above it. Returns train_model_ebll's (model, acc)."""
-    dsets = torch.load(dataset_path, weights_only=False) if isinstance(dataset_path, str) else dataset_path
+    dsets = load_task_datasets(dataset_path)
     dset_loaders = tc.make_loaders(dsets, batch_size, device)
     dset_sizes = {x: len(dsets[x]) for x in ["train", "val"]}
     dset_classes = dsets["train"].classes

@@ -8,6 +8,7 @@ import os
 import time
 
 import torch
+from ..data import load_task_datasets
 
 from .. import ops
 from ..data import DeviceLoader
@@ -80,7 +81,7 @@ def accumulate_EWC_weights(data_dir, reg_sets, model_ft, batch_size, device="cud
     """main_EWC.py:79-123 (data_dir is None on this path: reg_sets are pickled dataset dicts)."""
     dset_loader = None
     for data_path in reg_sets:
-        dset = torch.load(data_path, weights_only=False) if isinstance(data_path, str) else data_path
+        dset = load_task_datasets(data_path)
         dset = dset["train"]
         dset_loader = DeviceLoader(dset, batch_size, False, device)
     if not hasattr(model_ft, "reg_params"):
@@ -96,7 +97,7 @@ def fine_tune_EWC_acuumelation(dataset_path, previous_task_model_path, exp_dir, 
                                num_epochs=100, lr=0.0008, batch_size=200, weight_decay=0, head_shared=False,
                                saving_freq=5, device="cuda"):
     """main_EWC.py:14-76."""
-    dsets = torch.load(dataset_path, weights_only=False) if isinstance(dataset_path, str) else dataset_path
+    dsets = load_task_datasets(dataset_path)
     dset_loaders = tc.make_loaders(dsets, batch_size, device)
     dset_sizes = {x: len(dsets[x]) for x in ["train", "val"]}
     dset_classes = dsets["train"].classes

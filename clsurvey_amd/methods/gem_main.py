@@ -13,6 +13,7 @@ import os
 import time
 
 import torch
+from ..data import load_task_datasets
 
 from ..data import DeviceLoader
 from . import gem as G
@@ -125,7 +126,7 @@ def main(overwrite_args, nc_per_task, device="cuda"):
         assert args.postprocess, "FIRST TASK WE DO ONLY POSTPROCESSING"
     assert os.path.isfile(args.prev_model_path), "Must specify existing prev_model_path, got: " + args.prev_model_path
 
-    dsets = torch.load(args.dataset_path, weights_only=False) if isinstance(args.dataset_path, str) else args.dataset_path
+    dsets = load_task_datasets(args.dataset_path)
     args.task_imgfolders = dsets
     args.dset_loaders = {x: DeviceLoader(dsets[x], args.batch_size, True, device) for x in ["train", "val"]}
     dset_sizes = {x: len(dsets[x]) for x in ["train", "val"]}

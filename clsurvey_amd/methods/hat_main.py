@@ -12,6 +12,7 @@ import time
 from copy import deepcopy
 
 import torch
+from ..data import load_task_datasets
 
 from ..data import DeviceLoader
 from . import hat as H
@@ -307,7 +308,7 @@ def main(overwrite_args, device="cuda"):
     if "VGG" not in args.model_name:
         raise NotImplementedError("HAT on the HIP path covers the VGG family (vgg_hat.py), not: " + args.model_name)
 
-    dsets = torch.load(args.dataset_path, weights_only=False) if isinstance(args.dataset_path, str) else args.dataset_path
+    dsets = load_task_datasets(args.dataset_path)
     args.task_imgfolders = dsets
     args.dset_loaders = {x: DeviceLoader(dsets[x], args.batch_size, True, device) for x in ["train", "val"]}
     taskcla = [(t, nc) for t, nc in enumerate(args.nc_per_task)]

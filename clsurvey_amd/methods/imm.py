@@ -12,6 +12,7 @@ import os
 import time
 
 import torch
+from ..data import load_task_datasets
 
 from .. import _lib, ops
 from .._lib import check
@@ -36,7 +37,7 @@ def update_reg_params(model, freeze_layers=None):
 def fine_tune_l2transfer(dataset_path, model_path, exp_dir, batch_size=100, num_epochs=100, lr=0.0004, reg_lambda=100,
                          init_freeze=0, weight_decay=0, saving_freq=5, device="cuda"):
     """main_L2transfer.py:73-158."""
-    dsets = torch.load(dataset_path, weights_only=False) if isinstance(dataset_path, str) else dataset_path
+    dsets = load_task_datasets(dataset_path)
     dset_loaders = tc.make_loaders(dsets, batch_size, device)
     dset_sizes = {x: len(dsets[x]) for x in ["train", "val"]}
     dset_classes = dsets["train"].classes
@@ -146,7 +147,7 @@ def preprocess_merge_IMM(method, model_paths, datasets_path, batch_size, overwri
             if os.path.exists(out_file) and not overwrite:
                 prec = torch.load(out_file, weights_only=False)
             else:
-                dsets = torch.load(datasets_path[i], weights_only=False) if isinstance(datasets_path[i], str) else datasets_path[i]
+                dsets = load_task_datasets(datasets_path[i])
                 loaders = {x: DeviceLoader(dsets[x], batch_size, True, device) for x in ["train", "val"]}
                 prec = diag_fisher(model.to(device), loaders, exclude_params=head_param_names)
                 torch.save(prec, out_file)

@@ -13,6 +13,7 @@ import os
 import time
 
 import torch
+from ..data import load_task_datasets
 import torch.nn as nn
 
 from .. import _lib, ops
@@ -165,7 +166,7 @@ def fine_tune_SGD_LwF(dataset_path, previous_task_model_path, init_model_path=""
                       num_epochs=100, lr=0.0004, init_freeze=1, pretrained=True, weight_decay=0, last_layer_name=6,
                       saving_freq=5, reg_lambda=1, device="cuda"):
     """main_LWF.py:253-318. Returns what the reference returns: train_model_lwf's (model, acc) tuple."""
-    dsets = torch.load(dataset_path, weights_only=False) if isinstance(dataset_path, str) else dataset_path
+    dsets = load_task_datasets(dataset_path)
     dset_loaders = tc.make_loaders(dsets, batch_size, device)
     dset_sizes = {x: len(dsets[x]) for x in ["train", "val"]}
     dset_classes = dsets["train"].classes

@@ -4,6 +4,7 @@ import os
 import time
 
 import torch
+from ..data import load_task_datasets
 import torch.nn as nn
 
 from .. import ops
@@ -49,7 +50,7 @@ def accumulate_objective_based_weights(data_dir, reg_sets, model_ft, batch_size,
         raise NotImplementedError("only norm='L2' is reachable from the framework (method.py:748)")
     dset_loaders = []
     for data_path in reg_sets:
-        dset = torch.load(data_path, weights_only=False) if isinstance(data_path, str) else data_path
+        dset = load_task_datasets(data_path)
         dset_loaders.append(DeviceLoader(dset[test_set], batch_size, False, device))
     if not hasattr(model_ft, "reg_params"):
         model_ft.reg_params = initialize_reg_params(model_ft)
@@ -67,7 +68,7 @@ def fine_tune_objective_based_acuumelation(dataset_path, previous_task_model_pat
     """main_MAS.py:34-106."""
     if L1_decay:
         raise NotImplementedError("L1_decay is never set on the framework path")
-    dsets = torch.load(dataset_path, weights_only=False) if isinstance(dataset_path, str) else dataset_path
+    dsets = load_task_datasets(dataset_path)
     dset_loaders = tc.make_loaders(dsets, batch_size, device)
     dset_sizes = {x: len(dsets[x]) for x in ["train", "val"]}
     dset_classes = dsets["train"].classes

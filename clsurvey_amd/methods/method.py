@@ -15,7 +15,7 @@ from enum import Enum, auto
 
 import torch
 
-from ..data import DeviceLoader, TensorTaskDataset
+from ..data import DeviceLoader, TensorTaskDataset, load_task_datasets
 from . import ebll as trainEBLL
 from . import ewc as trainEWC
 from . import finetune as trainFT
@@ -155,7 +155,7 @@ class Finetune(Method):
         classes = {x: [] for x in ["train", "val"]}
         sizes = {x: [] for x in ["train", "val"]}
         for p in dataset_path:
-            w = torch.load(p, weights_only=False) if isinstance(p, str) else p
+            w = load_task_datasets(p, device)
             for mode in ["train", "val"]:
                 imgf[mode].append(w[mode])
                 classes[mode].append(w[mode].classes)

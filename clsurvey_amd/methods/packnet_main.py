@@ -18,6 +18,7 @@ import os
 import warnings
 
 import torch
+from ..data import load_task_datasets
 import torch.nn as nn
 
 from ..data import DeviceLoader
@@ -151,7 +152,7 @@ class Manager(object):
         if args.mode != "check":
             if "survey" not in args.dataset:
                 raise NotImplementedError("only the survey dataset format (main.py:95-108) is on this path")
-            dsets = torch.load(args.train_path, weights_only=False) if isinstance(args.train_path, str) else args.train_path
+            dsets = load_task_datasets(args.train_path)
             self.train_data_loader = DeviceLoader(dsets["train"], args.batch_size, True, self.device)
             self.test_data_loader = DeviceLoader(dsets["val" if args.mode != "eval" else "test"], args.batch_size, True,
                                                  self.device)

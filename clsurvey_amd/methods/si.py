@@ -3,6 +3,7 @@ import os
 import time
 
 import torch
+from ..data import load_task_datasets
 
 from .. import ops
 from ..optim import Elastic_SGD, arena_reg_params
@@ -41,7 +42,7 @@ def update_reg_params(model, slak=1e-3):
 def fine_tune_elastic(dataset_path, model_path, exp_dir, batch_size=200, num_epochs=100, lr=0.0004, reg_lambda=100,
                       init_freeze=0, weight_decay=0, saving_freq=5, device="cuda"):
     """main_SI.py:26-94."""
-    dsets = torch.load(dataset_path, weights_only=False) if isinstance(dataset_path, str) else dataset_path
+    dsets = load_task_datasets(dataset_path)
     dset_loaders = tc.make_loaders(dsets, batch_size, device)
     dset_sizes = {x: len(dsets[x]) for x in ["train", "val"]}
     dset_classes = dsets["train"].classes
