@@ -115,3 +115,46 @@ def test_device_loader_reproduces_dataloader_order():
     torch.manual_seed(7)
     dl = DeviceLoader(ds, 5, True, "cpu")
     assert [b[1].tolist() for _ in range(2) for b in dl] == ref and len(dl) == 5
+
+
+def test_ebll_autoencoder_grid_host_logic(tmp_path, monkeypatch):
+    """EBLL.prestep's autoencoder grid (method.py:842-908): every (dim, alpha, lr) node trained once, results checkpointed,
+    finished nodes skipped on a re-run, the best node's directory kept and the others removed."""
+    import types
+    from clsurvey_amd.methods import method as M
+    from clsurvey_amd.methods import ebll as E
+    calls = []
+
+    def fake_autoencoder(dataset_path, previous_task_model_path, exp_dir, batch_size, num_epochs, lr, alpha, last_layer_name,
+                         auto_dim, device="cuda"):
+        calls.append((auto_dim, alpha, lr))
+        torch.save({"dim": auto_dim}, os.path.join(exp_dir, "best_model.pth.tar"))
+        return None, {(100, 0.1): 0.55, (100, 0.01): 0.70, (300, 0.1): 0.62, (300, 0.01): 0.41}[(auto_dim, alpha)]
+
+    monkeypatch.setattr(E, "fine_tune_Adam_Autoencoder", fake_autoencoder)
+    ebll = M.parse("EBLL")
+    assert list(ebll.hyperparams) == ["reg_lambda", "ebll_reg_alpha"] and ebll.extra_hyperparams_count == 2
+    args = types.SimpleNamespace(task_counter=2, previous_task_dataset_path="d", batch_size=8, classifier_heads_starting_idx=4,
+                                 presteps_elapsed_time=0)
+    manager = types.SimpleNamespace(parent_exp_dir=str(tmp_path), previous_task_model_path="m")
+    ebll.prestep(args, manager)
+    enc = os.path.join(str(tmp_path), "task_1", "ENCODER_TRAINING")
+    assert manager.autoencoder_model_path == os.path.join(enc, "dim=100_alpha=0.01_lr=0.01", "best_model.pth.tar")
+    assert os.path.exists(manager.autoencoder_model_path)
+    assert sorted(os.listdir(enc)) == ["dim=100_alpha=0.01_lr=0.01", "grid_checkpoint.pth"]
+    assert len(calls) == 4 and args.presteps_elapsed_time >= 0
+    ck = torch.load(os.path.join(enc, "grid_checkpoint.pth"), weights_only=False)
+    assert ck[(100, 0.01, 0.01)] == 0.70 and ck["header"] == ("dim", "alpha", "lr")
+    ebll.prestep(args, manager)                      # everything is in the checkpoint: nothing is retrained
+    assert len(calls) == 4
+
+
+def test_task_dataset_cache_passthrough_on_cpu(tmp_path):
+    """load_task_datasets: dict passes through; without a device the file is simply unpickled (no HBM cache)."""
+    from clsurvey_amd import data as D
+    d = D.synthetic_task(8, 4, 4, 2, hw=8, seed=1)
+    assert D.load_task_datasets(d) is d
+    p = os.path.join(str(tmp_path), "t.pth.tar")
+    torch.save(d, p)
+    got = D.load_task_datasets(p)
+    assert sorted(got) == ["test", "train", "val"] and torch.equal(got["train"].x, d["train"].x)
