@@ -16,7 +16,7 @@ _l = C.c_long
 class LayerDesc(C.Structure):
     _fields_ = [("type", _i), ("cin", _i), ("cout", _i), ("relu", _i), ("pool", _i),
                 ("w_off", _l), ("b_off", _l), ("ksize", _i), ("stride", _i), ("pad", _i), ("pool_k", _i), ("pool_s", _i),
-                ("bn", _i), ("bn_w_off", _l), ("bn_b_off", _l)]
+                ("bn", _i), ("bn_w_off", _l), ("bn_b_off", _l), ("has_drop", _i)]
 
 
 # name -> (restype, argtypes); mirrors include/clhip.h one to one

@@ -35,6 +35,8 @@ struct LayerPlan {
     const float* extra_grad;   // added to the gradient w.r.t. this layer's input (side branches: clhip_net_set_input_grad)
     const float* drop;     // dropout mask applied to this layer's INPUT (NULL = none); see clhip_net_set_dropout
     long drop_stride;      // floats between the mask rows of consecutive samples (0 = one row shared by the batch)
+    int has_drop_buf;      // the masked input gets its own buffer (the un-masked activation stays readable: side branches)
+    size_t drop_off;       // float offset of that buffer in ws
 };
 
 struct NetPlan {
@@ -83,6 +85,21 @@ __global__ void add_inplace_kernel(float* __restrict__ a, const float* __restric
 
 int add_inplace(float* a, const float* b, size_t n, hipStream_t s) {
     hipLaunchKernelGGL(add_inplace_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, s, a, b, n);
+    CLHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void drop_copy_kernel(const float* __restrict__ h, float* __restrict__ out, const float* __restrict__ mask, long stride,
+                                 int feat, size_t total) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t n = i / feat, f = i - n * feat;
+        out[i] = h[i] * mask[n * stride + f];
+    }
+}
+
+int drop_copy(const float* h, float* out, const float* mask, long stride, size_t feat, int N, hipStream_t s) {
+    const size_t total = feat * N;
+    hipLaunchKernelGGL(drop_copy_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, s, h, out, mask, stride, (int)feat, total);
     CLHIP_LAUNCH_CHECK();
     return 0;
 }
@@ -167,6 +184,8 @@ int clhip_net_create(const clhip_layer_desc* descs, int n_layers, int max_batch,
             if (L.out_elems > gmax) gmax = L.out_elems;
             feat = L.out_elems;
         } else { delete p; return CLHIP_EINVAL; }
+        L.has_drop_buf = (descs[i].has_drop && i > 0) ? 1 : 0;
+        if (L.has_drop_buf) { L.drop_off = acts; acts += L.in_elems * max_batch; }
         p->layers.push_back(L);
     }
     p->n_classes = (int)feat;
@@ -294,7 +313,12 @@ int clhip_net_forward(void* handle, const float* params, const float* x, int N, 
     for (size_t li = 0; li < p->layers.size(); ++li) {
         const LayerPlan& L = p->layers[li];
         float* y = acts + L.act_off;
-        if (L.drop) {       // li > 0: cur is the previous layer's saved output; masked in place so that backward sees h * m
+        if (L.drop && L.has_drop_buf) {       // masked copy: backward reads it as this layer's input, cur stays intact
+            float* dropped = acts + L.drop_off;
+            rc = drop_copy(cur, dropped, L.drop, L.drop_stride, L.in_elems, N, as_stream(stream));
+            if (rc) return rc;
+            cur = dropped;
+        } else if (L.drop) {    // li > 0: cur is the previous layer's saved output; masked in place so that backward sees h * m
             rc = drop_scale(const_cast<float*>(cur), L.drop, L.drop_stride, L.in_elems, N, as_stream(stream));
             if (rc) return rc;
         }
@@ -411,6 +435,7 @@ int clhip_net_backward(void* handle, const float* params, float* grads, const fl
         if (i > 0) {
             const LayerPlan& P = p->layers[i - 1];
             xin = acts + ((P.type == 0 && P.pool) ? P.pool_off : P.act_off);
+            if (L.drop && L.has_drop_buf) xin = acts + L.drop_off;
         }
         if (L.type == 1) {
             if (!p->fc_fused) {
@@ -437,7 +462,12 @@ int clhip_net_backward(void* handle, const float* params, float* grads, const fl
             }
             if (p->fc_fused && i == p->fc_first) {
                 // all dz_l are in place: dW_l, db_l of every Linear layer in one launch
-                rc = clhip_internal_fc_chain_wgrad(&p->chain, grads, xin, N, acts, dlogits, fcdz, main_s);
+                clhip_fc_chain ch = p->chain;       // inputs of the hidden layers: their masked copies where a dropout is active
+                for (int l = 1; l < ch.n; ++l) {
+                    const LayerPlan& Ll = p->layers[p->fc_first + l];
+                    if (Ll.drop && Ll.has_drop_buf) ch.act_off[l - 1] = Ll.drop_off;
+                }
+                rc = clhip_internal_fc_chain_wgrad(&ch, grads, xin, N, acts, dlogits, fcdz, main_s);
                 if (rc) return rc;
             }
             continue;

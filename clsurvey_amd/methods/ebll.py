@@ -235,9 +235,6 @@ class EbllEngine:
         self.lwf = LwfEngine(wrapper, max_batch, in_shape, device)
         eng = self.lwf.engine
         self.fc_first = next(i for i, sp in enumerate(eng.layers) if sp[0] == "fc")
-        if self.fc_first in eng.drops:
-            raise NotImplementedError("EBLL: a Dropout directly on the flattened features (AlexNet's classifier[0]) masks "
-                                      "the activation the code layers read; not on the HIP path yet")
         self.wrapper = wrapper
         self.device = eng.device
         self.code_loss = torch.zeros(1, dtype=torch.float32, device=self.device)

@@ -205,6 +205,8 @@ class NetEngine:
                 d.ksize, d.stride, d.pad = (int(v) for v in (sp[7] if len(sp) > 7 else (w.shape[2], 1, w.shape[2] // 2)))
             d.w_off = self.arena.slot(w)[0]
             d.b_off = self.arena.slot(b)[0]
+        for li in self.drops:
+            descs[li].has_drop = 1
         for li, bn in self.bns.items():
             descs[li].bn = 1
             descs[li].bn_w_off = self.arena.slot(bn.weight)[0]

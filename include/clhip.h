@@ -241,6 +241,9 @@ typedef struct {
     int pool_k, pool_s;
     int bn;                   /* conv layers: 1 = BatchNorm2d between the convolution and the ReLU (clhip_net_set_bn) */
     long bn_w_off, bn_b_off;  /* float offsets of the BatchNorm weight / bias in the parameter arena */
+    int has_drop;             /* a dropout may be set in front of this layer (clhip_net_set_dropout): its masked input gets
+                               * its own buffer, so that the un-masked activation stays readable (clhip_net_layer_input);
+                               * without it the mask is applied in place */
 } clhip_layer_desc;
 
 int clhip_net_create(const clhip_layer_desc* layers, int n_layers, int max_batch, int in_c, int in_h,

@@ -1389,3 +1389,59 @@ def test_gem_gram_and_project_alexnet_scale():
     for a in range(m):
         want += float(np.float32(v[a])) * G[rows[a], :n].double()
     assert float((o.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+def test_ebll_step_with_dropout_on_the_features():
+    """EBLL on an AlexNet-structured net: classifier[0] is a Dropout on the flattened features, which the code layers
+    must read UN-masked (AlexNet_EBLL.py:110-117 applies the encoders before the classifier).  The plan keeps the masked
+    copy in its own buffer; objective and all gradients vs torch CPU with the same masks."""
+    import copy
+    import torch.nn.functional as F
+    from oracle import ebll_ref as EB
+    from clsurvey_amd.methods import ebll as E
+    model, _ = _small_alexnet(ncls=4, seed=9)
+    gen = np.random.default_rng(17)
+    ae = E.AutoEncoder(16, 6)
+    with torch.no_grad():
+        ae.encode[0].weight.copy_(rnd(gen, 6, 16) * 0.3)
+        ae.encode[0].bias.copy_(rnd(gen, 6) * 0.05)
+    w = E.AlexNet_EBLL(model, ae, last_layer_name=6)
+    head = torch.nn.Linear(64, 4)
+    w.classifier.add_module("7", head)
+    ref = copy.deepcopy(w)
+    N = 6
+    x = rnd(gen, N, 3, 67, 67)
+    y = torch.from_numpy(gen.integers(0, 4, N))
+    tl = rnd(gen, N, 4) * 2
+    tcode = torch.from_numpy(gen.uniform(0.1, 0.9, (N, 6)).astype(np.float32))
+    m0 = torch.from_numpy((gen.random((N, 16)) < 0.5).astype(np.float32) * 2)
+    m1 = torch.from_numpy((gen.random((N, 64)) < 0.5).astype(np.float32) * 2)
+    lam, alpha = 3.0, 2.0
+    # ---- torch CPU
+    feat = torch.flatten(ref.features(x), 1)
+    enc0 = ref.autoencoders._modules["0"][0]
+    code = EB.encode(feat, enc0.weight, enc0.bias)
+    cls = list(ref.classifier.children())
+    h = F.relu(cls[1](feat * m0))
+    h = F.relu(cls[4](h * m1))
+    outs = [cls[6](h), cls[7](h)]
+    task, dist, closs = EB.stage2_objective(outs, [code], y, [tl], [tcode], 2.0, lam, alpha)
+    leaves = [p for n, p in ref.named_parameters() if not n.startswith("autoencoders")]
+    grads = torch.autograd.grad(task + dist + alpha * closs, leaves)
+    # ---- device
+    w = w.to(dev())
+    eng = E.EbllEngine(w, N, (3, 67, 67), dev())
+    assert eng.fc_first == 5 and sorted(eng.lwf.engine.drops) == [5, 6]
+    eng.lwf.engine.auto_dropout = False
+    eng.lwf.engine.set_dropout(5, m0.to(dev()))
+    eng.lwf.engine.set_dropout(6, m1.to(dev()))
+    loss2, code_loss = eng.step(x.to(dev()), y.to(dev()), tl.to(dev()), [tcode.to(dev())], 2.0, lam, alpha, backward=True)
+    assert abs(float(loss2[0]) - float(task)) <= 2e-4 * max(1.0, abs(float(task)))
+    assert abs(float(loss2[1]) - float(dist)) <= 2e-4 * max(1.0, abs(float(dist)))
+    assert abs(float(code_loss) - float(closs)) <= 2e-4 * max(1.0, abs(float(closs)))
+    assert_close(eng.features(N).cpu(), feat.detach(), tol=1e-5, what="un-masked features after the step")
+    named = dict(w.named_parameters())
+    floor = 1e-4 * max(float(g.abs().max()) for g in grads)
+    for (name, _), g in zip([(n, p) for n, p in ref.named_parameters() if not n.startswith("autoencoders")], grads):
+        got = eng.arena.view("grad", named[name]).cpu()
+        assert float((got - g).abs().max()) <= 2e-3 * max(float(g.abs().max()), floor), name
