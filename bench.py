@@ -70,7 +70,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=14)      # ~12 s of host work at ~0.85 s per step
     ap.add_argument("--kernel-iters", type=int, default=20)
     return ap.parse_args()
 
