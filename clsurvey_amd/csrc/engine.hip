@@ -31,6 +31,7 @@ struct LayerPlan {
     size_t z_off;          // bn: float offset of the convolution output (pre-BatchNorm) in ws
     size_t stat_off;       // bn: float offset of save_mean[cout], save_invstd[cout]
     float* rmean; float* rvar; float bn_momentum, bn_eps;
+    int wg3;                   // weight gradient on the 3x3 kernel (else the general gather-GEMM)
     size_t wg_off, wg_bytes;   // this layer's own weight-gradient slabs (3x3 layers; reduced for all layers at once)
     const float* extra_grad;   // added to the gradient w.r.t. this layer's input (side branches: clhip_net_set_input_grad)
     const float* drop;     // dropout mask applied to this layer's INPUT (NULL = none); see clhip_net_set_dropout
@@ -164,10 +165,14 @@ int clhip_net_create(const clhip_layer_desc* descs, int n_layers, int max_batch,
                 L.idx_off = idxb; idxb += align_up(L.pool_elems * max_batch, 256);
                 oh = L.ph; ow = L.pw;
             }
-            size_t s = vgg ? clhip_conv3x3_bwd_weight_ws(max_batch, L.cin, L.cout, L.h, L.w)
-                           : clhip_conv2d_bwd_weight_ws(max_batch, L.cin, L.h, L.w, L.cout, L.ks, L.ks, L.st, L.pd);
+            // 3x3 layers whose rows are not 16-byte aligned (AlexNet's 13x13 maps) would take the scalar-staging variant of
+            // the 3x3 weight-gradient kernel with 16x4-pixel tiles (169 of 256 slots): the dense gather-GEMM is 1.8x faster
+            // there (measured 83 vs 46 TFLOP/s)
+            L.wg3 = (vgg && (L.w % 4 == 0 || L.cin * 9 <= 32)) ? 1 : 0;
+            size_t s = L.wg3 ? clhip_conv3x3_bwd_weight_ws(max_batch, L.cin, L.cout, L.h, L.w)
+                             : clhip_conv2d_bwd_weight_ws(max_batch, L.cin, L.h, L.w, L.cout, L.ks, L.ks, L.st, L.pd);
             if (s > scratch) scratch = s;
-            if (vgg) { L.wg_off = wg_total; L.wg_bytes = align_up(s, 256); wg_total += L.wg_bytes; ++n_wg; }
+            if (L.wg3) { L.wg_off = wg_total; L.wg_bytes = align_up(s, 256); wg_total += L.wg_bytes; ++n_wg; }
             if (L.out_elems > gmax) gmax = L.out_elems;
             if (L.in_elems > gmax) gmax = L.in_elems;
             h = oh; w = ow;
@@ -509,16 +514,16 @@ int clhip_net_backward(void* handle, const float* params, float* grads, const fl
         }
         if (!wdone) {
             rc = on_side(i, gy_buf, [&](void* st) {
-                if (vgg && defer)
+                if (L.wg3 && defer)
                     return clhip_internal_conv3x3_wgrad_partial(xin, gy, nullptr, grads + L.w_off, grads + L.b_off, N, L.cin, L.cout, L.h,
                                                                 L.w, base + p->off_wg + L.wg_off, L.wg_bytes, st, &jobs[n_jobs]);
-                return vgg ? clhip_conv3x3_bwd_weight(xin, gy, grads + L.w_off, grads + L.b_off, N, L.cin, L.cout, L.h, L.w, scratch,
+                return L.wg3 ? clhip_conv3x3_bwd_weight(xin, gy, grads + L.w_off, grads + L.b_off, N, L.cin, L.cout, L.h, L.w, scratch,
                                                       p->scratch_bytes, st)
                            : clhip_conv2d_bwd_weight(xin, gy, grads + L.w_off, grads + L.b_off, N, L.cin, L.h, L.w, L.cout, L.ks, L.ks,
                                                      L.st, L.pd, scratch, p->scratch_bytes, st);
             });
             if (rc) return rc;
-            if (vgg && defer) ++n_jobs;
+            if (L.wg3 && defer) ++n_jobs;
         }
         if (i > 0) {
             float* gout = take();
