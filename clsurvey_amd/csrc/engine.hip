@@ -1,4 +1,10 @@
-// Static-plan executor for VGG-style nets ([conv3x3+ReLU (+maxpool2)]* -> [Linear(+ReLU)]*).
+// Static-plan executor for the reference's feature-extractor / classifier nets:
+//   [conv (any square kernel / stride / pad) (+BatchNorm2d) (+ReLU) (+max-pool)]* -> [(Dropout) Linear (+ReLU)]*
+// i.e. VGGSlim and its _BN / _DROP variants (models/VGGSlim.py:27-76) and torchvision's AlexNet (models/net.py:96-125).
+// 3x3 stride-1 pad-1 layers take the conv3x3.hip fast path (fused ReLU + 2x2 pool forward, fused un-pool first-layer
+// weight gradient, one deferred reduction launch for all weight-gradient slabs); everything else runs through the
+// general kernels (conv2d.hip, pool.hip, bn.hip).  Side inputs per layer: dropout mask rows, an extra gradient for
+// side branches (EBLL's code layers), BatchNorm running buffers.
 //
 // The reference trains through nn.Sequential + autograd, one Python dispatch per op per batch
 // (EWC/train_EWC.py:181-189).  At N=200 a small_VGG9 step is < 1 ms of MFMA work, so the op
