@@ -314,6 +314,7 @@ def main():
             out["config"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     if dist:
+        dist.barrier()          # rank 0 was still timing kernels: tear the communicator down together
         dist.destroy_process_group()
 
 
