@@ -742,3 +742,68 @@ def test_ebll_through_driver(tmp_path):
     enc_dir = os.path.join(out["manager"].parent_exp_dir, "task_1", "ENCODER_TRAINING")
     assert os.path.exists(os.path.join(enc_dir, "grid_checkpoint.pth"))
     assert len([d for d in os.listdir(enc_dir) if d.startswith("dim=")]) == 1       # the losing grid node is removed
+
+
+def test_end_to_end_mas_si_match_reference_driver_g17(tmp_path, golden):
+    """BASELINE configs[2] methods at the framework level: same tiny 3-task sequence, start weights, flags and seeds as the
+    runs of the reference's UNCHANGED framework/main.py recorded in G17 (make_g17.py) — SI first-task dump, then MAS and
+    SI with --test.  Same criteria as the EWC run of G10: grid accuracies, every phase-2 attempt, the final state,
+    the just-trained task's test accuracy; importance-weight statistics to their order of magnitude."""
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from g10_weights import det_weights
+    from clsurvey_amd import models
+    from clsurvey_amd.framework import driver
+    from clsurvey_amd.framework.tasks import SyntheticTaskSequence
+    from clsurvey_amd.methods import method as M
+    g = golden("G17_framework_mas_si")
+    root = str(tmp_path)
+    ds = SyntheticTaskSequence(os.path.join(root, "data"), task_count=3, classes_per_task=4, sizes=(160, 40, 40),
+                               hw=32, noise=0.4, name="tiny3")
+    m = models.parse_model_name("small_VGG9_cl_128_128", (32, 32), 4)
+    with torch.no_grad():
+        for p, w in zip(m.parameters(), det_weights()):
+            p.copy_(torch.from_numpy(w))
+    os.makedirs(os.path.join(root, "models"))
+    torch.save(m, os.path.join(root, "models", "small_VGG9_cl_128_128.pth.tar"))
+    flags = COMMON + ["--drop_margin", "0.05"]
+    driver.main(flags + ["--method_name", "SI", "--results_root", root, "--runmode", "first_task_basemodel_dump"],
+                method=M.parse("SI"), dataset=ds)
+    one = 2.0 / 40 + 1e-9
+    three = 100.0 * 3 / 40 + 1e-9
+    for name in ("MAS", "SI"):
+        pre = name.lower() + "_"
+        meth = M.parse(name)
+        meth.hyperparams["lambda"] = float(g[pre + "lambda0"])
+        out = driver.main(flags + ["--method_name", name, "--results_root", root, "--test"], method=meth, dataset=ds)
+        assert out["args"].exp_name == str(g[pre + "exp_name"])
+        ref_attempts = g[pre + "attempts"]
+        mine = [(t, tr[0]["lambda"], tr[1]) for t, hf in zip((2, 3), out["frameworks"][1:]) for tr in hf.trace]
+        assert len(mine) == len(ref_attempts), (name, mine, ref_attempts)
+        for a, b in zip(mine, ref_attempts):
+            assert a[0] == int(b[0]) and a[1] == float(b[1]) and abs(a[2] - float(b[2])) <= one, (name, mine, ref_attempts)
+        for t, hf in zip((2, 3), out["frameworks"][1:]):
+            assert abs(hf.trace[-1][1] - float(g[pre + "t%d_val_acc" % t])) <= one, (name, t, hf.trace)
+            assert abs(hf.trace[-1][2] - float(g[pre + "t%d_threshold" % t])) <= one
+            assert hf.attempts == int(g[pre + "t%d_attempts" % t]) and hf.hyperparams["lambda"] == float(g[pre + "t%d_lambda" % t])
+            tdir = os.path.join(out["manager"].parent_exp_dir, "task_%d" % t)
+            grid = torch.load(os.path.join(tdir, "FT_LR_GRIDSEARCH", "grid_checkpoint.pth"), weights_only=False)["processed_lrs"]
+            for lr in (1e-2, 3e-3):
+                assert abs(grid[lr]["acc"][0] - float(g[pre + "t%d_lr%g" % (t, lr)][0])) <= one, (name, t, lr, grid[lr])
+            mt = torch.load(os.path.join(tdir, "TASK_TRAINING", "best_model.pth.tar"), weights_only=False)
+            om = [mt.reg_params[p]["omega"].double() for p in mt.parameters() if p in mt.reg_params]
+            ref = g[pre + "t%d_omega_stats" % t]
+            assert len(om) == ref.shape[0], (name, t, len(om), ref.shape)
+            for o, r in zip(om, ref):
+                st = np.array([float(o.sum()), float(o.max()), float(o.pow(2).sum().sqrt())])
+                # chaotic trajectories (see the G10 test): order of magnitude only; the arithmetic is pinned by G3 / G4
+                assert np.all((st <= 3.0 * r + 1e-9) & (st >= r / 3.0 - 1e-9)), (name, t, st, r)
+        res = out["results"]
+        for i in range(3):
+            got, ref = np.array(res[i]["seq_res"][i]), g[pre + "seq_res%d" % i]
+            assert got.shape == ref.shape and abs(got[0] - ref[0]) <= three, (name, i, got, ref)
+            assert np.all((got >= 0) & (got <= 100))
+            assert np.array(res[i]["seq_forgetting"][i]).shape == g[pre + "seq_forgetting%d" % i].shape
+        print("G17", name, "seq_res build:", {i: res[i]["seq_res"][i] for i in range(3)}, " reference:",
+              {i: list(g[pre + "seq_res%d" % i]) for i in range(3)})
