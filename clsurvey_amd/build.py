@@ -46,12 +46,18 @@ def build_variant(name, src, defines, verbose=True):
     Selected at run time with CLHIP_LIB=<path> (tools/ only; the product always loads libclhip.so)."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     build(verbose=verbose)
-    o = os.path.join(CSRC, src.replace(".hip", ".%s.o" % name))
-    cmd = [hipcc] + FLAGS + ["-D" + d for d in defines] + ["-c", os.path.join(CSRC, src), "-o", o]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    objs = [os.path.join(CSRC, x.replace(".hip", ".o")) if x != src else o for x in SOURCES]
+    srcs = [src] if isinstance(src, str) else list(src)
+    procs = []
+    for s in srcs:
+        o = os.path.join(CSRC, s.replace(".hip", ".%s.o" % name))
+        cmd = [hipcc] + FLAGS + ["-D" + d for d in defines] + ["-c", os.path.join(CSRC, s), "-o", o]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append(subprocess.Popen(cmd))
+    for p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed on variant " + name)
+    objs = [os.path.join(CSRC, x.replace(".hip", ".%s.o" % name if x in srcs else ".o")) for x in SOURCES]
     out = os.path.join(HERE, "libclhip_%s.so" % name)
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
     return out

@@ -21,6 +21,12 @@
 
 namespace {
 
+#ifdef CLHIP_TRACE
+// tools/trace_conv.py only (never in the product build): per-wave cycle stamps of the chunked kernel
+__device__ unsigned long long* g_trace = nullptr;
+#define TR_NOW() __builtin_amdgcn_s_memtime()
+#endif
+
 constexpr int KT = 64;     // output channels per block
 constexpr int LDW = 65;    // weight-tile row stride (odd: conflict-free transposing ds_write)
 
@@ -70,6 +76,10 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+#ifdef CLHIP_TRACE
+    const unsigned long long tr_start = TR_NOW();
+    unsigned long long tr_ld = 0, tr_mf = 0, tr_st = 0, tr_ba = 0;
+#endif
     const int wk = wave & 1;        // which 32 output channels
     const int wp = wave >> 1;       // which half of the pixels
     const int li = lane & 31;
@@ -292,13 +302,25 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
         }
     };
 
+#ifdef CLHIP_TRACE
+    const unsigned long long tr_idx = TR_NOW();
+#endif
     load_chunk(0);
     store_chunk(0);
     __syncthreads();
+#ifdef CLHIP_TRACE
+    const unsigned long long tr_pro = TR_NOW();
+#endif
 
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
         const int buf = chunk & 1;
+#ifdef CLHIP_TRACE
+        const unsigned long long ta = TR_NOW();
+#endif
         if (chunk + 1 < n_chunks) load_chunk(chunk + 1);
+#ifdef CLHIP_TRACE
+        const unsigned long long tb = TR_NOW();
+#endif
 
         const float* ws = lds + buf * BUF_FLOATS + a_lane;
         const float* xs = lds + buf * BUF_FLOATS + WS_FLOATS + b_lane;
@@ -330,9 +352,34 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
             __builtin_amdgcn_sched_barrier(0);
         }
 
+#ifdef CLHIP_TRACE
+        const unsigned long long tc = TR_NOW();
+#endif
         if (chunk + 1 < n_chunks) store_chunk(buf ^ 1);
+#ifdef CLHIP_TRACE
+        const unsigned long long td = TR_NOW();
+#endif
         __syncthreads();
+#ifdef CLHIP_TRACE
+        const unsigned long long te = TR_NOW();
+        tr_ld += tb - ta; tr_mf += tc - tb; tr_st += td - tc; tr_ba += te - td;
+#endif
     }
+#ifdef CLHIP_TRACE
+    const unsigned long long tr_loop = TR_NOW();
+    auto tr_finish = [&]() {
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long tr_end = TR_NOW();
+        if (g_trace && lane == 0) {
+            unsigned long long* t = g_trace + ((size_t)blockIdx.x * 4 + wave) * 16;
+            t[0] = tr_start; t[1] = tr_idx; t[2] = tr_pro; t[3] = tr_loop; t[4] = tr_end;
+            t[5] = tr_ld; t[6] = tr_mf; t[7] = tr_st; t[8] = tr_ba;
+            t[9] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
+            t[10] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // XCC_ID
+            t[11] = n_chunks;
+        }
+    };
+#endif
 
     // ---- epilogue: reg r of lane l = D[row = out-channel][col = pixel li]
     // Buffer stores: the lane's pixel/channel-base offset is one VGPR per subtile (CLHIP_OOB drops the store), the
@@ -373,6 +420,9 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
                 clhip_buf_store_u8((uint8_t)a, rs_i, okr ? eoff : CLHIP_OOB, rch(r) * chw);
             }
         }
+#ifdef CLHIP_TRACE
+        tr_finish();
+#endif
         return;
     }
     {
@@ -406,6 +456,9 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
             }
         }
     }
+#ifdef CLHIP_TRACE
+    tr_finish();
+#endif
 }
 
 template <int TW, int TH, int NB, int CK, int MODE, bool VEC>
@@ -661,6 +714,13 @@ bool vec_ok(const float* in, const float* wt, int Cin, int H, int W, int Cw) {
 }  // namespace
 
 extern "C" {
+
+#ifdef CLHIP_TRACE
+int clhip_debug_set_conv_trace(void* p) {
+    unsigned long long* q = static_cast<unsigned long long*>(p);
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &q, sizeof(q));
+}
+#endif
 
 int clhip_conv3x3_fwd(const float* x, const float* w, const float* b, float* y,
                       int N, int C, int K, int H, int W, int relu, void* stream) {

@@ -23,6 +23,12 @@ namespace {
 
 constexpr int KT = 64, CT = 64;
 
+#ifdef CLHIP_TRACE
+// tools/trace_conv.py only (never in the product build): per-wave cycle stamps
+__device__ unsigned long long* g_wtrace = nullptr;
+#define TR_NOW() __builtin_amdgcn_s_memtime()
+#endif
+
 template <int TW, int TH>
 struct WGeo {
     static constexpr int BP = TW * TH;                 // 64 pixels per stage, one image
@@ -63,6 +69,10 @@ __global__ __launch_bounds__(256, PS ? 2 : CLHIP_WGRAD_MINBLK) void conv3x3_wgra
     __shared__ float xs[(CTt * G::PLANEP > 3 * 1024 + 64) ? CTt * G::PLANEP : 3 * 1024 + 64];   // PS: reused as the 12 KB reduction pad
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef CLHIP_TRACE
+    const unsigned long long tr_start = TR_NOW();
+    unsigned long long tr_ld = 0, tr_mf = 0, tr_st = 0, tr_ba = 0;
+#endif
     const int wk = PS ? 0 : (wave & 1), wc = PS ? 0 : (wave >> 1);
     const int li = lane & 31, kk = lane >> 5;
 
@@ -228,12 +238,28 @@ __global__ __launch_bounds__(256, PS ? 2 : CLHIP_WGRAD_MINBLK) void conv3x3_wgra
         }
     };
 
+#ifdef CLHIP_TRACE
+    const unsigned long long tr_idx = TR_NOW();
+#endif
     if (st_begin < st_end) load_stage(st_begin);
     for (int st = st_begin; st < st_end; ++st) {
+#ifdef CLHIP_TRACE
+        const unsigned long long ta = TR_NOW();
+#endif
         __syncthreads();               // previous stage's LDS reads are done
+#ifdef CLHIP_TRACE
+        const unsigned long long tb = TR_NOW();
+#endif
         store_stage();
         __syncthreads();
+#ifdef CLHIP_TRACE
+        const unsigned long long tc = TR_NOW();
+#endif
         if (st + 1 < st_end) load_stage(st + 1);   // in flight while the matrix pipe runs
+#ifdef CLHIP_TRACE
+        const unsigned long long td = TR_NOW();
+        tr_ba += tb - ta; tr_st += tc - tb; tr_ld += td - tc;
+#endif
         // operands of pixel pair pp+1 are read while the 9 MFMAs of pair pp run (explicit register
         // double buffering; see conv3x3.hip)
         float af[2], bf[2][9];
@@ -263,7 +289,25 @@ __global__ __launch_bounds__(256, PS ? 2 : CLHIP_WGRAD_MINBLK) void conv3x3_wgra
                 acc[rs] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[pp & 1], bf[pp & 1][rs], acc[rs], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+#ifdef CLHIP_TRACE
+        tr_mf += TR_NOW() - td;
+#endif
     }
+#ifdef CLHIP_TRACE
+    const unsigned long long tr_loop = TR_NOW();
+    auto tr_finish = [&]() {
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long tr_end = TR_NOW();
+        if (g_wtrace && lane == 0) {
+            unsigned long long* t = g_wtrace + ((size_t)blockIdx.x * 4 + wave) * 16;
+            t[0] = tr_start; t[1] = tr_idx; t[2] = tr_idx; t[3] = tr_loop; t[4] = tr_end;
+            t[5] = tr_ld; t[6] = tr_mf; t[7] = tr_st; t[8] = tr_ba;
+            t[9] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
+            t[10] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // XCC_ID
+            t[11] = st_end - st_begin;
+        }
+    };
+#endif
 
     float* slab = part + (size_t)split * slab_stride;
     if constexpr (PS) {
@@ -303,6 +347,9 @@ __global__ __launch_bounds__(256, PS ? 2 : CLHIP_WGRAD_MINBLK) void conv3x3_wgra
                 if (kk == 0 && k < K) slab[(size_t)9 * K * C + k] = (float)tot;
             }
         }
+#ifdef CLHIP_TRACE
+        tr_finish();
+#endif
         return;
     }
 
@@ -320,6 +367,9 @@ __global__ __launch_bounds__(256, PS ? 2 : CLHIP_WGRAD_MINBLK) void conv3x3_wgra
         int k = k0 + wk * 32 + li;
         if (kk == 0 && k < K) slab[(size_t)9 * K * C + k] = (float)bsum;
     }
+#ifdef CLHIP_TRACE
+    tr_finish();
+#endif
 }
 
 // First-layer variant: C*9 <= 32 columns in one accumulator. Block = 256 threads = 4 waves:
@@ -617,6 +667,13 @@ WPlan make_plan(int N, int C, int K, int H, int W) {
 }  // namespace
 
 extern "C" {
+
+#ifdef CLHIP_TRACE
+int clhip_debug_set_wgrad_trace(void* p) {
+    unsigned long long* q = static_cast<unsigned long long*>(p);
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wtrace), &q, sizeof(q));
+}
+#endif
 
 size_t clhip_conv3x3_bwd_weight_ws(int N, int C, int K, int H, int W) {
     if (N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0) return 0;
