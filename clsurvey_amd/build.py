@@ -9,7 +9,11 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libclhip.so")
 SOURCES = ["elementwise.hip", "loss.hip", "pool.hip", "conv3x3.hip", "conv3x3_wgrad.hip", "conv2d.hip", "bn.hip", "gemm.hip", "fc_chain.hip",
            "packnet.hip", "hat.hip", "gem.hip", "engine.hip", "debug_naive.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# -pragma-unroll-threshold: the software-pipelined conv loops are fully unrolled by `#pragma unroll` (one piece of
+# staging work per MFMA slot, all register-array indices constant); at the default threshold hipcc silently stops
+# unrolling the largest instance and its operand registers land in scratch / LDS.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-mllvm", "-pragma-unroll-threshold=100000"]
 
 
 def _newer(a, b):

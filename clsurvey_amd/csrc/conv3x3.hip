@@ -78,7 +78,6 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
     const int wave = tid >> 6;
 #ifdef CLHIP_TRACE
     const unsigned long long tr_start = TR_NOW();
-    unsigned long long tr_ld = 0, tr_mf = 0, tr_st = 0, tr_ba = 0;
 #endif
     const int wk = wave & 1;        // which 32 output channels
     const int wp = wave >> 1;       // which half of the pixels
@@ -97,6 +96,226 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
     const int ko0 = kt * KT;        // first output channel of this block
     if (MODE == 0 && threadIdx.x < KT) bias_s[threadIdx.x] = (bias && ko0 + (int)threadIdx.x < Cout) ? bias[ko0 + threadIdx.x] : 0.f;
 
+    constexpr int W_ELEMS = KT * CK * 9;
+    const size_t plane_hw = (size_t)H * W;
+    const int n_chunks = (Cin + CK - 1) / CK;
+    const float* in_blk = in + (size_t)n0 * Cin * plane_hw;
+
+    // ------------------------------------------------------------------ staging
+    // All index math is done ONCE per block; per chunk only base pointers move.  Every load is
+    // unconditional + a select on the OFFSET (no exec-mask branches, nothing waits on a load).
+    //  VEC (aligned shapes: Cin % 8 == 0, W % 4 == 0, W % TW == 0, Cw % 4 == 0): 16-byte global loads
+    //      — weights 4.5 / activations 1.5-2 (+halo columns) instructions per thread per chunk;
+    //  scalar path: first layer (C = 3) and odd shapes.
+    // A chunk's staging work is cut into UNITS (one global load + the LDS writes of its result); the main loop
+    // issues them one at a time in the shadow of the MFMAs (see "pipeline" below).
+    constexpr int W_IT = VEC ? (W_ELEMS / 4 + 255) / 256 : (W_ELEMS + 255) / 256;
+    constexpr int XROWS = CK * NB * (TH + 2);                 // halo-plane rows per chunk
+    constexpr int XV_ELEMS = XROWS * (TW / 4);                // interior float4 per chunk
+    constexpr int X_IT = VEC ? (XV_ELEMS + 255) / 256 : (XS_FLOATS + 255) / 256;
+    constexpr int H_IT = VEC ? (XROWS * 2 + 255) / 256 : 0;   // halo-column scalars
+    constexpr int NUNITS = W_IT + X_IT + H_IT;
+    float4 wv[VEC ? W_IT : 1];
+    float4 xv[VEC ? X_IT : 1];
+    float hv[VEC ? (H_IT > 0 ? H_IT : 1) : 1];
+    float wreg[VEC ? 1 : W_IT];
+    float xreg[VEC ? 1 : X_IT];
+    int woff[W_IT], wdst[VEC ? W_IT * (MODE == 0 ? 1 : 4) : W_IT];
+    int xoff[X_IT], xdst[VEC ? X_IT : 1];
+    int hoff[H_IT > 0 ? H_IT : 1], hdst[H_IT > 0 ? H_IT : 1];
+    int wch[VEC ? 1 : W_IT], xch[VEC ? 1 : X_IT];             // scalar path: channel-in-chunk (tail chunks)
+
+    // ---- part A: global offsets only, so that chunk 0 is in flight while the rest of the index math runs.
+    // Raw buffer loads: out-of-range / halo elements get voffset = CLHIP_OOB and read back as 0 from the hardware
+    // range check (no select on the loaded value), the per-chunk base is the scalar offset of the instruction.
+    if constexpr (VEC) {
+#pragma unroll
+        for (int j = 0; j < W_IT; ++j) {
+            const int e = tid + 256 * j;
+            woff[j] = CLHIP_OOB;
+            if (MODE == 0) {
+                const int kl = e / (CK * 9 / 4), f = e - kl * (CK * 9 / 4);
+                if (e < W_ELEMS / 4 && ko0 + kl < Kw) woff[j] = ((ko0 + kl) * Cw * 9 + 4 * f) * 4;
+            } else {
+                const int kl = e / (KT * 9 / 4), f = e - kl * (KT * 9 / 4);
+                if (e < W_ELEMS / 4 && 4 * f < (Cw - ko0) * 9) woff[j] = ((kl * Cw + ko0) * 9 + 4 * f) * 4;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < X_IT; ++j) {
+            const int e = tid + 256 * j;
+            const int rowid = e / (TW / 4), f = e - rowid * (TW / 4);
+            const int cl = rowid / (NB * (TH + 2)), rr = rowid - cl * (NB * (TH + 2));
+            const int nb = rr / (TH + 2), row = rr - nb * (TH + 2);
+            const int n = n0 + nb, h = h0 - 1 + row;
+            xoff[j] = CLHIP_OOB;
+            if (e < XV_ELEMS && n < N && h >= 0 && h < H)
+                xoff[j] = ((int)(((size_t)nb * Cin + cl) * plane_hw) + h * W + w0 + 4 * f) * 4;
+        }
+#pragma unroll
+        for (int j = 0; j < H_IT; ++j) {
+            const int e = tid + 256 * j;
+            const int rowid = e >> 1, side = e & 1;
+            const int cl = rowid / (NB * (TH + 2)), rr = rowid - cl * (NB * (TH + 2));
+            const int nb = rr / (TH + 2), row = rr - nb * (TH + 2);
+            const int n = n0 + nb, h = h0 - 1 + row, w = side ? w0 + TW : w0 - 1;
+            hoff[j] = CLHIP_OOB;
+            if (e < XROWS * 2 && n < N && h >= 0 && h < H && w >= 0 && w < W)
+                hoff[j] = ((int)(((size_t)nb * Cin + cl) * plane_hw) + h * W + w) * 4;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < W_IT; ++j) {
+            const int e = tid + 256 * j;
+            woff[j] = CLHIP_OOB; wch[j] = 0;
+            if (e < W_ELEMS) {
+                if (MODE == 0) {
+                    const int kl = e / (CK * 9), kidx = e - kl * (CK * 9);
+                    wch[j] = kidx / 9;
+                    if (ko0 + kl < Kw) woff[j] = ((ko0 + kl) * Cw * 9 + kidx) * 4;
+                } else {
+                    const int kl = e / (KT * 9), rem = e - kl * (KT * 9);
+                    const int cl = rem / 9;
+                    wch[j] = kl;
+                    if (ko0 + cl < Cw) woff[j] = ((kl * Cw + ko0) * 9 + rem) * 4;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < X_IT; ++j) {
+            const int e = tid + 256 * j;
+            xoff[j] = CLHIP_OOB; xch[j] = 0;
+            if (e < XS_FLOATS) {
+                const int cl = e / G::PLANE, rem = e - cl * G::PLANE;
+                const int col = rem % G::TWP, rr = rem / G::TWP;
+                const int row = rr % (TH + 2), nb = rr / (TH + 2);
+                const int n = n0 + nb, h = h0 - 1 + row, w = w0 - 1 + col;
+                xch[j] = cl;
+                if (n < N && h >= 0 && h < H && w >= 0 && w < W)
+                    xoff[j] = ((int)(((size_t)nb * Cin + cl) * plane_hw) + h * W + w) * 4;
+            }
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rs_w = clhip_rsrc(wt, (size_t)Kw * Cw * 9 * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rs_x = clhip_rsrc(in_blk, (size_t)(N - n0) * Cin * plane_hw * sizeof(float));
+
+    // unit u of chunk `chunk` -> staging registers.  Chunks past the end load nothing (every voffset OOB).
+    auto load_unit = [&](int u, int chunk) {
+#ifdef CLHIP_ABL_NOLOAD
+        if (chunk >= 2) return;
+#endif
+        const int c0 = chunk * CK;
+        const bool live = chunk < n_chunks;                                   // wave-uniform
+        const int wb = (MODE == 0 ? c0 * 9 : c0 * Cw * 9) * (int)sizeof(float);
+        const int xb = c0 * (int)plane_hw * (int)sizeof(float);
+        if constexpr (VEC) {
+            if (u < W_IT) wv[u] = clhip_buf_load4(rs_w, live ? woff[u] : CLHIP_OOB, live ? wb : 0);
+            else if (u < W_IT + X_IT) xv[u - W_IT] = clhip_buf_load4(rs_x, live ? xoff[u - W_IT] : CLHIP_OOB, live ? xb : 0);
+            else hv[u - W_IT - X_IT] = clhip_buf_load(rs_x, live ? hoff[u - W_IT - X_IT] : CLHIP_OOB, live ? xb : 0);
+        } else {
+            const int cleft = live ? Cin - c0 : 0;               // channels left (>= CK except in the tail chunk)
+            if (u < W_IT) wreg[u] = clhip_buf_load(rs_w, wch[u] < cleft ? woff[u] : CLHIP_OOB, live ? wb : 0);
+            else xreg[u - W_IT] = clhip_buf_load(rs_x, xch[u - W_IT] < cleft ? xoff[u - W_IT] : CLHIP_OOB, live ? xb : 0);
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < NUNITS; ++u) load_unit(u, 0);
+#ifdef CLHIP_TRACE
+    const unsigned long long tr_idx = TR_NOW();
+#endif
+
+    // ---- part B: LDS destinations and fragment addresses (chunk 0 is on its way)
+    if constexpr (VEC) {
+#pragma unroll
+        for (int j = 0; j < W_IT; ++j) {
+            const int e = tid + 256 * j;
+            if (MODE == 0) {
+                // row kl: CK*9 contiguous floats = CK*9/4 float4; LDS dst of float t: (4f+t)*LDW + kl
+                const int kl = e / (CK * 9 / 4), f = e - kl * (CK * 9 / 4);
+                wdst[j] = (4 * f) * LDW + kl;
+            } else {
+                // in-channel row kl: KT*9 contiguous floats (c = ko0.., rs); dst of float t individually
+                const int kl = e / (KT * 9 / 4), f = e - kl * (KT * 9 / 4);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int rem = 4 * f + t, cl = rem / 9, rs = rem - cl * 9;
+                    wdst[j * 4 + t] = (kl * 9 + (8 - rs)) * LDW + cl;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < X_IT; ++j) {
+            const int e = tid + 256 * j;
+            const int rowid = e / (TW / 4), f = e - rowid * (TW / 4);
+            const int cl = rowid / (NB * (TH + 2)), rr = rowid - cl * (NB * (TH + 2));
+            const int nb = rr / (TH + 2), row = rr - nb * (TH + 2);
+            xdst[j] = cl * G::PLANE + (nb * (TH + 2) + row) * G::TWP + 1 + 4 * f;
+        }
+#pragma unroll
+        for (int j = 0; j < H_IT; ++j) {
+            const int e = tid + 256 * j;
+            const int rowid = e >> 1, side = e & 1;
+            const int cl = rowid / (NB * (TH + 2)), rr = rowid - cl * (NB * (TH + 2));
+            const int nb = rr / (TH + 2), row = rr - nb * (TH + 2);
+            hdst[j] = cl * G::PLANE + (nb * (TH + 2) + row) * G::TWP + (side ? TW + 1 : 0);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < W_IT; ++j) {
+            const int e = tid + 256 * j;
+            wdst[j] = 0;
+            if (e < W_ELEMS) {
+                if (MODE == 0) {
+                    const int kl = e / (CK * 9), kidx = e - kl * (CK * 9);
+                    wdst[j] = kidx * LDW + kl;
+                } else {
+                    const int kl = e / (KT * 9), rem = e - kl * (KT * 9);
+                    const int cl = rem / 9, rs = rem - cl * 9;
+                    wdst[j] = (kl * 9 + (8 - rs)) * LDW + cl;
+                }
+            }
+        }
+    }
+
+    // staging registers of unit u -> LDS buffer at float offset bo
+    auto store_unit = [&](int u, int bo) {
+#ifdef CLHIP_ABL_NOSTORE
+        if (bo >= 0 && n_chunks > 0) return;
+#endif
+        float* ws = lds + bo;
+        float* xs = ws + WS_FLOATS;
+        if constexpr (VEC) {
+            if (u < W_IT) {
+                const int j = u;
+                if (256 * (j + 1) <= W_ELEMS / 4 || tid + 256 * j < W_ELEMS / 4) {
+                    if (MODE == 0) {
+                        float* d = ws + wdst[j];
+                        d[0] = wv[j].x; d[LDW] = wv[j].y; d[2 * LDW] = wv[j].z; d[3 * LDW] = wv[j].w;
+                    } else {
+                        ws[wdst[4 * j]] = wv[j].x; ws[wdst[4 * j + 1]] = wv[j].y;
+                        ws[wdst[4 * j + 2]] = wv[j].z; ws[wdst[4 * j + 3]] = wv[j].w;
+                    }
+                }
+            } else if (u < W_IT + X_IT) {
+                const int j = u - W_IT;
+                if (256 * (j + 1) <= XV_ELEMS || tid + 256 * j < XV_ELEMS) {
+                    float* d = xs + xdst[j];
+                    d[0] = xv[j].x; d[1] = xv[j].y; d[2] = xv[j].z; d[3] = xv[j].w;
+                }
+            } else {
+                const int j = u - W_IT - X_IT;
+                if (256 * (j + 1) <= XROWS * 2 || tid + 256 * j < XROWS * 2) xs[hdst[j]] = hv[j];
+            }
+        } else {
+            if (u < W_IT) {
+                if (256 * (u + 1) <= W_ELEMS || tid + 256 * u < W_ELEMS) ws[wdst[u]] = wreg[u];
+            } else {
+                const int j = u - W_IT;
+                if (256 * (j + 1) <= XS_FLOATS || tid + 256 * j < XS_FLOATS) xs[tid + 256 * j] = xreg[j];
+            }
+        }
+    };
+
     // per-lane LDS offsets of this wave's pixel subtiles (pixel q -> halo-plane address)
     int pixoff[G::NT];
 #pragma unroll
@@ -108,262 +327,89 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
     const int a_lane = kk * 9 * LDW + wk * 32 + li;   // weight-tile read offset
     const int b_lane = kk * G::PLANE;                 // activation-plane read offset
 
-    floatx16 acc[G::NT];
+    // One accumulator per 32-pixel subtile, k-ordered: the channel reduction of an output element is ONE fmaf chain in
+    // (channel, tap) order, the order the reference's CPU kernels use per output element — a two-accumulator split of
+    // the 64-pixel tiles measured no faster and let chaotic end-to-end trajectories drift from the reference's (G10).
+    constexpr int NACC = G::NT;
+    floatx16 acc[NACC];
 #pragma unroll
-    for (int t = 0; t < G::NT; ++t)
+    for (int t = 0; t < NACC; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    constexpr int W_ELEMS = KT * CK * 9;
-    const size_t plane_hw = (size_t)H * W;
-    const int n_chunks = (Cin + CK - 1) / CK;
-    const float* in_blk = in + (size_t)n0 * Cin * plane_hw;
+    // ------------------------------------------------------------------ pipeline
+    // Two LDS buffers, ONE barrier per chunk, and no phase in which the matrix pipe waits for staging: an MFMA keeps
+    // the pipe busy for 64 cycles, in whose shadow this wave issues one piece of other work per MFMA "slot":
+    //   channel pair 0          : LDS writes of chunk c+1 (loaded during chunk c-1) into the other buffer
+    //   channel pair 1          : global loads of chunk c+2 into the staging registers just freed
+    //   every pair              : the LDS operand reads of the NEXT pair (register double buffering)
+    //   last pair, after barrier: the operand reads of chunk c+1's first pair from the other buffer
+    // The barrier sits in front of the last pair: by then every wave has issued (and waited for) all its reads of the
+    // current buffer — the last pair's operands are already in registers — and all writes of chunk c+1.
+    // (Measured on the phase-separated form of this loop, one wave per SIMD: 80 % of the MFMA phase busy and
+    // load-issue + store + barrier phases worth another 45 % of it with the pipe idle.)
+    constexpr int CP = CK / 2;                         // channel pairs per chunk
+    constexpr int SL = 9 * G::NT;                      // MFMA slots per pair
+    constexpr int UPS = (NUNITS + SL - 1) / SL;        // staging units per slot
+    constexpr int CP_LD = CP > 2 ? 1 : CP - 1;
+    float af[2][9], bf[2][G::NT][9];
 
-    // ------------------------------------------------------------------ staging
-    // All index math is done ONCE per block; per chunk only base pointers move.  Every load is
-    // unconditional from an always-mapped address + a select (no exec-mask branches): measured, the
-    // per-element bounds-check branches cost ~20 VALU/SALU instructions per 4-byte load and ran in
-    // series with this wave's MFMAs.
-    //  VEC (aligned shapes: Cin % 8 == 0, W % 4 == 0, W % TW == 0, Cw % 4 == 0): 16-byte global loads
-    //      — weights 4.5 / activations 1.5-2 (+halo columns) instructions per thread per chunk;
-    //  scalar path: first layer (C = 3) and odd shapes.
-    constexpr int W_IT = VEC ? (W_ELEMS / 4 + 255) / 256 : (W_ELEMS + 255) / 256;
-    constexpr int XROWS = CK * NB * (TH + 2);                 // halo-plane rows per chunk
-    constexpr int XV_ELEMS = XROWS * (TW / 4);                // interior float4 per chunk
-    constexpr int X_IT = VEC ? (XV_ELEMS + 255) / 256 : (XS_FLOATS + 255) / 256;
-    constexpr int H_IT = VEC ? (XROWS * 2 + 255) / 256 : 0;   // halo-column scalars
-    float4 wv[VEC ? W_IT : 1];
-    float4 xv[VEC ? X_IT : 1];
-    float hv[VEC ? (H_IT > 0 ? H_IT : 1) : 1];
-    float wreg[VEC ? 1 : W_IT];
-    float xreg[VEC ? 1 : X_IT];
-    int woff[W_IT], wdst[VEC ? W_IT * (MODE == 0 ? 1 : 4) : W_IT];
-    int xoff[X_IT], xdst[VEC ? X_IT : 1];
-    int hoff[H_IT > 0 ? H_IT : 1], hdst[H_IT > 0 ? H_IT : 1];
-    unsigned wok = 0, xok = 0, hok = 0;                        // validity bit per iteration
-    int wch[VEC ? 1 : W_IT], xch[VEC ? 1 : X_IT];             // scalar path: channel-in-chunk (tail chunks)
-
-    if constexpr (VEC) {
 #pragma unroll
-        for (int j = 0; j < W_IT; ++j) {
-            const int e = tid + 256 * j;
-            woff[j] = 0;
-            if (MODE == 0) {
-                // row kl: CK*9 contiguous floats = CK*9/4 float4; LDS dst of float t: (4f+t)*LDW + kl
-                const int kl = e / (CK * 9 / 4), f = e - kl * (CK * 9 / 4);
-                wdst[j] = (4 * f) * LDW + kl;
-                if (e < W_ELEMS / 4 && ko0 + kl < Kw) { woff[j] = (ko0 + kl) * Cw * 9 + 4 * f; wok |= 1u << j; }
-            } else {
-                // in-channel row kl: KT*9 contiguous floats (c = ko0.., rs); dst of float t individually
-                const int kl = e / (KT * 9 / 4), f = e - kl * (KT * 9 / 4);
+    for (int u = 0; u < NUNITS; ++u) store_unit(u, 0);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int rem = 4 * f + t, cl = rem / 9, rs = rem - cl * 9;
-                    wdst[j * 4 + t] = (kl * 9 + (8 - rs)) * LDW + cl;
-                }
-                if (e < W_ELEMS / 4 && 4 * f < (Cw - ko0) * 9) { woff[j] = (kl * Cw + ko0) * 9 + 4 * f; wok |= 1u << j; }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < X_IT; ++j) {
-            const int e = tid + 256 * j;
-            const int rowid = e / (TW / 4), f = e - rowid * (TW / 4);
-            const int cl = rowid / (NB * (TH + 2)), rr = rowid - cl * (NB * (TH + 2));
-            const int nb = rr / (TH + 2), row = rr - nb * (TH + 2);
-            const int n = n0 + nb, h = h0 - 1 + row;
-            xdst[j] = cl * G::PLANE + (nb * (TH + 2) + row) * G::TWP + 1 + 4 * f;
-            xoff[j] = 0;
-            if (e < XV_ELEMS && n < N && h >= 0 && h < H) {
-                xoff[j] = (int)(((size_t)nb * Cin + cl) * plane_hw) + h * W + w0 + 4 * f;
-                xok |= 1u << j;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < H_IT; ++j) {
-            const int e = tid + 256 * j;
-            const int rowid = e >> 1, side = e & 1;
-            const int cl = rowid / (NB * (TH + 2)), rr = rowid - cl * (NB * (TH + 2));
-            const int nb = rr / (TH + 2), row = rr - nb * (TH + 2);
-            const int n = n0 + nb, h = h0 - 1 + row, w = side ? w0 + TW : w0 - 1;
-            hdst[j] = cl * G::PLANE + (nb * (TH + 2) + row) * G::TWP + (side ? TW + 1 : 0);
-            hoff[j] = 0;
-            if (e < XROWS * 2 && n < N && h >= 0 && h < H && w >= 0 && w < W) {
-                hoff[j] = (int)(((size_t)nb * Cin + cl) * plane_hw) + h * W + w;
-                hok |= 1u << j;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < W_IT; ++j) {
-            const int e = tid + 256 * j;
-            woff[j] = 0; wdst[j] = 0; wch[j] = 0;
-            if (e < W_ELEMS) {
-                if (MODE == 0) {
-                    const int kl = e / (CK * 9), kidx = e - kl * (CK * 9);
-                    wdst[j] = kidx * LDW + kl; wch[j] = kidx / 9;
-                    if (ko0 + kl < Kw) { woff[j] = (ko0 + kl) * Cw * 9 + kidx; wok |= 1u << j; }
-                } else {
-                    const int kl = e / (KT * 9), rem = e - kl * (KT * 9);
-                    const int cl = rem / 9, rs = rem - cl * 9;
-                    wdst[j] = (kl * 9 + (8 - rs)) * LDW + cl; wch[j] = kl;
-                    if (ko0 + cl < Cw) { woff[j] = (kl * Cw + ko0) * 9 + rem; wok |= 1u << j; }
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < X_IT; ++j) {
-            const int e = tid + 256 * j;
-            xoff[j] = 0; xch[j] = 0;
-            if (e < XS_FLOATS) {
-                const int cl = e / G::PLANE, rem = e - cl * G::PLANE;
-                const int col = rem % G::TWP, rr = rem / G::TWP;
-                const int row = rr % (TH + 2), nb = rr / (TH + 2);
-                const int n = n0 + nb, h = h0 - 1 + row, w = w0 - 1 + col;
-                xch[j] = cl;
-                if (n < N && h >= 0 && h < H && w >= 0 && w < W) {
-                    xoff[j] = (int)(((size_t)nb * Cin + cl) * plane_hw) + h * W + w;
-                    xok |= 1u << j;
-                }
-            }
-        }
-    }
-
-    // Raw buffer loads: out-of-range / halo elements get voffset = CLHIP_OOB and read back as 0 from the hardware
-    // range check (no select on the loaded value, so nothing waits on the load), the per-chunk base is the scalar
-    // offset of the instruction (not range-checked, never VALU) and an element costs at most one v_cndmask.
-    const __amdgpu_buffer_rsrc_t rs_w = clhip_rsrc(wt, (size_t)Kw * Cw * 9 * sizeof(float));
-    const __amdgpu_buffer_rsrc_t rs_x = clhip_rsrc(in_blk, (size_t)(N - n0) * Cin * plane_hw * sizeof(float));
-    if constexpr (VEC) {
-#pragma unroll
-        for (int j = 0; j < W_IT; ++j) woff[j] = ((wok >> j) & 1u) ? woff[j] * 4 : CLHIP_OOB;
-#pragma unroll
-        for (int j = 0; j < X_IT; ++j) xoff[j] = ((xok >> j) & 1u) ? xoff[j] * 4 : CLHIP_OOB;
-#pragma unroll
-        for (int j = 0; j < H_IT; ++j) hoff[j] = ((hok >> j) & 1u) ? hoff[j] * 4 : CLHIP_OOB;
-    } else {
-#pragma unroll
-        for (int j = 0; j < W_IT; ++j) woff[j] = ((wok >> j) & 1u) ? woff[j] * 4 : CLHIP_OOB;
-#pragma unroll
-        for (int j = 0; j < X_IT; ++j) xoff[j] = ((xok >> j) & 1u) ? xoff[j] * 4 : CLHIP_OOB;
-    }
-    auto load_chunk = [&](int chunk) {
-        const int c0 = chunk * CK;
-        const int wb = (MODE == 0 ? c0 * 9 : c0 * Cw * 9) * (int)sizeof(float);
-        const int xb = c0 * (int)plane_hw * (int)sizeof(float);
-        if constexpr (VEC) {
-#pragma unroll
-            for (int j = 0; j < W_IT; ++j) wv[j] = clhip_buf_load4(rs_w, woff[j], wb);
-#pragma unroll
-            for (int j = 0; j < X_IT; ++j) xv[j] = clhip_buf_load4(rs_x, xoff[j], xb);
-#pragma unroll
-            for (int j = 0; j < H_IT; ++j) hv[j] = clhip_buf_load(rs_x, hoff[j], xb);
-        } else {
-            const int cleft = Cin - c0;                  // channels left (>= CK except in the tail chunk)
-#pragma unroll
-            for (int j = 0; j < W_IT; ++j) wreg[j] = clhip_buf_load(rs_w, wch[j] < cleft ? woff[j] : CLHIP_OOB, wb);
-#pragma unroll
-            for (int j = 0; j < X_IT; ++j) xreg[j] = clhip_buf_load(rs_x, xch[j] < cleft ? xoff[j] : CLHIP_OOB, xb);
-        }
-    };
-
-    auto store_chunk = [&](int buf) {
-        float* ws = lds + buf * BUF_FLOATS;
-        float* xs = ws + WS_FLOATS;
-        if constexpr (VEC) {
-#pragma unroll
-            for (int j = 0; j < W_IT; ++j) {
-                if (tid + 256 * j < W_ELEMS / 4) {
-                    if (MODE == 0) {
-                        float* d = ws + wdst[j];
-                        d[0] = wv[j].x; d[LDW] = wv[j].y; d[2 * LDW] = wv[j].z; d[3 * LDW] = wv[j].w;
-                    } else {
-                        ws[wdst[4 * j]] = wv[j].x; ws[wdst[4 * j + 1]] = wv[j].y;
-                        ws[wdst[4 * j + 2]] = wv[j].z; ws[wdst[4 * j + 3]] = wv[j].w;
-                    }
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < X_IT; ++j) {
-                if (tid + 256 * j < XV_ELEMS) {
-                    float* d = xs + xdst[j];
-                    d[0] = xv[j].x; d[1] = xv[j].y; d[2] = xv[j].z; d[3] = xv[j].w;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < H_IT; ++j)
-                if (tid + 256 * j < XROWS * 2) xs[hdst[j]] = hv[j];
-        } else {
-#pragma unroll
-            for (int j = 0; j < W_IT; ++j)
-                if (tid + 256 * j < W_ELEMS) ws[wdst[j]] = wreg[j];
-#pragma unroll
-            for (int j = 0; j < X_IT; ++j)
-                if (tid + 256 * j < XS_FLOATS) xs[tid + 256 * j] = xreg[j];
-        }
-    };
-
-#ifdef CLHIP_TRACE
-    const unsigned long long tr_idx = TR_NOW();
-#endif
-    load_chunk(0);
-    store_chunk(0);
+    for (int u = 0; u < NUNITS; ++u) load_unit(u, 1);
     __syncthreads();
+#pragma unroll
+    for (int rs = 0; rs < 9; ++rs) {
+        const int r = rs / 3, s3 = rs - 3 * (rs / 3);
+        af[0][rs] = lds[a_lane + rs * LDW];
+#pragma unroll
+        for (int t = 0; t < G::NT; ++t) bf[0][t][rs] = lds[WS_FLOATS + b_lane + pixoff[t] + r * G::TWP + s3];
+    }
 #ifdef CLHIP_TRACE
     const unsigned long long tr_pro = TR_NOW();
 #endif
 
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
-        const int buf = chunk & 1;
-#ifdef CLHIP_TRACE
-        const unsigned long long ta = TR_NOW();
-#endif
-        if (chunk + 1 < n_chunks) load_chunk(chunk + 1);
-#ifdef CLHIP_TRACE
-        const unsigned long long tb = TR_NOW();
-#endif
-
-        const float* ws = lds + buf * BUF_FLOATS + a_lane;
-        const float* xs = lds + buf * BUF_FLOATS + WS_FLOATS + b_lane;
-        // Explicit register double-buffering of the MFMA operands: the 9 + 9*NT LDS reads of channel
-        // pair cp+1 are issued BEFORE the 9*NT MFMAs of pair cp, so every MFMA block runs with all
-        // operands already in VGPRs (hipcc otherwise schedules ds_read -> lgkmcnt(0) -> mfma chains
-        // that expose the LDS latency once per two MFMAs; measured 50 % MFMA busy).
-        float af[2][9], bf[2][G::NT][9];
-        auto load_frag = [&](int cp, int slot) {
+        const int bo = (chunk & 1) * BUF_FLOATS, bn = BUF_FLOATS - bo;
+        const float* wsc = lds + bo + a_lane;
+        const float* xsc = lds + bo + WS_FLOATS + b_lane;
+        const float* wsn = lds + bn + a_lane;
+        const float* xsn = lds + bn + WS_FLOATS + b_lane;
+#pragma unroll
+        for (int cp = 0; cp < CP; ++cp) {
 #pragma unroll
             for (int rs = 0; rs < 9; ++rs) {
-                const int r = rs / 3, s = rs - 3 * (rs / 3);
-                af[slot][rs] = ws[((2 * cp) * 9 + rs) * LDW];
+                const int r = rs / 3, s3 = rs - 3 * (rs / 3);
 #pragma unroll
-                for (int t = 0; t < G::NT; ++t)
-                    bf[slot][t][rs] = xs[(2 * cp) * G::PLANE + pixoff[t] + r * G::TWP + s];
+                for (int t = 0; t < G::NT; ++t) {
+                    const int slot = rs * G::NT + t;
+                    const int ai = t;
+                    acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cp & 1][rs], bf[cp & 1][t][rs], acc[ai], 0, 0, 0);
+#ifndef CLHIP_ABL_NOBAR
+                    if (cp == CP - 1 && slot == 0) __syncthreads();
+#endif
+#ifndef CLHIP_ABL_NOFRAG
+                    if (cp + 1 < CP) {
+                        if (t == 0) af[(cp + 1) & 1][rs] = wsc[((2 * (cp + 1)) * 9 + rs) * LDW];
+                        bf[(cp + 1) & 1][t][rs] = xsc[(2 * (cp + 1)) * G::PLANE + pixoff[t] + r * G::TWP + s3];
+                    } else {
+                        if (t == 0) af[0][rs] = wsn[rs * LDW];
+                        bf[0][t][rs] = xsn[pixoff[t] + r * G::TWP + s3];
+                    }
+#endif
+                    if (cp == 0) {
+#pragma unroll
+                        for (int u = slot * UPS; u < (slot + 1) * UPS && u < NUNITS; ++u) store_unit(u, bn);
+                    }
+                    if (cp == CP_LD) {
+#pragma unroll
+                        for (int u = slot * UPS; u < (slot + 1) * UPS && u < NUNITS; ++u) load_unit(u, chunk + 2);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-        };
-        load_frag(0, 0);
-#pragma unroll
-        for (int cp = 0; cp < CK / 2; ++cp) {
-            if (cp + 1 < CK / 2) load_frag(cp + 1, (cp + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int rs = 0; rs < 9; ++rs)
-#pragma unroll
-                for (int t = 0; t < G::NT; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cp & 1][rs], bf[cp & 1][t][rs], acc[t], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
         }
-
-#ifdef CLHIP_TRACE
-        const unsigned long long tc = TR_NOW();
-#endif
-        if (chunk + 1 < n_chunks) store_chunk(buf ^ 1);
-#ifdef CLHIP_TRACE
-        const unsigned long long td = TR_NOW();
-#endif
-        __syncthreads();
-#ifdef CLHIP_TRACE
-        const unsigned long long te = TR_NOW();
-        tr_ld += tb - ta; tr_mf += tc - tb; tr_st += td - tc; tr_ba += te - td;
-#endif
     }
 #ifdef CLHIP_TRACE
     const unsigned long long tr_loop = TR_NOW();
@@ -373,7 +419,7 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
         if (g_trace && lane == 0) {
             unsigned long long* t = g_trace + ((size_t)blockIdx.x * 4 + wave) * 16;
             t[0] = tr_start; t[1] = tr_idx; t[2] = tr_pro; t[3] = tr_loop; t[4] = tr_end;
-            t[5] = tr_ld; t[6] = tr_mf; t[7] = tr_st; t[8] = tr_ba;
+            t[5] = 0; t[6] = 0; t[7] = 0; t[8] = 0;
             t[9] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
             t[10] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // XCC_ID
             t[11] = n_chunks;
@@ -416,8 +462,9 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
                 if (bl > m) { m = bl; a = 2; }
                 if (br > m) { m = br; a = 3; }
                 const bool okr = ok && (kfull || kb + rch(r) < Cout);
-                clhip_buf_store(m, rs_o, okr ? eoff * 4 : CLHIP_OOB, rch(r) * chw * 4);
-                clhip_buf_store_u8((uint8_t)a, rs_i, okr ? eoff : CLHIP_OOB, rch(r) * chw);
+                const int eo = eoff + rch(r) * chw;
+                clhip_buf_store(m, rs_o, okr ? eo * 4 : CLHIP_OOB, 0);
+                clhip_buf_store_u8((uint8_t)a, rs_i, okr ? eo : CLHIP_OOB, 0);
             }
         }
 #ifdef CLHIP_TRACE
@@ -436,12 +483,13 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
             tile_pixel<TW, TH>(wp * G::NT + t, li, false, nb, th, tw);
             const int h = h0 + th, w = w0 + tw;
             const bool ok = (n0 + nb < N) && (h < H) && (w < W);
+            // CLHIP_OOB (0x80000000) + a channel offset < 2^31 is still out of range
             const int boff = ok ? ((nb * Cout + kb) * chw + h * W + w) * 4 : CLHIP_OOB;
             float mk[16];
             if (MODE == 1 && mask_src) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    mk[r] = clhip_buf_load(rs_m, (kfull || kb + rch(r) < Cout) ? boff : CLHIP_OOB, rch(r) * chw * 4);
+                    mk[r] = clhip_buf_load(rs_m, (kfull || kb + rch(r) < Cout) ? boff + rch(r) * chw * 4 : CLHIP_OOB, 0);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -452,7 +500,7 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
                 } else {
                     if (mask_src) v = mk[r] > 0.f ? v : 0.f;
                 }
-                clhip_buf_store(v, rs_o, (kfull || kb + rch(r) < Cout) ? boff : CLHIP_OOB, rch(r) * chw * 4);
+                clhip_buf_store(v, rs_o, (kfull || kb + rch(r) < Cout) ? boff + rch(r) * chw * 4 : CLHIP_OOB, 0);
             }
         }
     }

@@ -55,23 +55,34 @@ __device__ __forceinline__ void decode_stage(int st, int tiles_w, int tiles_h, i
 //        pixels and their accumulators are added through LDS in wave order at the end.  A 4x smaller slab per block and
 //        4x more stages per block: at 16x16 / 8x8 the 64x64 form left 1.5-3 stages per block (20-30 % lost to the
 //        whole-stage quantisation) and moved 38 MB of partial slabs per layer.
-#ifndef CLHIP_WGRAD_MINBLK
-#define CLHIP_WGRAD_MINBLK 1
+//
+// Pipeline: two LDS stage buffers, ONE barrier per stage, and all staging work issued one piece per MFMA "slot" in
+// the shadow of the 64-cycle MFMAs of the current stage (the phase-separated form of this loop — barrier, LDS writes,
+// barrier, load issue, MFMAs — measured 71 % of its time in the MFMA phase with the pixel split, 86 % without):
+//   slots 0 .. NU-1      : LDS writes of stage st+1 (loaded during stage st-1) into the other buffer
+//   slots NU .. 2 NU-1   : global (raw buffer) loads of stage st+2 into the staging registers just freed
+//   every pixel pair     : the LDS operand reads of the NEXT pair (register double buffering)
+//   last pair, after the barrier: the operand reads of stage st+1's first pair from the other buffer
+// The barrier sits behind the first MFMA of the last pixel pair: every read of the current buffer has been issued and
+// waited for by then (the last pair's operands are in registers), and so have the writes of stage st+1.
+#ifndef CLHIP_WGRAD_PS_WAVES
+#define CLHIP_WGRAD_PS_WAVES 1
 #endif
 template <int TW, int TH, bool VEC, bool PS>
-__global__ __launch_bounds__(256, PS ? 2 : CLHIP_WGRAD_MINBLK) void conv3x3_wgrad_kernel(
+__global__ __launch_bounds__(256, CLHIP_WGRAD_PS_WAVES) void conv3x3_wgrad_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
     int N, int C, int K, int H, int W, int tiles_w, int tiles_h,
     int total_stages, int splits, int c_tiles, size_t slab_stride) {
     using G = WGeo<TW, TH>;
     constexpr int KTt = PS ? 32 : 64, CTt = PS ? 32 : 64;
-    __shared__ float dys[KTt * G::LDP];
-    __shared__ float xs[(CTt * G::PLANEP > 3 * 1024 + 64) ? CTt * G::PLANEP : 3 * 1024 + 64];   // PS: reused as the 12 KB reduction pad
+    constexpr int DYS_FLOATS = KTt * G::LDP, XS_FLOATS = CTt * G::PLANEP;
+    constexpr int BUF_FLOATS = DYS_FLOATS + XS_FLOATS;
+    static_assert(!PS || 2 * BUF_FLOATS >= 9 * 1024 + 3 * 128, "the pixel-split reduction pad lives in the stage buffers");
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF_FLOATS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef CLHIP_TRACE
     const unsigned long long tr_start = TR_NOW();
-    unsigned long long tr_ld = 0, tr_mf = 0, tr_st = 0, tr_ba = 0;
 #endif
     const int wk = PS ? 0 : (wave & 1), wc = PS ? 0 : (wave >> 1);
     const int li = lane & 31, kk = lane >> 5;
@@ -93,30 +104,26 @@ __global__ __launch_bounds__(256, PS ? 2 : CLHIP_WGRAD_MINBLK) void conv3x3_wgra
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     double bsum = 0.0;      // bias sums cancel heavily: accumulate in f64 (VALU has slack)
 
-    const float* a_ptr = dys + (wk * 32 + li) * G::LDP + kk;
-    const float* b_ptr = xs + (wc * 32 + li) * G::PLANEP + kk;
-    const size_t plane_hw = (size_t)H * W;
+    const int plane_hw = H * W;
 
-    // ------------------------------------------------------------------ staging
-    // Index math hoisted out of the stage loop; loads are unconditional from always-mapped addresses
-    // + a select (no exec-mask branches), 16 bytes wide on aligned shapes (VEC): 14 load instructions
-    // per thread per stage instead of 50 four-byte loads with ~20 VALU/SALU instructions of bounds
-    // logic each — this wave is alone on its SIMD, so all of that ran with the matrix pipe idle.
+    // ------------------------------------------------------------------ staging units
+    // Every unit is ONE raw buffer load per thread (+ the LDS writes of its result).  The buffer of a stage starts at
+    // the top-left HALO element of the (image, channel block) the stage reads, so all per-thread offsets are constants
+    // >= 0 and the per-stage part is the descriptor; the hardware range check masks the channel tail (k >= K, c >= C),
+    // the halo rows / columns outside the image get CLHIP_OOB by predicate (one v_cndmask, nothing waits on a load).
     constexpr int XROWS = CTt * (TH + 2);
     constexpr int DY_IT = VEC ? (KTt * G::BP / 4) / 256 : KTt * G::BP / 256;        // 4 | 16 (PS: 2 | 8)
     constexpr int X_ELEMS = CTt * G::PLANE;
     constexpr int XV_ELEMS = XROWS * (TW / 4);
-    constexpr int X_IT = VEC ? (XV_ELEMS + 255) / 256 : (X_ELEMS + 255) / 256;      // 8|5|5 | 34|27|25
-    constexpr int H_IT = VEC ? (XROWS * 2 + 255) / 256 : 0;                          // 2|2|3
+    constexpr int X_IT = VEC ? (XV_ELEMS + 255) / 256 : (X_ELEMS + 255) / 256;
+    constexpr int H_IT = VEC ? (XROWS * 2 + 255) / 256 : 0;
+    constexpr int NU = DY_IT + X_IT + H_IT;
     float4 dyv[VEC ? DY_IT : 1], xv[VEC ? X_IT : 1];
     float hv[H_IT > 0 ? H_IT : 1];
     float dyr[VEC ? 1 : DY_IT], xr[VEC ? 1 : X_IT];
-    int dyoff[VEC ? DY_IT : 1], dydst[VEC ? DY_IT : 1], dyrow[VEC ? DY_IT : 1];
-    int xoff[X_IT], xmeta[X_IT];           // VEC: row | ldsdst<<8 | cl<<24 ; scalar: row | col<<4 | cl<<10 | ldsdst<<17
-    int hoff[H_IT > 0 ? H_IT : 1], hmeta[H_IT > 0 ? H_IT : 1];   // row | side<<4 | ldsdst<<8 | cl<<24
-    const int q_t = tid & 63;
-    const int th_t = q_t / TW, tw_t = q_t - th_t * TW;
-    const int dy_lds = wave * G::LDP + q_t;
+    int dyoff[DY_IT], dydst[DY_IT], dyrow[DY_IT];      // byte offset | LDS float offset | tile row (scalar path: | col << 8)
+    int xoff[X_IT], xdst[X_IT], xrc[X_IT];             // byte offset from the halo origin | LDS float offset | halo row | col << 8
+    int hoff[H_IT > 0 ? H_IT : 1], hdst[H_IT > 0 ? H_IT : 1], hrc[H_IT > 0 ? H_IT : 1];
 
     if constexpr (VEC) {
 #pragma unroll
@@ -124,42 +131,53 @@ __global__ __launch_bounds__(256, PS ? 2 : CLHIP_WGRAD_MINBLK) void conv3x3_wgra
             const int e = tid + 256 * j;                     // float4 index: (kl, 16 float4 per k)
             const int kl = e / (G::BP / 4), f = e - kl * (G::BP / 4);
             const int q = 4 * f, th = q / TW, tw = q - th * TW;
-            dyoff[j] = kl * (int)plane_hw + th * W + tw;
+            dyoff[j] = (kl * plane_hw + th * W + tw) * 4;
             dydst[j] = kl * G::LDP + q;
-            dyrow[j] = th | (kl << 8);
+            dyrow[j] = th;
         }
 #pragma unroll
         for (int j = 0; j < X_IT; ++j) {
             const int e = tid + 256 * j;
             const int rowid = e / (TW / 4), f = e - rowid * (TW / 4);
             const int cl = rowid / (TH + 2), row = rowid - cl * (TH + 2);
-            xoff[j] = cl * (int)plane_hw + (row - 1) * W + 4 * f;
-            xmeta[j] = row | ((cl * G::PLANEP + row * G::TWP + 1 + 4 * f) << 8) | (cl << 24);
+            xoff[j] = e < XV_ELEMS ? (cl * plane_hw + row * W + 1 + 4 * f) * 4 : CLHIP_OOB;
+            xdst[j] = cl * G::PLANEP + row * G::TWP + 1 + 4 * f;
+            xrc[j] = row;
         }
 #pragma unroll
         for (int j = 0; j < H_IT; ++j) {
             const int e = tid + 256 * j;
             const int rowid = e >> 1, side = e & 1;
             const int cl = rowid / (TH + 2), row = rowid - cl * (TH + 2);
-            hoff[j] = cl * (int)plane_hw + (row - 1) * W + (side ? TW : -1);
-            hmeta[j] = row | (side << 4) | ((cl * G::PLANEP + row * G::TWP + (side ? TW + 1 : 0)) << 8) | (cl << 24);
+            hoff[j] = e < XROWS * 2 ? (cl * plane_hw + row * W + (side ? TW + 1 : 0)) * 4 : CLHIP_OOB;
+            hdst[j] = cl * G::PLANEP + row * G::TWP + (side ? TW + 1 : 0);
+            hrc[j] = row | (side << 8);
         }
     } else {
+        const int q_t = tid & 63;
+        const int th_t = q_t / TW, tw_t = q_t - th_t * TW;
+#pragma unroll
+        for (int j = 0; j < DY_IT; ++j) {
+            const int kl = wave + 4 * j;
+            dyoff[j] = (kl * plane_hw + th_t * W + tw_t) * 4;
+            dydst[j] = kl * G::LDP + q_t;
+            dyrow[j] = th_t | (tw_t << 8);
+        }
 #pragma unroll
         for (int j = 0; j < X_IT; ++j) {
             const int e = tid + 256 * j;
-            xoff[j] = 0; xmeta[j] = 0;
+            xoff[j] = CLHIP_OOB; xdst[j] = 0; xrc[j] = 0;
             if (e < X_ELEMS) {
                 const int cl = e / G::PLANE, rem = e - cl * G::PLANE;
                 const int row = rem / G::TWP, col = rem - row * G::TWP;
-                xoff[j] = cl * (int)plane_hw + (row - 1) * W + (col - 1);
-                xmeta[j] = row | (col << 4) | (cl << 10) | ((cl * G::PLANEP + rem) << 17);
+                xoff[j] = (cl * plane_hw + row * W + col) * 4;
+                xdst[j] = cl * G::PLANEP + rem;
+                xrc[j] = row | (col << 8);
             }
         }
     }
 
-    // stages are visited in order: decode the first one with divisions, then step (tile column, tile row, image) —
-    // the ~135 scalar instructions of a full decode per stage sat in front of every stage's MFMAs of this lone wave
+    // stages are visited in order: decode the first one with divisions, then step (tile column, tile row, image)
     int cur_n, cur_th, cur_tw;
     {
         const int st0 = st_begin < st_end ? st_begin : 0;
@@ -168,130 +186,146 @@ __global__ __launch_bounds__(256, PS ? 2 : CLHIP_WGRAD_MINBLK) void conv3x3_wgra
         cur_th = t0 % tiles_h;
         cur_n = t0 / tiles_h;
     }
-    auto load_stage = [&](int) {
-        const int n = cur_n, h0 = cur_th * TH, w0 = cur_tw * TW;
-        if (++cur_tw == tiles_w) { cur_tw = 0; if (++cur_th == tiles_h) { cur_th = 0; ++cur_n; } }
-        const float* xp = x + ((size_t)n * C + c0) * plane_hw + (size_t)h0 * W + w0;
+    // descriptors + tile origin of the stage whose loads are being issued (set by begin_stage, used by load_unit).
+    // The (image, channel block) base pointers step by one image when the stage walk wraps; per stage only the tile
+    // origin inside the plane changes (32-bit), so a stage costs ~25 scalar instructions, not two 64-bit multiplies.
+    __amdgpu_buffer_rsrc_t rs_dy = clhip_rsrc(dy, 0), rs_x = clhip_rsrc(x, 0);
+    int ld_h0 = 0, ld_w0 = 0;
+    const float* dy_img = dy + ((size_t)cur_n * K + k0) * plane_hw;
+    const float* x_img = x + ((size_t)cur_n * C + c0) * plane_hw;
+    const long long dy_blk = (long long)(K - k0) * plane_hw, x_blk = (long long)(C - c0) * plane_hw;   // floats to the end of the block
+    auto begin_stage = [&](bool live) {
+        const int h0 = cur_th * TH, w0 = cur_tw * TW;
+        ld_h0 = h0; ld_w0 = w0;
+        const int org = h0 * W + w0;                                         // tile origin inside a plane
+        const long long dy_left = dy_blk - org, x_left = x_blk - (org - W - 1);
+        rs_dy = clhip_rsrc(dy_img + org, live && dy_left > 0 ? (size_t)dy_left * 4 : 0);
+        rs_x = clhip_rsrc(x_img + org - W - 1, live && x_left > 0 ? (size_t)x_left * 4 : 0);
+        if (++cur_tw == tiles_w) {
+            cur_tw = 0;
+            if (++cur_th == tiles_h) { cur_th = 0; ++cur_n; dy_img += (size_t)K * plane_hw; x_img += (size_t)C * plane_hw; }
+        }
+    };
+    auto load_unit = [&](int u) {
+#ifdef CLHIP_ABL_NOLOAD
+        if (ld_h0 >= 0) return;
+#endif
+        const int h0 = ld_h0, w0 = ld_w0;
         if constexpr (VEC) {
-            const float* dyp = dy + ((size_t)n * K + k0) * plane_hw + (size_t)h0 * W + w0;
-#pragma unroll
-            for (int j = 0; j < DY_IT; ++j) {
-                const bool ok = (h0 + (dyrow[j] & 255) < H) && (k0 + (dyrow[j] >> 8) < K);
-                dyv[j] = *reinterpret_cast<const float4*>(ok ? dyp + dyoff[j] : clhip_zero16);
-            }
-#pragma unroll
-            for (int j = 0; j < X_IT; ++j) {
-                const int mt = xmeta[j];
-                const int h = h0 - 1 + (mt & 255);
-                const bool ok = (tid + 256 * j < XV_ELEMS) && (unsigned)h < (unsigned)H && (c0 + (mt >> 24) < C);
-                xv[j] = *reinterpret_cast<const float4*>(ok ? xp + xoff[j] : clhip_zero16);
-            }
-#pragma unroll
-            for (int j = 0; j < H_IT; ++j) {
-                const int mt = hmeta[j];
-                const int h = h0 - 1 + (mt & 15), w = ((mt >> 4) & 1) ? w0 + TW : w0 - 1;
-                const bool ok = (tid + 256 * j < XROWS * 2) && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W &&
-                                (c0 + (mt >> 24) < C);
-                hv[j] = *(ok ? xp + hoff[j] : clhip_zero16);
+            if (u < DY_IT) {
+                dyv[u] = clhip_buf_load4(rs_dy, h0 + dyrow[u] < H ? dyoff[u] : CLHIP_OOB, 0);
+            } else if (u < DY_IT + X_IT) {
+                const int j = u - DY_IT;
+                xv[j] = clhip_buf_load4(rs_x, (unsigned)(h0 - 1 + xrc[j]) < (unsigned)H ? xoff[j] : CLHIP_OOB, 0);
+            } else {
+                const int j = u - DY_IT - X_IT;
+                const int h = h0 - 1 + (hrc[j] & 255), w = (hrc[j] >> 8) ? w0 + TW : w0 - 1;
+                hv[j] = clhip_buf_load(rs_x, ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) ? hoff[j] : CLHIP_OOB, 0);
             }
         } else {
-            const bool pix_ok = (h0 + th_t < H) && (w0 + tw_t < W);
-            const float* dyp = dy + ((size_t)n * K + k0 + wave) * plane_hw + (size_t)(h0 + th_t) * W + (w0 + tw_t);
-#pragma unroll
-            for (int j = 0; j < DY_IT; ++j) {
-                const bool ok = pix_ok && (k0 + wave + 4 * j < K);
-                dyr[j] = *(ok ? dyp + (size_t)(4 * j) * plane_hw : clhip_zero16);
-            }
-#pragma unroll
-            for (int j = 0; j < X_IT; ++j) {
-                const int mt = xmeta[j];
-                const int h = h0 - 1 + (mt & 15), w = w0 - 1 + ((mt >> 4) & 63);
-                const bool ok = (tid + 256 * j < X_ELEMS) && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W &&
-                                (c0 + ((mt >> 10) & 127) < C);
-                xr[j] = *(ok ? xp + xoff[j] : clhip_zero16);
+            if (u < DY_IT) {
+                const bool ok = (h0 + (dyrow[u] & 255) < H) && (w0 + (dyrow[u] >> 8) < W);
+                dyr[u] = clhip_buf_load(rs_dy, ok ? dyoff[u] : CLHIP_OOB, 0);
+            } else {
+                const int j = u - DY_IT;
+                const int h = h0 - 1 + (xrc[j] & 255), w = w0 - 1 + (xrc[j] >> 8);
+                xr[j] = clhip_buf_load(rs_x, ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) ? xoff[j] : CLHIP_OOB, 0);
             }
         }
     };
-    auto store_stage = [&]() {
+    auto store_unit = [&](int u, int bo) {
+#ifdef CLHIP_ABL_NOSTORE
+        if (bo >= 0) return;
+#endif
+        float* dys = lds + bo;
+        float* xs = dys + DYS_FLOATS;
         if constexpr (VEC) {
-#pragma unroll
-            for (int j = 0; j < DY_IT; ++j) {
-                float* d = dys + dydst[j];
-                d[0] = dyv[j].x; d[1] = dyv[j].y; d[2] = dyv[j].z; d[3] = dyv[j].w;
-            }
-#pragma unroll
-            for (int j = 0; j < X_IT; ++j) {
-                if (tid + 256 * j < XV_ELEMS) {
-                    float* d = xs + ((xmeta[j] >> 8) & 0xffff);
+            if (u < DY_IT) {
+                float* d = dys + dydst[u];
+                d[0] = dyv[u].x; d[1] = dyv[u].y; d[2] = dyv[u].z; d[3] = dyv[u].w;
+            } else if (u < DY_IT + X_IT) {
+                const int j = u - DY_IT;
+                if (256 * (j + 1) <= XV_ELEMS || tid + 256 * j < XV_ELEMS) {
+                    float* d = xs + xdst[j];
                     d[0] = xv[j].x; d[1] = xv[j].y; d[2] = xv[j].z; d[3] = xv[j].w;
                 }
+            } else {
+                const int j = u - DY_IT - X_IT;
+                if (256 * (j + 1) <= XROWS * 2 || tid + 256 * j < XROWS * 2) xs[hdst[j]] = hv[j];
             }
-#pragma unroll
-            for (int j = 0; j < H_IT; ++j)
-                if (tid + 256 * j < XROWS * 2) xs[(hmeta[j] >> 8) & 0xffff] = hv[j];
         } else {
-#pragma unroll
-            for (int j = 0; j < DY_IT; ++j) dys[dy_lds + 4 * j * G::LDP] = dyr[j];
-#pragma unroll
-            for (int j = 0; j < X_IT; ++j)
-                if (tid + 256 * j < X_ELEMS) xs[xmeta[j] >> 17] = xr[j];
+            if (u < DY_IT) dys[dydst[u]] = dyr[u];
+            else {
+                const int j = u - DY_IT;
+                if (256 * (j + 1) <= X_ELEMS || tid + 256 * j < X_ELEMS) xs[xdst[j]] = xr[j];
+            }
         }
+    };
+
+    // ------------------------------------------------------------------ main loop
+    // PS: this wave's quarter of the stage starts at pixel 16*wave (whole rows or half rows for every TW)
+    constexpr int NPP = PS ? G::BP / 8 : G::BP / 2;
+    constexpr int SLOTS = NPP * 9;
+    constexpr int UPS = (2 * NU + SLOTS - 10) / (SLOTS - 9);     // units per slot so that stores + loads end before the last pair
+    const int pb = PS ? 16 * wave : 0;
+    const int a_off = (wk * 32 + li) * G::LDP + kk + pb;
+    const int b_off = DYS_FLOATS + (wc * 32 + li) * G::PLANEP + kk + (pb / TW) * G::TWP + (pb % TW);
+    float af[2], bf[2][9];
+    auto frag = [&](const float* base, int pp, int slot, int rs) {      // operand rs of pixel pair pp (rs = 0 also loads A)
+        const int q0 = 2 * pp;
+        const int th = q0 / TW, tw = q0 - (q0 / TW) * TW;
+        const int r = rs / 3, s3 = rs - 3 * (rs / 3);
+        if (rs == 0) af[slot] = base[a_off + q0];
+        bf[slot][rs] = base[b_off + (th + r) * G::TWP + tw + s3];
     };
 
 #ifdef CLHIP_TRACE
     const unsigned long long tr_idx = TR_NOW();
 #endif
-    if (st_begin < st_end) load_stage(st_begin);
-    for (int st = st_begin; st < st_end; ++st) {
-#ifdef CLHIP_TRACE
-        const unsigned long long ta = TR_NOW();
-#endif
-        __syncthreads();               // previous stage's LDS reads are done
-#ifdef CLHIP_TRACE
-        const unsigned long long tb = TR_NOW();
-#endif
-        store_stage();
-        __syncthreads();
-#ifdef CLHIP_TRACE
-        const unsigned long long tc = TR_NOW();
-#endif
-        if (st + 1 < st_end) load_stage(st + 1);   // in flight while the matrix pipe runs
-#ifdef CLHIP_TRACE
-        const unsigned long long td = TR_NOW();
-        tr_ba += tb - ta; tr_st += tc - tb; tr_ld += td - tc;
-#endif
-        // operands of pixel pair pp+1 are read while the 9 MFMAs of pair pp run (explicit register
-        // double buffering; see conv3x3.hip)
-        float af[2], bf[2][9];
-        // PS: this wave's quarter of the stage starts at pixel 16*wave (whole rows or half rows for every TW)
-        constexpr int NPP = PS ? G::BP / 8 : G::BP / 2;
-        const int pb = PS ? 16 * wave : 0;
-        const float* a_w = a_ptr + pb;
-        const float* b_w = b_ptr + (pb / TW) * G::TWP + (pb % TW);
-        auto load_frag = [&](int pp, int slot) {
-            const int q0 = 2 * pp;
-            const int th = q0 / TW, tw = q0 - (q0 / TW) * TW;
-            af[slot] = a_w[q0];
+    if (st_begin < st_end) {
+        begin_stage(true);
 #pragma unroll
-            for (int rs = 0; rs < 9; ++rs) {
-                const int r = rs / 3, s = rs - 3 * (rs / 3);
-                bf[slot][rs] = b_w[(th + r) * G::TWP + tw + s];
-            }
-        };
-        load_frag(0, 0);
+        for (int u = 0; u < NU; ++u) load_unit(u);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) store_unit(u, 0);
+        begin_stage(st_begin + 1 < st_end);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) load_unit(u);
+        __syncthreads();
+#pragma unroll
+        for (int rs = 0; rs < 9; ++rs) frag(lds, 0, 0, rs);
+    }
+    for (int st = st_begin; st < st_end; ++st) {
+        const int bo = ((st - st_begin) & 1) * BUF_FLOATS, bn = BUF_FLOATS - bo;
+        const float* cur = lds + bo;
+        const float* nxt = lds + bn;
 #pragma unroll
         for (int pp = 0; pp < NPP; ++pp) {
-            if (pp + 1 < NPP) load_frag(pp + 1, (pp + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
-            bsum += (double)af[pp & 1];
+            bsum += (double)af[pp & 1];      // f64: 819 200 cancelling terms per channel on the first layers
 #pragma unroll
-            for (int rs = 0; rs < 9; ++rs)
+            for (int rs = 0; rs < 9; ++rs) {
+                const int slot = pp * 9 + rs;
                 acc[rs] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[pp & 1], bf[pp & 1][rs], acc[rs], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#ifdef CLHIP_TRACE
-        tr_mf += TR_NOW() - td;
+#ifndef CLHIP_ABL_NOBAR
+                if (pp == NPP - 1 && rs == 0) __syncthreads();
 #endif
+#ifndef CLHIP_ABL_NOFRAG
+                if (pp + 1 < NPP) frag(cur, pp + 1, (pp + 1) & 1, rs);
+                else frag(nxt, 0, 0, rs);
+#endif
+#pragma unroll
+                for (int u = slot * UPS; u < (slot + 1) * UPS; ++u) {
+                    if (u < NU) store_unit(u, bn);
+                    else if (u < 2 * NU) {
+#ifndef CLHIP_ABL_NOBEGIN
+                        if (u == NU) begin_stage(st + 2 < st_end);
+#endif
+                        load_unit(u - NU);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
     }
 #ifdef CLHIP_TRACE
     const unsigned long long tr_loop = TR_NOW();
@@ -301,7 +335,7 @@ __global__ __launch_bounds__(256, PS ? 2 : CLHIP_WGRAD_MINBLK) void conv3x3_wgra
         if (g_wtrace && lane == 0) {
             unsigned long long* t = g_wtrace + ((size_t)blockIdx.x * 4 + wave) * 16;
             t[0] = tr_start; t[1] = tr_idx; t[2] = tr_idx; t[3] = tr_loop; t[4] = tr_end;
-            t[5] = tr_ld; t[6] = tr_mf; t[7] = tr_st; t[8] = tr_ba;
+            t[5] = 0; t[6] = 0; t[7] = 0; t[8] = 0;
             t[9] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
             t[10] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // XCC_ID
             t[11] = st_end - st_begin;
@@ -311,41 +345,53 @@ __global__ __launch_bounds__(256, PS ? 2 : CLHIP_WGRAD_MINBLK) void conv3x3_wgra
 
     float* slab = part + (size_t)split * slab_stride;
     if constexpr (PS) {
-        // add the four pixel quarters in wave order 0 + 1 + 2 + 3 (fixed => deterministic), one tap per round through a
-        // 12 KB pad in xs; wave 0 then owns the tile
+        // add the four pixel quarters in wave order ((0 + 1) + 2) + 3 (fixed => deterministic).  Three rounds of three
+        // taps through a 36 KB pad at the start of the stage buffers: every wave parks the taps it does not own, then
+        // wave w (< 3) sums tap 3*round + w in that order — its own quarter from registers — and writes it to the slab,
+        // so three waves share the additions and the 144 slab stores per lane that one wave used to do alone.
         __syncthreads();                                   // the last stage's LDS reads are done
-        float* pad = xs;                                   // [3 waves][16 regs][64 lanes]
-        double* bpad = reinterpret_cast<double*>(dys);     // [3 waves][64 lanes]
+        static_assert(2 * BUF_FLOATS >= 9 * 1024 + 3 * 128, "pad [3 taps][3 other waves][16 regs][64 lanes] + bias pad");
+        float* pad = lds;
+        double* bpad = reinterpret_cast<double*>(lds + 9 * 1024);     // [3 waves][64 lanes]
         bsum += __shfl_xor(bsum, 32, 64);                  // even + odd pixels of this wave
         if (wave > 0) bpad[(wave - 1) * 64 + lane] = bsum;
+        const int c = c0 + li;
 #pragma unroll
-        for (int rs = 0; rs < 9; ++rs) {
-            if (wave > 0) {
+        for (int round = 0; round < 3; ++round) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) pad[((wave - 1) * 16 + r) * 64 + lane] = acc[rs][r];
-            }
-            __syncthreads();
-            if (wave == 0) {
+            for (int t = 0; t < 3; ++t) {
+                // slot of wave `wave` in tap t's pad: the three waves other than the owner t, in ascending order
+                if (wave != t) {
+                    const int sl = wave - (wave > t ? 1 : 0);
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    acc[rs][r] = ((acc[rs][r] + pad[(0 * 16 + r) * 64 + lane]) + pad[(1 * 16 + r) * 64 + lane]) + pad[(2 * 16 + r) * 64 + lane];
-            }
-            __syncthreads();
-        }
-        if (wave == 0) {
-            const int c = c0 + li;
-#pragma unroll
-            for (int rs = 0; rs < 9; ++rs)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int k = k0 + mfma32_row(r, lane);
-                    if (k < K && c < C) slab[((size_t)rs * K + k) * C + c] = acc[rs][r];
+                    for (int r = 0; r < 16; ++r) pad[((t * 3 + sl) * 16 + r) * 64 + lane] = acc[3 * round + t][r];
                 }
-            if (ct == 0) {
-                const double tot = ((bsum + bpad[0 * 64 + lane]) + bpad[1 * 64 + lane]) + bpad[2 * 64 + lane];
-                const int k = k0 + li;
-                if (kk == 0 && k < K) slab[(size_t)9 * K * C + k] = (float)tot;
             }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                if (wave == t) {
+                    const int rs = 3 * round + t;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        // contributions in wave order 0, 1, 2, 3; this wave's own sits in registers at position t
+                        float v = 0.f;
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            const float contrib = (w == t) ? acc[rs][r] : pad[((t * 3 + (w - (w > t ? 1 : 0))) * 16 + r) * 64 + lane];
+                            v = (w == 0) ? contrib : v + contrib;
+                        }
+                        const int k = k0 + mfma32_row(r, lane);
+                        if (k < K && c < C) slab[((size_t)rs * K + k) * C + c] = v;
+                    }
+                }
+            }
+            if (round < 2) __syncthreads();
+        }
+        if (wave == 0 && ct == 0) {
+            const double tot = ((bsum + bpad[0 * 64 + lane]) + bpad[1 * 64 + lane]) + bpad[2 * 64 + lane];
+            const int k = k0 + li;
+            if (kk == 0 && k < K) slab[(size_t)9 * K * C + k] = (float)tot;
         }
 #ifdef CLHIP_TRACE
         tr_finish();
