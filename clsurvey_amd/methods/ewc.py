@@ -63,6 +63,7 @@ def diag_fisher(model, dset_loader, data_len, engine=None):
     plan executor, then omega += grad^2 / data_len over the whole arena (clhip_fisher_accum).
     Parameters absent from reg_params keep no omega (their arena slot is scratch)."""
     reg_params = model.reg_params
+    model.eval()                                # main_EWC.py:140: no Dropout noise, BatchNorm running statistics
     if engine is None:
         engine = NetEngine(model, dset_loader.batch_size, tuple(dset_loader.x.shape[1:]), dset_loader.device)
     A = engine.arena

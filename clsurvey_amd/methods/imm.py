@@ -77,6 +77,7 @@ def diag_fisher(model, dataset, exclude_params=None, sampler=sample_targets, eng
     `dataset` = {'train': loader, 'val': loader}. Per batch: forward (logits), sample labels, one fused
     forward + CE(mean) + backward, then clhip_fisher_accum over the whole arena."""
     exclude_params = exclude_params or []
+    model.eval()                                # merge.py:165
     loaders = list(dataset.values())
     if engine is None:
         engine = NetEngine(model, loaders[0].batch_size, tuple(loaders[0].x.shape[1:]), loaders[0].device)

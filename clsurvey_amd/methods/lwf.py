@@ -119,12 +119,12 @@ def train_model_lwf(model, original_model, optimizer, lr, dset_loaders, dset_siz
     if os.path.isfile(resume):
         ck = torch.load(resume, weights_only=False)
         start_epoch, best_acc, lr, val_beat_counts = ck["epoch"], ck["best_acc"], ck["lr"], ck["val_beat_counts"]
-        with torch.no_grad():
-            for p, (_, v) in zip(model.parameters(), ck["state_dict"].items()):
-                p.data.copy_(v)
+        model.load_state_dict(ck["state_dict"])
         optimizer.load_state_dict(ck["optimizer"])
     stats = torch.zeros(2, dtype=torch.float64, device=engine.device)
     preprocessing_time = 0.0
+    if original_model is not None:
+        original_model.eval()                   # main_LWF.py:104: the frozen teacher never drops units
     for epoch in range(start_epoch, num_epochs):
         print("Epoch {}/{}".format(epoch, num_epochs - 1))
         for phase in ("train", "val"):
@@ -133,6 +133,7 @@ def train_model_lwf(model, original_model, optimizer, lr, dset_loaders, dset_siz
                 if not cont:
                     tc.save_preprocessing_time(exp_dir, preprocessing_time)
                     return model, best_acc
+            model.train(phase == "train")       # main_LWF.py:145-147
             stats.zero_()
             for inputs, labels in dset_loaders[phase]:
                 t0 = time.time()

@@ -24,6 +24,7 @@ def compute_importance_l2(model, optimizer, lr_scheduler, dset_loaders, use_gpu=
     backward, then Objective_After_SGD.step(reg_params, index, labels.size(0)) — the batch size
     used in the running mean is the CURRENT batch's (short-last-batch quirk kept)."""
     reg_params = model.reg_params
+    model.eval()                                # train_MAS.py:518
     first = dset_loaders[0]
     if engine is None:
         engine = NetEngine(model, first.batch_size, tuple(first.x.shape[1:]), first.device)

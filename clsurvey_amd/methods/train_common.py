@@ -68,10 +68,8 @@ def train_model(model, engine, optimizer, lr, dset_loaders, dset_sizes, num_epoc
         checkpoint = torch.load(resume, weights_only=False)
         start_epoch = checkpoint["epoch"]
         best_acc = checkpoint["best_acc"]
-        with torch.no_grad():
-            for p, (_, v) in zip(model.parameters(), checkpoint["state_dict"].items()):
-                p.data.copy_(v)
-        optimizer.load_state_dict(checkpoint["optimizer"])
+        model.load_state_dict(checkpoint["state_dict"])     # in place: parameters AND BatchNorm buffers, by name
+        optimizer.load_state_dict(checkpoint["optimizer"])   # momentum goes back into the arena (optim._SGDBase)
         lr = checkpoint["lr"]
         val_beat_counts = checkpoint["val_beat_counts"]
         print("=> loaded checkpoint '{}' (epoch {})".format(resume, checkpoint["epoch"]))
@@ -89,6 +87,7 @@ def train_model(model, engine, optimizer, lr, dset_loaders, dset_sizes, num_epoc
                 if not cont:
                     print("Training complete in {:.0f}s, best val acc {:.4f}".format(time.time() - since, best_acc))
                     return model, best_acc
+            model.train(phase == "train")       # train_SGD.py:97-99, train_EWC.py:157-159: Dropout / BatchNorm mode
             stats.zero_()
             for inputs, labels in dset_loaders[phase]:
                 engine.loss_step(inputs, labels, "ce_mean", backward=(phase == "train"), stats=stats)

@@ -46,6 +46,23 @@ class _SGDBase(Optimizer):
             st["momentum_buffer"] = arena.view("buf", p) if arena is not None else torch.zeros_like(p.data)
         return st["momentum_buffer"], first
 
+    def load_state_dict(self, state_dict):
+        """Resume (train_SGD.py:62-75): torch restores `momentum_buffer` as fresh tensors; the fused arena kernels read
+        the momentum from the arena's 'buf' region, so copy the restored values there, rebind the state entries to the
+        arena views and mark the optimizer as past its first step (first=True would overwrite the buffer with g)."""
+        super().load_state_dict(state_dict)
+        restored = [p for p in self._group()["params"] if "momentum_buffer" in self.state.get(p, {})]
+        if not restored:
+            return
+        a = self.arena()
+        if a is not None:
+            a.buffer("buf")                     # allocate (zeroed) if this optimizer has not stepped yet
+            for p in restored:
+                view = a.view("buf", p)
+                view.copy_(self.state[p]["momentum_buffer"].to(view.device))
+                self.state[p]["momentum_buffer"] = view
+        self._steps = max(self._steps, 1)
+
     def zero_grad(self, set_to_none=False):
         a = self.arena()
         if a is not None:

@@ -1,0 +1,155 @@
+"""train / eval mode and checkpoint resume on the HIP path ('_DROP', '_BN' nets).
+
+The reference switches the module mode at every phase (Finetune/train_SGD.py:97-99, EWC/train_EWC.py:157-159,
+SI/train_SI.py:193-195, MAS/train_MAS.py:250-252, LwF/main_LWF.py:145-147) and computes importance weights in eval mode
+(EWC/main_EWC.py:140, MAS/train_MAS.py:518, IMM/merge.py:165); NetEngine takes Dropout masks and the BatchNorm mode from
+model.training, so the trainers have to do the same."""
+import copy
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _task(n_train=80, n_val=40, hw=32, classes=4, seed=0):
+    from clsurvey_amd.data import TensorTaskDataset
+    g = torch.Generator().manual_seed(seed)
+    proto = torch.randn(classes, 3, hw, hw, generator=g)
+
+    def split(n):
+        y = torch.arange(n) % classes
+        x = proto[y] + 0.4 * torch.randn(n, 3, hw, hw, generator=g)
+        return TensorTaskDataset(x.to(DEV), y.to(DEV), [str(c) for c in range(classes)])
+    return {"train": split(n_train), "val": split(n_val)}
+
+
+def _model(name="small_VGG9_cl_128_128_DROP_BN", hw=32, classes=4, seed=1):
+    from clsurvey_amd import models
+    torch.manual_seed(seed)
+    m = models.parse_model_name(name, (hw, hw), classes)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Linear):
+            torch.nn.init.kaiming_normal_(mod.weight, nonlinearity="relu")
+    return m
+
+
+def _cpu_forward(ref, x):
+    """torch-CPU evaluation of the same module tree (the product's VGGSlim.forward itself runs on the HIP kernels)."""
+    return ref.classifier(torch.flatten(ref.features(x), 1))
+
+
+def test_val_phase_runs_in_eval_mode(tmp_path):
+    """One epoch of the shared train_model loop on a '_DROP_BN' net: BatchNorm counts only the TRAIN batches, the running
+    statistics after the epoch are those left by the train phase, and the val-phase numbers are the eval-mode forward's
+    (= the torch-CPU oracle's eval forward on the same weights)."""
+    from clsurvey_amd.methods import train_common as tc
+    from clsurvey_amd.optim import Weight_Regularized_SGD
+    from clsurvey_amd.methods import ewc
+    dsets = _task()
+    m = _model().to(DEV)
+    loaders = tc.make_loaders(dsets, 20, DEV)
+    eng = tc.engine_for(m, loaders, 20, DEV)
+    m.reg_params = ewc.initialize_reg_params(m)
+    m.reg_params["lambda"] = 0.0
+    opt = Weight_Regularized_SGD(m.parameters(), lr=1e-3, momentum=0.9)
+    snap = {}
+
+    def step():
+        opt.step(m.reg_params)
+        bn0 = next(mod for mod in m.modules() if isinstance(mod, torch.nn.BatchNorm2d))
+        snap["mean"] = bn0.running_mean.clone()
+        snap["var"] = bn0.running_var.clone()
+    m, acc = tc.train_model(m, eng, opt, 1e-3, loaders, {"train": 80, "val": 40}, 1, exp_dir=str(tmp_path), step_fn=step)
+    bns = [mod for mod in m.modules() if isinstance(mod, torch.nn.BatchNorm2d)]
+    assert not m.training                                    # left in the val phase's mode, as the reference does
+    assert all(int(b.num_batches_tracked) == 4 for b in bns)     # 80 / 20 train batches; the 2 val batches do not count
+    assert torch.equal(bns[0].running_mean, snap["mean"]) and torch.equal(bns[0].running_var, snap["var"])
+    # eval forward: deterministic (no Dropout noise) and equal to torch-CPU eval on the same module
+    x = dsets["val"].x[:20].contiguous()
+    z1 = eng.forward(x).clone()
+    z2 = eng.forward(x).clone()
+    assert torch.equal(z1, z2)
+    ref = copy.deepcopy(m).cpu().eval()
+    with torch.no_grad():
+        zr = _cpu_forward(ref, x.cpu())
+    assert float((z1.cpu() - zr).abs().max()) <= 1e-3 * max(1.0, float(zr.abs().max()))
+    # and the accuracy the loop reported is that eval forward's
+    with torch.no_grad():
+        hits = sum(int((_cpu_forward(ref, dsets["val"].x[i:i + 20].cpu()).argmax(1) == dsets["val"].y[i:i + 20].cpu()).sum()) for i in (0, 20))
+    assert abs(acc - hits / 40.0) <= 1.0 / 40 + 1e-9
+
+
+def test_importance_passes_run_in_eval_mode():
+    """diag_fisher / compute_importance_l2 on a '_DROP' net that arrives in TRAINING mode: Omega must be the dropout-free
+    one (torch-CPU autograd on the eval-mode module, main_EWC.py:138-157, train_MAS.py:508-567)."""
+    from clsurvey_amd.data import DeviceLoader
+    from clsurvey_amd.methods import ewc, mas
+    from clsurvey_amd.optim import Objective_After_SGD
+    dsets = _task(n_train=40)
+    for which in ("ewc", "mas"):
+        m = _model("small_VGG9_cl_128_128_DROP").to(DEV)
+        m.train()
+        m.reg_params = ewc.initialize_reg_params(m)
+        m.reg_params = ewc.store_prev_reg_params(m)
+        loader = DeviceLoader(dsets["train"], 20, False, DEV)
+        ref = copy.deepcopy(m).cpu().eval()
+        for p in ref.parameters():
+            p.grad = None
+        want = [torch.zeros_like(p) for p in ref.parameters()]
+        nb = 0
+        for i in (0, 20):
+            x, y = dsets["train"].x[i:i + 20].cpu(), dsets["train"].y[i:i + 20].cpu()
+            ref.zero_grad()
+            out = _cpu_forward(ref, x)
+            if which == "ewc":
+                torch.nn.functional.nll_loss(torch.log_softmax(out, 1), y, reduction="sum").backward()
+                for w, p in zip(want, ref.parameters()):
+                    w += p.grad ** 2 / 40.0
+            else:
+                (out ** 2).sum().backward()
+                for w, p in zip(want, ref.parameters()):
+                    w.copy_((w * nb * 20 + p.grad.abs()) / ((nb + 1) * 20))      # Objective_After_SGD running mean
+            nb += 1
+        if which == "ewc":
+            ewc.diag_fisher(m, loader, 40)
+        else:
+            mas.compute_importance_l2(m, Objective_After_SGD(m.parameters(), lr=1e-4, momentum=0.9), None, [loader])
+        assert not m.training
+        for p, w in zip(m.parameters(), want):
+            # Frobenius criterion: a ReLU / arg-max decision within rounding of a tie moves single entries below it by
+            # ~1 % (the flip-aware full-size test pins the arithmetic); Dropout noise would be O(1)
+            got = m.reg_params[p]["omega"].cpu()
+            assert float((got - w).norm()) <= 2e-2 * max(float(w.norm()), 1e-12), which
+
+
+def test_resume_restores_bn_buffers_and_momentum(tmp_path):
+    """epoch.pth.tar round trip on a '_BN' net (train_SGD.py:62-75): after the resume the next epoch must be the one an
+    uninterrupted run performs — state_dict restored BY NAME (BatchNorm buffers sit between the parameters) and the
+    momentum buffers back in the arena."""
+    from clsurvey_amd.methods import train_common as tc
+    from clsurvey_amd.methods import ewc
+    from clsurvey_amd.optim import Weight_Regularized_SGD
+
+    def run(epochs, resume, exp_dir, seed_model):
+        torch.manual_seed(5)
+        m = copy.deepcopy(seed_model).to(DEV)
+        loaders = tc.make_loaders(_task(), 20, DEV, shuffle=False)
+        eng = tc.engine_for(m, loaders, 20, DEV)
+        m.reg_params = ewc.initialize_reg_params(m)
+        m.reg_params["lambda"] = 0.0
+        opt = Weight_Regularized_SGD(m.parameters(), lr=1e-2, momentum=0.9)
+        tc.train_model(m, eng, opt, 1e-2, loaders, {"train": 80, "val": 40}, epochs, exp_dir=exp_dir, resume=resume,
+                       saving_freq=1)
+        return m
+
+    base = _model("small_VGG9_cl_128_128_BN")
+    d1, d2 = str(tmp_path / "a"), str(tmp_path / "b")
+    os.makedirs(d1), os.makedirs(d2)
+    full = run(2, "", d1, base)                                   # two epochs in one go
+    run(1, "", d2, base)                                          # one epoch, checkpoint written
+    resumed = run(2, os.path.join(d2, "epoch.pth.tar"), d2, base)  # fresh model + optimizer, resume into epoch 1
+    for (n, a), (_, b) in zip(full.state_dict().items(), resumed.state_dict().items()):
+        assert torch.equal(a, b), n
