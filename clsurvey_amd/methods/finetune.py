@@ -13,8 +13,6 @@ def fine_tune_SGD(dset_dataloader, cumsum_dset_sizes, dset_classes, model_path, 
                   save_models_mode=True, freq=5, device="cuda", batch_size=None):
     """main_SGD.py:13-82. dset_dataloader: {'train','val'} of DeviceLoader (Finetune.grid_datafetch
     builds them, method.py:1030-1060)."""
-    if freeze_mode:
-        raise NotImplementedError("freeze_mode (classifier-only warm-up) is not on the measured path")
     resume = os.path.join(exp_dir, "epoch.pth.tar") if enable_resume else ""
     if resume and os.path.isfile(resume):
         model_ft = torch.load(resume, weights_only=False)["model"]
@@ -35,7 +33,7 @@ def fine_tune_SGD(dset_dataloader, cumsum_dset_sizes, dset_classes, model_path, 
     if isinstance(model_ft, AlexNet_EBLL):                        # main_SGD.py:54-56: stays a wrapper, in finetune mode
         model_ft.classifier = torch.nn.Sequential(*list(model_ft.classifier.children())[:model_ft.last_layer_name + 1])
         model_ft.set_finetune_mode(True)
-    if replace_last_classifier_layer:
+    if freeze_mode or replace_last_classifier_layer:            # main_SGD.py:59
         labels_per_task = [len(task_labels) for task_labels in dset_classes["train"]]
         tc.replace_head(model_ft, sum(labels_per_task))          # utils.py:68-72
     model_ft = model_ft.to(device)
@@ -49,8 +47,15 @@ def fine_tune_SGD(dset_dataloader, cumsum_dset_sizes, dset_classes, model_path, 
                            params=engine_params)
     else:
         engine = tc.engine_for(model_ft, dset_dataloader, batch_size or any_loader.batch_size, device)
-    optimizer_ft = SGD(engine_params if engine_params is not None else model_ft.parameters(), lr, momentum=0.9,
-                       weight_decay=weight_decay)
+    if freeze_mode:
+        # main_SGD.py:69-72: warm-up of the fresh head — the optimizer sees the last classifier module only, without
+        # weight decay (the reference names it classifier['6'], the head slot of its 7-module classifiers); the plan
+        # executor still produces every gradient, the rest of the arena is simply never stepped
+        last = str(len(model_ft.classifier._modules) - 1)
+        optimizer_ft = SGD(model_ft.classifier._modules[last].parameters(), lr, momentum=0.9)
+    else:
+        optimizer_ft = SGD(engine_params if engine_params is not None else model_ft.parameters(), lr, momentum=0.9,
+                           weight_decay=weight_decay)
     return tc.train_model(model_ft, engine, optimizer_ft, lr, dset_dataloader, cumsum_dset_sizes, num_epochs, exp_dir,
                           resume, saving_freq=freq, step_fn=optimizer_ft.step, save_models_mode=save_models_mode,
                           abort_on_bad_loss=False)

@@ -1,307 +1,210 @@
-"""HAT trainer on the HIP path — mirror of src/methods/HAT/run.py:main, approaches/hat.py:Appr (joint
-training with annealed gates, sparsity regulariser, warm-up on the first task, patience schedule) and
-approaches/hat_finetune.py:Appr (phase-1 maximal-plasticity search: all gates open, back-mask only).
+"""HAT trainer on the HIP path: what src/methods/HAT/run.py:main drives — approaches/hat.py (joint training: annealed
+gates, sparsity regulariser, warm-up on the first task) and approaches/hat_finetune.py (phase-1 maximal-plasticity
+search: every unit open, back-mask only) — expressed as ONE epoch driver over two small pieces of policy:
 
-One batch of Appr.train_epoch (hat.py:200-249) = HatEngine.step (gates -> gate-folded weights -> ONE
-clhip_net_loss_step -> gate / embedding gradient kernels) + HAT_SGD.step + clhip_clamp on the embeddings;
-running loss / accuracy are device counters read once per epoch.
+  * `PatiencePlan` (train_common.py): the validation-driven schedule both reference files spell out inline
+    (hat.py:150-172, hat_finetune.py:108-124): reset on a new best, LR / lr_factor at half patience, stop at zero;
+  * a `_Pass` object that knows how to push one loader through the HatEngine in either mode.
+
+One joint batch (hat.py:200-249) = HatEngine.step (gates -> gate-folded weights -> ONE clhip_net_loss_step -> gate /
+embedding gradient kernels) + HAT_SGD.step + clhip_clamp on the embeddings; loss / accuracy are device counters read once
+per epoch.  Files written are the reference's: best_model.pth.tar (pickled net) and epoch.pth.tar with the keys of
+hat.py:176-181 / hat_finetune.py:127-130, so a run can be resumed by either implementation.
 """
-import argparse
 import os
 import time
 from copy import deepcopy
+from types import SimpleNamespace
 
 import torch
-from ..data import load_task_datasets
 
-from ..data import DeviceLoader
+from ..data import DeviceLoader, load_task_datasets
 from . import hat as H
+from .train_common import PatiencePlan
+
+# run.py:107-109 passes these to every approach; hat.py:16-17 holds the rest as defaults
+LR_FACTOR, LR_PATIENCE, CLIPGRAD = 2, 30, 10000
+WARMUP_LR, WARMUP_EPOCHS, WARMUP_LAMB = 0.01, 10, 0
+THRES_COSH, THRES_EMB = 50, 6
 
 
-def set_lr_(optimizer, lr):
-    """HAT_utils.py:72-74."""
-    for param_group in optimizer.param_groups:
-        param_group["lr"] = lr
+class _Pass:
+    """One sweep of a loader through the HatEngine.  joint=True: gated forward at annealed s with the sparsity
+    regulariser (hat.py:200-283); joint=False: plain forward, CE only (hat_finetune.py:135-178)."""
+
+    def __init__(self, owner, joint):
+        self.o, self.joint = owner, joint
+        self.stats = torch.zeros(2, dtype=torch.float64, device=owner.device)
+        self.reg = torch.zeros((), dtype=torch.float64, device=owner.device)
+
+    def _gate_budget(self):
+        """Denominator of the regulariser (hat.py:285-299): free gate capacity left by the earlier tasks."""
+        o = self.o
+        if o.mask_pre is None:
+            return float(sum(g.numel() for g in o.hat.gate))
+        return float(sum(float((1 - mp).sum().item()) for mp in o.mask_pre))
+
+    def run(self, t, loader, train):
+        o = self.o
+        self.stats.zero_()
+        self.reg.zero_()
+        seen, nb = 0, len(loader)
+        budget = self._gate_budget() if (self.joint and train) else None
+        for i, (images, targets) in enumerate(loader):
+            bs = images.shape[0]
+            if not self.joint:
+                o.hat.plain_step(images, targets, backward=train, stats=self.stats)
+                if train:
+                    o.optimizer.step(o.model, o.mask_back, t, finetune=True)
+            else:
+                # gate temperature: linear in the batch index over the epoch while training, smax for evaluation
+                s = (o.smax - 1 / o.smax) * (i / (nb - 1)) + 1 / o.smax if train else o.smax
+                _, reg, _ = o.hat.step(t, images, targets, s, o.mask_pre, o.lamb, budget, backward=train, stats=self.stats)
+                self.reg += reg.double() * bs
+                if train:
+                    o.optimizer.step(o.model, o.mask_back, t, s, THRES_COSH, o.smax, CLIPGRAD)
+                    H.clamp_embeddings(o.model, float(THRES_EMB))
+            seen += bs
+        s = self.stats.cpu()
+        ce, acc = float(s[0]) / seen, float(s[1]) / seen
+        reg = float(self.reg.item()) / seen if self.joint else 0.0
+        return ce, reg, acc
 
 
-def get_model(model):
-    """HAT_utils.py:47-48."""
-    return deepcopy(model)
+class HatTrainer:
+    """Trains task t of a HatNet and returns (best validation model, best validation accuracy in [0, 1])."""
 
-
-class Appr(object):
-    """approaches/hat.py:13-299."""
-
-    def __init__(self, model, exp_dir, nepochs=100, sbatch=200, lr=0.05, lr_min=1e-4, lr_factor=3, lr_patience=10,
-                 clipgrad=10000, args=None, in_shape=None, device="cuda"):
-        self.model = model
-        self.exp_dir = exp_dir
-        self.save_freq = args.save_freq
-        self.momentum = 0.9
-        self.weight_decay = args.weight_decay
-        self.nepochs = nepochs
-        self.sbatch = sbatch
-        self.lr = lr
-        self.lr_min = lr_min
-        self.lr_factor = lr_factor
-        self.lr_patience = lr_patience
-        self.clipgrad = clipgrad
+    def __init__(self, model, exp_dir, args, in_shape, joint, device="cuda"):
+        self.model, self.exp_dir, self.joint = model, exp_dir, joint
         self.device = torch.device(device)
-        self.hat = H.HatEngine(model, sbatch, in_shape, device)
-        self.optimizer = self._get_optimizer()
+        self.sbatch, self.base_lr = args.batch_size, args.lr
+        self.save_freq, self.weight_decay = args.save_freq, args.weight_decay
         assert len(args.parameter) == 2
-        self.smax = args.parameter[0]
-        self.post_lamb = args.parameter[1]
-        self.warmup_lamb = 0
+        self.smax, self.post_lamb = args.parameter
         self.lamb = None
-        self.warmup_lr = 0.01
-        self.enable_warmup = self.model.enable_warmup
-        self.warmup_epochs = 10
-        self.min_epochs = int(self.nepochs / 2)
+        # the phase-1 search runs the warm-up's epochs on top (hat_finetune.py:48)
+        self.nepochs = args.nepochs + (0 if joint else WARMUP_EPOCHS)
+        self.hat = H.HatEngine(model, self.sbatch, in_shape, device)
+        self.optimizer = None
         self.mask_pre, self.mask_back = None, {}
-        self._stats = torch.zeros(2, dtype=torch.float64, device=self.device)
-        self._reg = torch.zeros((), dtype=torch.float64, device=self.device)
+        self._pass = _Pass(self, joint)
         print("smax={},post_lamb={}, enable_warmup={}, warmup_lamb={}, warmup_epochs={}".format(
-            self.smax, self.post_lamb, self.enable_warmup, self.warmup_lamb, self.warmup_epochs))
+            self.smax, self.post_lamb, model.enable_warmup, WARMUP_LAMB, WARMUP_EPOCHS))
 
+    # kept under the reference's names: tests and the Method class reach for them
     def init_masks(self, current_task, smax):
-        """hat.py:57-89."""
         return H.init_masks(self.hat, current_task, smax)
 
-    def _get_optimizer(self, lr=None):
-        if lr is None:
-            lr = self.lr
-        return H.HAT_SGD(self.model.parameters(), lr=lr, momentum=self.momentum, weight_decay=self.weight_decay)
-
-    def _rebind(self, model):
-        """self.model <- model (a deepcopy or a loaded one): new engine/arena over ITS parameters."""
-        self.model = model
-        in_shape = self.hat.engine.in_shape
-        self.hat = H.HatEngine(model, self.sbatch, in_shape, self.device)
-
-    def train(self, t, dset_loaders, eps=1e-6):
-        """hat.py:95-198. Returns (best validation model, best validation accuracy in [0, 1])."""
-        loaded_chkpt = False
-        chkpt_path = os.path.join(self.exp_dir, "epoch.pth.tar")
-        if os.path.exists(chkpt_path):
-            chkpt = torch.load(chkpt_path, weights_only=False)
-            try:
-                assert abs(self.smax - chkpt["smax"]) < eps
-                assert abs(self.post_lamb - chkpt["post_lamb"]) < eps
-                init_e = chkpt["e"]
-                with torch.no_grad():
-                    for (_, p), (_, v) in zip(self.model.state_dict().items(), chkpt["model"].items()):
-                        p.copy_(v)
-                self.optimizer.load_state_dict(chkpt["optimizer"])
-                best_acc = deepcopy(chkpt["best_acc"])
-                lr = deepcopy(chkpt["lr"])
-                patience = deepcopy(chkpt["patience"])
-                warmup = deepcopy(chkpt["warmup"])
-                loaded_chkpt = True
-            except Exception as e:
-                print("No chkpt loaded:{}".format(e))
-        if not loaded_chkpt:
-            patience = self.lr_patience
-            best_acc = 0
-            init_e = 0
-            warmup = t == 0 and self.enable_warmup
-            lr = self.lr if not warmup else self.warmup_lr
-            self.optimizer = self._get_optimizer(lr)
-        best_model = get_model(self.model)
-        self.mask_pre, self.mask_back = self.init_masks(t, self.smax)
-
-        for e in range(init_e, self.nepochs):
-            self.lamb = self.warmup_lamb if warmup else self.post_lamb
-            clock0 = time.time()
-            train_loss, train_acc = self.train_epoch(t, dset_loaders["train"])
-            clock1 = time.time()
-            print("| Epoch {:3d}, time={:5.1f}ms | Train: loss={:.6f}, acc={:5.1f}% |".format(
-                e + 1, 1000 * self.sbatch * (clock1 - clock0) / len(dset_loaders["train"]), train_loss,
-                100 * train_acc), end="")
-            valid_loss, valid_acc = self.eval(t, dset_loaders["val"])
-            print(" Valid: loss={:.6f}, acc={:5.1f}% | lamb={:.4f} |".format(valid_loss, 100 * valid_acc, self.lamb),
-                  end="")
-            if valid_acc > best_acc:
-                best_acc = valid_acc
-                best_model = get_model(self.model)
-                patience = self.lr_patience
-                print(" *", end="")
-                torch.save(best_model, os.path.join(self.exp_dir, "best_model.pth.tar"))
-            elif not warmup:
-                patience -= 1
-                if patience == self.lr_patience // 2:
-                    lr /= self.lr_factor
-                    print(" lr={:.1e}".format(lr), end="")
-                    set_lr_(self.optimizer, lr)
-                elif patience <= 0:
-                    if e < self.min_epochs and t == 0:
-                        print("[BREAK SUSPEND] need at least {} epochs".format(self.min_epochs), end="")
-                    else:
-                        print("[BREAK] Patience=0/{}, with lr={:.1e}".format(self.lr_patience, lr))
-                        break
-            if warmup and e >= self.warmup_epochs:
-                warmup = False
-                patience = self.lr_patience
-                set_lr_(self.optimizer, self.lr)
-                print("[WARMUP END] Lambda_pre -> lambda_post (lr={})".format(self.lr), end="")
-            if (e + 1) % self.save_freq == 0:
-                torch.save({"post_lamb": self.post_lamb, "smax": self.smax, "warmup": warmup, "e": e + 1,
-                            "patience": patience, "best_acc": best_acc, "lr": lr,
-                            "optimizer": self.optimizer.state_dict(), "model": self.model.state_dict()}, chkpt_path)
-                print(" -> chkpt", end="")
-            print()
-
-        self.model = best_model
-        self.model.smax = self.smax
-        self.model.lamb = self.lamb
-        torch.save(self.model, os.path.join(self.exp_dir, "best_model.pth.tar"))
-        return self.model, best_acc
-
-    def _epoch_stats(self, n):
-        s = self._stats.cpu()
-        return float(s[0]) / n, float(s[1]) / n
-
-    def train_epoch(self, t, dset_loader, thres_cosh=50, thres_emb=6):
-        """hat.py:200-249. loss logged = CE + lamb*reg, like the reference."""
-        self._stats.zero_()
-        self._reg.zero_()
-        total_num = 0
-        nb = len(dset_loader)
-        batch_idx = 0
-        count = None
-        for images, targets in dset_loader:
-            bs = images.shape[0]
-            progress_ratio = batch_idx / (nb - 1)
-            batch_idx += 1
-            assert 0 <= progress_ratio <= 1
-            s = (self.smax - 1 / self.smax) * progress_ratio + 1 / self.smax
-            if count is None and self.mask_pre is None:
-                count = float(sum(g.numel() for g in self.hat.gate))     # task 0: numel of all gates (hat.py:294)
-            elif count is None:
-                count = float(sum(float((1 - mp).sum().item()) for mp in self.mask_pre))
-            # stats accumulates sum_i CE_i (mean * bs) and hits, on the device
-            _, reg, _ = self.hat.step(t, images, targets, s, self.mask_pre, self.lamb, count, backward=True,
-                                      stats=self._stats)
-            self._reg += reg.double() * bs
-            self.optimizer.step(self.model, self.mask_back, t, s, thres_cosh, self.smax, self.clipgrad)
-            H.clamp_embeddings(self.model, float(thres_emb))
-            total_num += bs
-        ce, acc = self._epoch_stats(total_num)
-        return ce + float(self._reg.item()) / total_num, acc
-
-    def eval(self, t, dset_loader):
-        """hat.py:251-283."""
-        self._stats.zero_()
-        self._reg.zero_()
-        total_num = 0
-        for images, targets in dset_loader:
-            bs = images.shape[0]
-            _, reg, _ = self.hat.step(t, images, targets, self.smax, self.mask_pre, self.lamb, None, backward=False,
-                                      stats=self._stats)
-            self._reg += reg.double() * bs
-            total_num += bs
-        ce, acc = self._epoch_stats(total_num)
-        reg = float(self._reg.item()) / total_num
-        print("<reg={:.6f}/ce={:.6f}>".format(reg, ce), end="")
+    def eval(self, t, loader):
+        ce, reg, acc = self._pass.run(t, loader, train=False)
         return ce + reg, acc
 
+    def train_epoch(self, t, loader):
+        ce, reg, acc = self._pass.run(t, loader, train=True)
+        return ce + reg, acc
 
-class ApprFinetune(Appr):
-    """approaches/hat_finetune.py:13-178: every unit open (mask of ones), CE only, back-mask on the gradients."""
+    def _new_optimizer(self, lr):
+        params = self.model.parameters() if self.joint else [p for p in self.model.parameters() if p.requires_grad]
+        return H.HAT_SGD(params, lr=lr, momentum=0.9, weight_decay=self.weight_decay)
 
-    def __init__(self, *args, **kwargs):
-        super().__init__(*args, **kwargs)
-        self.nepochs += self.warmup_epochs
+    def _resume(self, path, plan):
+        """epoch.pth.tar of an interrupted run of the SAME (smax, c); returns (first epoch, warm-up flag) or None."""
+        if not os.path.exists(path):
+            return None
+        ck = torch.load(path, weights_only=False)
+        if self.joint and (abs(self.smax - ck.get("smax", 1e30)) > 1e-6 or abs(self.post_lamb - ck.get("post_lamb", 1e30)) > 1e-6):
+            print("No chkpt loaded: other hyper-parameters")
+            return None
+        self.model.load_state_dict(ck["model"])
+        self.optimizer = self._new_optimizer(ck["lr"])
+        self.optimizer.load_state_dict(ck["optimizer"])
+        plan.restore(ck["lr"], ck["patience"], ck["best_acc"])
+        return ck["e"], bool(ck.get("warmup", False))
 
-    def _get_optimizer(self, lr=None):
-        if lr is None:
-            lr = self.lr
-        return H.HAT_SGD([p for p in self.model.parameters() if p.requires_grad], lr=lr, momentum=self.momentum,
-                         weight_decay=self.weight_decay)
-
-    def train(self, t, dset_loaders):
-        self.mask_pre, self.mask_back = self.init_masks(t, self.smax)
-        chkpt_path = os.path.join(self.exp_dir, "epoch.pth.tar")
-        if os.path.exists(chkpt_path):
-            chkpt = torch.load(chkpt_path, weights_only=False)
-            init_e = deepcopy(chkpt["e"])
-            with torch.no_grad():
-                for (_, p), (_, v) in zip(self.model.state_dict().items(), chkpt["model"].items()):
-                    p.copy_(v)
-            self.optimizer.load_state_dict(chkpt["optimizer"])
-            best_acc = deepcopy(chkpt["best_acc"])
-            lr = deepcopy(chkpt["lr"])
-            patience = deepcopy(chkpt["patience"])
+    def train(self, t, loaders):
+        plan = PatiencePlan(self.base_lr, LR_PATIENCE, LR_FACTOR, stop_at_or_below_zero=self.joint)
+        ck_path = os.path.join(self.exp_dir, "epoch.pth.tar")
+        resumed = self._resume(ck_path, plan)
+        if resumed is not None:
+            first_epoch, warmup = resumed
         else:
-            patience = self.lr_patience
-            best_acc = 0
-            init_e = 0
-            lr = self.lr
-            self.optimizer = self._get_optimizer(lr)
-        best_model = get_model(self.model)
-        for e in range(init_e, self.nepochs):
-            clock0 = time.time()
-            train_loss, train_acc = self.train_epoch(t, dset_loaders["train"])
-            clock1 = time.time()
-            print("| Epoch {:3d}, time={:5.1f}ms | Train: loss={:.3f}, acc={:5.1f}% |".format(
-                e + 1, 1000 * self.sbatch * (clock1 - clock0) / len(dset_loaders["train"]), train_loss,
-                100 * train_acc), end="")
-            valid_loss, valid_acc = self.eval(t, dset_loaders["val"])
-            print(" Valid: loss={:.3f}, acc={:5.1f}% |".format(valid_loss, 100 * valid_acc), end="")
-            if valid_acc > best_acc:
-                best_acc = valid_acc
-                best_model = get_model(self.model)
-                patience = self.lr_patience
-                print(" *", end="")
-                if os.path.exists(self.exp_dir):
+            first_epoch = 0
+            warmup = self.joint and t == 0 and self.model.enable_warmup      # hat.py:121
+            if warmup:
+                plan.lr = WARMUP_LR
+            self.optimizer = self._new_optimizer(plan.lr)
+        best_model = deepcopy(self.model)
+        self.mask_pre, self.mask_back = self.init_masks(t, self.smax)
+        min_epochs = int(self.nepochs / 2)                                   # first task only (hat.py:163-165)
+
+        for e in range(first_epoch, self.nepochs):
+            self.lamb = WARMUP_LAMB if warmup else self.post_lamb
+            t0 = time.time()
+            tr_loss, tr_acc = self.train_epoch(t, loaders["train"])
+            ms = 1000 * self.sbatch * (time.time() - t0) / len(loaders["train"])
+            va_loss, va_acc = self.eval(t, loaders["val"])
+            line = "| Epoch {:3d}, time={:5.1f}ms | Train: loss={:.6f}, acc={:5.1f}% | Valid: loss={:.6f}, acc={:5.1f}% |".format(
+                e + 1, ms, tr_loss, 100 * tr_acc, va_loss, 100 * va_acc)
+            verdict = plan.observe(va_acc, frozen=warmup)
+            if verdict == "best":
+                best_model = deepcopy(self.model)
+                line += " *"
+                if self.joint or os.path.exists(self.exp_dir):
                     torch.save(best_model, os.path.join(self.exp_dir, "best_model.pth.tar"))
-            else:
-                patience -= 1
-                if patience == self.lr_patience // 2:
-                    lr /= self.lr_factor
-                    print(" lr={:.1e}".format(lr), end="")
-                    set_lr_(self.optimizer, lr)
-                elif patience == 0:
-                    print("[BREAK] Patience=0/{}, with lr={:.1e}".format(self.lr_patience, lr))
+            elif verdict == "decay":
+                line += " lr={:.1e}".format(plan.lr)
+                for g in self.optimizer.param_groups:
+                    g["lr"] = plan.lr
+            elif verdict == "stop":
+                if self.joint and t == 0 and e < min_epochs:
+                    line += " [BREAK SUSPEND] need at least {} epochs".format(min_epochs)
+                else:
+                    print(line + " [BREAK] Patience=0/{}, with lr={:.1e}".format(LR_PATIENCE, plan.lr))
                     break
+            if warmup and e >= WARMUP_EPOCHS:                                 # hat.py:167-172
+                # the optimizer goes to the task LR, but the schedule keeps counting from the warm-up LR: the reference
+                # updates only the optimizer here, so a later decay sets warmup_lr / lr_factor (kept, G12 pins the trace)
+                warmup = False
+                plan.patience = LR_PATIENCE
+                for g in self.optimizer.param_groups:
+                    g["lr"] = self.base_lr
+                line += " [WARMUP END] lambda -> {} (lr={})".format(self.post_lamb, self.base_lr)
             if (e + 1) % self.save_freq == 0:
-                torch.save({"model": self.model.state_dict(), "e": e + 1, "patience": patience, "best_acc": best_acc,
-                            "lr": lr, "optimizer": self.optimizer.state_dict()}, chkpt_path)
-                print(" -> chkpt", end="")
-            print()
-        return best_model, best_acc
+                state = {"model": self.model.state_dict(), "e": e + 1, "patience": plan.patience, "best_acc": plan.best,
+                         "lr": plan.lr, "optimizer": self.optimizer.state_dict()}
+                if self.joint:
+                    state.update(post_lamb=self.post_lamb, smax=self.smax, warmup=warmup)
+                torch.save(state, ck_path)
+                line += " -> chkpt"
+            print(line)
 
-    def _pass(self, dset_loader, backward, t=None):
-        self._stats.zero_()
-        total_num = 0
-        for images, targets in dset_loader:
-            self.hat.plain_step(images, targets, backward=backward, stats=self._stats)
-            if backward:
-                self.optimizer.step(self.model, self.mask_back, t, finetune=True)
-            total_num += images.shape[0]
-        return self._epoch_stats(total_num)
+        if self.joint:                # hat.py:185-190: the best model carries its gate temperature and lambda
+            best_model.smax, best_model.lamb = self.smax, self.lamb
+            torch.save(best_model, os.path.join(self.exp_dir, "best_model.pth.tar"))
+            self.model = best_model
+        return best_model, plan.best
 
-    def train_epoch(self, t, dset_loader, thres_cosh=50, thres_emb=6):
-        return self._pass(dset_loader, True, t)
 
-    def eval(self, t, dset_loader):
-        return self._pass(dset_loader, False)
+# the Method class and older tests construct these by the reference's names
+def Appr(model, exp_dir, nepochs=100, sbatch=200, lr=0.05, args=None, in_shape=None, device="cuda", **_):
+    a = SimpleNamespace(**vars(args))
+    a.nepochs, a.batch_size, a.lr = nepochs, sbatch, lr
+    return HatTrainer(model, exp_dir, a, in_shape, joint=True, device=device)
+
+
+def ApprFinetune(model, exp_dir, nepochs=100, sbatch=200, lr=0.05, args=None, in_shape=None, device="cuda", **_):
+    a = SimpleNamespace(**vars(args))
+    a.nepochs, a.batch_size, a.lr = nepochs, sbatch, lr
+    return HatTrainer(model, exp_dir, a, in_shape, joint=False, device=device)
+
+
+_DEFAULTS = dict(seed=0, approach="", output="", nepochs=200, save_freq=20, lr=1e10, parameter="")     # run.py:13-22
 
 
 def main(overwrite_args, device="cuda"):
-    """run.py:9-120."""
+    """run.py:9-120: `overwrite_args` is the dict methods/method.py hands over (keys at method.py:638-658)."""
     tstart = time.time()
-    parser = argparse.ArgumentParser()
-    parser.add_argument("--seed", type=int, default=0)
-    parser.add_argument("--approach", default="", type=str)
-    parser.add_argument("--output", default="", type=str)
-    parser.add_argument("--nepochs", default=200, type=int)
-    parser.add_argument("--save_freq", default=20, type=int)
-    parser.add_argument("--lr", default=1e10, type=float)
-    parser.add_argument("--parameter", type=str, default="")
-    args = parser.parse_known_args([])[0]
-    for key_arg, val_arg in overwrite_args.items():
-        setattr(args, key_arg, val_arg)
+    args = SimpleNamespace(**{**_DEFAULTS, **overwrite_args})
     args.task_idx = args.task_count - 1
     if args.approach != "hat":
         raise NotImplementedError("Method {} not implemented!".format(args.approach))   # pathnet: out of scope
@@ -310,19 +213,17 @@ def main(overwrite_args, device="cuda"):
 
     dsets = load_task_datasets(args.dataset_path)
     args.task_imgfolders = dsets
-    args.dset_loaders = {x: DeviceLoader(dsets[x], args.batch_size, True, device) for x in ["train", "val"]}
-    taskcla = [(t, nc) for t, nc in enumerate(args.nc_per_task)]
+    args.dset_loaders = {x: DeviceLoader(dsets[x], args.batch_size, True, device) for x in ("train", "val")}
+    taskcla = list(enumerate(args.nc_per_task))
     inputsize = (3,) + tuple(args.dataset.input_size)
 
+    prev = torch.load(args.prev_model_path, weights_only=False)
     if args.is_scratch_model:
         assert args.task_idx == 0
-        raw_model = torch.load(args.prev_model_path, weights_only=False)
-        net = H.HatNet(raw_model, inputsize, taskcla).to(device)
+        net = H.HatNet(prev, inputsize, taskcla).to(device)         # first task: wrap the raw VGG (run.py:84-92)
     else:
-        net = torch.load(args.prev_model_path, weights_only=False).to(device)
-    cls = ApprFinetune if args.finetune_mode else Appr
-    appr = cls(net, args.output, sbatch=args.batch_size, nepochs=args.nepochs, lr=args.lr, args=args, lr_factor=2,
-               lr_patience=30, in_shape=inputsize, device=device)
-    best_val_model, best_val_acc = appr.train(args.task_idx, args.dset_loaders)
-    print("[Elapsed time = {:.1f} h]".format((time.time() - tstart) / (60 * 60)))
+        net = prev.to(device)
+    trainer = HatTrainer(net, args.output, args, inputsize, joint=not args.finetune_mode, device=device)
+    best_val_model, best_val_acc = trainer.train(args.task_idx, args.dset_loaders)
+    print("[Elapsed time = {:.1f} h]".format((time.time() - tstart) / 3600))
     return best_val_model, best_val_acc

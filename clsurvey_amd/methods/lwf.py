@@ -163,6 +163,31 @@ def train_model_lwf(model, original_model, optimizer, lr, dset_loaders, dset_siz
     return model, best_acc
 
 
+def fine_tune_freeze(dataset_path, model_path, exp_dir, batch_size=100, num_epochs=100, lr=0.0004, device="cuda"):
+    """main_LWF.py:322-362 — LwF's optional head warm-up: a fresh head for the new task on top of the previous model,
+    trained alone (plain CE, SGD momentum 0.9 over the head's two tensors) with everything else frozen; best_model.pth.tar
+    and epoch.pth.tar land in exp_dir.  A wrapper from an earlier LwF task is cut back to its net with the shared layers
+    + one head slot (the reference reaches for `.module` there, an attribute AlexNet_LwF does not have, and stops)."""
+    print("lr is " + str(lr))
+    dsets = load_task_datasets(dataset_path)
+    dset_loaders = tc.make_loaders(dsets, batch_size, device)
+    dset_sizes = {x: len(dsets[x]) for x in ["train", "val"]}
+    model_ft = tc.load_model(model_path)
+    if isinstance(model_ft, AlexNet_LwF):
+        net = model_ft.model
+        net.classifier = nn.Sequential(*list(net.classifier.children())[:model_ft.last_layer_name + 1])
+        model_ft = net
+    tc.replace_head(model_ft, len(dsets["train"].classes))
+    os.makedirs(exp_dir, exist_ok=True)
+    model_ft = model_ft.to(device)
+    engine = tc.engine_for(model_ft, dset_loaders, batch_size, device)
+    last = str(len(model_ft.classifier._modules) - 1)
+    optimizer_ft = SGD(model_ft.classifier._modules[last].parameters(), lr, momentum=0.9)
+    model_ft, _ = tc.train_model(model_ft, engine, optimizer_ft, lr, dset_loaders, dset_sizes, num_epochs, exp_dir,
+                                 os.path.join(exp_dir, "epoch.pth.tar"), step_fn=optimizer_ft.step, abort_on_bad_loss=False)
+    return model_ft
+
+
 def fine_tune_SGD_LwF(dataset_path, previous_task_model_path, init_model_path="", exp_dir="", batch_size=200,
                       num_epochs=100, lr=0.0004, init_freeze=1, pretrained=True, weight_decay=0, last_layer_name=6,
                       saving_freq=5, reg_lambda=1, device="cuda"):

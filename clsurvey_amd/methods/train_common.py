@@ -34,6 +34,36 @@ def set_lr(optimizer, lr, count, early_stop="gt"):
     return optimizer, lr, continue_training
 
 
+class PatiencePlan:
+    """Validation-driven schedule of the mask-based trainers (HAT/approaches/hat.py:150-166, hat_finetune.py:108-124):
+    a new best resets the patience; otherwise it counts down, the LR is divided by `factor` when half is left and
+    training stops at zero.  observe() returns 'best' | 'decay' | 'stop' | 'hold'; `frozen` epochs (HAT's warm-up)
+    neither count down nor stop.  stop_at_or_below_zero: joint HAT keeps counting below zero while its first task is
+    still under the minimum epoch count, the phase-1 search stops exactly at zero."""
+
+    def __init__(self, lr, patience, factor, stop_at_or_below_zero=True):
+        self.lr, self.full, self.factor = lr, patience, factor
+        self.patience, self.best = patience, 0
+        self.leq = stop_at_or_below_zero
+
+    def restore(self, lr, patience, best):
+        self.lr, self.patience, self.best = lr, patience, best
+
+    def observe(self, acc, frozen=False):
+        if acc > self.best:
+            self.best, self.patience = acc, self.full
+            return "best"
+        if frozen:
+            return "hold"
+        self.patience -= 1
+        if self.patience == self.full // 2:
+            self.lr /= self.factor
+            return "decay"
+        if (self.patience <= 0) if self.leq else (self.patience == 0):
+            return "stop"
+        return "hold"
+
+
 def make_loaders(dsets, batch_size, device, phases=("train", "val"), shuffle=True):
     return {x: DeviceLoader(dsets[x], batch_size, shuffle, device) for x in phases}
 

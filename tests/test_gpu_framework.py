@@ -658,9 +658,11 @@ def test_gem_alexnet_through_driver(tmp_path):
     for mod in m.modules():
         if isinstance(mod, (torch.nn.Linear, torch.nn.Conv2d)):
             torch.nn.init.kaiming_normal_(mod.weight, nonlinearity="relu")
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.1     # at p = 0.5 this narrow net does not leave chance level on 96 samples (torch-CPU does not either)
     os.makedirs(os.path.join(root, "models"), exist_ok=True)
     torch.save(m, os.path.join(root, "models", "alexnet_scratch.pth.tar"))
-    common = ["alexnet_scratch", "--lr_grid", "3e-3", "--num_epochs", "6", "--batch_size", "24", "--saving_freq", "100"]
+    common = ["alexnet_scratch", "--lr_grid", "3e-3", "--num_epochs", "12", "--batch_size", "24", "--saving_freq", "100"]
     driver.main(common + ["--method_name", "SI", "--results_root", root, "--runmode", "first_task_basemodel_dump"],
                 method=M.parse("SI"), dataset=ds)
     gem = M.parse("GEM")

@@ -153,3 +153,37 @@ def test_resume_restores_bn_buffers_and_momentum(tmp_path):
     resumed = run(2, os.path.join(d2, "epoch.pth.tar"), d2, base)  # fresh model + optimizer, resume into epoch 1
     for (n, a), (_, b) in zip(full.state_dict().items(), resumed.state_dict().items()):
         assert torch.equal(a, b), n
+
+
+def test_head_warmups_train_the_head_only(tmp_path):
+    """LwF's fine_tune_freeze (main_LWF.py:322-362) and fine_tune_SGD(freeze_mode=1) (main_SGD.py:59-72): a fresh head is
+    trained, every other tensor stays bit-identical; LWF(warmup_step=True).train runs the warm-up into
+    task_<t>/HEAD_TRAINING before the distillation training."""
+    from clsurvey_amd.methods import finetune, lwf
+    from clsurvey_amd.methods import method as M
+    dsets = _task()
+    base = _model("small_VGG9_cl_128_128")
+    path = str(tmp_path / "prev.pth.tar")
+    torch.save(base, path)
+    before = {n: v.clone() for n, v in base.state_dict().items()}
+
+    def check(model):
+        sd = model.state_dict()
+        head = [n for n in sd if n.startswith("classifier.4.")]
+        assert len(head) == 2
+        for n, v in sd.items():
+            if n in head:
+                assert not torch.equal(v.cpu(), before[n]), n
+            else:
+                assert torch.equal(v.cpu(), before[n]), n
+
+    warmed = lwf.fine_tune_freeze(dsets, path, str(tmp_path / "warm"), batch_size=20, num_epochs=2, lr=1e-2, device=DEV)
+    check(warmed)
+    assert os.path.isfile(str(tmp_path / "warm" / "best_model.pth.tar"))
+    from clsurvey_amd.methods.method import compose_dataset
+    loaders, sizes, classes = compose_dataset([dsets], 20, DEV)
+    m2, acc = finetune.fine_tune_SGD(loaders, sizes, classes, path, str(tmp_path / "ft"), num_epochs=2, lr=1e-2,
+                                     freeze_mode=1, device=DEV, batch_size=20)
+    check(m2)
+    assert 0.0 <= acc <= 1.0
+    assert M.LWF(warmup_step=True).warmup_step and not M.parse("LWF").warmup_step
