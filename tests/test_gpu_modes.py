@@ -23,7 +23,7 @@ def _task(n_train=80, n_val=40, hw=32, classes=4, seed=0):
         y = torch.arange(n) % classes
         x = proto[y] + 0.4 * torch.randn(n, 3, hw, hw, generator=g)
         return TensorTaskDataset(x.to(DEV), y.to(DEV), [str(c) for c in range(classes)])
-    return {"train": split(n_train), "val": split(n_val)}
+    return {"train": split(n_train), "val": split(n_val), "test": split(n_val)}
 
 
 def _model(name="small_VGG9_cl_128_128_DROP_BN", hw=32, classes=4, seed=1):
@@ -187,3 +187,55 @@ def test_head_warmups_train_the_head_only(tmp_path):
     check(m2)
     assert 0.0 <= acc <= 1.0
     assert M.LWF(warmup_step=True).warmup_step and not M.parse("LWF").warmup_step
+
+
+@pytest.mark.parametrize("train_bn", [False, True])
+def test_packnet_train_bn_switch(tmp_path, train_bn):
+    """PackNet on a '_BN' net (packnet/prune.py:94-98, main.py:158-161, 263-266): with train_bn off the BatchNorm scale /
+    shift of the shared body stay bit-identical through a later task's training (their gradients are zeroed in the fused
+    batch tail), with train_bn on they move; the first task's weights stay frozen either way; evaluation runs on the
+    running statistics (same error from two sweeps)."""
+    import torch.nn as nn
+    from clsurvey_amd.methods import packnet_main as PM
+    root = str(tmp_path)
+    raw = os.path.join(root, "raw.pth.tar")
+    torch.save(_model("small_VGG9_cl_128_128_BN"), raw)
+    tasks = [_task(seed=3), _task(seed=4)]
+    init = os.path.join(root, "INIT_WRAPPED.pth")
+    PM.main({"arch": "VGGslim_nopretrain", "init_dump": True, "cuda": True, "loadname": raw, "save_prefix": init,
+             "last_layer_idx": 4, "current_dataset_idx": 1})
+    common = dict(weight_decay=0.0, cuda=True, batch_size=20, train_bn=train_bn, saving_freq=100, num_outputs=4)
+
+    def finetune(t, prev):
+        ft = os.path.join(root, "ft%d" % t, "best_model")
+        os.makedirs(os.path.dirname(ft))
+        PM.main(dict(common, disable_pruning_mask=t == 1, train_path=tasks[t - 1], test_path=tasks[t - 1], mode="finetune",
+                     dataset="survey_TASK_%d" % t, loadname=prev, lr=1e-2, finetune_epochs=3, save_prefix=ft,
+                     current_dataset_idx=t))
+        return ft + ".pth.tar"
+
+    f1 = finetune(1, init)
+    pr = os.path.join(root, "pr1", "best_model_PRUNED")
+    os.makedirs(os.path.dirname(pr))
+    PM.main(dict(common, train_path=tasks[0], test_path=tasks[0], mode="prune", dataset="survey_TASK_1", loadname=f1,
+                 post_prune_epochs=1, prune_perc_per_layer=0.5, lr=1e-3, finetune_epochs=3, save_prefix=pr,
+                 current_dataset_idx=1))
+    start = pr + ("_final.pth.tar" if os.path.exists(pr + "_final.pth.tar") else "_postprune.pth.tar")
+    before = torch.load(start, weights_only=False)
+    f2 = finetune(2, start)
+    after = torch.load(f2, weights_only=False)
+    bn_b = [m for m in before["model"].shared.modules() if isinstance(m, nn.BatchNorm2d)]
+    bn_a = [m for m in after["model"].shared.modules() if isinstance(m, nn.BatchNorm2d)]
+    assert len(bn_b) == 6
+    same = all(torch.equal(a.weight.cpu(), b.weight.cpu()) and torch.equal(a.bias.cpu(), b.bias.cpu()) for a, b in zip(bn_a, bn_b))
+    assert same == (not train_bn)
+    assert any(not torch.equal(a.running_mean.cpu(), b.running_mean.cpu()) for a, b in zip(bn_a, bn_b))   # train mode
+    for i, (ma, mb) in enumerate(zip(after["model"].shared.modules(), before["model"].shared.modules())):
+        if isinstance(ma, (nn.Conv2d, nn.Linear)):
+            owned = before["previous_masks"][i].cpu() == 1
+            assert torch.equal(ma.weight.cpu()[owned], mb.weight.cpu()[owned]), i
+    e1 = PM.main(dict(common, train_path=tasks[0], test_path=tasks[0], mode="eval", dataset="survey_TASK_1", loadname=f2,
+                      current_dataset_idx=1))
+    e2 = PM.main(dict(common, train_path=tasks[0], test_path=tasks[0], mode="eval", dataset="survey_TASK_1", loadname=f2,
+                      current_dataset_idx=1))
+    assert e1 == e2 and 0.0 <= e1 <= 100.0
