@@ -11,7 +11,12 @@ Reproduced semantics (file:line of the reference):
   * phase 2: threshold A_ft*(1-p), decay, max attempts, hyperparams.pth.tar + SUCCESS.FLAG
                                                              framework_train.py:76-216
   * eval: seq_res / seq_forgetting dict layout and file name  eval.py:146-247, utils.py:200-230
-The phase-1 grid can be sharded over ranks (clsurvey_amd.framework.shard); phase 2 stays sequential.
+`--shard` under torch.distributed.run spreads the independent trainings over one process per GPU
+(clsurvey_amd.framework.shard): phase-1 grid nodes, speculative phase-2 attempts and the evaluation pairs; models and
+metrics move by RCCL broadcast / all_gather, every rank keeps its own results tree.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m clsurvey_amd.framework.driver \
+        base_VGG9_cl_512_512 --method_name MAS --synthetic 10,20,8000,2000,1000,64 --shard --test
 """
 import argparse
 import copy
@@ -64,6 +69,13 @@ def build_parser():
     # build-specific
     p.add_argument("--results_root", type=str, default="./exp_results")
     p.add_argument("--device", type=str, default="cuda")
+    p.add_argument("--shard", action="store_true",
+                   help="one process per GPU (torch.distributed.run): grid nodes, decay attempts and evaluations are "
+                        "spread over the ranks; each rank writes under <results_root>/rank<r>")
+    p.add_argument("--no_speculation", action="store_true", help="with --shard: keep phase 2 sequential on every rank")
+    p.add_argument("--synthetic", type=str, default=None,
+                   help="command-line runs: tasks,classes,train,val,test,hw of a synthetic task sequence "
+                        "(clsurvey_amd.framework.tasks), e.g. 10,20,8000,2000,1000,64 = Tiny-ImageNet's shape")
     return p
 
 
@@ -209,6 +221,8 @@ def lr_grid_single_task(args, manager, save_models_mode="keep_none", train_node=
             for d in iteration_batch_dirs:
                 shutil.rmtree(d, ignore_errors=True)
     print("FINETUNE DONE: best_lr={}, best_acc={}".format(best_lr, best_acc))
+    if getattr(manager, "after_grid", None) is not None:         # sharded grid: fetch the winner's files from its rank
+        manager.after_grid(args, manager, best_lr)
     if hasattr(manager.method, "grid_poststep"):
         manager.method.grid_poststep(args, manager)
     return best_lr, best_acc
@@ -266,8 +280,15 @@ class HyperparameterFramework(object):
             manager.best_model_path = os.path.join(manager.heuristic_exp_dir, "best_model.pth.tar")
             return
         args.presteps_elapsed_time = 0
+        sharded = getattr(manager, "speculative", False)
         if hasattr(manager.method, "prestep"):
-            manager.method.prestep(args, manager)
+            if sharded:
+                self._prestep_on_rank0(args, manager)
+            else:
+                manager.method.prestep(args, manager)
+        if sharded:
+            self._speculative_decay(args, manager, finetune_acc)
+            return
         max_attempts = args.max_attempts_per_task
         converged = False
         while not converged and self.attempts < max_attempts:
@@ -293,6 +314,47 @@ class HyperparameterFramework(object):
                     converged = True
             manager.save_hyperparams(manager.heuristic_exp_dir,
                                      {"acc_threshold": threshold, "val_acc": task_lr_acc, "state": self._get_state()})
+        manager.best_model_path = os.path.join(manager.heuristic_exp_dir, "best_model.pth.tar")
+        manager.create_success_token(manager.heuristic_exp_dir)
+
+    @staticmethod
+    def _prestep_on_rank0(args, manager):
+        """A prestep trains something of its own (EBLL: the autoencoder grid on the previous task) and publishes it as
+        manager.autoencoder_model_path: trained once, on rank 0, then copied into every rank's tree."""
+        from . import shard
+        rank, _ = shard.rank_world()
+        rel = None
+        if rank == 0:
+            manager.method.prestep(args, manager)
+            if manager.autoencoder_model_path:
+                rel = os.path.relpath(manager.autoencoder_model_path, manager.parent_exp_dir)
+        rel = shard.broadcast_object(rel, src=0)
+        if rel is not None:
+            manager.autoencoder_model_path = os.path.join(manager.parent_exp_dir, rel)
+            shard.broadcast_files(os.path.dirname(manager.autoencoder_model_path), 0)
+
+    def _speculative_decay(self, args, manager, finetune_acc):
+        """Phase 2 with one attempt per rank in flight (shard.speculative_round).  Leaves this object, the trace and
+        hyperparams.pth.tar in the state the sequential loop reaches when the same attempts succeed / fail."""
+        from . import shard
+        threshold = finetune_acc * args.inv_drop_margin
+        while True:
+            t0 = time.time()
+            accs, accepted = shard.speculative_round(self, args, manager, finetune_acc)
+            upto = accepted if accepted is not None else max(accs)
+            for k in range(self.attempts, upto + 1):                 # one trace entry per attempt, in attempt order
+                twin = shard.decayed_copy(self, args, manager, k - self.attempts)
+                self.trace.append((copy.deepcopy(dict(twin.hyperparams)), accs[k], threshold))
+            failures = (upto - self.attempts) + (0 if accs[upto] >= threshold else 1)
+            for _ in range(failures):
+                self.hyperparamDecay(args, manager)
+                self.attempts += 1
+            manager.method.hyperparams = self.hyperparams
+            if accepted is not None:
+                args.convergence_iteration_elapsed_time = time.time() - t0
+                manager.save_hyperparams(manager.heuristic_exp_dir, {"acc_threshold": threshold, "val_acc": accs[accepted],
+                                                                     "state": self._get_state()})
+                break
         manager.best_model_path = os.path.join(manager.heuristic_exp_dir, "best_model.pth.tar")
         manager.create_success_token(manager.heuristic_exp_dir)
 
@@ -361,20 +423,31 @@ def get_perf_output_filename(method_name, dataset_index):
 
 
 def eval_all_models_all_tasks(args, manager, ds_paths, model_paths):
-    """eval.py:146-247: model j >= i evaluated on task i with task i's head; forgetting = acc_i(i) - acc_i(j)."""
-    out = {}
-    os.makedirs(args.out_path, exist_ok=True)
-    for dataset_index in range(args.test_starting_task_count - 1, args.test_max_task_count):
-        if dataset_index >= len(ds_paths):
-            break
+    """eval.py:146-247: model j >= i evaluated on task i with task i's head; forgetting = acc_i(i) - acc_i(j).
+    With --shard the (task, model) pairs are spread over the ranks and the accuracies all-gathered."""
+    from . import shard
+    rank, world = shard.rank_world() if getattr(manager, "speculative", False) or getattr(manager, "after_grid", None) else (0, 1)
+    tasks = [i for i in range(args.test_starting_task_count - 1, args.test_max_task_count) if i < len(ds_paths)]
+    pairs = [(i, j) for i in tasks for j in range(i, len(ds_paths))]
+
+    def evaluate(dataset_index, trained_model_idx):
         args.eval_dset_idx = dataset_index
-        seq_acc, seq_forgetting = {dataset_index: []}, {dataset_index: []}
         args.dset_path = ds_paths[dataset_index]
         args.head_paths = model_paths[dataset_index]
+        args.trained_model_idx = trained_model_idx
+        args.eval_model_path = model_paths[trained_model_idx]
+        return manager.method.inference_eval(args, manager)
+
+    table = {n: evaluate(*pq) for n, pq in enumerate(pairs) if n % world == rank}
+    if world > 1:
+        table = shard.gather_scalars(table)
+    acc_of = {pq: table[n] for n, pq in enumerate(pairs)}
+    out = {}
+    os.makedirs(args.out_path, exist_ok=True)
+    for dataset_index in tasks:
+        seq_acc, seq_forgetting = {dataset_index: []}, {dataset_index: []}
         for trained_model_idx in range(dataset_index, len(ds_paths)):
-            args.trained_model_idx = trained_model_idx
-            args.eval_model_path = model_paths[trained_model_idx]
-            accuracy = manager.method.inference_eval(args, manager)
+            accuracy = acc_of[(dataset_index, trained_model_idx)]
             seq_acc[dataset_index].append(accuracy)
             if trained_model_idx > dataset_index:
                 seq_forgetting[dataset_index].append(seq_acc[dataset_index][0] - accuracy)
@@ -408,6 +481,19 @@ def first_task_modelname(args):
 
 def main(argv=None, method=None, dataset=None, train_node_factory=None):
     args = build_parser().parse_args(argv)
+    speculative = False
+    if args.shard:
+        from . import shard
+        rank, world = shard.init_from_env()
+        if world > 1:
+            args.results_root = os.path.join(args.results_root, "rank%d" % rank)
+            train_node_factory = train_node_factory or shard.sharded_grid_factory()
+            speculative = not args.no_speculation
+    if dataset is None and args.synthetic:
+        from .tasks import SyntheticTaskSequence
+        n_tasks, n_cls, n_tr, n_va, n_te, hw = [int(v) for v in args.synthetic.split(",")]
+        dataset = SyntheticTaskSequence(os.path.join(args.results_root, "data"), task_count=n_tasks, classes_per_task=n_cls,
+                                        sizes=(n_tr, n_va, n_te), hw=hw)
     set_random(7)                                                 # utils.init -> set_random()
     if method is None:
         method = methods.parse(args.method_name)
@@ -459,6 +545,7 @@ def main(argv=None, method=None, dataset=None, train_node_factory=None):
     if not os.path.exists(prev) and not args.first_task_basemodel_dump:
         raise Exception("NOT EXISTING previous_task_model_path = " + prev)
     manager = Manager(dataset, method, prev, parent_exp_dir, base_model)
+    manager.speculative = speculative
     ds_paths, model_paths, frameworks = [], [], []
     for task_counter in range(args.starting_task_count, args.max_task_count + 1):
         args.task_counter = task_counter
@@ -489,3 +576,13 @@ def main(argv=None, method=None, dataset=None, train_node_factory=None):
         results = eval_all_models_all_tasks(args, manager, ds_paths, model_paths)
     return {"manager": manager, "frameworks": frameworks, "ds_paths": ds_paths, "model_paths": model_paths,
             "results": results, "args": args}
+
+
+if __name__ == "__main__":
+    out = main()
+    from . import shard as _shard
+    if _shard.rank_world()[0] == 0 and out["results"] is not None:
+        for i, r in sorted(out["results"].items()):
+            print("task %d: acc %s  forgetting %s" % (i + 1, ["%.2f" % a for a in r["seq_res"][i]],
+                                                      ["%.2f" % f for f in r["seq_forgetting"][i]]))
+    _shard.barrier()

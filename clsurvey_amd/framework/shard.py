@@ -1,19 +1,30 @@
-"""Grid sharding of the Continual Hyperparameter Framework over the GPUs of one node.
+"""Sharding the Continual Hyperparameter Framework over the GPUs of one node.
 
-What shards: the phase-1 LR grid — `for lr in args.lrs` x finetune_iterations
-(framework/lr_grid_train.py:51,60) are independent trainings from the same start model, seeded by
-the iteration index only — and, optionally, the phase-2 stability-decay attempts run speculatively
-(attempt k uses lambda * decay^k; the smallest k meeting acc >= A_ft(1-p) wins, the same decision
-rule as framework_train.py:100-136).  What does not: the task order and a single training run.
+What shards, all of it independent trainings — there is NO collective on the per-batch data path:
+  * phase 1: the LR grid, `for lr in args.lrs` x finetune_iterations (framework/lr_grid_train.py:51,60): nodes start
+    from the same model and are seeded by their iteration index only, so node i simply runs on rank i % world;
+  * phase 2: the stability-decay attempts (framework_train.py:100-136) run speculatively, attempt `attempts + rank` on
+    rank `rank`, each at the hyper-parameters the reference's decay schedule reaches after that many failures
+    (one-at-a-time order for methods with several hyper-parameters, framework_train.py:168-216, replayed on a copy of
+    the framework state); the smallest attempt index that meets acc >= A_ft (1 - p) is accepted, exactly the
+    sequential rule;
+  * evaluation: the (task, model) pairs of eval.py:146-247.
+What does not: the task order, and a single training.
 
-One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" in the CPU
-tests).  Collectives carry models and metrics only:
-  * broadcast of the flat parameter arena of the start / winning model (2.4-36 MB for the VGG9s)
-  * all_gather of (node index, accuracy) scalars
-There is no collective on the per-batch data path.
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" in the CPU tests).  Every
+rank executes the same host logic on ITS OWN results tree (`<results_root>/rank<r>` — no shared filesystem is assumed and
+no two ranks ever write one path); what a rank needs from another travels through collectives, models and metrics only:
+  * all_gather of (index, accuracy) scalars after a batch of trainings,
+  * broadcast of the winner's saved model file(s) from the rank that trained it (2.4 - 36 MB for the VGG9s),
+  * broadcast of a flat parameter arena (bench.py: start model / winner).
+Sharded runs are reproducible for a fixed world size; against a 1-rank run they differ where the reference's own
+results depend on the RNG state left by the previous training (it never re-seeds between decay attempts): every
+speculative attempt is seeded by (task, attempt index) instead.
 """
 import copy
+import fnmatch
 import os
+import shutil
 
 import torch
 import torch.distributed as dist
@@ -23,6 +34,21 @@ def rank_world():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
+
+
+def init_from_env(backend=None):
+    """torch.distributed.run contract: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment.  Returns
+    (rank, world); a single process initialises nothing."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        use_gpu = torch.cuda.is_available()
+        if use_gpu:
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(backend or ("nccl" if use_gpu else "gloo"), rank=int(os.environ["RANK"]), world_size=world)
+    return rank_world()
 
 
 def _dev():
@@ -36,8 +62,14 @@ def assign(n_nodes, world):
     return [i % world for i in range(n_nodes)]
 
 
+def fill_factor(n_nodes, world):
+    """Busy fraction of the ranks while a batch of n_nodes equal trainings runs: n / (world * ceil(n / world))."""
+    rounds = -(-n_nodes // world)
+    return n_nodes / float(world * rounds) if n_nodes else 0.0
+
+
 def gather_scalars(values):
-    """values: {node_index: float} computed on this rank -> merged dict on every rank."""
+    """values: {index: float} computed on this rank -> merged dict on every rank."""
     rank, world = rank_world()
     if world == 1:
         return dict(values)
@@ -74,10 +106,67 @@ def broadcast_model(model, src=0):
     return model
 
 
-def sharded_grid_factory(node_dir_fn=None):
-    """train_node factory for driver.main(): every rank trains the grid nodes assigned to it, the
-    accuracies are all-gathered, and each rank then replays the reference's sequential
-    selection rule over the complete table (identical decision on every rank)."""
+def broadcast_bytes(payload, src):
+    """bytes on rank src (anything on the others) -> the same bytes everywhere; length first, then one uint8 tensor."""
+    rank, world = rank_world()
+    if world == 1:
+        return payload
+    n = torch.tensor([len(payload) if rank == src else 0], dtype=torch.int64, device=_dev())
+    dist.broadcast(n, src=src)
+    size = int(n.item())
+    if rank == src:
+        buf = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(_dev()) if size else torch.zeros(0, dtype=torch.uint8, device=_dev())
+    else:
+        buf = torch.zeros(size, dtype=torch.uint8, device=_dev())
+    if size:
+        dist.broadcast(buf, src=src)
+    return bytes(buf.cpu().numpy().tobytes())
+
+
+def broadcast_files(directory, src, patterns=("*.pth.tar", "*.pth", "*.FLAG")):
+    """The model / checkpoint files directly under `directory` on rank src appear under the same relative name in
+    every rank's `directory` (which is a different absolute tree per rank).  Returns the file names."""
+    rank, world = rank_world()
+    if world == 1:
+        return []
+    names = []
+    if rank == src and os.path.isdir(directory):
+        # (no glob on the path: experiment directories carry the LR grid in brackets, a glob character class)
+        names = sorted(n for n in os.listdir(directory) if os.path.isfile(os.path.join(directory, n))
+                       and any(fnmatch.fnmatch(n, pat) for pat in patterns))
+    names = broadcast_bytes("\n".join(names).encode(), src).decode().split("\n")
+    names = [n for n in names if n]
+    if rank != src:
+        os.makedirs(directory, exist_ok=True)
+    for name in names:
+        path = os.path.join(directory, name)
+        data = b""
+        if rank == src:
+            with open(path, "rb") as f:
+                data = f.read()
+        data = broadcast_bytes(data, src)
+        if rank != src:
+            with open(path, "wb") as f:
+                f.write(data)
+    return names
+
+
+def broadcast_object(obj, src=0):
+    import pickle
+    return pickle.loads(broadcast_bytes(pickle.dumps(obj), src))
+
+
+def barrier():
+    if rank_world()[1] > 1:
+        dist.barrier()
+
+
+# ------------------------------------------------------------------------------------------------ phase 1
+def sharded_grid_factory():
+    """train_node factory for driver.main(): every rank trains the grid nodes assigned to it, the accuracies are
+    all-gathered, and each rank then replays the reference's sequential selection rule over the complete table (same
+    decision everywhere).  After the selection the winner's node directory is copied from its owner to every rank
+    (manager.after_grid), because the methods without a phase 2 adopt that model as the task's model."""
     from . import driver
 
     def factory(args, manager):
@@ -86,14 +175,17 @@ def sharded_grid_factory(node_dir_fn=None):
         owner = assign(len(nodes), world)
         table = {}
 
+        def node_dir(lr, it):
+            d = "lr=" + driver.float_to_scientific_str(lr) + ("_it%d" % it if args.finetune_iterations > 1 else "")
+            return os.path.join(manager.ft_parent_exp_dir, d)
+
         def run_all():
             mine = {}
             for i, (lr, it) in enumerate(nodes):
                 if owner[i] != rank:
                     continue
                 driver.set_random(it)
-                d = "lr=" + driver.float_to_scientific_str(lr) + ("_it%d" % it if args.finetune_iterations > 1 else "")
-                manager.gridsearch_exp_dir = os.path.join(manager.ft_parent_exp_dir, d)
+                manager.gridsearch_exp_dir = node_dir(lr, it)
                 os.makedirs(manager.gridsearch_exp_dir, exist_ok=True)
                 _, acc = manager.method.grid_train(args, manager, lr)
                 mine[i] = acc
@@ -103,25 +195,57 @@ def sharded_grid_factory(node_dir_fn=None):
             if not table:
                 run_all()
             return table[nodes.index((lr, it))]
+
+        def after_grid(args_, manager_, best_lr):
+            best_dir = manager_.best_exp_grid_node_dirname
+            if best_dir is None:
+                return
+            src = next(owner[i] for i, (lr, it) in enumerate(nodes) if node_dir(lr, it) == best_dir)
+            broadcast_files(best_dir, src)
+        manager.after_grid = after_grid
+        manager.grid_fill_factor = fill_factor(len(nodes), world)
         return train_node
     return factory
 
 
-def speculative_decay(hf, args, manager, finetune_acc, max_parallel=None):
-    """Run stability-decay attempts k = attempts .. attempts+world-1 concurrently (one per rank) and
-    accept the smallest k with acc >= threshold.  Returns (k_accepted or None, {k: acc})."""
-    rank, world = rank_world()
-    lam0 = copy.deepcopy(dict(hf.hyperparams))
-    k = rank
-    hp = dict(lam0)
+# ------------------------------------------------------------------------------------------------ phase 2
+def decayed_copy(hf, args, manager, k):
+    """Framework state after k more failed attempts: a deep copy of `hf` advanced by the reference's own decay rule."""
+    twin = copy.copy(hf)
+    twin.hyperparams = copy.deepcopy(hf.hyperparams)
+    twin.hyperparams_backup = copy.deepcopy(hf.hyperparams_backup)
     for _ in range(k):
-        for key in hp:
-            hp[key] = hp[key] * args.decaying_factor
-    base = manager.heuristic_exp_dir
-    manager.heuristic_exp_dir = base + "_spec%d" % k
-    _, acc = manager.method.train(args, manager, hp)
-    manager.heuristic_exp_dir = base
-    accs = gather_scalars({k: acc})
-    thr = finetune_acc * args.inv_drop_margin
-    ok = sorted(kk for kk, a in accs.items() if a >= thr)
-    return (ok[0] if ok else None), accs
+        twin.hyperparamDecay(args, manager)
+        twin.attempts += 1
+    return twin
+
+
+def speculative_round(hf, args, manager, finetune_acc):
+    """One round of speculative stability decay: rank r trains attempt `hf.attempts + r` (skipped past
+    max_attempts_per_task).  Returns (accs {attempt: acc}, accepted attempt or None); on acceptance every rank's
+    heuristic_exp_dir holds the accepted attempt's files."""
+    from . import driver
+    rank, world = rank_world()
+    k = hf.attempts + rank
+    mine = {}
+    if k < args.max_attempts_per_task:
+        twin = decayed_copy(hf, args, manager, rank)
+        driver.set_random(1000 * int(args.task_counter) + k)
+        print(" => ATTEMPT {}/{} (speculative, rank {}): Hyperparams {}".format(k, args.max_attempts_per_task - 1, rank,
+                                                                                 twin.hyperparams))
+        shutil.rmtree(manager.heuristic_exp_dir, ignore_errors=True)
+        os.makedirs(manager.heuristic_exp_dir, exist_ok=True)
+        manager.method.hyperparams = twin.hyperparams
+        _, acc = manager.method.train(args, manager, twin.hyperparams)
+        mine[k] = acc
+    accs = gather_scalars(mine)
+    threshold = finetune_acc * args.inv_drop_margin
+    ok = sorted(kk for kk, a in accs.items() if a >= threshold)
+    last = args.max_attempts_per_task - 1
+    accepted = ok[0] if ok else (last if last in accs else None)      # the final attempt is kept whatever it scored
+    if accepted is not None:
+        src = accepted - hf.attempts
+        if rank != src:
+            shutil.rmtree(manager.heuristic_exp_dir, ignore_errors=True)
+        broadcast_files(manager.heuristic_exp_dir, src)
+    return accs, accepted

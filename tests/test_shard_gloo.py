@@ -1,7 +1,11 @@
-"""world_size-2 gloo test of the N>1 path: grid-node assignment, scalar all-gather, flat model
-broadcast, and that both ranks take the same best-LR decision as the sequential rule."""
+"""world_size-2 gloo tests of the N>1 path (clsurvey_amd.framework.shard + the driver's --shard mode): grid-node
+assignment, scalar all-gather, flat model / file broadcast, the same best-LR decision as the sequential rule with the
+winner's model arriving on every rank, speculative stability decay that ends in the sequential loop's state for a method
+with TWO hyper-parameters (one-at-a-time decay order, framework_train.py:168-216), and sharded evaluation."""
+import copy
 import os
 import sys
+from collections import OrderedDict
 
 import torch
 import torch.distributed as dist
@@ -10,56 +14,149 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+class _DS:
+    name = argname = test_results_dir = train_exp_results_dir = "fake"
+    task_count = 1
+
+    def get_taskname(self, i):
+        return str(i)
+
+
+_GRID_ACC = {1e-2: 0.3, 5e-3: 0.9, 1e-3: 0.7, 5e-4: 0.2, 1e-4: 0.1}
+
+
+class _GridMethod:
+    """Phase-1 stand-in: accuracy is a table of the LR; the 'model' it saves names the LR and the rank that trained it."""
+    name = eval_name = "finetuning"
+    hyperparams = {}
+
+    def __init__(self, rank):
+        self.rank, self.trained = rank, []
+
+    def grid_train(self, args, manager, lr):
+        self.trained.append(lr)
+        torch.save({"lr": lr, "rank": self.rank}, os.path.join(manager.gridsearch_exp_dir, "best_model.pth.tar"))
+        return None, _GRID_ACC[lr]
+
+
+class _DecayMethod:
+    """Phase-2 stand-in with two hyper-parameters: accuracy rises as they shrink; the saved 'model' is the pair used."""
+    name = eval_name = "twoparam"
+
+    def __init__(self):
+        self.hyperparams = OrderedDict([("a", 8.0), ("b", 4.0)])
+        self.calls = []
+
+    def train(self, args, manager, hp):
+        self.calls.append(dict(hp))
+        os.makedirs(manager.heuristic_exp_dir, exist_ok=True)
+        torch.save(dict(hp), os.path.join(manager.heuristic_exp_dir, "best_model.pth.tar"))
+        return None, 1.0 / (1.0 + hp["a"] * hp["b"])
+
+
+def _args(**kw):
+    class A:
+        task_counter = 1
+        lrs = [1e-2, 5e-3, 1e-3, 5e-4, 1e-4]
+        finetune_iterations = 1
+        decaying_factor = 0.5
+        max_attempts_per_task = 10
+        inv_drop_margin = 0.8
+    a = A()
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
 def _worker(rank, world, port, tmp):
     sys.path.insert(0, ROOT)
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     from clsurvey_amd.framework import driver, shard
+    assert shard.init_from_env("gloo") == (rank, world)
     # --- collectives
     got = shard.gather_scalars({rank: 0.1 * (rank + 1), rank + 2: 0.5 + rank})
     assert got == {0: 0.1, 2: 0.5, 1: 0.2, 3: 1.5}, got
     torch.manual_seed(rank)
     m = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))
-    ref = [p.detach().clone() for p in m.parameters()]
     shard.broadcast_model(m, src=0)
     torch.manual_seed(0)
     m0 = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))
-    for p, q in zip(m.parameters(), m0.parameters()):
-        assert torch.equal(p, q)
-    if rank == 1:
-        assert not all(torch.equal(a, b) for a, b in zip(ref, m0.parameters()))
+    assert all(torch.equal(p, q) for p, q in zip(m.parameters(), m0.parameters()))
+    assert shard.broadcast_object({"from": rank}, src=1) == {"from": 1}
+    assert shard.broadcast_bytes(b"x" * (3 + rank), src=1) == b"xxxx"
+    assert shard.fill_factor(7, 8) == 7 / 8 and shard.fill_factor(7, 2) == 7 / 8 and shard.fill_factor(5, 1) == 1.0
 
-    # --- sharded grid == sequential decision
-    class DS:
-        name = argname = test_results_dir = train_exp_results_dir = "fake"
-        task_count = 1
-
-        def get_taskname(self, i):
-            return str(i)
-
-    trained = []
-
-    class M:
-        name = eval_name = "finetuning"
-        hyperparams = {}
-
-        def grid_train(self, args, manager, lr):
-            trained.append(lr)
-            return None, {1e-2: 0.3, 5e-3: 0.9, 1e-3: 0.7, 5e-4: 0.2, 1e-4: 0.1}[lr]
-
-    class Args:
-        task_counter = 1
-        lrs = [1e-2, 5e-3, 1e-3, 5e-4, 1e-4]
-        finetune_iterations = 1
-
-    mgr = driver.Manager(DS(), M(), "prev", os.path.join(tmp, "exp%d" % rank), None)
-    args = Args()
-    factory = shard.sharded_grid_factory()
-    mgr.ft_parent_exp_dir = os.path.join(mgr.parent_exp_dir, "task_1", "FT_LR_GRIDSEARCH")
-    best_lr, best_acc = driver.lr_grid_single_task(args, mgr, "keep_none", train_node=factory(args, mgr))
+    # --- sharded grid == sequential decision; the winner's file reaches the rank that did not train it
+    meth = _GridMethod(rank)
+    mgr = driver.Manager(_DS(), meth, "prev", os.path.join(tmp, "rank%d" % rank, "exp_lr=[0.01, 0.005]"), None)   # brackets as in real runs
+    args = _args()
+    best_lr, best_acc = driver.lr_grid_single_task(args, mgr, "all", train_node=shard.sharded_grid_factory()(args, mgr))
     assert (best_lr, best_acc) == (5e-3, 0.9)
-    assert trained == ([1e-2, 1e-3, 1e-4] if rank == 0 else [5e-3, 5e-4]), trained
+    assert meth.trained == ([1e-2, 1e-3, 1e-4] if rank == 0 else [5e-3, 5e-4]), meth.trained
+    assert mgr.grid_fill_factor == 5 / 6
+    won = torch.load(os.path.join(mgr.best_exp_grid_node_dirname, "best_model.pth.tar"), weights_only=False)
+    assert won == {"lr": 5e-3, "rank": 1}, won              # trained on rank 1, present in BOTH trees
+    assert mgr.best_exp_grid_node_dirname.startswith(os.path.join(tmp, "rank%d" % rank))
+
+    # --- speculative phase 2 with two hyper-parameters == the sequential loop's outcome
+    def phase2(speculative, sub):
+        meth2 = _DecayMethod()
+        mg = driver.Manager(_DS(), meth2, "prev", os.path.join(tmp, "rank%d" % rank, sub), None)
+        mg.speculative = speculative
+        hf = driver.HyperparameterFramework(meth2)
+        a2 = _args()
+        hf.stabilityDecay(a2, mg, 1e-3, finetune_acc=0.25)          # threshold 0.2 <=> a * b <= 4
+        model = torch.load(os.path.join(mg.heuristic_exp_dir, "best_model.pth.tar"), weights_only=False)
+        saved = torch.load(os.path.join(mg.heuristic_exp_dir, "hyperparams.pth.tar"), weights_only=False)
+        assert os.path.exists(mg.get_success_token_path(mg.heuristic_exp_dir))
+        return hf, meth2, model, saved
+
+    seq_hf, seq_m, seq_model, seq_saved = phase2(False, "seq")
+    spec_hf, spec_m, spec_model, spec_saved = phase2(True, "spec")
+    # sequential reference: (8,4) (4,4) (8,2) (4,2) (2,4)->no: one-at-a-time = a, b, then both
+    assert [c for c in seq_m.calls][:3] == [{"a": 8.0, "b": 4.0}, {"a": 4.0, "b": 4.0}, {"a": 8.0, "b": 2.0}]
+    assert dict(spec_hf.hyperparams) == dict(seq_hf.hyperparams) and spec_hf.attempts == seq_hf.attempts
+    assert spec_hf.hyperparam_idx == seq_hf.hyperparam_idx
+    assert dict(spec_hf.hyperparams_backup) == dict(seq_hf.hyperparams_backup)
+    assert spec_hf.trace == seq_hf.trace
+    assert spec_model == seq_model == dict(seq_hf.hyperparams)      # the accepted attempt's model, on every rank
+    assert spec_saved["val_acc"] == seq_saved["val_acc"] and spec_saved["state"]["attempts"] == seq_saved["state"]["attempts"]
+    # each rank ran only its own attempts: attempt r, r + 2, ...
+    assert len(spec_m.calls) <= (len(seq_m.calls) + 1) // 2 + 1
+    assert spec_m.calls[0] == ({"a": 8.0, "b": 4.0} if rank == 0 else {"a": 4.0, "b": 4.0})
+
+    # --- never accepted: the last attempt is kept, state as after max_attempts failures
+    def phase2_exhausted(speculative, sub):
+        meth3 = _DecayMethod()
+        mg = driver.Manager(_DS(), meth3, "prev", os.path.join(tmp, "rank%d" % rank, sub), None)
+        mg.speculative = speculative
+        hf = driver.HyperparameterFramework(meth3)
+        hf.stabilityDecay(_args(max_attempts_per_task=3), mg, 1e-3, finetune_acc=10.0)
+        return hf, torch.load(os.path.join(mg.heuristic_exp_dir, "best_model.pth.tar"), weights_only=False)
+    s_hf, s_model = phase2_exhausted(False, "seq_x")
+    p_hf, p_model = phase2_exhausted(True, "spec_x")
+    assert p_hf.attempts == s_hf.attempts == 3 and dict(p_hf.hyperparams) == dict(s_hf.hyperparams)
+    assert p_hf.trace == s_hf.trace and p_model == s_model
+
+    # --- sharded evaluation: pairs split over the ranks, same table everywhere
+    class EvalMethod:
+        name = eval_name = "evalfake"
+
+        def __init__(self):
+            self.seen = []
+
+        def inference_eval(self, a, manager):
+            self.seen.append((a.eval_dset_idx, a.trained_model_idx))
+            return 100.0 - 10 * a.eval_dset_idx - a.trained_model_idx
+
+    em = EvalMethod()
+    mg = driver.Manager(_DS(), em, "prev", os.path.join(tmp, "rank%d" % rank, "ev"), None)
+    mg.speculative = True
+    ea = _args(test_starting_task_count=1, test_max_task_count=3, out_path=os.path.join(tmp, "rank%d" % rank, "ev_out"))
+    res = driver.eval_all_models_all_tasks(ea, mg, ["d0", "d1", "d2"], ["m0", "m1", "m2"])
+    assert res[0]["seq_res"][0] == [100.0, 99.0, 98.0] and res[0]["seq_forgetting"][0] == [1.0, 2.0]
+    assert res[1]["seq_res"][1] == [89.0, 88.0] and res[2]["seq_res"][2] == [78.0]
+    assert len(em.seen) == 3 and set(em.seen) == {p for n, p in enumerate([(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]) if n % 2 == rank}
     dist.barrier()
     dist.destroy_process_group()
 

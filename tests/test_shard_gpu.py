@@ -1,0 +1,50 @@
+"""The driver's --shard mode end to end on the GPU: two ranks (RCCL when the box has two GPUs, otherwise both ranks on
+cuda:0 with gloo carrying the metrics / model files) run the SI first-task dump and a 2-task EWC sequence with --test.
+Both ranks must end with the same decisions, the same saved models (bitwise) and the same result tables, each in its
+own results tree."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, tmp, ndev):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank % ndev), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank % ndev)
+    from clsurvey_amd.framework import driver, shard
+    from clsurvey_amd.methods import method as M
+    assert shard.init_from_env("nccl" if ndev >= world else "gloo") == (rank, world)
+    common = ["small_VGG9_cl_128_128", "--lr_grid", "1e-2,3e-3,1e-3", "--num_epochs", "6", "--batch_size", "40",
+              "--saving_freq", "100", "--results_root", tmp, "--synthetic", "2,4,160,40,40,32", "--shard",
+              "--device", "cuda:%d" % (rank % ndev)]
+    driver.main(common + ["--method_name", "SI", "--runmode", "first_task_basemodel_dump"], method=M.parse("SI"))
+    out = driver.main(common + ["--method_name", "EWC", "--test", "--drop_margin", "0.05"], method=M.parse("EWC"))
+    mgr = out["manager"]
+    assert mgr.previous_task_model_path.startswith(os.path.join(tmp, "rank%d" % rank))
+    assert 0 < mgr.grid_fill_factor <= 1.0
+    model = torch.load(out["model_paths"][-1], weights_only=False)
+    digest = [float(p.detach().double().sum().cpu()) for p in model.parameters()]
+    omega = [float(model.reg_params[p]["omega"].double().sum().cpu()) for p in model.parameters() if p in model.reg_params]
+    mine = dict(results=out["results"], grid=mgr.grid_trace, trace=out["frameworks"][-1].trace,
+                attempts=out["frameworks"][-1].attempts, digest=digest, omega=omega)
+    other = shard.broadcast_object(mine, src=0)
+    assert other["grid"] == mine["grid"] and other["trace"] == mine["trace"] and other["attempts"] == mine["attempts"]
+    assert other["digest"] == mine["digest"] and other["omega"] == mine["omega"]
+    assert other["results"] == mine["results"]
+    assert sorted(mine["results"]) == [0, 1] and len(mine["results"][0]["seq_res"][0]) == 2
+    assert len(mine["grid"]) == 3 and len(mine["trace"]) >= 1
+    shard.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_driver_shard_two_ranks(tmp_path):
+    ndev = torch.cuda.device_count()
+    port = 29500 + (os.getpid() * 7) % 2000
+    mp.spawn(_worker, args=(2, port, str(tmp_path), ndev), nprocs=2, join=True)
