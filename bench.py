@@ -15,9 +15,19 @@ Prints ONE JSON line (rank 0).  Extra objects:
   cpu_baseline  — the CPU oracle (torch-CPU restatement of the reference path, kind "port")
                   timed on this box's host cores on a bounded sample (rank 0, N=1 only)
 
-Multi-GPU (`--gpus N` under torch.distributed.run): the Continual Hyperparameter Framework's
-grid nodes are independent trainings (framework/lr_grid_train.py:51), so every rank runs its
-own replica of the workload; no data-path collective; value = all ranks' images / max time.
+  configs       — the other BASELINE.json configs, each a short measured loop of ITS hot path on this GPU
+                  (MAS importance + SI step on base_VGG9_cl_512_512, PackNet batch + HAT step on wide_VGG9 at 64x64 and
+                  224x224, GEM observe on AlexNet 224x224 at 1 / 5 / 9 tasks in memory): ms per step, images/s, TFLOP/s
+  sweep         — BASELINE.json's second metric on a BOUNDED sweep, run twice with the same task files, LR grid,
+                  epoch cap and decay rule: through the build's driver on the GPU and through the same driver with
+                  the CPU oracle's EWC method on the host cores (oracle/sweep_ref.py); wall-clock of both, measured
+
+Multi-GPU (`--gpus N` under torch.distributed.run): the phase-1 LR grid of the Continual Hyperparameter Framework is
+N independent trainings from one start model (framework/lr_grid_train.py:51-151).  Rank r runs grid node r (LR =
+lr_grid[r % 5], iteration r // 5) for the K timed steps; the timed region also holds what the sharded grid exchanges
+over RCCL: the broadcast of the start model's parameter arena before the steps, the all_gather of the nodes' metrics
+and the broadcast of the winner's arena after them.  No collective on the per-batch path; value = all ranks' images /
+max time; `grid.fill_factor` = busy fraction of the GPUs for the reference's default 5-LR single-iteration grid.
 """
 import argparse
 import json
@@ -63,6 +73,11 @@ def algorithmic_flops_per_image(cfg, fc, ncls, hw):
     return fwd, 3 * fwd - first
 
 
+def shard_fill(n_nodes, world):
+    from clsurvey_amd.framework.shard import fill_factor
+    return fill_factor(n_nodes, world)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,6 +87,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=14)      # ~12 s of host work at ~0.85 s per step
     ap.add_argument("--kernel-iters", type=int, default=20)
+    ap.add_argument("--config-steps", type=int, default=8, help="timed steps per entry of the `configs` object")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` object (BASELINE configs 3-5)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the bounded GPU / CPU sweep pair")
     return ap.parse_args()
 
 
@@ -133,13 +151,15 @@ def time_kernels(eng, x, N, iters):
                              instance=conv_instance(C, H, W, N, K, 0, False), alg_bytes=4.0 * N * H * W * (C + K)))
         if C == 3 and pool:
             dyp = torch.randn_like(yp)
-            t_w = timed(lambda: ops.conv3x3_bwd_weight_unpool(xin, dyp, idx))
+            # the slab kernel alone, as the plan executor launches it (the slabs of all layers are reduced by ONE
+            # wgrad_reduce_multi launch at the end of backward: its row is in profiles/*kernel_stats.csv)
+            t_w = timed(lambda: ops.conv3x3_bwd_weight_slabs(xin, dyp, idx))
             rows.append(dict(kernel="conv3x3_bwd_weight_unpool", layer=layer, flops=fl, sec=t_w,
                              instance="conv3x3_wgrad_smallc_kernel", alg_bytes=4.0 * N * H * W * (C + K / 4.0)))
         else:
-            t_w = timed(lambda: ops.conv3x3_bwd_weight(xin, dy))
+            t_w = timed(lambda: ops.conv3x3_bwd_weight_slabs(xin, dy))
             rows.append(dict(kernel="conv3x3_bwd_weight", layer=layer, flops=fl, sec=t_w,
-                             instance="conv3x3_wgrad_kernel (+ fixed-order reduce)", alg_bytes=4.0 * N * H * W * (C + K)))
+                             instance="conv3x3_wgrad_kernel (slabs; reduction deferred)", alg_bytes=4.0 * N * H * W * (C + K)))
         if C > 3:
             t_d = timed(lambda: ops.conv3x3_bwd_data(dy, m.weight.data, xin))
             rows.append(dict(kernel="conv3x3_bwd_data", layer=layer, flops=fl, sec=t_d,
@@ -160,6 +180,207 @@ def measured_traffic(kernel, layer, N):
         return None
     e = t.get("%s %s N=%d" % (kernel, layer, N))
     return None if e is None else float(e["hbm_bytes_per_launch"])
+
+
+CFGS = {"small_VGG9": SMALL, "base_VGG9": [64, "M", 64, "M", 128, 128, "M", 256, 256, "M"],
+        "wide_VGG9": [64, "M", 128, "M", 256, 256, "M", 512, 512, "M"]}
+
+
+def _timed_loop(fn, steps, warm=2):
+    """ms per call: `warm` untimed calls, then `steps` calls between two synchronisations."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def module_flops_per_image(model, hw):
+    """2*MAC of every Conv2d / Linear of a features -> classifier net at hw x hw inputs (pool / stride geometry followed)."""
+    fwd, first, h = 0.0, None, hw
+    for m in model.features.children():
+        if isinstance(m, torch.nn.Conv2d):
+            h = (h + 2 * m.padding[0] - m.kernel_size[0]) // m.stride[0] + 1
+            f = 2.0 * m.kernel_size[0] * m.kernel_size[1] * m.in_channels * m.out_channels * h * h
+            fwd += f
+            first = f if first is None else first
+        elif isinstance(m, torch.nn.MaxPool2d):
+            k = m.kernel_size if isinstance(m.kernel_size, int) else m.kernel_size[0]
+            st = m.stride if isinstance(m.stride, int) else m.stride[0]
+            h = (h - k) // st + 1
+    for m in model.classifier.children():
+        if isinstance(m, torch.nn.Linear):
+            fwd += 2.0 * m.in_features * m.out_features
+    return fwd, 3 * fwd - first
+
+
+def extra_configs(dev, N, steps):
+    """BASELINE.json configs 3-5 on this GPU: a short loop of each config's own hot path (inputs resident in HBM).
+    TFLOP/s = algorithmic FLOPs of the step (train / importance pass = 3 x forward - first-layer backward-data) / time."""
+    from clsurvey_amd import models, net, ops
+    from clsurvey_amd.methods import hat as H
+    from clsurvey_amd.methods import packnet as PK
+    from clsurvey_amd.methods.gem import GemNet, extend_head
+    out = {}
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+
+    def entry(ms, images, flops, what):
+        return {"what": what, "ms_per_step": ms, "images_per_s": images / ms * 1e3, "tflops": flops / ms / 1e9,
+                "frac_of_f32_mfma_peak": flops / ms / 1e9 / PEAK_F32_MFMA_TFLOPS}
+
+    # ---- config 3: MAS importance pass + SI step, base_VGG9_cl_512_512, 3x64x64, batch N
+    x = torch.randn((N, 3, 64, 64), generator=g, device=dev)
+    y = torch.randint(0, 20, (N,), generator=g, device=dev)
+    m = models.parse_model_name("base_VGG9_cl_512_512", (64, 64), 20)
+    eng = net.NetEngine(m, N, (3, 64, 64), dev)
+    A = eng.arena
+    _, step_fl = algorithmic_flops_per_image(CFGS["base_VGG9"], (512, 512), 20, 64)
+    omega, init_val, w, buf = A.buffer("omega"), A.buffer("init_val"), A.buffer("w"), A.buffer("buf")
+    init_val.copy_(A.theta)
+    it = [0]
+
+    def mas():
+        eng.loss_step(x, None, "mse_sum_zero", True)                      # train_MAS.py:556-560
+        ops.mas_accum(omega, A.grad, it[0], N)                             # :167-173
+        it[0] += 1
+
+    def si():
+        eng.loss_step(x, y, "ce_mean", True)
+        ops.si_step(A.theta, A.grad, omega, init_val, w, buf, 400.0, 1e-3, 0.9, 0.0, it[0] == 0)    # train_SI.py:28-126
+        it[0] += 1
+    out["mas_importance_base_vgg9"] = entry(_timed_loop(mas, steps), N, N * step_fl,
+                                            "MAS compute_importance_l2 batch (fwd + sum(out^2) + bwd + Omega running mean), base_VGG9_cl_512_512 64x64 N=%d" % N)
+    it[0] = 0
+    out["si_step_base_vgg9"] = entry(_timed_loop(si, steps), N, N * step_fl,
+                                     "SI training batch (fwd + CE + bwd + Elastic_SGD.step with path integral), base_VGG9_cl_512_512 64x64 N=%d" % N)
+    del eng, A, omega, init_val, w, buf, m
+
+    # ---- config 5: PackNet batch + HAT step, wide_VGG9_cl_512_512 at 64x64 (N) and 224x224 (iNaturalist geometry, N/4)
+    for hw, nb in ((64, N), (224, max(N // 4, 8))):
+        x = torch.randn((nb, 3, hw, hw), generator=g, device=dev)
+        y = torch.randint(0, 20, (nb,), generator=g, device=dev)
+        st = max(2, steps // (4 if hw == 224 else 1))
+        _, step_fl = algorithmic_flops_per_image(CFGS["wide_VGG9"], (512, 512), 20, hw)
+        m = models.parse_model_name("wide_VGG9_cl_512_512", (hw, hw), 20)
+        eng = net.NetEngine(m, nb, (3, hw, hw), dev)
+        A = eng.arena
+        buf = torch.zeros_like(A.theta)
+        mask = torch.randint(1, 3, (A.numel,), generator=g, device=dev, dtype=torch.int64).to(torch.uint8)   # owners 1 / 2
+        first = [True]
+
+        def packnet():
+            eng.loss_step(x, y, "ce_mean", True)
+            PK.fused_batch_tail(A.theta, A.grad, buf, mask, 2, 1e-3, 0.9, 0.0, first[0])      # main.py:187-193
+            first[0] = False
+        out["packnet_batch_wide_vgg9_%d" % hw] = entry(
+            _timed_loop(packnet, st), nb, nb * step_fl,
+            "PackNet do_batch (fwd + CE + bwd + foreign-grad zero / PacknetSGD / pruned zero fused), wide_VGG9_cl_512_512 %dx%d N=%d" % (hw, hw, nb))
+        del eng, A, buf, mask
+        hn = H.HatNet(m, (3, hw, hw), [(0, 20), (1, 20)]).to(dev)
+        hat = H.HatEngine(hn, nb, (3, hw, hw), dev)
+        mask_pre, mask_back = H.init_masks(hat, 1, 800.0)
+        opt = H.HAT_SGD(hn.parameters(), lr=1e-3, momentum=0.9, weight_decay=0.0)
+        count = float(sum(float((1 - mp).sum().item()) for mp in mask_pre))
+
+        def hat_step():
+            hat.step(1, x, y, 400.0, mask_pre, 2.5, count, backward=True)          # hat.py:200-249
+            opt.step(hn, mask_back, 1, 400.0, 50, 800.0, 10000)
+            H.clamp_embeddings(hn, 6.0)
+        out["hat_step_wide_vgg9_%d" % hw] = entry(
+            _timed_loop(hat_step, st), nb, nb * step_fl,
+            "HAT training batch of task 2 (gates, gated fwd + CE + reg, bwd, HAT_SGD, clamp), wide_VGG9_cl_512_512 %dx%d N=%d" % (hw, hw, nb))
+        del hat, hn, opt, m
+
+    # ---- config 4: GEM observe on AlexNet at 224x224 with 1 / 5 / 9 tasks in memory (mem_per_task 1024, method.py:286)
+    nb, n_tasks, nc, mem = N, 10, 20, 1024
+    x = torch.randn((nb, 3, 224, 224), generator=g, device=dev)
+    m = extend_head(models.AlexNet(num_classes=nc), n_tasks * nc)
+    fwd_fl, step_fl = module_flops_per_image(m, 224)
+    gem = GemNet(m, n_tasks * nc, n_tasks, [nc] * n_tasks, mem, 1e-3, 0.0, 1.0, batch_size=nb, in_shape=(3, 224, 224), device=dev)
+    for past in (1, 5, 9):
+        # fill the ring buffers of tasks 0..past-1 with synthetic exemplars, then observe batches of task `past`
+        gem.observed_tasks, gem.old_task, gem.mem_cnt = list(range(past)), past - 1, 0
+        for t in range(past):
+            gem.memory_x[t].normal_(generator=g)
+            gem.memory_labels[t].random_(t * nc, (t + 1) * nc, generator=g)
+        y = torch.randint(past * nc, (past + 1) * nc, (nb,), generator=g, device=dev)
+        ms = _timed_loop(lambda: gem.observe(x, past, y), 2, warm=1)
+        imgs = nb + past * mem
+        out["gem_observe_alexnet_%dtasks" % past] = entry(
+            ms, imgs, imgs * step_fl,
+            "GEM observe (%d memory passes of %d exemplars + the batch of %d, Gram, QP, projection, SGD), AlexNet 224x224" % (past, mem, nb))
+    out["alexnet_mflop_per_image_fwd"] = fwd_fl / 1e6
+    return out
+
+
+def bounded_sweep(dev_index, cpu_threads, sizes=(1600, 400, 400), epochs=2, lr_grid="1e-2,1e-3"):
+    """BASELINE.json's 'full-sweep wall-clock' on a bounded 2-task EWC sweep at Tiny-ImageNet image shape (3x64x64, 20
+    classes per task): what framework/main.py runs for `small_VGG9_cl_128_128 --method_name EWC --test` (phase-1 LR grid,
+    stability decay with the Fisher pass, evaluation of every model on every task) starting from the shared first-task
+    model — once through the build's driver on the GPU, once through the SAME driver with the CPU oracle's EWC method
+    (oracle/sweep_ref.py) on the host cores.  Task files, grid, epoch cap, batch size and decay rule are identical; the
+    first-task model is trained once on the GPU outside both timed regions and given to both."""
+    import contextlib
+    import io
+    import shutil
+    import tempfile
+    from clsurvey_amd.framework import driver
+    from clsurvey_amd.methods import method as M
+    root = tempfile.mkdtemp(prefix="clhip_sweep_")
+    spec = "2,20,%d,%d,%d,64" % sizes
+    common = ["small_VGG9_cl_128_128", "--lr_grid", lr_grid, "--num_epochs", str(epochs), "--batch_size", "200",
+              "--saving_freq", "1000", "--synthetic", spec, "--device", "cuda:%d" % dev_index]
+    res = {"what": "2-task EWC sweep, small_VGG9_cl_128_128, %d/%d/%d images of 3x64x64 per task, LR grid {%s}, %d-epoch cap, "
+                   "batch 200, --test" % (sizes + (lr_grid, epochs))}
+    quiet = io.StringIO()
+    try:
+        groot = os.path.join(root, "gpu")
+        with contextlib.redirect_stdout(quiet):
+            driver.main(common + ["--results_root", groot, "--method_name", "SI", "--runmode", "first_task_basemodel_dump"],
+                        method=M.parse("SI"))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = driver.main(common + ["--results_root", groot, "--method_name", "EWC", "--test"], method=M.parse("EWC"))
+            torch.cuda.synchronize()
+            res["gpu_s"] = time.perf_counter() - t0
+        res["gpu_attempts"] = out["frameworks"][-1].attempts + 1
+        res["gpu_task_accuracies"] = [out["results"][i]["seq_res"][i][-1] for i in sorted(out["results"])]
+        if cpu_threads:
+            from oracle import sweep_ref
+            croot = os.path.join(root, "cpu")
+            for sub in ("data", "models", os.path.join("train", "synthetic_tiny_imagenet", "SI")):
+                shutil.copytree(os.path.join(groot, sub), os.path.join(croot, sub))
+            torch.set_num_threads(cpu_threads)      # the thread count that won cpu_baseline's probe on this host
+            meth = sweep_ref.OracleEWC("small_VGG9")
+            with contextlib.redirect_stdout(quiet):
+                t0 = time.perf_counter()
+                cout = driver.main(common + ["--results_root", croot, "--method_name", "EWC", "--test"], method=meth)
+                res["cpu_s"] = time.perf_counter() - t0
+            res["cpu_attempts"] = cout["frameworks"][-1].attempts + 1
+            res["cpu_image_passes"] = dict(meth.image_passes)
+            res["cpu_task_accuracies"] = [cout["results"][i]["seq_res"][i][-1] for i in sorted(cout["results"])]
+            res["cpu_threads"] = torch.get_num_threads()
+            res["gpu_over_cpu_wall_clock"] = res["cpu_s"] / res["gpu_s"]
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+    return res
+
+
+def host_cpu():
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"logical_cores": os.cpu_count() or 1, "model": model}
 
 
 def cpu_baseline(batch, steps):
@@ -202,9 +423,11 @@ def cpu_baseline(batch, steps):
     for _ in range(steps):
         step(False)
     dt = time.perf_counter() - t0
-    return dict(value=2 * batch * steps / dt, unit="images/s", cores=cores, kind="port",
-                sample="%d steps (EWC train batch + Fisher batch, N=%d) of the torch-CPU oracle, %d threads, %.1f s"
-                       % (steps, batch, cores, dt))
+    cpu = host_cpu()
+    return dict(value=2 * batch * steps / dt, unit="images/s", cores=cores, kind="port", host_logical_cores=cpu["logical_cores"],
+                host_cpu_model=cpu["model"],
+                sample="%d steps (EWC train batch + Fisher batch, N=%d) of the torch-CPU oracle, %d threads (fastest of "
+                       "16 / 32 / 64 on this host's %d logical cores), %.1f s" % (steps, batch, cores, cpu["logical_cores"], dt))
 
 
 def main():
@@ -214,13 +437,27 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    local_rank %= torch.cuda.device_count()          # (dry runs of the N > 1 path on a 1-GPU box: CLHIP_BENCH_BACKEND=gloo)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    backend = os.environ.get("CLHIP_BENCH_BACKEND", "nccl")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+
+    def bcast(t, src):
+        """RCCL broadcast of a device tensor (gloo dry runs stage through the host)."""
+        if backend == "nccl":
+            dist.broadcast(t, src=src)
+        else:
+            h = t.cpu()
+            dist.broadcast(h, src=src)
+            t.copy_(h)
 
     from clsurvey_amd import models, net, ops
     torch.manual_seed(7 + rank)
@@ -243,12 +480,16 @@ def main():
     perm = torch.randperm(8000, device=dev)
     nb = 8000 // N
 
+    # N > 1: rank r is grid node r of the phase-1 LR grid (lr_grid_train.py:51-151) — its own LR, same start model
+    LR_GRID = [1e-2, 5e-3, 1e-3, 5e-4, 1e-4]                                # framework/main.py:61
+    lr = LR_GRID[rank % len(LR_GRID)] if world > 1 else 1e-3
+
     def step(i, first=False):
         idx = perm[(i % nb) * N:(i % nb + 1) * N]
         x = data_x.index_select(0, idx)
         y = data_y.index_select(0, idx)
         eng.loss_step(x, y, "ce_mean", True, stats)                       # train_EWC.py:181-187
-        ops.reg_sgd_step(A.theta, A.grad, omega, init_val, buf, 400.0, 1e-3, 0.9, 0.0, first)   # :189
+        ops.reg_sgd_step(A.theta, A.grad, omega, init_val, buf, 400.0, lr, 0.9, 0.0, first)     # :189
         j = (i % nb) * N
         eng.loss_step(data_x[j:j + N], data_y[j:j + N], "ce_sum", True)   # main_EWC.py:147-149
         ops.fisher_accum(fisher, A.grad, 8000.0)                          # :155
@@ -261,15 +502,33 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    grid = None
+    if dist:
+        bcast(A.theta, 0)                              # every node starts from the previous task's model (one RCCL broadcast)
+        stats.zero_()
     for i in range(args.steps):
         step(i)
+    if dist:
+        # metrics of the N nodes to every rank, the winner's parameter arena back to every rank
+        mine = torch.stack([stats[1] / max(float(args.steps * N), 1.0), torch.tensor(float(rank), dtype=torch.float64, device=dev)])
+        if backend != "nccl":
+            mine = mine.cpu()
+        table = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(table, mine)
+        winner = int(max(table, key=lambda t: (float(t[0]), -float(t[1])))[1])
+        bcast(A.theta, winner)
+        grid = {"nodes": world, "lr_grid": LR_GRID, "iterations": -(-world // len(LR_GRID)), "winner_rank": winner,
+                "winner_lr": LR_GRID[winner % len(LR_GRID)],
+                "collectives_in_timed_region": ["broadcast(start arena %.1f MB)" % (A.numel * 4 / 1e6),
+                                                "all_gather(node metrics)", "broadcast(winner arena)"],
+                "fill_factor": shard_fill(len(LR_GRID), world)}
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if not torch.isfinite(A.theta).all():
@@ -285,11 +544,15 @@ def main():
         "config": {"workload": "EWC small_VGG9_cl_128_128, Tiny-ImageNet shapes (3x64x64, 20 classes), "
                                "batch 200: train step + Fisher step (BASELINE configs[1])",
                    "images_per_step": 2 * N, "batch": N,
-                   "parallelism": "%d independent grid-node replica(s)" % world,
+                   "parallelism": ("1 GPU" if world == 1 else
+                                   "%d grid nodes of the phase-1 LR grid, one per GPU (RCCL: start-model broadcast, metric "
+                                   "all_gather, winner broadcast)" % world),
                    "algorithmic_gflop_per_step": 2 * N * step_fl / 1e9,
                    "step_tflops": 2 * N * step_fl * args.steps / dt / 1e12,
                    "step_frac_of_f32_mfma_peak": 2 * N * step_fl * args.steps / dt / 1e12 / PEAK_F32_MFMA_TFLOPS},
     }
+    if grid is not None:
+        out["grid"] = grid
     if rank == 0:
         rows = time_kernels(eng, data_x[:N].contiguous(), N, args.kernel_iters)
         agg = {}
@@ -309,9 +572,16 @@ def main():
                                           for k, v in agg.items()},
                            "per_layer": [{"kernel": r["kernel"], "layer": r["layer"], "instance": r["instance"],
                                           "us": r["sec"] * 1e6, "tflops": r["flops"] / r["sec"] / 1e12} for r in rows]}
+        if world == 1 and not args.no_configs:
+            del eng
+            torch.cuda.empty_cache()
+            out["configs"] = extra_configs(dev, N, args.config_steps)
+            torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, args.cpu_steps)
             out["config"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        if world == 1 and not args.no_sweep:
+            out["sweep"] = bounded_sweep(local_rank, cpu_threads=0 if args.no_cpu_baseline else out["cpu_baseline"]["cores"])
         print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()          # rank 0 was still timing kernels: tear the communicator down together

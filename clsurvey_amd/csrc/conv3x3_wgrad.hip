@@ -779,6 +779,26 @@ int clhip_conv3x3_bwd_weight_unpool(const float* x, const float* dy_pool, const 
     return bwd_weight_impl(x, dy_pool, idx_u8, dw, db, N, C, K, H, W, ws, ws_bytes, stream);
 }
 
+// The two halves of clhip_conv3x3_bwd_weight for callers that defer the reduction (the plan executor reduces the
+// slabs of all layers in one launch at the end of backward): slabs only, then the fixed-order reduction.
+int clhip_conv3x3_bwd_weight_slabs(const float* x, const float* dy, const uint8_t* idx_u8_or_null, int N, int C, int K, int H,
+                                   int W, void* ws, size_t ws_bytes, int* splits_out, void* stream) {
+    if (!splits_out || !ws) return CLHIP_EINVAL;
+    clhip_wgrad_job job;
+    const int rc = bwd_weight_impl(x, dy, idx_u8_or_null, static_cast<float*>(ws), nullptr, N, C, K, H, W, ws, ws_bytes, stream, &job);
+    if (rc == 0) *splits_out = job.splits;
+    return rc;
+}
+
+int clhip_conv3x3_bwd_weight_reduce(const void* ws, float* dw, float* db, int K, int C, int splits, void* stream) {
+    if (!ws || !dw || K <= 0 || C <= 0 || splits <= 0) return CLHIP_EINVAL;
+    const size_t slab = (size_t)9 * K * C + K;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((slab + RED_EL - 1) / RED_EL)), dim3(RED_THREADS), 0, as_stream(stream),
+                       static_cast<const float*>(ws), dw, db, K, C, splits);
+    CLHIP_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // extern "C"
 
 // Partial slabs only; the caller reduces several layers at once with clhip_internal_wgrad_reduce_multi (the slabs in

@@ -102,6 +102,29 @@ def conv3x3_bwd_weight(x, dy, need_bias=True):
     return dw, db
 
 
+def conv3x3_bwd_weight_slabs(x, dy, idx=None):
+    """First half of conv3x3_bwd_weight as the plan executor issues it: per-split partial sums into the 'wgrad' workspace.
+    Returns (workspace, splits) for conv3x3_bwd_weight_reduce."""
+    import ctypes
+    _chk(x, dy, idx)
+    N, C, H, W = x.shape
+    K = dy.shape[1]
+    L = _lib.lib()
+    ws = workspace(L.clhip_conv3x3_bwd_weight_ws(N, C, K, H, W), x.device, "wgrad")
+    splits = ctypes.c_int(0)
+    check(L.clhip_conv3x3_bwd_weight_slabs(_ptr(x), _ptr(dy), _ptr(idx), N, C, K, H, W, _ptr(ws), ws.numel(),
+                                           ctypes.byref(splits), _stream()), "clhip_conv3x3_bwd_weight_slabs")
+    return ws, splits.value
+
+
+def conv3x3_bwd_weight_reduce(ws, splits, K, C, need_bias=True):
+    dw = torch.empty((K, C, 3, 3), dtype=torch.float32, device=ws.device)
+    db = torch.empty((K,), dtype=torch.float32, device=ws.device) if need_bias else None
+    check(_lib.lib().clhip_conv3x3_bwd_weight_reduce(_ptr(ws), _ptr(dw), _ptr(db), K, C, int(splits), _stream()),
+          "clhip_conv3x3_bwd_weight_reduce")
+    return dw, db
+
+
 def _out_hw(H, W, R, S, stride, pad):
     return (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
 

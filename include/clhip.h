@@ -64,6 +64,14 @@ int clhip_conv3x3_bwd_weight(const float* x, const float* dy, float* dw, float* 
                              int N, int C, int K, int H, int W, void* ws, size_t ws_bytes,
                              void* stream);
 
+/* The same computation in two calls, for callers that defer the reduction (the plan executor reduces the slabs of
+ * every layer of a backward pass in ONE launch): `_slabs` writes the per-split partial sums into ws and reports their
+ * count, `_reduce` adds them in the fixed order of clhip_conv3x3_bwd_weight (bitwise the same dw / db).
+ * idx_u8_or_null != NULL: dy is the POOLED gradient (see clhip_conv3x3_bwd_weight_unpool).                */
+int clhip_conv3x3_bwd_weight_slabs(const float* x, const float* dy, const uint8_t* idx_u8_or_null, int N, int C, int K,
+                                   int H, int W, void* ws, size_t ws_bytes, int* splits_out, void* stream);
+int clhip_conv3x3_bwd_weight_reduce(const void* ws, float* dw, float* db, int K, int C, int splits, void* stream);
+
 /* Same from the gradient w.r.t. the POOLED output + argmax (fused max_pool2d backward). Implemented for the
  * first-layer kernel (C*9 <= 32); returns CLHIP_ENOTSUP otherwise (callers then un-pool with
  * clhip_maxpool2_bwd first).                                                                             */
