@@ -80,6 +80,7 @@ SIGNATURES = {
     "clhip_net_set_bn": (_i, [_p, _i, _p, _p, _f, _f]),
     "clhip_net_set_training": (_i, [_p, _i]),
     "clhip_net_layer_input": (_i, [_p, _i, _p, _p]),
+    "clhip_net_layer_pool_idx": (_i, [_p, _i, _p, _p]),
     "clhip_net_set_input_grad": (_i, [_p, _i, _p]),
     "clhip_sigmoid_fwd": (_i, [_p, _p, _z, _p]),
     "clhip_sigmoid_bwd": (_i, [_p, _p, _p, _z, _p]),

@@ -290,6 +290,16 @@ int clhip_net_layer_input(void* handle, int layer, size_t* ws_float_off, size_t*
     return 0;
 }
 
+int clhip_net_layer_pool_idx(void* handle, int layer, size_t* ws_byte_off, size_t* elems) {
+    NetPlan* p = static_cast<NetPlan*>(handle);
+    if (!p || layer < 0 || layer >= (int)p->layers.size() || !ws_byte_off || !elems) return CLHIP_EINVAL;
+    const LayerPlan& L = p->layers[layer];
+    if (L.type != 0 || !L.pool) return CLHIP_EINVAL;
+    *ws_byte_off = p->off_idx + L.idx_off;
+    *elems = L.pool_elems;
+    return 0;
+}
+
 int clhip_net_set_input_grad(void* handle, int layer, const float* extra) {
     NetPlan* p = static_cast<NetPlan*>(handle);
     if (!p || layer <= 0 || layer >= (int)p->layers.size()) return CLHIP_EINVAL;

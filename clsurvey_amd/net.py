@@ -268,6 +268,13 @@ class NetEngine:
         lo = off.value * 4
         return self.ws[lo:lo + n * elems.value * 4].view(torch.float32).view(n, elems.value)
 
+    def pool_idx(self, layer, n):
+        """[n][elems] uint8 view of the arg-max codes (window position r*k + c) the last forward stored for the
+        max-pooled conv layer `layer`."""
+        off, elems = C.c_size_t(), C.c_size_t()
+        check(_lib.lib().clhip_net_layer_pool_idx(self._h, int(layer), C.byref(off), C.byref(elems)), "clhip_net_layer_pool_idx")
+        return self.ws[off.value:off.value + n * elems.value].view(n, elems.value)
+
     def set_input_grad(self, layer, extra):
         """extra [N][in_elems] (or None) is added to the gradient w.r.t. layer_input(layer) in the following backward
         passes; if that activation is a ReLU output the caller masks extra with (activation > 0) first."""

@@ -266,6 +266,12 @@ int clhip_net_set_dropout(void* handle, int layer, const float* mask, long row_s
  * (nn.Module.train / eval). */
 int clhip_net_set_bn(void* handle, int layer, float* running_mean, float* running_var, float momentum, float eps);
 int clhip_net_set_training(void* handle, int training);
+/* Where the arg-max bytes of a max-pooled conv layer live after a forward: byte offset into ws and bytes per
+ * sample ([cout][oh][ow], window position r*k + c, first maximum wins).  With the saved activations
+ * (clhip_net_layer_input) this is every non-linear decision the backward pass will use — what a parity harness
+ * needs to judge gradients independently of ReLU / arg-max near-ties.  EINVAL for layers without a pool.   */
+int clhip_net_layer_pool_idx(void* handle, int layer, size_t* ws_byte_off, size_t* elems_per_sample);
+
 /* Side branches off a plan (EBLL's code layers on the flattened features, AlexNet_EBLL.py:110-117): the INPUT activation
  * of plan layer `layer` (> 0) lives at float offset *ws_float_off of the workspace after a forward (in_elems floats per
  * sample); `extra` ([N][in_elems], device, may be NULL = none) is added to the gradient w.r.t. that activation in the

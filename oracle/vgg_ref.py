@@ -98,3 +98,71 @@ def loss_and_grads(params, cfg, x, y, kind="ce_mean", need_dx=False):
     grads = list(outs[:len(ps)])
     dx = outs[len(ps)] if need_dx else None
     return logits.detach(), loss.detach(), grads, dx
+
+
+# ------------------------------------------------------------------------------------------------ decision-forced evaluation
+def _windows(z):
+    """[N,K,H,W] -> [N,K,H/2,W/2,4], window position r*2 + c (ATen's scan order inside a 2x2 window)."""
+    n, k, h, w = z.shape
+    return z.reshape(n, k, h // 2, 2, w // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, k, h // 2, w // 2, 4)
+
+
+def forward_forced(params, cfg, x, decisions):
+    """The same network with every non-linear DECISION taken from `decisions` instead of from the data: per conv block
+    {'mask': bool [N,K,H',W']} (ReLU on / off per output element) and, for a pooled block, {'idx': int64 [N,K,H/2,W/2]}
+    (which of the four window elements is passed on); per hidden Linear {'mask': bool [N,D]}.  Where the decisions are the
+    network's own this IS the network (ReLU(z) = z * [z > 0], max-pool = gather at the arg-max); with another
+    evaluation's decisions it is the piecewise-linear branch that evaluation computed — so two fp32 evaluation orders
+    that disagree on a near-tie can still be compared at rounding level.  Returns (logits, pre-activations)."""
+    i, b, pre = 0, 0, []
+    vs = list(cfg)
+    j = 0
+    while j < len(vs):
+        z = F.conv2d(x, params[i], params[i + 1], padding=1)
+        i += 2
+        d = decisions[b]
+        b += 1
+        pooled = j + 1 < len(vs) and vs[j + 1] == "M"
+        pre.append(z)
+        if pooled:
+            z = torch.gather(_windows(z), 4, d["idx"].unsqueeze(-1)).squeeze(-1)
+            j += 1
+        x = z * d["mask"].to(z.dtype)
+        j += 1
+    x = torch.flatten(x, 1)
+    nfc = (len(params) - i) // 2
+    for f in range(nfc):
+        x = F.linear(x, params[i], params[i + 1])
+        i += 2
+        if f < nfc - 1:
+            pre.append(x)
+            x = x * decisions[b]["mask"].to(x.dtype)
+            b += 1
+    return x, pre
+
+
+def loss_and_grads_forced(params, cfg, x, y, kind, decisions):
+    ps = [p.detach().clone().requires_grad_(True) for p in params]
+    logits, pre = forward_forced(ps, cfg, x, decisions)
+    loss = loss_fn(logits, y, kind)
+    grads = torch.autograd.grad(loss, ps)
+    return logits.detach(), loss.detach(), list(grads), [z.detach() for z in pre]
+
+
+def own_decisions(cfg, pre):
+    """The decisions the data itself implies for the pre-activations `pre` of forward_forced (first maximum wins)."""
+    out, b, j, vs = [], 0, 0, list(cfg)
+    while j < len(vs):
+        z = pre[b]
+        if j + 1 < len(vs) and vs[j + 1] == "M":
+            win = _windows(z)
+            idx = win.argmax(4)               # torch returns the first maximal index
+            out.append({"idx": idx, "mask": torch.gather(win, 4, idx.unsqueeze(-1)).squeeze(-1) > 0})
+            j += 1
+        else:
+            out.append({"mask": z > 0})
+        b += 1
+        j += 1
+    for z in pre[b:]:
+        out.append({"mask": z > 0})
+    return out

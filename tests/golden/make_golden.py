@@ -243,6 +243,28 @@ def g9():
                 count = 0 if imp else count + 1
             out["%s_c%d_improved" % (tag, case)] = improved
             out["%s_c%d_trace" % (tag, case)] = np.array(trace, dtype=np.float64)
+    # the reference's HyperparameterFramework.hyperparamDecay (framework_train.py:168-216): value of every
+    # hyper-parameter after each of 9 consecutive failed attempts, for methods with 1 / 2 / 3 hyper-parameters and for a
+    # method that brings its own decay_operator
+    import collections
+    import operator
+    import types
+    import framework.framework_train as FT
+    cases = {"one": ([("lambda", 400.0)], None), "two": ([("smax", 800.0), ("c", 2.5)], None),
+             "three": ([("a", 8.0), ("b", 4.0), ("c", 2.0)], None), "sub": ([("margin", 1.0), ("k", 3.0)], operator.sub)}
+    for tag, (hp, op) in cases.items():
+        method = types.SimpleNamespace(hyperparams=collections.OrderedDict(hp))
+        if op is not None:
+            method.decay_operator = op
+        hf = FT.HyperparameterFramework(method)
+        args = types.SimpleNamespace(decaying_factor=0.5)
+        manager = types.SimpleNamespace(method=method)
+        rows = [[float(v) for v in hf.hyperparams.values()]]
+        for _ in range(9):
+            hf.hyperparamDecay(args, manager)
+            rows.append([float(v) for v in hf.hyperparams.values()])
+        out["decay_%s" % tag] = np.array(rows, dtype=np.float64)
+        out["decay_%s_keys" % tag] = np.array([k for k, _ in hp])
     save("G9_schedules", **out)
 
 

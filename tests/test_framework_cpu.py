@@ -158,3 +158,91 @@ def test_task_dataset_cache_passthrough_on_cpu(tmp_path):
     torch.save(d, p)
     got = D.load_task_datasets(p)
     assert sorted(got) == ["test", "train", "val"] and torch.equal(got["train"].x, d["train"].x)
+
+
+# --------------------------------------------------------------------------- G9: the PRODUCT's schedules vs the reference's
+def test_product_set_lr_matches_reference_traces_g9():
+    """train_common.set_lr driven exactly as train_model drives it (count of epochs without a new best validation
+    accuracy) against the traces the reference's own set_lr produced (EWC/train_EWC.py:89-101 'gt', SI/train_SI.py:129-141
+    'ge'): LR used and continue flag per epoch."""
+    import numpy as np
+    from clsurvey_amd.methods import train_common as tc
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "G9_schedules.npz"), allow_pickle=True)
+    for tag, rule in (("ewc", "gt"), ("si", "ge")):
+        for case in range(3):
+            opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=0.01)
+            lr, count, trace = 0.01, 0, []
+            for ep, imp in enumerate(g["%s_c%d_improved" % (tag, case)]):
+                opt, lr, cont = tc.set_lr(opt, lr, count, rule)
+                trace.append((ep, lr, float(cont)))
+                assert opt.param_groups[0]["lr"] == lr or count != 5
+                if not cont:
+                    break
+                count = 0 if imp else count + 1
+            ref = g["%s_c%d_trace" % (tag, case)]
+            assert len(trace) == len(ref)
+            for a, b in zip(trace, ref):
+                assert a[0] == int(b[0]) and a[2] == b[2] and abs(a[1] - b[1]) <= 1e-12
+
+
+def test_product_hyperparam_decay_matches_reference_g9():
+    """driver.HyperparameterFramework.hyperparamDecay against the reference's framework_train.py:168-216 sequences for
+    1 / 2 / 3 hyper-parameters (one at a time, then all together from the updated restore values) and for a method with
+    its own decay_operator; shard.decayed_copy (speculative attempt k) must land on the same values without touching
+    the original."""
+    import collections
+    import operator
+    import types
+    import numpy as np
+    from clsurvey_amd.framework import driver, shard
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "G9_schedules.npz"), allow_pickle=True)
+    for tag, op in (("one", None), ("two", None), ("three", None), ("sub", operator.sub)):
+        ref = g["decay_%s" % tag]
+        keys = [str(k) for k in g["decay_%s_keys" % tag]]
+        method = types.SimpleNamespace(hyperparams=collections.OrderedDict(zip(keys, ref[0].tolist())))
+        if op is not None:
+            method.decay_operator = op
+        hf = driver.HyperparameterFramework(method)
+        args = types.SimpleNamespace(decaying_factor=0.5)
+        manager = types.SimpleNamespace(method=method)
+        for k in range(1, len(ref)):
+            twin = shard.decayed_copy(hf, args, manager, 1)
+            hf_before = (dict(hf.hyperparams), dict(hf.hyperparams_backup), hf.hyperparam_idx, hf.attempts)
+            assert [twin.hyperparams[key] for key in keys] == ref[k].tolist()
+            assert hf_before == (dict(hf.hyperparams), dict(hf.hyperparams_backup), hf.hyperparam_idx, hf.attempts)
+            hf.hyperparamDecay(args, manager)
+            assert [hf.hyperparams[key] for key in keys] == ref[k].tolist(), (tag, k)
+        hf0 = driver.HyperparameterFramework(types.SimpleNamespace(hyperparams=collections.OrderedDict(zip(keys, ref[0].tolist()))))
+        method0 = types.SimpleNamespace(hyperparams=hf0.hyperparams)
+        if op is not None:
+            method0.decay_operator = op
+        far = shard.decayed_copy(hf0, args, types.SimpleNamespace(method=method0), 7)
+        assert [far.hyperparams[key] for key in keys] == ref[7].tolist()
+
+
+def test_patience_plan_reference_sequences():
+    """PatiencePlan against a literal transcription of the two inline schedules it replaces (HAT/approaches/hat.py:150-166
+    with `patience <= 0`, hat_finetune.py:108-124 with `patience == 0`): same verdict and LR at every epoch."""
+    import numpy as np
+    from clsurvey_amd.methods.train_common import PatiencePlan
+    rs = np.random.RandomState(3)
+    for leq in (True, False):
+        for trial in range(20):
+            accs = np.round(rs.rand(60) * (0.5 + 0.5 * rs.rand()), 2)
+            plan = PatiencePlan(0.05, 6, 2, stop_at_or_below_zero=leq)
+            best, patience, lr = 0, 6, 0.05
+            for a in accs:
+                want = "hold"
+                if a > best:
+                    best, patience, want = a, 6, "best"
+                else:
+                    patience -= 1
+                    if patience == 6 // 2:
+                        lr /= 2
+                        want = "decay"
+                    elif (patience <= 0) if leq else (patience == 0):
+                        want = "stop"
+                got = plan.observe(a)
+                assert got == want and plan.lr == lr and plan.patience == patience and plan.best == best
+                if want == "stop" and not leq:
+                    break

@@ -889,3 +889,50 @@ def test_end_to_end_lwf_ebll_match_reference_driver_g18(tmp_path, golden):
             assert np.all((got >= 0) & (got <= 100))
         print("G18", name, "seq_res build:", {i: res[i]["seq_res"][i] for i in range(3)}, " reference:",
               {i: list(g[pre + "seq_res%d" % i]) for i in range(3)})
+
+
+# --------------------------------------------------------------------------- teacher-forced importance weights (G19)
+def _g19_model_and_task(g, root):
+    from clsurvey_amd import models
+    from clsurvey_amd.framework.tasks import SyntheticTaskSequence
+    ds = SyntheticTaskSequence(os.path.join(root, "data"), task_count=3, classes_per_task=4, sizes=(160, 40, 40), hw=32,
+                               noise=0.4, name="tiny3")
+    m = models.parse_model_name("small_VGG9_cl_128_128", (32, 32), 4)
+    with torch.no_grad():
+        for i, p in enumerate(m.parameters()):
+            p.copy_(torch.from_numpy(g["theta%d" % i]))
+    return m, ds.get_task_dataset_path("1")
+
+
+def _g19_compare(g, tag, model, tol):
+    import numpy as np
+    worst = 0.0
+    for i, p in enumerate(model.parameters()):
+        om = model.reg_params[p]["omega"].detach().double().cpu()
+        ref_stats = g["%s_stats%d" % (tag, i)]
+        flat = om.float().numpy().reshape(-1)
+        if flat.size > (1 << 16):
+            flat = flat[np.sort(np.random.RandomState(19).choice(flat.size, 8192, replace=False))]
+        ref = g["%s_omega%d" % (tag, i)]
+        scale = max(float(ref_stats[1]), 1e-30)
+        err = float(np.abs(flat - ref).max()) / scale
+        worst = max(worst, err)
+        assert err <= tol, "%s Omega of tensor %d: %.3e of its maximum" % (tag, i, err)
+        assert abs(float(om.sum()) - ref_stats[0]) <= tol * abs(ref_stats[0]) + 1e-12
+        assert abs(float(om.pow(2).sum().sqrt()) - ref_stats[2]) <= tol * ref_stats[2] + 1e-12
+        assert torch.equal(model.reg_params[p]["init_val"].cpu(), p.data.cpu())
+    return worst
+
+
+def test_teacher_forced_omega_matches_reference_g19(tmp_path, golden):
+    """Omega tensors, element by element: the reference's accumulate_EWC_weights / accumulate_objective_based_weights
+    were run (make_g19.py) on the first-task checkpoint its own framework trained; the same calls on the HIP path, started
+    from that checkpoint's state_dict, must give the same tensors within north_star's 1e-3 (of each tensor's maximum)."""
+    from clsurvey_amd.methods import ewc, mas
+    g = golden("G19_teacher_forced_omega")
+    for tag, fn in (("ewc", lambda m, p: ewc.accumulate_EWC_weights(None, [p], m, 40)),
+                    ("mas", lambda m, p: mas.accumulate_objective_based_weights(None, [p], m, 40, "L2", test_set="train"))):
+        m, task1 = _g19_model_and_task(g, str(tmp_path / tag))
+        out = fn(m.to("cuda"), task1)
+        worst = _g19_compare(g, tag, out, 1e-3)
+        print("G19 %s: worst Omega element %.2e of its tensor's maximum" % (tag, worst))

@@ -302,27 +302,58 @@ def test_engine_full_size_vs_oracle(name, N, hw):
     loss, logits = eng.loss_step(x.to(dev()), y.to(dev()), "ce_sum", True, want_logits=True)
     assert_close(logits, logits_ref, what="logits")
     assert_close(loss, loss_ref.view(1), what="loss")
-    # A single ReLU / max-pool decision that flips between two fp32 evaluation orders changes one
-    # output-channel row of a dW by ~1/sqrt(#pixels) (measured: ONE row of conv3.weight off by 3e-3,
-    # every other row at 1e-6, tools/grad_table.py) and the flip propagates to the layers below.  So:
-    # the bulk of every tensor must agree to fp32 round-off class, the worst element to 1e-2.
     deep = name == "deep_VGG22"
-    for i, (p, g32, g64) in enumerate(zip(m.parameters(), grads_ref, grads64)):
-        g = p.grad.double().cpu()
-        scale = float(g64.abs().max())
-        rows = (g - g64).abs().reshape(g.shape[0], -1).max(1).values / scale
-        cpu_rows = (g32.double() - g64).abs().reshape(g.shape[0], -1).max(1).values / scale
-        if deep:
-            # N = 6 and 19 conv layers: ONE max-pool argmax flip in the top conv layer (tools/grad_table.py 6 deep_VGG22:
-            # row 61 of conv19.weight off by 2e-2, its other 255 rows at 1e-6, the classifier at 1e-6) moves every
-            # gradient below it by ~1e-2; torch-CPU fp32 has its own flip six layers further down.  Only the order of
-            # magnitude is meaningful below a flip; above it (classifier) the gradients must be exact.
-            assert float(rows.max()) <= (1e-5 if i >= 38 else 4e-2), "grad %d worst row %.3e" % (i, float(rows.max()))
-            continue
-        assert float(rows.max()) <= max(1e-2, 2.0 * float(cpu_rows.max())), \
-            "grad %d worst row %.3e (cpu fp32: %.3e)" % (i, float(rows.max()), float(cpu_rows.max()))
-        assert float(rows.median()) <= max(1e-3, 1.5 * float(cpu_rows.median())), \
-            "grad %d median row err %.3e (cpu fp32: %.3e)" % (i, float(rows.median()), float(cpu_rows.median()))
+    # north_star: 1e-3 relative on fp32.  A ReLU / arg-max decision that sits within rounding of a tie may come out
+    # differently in two fp32 evaluation orders (the reference's own CPU kernels against an fp64 evaluation included); one
+    # such flip moves a row of the dW below it by ~1/sqrt(#pixels).  So the arithmetic is judged with the decisions held
+    # fixed: the fp64 oracle is evaluated on the piecewise-linear branch the GPU took (oracle.vgg_ref.forward_forced with
+    # the ReLU masks and pool arg-max codes read back from the plan executor), where EVERY gradient element must agree to
+    # 1e-3 of the tensor's scale (measured: <= 2e-5); and the decisions themselves are judged separately: wherever the
+    # GPU's differ from what the fp64 pre-activations imply, the element must be a near-tie.
+    decisions, shapes = [], []
+    c, h, j, li = 3, hw, 0, 0
+    while j < len(cfg):
+        k = cfg[j]
+        pooled = j + 1 < len(cfg) and cfg[j + 1] == "M"
+        oh = h // 2 if pooled else h
+        act = eng.layer_input(li + 1, N).view(N, k, oh, oh).cpu()
+        d = {"mask": act > 0}
+        if pooled:
+            d["idx"] = eng.pool_idx(li, N).view(N, k, oh, oh).cpu().long()
+        decisions.append(d)
+        c, h, j, li = k, oh, j + (2 if pooled else 1), li + 1
+    for f in range(2):
+        decisions.append({"mask": eng.layer_input(li + 1, N).cpu() > 0})
+        li += 1
+    lo_f, loss_f, grads_f, pre = vgg_ref.loss_and_grads_forced(p64, cfg, x.double(), y, "ce_sum", decisions)
+    assert float((logits.double().cpu() - lo_f).abs().max()) <= 1e-4 * max(1.0, float(lo_f.abs().max()))
+    worst = 0.0
+    for i, (p, gf) in enumerate(zip(m.parameters(), grads_f)):
+        err = float((p.grad.double().cpu() - gf).abs().max()) / max(float(gf.abs().max()), 1e-30)
+        worst = max(worst, err)
+        assert err <= 1e-4, "grad %d: %.3e of its scale on the GPU's own branch (north_star: 1e-3)" % (i, err)
+    own = vgg_ref.own_decisions(cfg, pre)
+    flips = 0
+    for b, (dg, do, z) in enumerate(zip(decisions, own, pre)):
+        tie = 1e-4 * float(z.abs().max())
+        if "idx" in dg:
+            win = vgg_ref._windows(z)
+            zg = torch.gather(win, 4, dg["idx"].unsqueeze(-1)).squeeze(-1)
+            zo = torch.gather(win, 4, do["idx"].unsqueeze(-1)).squeeze(-1)
+            # the pool runs on ReLU outputs: where the whole window is <= 0 the code is 0 by convention and carries no
+            # gradient; only windows that pass something on count
+            moved = (dg["idx"] != do["idx"]) & (dg["mask"] | do["mask"])
+            flips += int(moved.sum())
+            assert float((zo - zg)[moved].abs().max()) <= tie if moved.any() else True, "block %d: arg-max differs off a tie" % b
+            z_sel = zg
+        else:
+            z_sel = z
+        off = dg["mask"] != (z_sel > 0)
+        flips += int(off.sum())
+        assert float(z_sel[off].abs().max()) <= tie if off.any() else True, "block %d: ReLU decision differs off a tie" % b
+    print("%s N=%d hw=%d: worst gradient element %.2e of scale on the forced branch; %d near-tie decisions differ from fp64"
+          % (name, N, hw, worst, flips))
+    del deep
     # eval-only pass leaves gradients untouched and reproduces the logits bit for bit
     before = eng.arena.grad.clone()
     _, logits2 = eng.loss_step(x.to(dev()), y.to(dev()), "ce_mean", False, want_logits=True)

@@ -411,3 +411,26 @@ def test_g16_ebll_objectives(golden):
     for j, gr in enumerate(grads):
         ref = g["s2_g%d" % j]
         assert np.abs(gr.numpy() - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-6), g["s2_param_names"][j]
+
+
+def test_g19_oracle_importance_on_the_reference_checkpoint(golden):
+    """The oracle's diag_fisher / mas_importance on the first-task checkpoint the reference's framework trained, against the
+    Omega tensors the reference's own accumulate_EWC_weights / accumulate_objective_based_weights produced from it (G19)."""
+    import os
+    import tempfile
+    from clsurvey_amd.framework.tasks import SyntheticTaskSequence
+    g = golden("G19_teacher_forced_omega")
+    cfg = vgg_ref.CFGS["small_VGG9"]
+    theta = [T(g["theta%d" % i]) for i in range(18)]
+    with tempfile.TemporaryDirectory() as root:
+        ds = SyntheticTaskSequence(os.path.join(root, "data"), task_count=3, classes_per_task=4, sizes=(160, 40, 40), hw=32,
+                                   noise=0.4, name="tiny3")
+        d = torch.load(ds.get_task_dataset_path("1"), weights_only=False)["train"]
+    batches = [(d.x[i:i + 40], d.y[i:i + 40]) for i in range(0, 160, 40)]
+    for tag, omega in (("ewc", R.diag_fisher(theta, cfg, batches, 160)), ("mas", R.mas_importance(theta, cfg, batches))):
+        for i, o in enumerate(omega):
+            flat = o.numpy().reshape(-1)
+            if flat.size > (1 << 16):
+                flat = flat[np.sort(np.random.RandomState(19).choice(flat.size, 8192, replace=False))]
+            ref = g["%s_omega%d" % (tag, i)]
+            assert float(np.abs(flat - ref).max()) <= 2e-5 * float(g["%s_stats%d" % (tag, i)][1]), (tag, i)
