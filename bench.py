@@ -168,7 +168,7 @@ def time_kernels(eng, x, N, iters):
     return rows
 
 
-def measured_traffic(kernel, layer, N):
+def measured_traffic(kernel, layer, N, instance=None):
     """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (tools/gpu_traffic.sh: FETCH_SIZE
     and WRITE_SIZE in separate passes; FETCH_SIZE doubled for 16-byte-per-lane reads as MI355X_MICROARCH.md
     prescribes for gfx950).  None when no measurement for this kernel/shape is on file."""
@@ -179,7 +179,9 @@ def measured_traffic(kernel, layer, N):
     except Exception:
         return None
     e = t.get("%s %s N=%d" % (kernel, layer, N))
-    return None if e is None else float(e["hbm_bytes_per_launch"])
+    if e is None or (instance is not None and e.get("instance") != instance):
+        return None                 # measured for another kernel instance (tiling changed since): not this launch's traffic
+    return float(e["hbm_bytes_per_launch"])
 
 
 CFGS = {"small_VGG9": SMALL, "base_VGG9": [64, "M", 64, "M", 128, 128, "M", 256, 256, "M"],
@@ -564,7 +566,7 @@ def main():
         out["roofline"] = {"bound": "mfma", "kernel": "%s [%s, layer %s, N=%d]" % (dom["instance"], dom["kernel"], dom["layer"], N),
                            "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                           "traffic": measured_traffic(dom["kernel"], dom["layer"], N),
+                           "traffic": measured_traffic(dom["kernel"], dom["layer"], N, dom["instance"]),
                            "algorithmic_gflop_per_launch": dom["flops"] / 1e9,
                            "algorithmic_bytes_per_launch": dom["alg_bytes"],
                            "avg_launch_us": dom["sec"] * 1e6,

@@ -16,8 +16,15 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
          "-mllvm", "-pragma-unroll-threshold=100000"]
 
 
-def _newer(a, b):
-    return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
+def _fingerprint(paths, flags):
+    """sha256 over the compiler flags and the bytes of a source and the headers it includes: an object file is reused
+    only when this matches the stamp written next to it (mtimes do not survive a repository snapshot)."""
+    import hashlib
+    h = hashlib.sha256(" ".join(flags).encode())
+    for path in paths:
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def build(force=False, verbose=True):
@@ -28,15 +35,22 @@ def build(force=False, verbose=True):
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        stamp = o + ".sha256"
         objs.append(o)
-        if force or _newer(s, o) or any(_newer(h, o) for h in hdrs):
+        want = _fingerprint([s] + hdrs, FLAGS)
+        have = open(stamp).read().strip() if os.path.exists(stamp) and os.path.exists(o) else ""
+        if force or have != want:
             cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
-            procs.append((src, subprocess.Popen(cmd)))
-    for src, p in procs:
+            if os.path.exists(stamp):
+                os.remove(stamp)
+            procs.append((src, stamp, want, subprocess.Popen(cmd)))
+    for src, stamp, want, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on " + src)
+        with open(stamp, "w") as f:
+            f.write(want + "\n")
     if force or procs or not os.path.exists(OUT):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
         if verbose:

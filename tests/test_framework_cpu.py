@@ -246,3 +246,22 @@ def test_patience_plan_reference_sequences():
                 assert got == want and plan.lr == lr and plan.patience == patience and plan.best == best
                 if want == "stop" and not leq:
                     break
+
+
+def test_traffic_json_names_the_kernel_bench_reports():
+    """profiles/traffic.json holds PMC-measured HBM bytes of the dominant launch; bench.py copies it into
+    roofline.traffic.  The entry must be for the kernel INSTANCE the library launches for that layer today (the tile
+    geometry decides the halo re-reads), otherwise bench reports null instead of a stale number."""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    t = json.load(open(os.path.join(root, "profiles", "traffic.json")))
+    inst = bench.conv_instance(64, 32, 32, 200, 64, 0, True)
+    e = t["conv3x3_relu_pool_fwd 64x64@32 N=200"]
+    assert e["instance"] == inst, (e["instance"], inst)
+    assert bench.measured_traffic("conv3x3_relu_pool_fwd", "64x64@32", 200, inst) == e["hbm_bytes_per_launch"]
+    assert bench.measured_traffic("conv3x3_relu_pool_fwd", "64x64@32", 200, "conv3x3_mfma_kernel<other>") is None
+    assert t["conv3x3_bwd_data 64x64@32 N=200"]["instance"] == bench.conv_instance(64, 32, 32, 200, 64, 1, False)
