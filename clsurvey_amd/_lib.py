@@ -75,6 +75,8 @@ SIGNATURES = {
     "clhip_gem_gram_ws": (_z, [_i]),
     "clhip_gem_gram": (_i, [_p, _z, C.POINTER(_i), _i, _z, _p, _p, _z, _p]),
     "clhip_gem_project": (_i, [_p, _z, C.POINTER(_i), C.POINTER(_f), _i, _p, _p, _z, _p]),
+    "clhip_gem_qp": (_i, [_p, _i, C.c_double, C.c_double, _p, _p, _p]),
+    "clhip_gem_project_dev": (_i, [_p, _z, C.POINTER(_i), _p, _p, _i, _p, _p, _z, _p]),
     "clhip_net_create": (_i, [C.POINTER(LayerDesc), _i, _i, _i, _i, _i, C.POINTER(_p)]),
     "clhip_net_set_dropout": (_i, [_p, _i, _p, _l]),
     "clhip_net_set_bn": (_i, [_p, _i, _p, _p, _f, _f]),

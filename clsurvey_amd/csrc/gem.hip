@@ -131,6 +131,170 @@ __global__ __launch_bounds__(GB) void project_kernel(const float* __restrict__ G
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// GEM's QP on the device (rehearsal/model/gem.py:58-80): from the f64 Gram matrix of [memory rows..., current row]
+//     P = 1/2 (M M^T + (M M^T)^T) + eps I,   q = -M g,   minimise 1/2 v^T P v - q^T v   subject to  v >= margin
+// solved by the Goldfarb-Idnani dual active-set method (the algorithm of quadprog.solve_qp, which the reference calls;
+// Math. Programming 27, 1983), restated for at most QP_MAX unknowns in f64 — the same steps as methods/qp.py, which stays
+// as the host-side cross-check.  t <= 9 here: the whole solve is a few thousand flops, so ONE lane does it; what matters is
+// that neither the Gram matrix nor v ever visits the host (the previous form synchronised the stream once per observe).
+// info[0] = number of violated constraints g.G_k < 0 (gem.py:275-277: 0 => no projection), info[1] = status (0 ok).
+constexpr int QP_MAX = 16;
+
+__device__ void qp_inverse_spd(const double (*A)[QP_MAX], int n, double (*Inv)[QP_MAX]) {
+    // Cholesky A = L L^T, Linv by forward substitution, Inv = Linv^T Linv (numpy: cholesky, inv, Linv.T @ Linv)
+    double L[QP_MAX][QP_MAX], Li[QP_MAX][QP_MAX];
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double s = A[i][j];
+            for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
+            L[i][j] = (i == j) ? sqrt(s) : s / L[j][j];
+        }
+    for (int c = 0; c < n; ++c)
+        for (int i = 0; i < n; ++i) {
+            if (i < c) { Li[i][c] = 0.0; continue; }
+            double s = (i == c) ? 1.0 : 0.0;
+            for (int k = c; k < i; ++k) s -= L[i][k] * Li[k][c];
+            Li[i][c] = s / L[i][i];
+        }
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            double s = 0.0;
+            for (int k = (i > j ? i : j); k < n; ++k) s += Li[k][i] * Li[k][j];
+            Inv[i][j] = s;
+        }
+}
+
+// solve S X = B for SPD S (na x na) and B (na x nb) by Gaussian elimination with partial pivoting (numpy.linalg.solve)
+__device__ void qp_solve(double (*S)[QP_MAX], double (*B)[QP_MAX], int na, int nb) {
+    for (int c = 0; c < na; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < na; ++r)
+            if (fabs(S[r][c]) > fabs(S[piv][c])) piv = r;
+        if (piv != c) {
+            for (int k = 0; k < na; ++k) { const double t = S[c][k]; S[c][k] = S[piv][k]; S[piv][k] = t; }
+            for (int k = 0; k < nb; ++k) { const double t = B[c][k]; B[c][k] = B[piv][k]; B[piv][k] = t; }
+        }
+        for (int r = c + 1; r < na; ++r) {
+            const double f = S[r][c] / S[c][c];
+            for (int k = c; k < na; ++k) S[r][k] -= f * S[c][k];
+            for (int k = 0; k < nb; ++k) B[r][k] -= f * B[c][k];
+        }
+    }
+    for (int r = na - 1; r >= 0; --r)
+        for (int k = 0; k < nb; ++k) {
+            double s = B[r][k];
+            for (int c = r + 1; c < na; ++c) s -= S[r][c] * B[c][k];
+            B[r][k] = s / S[r][r];
+        }
+}
+
+__global__ void gem_qp_kernel(const double* __restrict__ gram, int m, double margin, double eps, double* __restrict__ v_out,
+                              int* __restrict__ info) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int n = m - 1;                                   // unknowns = memory rows; row / column n = current gradient
+    int viol = 0;
+    for (int i = 0; i < n; ++i) viol += gram[(size_t)n * m + i] < 0.0;
+    info[0] = viol;
+    info[1] = 0;
+    for (int i = 0; i < n; ++i) v_out[i] = 0.0;
+    if (viol == 0) return;
+    const double tol = 1e-12;
+    double G[QP_MAX][QP_MAX], Ginv[QP_MAX][QP_MAX], a[QP_MAX], x[QP_MAX], b[QP_MAX];
+    for (int i = 0; i < n; ++i) {
+        for (int j = 0; j < n; ++j) G[i][j] = 0.5 * (gram[(size_t)i * m + j] + gram[(size_t)j * m + i]) + (i == j ? eps : 0.0);
+        a[i] = -gram[(size_t)i * m + n];                   // q = -M g; quadprog minimises 1/2 x^T G x - a^T x with a = q
+        b[i] = margin;
+    }
+    qp_inverse_spd(G, n, Ginv);
+    for (int i = 0; i < n; ++i) {
+        double s = 0.0;
+        for (int j = 0; j < n; ++j) s += Ginv[i][j] * a[j];
+        x[i] = s;                                          // unconstrained minimum
+    }
+    int active[QP_MAX], na = 0;
+    double u[QP_MAX + 1];
+    for (int it = 0; it < 200; ++it) {
+        // constraints are v_i >= margin (C = I): slack s_i = x_i - b_i; most violated inactive one
+        int p = -1;
+        double worst = 0.0;
+        for (int i = 0; i < n; ++i) {
+            bool act = false;
+            for (int k = 0; k < na; ++k) act |= active[k] == i;
+            const double si = x[i] - b[i];
+            if (!act && si < -tol * fmax(1.0, fabs(b[i])) && (p < 0 || si < worst)) { p = i; worst = si; }
+        }
+        if (p < 0) {
+            for (int i = 0; i < n; ++i) v_out[i] = x[i];
+            return;
+        }
+        u[na] = 0.0;
+        for (int inner = 0; inner < 200; ++inner) {
+            double z[QP_MAX], r[QP_MAX];
+            if (na > 0) {
+                // Nstar = (N^T Ginv N)^-1 N^T Ginv ; H = Ginv - Ginv N Nstar ; z = H n_p ; r = Nstar n_p   (n_p = e_p)
+                double S[QP_MAX][QP_MAX], B[QP_MAX][QP_MAX];
+                for (int i = 0; i < na; ++i) {
+                    for (int j = 0; j < na; ++j) S[i][j] = Ginv[active[i]][active[j]];
+                    for (int j = 0; j < n; ++j) B[i][j] = Ginv[active[i]][j];
+                }
+                qp_solve(S, B, na, n);                     // B = Nstar (na x n)
+                for (int j = 0; j < na; ++j) r[j] = B[j][p];
+                for (int i = 0; i < n; ++i) {
+                    double s = Ginv[i][p];
+                    for (int k = 0; k < na; ++k) s -= Ginv[i][active[k]] * B[k][p];
+                    z[i] = s;
+                }
+            } else {
+                for (int i = 0; i < n; ++i) z[i] = Ginv[i][p];
+            }
+            double t1 = INFINITY, t2 = INFINITY;
+            int drop = -1;
+            for (int j = 0; j < na; ++j)
+                if (r[j] > tol && u[j] / r[j] < t1) { t1 = u[j] / r[j]; drop = j; }
+            const double zn = z[p];
+            const double sp = x[p] - b[p];
+            if (zn > tol) t2 = -sp / zn;
+            const double t = fmin(t1, t2);
+            if (!(t < INFINITY)) { info[1] = 2; return; }           // infeasible
+            if (t2 < INFINITY)
+                for (int i = 0; i < n; ++i) x[i] += t * z[i];
+            for (int j = 0; j < na; ++j) u[j] -= t * r[j];
+            u[na] += t;
+            if (t == t2) { active[na++] = p; break; }                 // full step: p joins the active set
+            for (int j = drop; j < na; ++j) { active[j] = active[j + 1]; u[j] = u[j + 1]; }   // partial step: drop, retry p
+            --na;
+            if (inner == 199) { info[1] = 1; return; }
+        }
+    }
+    info[1] = 1;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(GB) void project_dev_kernel(const float* __restrict__ G, size_t ld, RowSel sel, const double* __restrict__ v,
+                                                         const int* __restrict__ info, int m, const float* __restrict__ g,
+                                                         float* __restrict__ out, size_t n) {
+    if (info[0] == 0 && out == g) return;                   // no violated constraint: the gradient stays as it is
+    double cv[MAXM];
+    for (int i = 0; i < m; ++i) cv[i] = info[0] == 0 ? 0.0 : (double)(float)v[i];     // v rounded to fp32 as torch.Tensor(x) does downstream
+    size_t stride = (size_t)gridDim.x * GB;
+    const size_t n4 = VEC ? n / 4 : 0;
+    for (size_t c4 = (size_t)blockIdx.x * GB + threadIdx.x; c4 < n4; c4 += stride) {
+        const float4 gv = reinterpret_cast<const float4*>(g)[c4];
+        double s0 = (double)gv.x, s1 = (double)gv.y, s2 = (double)gv.z, s3 = (double)gv.w;
+        for (int i = 0; i < m; ++i) {
+            const float4 r = reinterpret_cast<const float4*>(G + (size_t)sel.idx[i] * ld)[c4];
+            s0 += cv[i] * (double)r.x; s1 += cv[i] * (double)r.y; s2 += cv[i] * (double)r.z; s3 += cv[i] * (double)r.w;
+        }
+        reinterpret_cast<float4*>(out)[c4] = make_float4((float)s0, (float)s1, (float)s2, (float)s3);
+    }
+    for (size_t c = n4 * 4 + (size_t)blockIdx.x * GB + threadIdx.x; c < n; c += stride) {
+        double s = (double)g[c];
+        for (int i = 0; i < m; ++i) s += cv[i] * (double)G[(size_t)sel.idx[i] * ld + c];
+        out[c] = (float)s;
+    }
+}
+
 template <int M>
 int gram_launch(const float* G, size_t ld, const RowSel& sel, size_t n, double* partial, int blocks, bool vec, hipStream_t s) {
     if (vec) hipLaunchKernelGGL((gram_partial_kernel<M, true>), dim3(blocks), dim3(GB), 0, s, G, ld, sel, n, partial);
@@ -194,6 +358,32 @@ int clhip_gem_project(const float* G, size_t ld, const int* row_idx_host, const 
         hipLaunchKernelGGL(project_kernel<true>, dim3(ew_grid(n / 4 + 1, GB)), dim3(GB), 0, as_stream(stream), G, ld, sel, cf, m, g, out, n);
     else
         hipLaunchKernelGGL(project_kernel<false>, dim3(ew_grid(n, GB)), dim3(GB), 0, as_stream(stream), G, ld, sel, cf, m, g, out, n);
+    CLHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// v = argmin of GEM's QP, computed on the device from clhip_gem_gram's output (m = memory rows + 1; the current gradient
+// is the LAST row).  v_out_f64[m - 1], info_i32[2] = {violated constraints, status}.  Nothing is copied to the host.
+int clhip_gem_qp(const double* gram_f64, int m, double margin, double eps, double* v_out_f64, int* info_i32, void* stream) {
+    if (!gram_f64 || !v_out_f64 || !info_i32 || m < 2 || m - 1 > QP_MAX || m > MAXM) return CLHIP_EINVAL;
+    hipLaunchKernelGGL(gem_qp_kernel, dim3(1), dim3(64), 0, as_stream(stream), gram_f64, m, margin, eps, v_out_f64, info_i32);
+    CLHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// clhip_gem_project with the coefficients (and the "anything violated?" flag) read from device memory: out = g when
+// info[0] == 0, else g + sum_i v[i] * G[row_idx[i]].
+int clhip_gem_project_dev(const float* G, size_t ld, const int* row_idx_host, const double* v_dev_f64, const int* info_dev, int m,
+                          const float* g, float* out, size_t n, void* stream) {
+    if (!G || !row_idx_host || !v_dev_f64 || !info_dev || !g || !out || m < 1 || m > MAXM || n == 0) return CLHIP_EINVAL;
+    RowSel sel{};
+    for (int i = 0; i < m; ++i) sel.idx[i] = row_idx_host[i];
+    if (aligned16(G) && (ld % 4 == 0) && aligned16(g) && aligned16(out))
+        hipLaunchKernelGGL(project_dev_kernel<true>, dim3(ew_grid(n / 4 + 1, GB)), dim3(GB), 0, as_stream(stream), G, ld, sel, v_dev_f64,
+                           info_dev, m, g, out, n);
+    else
+        hipLaunchKernelGGL(project_dev_kernel<false>, dim3(ew_grid(n, GB)), dim3(GB), 0, as_stream(stream), G, ld, sel, v_dev_f64,
+                           info_dev, m, g, out, n);
     CLHIP_LAUNCH_CHECK();
     return 0;
 }

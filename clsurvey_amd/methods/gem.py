@@ -72,6 +72,9 @@ class GemNet:
         L = _lib.lib()
         self._gram_ws = torch.zeros(L.clhip_gem_gram_ws(16), dtype=torch.uint8, device=self.device)
         self._gram = torch.zeros(16 * 16, dtype=torch.float64, device=self.device)
+        self._v = torch.zeros(16, dtype=torch.float64, device=self.device)          # QP solution, stays on the device
+        self._info = torch.zeros(2, dtype=torch.int32, device=self.device)          # {violated constraints, status}
+        self.qp_on_device = True
         self.stats = torch.zeros(2, dtype=torch.float64, device=self.device)
 
     def init_setup(self, args=None, lr=None, weight_decay=None, memory_strength=None):
@@ -102,7 +105,7 @@ class GemNet:
         """gem.py:183-186: torch.bernoulli(fill(p_retain)) / p_retain over one sample's features (device generator)."""
         return torch.full((n,), p_retain_unit, dtype=torch.float32, device=self.device).bernoulli_().div_(p_retain_unit)
 
-    _TRANSIENT = ("engine", "A", "G", "_gram_ws", "_gram", "stats", "opt", "dropout_masks")
+    _TRANSIENT = ("engine", "A", "G", "_gram_ws", "_gram", "_v", "_info", "stats", "opt", "dropout_masks")
 
     def __getstate__(self):
         return {k: v for k, v in self.__dict__.items() if k not in self._TRANSIENT}
@@ -158,12 +161,27 @@ class GemNet:
         check(_lib.lib().clhip_axpy(row.data_ptr(), self.A.grad.data_ptr(), self.A.numel, 1.0, int(assign), _stream()),
               "clhip_axpy")
 
-    def gram(self, rows):
+    def gram(self, rows, to_host=True):
         m = len(rows)
         idx = (C.c_int * m)(*rows)
         check(_lib.lib().clhip_gem_gram(self.G.data_ptr(), self.G.shape[1], idx, m, self.A.numel, self._gram.data_ptr(),
                                         self._gram_ws.data_ptr(), self._gram_ws.numel(), _stream()), "clhip_gem_gram")
-        return self._gram[:m * m].cpu().numpy().reshape(m, m)
+        return self._gram[:m * m].cpu().numpy().reshape(m, m) if to_host else self._gram
+
+    def project_on_device(self, rows, t, eps=1e-3):
+        """Violation test (gem.py:275-277), QP (:58-80) and projection / overwrite_grad (:79, :38-55) of the current
+        gradient G[t] without a host round trip: Gram of rows + [t] -> clhip_gem_qp -> clhip_gem_project_dev.  Returns the
+        device counter of violated constraints (0 => the gradient was left as it is)."""
+        m = len(rows) + 1
+        self.gram(list(rows) + [t], to_host=False)
+        L = _lib.lib()
+        check(L.clhip_gem_qp(self._gram.data_ptr(), m, float(self.margin), float(eps), self._v.data_ptr(), self._info.data_ptr(),
+                             _stream()), "clhip_gem_qp")
+        idx = (C.c_int * (m - 1))(*rows)
+        check(L.clhip_gem_project_dev(self.G.data_ptr(), self.G.shape[1], idx, self._v.data_ptr(), self._info.data_ptr(), m - 1,
+                                      self.G[t].data_ptr(), self.A.grad.data_ptr(), self.A.numel, _stream()),
+              "clhip_gem_project_dev")
+        return self._info[0].clone()
 
     def project(self, rows, v, t):
         m = len(rows)
@@ -197,13 +215,16 @@ class GemNet:
         if len(self.observed_tasks) > 1:
             self._axpy(self.G[t], assign=True)                       # store_grad (:272)
             rows = list(self.observed_tasks[:-1]) + [t]
-            gram = self.gram(rows)
-            dotp = gram[-1, :-1]                                      # g . G_tt (:275-276)
-            viol = int((dotp < 0).sum())
-            if viol != 0:
-                batch_stats["projected_grads"] = [viol]
-                v = qp.project2cone2_coefficients(gram, len(rows) - 1, list(range(len(rows) - 1)), self.margin)
-                self.project(rows[:-1], v, t)                         # project2cone2 + overwrite_grad (:278-283)
+            if self.qp_on_device:
+                batch_stats["projected_grads"] = [self.project_on_device(rows[:-1], t)]     # device counter, no sync
+            else:                                                     # host cross-check path (tests)
+                gram = self.gram(rows)
+                dotp = gram[-1, :-1]                                  # g . G_tt (:275-276)
+                viol = int((dotp < 0).sum())
+                if viol != 0:
+                    batch_stats["projected_grads"] = [viol]
+                    v = qp.project2cone2_coefficients(gram, len(rows) - 1, list(range(len(rows) - 1)), self.margin)
+                    self.project(rows[:-1], v, t)                     # project2cone2 + overwrite_grad (:278-283)
         self.opt.step()
         return loss, self.stats[1], batch_stats
 

@@ -77,7 +77,7 @@ def train_model(model, args, dset_sizes, resume="", save_models_mode=False, savi
             epoch_acc = float(running_corrects.item()) / dset_sizes[phase]
             print("{} Loss: {:.4f} Acc: {:.4f}".format(phase, epoch_loss, epoch_acc))
             if projected:
-                print("projected_grads = {}".format(projected))
+                print("projected_grads = {}".format([int(v) for v in projected]))    # device counters: read once per epoch
             if math.isnan(epoch_loss):
                 print("Canceling because Nan LOSS")         # train_rehearsal.py:139-141 (checked per phase here)
                 return model, best_acc

@@ -308,6 +308,17 @@ int clhip_gem_gram(const float* G, size_t ld, const int* row_idx_host, int m, si
                    size_t ws_bytes, void* stream);
 int clhip_gem_project(const float* G, size_t ld, const int* row_idx_host, const float* v_host, int m, const float* g,
                       float* out, size_t n, void* stream);
+/* project2cone2's QP itself (gem.py:58-80, quadprog.solve_qp = Goldfarb-Idnani dual active set) on the device, so that an
+ * observe step never synchronises with the host:
+ *   gem_qp          from clhip_gem_gram's f64 output over [memory rows..., current gradient LAST] (m rows, m - 1 <= 15
+ *                   unknowns): P = 1/2 (MM^T + MM^T^T) + eps I, q = -M g, min 1/2 v^T P v - q^T v s.t. v >= margin;
+ *                   v_out_f64[m - 1]; info_i32[0] = #{k : g . G_k < 0} (gem.py:275-277; 0 => v = 0), info_i32[1] = 0 ok,
+ *                   1 iteration limit, 2 infeasible
+ *   gem_project_dev clhip_gem_project with v and the violation count read from device memory: out = g when nothing is
+ *                   violated (a no-op for out == g), else g + sum_i v[i] G[row_idx[i]]                                  */
+int clhip_gem_qp(const double* gram_f64, int m, double margin, double eps, double* v_out_f64, int* info_i32, void* stream);
+int clhip_gem_project_dev(const float* G, size_t ld, const int* row_idx_host, const double* v_dev_f64, const int* info_dev,
+                          int m, const float* g, float* out, size_t n, void* stream);
 
 /* ------------------------------------------------------------------ debug reference kernels
  * Direct (one thread per output, no MFMA/LDS) convolutions used only by tests to triage the

@@ -1476,3 +1476,88 @@ def test_ebll_step_with_dropout_on_the_features():
     for (name, _), g in zip([(n, p) for n, p in ref.named_parameters() if not n.startswith("autoencoders")], grads):
         got = eng.arena.view("grad", named[name]).cpu()
         assert float((got - g).abs().max()) <= 2e-3 * max(float(g.abs().max()), floor), name
+
+
+def test_gem_qp_on_device_vs_host_and_scipy():
+    """clhip_gem_qp (Goldfarb-Idnani in f64 on the device, fed by a Gram matrix that never leaves HBM) on 240 random
+    problems of project2cone2's form (gem.py:58-80): well conditioned, rank deficient (fewer parameters than tasks: only
+    eps*I keeps P definite), near-collinear memory gradients, many / no violated constraints, margins 0 / 0.5 / 1.
+    Judged by (a) the host restatement methods/qp.py, (b) scipy's bounded least squares on the Cholesky factor (an
+    independent algorithm), (c) the KKT conditions.  Parity with quadprog 0.1.6 itself stays unpinned (package absent)."""
+    import ctypes as C
+    from scipy.optimize import lsq_linear
+    from clsurvey_amd import _lib
+    from clsurvey_amd.methods import qp
+    L = _lib.lib()
+    rs = np.random.RandomState(58)
+    gram_d = torch.zeros(16 * 16, dtype=torch.float64, device=dev())
+    v_d = torch.zeros(16, dtype=torch.float64, device=dev())
+    info_d = torch.zeros(2, dtype=torch.int32, device=dev())
+    stream = torch.cuda.current_stream().cuda_stream
+    solved = skipped = 0
+    for case in range(240):
+        t = int(rs.randint(1, 16))
+        kind = case % 4
+        d = {0: 3 * t + 2, 1: max(1, t - 2), 2: 2 * t, 3: t + 1}[kind]
+        M = rs.standard_normal((t, d))
+        if kind == 2 and t > 1:                    # near-collinear memory gradients
+            M[1:] = M[0] + 1e-4 * rs.standard_normal((t - 1, d))
+        g = rs.standard_normal(d) * (1.0 if case % 5 else 5.0)
+        if case % 7 == 0:
+            g = np.abs(M).sum(0)                   # positive correlation with most rows: few / no violations
+        margin = [0.0, 0.5, 1.0][case % 3]
+        rows = np.vstack([M, g[None]])
+        gram = rows @ rows.T
+        m = t + 1
+        gram_d[:m * m].copy_(torch.from_numpy(gram.reshape(-1)))
+        rc = L.clhip_gem_qp(gram_d.data_ptr(), m, C.c_double(margin), C.c_double(1e-3), v_d.data_ptr(), info_d.data_ptr(), stream)
+        assert rc == 0
+        info = info_d.cpu().tolist()
+        v = v_d[:t].cpu().numpy()
+        viol = int((gram[-1, :-1] < 0).sum())
+        assert info[0] == viol and info[1] == 0, (case, info)
+        if viol == 0:
+            assert not v.any()
+            skipped += 1
+            continue
+        P = 0.5 * (gram[:t, :t] + gram[:t, :t].T) + 1e-3 * np.eye(t)
+        q = -gram[:t, t]
+        v_host = qp.project2cone2_coefficients(gram, t, list(range(t)), margin)
+        scale = max(1.0, float(np.abs(v_host).max()))
+        assert float(np.abs(v - v_host).max()) <= 1e-9 * scale, (case, t, kind, float(np.abs(v - v_host).max()))
+        # independent solver: min 1/2 v^T P v - q^T v = 1/2 |R v - R^-T q|^2 + const with P = R^T R
+        R = np.linalg.cholesky(P).T
+        ls = lsq_linear(R, np.linalg.solve(R.T, q), bounds=(margin, np.inf), method="bvls", tol=1e-14, max_iter=500)
+        obj = lambda z: 0.5 * z @ P @ z - q @ z        # noqa: E731
+        assert obj(v) <= obj(ls.x) + 1e-8 * max(1.0, abs(obj(ls.x))), (case, obj(v), obj(ls.x))
+        lam = P @ v - q                                  # multipliers of v >= margin
+        kkt = max(float(np.maximum(margin - v, 0).max()), float(np.maximum(-lam, 0).max()), float(np.abs(lam * (v - margin)).max()))
+        # relative to the size of the terms the residual is a difference of (|P| |v| reaches 1e2-1e3 in the collinear cases)
+        assert kkt <= 1e-10 * max(1.0, float(np.abs(q).max()), float(np.abs(P).sum(1).max()) * scale), (case, t, kind, kkt)
+        solved += 1
+    assert solved >= 150 and skipped >= 5, (solved, skipped)
+
+
+def test_gem_observe_device_qp_equals_host_path():
+    """GemNet.observe with the QP on the device (default) against the host cross-check path: same projected gradient
+    bit for bit (the coefficients are rounded to fp32 at the same place) and the same parameters after the step."""
+    from clsurvey_amd.methods.gem import GemNet, extend_head
+    from clsurvey_amd import models
+    outs = []
+    for on_device in (True, False):
+        torch.manual_seed(4)
+        m = extend_head(models.parse_model_name("small_VGG9_cl_128_128", (32, 32), 4), 12)
+        gem = GemNet(m, 12, 3, [4, 4, 4], 16, 1e-2, 0.0, 0.5, batch_size=16, in_shape=(3, 32, 32), device=dev())
+        gem.qp_on_device = on_device
+        gen = torch.Generator().manual_seed(9)
+        counts = []
+        for t in range(3):
+            for _ in range(3):
+                x = torch.randn(16, 3, 32, 32, generator=gen).to(dev())
+                y = (torch.randint(0, 4, (16,), generator=gen) + 4 * t).to(dev())
+                _, _, st = gem.observe(x, t, y)
+                counts.append(int(st["projected_grads"][0]))
+        outs.append(([p.detach().clone() for p in gem.net.parameters()], counts))
+    assert outs[0][1] == outs[1][1] and any(c > 0 for c in outs[0][1]), outs[0][1]
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert torch.equal(a, b)
