@@ -27,6 +27,7 @@ SIGNATURES = {
     "clhip_conv3x3_relu_pool_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "clhip_conv3x3_bwd_weight_unpool": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
     "clhip_conv3x3_bwd_data": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "clhip_conv3x3_bwd_data_unpool": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "clhip_conv3x3_bwd_weight_ws": (_z, [_i, _i, _i, _i, _i]),
     "clhip_conv3x3_bwd_weight": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
     "clhip_conv3x3_bwd_weight_slabs": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _z, C.POINTER(_i), _p]),

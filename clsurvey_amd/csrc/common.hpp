@@ -45,6 +45,17 @@ __device__ __forceinline__ float4 clhip_buf_load4(__amdgpu_buffer_rsrc_t r, int 
     const clhip_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
+__device__ __forceinline__ float2 clhip_buf_load2(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+}
+__device__ __forceinline__ unsigned clhip_buf_load_u16(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return (unsigned)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0);
+}
+__device__ __forceinline__ unsigned clhip_buf_load_u8(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return (unsigned)__builtin_amdgcn_raw_buffer_load_b8(r, voff, soff, 0);
+}
 __device__ __forceinline__ void clhip_buf_store(float v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
 }

@@ -59,14 +59,18 @@ __device__ __forceinline__ void tile_pixel(int s, int li, bool pool, int& nb, in
 #ifndef CLHIP_CONV_MIN_WAVES
 #define CLHIP_CONV_MIN_WAVES 1
 #endif
-template <int TW, int TH, int NB, int CK, int MODE, bool VEC>
+// UNPOOL (MODE 1, VEC only): `in` is the gradient w.r.t. the 2x2-max-POOLED output [N][Cin][H/2][W/2] and `pool_idx` the
+// 2-bit arg-max codes of the forward pass; the un-pooled gradient tile is rebuilt while it is staged into LDS (fused
+// max_pool2d backward: the 4x larger tensor is never written nor read, and its kernel launch disappears).
+template <int TW, int TH, int NB, int CK, int MODE, bool VEC, bool UNPOOL = false>
 __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel(
     const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
     const float* __restrict__ mask_src, float* __restrict__ out,
     int N, int Cin, int Cout, int H, int W, int Kw, int Cw, int relu,
     int tiles_w, int tiles_h, int n_pix_tiles, uint8_t* __restrict__ pool_idx) {
     using G = Geo<TW, TH, NB>;
-    const bool pool = pool_idx != nullptr;     // MODE 0 only: out = 2x2-max-pooled relu(conv), idx = argmax
+    static_assert(!UNPOOL || (MODE == 1 && VEC), "the fused un-pool lives in the 16-byte staging of backward-data");
+    const bool pool = !UNPOOL && pool_idx != nullptr;     // MODE 0 only: out = 2x2-max-pooled relu(conv), idx = argmax
     constexpr int WS_FLOATS = CK * 9 * LDW;
     constexpr int XS_FLOATS = CK * G::PLANE;
     constexpr int BUF_FLOATS = WS_FLOATS + XS_FLOATS;
@@ -99,7 +103,9 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
     constexpr int W_ELEMS = KT * CK * 9;
     const size_t plane_hw = (size_t)H * W;
     const int n_chunks = (Cin + CK - 1) / CK;
-    const float* in_blk = in + (size_t)n0 * Cin * plane_hw;
+    const int Wp = W >> 1;
+    const size_t plane_in = UNPOOL ? (size_t)(H >> 1) * Wp : plane_hw;       // plane of the tensor `in` points at
+    const float* in_blk = in + (size_t)n0 * Cin * plane_in;
 
     // ------------------------------------------------------------------ staging
     // All index math is done ONCE per block; per chunk only base pointers move.  Every load is
@@ -124,6 +130,11 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
     int xoff[X_IT], xdst[VEC ? X_IT : 1];
     int hoff[H_IT > 0 ? H_IT : 1], hdst[H_IT > 0 ? H_IT : 1];
     int wch[VEC ? 1 : W_IT], xch[VEC ? 1 : X_IT];             // scalar path: channel-in-chunk (tail chunks)
+    // UNPOOL: per unit the pooled pair / element, its arg-max byte(s), the byte offset into the idx tensor and the code
+    // (row parity * 2 [+ column parity]) an element must carry to receive the gradient
+    float2 xp[UNPOOL ? X_IT : 1];
+    unsigned xi[UNPOOL ? X_IT : 1], hi[UNPOOL && H_IT > 0 ? H_IT : 1];
+    int xioff[UNPOOL ? X_IT : 1], xcode[UNPOOL ? X_IT : 1], hioff[UNPOOL && H_IT > 0 ? H_IT : 1], hcode[UNPOOL && H_IT > 0 ? H_IT : 1];
 
     // ---- part A: global offsets only, so that chunk 0 is in flight while the rest of the index math runs.
     // Raw buffer loads: out-of-range / halo elements get voffset = CLHIP_OOB and read back as 0 from the hardware
@@ -149,8 +160,16 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
             const int nb = rr / (TH + 2), row = rr - nb * (TH + 2);
             const int n = n0 + nb, h = h0 - 1 + row;
             xoff[j] = CLHIP_OOB;
-            if (e < XV_ELEMS && n < N && h >= 0 && h < H)
+            if constexpr (UNPOOL) {
+                xioff[j] = CLHIP_OOB;
+                xcode[j] = (h & 1) << 1;
+                if (e < XV_ELEMS && n < N && h >= 0 && h < H) {
+                    xioff[j] = (int)(((size_t)nb * Cin + cl) * plane_in) + (h >> 1) * Wp + ((w0 + 4 * f) >> 1);
+                    xoff[j] = xioff[j] * 4;
+                }
+            } else if (e < XV_ELEMS && n < N && h >= 0 && h < H) {
                 xoff[j] = ((int)(((size_t)nb * Cin + cl) * plane_hw) + h * W + w0 + 4 * f) * 4;
+            }
         }
 #pragma unroll
         for (int j = 0; j < H_IT; ++j) {
@@ -160,8 +179,16 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
             const int nb = rr / (TH + 2), row = rr - nb * (TH + 2);
             const int n = n0 + nb, h = h0 - 1 + row, w = side ? w0 + TW : w0 - 1;
             hoff[j] = CLHIP_OOB;
-            if (e < XROWS * 2 && n < N && h >= 0 && h < H && w >= 0 && w < W)
+            if constexpr (UNPOOL) {
+                hioff[j] = CLHIP_OOB;
+                hcode[j] = ((h & 1) << 1) | (w & 1);
+                if (e < XROWS * 2 && n < N && h >= 0 && h < H && w >= 0 && w < W) {
+                    hioff[j] = (int)(((size_t)nb * Cin + cl) * plane_in) + (h >> 1) * Wp + (w >> 1);
+                    hoff[j] = hioff[j] * 4;
+                }
+            } else if (e < XROWS * 2 && n < N && h >= 0 && h < H && w >= 0 && w < W) {
                 hoff[j] = ((int)(((size_t)nb * Cin + cl) * plane_hw) + h * W + w) * 4;
+            }
         }
     } else {
 #pragma unroll
@@ -197,7 +224,9 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
         }
     }
     const __amdgpu_buffer_rsrc_t rs_w = clhip_rsrc(wt, (size_t)Kw * Cw * 9 * sizeof(float));
-    const __amdgpu_buffer_rsrc_t rs_x = clhip_rsrc(in_blk, (size_t)(N - n0) * Cin * plane_hw * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rs_x = clhip_rsrc(in_blk, (size_t)(N - n0) * Cin * plane_in * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rs_i = clhip_rsrc(UNPOOL ? pool_idx + (size_t)n0 * Cin * plane_in : pool_idx,
+                                                   UNPOOL ? (size_t)(N - n0) * Cin * plane_in : 0);
 
     // unit u of chunk `chunk` -> staging registers.  Chunks past the end load nothing (every voffset OOB).
     auto load_unit = [&](int u, int chunk) {
@@ -207,11 +236,22 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
         const int c0 = chunk * CK;
         const bool live = chunk < n_chunks;                                   // wave-uniform
         const int wb = (MODE == 0 ? c0 * 9 : c0 * Cw * 9) * (int)sizeof(float);
-        const int xb = c0 * (int)plane_hw * (int)sizeof(float);
+        const int xb = c0 * (int)plane_in * (int)sizeof(float);
         if constexpr (VEC) {
             if (u < W_IT) wv[u] = clhip_buf_load4(rs_w, live ? woff[u] : CLHIP_OOB, live ? wb : 0);
-            else if (u < W_IT + X_IT) xv[u - W_IT] = clhip_buf_load4(rs_x, live ? xoff[u - W_IT] : CLHIP_OOB, live ? xb : 0);
-            else hv[u - W_IT - X_IT] = clhip_buf_load(rs_x, live ? hoff[u - W_IT - X_IT] : CLHIP_OOB, live ? xb : 0);
+            else if (u < W_IT + X_IT) {
+                const int j = u - W_IT;
+                if constexpr (UNPOOL) {
+                    xp[j] = clhip_buf_load2(rs_x, live ? xoff[j] : CLHIP_OOB, live ? xb : 0);
+                    xi[j] = clhip_buf_load_u16(rs_i, live ? xioff[j] : CLHIP_OOB, live ? xb / 4 : 0);
+                } else {
+                    xv[j] = clhip_buf_load4(rs_x, live ? xoff[j] : CLHIP_OOB, live ? xb : 0);
+                }
+            } else {
+                const int j = u - W_IT - X_IT;
+                hv[j] = clhip_buf_load(rs_x, live ? hoff[j] : CLHIP_OOB, live ? xb : 0);
+                if constexpr (UNPOOL) hi[j] = clhip_buf_load_u8(rs_i, live ? hioff[j] : CLHIP_OOB, live ? xb / 4 : 0);
+            }
         } else {
             const int cleft = live ? Cin - c0 : 0;               // channels left (>= CK except in the tail chunk)
             if (u < W_IT) wreg[u] = clhip_buf_load(rs_w, wch[u] < cleft ? woff[u] : CLHIP_OOB, live ? wb : 0);
@@ -300,11 +340,20 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
                 const int j = u - W_IT;
                 if (256 * (j + 1) <= XV_ELEMS || tid + 256 * j < XV_ELEMS) {
                     float* d = xs + xdst[j];
-                    d[0] = xv[j].x; d[1] = xv[j].y; d[2] = xv[j].z; d[3] = xv[j].w;
+                    if constexpr (UNPOOL) {
+                        // four columns of one row = two pooling windows: the element whose position code the forward
+                        // pass recorded gets the window's gradient, the others 0 (max_pool2d backward)
+                        const int c = xcode[j], i0 = (int)(xi[j] & 0xffu), i1 = (int)((xi[j] >> 8) & 0xffu);
+                        d[0] = i0 == c ? xp[j].x : 0.f; d[1] = i0 == c + 1 ? xp[j].x : 0.f;
+                        d[2] = i1 == c ? xp[j].y : 0.f; d[3] = i1 == c + 1 ? xp[j].y : 0.f;
+                    } else {
+                        d[0] = xv[j].x; d[1] = xv[j].y; d[2] = xv[j].z; d[3] = xv[j].w;
+                    }
                 }
             } else {
                 const int j = u - W_IT - X_IT;
-                if (256 * (j + 1) <= XROWS * 2 || tid + 256 * j < XROWS * 2) xs[hdst[j]] = hv[j];
+                if (256 * (j + 1) <= XROWS * 2 || tid + 256 * j < XROWS * 2)
+                    xs[hdst[j]] = (!UNPOOL || (int)hi[j] == hcode[j]) ? hv[j] : 0.f;
             }
         } else {
             if (u < W_IT) {
@@ -400,7 +449,15 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
 #endif
                     if (cp == 0) {
 #pragma unroll
-                        for (int u = slot * UPS; u < (slot + 1) * UPS && u < NUNITS; ++u) store_unit(u, bn);
+                        for (int u = slot * UPS; u < (slot + 1) * UPS && u < NUNITS; ++u) {
+#ifdef CLHIP_ABL_NOWSTORE          // tuning aid: weight tiles stay those of chunks 0 / 1 (valid data, wrong results)
+                            if (u < W_IT && chunk >= 1) continue;
+#endif
+#ifdef CLHIP_ABL_NOXSTORE
+                            if (u >= W_IT && chunk >= 1) continue;
+#endif
+                            store_unit(u, bn);
+                        }
                     }
                     if (cp == CP_LD) {
 #pragma unroll
@@ -509,7 +566,7 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
 #endif
 }
 
-template <int TW, int TH, int NB, int CK, int MODE, bool VEC>
+template <int TW, int TH, int NB, int CK, int MODE, bool VEC, bool UNPOOL = false>
 int launch_geo(const float* in, const float* wt, const float* bias, const float* mask_src, float* out,
                int N, int Cin, int Cout, int H, int W, int Kw, int Cw, int relu, hipStream_t s, uint8_t* pool_idx) {
     int tiles_w = (W + TW - 1) / TW, tiles_h = (H + TH - 1) / TH, ngrp = (N + NB - 1) / NB;
@@ -517,7 +574,7 @@ int launch_geo(const float* in, const float* wt, const float* bias, const float*
     int kts = (Cout + KT - 1) / KT;
     long long blocks = (long long)n_pix_tiles * kts;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return CLHIP_EINVAL;
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<TW, TH, NB, CK, MODE, VEC>), dim3((unsigned)blocks), dim3(256), 0, s,
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<TW, TH, NB, CK, MODE, VEC, UNPOOL>), dim3((unsigned)blocks), dim3(256), 0, s,
                        in, wt, bias, mask_src, out, N, Cin, Cout, H, W, Kw, Cw, relu, tiles_w, tiles_h, n_pix_tiles, pool_idx);
     CLHIP_LAUNCH_CHECK();
     return 0;
@@ -525,7 +582,7 @@ int launch_geo(const float* in, const float* wt, const float* bias, const float*
 
 // Tile geometry choice: full 128-pixel tiles while they still give more blocks than CUs,
 // otherwise 64-pixel tiles (deep layers at 8x8 have few pixels).
-template <int CK, int MODE, bool VEC>
+template <int CK, int MODE, bool VEC, bool UNPOOL = false>
 int launch_conv(const float* in, const float* wt, const float* bias, const float* mask_src, float* out,
                 int N, int Cin, int Cout, int H, int W, int Kw, int Cw, int relu, hipStream_t s,
                 uint8_t* pool_idx = nullptr) {
@@ -533,8 +590,11 @@ int launch_conv(const float* in, const float* wt, const float* bias, const float
     const long long pix = (long long)N * H * W;
     // measured on small_VGG9 at N=200: 400 blocks of 128 pixels beat 800 of 64 (47 vs 51 us at 16x16: one A fragment
     // feeds two MFMAs), 200 of 128 lose to 400 of 64 at 8x8 (too few blocks for 256 CUs)
-    const bool big = (pix / 128) * kts >= 300;
-#define GEO(TW_, TH_, NB_) launch_geo<TW_, TH_, NB_, CK, MODE, VEC>(in, wt, bias, mask_src, out, N, Cin, Cout, H, W, Kw, Cw, relu, s, pool_idx)
+#ifndef CLHIP_BIG_MIN
+#define CLHIP_BIG_MIN 300
+#endif
+    const bool big = (pix / 128) * kts >= CLHIP_BIG_MIN;
+#define GEO(TW_, TH_, NB_) launch_geo<TW_, TH_, NB_, CK, MODE, VEC, UNPOOL>(in, wt, bias, mask_src, out, N, Cin, Cout, H, W, Kw, Cw, relu, s, pool_idx)
     if (W > 16) return big ? GEO(32, 4, 1) : GEO(32, 2, 1);
     if (W > 8) return big ? GEO(16, 8, 1) : GEO(16, 4, 1);
     return (big && H > 4) ? GEO(8, 8, 2) : GEO(8, 8, 1);
@@ -798,6 +858,17 @@ int clhip_conv3x3_bwd_data(const float* dy, const float* w, const float* relu_sr
     if (vec_ok(dy, w, K, H, W, C))
         return launch_conv<8, 1, true>(dy, w, nullptr, relu_src, dx, N, K, C, H, W, K, C, 0, as_stream(stream));
     return launch_conv<8, 1, false>(dy, w, nullptr, relu_src, dx, N, K, C, H, W, K, C, 0, as_stream(stream));
+}
+
+// Backward-data of a conv whose ReLU output was 2x2-max-pooled, straight from the gradient w.r.t. the POOLED output and
+// the arg-max codes (no un-pooled gradient tensor, no clhip_maxpool2_bwd launch).  Aligned shapes only (the 16-byte
+// staging path): CLHIP_ENOTSUP otherwise, callers then un-pool first.
+int clhip_conv3x3_bwd_data_unpool(const float* dy_pool, const uint8_t* idx_u8, const float* w, const float* relu_src, float* dx,
+                                  int N, int C, int K, int H, int W, void* stream) {
+    if (!dy_pool || !idx_u8 || !w || !dx || N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0) return CLHIP_EINVAL;
+    if ((H & 1) || (W & 1) || !vec_ok(dy_pool, w, K, H, W, C) || (reinterpret_cast<uintptr_t>(idx_u8) & 1u)) return CLHIP_ENOTSUP;
+    return launch_conv<8, 1, true, true>(dy_pool, w, nullptr, relu_src, dx, N, K, C, H, W, K, C, 0, as_stream(stream),
+                                         const_cast<uint8_t*>(idx_u8));
 }
 
 }  // extern "C"

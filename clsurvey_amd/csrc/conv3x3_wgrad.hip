@@ -68,11 +68,14 @@ __device__ __forceinline__ void decode_stage(int st, int tiles_w, int tiles_h, i
 #ifndef CLHIP_WGRAD_PS_WAVES
 #define CLHIP_WGRAD_PS_WAVES 1
 #endif
-template <int TW, int TH, bool VEC, bool PS>
+// UNPOOL (VEC only): `dy` is the gradient w.r.t. the 2x2-max-POOLED output [N][K][H/2][W/2] and `unpool_idx` the arg-max
+// codes of the forward pass; the un-pooled dy tile is rebuilt while it is staged (fused max_pool2d backward).
+template <int TW, int TH, bool VEC, bool PS, bool UNPOOL = false>
 __global__ __launch_bounds__(256, CLHIP_WGRAD_PS_WAVES) void conv3x3_wgrad_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
     int N, int C, int K, int H, int W, int tiles_w, int tiles_h,
-    int total_stages, int splits, int c_tiles, size_t slab_stride) {
+    int total_stages, int splits, int c_tiles, size_t slab_stride, const uint8_t* __restrict__ unpool_idx) {
+    static_assert(!UNPOOL || VEC, "the fused un-pool lives in the 16-byte staging path");
     using G = WGeo<TW, TH>;
     constexpr int KTt = PS ? 32 : 64, CTt = PS ? 32 : 64;
     constexpr int DYS_FLOATS = KTt * G::LDP, XS_FLOATS = CTt * G::PLANEP;
@@ -105,6 +108,7 @@ __global__ __launch_bounds__(256, CLHIP_WGRAD_PS_WAVES) void conv3x3_wgrad_kerne
     double bsum = 0.0;      // bias sums cancel heavily: accumulate in f64 (VALU has slack)
 
     const int plane_hw = H * W;
+    const int Wp = W >> 1, plane_dy = UNPOOL ? (H >> 1) * Wp : plane_hw;       // plane of the tensor `dy` points at
 
     // ------------------------------------------------------------------ staging units
     // Every unit is ONE raw buffer load per thread (+ the LDS writes of its result).  The buffer of a stage starts at
@@ -122,6 +126,8 @@ __global__ __launch_bounds__(256, CLHIP_WGRAD_PS_WAVES) void conv3x3_wgrad_kerne
     float hv[H_IT > 0 ? H_IT : 1];
     float dyr[VEC ? 1 : DY_IT], xr[VEC ? 1 : X_IT];
     int dyoff[DY_IT], dydst[DY_IT], dyrow[DY_IT];      // byte offset | LDS float offset | tile row (scalar path: | col << 8)
+    float2 dyp[UNPOOL ? DY_IT : 1];                    // UNPOOL: pooled pair + its two arg-max bytes per unit
+    unsigned dyi[UNPOOL ? DY_IT : 1];
     int xoff[X_IT], xdst[X_IT], xrc[X_IT];             // byte offset from the halo origin | LDS float offset | halo row | col << 8
     int hoff[H_IT > 0 ? H_IT : 1], hdst[H_IT > 0 ? H_IT : 1], hrc[H_IT > 0 ? H_IT : 1];
 
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(256, CLHIP_WGRAD_PS_WAVES) void conv3x3_wgrad_kerne
             const int e = tid + 256 * j;                     // float4 index: (kl, 16 float4 per k)
             const int kl = e / (G::BP / 4), f = e - kl * (G::BP / 4);
             const int q = 4 * f, th = q / TW, tw = q - th * TW;
-            dyoff[j] = (kl * plane_hw + th * W + tw) * 4;
+            dyoff[j] = UNPOOL ? (kl * plane_dy + (th >> 1) * Wp + (tw >> 1)) * 4 : (kl * plane_hw + th * W + tw) * 4;
             dydst[j] = kl * G::LDP + q;
             dyrow[j] = th;
         }
@@ -189,21 +195,27 @@ __global__ __launch_bounds__(256, CLHIP_WGRAD_PS_WAVES) void conv3x3_wgrad_kerne
     // descriptors + tile origin of the stage whose loads are being issued (set by begin_stage, used by load_unit).
     // The (image, channel block) base pointers step by one image when the stage walk wraps; per stage only the tile
     // origin inside the plane changes (32-bit), so a stage costs ~25 scalar instructions, not two 64-bit multiplies.
-    __amdgpu_buffer_rsrc_t rs_dy = clhip_rsrc(dy, 0), rs_x = clhip_rsrc(x, 0);
+    __amdgpu_buffer_rsrc_t rs_dy = clhip_rsrc(dy, 0), rs_x = clhip_rsrc(x, 0), rs_di = clhip_rsrc(x, 0);
     int ld_h0 = 0, ld_w0 = 0;
-    const float* dy_img = dy + ((size_t)cur_n * K + k0) * plane_hw;
+    const float* dy_img = dy + ((size_t)cur_n * K + k0) * plane_dy;
+    const uint8_t* di_img = UNPOOL ? unpool_idx + ((size_t)cur_n * K + k0) * plane_dy : nullptr;
     const float* x_img = x + ((size_t)cur_n * C + c0) * plane_hw;
-    const long long dy_blk = (long long)(K - k0) * plane_hw, x_blk = (long long)(C - c0) * plane_hw;   // floats to the end of the block
+    const long long dy_blk = (long long)(K - k0) * plane_dy, x_blk = (long long)(C - c0) * plane_hw;   // floats to the end of the block
     auto begin_stage = [&](bool live) {
         const int h0 = cur_th * TH, w0 = cur_tw * TW;
         ld_h0 = h0; ld_w0 = w0;
         const int org = h0 * W + w0;                                         // tile origin inside a plane
-        const long long dy_left = dy_blk - org, x_left = x_blk - (org - W - 1);
-        rs_dy = clhip_rsrc(dy_img + org, live && dy_left > 0 ? (size_t)dy_left * 4 : 0);
+        const int org_dy = UNPOOL ? (h0 >> 1) * Wp + (w0 >> 1) : org;         // ... of the (pooled) dy plane
+        const long long dy_left = dy_blk - org_dy, x_left = x_blk - (org - W - 1);
+        rs_dy = clhip_rsrc(dy_img + org_dy, live && dy_left > 0 ? (size_t)dy_left * 4 : 0);
+        if constexpr (UNPOOL) rs_di = clhip_rsrc(di_img + org_dy, live && dy_left > 0 ? (size_t)dy_left : 0);
         rs_x = clhip_rsrc(x_img + org - W - 1, live && x_left > 0 ? (size_t)x_left * 4 : 0);
         if (++cur_tw == tiles_w) {
             cur_tw = 0;
-            if (++cur_th == tiles_h) { cur_th = 0; ++cur_n; dy_img += (size_t)K * plane_hw; x_img += (size_t)C * plane_hw; }
+            if (++cur_th == tiles_h) {
+                cur_th = 0; ++cur_n; dy_img += (size_t)K * plane_dy; x_img += (size_t)C * plane_hw;
+                if constexpr (UNPOOL) di_img += (size_t)K * plane_dy;
+            }
         }
     };
     auto load_unit = [&](int u) {
@@ -213,7 +225,12 @@ __global__ __launch_bounds__(256, CLHIP_WGRAD_PS_WAVES) void conv3x3_wgrad_kerne
         const int h0 = ld_h0, w0 = ld_w0;
         if constexpr (VEC) {
             if (u < DY_IT) {
-                dyv[u] = clhip_buf_load4(rs_dy, h0 + dyrow[u] < H ? dyoff[u] : CLHIP_OOB, 0);
+                if constexpr (UNPOOL) {
+                    dyp[u] = clhip_buf_load2(rs_dy, h0 + dyrow[u] < H ? dyoff[u] : CLHIP_OOB, 0);
+                    dyi[u] = clhip_buf_load_u16(rs_di, h0 + dyrow[u] < H ? dyoff[u] >> 2 : CLHIP_OOB, 0);
+                } else {
+                    dyv[u] = clhip_buf_load4(rs_dy, h0 + dyrow[u] < H ? dyoff[u] : CLHIP_OOB, 0);
+                }
             } else if (u < DY_IT + X_IT) {
                 const int j = u - DY_IT;
                 xv[j] = clhip_buf_load4(rs_x, (unsigned)(h0 - 1 + xrc[j]) < (unsigned)H ? xoff[j] : CLHIP_OOB, 0);
@@ -242,7 +259,14 @@ __global__ __launch_bounds__(256, CLHIP_WGRAD_PS_WAVES) void conv3x3_wgrad_kerne
         if constexpr (VEC) {
             if (u < DY_IT) {
                 float* d = dys + dydst[u];
-                d[0] = dyv[u].x; d[1] = dyv[u].y; d[2] = dyv[u].z; d[3] = dyv[u].w;
+                if constexpr (UNPOOL) {
+                    // four columns of one row = two pooling windows (tile rows start at even image rows)
+                    const int c = (dyrow[u] & 1) << 1, i0 = (int)(dyi[u] & 0xffu), i1 = (int)((dyi[u] >> 8) & 0xffu);
+                    d[0] = i0 == c ? dyp[u].x : 0.f; d[1] = i0 == c + 1 ? dyp[u].x : 0.f;
+                    d[2] = i1 == c ? dyp[u].y : 0.f; d[3] = i1 == c + 1 ? dyp[u].y : 0.f;
+                } else {
+                    d[0] = dyv[u].x; d[1] = dyv[u].y; d[2] = dyv[u].z; d[3] = dyv[u].w;
+                }
             } else if (u < DY_IT + X_IT) {
                 const int j = u - DY_IT;
                 if (256 * (j + 1) <= XV_ELEMS || tid + 256 * j < XV_ELEMS) {
@@ -730,7 +754,7 @@ static int bwd_weight_impl(const float* x, const float* dy, const uint8_t* unpoo
                            int N, int C, int K, int H, int W, void* ws, size_t ws_bytes, void* stream,
                            clhip_wgrad_job* defer = nullptr) {
     if (!x || !dy || !dw || !ws || N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0) return CLHIP_EINVAL;
-    if (unpool_idx && (C * 9 > 32 || (H & 1) || (W & 1))) return CLHIP_ENOTSUP;
+    if (unpool_idx && ((H & 1) || (W & 1))) return CLHIP_ENOTSUP;
     WPlan p = make_plan(N, C, K, H, W);
     if (ws_bytes < p.ws_floats * sizeof(float)) return CLHIP_ENOSPC;
     hipStream_t s = as_stream(stream);
@@ -745,14 +769,18 @@ static int bwd_weight_impl(const float* x, const float* dy, const uint8_t* unpoo
     } else {
         // 16-byte staging needs aligned rows and whole tiles along w
         const bool vec = (W % 4 == 0) && (W % p.TW == 0) && aligned16(x) && aligned16(dy);
-#define WG_LAUNCH1(TW_, TH_, PS_) do { if (vec) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TW_, TH_, true, PS_>), dim3(grid), dim3(256), 0, s, WG_ARGS, p.c_tiles, p.slab); \
-                                      else hipLaunchKernelGGL((conv3x3_wgrad_kernel<TW_, TH_, false, PS_>), dim3(grid), dim3(256), 0, s, WG_ARGS, p.c_tiles, p.slab); } while (0)
+        if (unpool_idx && (!vec || (reinterpret_cast<uintptr_t>(unpool_idx) & 1u))) return CLHIP_ENOTSUP;
+#define WG_K(TW_, TH_, VEC_, PS_, UNP_) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TW_, TH_, VEC_, PS_, UNP_>), dim3(grid), dim3(256), 0, s, \
+                                                           WG_ARGS, p.c_tiles, p.slab, unpool_idx)
+#define WG_LAUNCH1(TW_, TH_, PS_) do { if (unpool_idx) WG_K(TW_, TH_, true, PS_, true); else if (vec) WG_K(TW_, TH_, true, PS_, false); \
+                                      else WG_K(TW_, TH_, false, PS_, false); } while (0)
 #define WG_LAUNCH(TW_, TH_) do { if (p.ps) WG_LAUNCH1(TW_, TH_, true); else WG_LAUNCH1(TW_, TH_, false); } while (0)
         if (p.TW == 32) WG_LAUNCH(32, 2);
         else if (p.TW == 16) WG_LAUNCH(16, 4);
         else WG_LAUNCH(8, 8);
 #undef WG_LAUNCH
 #undef WG_LAUNCH1
+#undef WG_K
     }
 #undef WG_ARGS
     CLHIP_LAUNCH_CHECK();

@@ -498,9 +498,14 @@ int clhip_net_backward(void* handle, const float* params, float* grads, const fl
         const float* gy = gin;
         int gy_buf = gin_buf;
         bool wdone = false;
-        if (vgg && pool22 && i == 0 && !L.bn) {
-            // no backward-data below the first layer: take the weight gradient straight from the pooled gradient +
-            // argmax (fused max-pool backward), when the kernel supports the shape
+        bool ddone = false;
+        float* gout_d = nullptr;
+        int gout_d_buf = -1;
+        if (vgg && pool22 && !L.bn && L.wg3) {
+            // fused max-pool backward: weight gradient and backward-data both rebuild the un-pooled gradient tile from
+            // the POOLED gradient + the arg-max codes while staging it, when their kernels support the shape (first
+            // layer: the small-C kernel; others: the 16-byte staging paths).  The 4x larger un-pooled tensor and the
+            // clhip_maxpool2_bwd launch disappear.
             rc = on_side(i, gin_buf, [&](void* st) {
                 if (defer)
                     return clhip_internal_conv3x3_wgrad_partial(xin, gin, idx + L.idx_off, grads + L.w_off, grads + L.b_off, N, L.cin,
@@ -511,9 +516,16 @@ int clhip_net_backward(void* handle, const float* params, float* grads, const fl
             });
             if (rc == 0) { wdone = true; if (defer) ++n_jobs; }
             else if (rc != CLHIP_ENOTSUP) return rc;
+            if (wdone && i > 0 && !L.drop && !L.extra_grad) {
+                gout_d = take(); gout_d_buf = taken;
+                rc = clhip_conv3x3_bwd_data_unpool(gin, idx + L.idx_off, params + L.w_off, xin, gout_d, N, L.cin, L.cout, L.h, L.w, stream);
+                if (rc == 0) ddone = true;
+                else if (rc != CLHIP_ENOTSUP) return rc;
+            }
         }
-        if (L.pool && !wdone) {
-            float* gout = take();
+        if (L.pool && !(wdone && (i == 0 || ddone))) {      // somebody still needs the un-pooled gradient
+            float* gout = gout_d;
+            if (gout) taken = gout_d_buf; else gout = take();
             rc = pool22 ? clhip_maxpool2_bwd(gin, idx + L.idx_off, gout, N * L.cout, L.oh, L.ow, stream)
                         : clhip_maxpool_bwd(gin, idx + L.idx_off, gout, N * L.cout, L.oh, L.ow, L.pk, L.ps, stream);
             if (rc) return rc;
@@ -541,7 +553,9 @@ int clhip_net_backward(void* handle, const float* params, float* grads, const fl
             if (rc) return rc;
             if (L.wg3 && defer) ++n_jobs;
         }
-        if (i > 0) {
+        if (i > 0 && ddone) {
+            gin = gout_d; gin_buf = gout_d_buf;
+        } else if (i > 0) {
             float* gout = take();
             rc = vgg ? clhip_conv3x3_bwd_data(gy, params + L.w_off, xin, gout, N, L.cin, L.cout, L.h, L.w, stream)
                      : clhip_conv2d_bwd_data(gy, params + L.w_off, xin, gout, N, L.cin, L.h, L.w, L.cout, L.ks, L.ks, L.st, L.pd, stream);

@@ -88,6 +88,18 @@ def conv3x3_bwd_data(dy, w, relu_src=None):
     return dx
 
 
+def conv3x3_bwd_data_unpool(dy_pool, idx, w, relu_src=None):
+    """backward-data from the POOLED gradient + arg-max codes (fused max-pool backward); raises ClhipError
+    (CLHIP_ENOTSUP) on shapes outside the 16-byte staging path."""
+    _chk(dy_pool, idx, w, relu_src)
+    N, K, Hp, Wp = dy_pool.shape
+    C = w.shape[1]
+    dx = torch.empty((N, C, 2 * Hp, 2 * Wp), dtype=torch.float32, device=dy_pool.device)
+    check(_lib.lib().clhip_conv3x3_bwd_data_unpool(_ptr(dy_pool), _ptr(idx), _ptr(w), _ptr(relu_src), _ptr(dx), N, C, K,
+                                                   2 * Hp, 2 * Wp, _stream()), "clhip_conv3x3_bwd_data_unpool")
+    return dx
+
+
 def conv3x3_bwd_weight(x, dy, need_bias=True):
     _chk(x, dy)
     N, C, H, W = x.shape

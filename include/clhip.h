@@ -64,6 +64,13 @@ int clhip_conv3x3_bwd_weight(const float* x, const float* dy, float* dw, float* 
                              int N, int C, int K, int H, int W, void* ws, size_t ws_bytes,
                              void* stream);
 
+/* Backward-data of a conv whose ReLU output was 2x2-max-pooled, from the gradient w.r.t. the POOLED output + arg-max
+ * codes (fused max_pool2d backward, as clhip_conv3x3_bwd_weight_unpool below).  16-byte-staging shapes only (K % 8 == 0,
+ * C % 4 == 0, W % 4 == 0, whole tiles along w, aligned pointers): CLHIP_ENOTSUP otherwise.  relu_src as in
+ * clhip_conv3x3_bwd_data.                                                                                      */
+int clhip_conv3x3_bwd_data_unpool(const float* dy_pool, const uint8_t* idx_u8, const float* w, const float* relu_src,
+                                  float* dx, int N, int C, int K, int H, int W, void* stream);
+
 /* The same computation in two calls, for callers that defer the reduction (the plan executor reduces the slabs of
  * every layer of a backward pass in ONE launch): `_slabs` writes the per-split partial sums into ws and reports their
  * count, `_reduce` adds them in the fixed order of clhip_conv3x3_bwd_weight (bitwise the same dw / db).
@@ -72,9 +79,9 @@ int clhip_conv3x3_bwd_weight_slabs(const float* x, const float* dy, const uint8_
                                    int H, int W, void* ws, size_t ws_bytes, int* splits_out, void* stream);
 int clhip_conv3x3_bwd_weight_reduce(const void* ws, float* dw, float* db, int K, int C, int splits, void* stream);
 
-/* Same from the gradient w.r.t. the POOLED output + argmax (fused max_pool2d backward). Implemented for the
- * first-layer kernel (C*9 <= 32); returns CLHIP_ENOTSUP otherwise (callers then un-pool with
- * clhip_maxpool2_bwd first).                                                                             */
+/* Same from the gradient w.r.t. the POOLED output + argmax (fused max_pool2d backward).  Implemented for the first-layer
+ * kernel (C*9 <= 32) and for the 16-byte staging path of the general kernel (W % 4 == 0, whole tiles along w, aligned
+ * pointers); returns CLHIP_ENOTSUP otherwise (callers then un-pool with clhip_maxpool2_bwd first).          */
 int clhip_conv3x3_bwd_weight_unpool(const float* x, const float* dy_pool, const uint8_t* idx_u8, float* dw, float* db,
                                     int N, int C, int K, int H, int W, void* ws, size_t ws_bytes, void* stream);
 

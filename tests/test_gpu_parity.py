@@ -1561,3 +1561,29 @@ def test_gem_observe_device_qp_equals_host_path():
     assert outs[0][1] == outs[1][1] and any(c > 0 for c in outs[0][1]), outs[0][1]
     for a, b in zip(outs[0][0], outs[1][0]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("N,C,K,hw", [(7, 64, 64, 32), (5, 64, 128, 16), (9, 128, 128, 8), (3, 32, 24, 16), (200, 64, 64, 32)])
+def test_fused_unpool_is_bitwise_maxpool_backward(N, C, K, hw):
+    """clhip_conv3x3_bwd_data_unpool and clhip_conv3x3_bwd_weight_unpool (general kernel) rebuild the un-pooled gradient
+    tile from the pooled gradient + arg-max codes while staging it: the arithmetic that follows is the unfused kernels',
+    so dx, dW and db must equal maxpool2_bwd followed by the plain kernels BIT FOR BIT; the two-call form
+    (slabs + reduce) must equal clhip_conv3x3_bwd_weight likewise."""
+    from clsurvey_amd import ops
+    gen = np.random.RandomState(N + C + hw)
+    x = rnd(gen, N, C, hw, hw).to(dev())
+    w = (rnd(gen, K, C, 3, 3) * 0.1).to(dev())
+    b = rnd(gen, K).to(dev())
+    y_pool, idx = ops.conv3x3_relu_pool_fwd(x, w, b)
+    dyp = rnd(gen, *y_pool.shape).to(dev()) * (y_pool > 0)
+    dy = ops.maxpool2_bwd(dyp, idx)
+    assert dy.shape == (N, K, hw, hw)
+    dx_ref = ops.conv3x3_bwd_data(dy, w, x)
+    dw_ref, db_ref = ops.conv3x3_bwd_weight(x, dy)
+    dx = ops.conv3x3_bwd_data_unpool(dyp, idx, w, x)
+    dw, db = ops.conv3x3_bwd_weight_unpool(x, dyp, idx)
+    assert torch.equal(dx, dx_ref)
+    assert torch.equal(dw, dw_ref) and torch.equal(db, db_ref)
+    ws, splits = ops.conv3x3_bwd_weight_slabs(x, dy)
+    dw2, db2 = ops.conv3x3_bwd_weight_reduce(ws, splits, K, C)
+    assert torch.equal(dw2, dw_ref) and torch.equal(db2, db_ref)

@@ -1,6 +1,7 @@
+"""Build experimental variants libclhip_<name>.so: mkvars.py <source.hip> name=DEF1,DEF2=val ..."""
 import sys
 from clsurvey_amd import build as b
 src = sys.argv[1]
-for name in sys.argv[2:]:
-    defs = ["CLHIP_ABL_" + d.upper() for d in name.split("+")]
-    print(b.build_variant(name.replace("+", "_"), [src], defs, verbose=False))
+for spec in sys.argv[2:]:
+    name, defs = spec.split("=", 1) if "=" in spec else (spec, "CLHIP_ABL_" + spec.upper())
+    print(b.build_variant(name, [src], defs.split(","), verbose=False))
