@@ -93,7 +93,7 @@ def parse():
     return ap.parse_args()
 
 
-def conv_instance(C, H, W, N, K, mode, pool):
+def conv_instance(C, H, W, N, K, mode, pool, unpool=False):
     """Name of the kernel the library launches for this layer (mirrors launch_conv / clhip_conv3x3_relu_pool_fwd in
     csrc/conv3x3.hip), so that the roofline entry can be matched against the rocprofv3 kernel stats in profiles/."""
     if mode == 0 and pool and C == 3 and W % 32 == 0:
@@ -107,7 +107,7 @@ def conv_instance(C, H, W, N, K, mode, pool):
     else:
         geo = (8, 8, 2) if (big and H > 4) else (8, 8, 1)
     ck, vec = (4, "false") if C <= 4 else (8, "true" if (C % 8 == 0 and W % 4 == 0 and W % geo[0] == 0) else "false")
-    return "conv3x3_mfma_kernel<%d, %d, %d, %d, %d, %s>" % (geo[0], geo[1], geo[2], ck, mode, vec)
+    return "conv3x3_mfma_kernel<%d, %d, %d, %d, %d, %s, %s>" % (geo[0], geo[1], geo[2], ck, mode, vec, "true" if unpool else "false")
 
 
 def time_kernels(eng, x, N, iters):
@@ -149,18 +149,30 @@ def time_kernels(eng, x, N, iters):
             t_f = timed(lambda: ops.conv3x3_fwd(xin, m.weight.data, m.bias.data, True))
             rows.append(dict(kernel="conv3x3_fwd", layer=layer, flops=fl, sec=t_f,
                              instance=conv_instance(C, H, W, N, K, 0, False), alg_bytes=4.0 * N * H * W * (C + K)))
-        if C == 3 and pool:
+        if pool:
             dyp = torch.randn_like(yp)
-            # the slab kernel alone, as the plan executor launches it (the slabs of all layers are reduced by ONE
-            # wgrad_reduce_multi launch at the end of backward: its row is in profiles/*kernel_stats.csv)
+        # the slab kernel alone, as the plan executor launches it (the slabs of all layers are reduced by ONE
+        # wgrad_reduce_multi launch at the end of backward: its row is in profiles/*kernel_stats.csv); on pooled layers
+        # both backward kernels take the POOLED gradient + arg-max bytes and rebuild the un-pooled tile while staging
+        if C == 3 and pool:
             t_w = timed(lambda: ops.conv3x3_bwd_weight_slabs(xin, dyp, idx))
             rows.append(dict(kernel="conv3x3_bwd_weight_unpool", layer=layer, flops=fl, sec=t_w,
                              instance="conv3x3_wgrad_smallc_kernel", alg_bytes=4.0 * N * H * W * (C + K / 4.0)))
+        elif pool:
+            t_w = timed(lambda: ops.conv3x3_bwd_weight_slabs(xin, dyp, idx))
+            rows.append(dict(kernel="conv3x3_bwd_weight_unpool", layer=layer, flops=fl, sec=t_w,
+                             instance="conv3x3_wgrad_kernel<..., UNPOOL=true> (slabs; reduction deferred)",
+                             alg_bytes=4.0 * N * H * W * (C + K / 4.0) + 1.0 * N * K * H * W / 4))
         else:
             t_w = timed(lambda: ops.conv3x3_bwd_weight_slabs(xin, dy))
             rows.append(dict(kernel="conv3x3_bwd_weight", layer=layer, flops=fl, sec=t_w,
                              instance="conv3x3_wgrad_kernel (slabs; reduction deferred)", alg_bytes=4.0 * N * H * W * (C + K)))
-        if C > 3:
+        if C > 3 and pool:
+            t_d = timed(lambda: ops.conv3x3_bwd_data_unpool(dyp, idx, m.weight.data, xin))
+            rows.append(dict(kernel="conv3x3_bwd_data_unpool", layer=layer, flops=fl, sec=t_d,
+                             instance=conv_instance(K, H, W, N, C, 1, False, True),
+                             alg_bytes=4.0 * N * H * W * (2 * C + K / 4.0) + 1.0 * N * K * H * W / 4))
+        elif C > 3:
             t_d = timed(lambda: ops.conv3x3_bwd_data(dy, m.weight.data, xin))
             rows.append(dict(kernel="conv3x3_bwd_data", layer=layer, flops=fl, sec=t_d,
                              instance=conv_instance(K, H, W, N, C, 1, False), alg_bytes=4.0 * N * H * W * (2 * C + K)))

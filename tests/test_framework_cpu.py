@@ -264,4 +264,4 @@ def test_traffic_json_names_the_kernel_bench_reports():
     assert e["instance"] == inst, (e["instance"], inst)
     assert bench.measured_traffic("conv3x3_relu_pool_fwd", "64x64@32", 200, inst) == e["hbm_bytes_per_launch"]
     assert bench.measured_traffic("conv3x3_relu_pool_fwd", "64x64@32", 200, "conv3x3_mfma_kernel<other>") is None
-    assert t["conv3x3_bwd_data 64x64@32 N=200"]["instance"] == bench.conv_instance(64, 32, 32, 200, 64, 1, False)
+    assert t["conv3x3_bwd_data_unpool 64x64@32 N=200"]["instance"] == bench.conv_instance(64, 32, 32, 200, 64, 1, False, True)

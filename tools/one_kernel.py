@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Run ONE conv entry point a few times (for rocprofv3 --pmc passes).
-usage: python tools/one_kernel.py {c3pool|fwdpool|fwd|dgrad|wgrad} N C K HW [iters]"""
+usage: python tools/one_kernel.py {c3pool|fwdpool|fwd|dgrad|dgrad_unpool|wgrad} N C K HW [iters]"""
 import os
 import sys
 
@@ -17,7 +17,9 @@ x = torch.randn(N, C, HW, HW, device=dev)
 w = torch.randn(K, C, 3, 3, device=dev) * 0.05
 b = torch.zeros(K, device=dev)
 dy = torch.randn(N, K, HW, HW, device=dev)
-fn = {"c3pool": lambda: ops.conv3x3_relu_pool_fwd(x, w, b), "fwdpool": lambda: ops.conv3x3_relu_pool_fwd(x, w, b), "fwd": lambda: ops.conv3x3_fwd(x, w, b, True),
+yp, idx = ops.conv3x3_relu_pool_fwd(x, w, b)
+dyp = torch.randn_like(yp)
+fn = {"dgrad_unpool": lambda: ops.conv3x3_bwd_data_unpool(dyp, idx, w, x), "c3pool": lambda: ops.conv3x3_relu_pool_fwd(x, w, b), "fwdpool": lambda: ops.conv3x3_relu_pool_fwd(x, w, b), "fwd": lambda: ops.conv3x3_fwd(x, w, b, True),
       "dgrad": lambda: ops.conv3x3_bwd_data(dy, w, x), "wgrad": lambda: ops.conv3x3_bwd_weight(x, dy)}[kind]
 for _ in range(iters):
     fn()
