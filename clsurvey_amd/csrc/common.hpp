@@ -87,6 +87,11 @@ struct clhip_fc_chain {
 int clhip_internal_fc_chain_ok(const clhip_fc_chain* d);
 int clhip_internal_fc_chain_wgrad(const clhip_fc_chain* d, float* grads, const float* x, int N, const float* acts,
                                   const float* dlogits, const float* dz, hipStream_t s);
+// fused classifier tail (fc_chain.hip): layers 2..3 forward, cross-entropy, backward-data down to dz of h1
+int clhip_internal_fc_tail_ok(const clhip_fc_chain* d);
+int clhip_internal_fc_tail(const clhip_fc_chain* d, const float* params, float* acts, int N, const int64_t* labels,
+                           int reduction, int col_off, int ncols, float* dlogits, float* fcdz, float* loss_out, double* stats,
+                           void* row_scratch, unsigned* counter, int do_loss, int do_bwd, hipStream_t s);
 
 // conv3x3_wgrad.hip: deferred slab reduction (see clhip_internal_conv3x3_wgrad_partial)
 #define CLHIP_WGRAD_JOBS_MAX 32

@@ -63,6 +63,11 @@ struct NetPlan {
     int fc_first;
     bool fc_fused;
     clhip_fc_chain chain;
+    // layers fc_first+1 .. end forward + cross-entropy + backward-data down to dz(h1) in one launch (fc_tail_kernel); the
+    // arrival counter of its last-workgroup reduction is the plan's own 4 bytes of device memory (zero between launches),
+    // so a plan must not run on two streams at once (it never could: the activations live in one workspace)
+    bool fc_tail;
+    unsigned* tail_counter;
     // backward (optional, CLHIP_WGRAD_OVERLAP=1): the weight-gradient launches of the conv layers run on a side stream
     // next to the backward-data launch of the same layer (both only read dy)
     bool overlap;
@@ -72,6 +77,7 @@ struct NetPlan {
         for (hipEvent_t e : ev_dy) (void)hipEventDestroy(e);
         for (hipEvent_t e : ev_wg) (void)hipEventDestroy(e);
         if (side) (void)hipStreamDestroy(side);
+        if (tail_counter) (void)hipFree(tail_counter);
     }
 };
 
@@ -258,6 +264,20 @@ int clhip_net_create(const clhip_layer_desc* descs, int n_layers, int max_batch,
             p->side = nullptr;
         }
     }
+    p->fc_tail = false;
+    p->tail_counter = nullptr;
+    const char* tl = getenv("CLHIP_FC_TAIL");      // CLHIP_FC_TAIL=0: per-layer launches (the bitwise reference of the fused tail)
+    if (p->fc_fused && !(tl && tl[0] == '0') && clhip_internal_fc_tail_ok(&p->chain) &&
+        p->scratch_bytes >= (size_t)max_batch * 8 && max_batch <= 1024) {
+        // needs a device: plans made on a host without one (shape tests) keep the per-layer launches
+        if (hipMalloc(reinterpret_cast<void**>(&p->tail_counter), 256) == hipSuccess &&
+            hipMemset(p->tail_counter, 0, 256) == hipSuccess) {
+            p->fc_tail = true;
+        } else {
+            (void)hipGetLastError();
+            if (p->tail_counter) { (void)hipFree(p->tail_counter); p->tail_counter = nullptr; }
+        }
+    }
     *out_handle = p;
     return 0;
 }
@@ -321,8 +341,19 @@ int clhip_net_num_classes(void* handle) { return handle ? static_cast<NetPlan*>(
 
 // Forward pass; activations are kept in ws for a following backward. logits_out (optional) receives
 // a copy of the [N][classes] logits.
-int clhip_net_forward(void* handle, const float* params, const float* x, int N, void* ws, float* logits_out,
-                      void* stream) {
+// tail: 0 = every layer; 1 = stop behind the first Linear layer, the caller launches the fused tail itself (loss step);
+// 2 = stop there and finish with the fused tail, forward only.
+static bool tail_usable(const NetPlan* p, const float* params, const void* ws, int N) {
+    if (!p->fc_tail) return false;
+    for (size_t i = p->fc_first + 1; i < p->layers.size(); ++i)
+        if (p->layers[i].drop || p->layers[i].extra_grad) return false;
+    const float* acts = reinterpret_cast<const float*>(static_cast<const char*>(ws) + p->off_acts);
+    return aligned16(params + p->chain.w_off[1]) && aligned16(params + p->chain.w_off[2]) && aligned16(acts + p->chain.act_off[0]) &&
+           (size_t)N * (p->n_classes | 1) <= 12288;        // the range in which the per-layer path uses softmax_ce_rows_lds_kernel
+}
+
+static int net_forward_impl(void* handle, const float* params, const float* x, int N, void* ws, float* logits_out,
+                            void* stream, int tail) {
     NetPlan* p = static_cast<NetPlan*>(handle);
     if (!p || !params || !x || !ws || N <= 0 || N > p->max_batch) return CLHIP_EINVAL;
     char* base = static_cast<char*>(ws);
@@ -331,7 +362,8 @@ int clhip_net_forward(void* handle, const float* params, const float* x, int N, 
     void* scratch = base + p->off_scratch;
     const float* cur = x;
     int rc;
-    for (size_t li = 0; li < p->layers.size(); ++li) {
+    const size_t n_run = tail ? (size_t)p->fc_first + 1 : p->layers.size();
+    for (size_t li = 0; li < n_run; ++li) {
         const LayerPlan& L = p->layers[li];
         float* y = acts + L.act_off;
         if (L.drop && L.has_drop_buf) {       // masked copy: backward reads it as this layer's input, cur stays intact
@@ -393,6 +425,13 @@ int clhip_net_forward(void* handle, const float* params, const float* x, int N, 
             cur = y;
         }
     }
+    if (tail == 1) return 0;
+    if (tail == 2) {
+        rc = clhip_internal_fc_tail(&p->chain, params, acts, N, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, scratch,
+                                    p->tail_counter, 0, 0, as_stream(stream));
+        if (rc) return rc;
+        cur = acts + p->layers.back().act_off;
+    }
     if (logits_out) {
         hipError_t e = hipMemcpyAsync(logits_out, cur, (size_t)N * p->n_classes * sizeof(float),
                                       hipMemcpyDeviceToDevice, as_stream(stream));
@@ -401,11 +440,18 @@ int clhip_net_forward(void* handle, const float* params, const float* x, int N, 
     return 0;
 }
 
+int clhip_net_forward(void* handle, const float* params, const float* x, int N, void* ws, float* logits_out,
+                      void* stream) {
+    NetPlan* p = static_cast<NetPlan*>(handle);
+    if (!p || !params || !x || !ws || N <= 0 || N > p->max_batch) return CLHIP_EINVAL;
+    return net_forward_impl(handle, params, x, N, ws, logits_out, stream, tail_usable(p, params, ws, N) ? 2 : 0);
+}
+
 // Backward pass from dlogits[N][classes] (device) through the activations saved by the last
 // clhip_net_forward on the same ws.  Writes every parameter gradient into `grads` (same offsets
 // as params; overwritten, not accumulated).
-int clhip_net_backward(void* handle, const float* params, float* grads, const float* x, int N, void* ws,
-                       const float* dlogits, void* stream) {
+static int net_backward_impl(void* handle, const float* params, float* grads, const float* x, int N, void* ws,
+                             const float* dlogits, void* stream, bool tail_done) {
     NetPlan* p = static_cast<NetPlan*>(handle);
     if (!p || !params || !grads || !x || !ws || !dlogits || N <= 0 || N > p->max_batch) return CLHIP_EINVAL;
     char* base = static_cast<char*>(ws);
@@ -457,6 +503,12 @@ int clhip_net_backward(void* handle, const float* params, float* grads, const fl
             const LayerPlan& P = p->layers[i - 1];
             xin = acts + ((P.type == 0 && P.pool) ? P.pool_off : P.act_off);
             if (L.drop && L.has_drop_buf) xin = acts + L.drop_off;
+        }
+        if (L.type == 1 && tail_done && i > p->fc_first) {
+            // the fused tail has already left dz of this layer's input in its fcdz slot
+            gin = fcdz + p->chain.dz_off[i - p->fc_first - 1];
+            gin_buf = -1;
+            continue;
         }
         if (L.type == 1) {
             if (!p->fc_fused) {
@@ -582,6 +634,11 @@ int clhip_net_backward(void* handle, const float* params, float* grads, const fl
     return 0;
 }
 
+int clhip_net_backward(void* handle, const float* params, float* grads, const float* x, int N, void* ws,
+                       const float* dlogits, void* stream) {
+    return net_backward_impl(handle, params, grads, x, N, ws, dlogits, stream, false);
+}
+
 // forward + loss (+ backward when grads != NULL) in one call.
 //   loss_kind 0: CrossEntropy mean   1: CrossEntropy sum   2: sum of squared logits (MAS)
 int clhip_net_loss_step_slice(void* handle, const float* params, float* grads, const float* x, const int64_t* labels,
@@ -592,7 +649,28 @@ int clhip_net_loss_step_slice(void* handle, const float* params, float* grads, c
     char* base = static_cast<char*>(ws);
     float* dlogits = reinterpret_cast<float*>(base + p->off_dlogits);
     float* loss_dev = loss_out ? loss_out : reinterpret_cast<float*>(base + p->off_loss);
-    int rc = clhip_net_forward(handle, params, x, N, ws, logits_out, stream);
+    if (!params || !x || N <= 0 || N > p->max_batch) return CLHIP_EINVAL;
+    const int nc = ncols > 0 ? ncols : p->n_classes - col_off;
+    if (loss_kind != 2 && nc <= 64 && col_off >= 0 && col_off + nc <= p->n_classes && tail_usable(p, params, ws, N)) {
+        // first Linear layer by the GEMM launches, then ONE launch for the rest of the classifier, the loss and the
+        // backward-data chain down to dz(h1); backward resumes at the first Linear layer
+        if (loss_kind != 0 && loss_kind != 1) return CLHIP_EINVAL;
+        int rc = net_forward_impl(handle, params, x, N, ws, nullptr, stream, 1);
+        if (rc) return rc;
+        float* acts = reinterpret_cast<float*>(base + p->off_acts);
+        rc = clhip_internal_fc_tail(&p->chain, params, acts, N, labels, loss_kind, col_off, nc, dlogits,
+                                    reinterpret_cast<float*>(base + p->off_fcdz), loss_dev, stats, base + p->off_scratch,
+                                    p->tail_counter, 1, grads ? 1 : 0, as_stream(stream));
+        if (rc) return rc;
+        if (logits_out) {
+            hipError_t e = hipMemcpyAsync(logits_out, acts + p->layers.back().act_off, (size_t)N * p->n_classes * sizeof(float),
+                                          hipMemcpyDeviceToDevice, as_stream(stream));
+            if (e != hipSuccess) return (int)e;
+        }
+        if (grads) rc = net_backward_impl(handle, params, grads, x, N, ws, dlogits, stream, true);
+        return rc;
+    }
+    int rc = net_forward_impl(handle, params, x, N, ws, logits_out, stream, 0);
     if (rc) return rc;
     const LayerPlan& last = p->layers.back();
     const float* logits = reinterpret_cast<float*>(base + p->off_acts) + last.act_off;

@@ -85,6 +85,239 @@ __global__ __launch_bounds__(256) void fc_chain_wgrad_kernel(FcChain c, FcTileMa
     }
 }
 
+// ---------------------------------------------------------------------------------------------- classifier tail
+// Everything between the first Linear layer's output h1 and the gradient w.r.t. h1, in ONE launch:
+//     h2 = relu(h1 W2^T + b2), z = h2 W3^T + b3, softmax cross-entropy (loss, top-1 hits, dlogits),
+//     dz2 = (dlogits W3) . [h2 > 0], dz1 = (dz2 W2) . [h1 > 0]
+// (models/VGGSlim.py:68-74 with the 128-wide classifiers of small_VGG9_cl_128_128; train_EWC.py:179-186).  The samples
+// of a batch are independent through all of it, so a workgroup owns 32 rows: W2, W3 and the row block of h1 are loaded
+// once into LDS, the products run on the 32x32x2 MFMA with wave w owning output columns 32w..32w+31, activations and
+// gradients go from one product to the next through LDS.  It replaces 2 forward GEMMs, the loss kernel and 2
+// backward-data GEMMs (9.4 + 9.4 + 9.4 + 11.7 + 11.7 us of launch latency per pass at batch 200) by one ~10 us launch.
+//
+// Bit-compatibility with the per-layer path is part of the contract (the end-to-end fixtures are chaotic in the last
+// bit): every product accumulates k in ascending pairs on the same MFMA instruction with the same zero padding to a
+// multiple of 32 as gemm_mfma_kernel with one split, epilogues apply bias / ReLU / mask in the same order, the
+// per-row loss code is the text of softmax_ce_rows_lds_kernel (loss.hip), and the loss / hit totals are formed by the
+// last workgroup to finish in that kernel's order (64-row butterflies, then 16 sequential adds).
+constexpr int TL = 129;            // LDS row stride in floats: odd, so walks along rows and along columns are conflict-free
+constexpr int ZL = 33;
+struct FcTail {
+    long w2, b2, w3, b3;           // float offsets into the parameter arena
+    int d1, d2, d3, relu2, relu3;  // widths of h1, h2, logits
+    size_t a2, a3, dz1, dz2;       // float offsets: h2 / logits in the activation workspace, dz1 / dz2 in the fc gradient scratch
+};
+
+// acc = sum over k (ascending pairs) of A(k) * B(k), K a multiple of 32: operands of 16 MFMAs are fetched from LDS
+// as a batch while the previous batch feeds the matrix pipe (named register batches: no runtime-indexed arrays)
+template <class FA, class FB>
+__device__ __forceinline__ floatx16 tail_mm(int K, FA a_at, FB b_at) {
+    floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float aA[16], bA[16], aB[16], bB[16];
+    auto fetch = [&](int k0, float (&aq)[16], float (&bq)[16]) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { aq[q] = a_at(k0 + 2 * q); bq[q] = b_at(k0 + 2 * q); }
+    };
+    auto run = [&](const float (&aq)[16], const float (&bq)[16]) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[q], bq[q], acc, 0, 0, 0);
+    };
+    fetch(0, aA, bA);
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        const bool hasB = k0 + 32 < K;
+        if (hasB) fetch(k0 + 32, aB, bB);
+        run(aA, bA);
+        if (hasB) {
+            if (k0 + 64 < K) fetch(k0 + 64, aA, bA);
+            run(aB, bB);
+        }
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void fc_tail_kernel(FcTail t, const float* __restrict__ params, const float* __restrict__ h1,
+                                                      float* __restrict__ acts, int N, const int64_t* __restrict__ labels,
+                                                      int reduction, int col_off, int C, float* __restrict__ dlogits,
+                                                      float* __restrict__ fcdz, float* __restrict__ loss_out,
+                                                      double* __restrict__ stats, float* row_loss, int* row_ok,
+                                                      unsigned* counter, int do_loss, int do_bwd) {
+    __shared__ float W2s[128 * TL];
+    __shared__ float W3s[32 * TL];
+    __shared__ float h1s[32 * TL];
+    __shared__ float h2s[32 * TL];
+    __shared__ float dz2s[32 * TL];
+    __shared__ float zs[32 * ZL];
+    __shared__ float w_loss[16];
+    __shared__ int w_corr[16];
+    __shared__ unsigned s_ticket;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kk = lane >> 5;
+    const int m0 = blockIdx.x * 32;
+    const int K1 = (t.d1 + 31) & ~31, K2 = (t.d2 + 31) & ~31;       // padded widths of h1 / h2
+
+    // ---- stage W2 [d2][d1], the h1 row block and W3 [d3][d2]: all loads in flight before the first LDS write;
+    //      everything outside the real extents reads as zero (buffer range check), which is the GEMM kernel's padding
+    const __amdgpu_buffer_rsrc_t r_w2 = clhip_rsrc(params + t.w2, (size_t)t.d2 * t.d1 * 4);
+    const __amdgpu_buffer_rsrc_t r_w3 = clhip_rsrc(params + t.w3, (size_t)t.d3 * t.d2 * 4);
+    const int rows_here = min(32, N - m0);
+    const __amdgpu_buffer_rsrc_t r_h1 = clhip_rsrc(h1 + (size_t)m0 * t.d1, (size_t)rows_here * t.d1 * 4);
+    float4 q2[16], q1[4], q3[4];
+    const int c1 = K1 >> 2, c2 = K2 >> 2;           // float4 columns
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int e = tid + 256 * j, o = e / c1, i = (e - o * c1) * 4;
+        q2[j] = clhip_buf_load4(r_w2, (o < t.d2 && i < t.d1 && e < K2 * c1) ? (o * t.d1 + i) * 4 : CLHIP_OOB, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int e = tid + 256 * j, r = e / c1, i = (e - r * c1) * 4;
+        q1[j] = clhip_buf_load4(r_h1, (r < rows_here && i < t.d1 && e < 32 * c1) ? (r * t.d1 + i) * 4 : CLHIP_OOB, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int e = tid + 256 * j, o = e / c2, i = (e - o * c2) * 4;
+        q3[j] = clhip_buf_load4(r_w3, (o < t.d3 && i < t.d2 && e < 32 * c2) ? (o * t.d2 + i) * 4 : CLHIP_OOB, 0);
+    }
+    auto put4 = [](float* d, const float4& v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int e = tid + 256 * j, r = e / c1, i = (e - r * c1) * 4;
+        if (e < 32 * c1) put4(h1s + r * TL + i, q1[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int e = tid + 256 * j, o = e / c2, i = (e - o * c2) * 4;
+        if (e < 32 * c2) put4(W3s + o * TL + i, q3[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int e = tid + 256 * j, o = e / c1, i = (e - o * c1) * 4;
+        if (e < K2 * c1) put4(W2s + o * TL + i, q2[j]);
+    }
+    __syncthreads();
+
+    const int n0 = wave * 32, n = n0 + li;
+    floatx16 acc;
+    // ---- h2 = relu(h1 . W2^T + b2): wave w owns columns 32w .. 32w+31 of h2
+    if (n0 < K2) {
+        acc = tail_mm(K1, [&](int k) { return h1s[li * TL + k + kk]; }, [&](int k) { return W2s[n * TL + k + kk]; });
+        const float bias = n < t.d2 ? params[t.b2 + n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = mfma32_row(r, lane), m = m0 + row;
+            float v = acc[r];
+            v += bias;
+            if (t.relu2) v = fmaxf(v, 0.f);
+            if (n >= t.d2) v = 0.f;
+            h2s[row * TL + n] = v;
+            if (m < N && n < t.d2) acts[t.a2 + (size_t)m * t.d2 + n] = v;
+        }
+    }
+    __syncthreads();
+    // ---- logits = h2 . W3^T + b3 (one column tile: d3 <= 32)
+    if (wave == 0) {
+        acc = tail_mm(K2, [&](int k) { return h2s[li * TL + k + kk]; }, [&](int k) { return W3s[li * TL + k + kk]; });
+        const float bias = li < t.d3 ? params[t.b3 + li] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = mfma32_row(r, lane), m = m0 + row;
+            float v = acc[r];
+            v += bias;
+            if (t.relu3) v = fmaxf(v, 0.f);
+            if (li >= t.d3) v = 0.f;
+            zs[row * ZL + li] = v;
+            if (m < N && li < t.d3) acts[t.a3 + (size_t)m * t.d3 + li] = v;
+        }
+    }
+    if (!do_loss) return;
+    __syncthreads();
+    // ---- softmax cross-entropy per row: the per-row text of softmax_ce_rows_lds_kernel (loss.hip) — keep in sync
+    const int ld = t.d3;
+    const float scale = reduction == 0 ? 1.f / (float)N : 1.f;
+    if (tid < 32) {
+        const int row = tid, m = m0 + row;
+        float* zr = zs + row * ZL;
+        if (m < N) {
+            float* z = zr + col_off;
+            const int y = (int)labels[m];
+            float mx = -INFINITY;
+            int am = 0;
+            for (int c = 0; c < C; ++c) {
+                float v = z[c];
+                if (v > mx) { mx = v; am = c; }
+            }
+            float se = 0.f;
+            for (int c = 0; c < C; ++c) se += expf(z[c] - mx);
+            const float lse = logf(se);
+            const float lrow = -(z[y] - mx - lse);
+            for (int c = 0; c < ld; ++c) {
+                const int cc = c - col_off;
+                zr[c] = (cc >= 0 && cc < C) ? (expf(zr[c] - mx - lse) - (cc == y ? 1.f : 0.f)) * scale : 0.f;
+            }
+            row_loss[m] = lrow;
+            row_ok[m] = (am == y);
+        } else {
+            for (int c = 0; c < 32; ++c) zr[c] = 0.f;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < 32 * ld; e += 256) {
+        const int row = e / ld, c = e - row * ld;
+        if (m0 + row < N) dlogits[(size_t)(m0 + row) * ld + c] = zs[row * ZL + c];
+    }
+    if (do_bwd) {
+        // ---- dz2 = (dlogits . W3) masked by h2 > 0: K = d3 padded to 32 (zs columns >= d3 and W3s rows >= d3 are zero)
+        if (n0 < K2) {
+            acc = tail_mm(32, [&](int k) { return zs[li * ZL + k + kk]; }, [&](int k) { return W3s[(k + kk) * TL + n]; });
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mfma32_row(r, lane), m = m0 + row;
+                float v = h2s[row * TL + n] > 0.f ? acc[r] : 0.f;
+                if (n >= t.d2) v = 0.f;
+                dz2s[row * TL + n] = v;
+                if (m < N && n < t.d2) fcdz[t.dz2 + (size_t)m * t.d2 + n] = v;
+            }
+        }
+        __syncthreads();
+        // ---- dz1 = (dz2 . W2) masked by h1 > 0
+        if (n0 < K1) {
+            acc = tail_mm(K2, [&](int k) { return dz2s[li * TL + k + kk]; }, [&](int k) { return W2s[(k + kk) * TL + n]; });
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mfma32_row(r, lane), m = m0 + row;
+                const float v = h1s[row * TL + n] > 0.f ? acc[r] : 0.f;
+                if (m < N && n < t.d1) fcdz[t.dz1 + (size_t)m * t.d1 + n] = v;
+            }
+        }
+    }
+    // ---- totals: the last workgroup to arrive sums the per-row values in softmax_ce_rows_lds_kernel's order
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_ticket = atomicAdd(counter, 1u);
+    __syncthreads();
+    if (s_ticket != gridDim.x - 1) return;
+    __threadfence();
+    for (int g = wave; g < 16; g += 4) {
+        const int row = g * 64 + lane;
+        // agent-scope loads: the other workgroups' values come from L2, not from this CU's vector cache
+        float v = row < N ? __hip_atomic_load(row_loss + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+        int cc = row < N ? __hip_atomic_load(row_ok + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { v += __shfl_xor(v, o, 64); cc += __shfl_xor(cc, o, 64); }
+        if (lane == 0) { w_loss[g] = v; w_corr[g] = cc; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float tt = 0.f; int c = 0;
+        for (int w = 0; w < 16; ++w) { tt += w_loss[w]; c += w_corr[w]; }
+        tt *= scale;
+        loss_out[0] = tt;
+        if (stats) { stats[0] += (double)tt; stats[1] += (double)c; }
+        *counter = 0u;
+    }
+}
+
 FcChain to_chain(const clhip_fc_chain* d) {
     FcChain c;
     c.n = d->n;
@@ -115,6 +348,32 @@ int clhip_internal_fc_chain_wgrad(const clhip_fc_chain* d, float* grads, const f
     for (int l = 0; l < c.n; ++l) tm.first[l + 1] = tm.first[l] + ((c.l[l].dout + 31) / 32) * ((c.l[l].din + 31) / 32);
     for (int l = c.n; l < CLHIP_FC_MAX; ++l) tm.first[l + 1] = tm.first[c.n];
     hipLaunchKernelGGL(fc_chain_wgrad_kernel, dim3((tm.first[c.n] + 3) / 4), dim3(256), 0, s, c, tm, x, N, acts, dlogits, dz, grads);
+    CLHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// Envelope of the fused tail: Linear-ReLU-Linear-(ReLU)-Linear with both hidden widths <= 128 (multiples of 4) and at most
+// 32 logits; anything else runs the per-layer launches.
+int clhip_internal_fc_tail_ok(const clhip_fc_chain* d) {
+    if (!d || d->n != 3) return 0;
+    if (d->din[1] != d->dout[0] || d->din[2] != d->dout[1]) return 0;
+    if (d->din[1] > 128 || d->dout[1] > 128 || d->dout[2] > 32) return 0;
+    if ((d->din[1] & 3) || (d->dout[1] & 3)) return 0;
+    if ((d->w_off[1] & 3) || (d->w_off[2] & 3) || (d->act_off[0] & 3)) return 0;
+    return 1;
+}
+
+int clhip_internal_fc_tail(const clhip_fc_chain* d, const float* params, float* acts, int N, const int64_t* labels,
+                           int reduction, int col_off, int ncols, float* dlogits, float* fcdz, float* loss_out, double* stats,
+                           void* row_scratch, unsigned* counter, int do_loss, int do_bwd, hipStream_t s) {
+    FcTail t;
+    t.w2 = d->w_off[1]; t.b2 = d->b_off[1]; t.w3 = d->w_off[2]; t.b3 = d->b_off[2];
+    t.d1 = d->din[1]; t.d2 = d->dout[1]; t.d3 = d->dout[2]; t.relu2 = d->relu[1]; t.relu3 = d->relu[2];
+    t.a2 = d->act_off[1]; t.a3 = d->act_off[2]; t.dz1 = d->dz_off[0]; t.dz2 = d->dz_off[1];
+    float* row_loss = static_cast<float*>(row_scratch);
+    int* row_ok = reinterpret_cast<int*>(row_loss + N);
+    hipLaunchKernelGGL(fc_tail_kernel, dim3((N + 31) / 32), dim3(256), 0, s, t, params, acts + d->act_off[0], acts, N, labels,
+                       reduction, col_off, ncols, dlogits, fcdz, loss_out, stats, row_loss, row_ok, counter, do_loss, do_bwd);
     CLHIP_LAUNCH_CHECK();
     return 0;
 }

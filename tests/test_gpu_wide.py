@@ -1,0 +1,138 @@
+"""Config 5 at its real widths (wide_VGG9_cl_512_512): the HAT training step at 3x64x64 and PackNet's batch step at
+3x64x64 / 3x224x224 against runs of the reference's unchanged code (fixture G20, tests/golden/make_g20.py).
+
+The models have 4.7 M - 56 M parameters: both sides regenerate parameters, batches and owner masks from seeds
+(tests/golden/g20_common.py); the fixture holds the reference's logits / losses / gates in full, gradients and updated
+parameters at sampled positions with float64 checksums, and the sha256 of every PackNet layer's zero bitmap."""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import g20_common as C  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = 1e-3          # north_star: 1e-3 relative in fp32
+
+
+def _load(module, seed):
+    named = [(n, tuple(p.shape)) for n, p in module.named_parameters()]
+    with torch.no_grad():
+        for (n, p), q in zip(module.named_parameters(), C.fill_params(named, seed)):
+            p.copy_(torch.from_numpy(q))
+    return [n for n, _ in named]
+
+
+def _check(g, tag, tensor, seed, what, tol=TOL, flips=False):
+    """sampled values within tol of the tensor's largest sampled magnitude; float64 sum within tol of the sum of magnitudes.
+    flips=True (gradients of a SECOND step: the two runs enter it with parameters that differ in the last bits, so a few
+    ReLU / max-pool decisions of the 8-image batch fall the other way and move individual gradient entries): the sampled
+    values agree in the Euclidean norm to 1e-2 and every entry to 3e-2 of the largest instead."""
+    d = C.digest(tensor.detach().float().cpu().numpy(), seed)
+    ref_v, ref_s = g[tag + "__v"], g[tag + "__s"]
+    assert d["v"].shape == ref_v.shape and d["s"][2] == ref_s[2], what
+    scale = max(float(np.abs(ref_v).max()), 1e-30)
+    err = float(np.abs(d["v"] - ref_v).max()) / scale
+    if flips:
+        l2 = float(np.linalg.norm(d["v"].astype(np.float64) - ref_v) / max(np.linalg.norm(ref_v.astype(np.float64)), 1e-30))
+        assert l2 <= 1e-2 and err <= 3e-2, "%s: l2 %.3e max %.3e" % (what, l2, err)
+        return 0.0
+    assert err <= tol, "%s: sampled rel err %.3e" % (what, err)
+    assert abs(d["s"][0] - ref_s[0]) <= tol * max(ref_s[1], 1e-30), "%s: checksum" % what
+    return err
+
+
+def _raw(hw):
+    from clsurvey_amd import models
+    return models.VGGSlim(cfg=C.WIDE, num_classes=C.NCLS, classifier_inputdim=512 * (hw // 16) ** 2,
+                          classifier_dim1=C.FC[0], classifier_dim2=C.FC[1])
+
+
+def test_hat_step_wide_vgg9_g20(golden):
+    """vgg_hat.Net.forward + Appr.criterion + backward + HAT_SGD.step + clamp at wide_VGG9 widths, two batches of 8
+    (methods/HAT/networks/vgg_hat.py:83-127): second step at s = 171 (steep gates, near the end of the annealing)."""
+    from clsurvey_amd.methods import hat as HT
+    g = golden("G20_wide_widths")
+    smax, lamb, t, lr, mom, wd = [float(v) for v in g["hat64_hyper"]]
+    t = int(t)
+    net = HT.HatNet(_raw(64), (3, 64, 64), [(0, C.NCLS), (1, C.NCLS), (2, C.NCLS)])
+    assert _load(net, 2001) == [str(n) for n in g["hat64_param_names"]]
+    hat = HT.HatEngine(net, 8, (3, 64, 64), DEV)
+    mask_pre, mask_back = HT.init_masks(hat, t, smax)
+    opt = HT.HAT_SGD(net.parameters(), lr=lr, momentum=mom, weight_decay=wd)
+    worst = 0.0
+    for step, s in enumerate((3.1, 171.0)):
+        x, y = (torch.from_numpy(a).to(DEV) for a in C.batch(2100 + step, 8, 64))
+        ce, reg, logits = hat.step(t, x, y, s, mask_pre, lamb, None, True, want_logits=True)
+        ref_logits = g["hat64_s%d_logits" % step]
+        assert float(np.abs(logits.cpu().numpy() - ref_logits).max()) <= TOL * float(np.abs(ref_logits).max())
+        loss_ref, reg_ref = g["hat64_s%d_loss" % step]
+        assert abs(float(ce) + float(reg) - loss_ref) <= TOL * abs(loss_ref) and abs(float(reg) - reg_ref) <= 1e-5 * abs(reg_ref) + 1e-7
+        for j, (n, p) in enumerate(net.named_parameters()):
+            key = "hat64_s%d_grad_%s" % (step, n)
+            if key + "__v" in g.files:
+                worst = max(worst, _check(g, key, p.grad, 2200 + j, "step %d grad %s" % (step, n), flips=step > 0))
+        opt.step(net, mask_back, t, s, 50, smax, 10000)
+        HT.clamp_embeddings(net)
+        for j, (n, p) in enumerate(net.named_parameters()):
+            worst = max(worst, _check(g, "hat64_s%d_theta_%s" % (step, n), p.data, 2300 + j, "step %d theta %s" % (step, n)))
+    print("HAT wide_VGG9: worst sampled relative deviation %.2e" % worst)
+
+
+@pytest.mark.parametrize("tag,hw,nb,seed", [("pack64", 64, 8, 3000), ("pack224", 224, 4, 4000)])
+def test_packnet_batch_wide_vgg9_g20(golden, tag, hw, nb, seed):
+    """packnet Manager.do_batch x2 at wide_VGG9 widths (methods/packnet/main.py:164-198): forward, backward, foreign
+    gradients to zero, PacknetSGD with momentum, pruned weights to zero — in the state prune() leaves for the post-prune
+    epochs (owner 0 pruned, owner 1 frozen, owner 2 training).  Updated parameters within 1e-3; pruned positions and the
+    frozen task's weights bit-exact."""
+    import torch.nn as nn
+    from clsurvey_amd.data import DeviceLoader, TensorTaskDataset
+    from clsurvey_amd.methods import packnet_main as PM
+    from clsurvey_amd.methods.packnet import PacknetSGD
+    g = golden("G20_wide_widths")
+    lr, mom, wd = [float(v) for v in g[tag + "_hyper"][:3]]
+    wrapper = PM.ModifiedWrapperModel(_raw(hw), 4, (3, hw, hw))
+    wrapper.add_dataset("t1", C.NCLS)
+    wrapper.add_dataset("t2", C.NCLS)
+    wrapper.set_dataset("t2")
+    assert _load(wrapper, seed) == [str(n) for n in g[tag + "_param_names"]]
+    masks = {i: torch.from_numpy(C.owner_mask(seed + 100 + i, mod.weight.shape)).to(DEV)
+             for i, mod in enumerate(wrapper.shared.modules()) if isinstance(mod, (nn.Conv2d, nn.Linear))}
+    assert sorted(masks) == g[tag + "_layout"].tolist()
+    classes = [str(c) for c in range(C.NCLS)]
+    batches = [tuple(torch.from_numpy(a).to(DEV) for a in C.batch(seed + 10 + step, nb, hw)) for step in range(2)]
+    sets = [TensorTaskDataset(x, y, classes) for x, y in batches]
+    args = SimpleNamespace(**{**PM.DEFAULTS, "mode": "finetune", "dataset": "survey_t2", "cuda": True, "batch_size": nb,
+                              "train_path": {"train": sets[0], "val": sets[0], "test": sets[0]}, "current_dataset_idx": 2,
+                              "prune_perc_per_layer": 0.5, "train_biases": False, "train_bn": False})
+    mgr = PM.Manager(args, wrapper, masks, {}, {}, DEV)
+    mgr.pruner.current_masks = masks
+    mgr.pruner.make_pruned_zero()
+    frozen = {i: mod.weight.detach().clone() for i, mod in enumerate(wrapper.shared.modules()) if i in masks}
+    bias0 = {n: p.detach().clone() for n, p in wrapper.named_parameters() if n.startswith("shared") and p.dim() == 1}
+    opt = PacknetSGD(mgr.engine.arena.params, lr=lr, momentum=mom, weight_decay=wd)
+    mgr._mode(True)
+    worst = 0.0
+    for step in range(2):
+        mgr.train_data_loader = DeviceLoader(sets[step], nb, True, torch.device(DEV))
+        err = mgr.do_epoch(step, opt)
+        assert abs(err[0] - float(g["%s_s%d_err" % (tag, step)][0])) <= 100.0 / nb + 1e-6       # top-1, one near-tie allowed
+        for j, (n, p) in enumerate(wrapper.named_parameters()):
+            worst = max(worst, _check(g, "%s_s%d_theta_%s" % (tag, step, n), p.data, seed + 300 + j, "step %d %s" % (step, n)))
+            if p.dim() > 1 and n.startswith("shared"):
+                assert C.zero_pattern(p.detach().cpu().numpy()) == str(g["%s_s%d_zeros_%s" % (tag, step, n)]), n
+    for i, mod in enumerate(wrapper.shared.modules()):
+        if i in masks:
+            keep = masks[i] == 1
+            assert torch.equal(mod.weight.detach()[keep], frozen[i][keep]), i          # the earlier task's weights: bit-exact
+            assert not bool((mod.weight.detach()[masks[i] == 0] != 0).any())
+            assert not torch.equal(mod.weight.detach()[masks[i] == 2], frozen[i][masks[i] == 2])
+    for n, p in wrapper.named_parameters():
+        if n in bias0:
+            assert torch.equal(p.detach(), bias0[n]), n                                 # shared biases are fixed (prune.py:91-93)
+    print("PackNet wide_VGG9 @%d: worst sampled relative deviation %.2e" % (hw, worst))
