@@ -1,5 +1,6 @@
 """Build recipe for libclhip.so (hipcc, gfx950 only). In-tree output: clsurvey_amd/libclhip.so
 so the built library travels with the repo snapshot to the GPU box."""
+import glob
 import os
 import subprocess
 import sys
@@ -30,7 +31,7 @@ def _fingerprint(paths, flags):
 def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
-    hdrs = [os.path.join(CSRC, "common.hpp"), os.path.join(HERE, "..", "include", "clhip.h")]
+    hdrs = sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + [os.path.join(HERE, "..", "include", "clhip.h")]
     procs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

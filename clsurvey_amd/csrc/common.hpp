@@ -87,11 +87,27 @@ struct clhip_fc_chain {
 int clhip_internal_fc_chain_ok(const clhip_fc_chain* d);
 int clhip_internal_fc_chain_wgrad(const clhip_fc_chain* d, float* grads, const float* x, int N, const float* acts,
                                   const float* dlogits, const float* dz, hipStream_t s);
+// gemm_body.hpp: arguments of one strided-GEMM launch (see gemm.hip)
+struct clhip_gemm_args {
+    const float* a; const float* b; float* out;
+    int M, N, K; long sam, sak, sbk, sbn; int n_tiles, splits, k_per_split;
+    const float* bias; const float* mask_src; int relu;
+};
+// backward-data GEMM of a Linear layer as arguments for a combined launch; returns its block count, 0 when the shape is split over K
+int clhip_internal_fc_bwd_data_args(const float* dy, const float* w, const float* relu_src, float* dx, int M, int I, int O,
+                                    clhip_gemm_args* args_out);
+// fc_chain.hip: that GEMM and the weight / bias gradients of the whole classifier in ONE launch
+int clhip_internal_fc_bwd_combo(const clhip_gemm_args* g, int gemm_blocks, const clhip_fc_chain* d, float* grads, const float* x,
+                                int N, const float* acts, const float* dlogits, const float* dz, hipStream_t s);
+
 // fused classifier tail (fc_chain.hip): layers 2..3 forward, cross-entropy, backward-data down to dz of h1
 int clhip_internal_fc_tail_ok(const clhip_fc_chain* d);
 int clhip_internal_fc_tail(const clhip_fc_chain* d, const float* params, float* acts, int N, const int64_t* labels,
                            int reduction, int col_off, int ncols, float* dlogits, float* fcdz, float* loss_out, double* stats,
-                           void* row_scratch, unsigned* counter, int do_loss, int do_bwd, hipStream_t s);
+                           void* row_scratch, unsigned* counter, int do_loss, int do_bwd, const float* h1_slabs, int live,
+                           hipStream_t s);
+int clhip_internal_fc_fwd_partial(const float* x, const float* w, int M, int I, int O, void* ws, size_t ws_bytes, int* live,
+                                  hipStream_t s);
 
 // conv3x3_wgrad.hip: deferred slab reduction (see clhip_internal_conv3x3_wgrad_partial)
 #define CLHIP_WGRAD_JOBS_MAX 32

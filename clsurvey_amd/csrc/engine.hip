@@ -66,8 +66,9 @@ struct NetPlan {
     // layers fc_first+1 .. end forward + cross-entropy + backward-data down to dz(h1) in one launch (fc_tail_kernel); the
     // arrival counter of its last-workgroup reduction is the plan's own 4 bytes of device memory (zero between launches),
     // so a plan must not run on two streams at once (it never could: the activations live in one workspace)
-    bool fc_tail;
+    bool fc_tail, no_combo;
     unsigned* tail_counter;
+    size_t off_rows;
     // backward (optional, CLHIP_WGRAD_OVERLAP=1): the weight-gradient launches of the conv layers run on a side stream
     // next to the backward-data launch of the same layer (both only read dy)
     bool overlap;
@@ -235,6 +236,8 @@ int clhip_net_create(const clhip_layer_desc* descs, int n_layers, int max_batch,
         if (clhip_internal_fc_chain_ok(&ch)) {
             p->fc_fused = true;
             off += align_up(dzf * 4 + 256, 256);
+            p->off_rows = off;                       // per-row loss / hit of the fused classifier tail
+            off += align_up((size_t)max_batch * 8, 256);
         }
     }
     // own slabs per 3x3 layer so that ONE launch reduces them all at the end of backward (HBM is plentiful: 288 GB)
@@ -265,10 +268,12 @@ int clhip_net_create(const clhip_layer_desc* descs, int n_layers, int max_batch,
         }
     }
     p->fc_tail = false;
+    p->no_combo = false;
     p->tail_counter = nullptr;
     const char* tl = getenv("CLHIP_FC_TAIL");      // CLHIP_FC_TAIL=0: per-layer launches (the bitwise reference of the fused tail)
+    if (tl && tl[0] == '0') p->no_combo = true;
     if (p->fc_fused && !(tl && tl[0] == '0') && clhip_internal_fc_tail_ok(&p->chain) &&
-        p->scratch_bytes >= (size_t)max_batch * 8 && max_batch <= 1024) {
+        max_batch <= 1024) {
         // needs a device: plans made on a host without one (shape tests) keep the per-layer launches
         if (hipMalloc(reinterpret_cast<void**>(&p->tail_counter), 256) == hipSuccess &&
             hipMemset(p->tail_counter, 0, 256) == hipSuccess) {
@@ -349,11 +354,12 @@ static bool tail_usable(const NetPlan* p, const float* params, const void* ws, i
         if (p->layers[i].drop || p->layers[i].extra_grad) return false;
     const float* acts = reinterpret_cast<const float*>(static_cast<const char*>(ws) + p->off_acts);
     return aligned16(params + p->chain.w_off[1]) && aligned16(params + p->chain.w_off[2]) && aligned16(acts + p->chain.act_off[0]) &&
+           aligned16(params + p->chain.b_off[0]) &&
            (size_t)N * (p->n_classes | 1) <= 12288;        // the range in which the per-layer path uses softmax_ce_rows_lds_kernel
 }
 
 static int net_forward_impl(void* handle, const float* params, const float* x, int N, void* ws, float* logits_out,
-                            void* stream, int tail) {
+                            void* stream, int tail, int* slabs_live = nullptr) {
     NetPlan* p = static_cast<NetPlan*>(handle);
     if (!p || !params || !x || !ws || N <= 0 || N > p->max_batch) return CLHIP_EINVAL;
     char* base = static_cast<char*>(ws);
@@ -363,6 +369,7 @@ static int net_forward_impl(void* handle, const float* params, const float* x, i
     const float* cur = x;
     int rc;
     const size_t n_run = tail ? (size_t)p->fc_first + 1 : p->layers.size();
+    int live = 0;            // split-K slabs of the first Linear layer left in `scratch` for the fused tail
     for (size_t li = 0; li < n_run; ++li) {
         const LayerPlan& L = p->layers[li];
         float* y = acts + L.act_off;
@@ -419,16 +426,26 @@ static int net_forward_impl(void* handle, const float* params, const float* x, i
                 }
             }
         } else {
-            rc = clhip_fc_fwd(cur, params + L.w_off, params + L.b_off, y, N, L.cin, L.cout, L.relu, scratch,
-                              p->scratch_bytes, stream);
-            if (rc) return rc;
+            if (tail && (int)li == p->fc_first) {
+                // the fused tail sums the split-K slabs of this layer itself (no reduction launch)
+                rc = clhip_internal_fc_fwd_partial(cur, params + L.w_off, N, L.cin, L.cout, scratch, p->scratch_bytes, &live,
+                                                   as_stream(stream));
+                if (rc) return rc;
+            }
+            if (!live) {
+                rc = clhip_fc_fwd(cur, params + L.w_off, params + L.b_off, y, N, L.cin, L.cout, L.relu, scratch,
+                                  p->scratch_bytes, stream);
+                if (rc) return rc;
+            }
             cur = y;
         }
     }
+    if (slabs_live) *slabs_live = live;
     if (tail == 1) return 0;
     if (tail == 2) {
-        rc = clhip_internal_fc_tail(&p->chain, params, acts, N, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, scratch,
-                                    p->tail_counter, 0, 0, as_stream(stream));
+        rc = clhip_internal_fc_tail(&p->chain, params, acts, N, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr,
+                                    base + p->off_rows, p->tail_counter, 0, 0, static_cast<const float*>(scratch), live,
+                                    as_stream(stream));
         if (rc) return rc;
         cur = acts + p->layers.back().act_off;
     }
@@ -515,13 +532,31 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
                 rc = clhip_fc_bwd_weight(xin, gin, grads + L.w_off, grads + L.b_off, N, L.cin, L.cout, scratch, p->scratch_bytes, stream);
                 if (rc) return rc;
             }
+            bool combo = false;
+            clhip_fc_chain ch;
+            if (p->fc_fused && i == p->fc_first) {
+                ch = p->chain;       // inputs of the hidden layers: their masked copies where a dropout is active
+                for (int l = 1; l < ch.n; ++l) {
+                    const LayerPlan& Ll = p->layers[p->fc_first + l];
+                    if (Ll.drop && Ll.has_drop_buf) ch.act_off[l - 1] = Ll.drop_off;
+                }
+            }
             if (i > 0) {
                 // fused weight gradients (below) read the hidden layers' dz after the chain: keep them in their own slots
                 float* gout;
                 if (p->fc_fused && i > p->fc_first) { gout = fcdz + p->chain.dz_off[i - p->fc_first - 1]; gin_buf = -1; }
                 else { gout = take(); gin_buf = taken; }
                 // mask with (xin > 0): xin is a ReLU (or pooled ReLU) output
-                rc = clhip_fc_bwd_data(gin, params + L.w_off, xin, gout, N, L.cin, L.cout, scratch, p->scratch_bytes, stream);
+                clhip_gemm_args ga;
+                const int gb = (p->fc_fused && i == p->fc_first && !p->no_combo)
+                                   ? clhip_internal_fc_bwd_data_args(gin, params + L.w_off, xin, gout, N, L.cin, L.cout, &ga) : 0;
+                if (gb > 0) {
+                    // backward-data of the first Linear layer and every Linear layer's dW / db in ONE launch
+                    rc = clhip_internal_fc_bwd_combo(&ga, gb, &ch, grads, xin, N, acts, dlogits, fcdz, main_s);
+                    combo = true;
+                } else {
+                    rc = clhip_fc_bwd_data(gin, params + L.w_off, xin, gout, N, L.cin, L.cout, scratch, p->scratch_bytes, stream);
+                }
                 if (rc) return rc;
                 gin = gout;
                 if (L.drop) {
@@ -533,13 +568,8 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
                     if (rc) return rc;
                 }
             }
-            if (p->fc_fused && i == p->fc_first) {
+            if (p->fc_fused && i == p->fc_first && !combo) {
                 // all dz_l are in place: dW_l, db_l of every Linear layer in one launch
-                clhip_fc_chain ch = p->chain;       // inputs of the hidden layers: their masked copies where a dropout is active
-                for (int l = 1; l < ch.n; ++l) {
-                    const LayerPlan& Ll = p->layers[p->fc_first + l];
-                    if (Ll.drop && Ll.has_drop_buf) ch.act_off[l - 1] = Ll.drop_off;
-                }
                 rc = clhip_internal_fc_chain_wgrad(&ch, grads, xin, N, acts, dlogits, fcdz, main_s);
                 if (rc) return rc;
             }
@@ -655,12 +685,14 @@ int clhip_net_loss_step_slice(void* handle, const float* params, float* grads, c
         // first Linear layer by the GEMM launches, then ONE launch for the rest of the classifier, the loss and the
         // backward-data chain down to dz(h1); backward resumes at the first Linear layer
         if (loss_kind != 0 && loss_kind != 1) return CLHIP_EINVAL;
-        int rc = net_forward_impl(handle, params, x, N, ws, nullptr, stream, 1);
+        int live = 0;
+        int rc = net_forward_impl(handle, params, x, N, ws, nullptr, stream, 1, &live);
         if (rc) return rc;
         float* acts = reinterpret_cast<float*>(base + p->off_acts);
         rc = clhip_internal_fc_tail(&p->chain, params, acts, N, labels, loss_kind, col_off, nc, dlogits,
-                                    reinterpret_cast<float*>(base + p->off_fcdz), loss_dev, stats, base + p->off_scratch,
-                                    p->tail_counter, 1, grads ? 1 : 0, as_stream(stream));
+                                    reinterpret_cast<float*>(base + p->off_fcdz), loss_dev, stats, base + p->off_rows,
+                                    p->tail_counter, 1, grads ? 1 : 0, reinterpret_cast<const float*>(base + p->off_scratch), live,
+                                    as_stream(stream));
         if (rc) return rc;
         if (logits_out) {
             hipError_t e = hipMemcpyAsync(logits_out, acts + p->layers.back().act_off, (size_t)N * p->n_classes * sizeof(float),

@@ -10,6 +10,7 @@
 // (A fused forward / backward-data chain with activations kept in LDS was also tried: 134 us / 91 us against
 // 25 us / 43 us for the GEMM launches, because its per-lane strided operand reads are latency-serialised; removed.)
 #include "common.hpp"
+#include "gemm_body.hpp"
 
 namespace {
 
@@ -20,12 +21,11 @@ struct FcChain { FcLayer l[CLHIP_FC_MAX]; int n; };
 // One wave per 32x32 tile of some layer's dW: dW[o][i] = sum_n dz[n][o] * h[n][i]; tiles with i-tile 0 also db[o].
 struct FcTileMap { int first[CLHIP_FC_MAX + 1]; };     // prefix sums of tiles per layer
 
-__global__ __launch_bounds__(256) void fc_chain_wgrad_kernel(FcChain c, FcTileMap tm, const float* __restrict__ x, int N,
-                                                             const float* __restrict__ acts,
-                                                             const float* __restrict__ dlogits, const float* __restrict__ dz,
-                                                             float* __restrict__ grads) {
+__device__ __forceinline__ void fc_chain_wgrad_block(const FcChain& c, const FcTileMap& tm, const float* __restrict__ x, int N,
+                                                     const float* __restrict__ acts, const float* __restrict__ dlogits,
+                                                     const float* __restrict__ dz, float* __restrict__ grads, int block) {
     const int lane = threadIdx.x & 63, li = lane & 31, kk = lane >> 5;
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int t = block * 4 + (threadIdx.x >> 6);
     if (t >= tm.first[c.n]) return;
     int l = 0;
     while (t >= tm.first[l + 1]) ++l;
@@ -63,14 +63,26 @@ __global__ __launch_bounds__(256) void fc_chain_wgrad_kernel(FcChain c, FcTileMa
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
         }
     };
-    fetch(0, aA, bA);
-    for (int n0 = 0; n0 < npad; n0 += 64) {
-        const bool hasB = n0 + 32 < npad;
-        if (hasB) fetch(n0 + 32, aB, bB);
-        compute(n0, aA, bA);
-        if (hasB) {
-            if (n0 + 64 < npad) fetch(n0 + 64, aA, bA);
-            compute(n0 + 32, aB, bB);
+    if (npad <= 256) {
+        // the usual batch sizes: every operand load of the tile is in flight before the first MFMA (one memory latency
+        // instead of one per 64 samples; 256 operand registers, the kernel runs one wave per SIMD anyway)
+        float a8[8][16], b8[8][16];
+#pragma unroll
+        for (int bt = 0; bt < 8; ++bt)
+            if (bt * 32 < npad) fetch(bt * 32, a8[bt], b8[bt]);
+#pragma unroll
+        for (int bt = 0; bt < 8; ++bt)
+            if (bt * 32 < npad) compute(bt * 32, a8[bt], b8[bt]);
+    } else {
+        fetch(0, aA, bA);
+        for (int n0 = 0; n0 < npad; n0 += 64) {
+            const bool hasB = n0 + 32 < npad;
+            if (hasB) fetch(n0 + 32, aB, bB);
+            compute(n0, aA, bA);
+            if (hasB) {
+                if (n0 + 64 < npad) fetch(n0 + 64, aA, bA);
+                compute(n0 + 32, aB, bB);
+            }
         }
     }
     float* gw = grads + L.w_off;
@@ -103,9 +115,9 @@ __global__ __launch_bounds__(256) void fc_chain_wgrad_kernel(FcChain c, FcTileMa
 constexpr int TL = 129;            // LDS row stride in floats: odd, so walks along rows and along columns are conflict-free
 constexpr int ZL = 33;
 struct FcTail {
-    long w2, b2, w3, b3;           // float offsets into the parameter arena
-    int d1, d2, d3, relu2, relu3;  // widths of h1, h2, logits
-    size_t a2, a3, dz1, dz2;       // float offsets: h2 / logits in the activation workspace, dz1 / dz2 in the fc gradient scratch
+    long w2, b2, w3, b3, b1;       // float offsets into the parameter arena
+    int d1, d2, d3, relu1, relu2, relu3;  // widths of h1, h2, logits
+    size_t a1, a2, a3, dz1, dz2;   // float offsets: h1 / h2 / logits in the activation workspace, dz1 / dz2 in the fc gradient scratch
 };
 
 // acc = sum over k (ascending pairs) of A(k) * B(k), K a multiple of 32: operands of 16 MFMAs are fetched from LDS
@@ -142,13 +154,17 @@ __global__ __launch_bounds__(256) void fc_tail_kernel(FcTail t, const float* __r
                                                       int reduction, int col_off, int C, float* __restrict__ dlogits,
                                                       float* __restrict__ fcdz, float* __restrict__ loss_out,
                                                       double* __restrict__ stats, float* row_loss, int* row_ok,
-                                                      unsigned* counter, int do_loss, int do_bwd) {
+                                                      unsigned* counter, int do_loss, int do_bwd,
+                                                      const float* __restrict__ slabs, int live) {
     __shared__ float W2s[128 * TL];
     __shared__ float W3s[32 * TL];
     __shared__ float h1s[32 * TL];
     __shared__ float h2s[32 * TL];
     __shared__ float dz2s[32 * TL];
     __shared__ float zs[32 * ZL];
+    __shared__ float exs[32 * ZL];
+    __shared__ float r_mx[32], r_lse[32];
+    __shared__ int r_am[32], r_y[32];
     __shared__ float w_loss[16];
     __shared__ int w_corr[16];
     __shared__ unsigned s_ticket;
@@ -169,15 +185,55 @@ __global__ __launch_bounds__(256) void fc_tail_kernel(FcTail t, const float* __r
         const int e = tid + 256 * j, o = e / c1, i = (e - o * c1) * 4;
         q2[j] = clhip_buf_load4(r_w2, (o < t.d2 && i < t.d1 && e < K2 * c1) ? (o * t.d1 + i) * 4 : CLHIP_OOB, 0);
     }
+    if (!slabs) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int e = tid + 256 * j, r = e / c1, i = (e - r * c1) * 4;
-        q1[j] = clhip_buf_load4(r_h1, (r < rows_here && i < t.d1 && e < 32 * c1) ? (r * t.d1 + i) * 4 : CLHIP_OOB, 0);
+        for (int j = 0; j < 4; ++j) {
+            const int e = tid + 256 * j, r = e / c1, i = (e - r * c1) * 4;
+            q1[j] = clhip_buf_load4(r_h1, (r < rows_here && i < t.d1 && e < 32 * c1) ? (r * t.d1 + i) * 4 : CLHIP_OOB, 0);
+        }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int e = tid + 256 * j, o = e / c2, i = (e - o * c2) * 4;
         q3[j] = clhip_buf_load4(r_w3, (o < t.d3 && i < t.d2 && e < 32 * c2) ? (o * t.d2 + i) * 4 : CLHIP_OOB, 0);
+    }
+    if (slabs) {
+        // h1 = relu(sum of the first Linear layer's split-K slabs, ascending + b1): gemm_splitk_reduce_kernel's arithmetic on
+        // this row block (slabs past `live` are all zero and adding them changes nothing); h1 also goes to the activation
+        // workspace, where the weight-gradient launch and the per-layer path expect it
+        const size_t slab = (size_t)N * t.d1;
+        const __amdgpu_buffer_rsrc_t r_p = clhip_rsrc(slabs + (size_t)m0 * t.d1, ((size_t)(live - 1) * slab + (size_t)rows_here * t.d1) * 4);
+        int off[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = tid + 256 * j, r = e / c1, i = (e - r * c1) * 4;
+            off[j] = (r < rows_here && i < t.d1 && e < 32 * c1) ? (r * t.d1 + i) * 4 : CLHIP_OOB;
+            q1[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        for (int s0 = 0; s0 < live; s0 += 8) {
+            float4 pv[8][4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    pv[u][j] = clhip_buf_load4(r_p, (s0 + u < live && off[j] != CLHIP_OOB) ? off[j] + (int)((size_t)(s0 + u) * slab * 4) : CLHIP_OOB, 0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { q1[j].x += pv[u][j].x; q1[j].y += pv[u][j].y; q1[j].z += pv[u][j].z; q1[j].w += pv[u][j].w; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = tid + 256 * j, r = e / c1, i = (e - r * c1) * 4;
+            if (off[j] != CLHIP_OOB) {
+                const float4 b = *reinterpret_cast<const float4*>(params + t.b1 + i);
+                float4 v = q1[j];
+                v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+                if (t.relu1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                q1[j] = v;
+                *reinterpret_cast<float4*>(acts + t.a1 + (size_t)(m0 + r) * t.d1 + i) = v;
+            }
+        }
     }
     auto put4 = [](float* d, const float4& v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; };
 #pragma unroll
@@ -235,31 +291,49 @@ __global__ __launch_bounds__(256) void fc_tail_kernel(FcTail t, const float* __r
     // ---- softmax cross-entropy per row: the per-row text of softmax_ce_rows_lds_kernel (loss.hip) — keep in sync
     const int ld = t.d3;
     const float scale = reduction == 0 ? 1.f / (float)N : 1.f;
+    // (spread over the workgroup: the exponentials of a row are evaluated by different lanes, every sum still runs over
+    //  the classes in ascending order in one lane, so each value is the one the row-per-thread text produces)
     if (tid < 32) {
-        const int row = tid, m = m0 + row;
-        float* zr = zs + row * ZL;
+        const int m = m0 + tid;
+        float mx = -INFINITY;
+        int am = 0;
         if (m < N) {
-            float* z = zr + col_off;
-            const int y = (int)labels[m];
-            float mx = -INFINITY;
-            int am = 0;
+            const float* z = zs + tid * ZL + col_off;
             for (int c = 0; c < C; ++c) {
                 float v = z[c];
                 if (v > mx) { mx = v; am = c; }
             }
+        }
+        r_mx[tid] = mx; r_am[tid] = am;
+    }
+    __syncthreads();
+    for (int e = tid; e < 32 * 32; e += 256) {
+        const int row = e >> 5, c = e & 31;
+        if (c < C) exs[row * ZL + c] = expf(zs[row * ZL + col_off + c] - r_mx[row]);
+    }
+    __syncthreads();
+    if (tid < 32) {
+        const int m = m0 + tid;
+        if (m < N) {
+            const float* z = zs + tid * ZL + col_off;
+            const int y = (int)labels[m];
+            const float mx = r_mx[tid];
             float se = 0.f;
-            for (int c = 0; c < C; ++c) se += expf(z[c] - mx);
+            for (int c = 0; c < C; ++c) se += exs[tid * ZL + c];
             const float lse = logf(se);
             const float lrow = -(z[y] - mx - lse);
-            for (int c = 0; c < ld; ++c) {
-                const int cc = c - col_off;
-                zr[c] = (cc >= 0 && cc < C) ? (expf(zr[c] - mx - lse) - (cc == y ? 1.f : 0.f)) * scale : 0.f;
-            }
+            r_lse[tid] = lse; r_y[tid] = y;
             row_loss[m] = lrow;
-            row_ok[m] = (am == y);
-        } else {
-            for (int c = 0; c < 32; ++c) zr[c] = 0.f;
+            row_ok[m] = (r_am[tid] == y);
         }
+    }
+    __syncthreads();
+    for (int e = tid; e < 32 * 32; e += 256) {
+        const int row = e >> 5, c = e & 31, cc = c - col_off;
+        float v = 0.f;
+        if (m0 + row < N && c < ld && cc >= 0 && cc < C)
+            v = (expf(zs[row * ZL + c] - r_mx[row] - r_lse[row]) - (cc == r_y[row] ? 1.f : 0.f)) * scale;
+        zs[row * ZL + c] = v;
     }
     __syncthreads();
     for (int e = tid; e < 32 * ld; e += 256) {
@@ -318,6 +392,28 @@ __global__ __launch_bounds__(256) void fc_tail_kernel(FcTail t, const float* __r
     }
 }
 
+__global__ __launch_bounds__(256) void fc_chain_wgrad_kernel(FcChain c, FcTileMap tm, const float* __restrict__ x, int N,
+                                                             const float* __restrict__ acts,
+                                                             const float* __restrict__ dlogits, const float* __restrict__ dz,
+                                                             float* __restrict__ grads) {
+    fc_chain_wgrad_block(c, tm, x, N, acts, dlogits, dz, grads, blockIdx.x);
+}
+
+// Backward of the first Linear layer in one launch: blocks [0, gemm_blocks) are the 64x64 tiles of its backward-data GEMM
+// (dx = dz1 . W1, masked by the layer input), the rest are the weight / bias gradient tiles of the whole classifier.  Both
+// only read dz and the activations, both are latency-bound at batch 200 (11.7 + 13.7 us as two launches) and together
+// they still fit the chip's 256 CUs.  Same device functions as the two stand-alone kernels => same bits.
+__global__ __launch_bounds__(256) void fc_bwd_combo_kernel(clhip_gemm_args g, int gemm_blocks, FcChain c, FcTileMap tm,
+                                                           const float* __restrict__ x, int N, const float* __restrict__ acts,
+                                                           const float* __restrict__ dlogits, const float* __restrict__ dz,
+                                                           float* __restrict__ grads) {
+    if ((int)blockIdx.x < gemm_blocks) {
+        if (g.k_per_split <= 128 && g.K > 32) gemm_tile<true, false, 128>(g, blockIdx.x);
+        else gemm_tile<true, false>(g, blockIdx.x);
+    }
+    else fc_chain_wgrad_block(c, tm, x, N, acts, dlogits, dz, grads, (int)blockIdx.x - gemm_blocks);
+}
+
 FcChain to_chain(const clhip_fc_chain* d) {
     FcChain c;
     c.n = d->n;
@@ -352,6 +448,19 @@ int clhip_internal_fc_chain_wgrad(const clhip_fc_chain* d, float* grads, const f
     return 0;
 }
 
+int clhip_internal_fc_bwd_combo(const clhip_gemm_args* g, int gemm_blocks, const clhip_fc_chain* d, float* grads, const float* x,
+                                int N, const float* acts, const float* dlogits, const float* dz, hipStream_t s) {
+    const FcChain c = to_chain(d);
+    FcTileMap tm;
+    tm.first[0] = 0;
+    for (int l = 0; l < c.n; ++l) tm.first[l + 1] = tm.first[l] + ((c.l[l].dout + 31) / 32) * ((c.l[l].din + 31) / 32);
+    for (int l = c.n; l < CLHIP_FC_MAX; ++l) tm.first[l + 1] = tm.first[c.n];
+    hipLaunchKernelGGL(fc_bwd_combo_kernel, dim3(gemm_blocks + (tm.first[c.n] + 3) / 4), dim3(256), 0, s, *g, gemm_blocks, c, tm, x, N,
+                       acts, dlogits, dz, grads);
+    CLHIP_LAUNCH_CHECK();
+    return 0;
+}
+
 // Envelope of the fused tail: Linear-ReLU-Linear-(ReLU)-Linear with both hidden widths <= 128 (multiples of 4) and at most
 // 32 logits; anything else runs the per-layer launches.
 int clhip_internal_fc_tail_ok(const clhip_fc_chain* d) {
@@ -359,21 +468,24 @@ int clhip_internal_fc_tail_ok(const clhip_fc_chain* d) {
     if (d->din[1] != d->dout[0] || d->din[2] != d->dout[1]) return 0;
     if (d->din[1] > 128 || d->dout[1] > 128 || d->dout[2] > 32) return 0;
     if ((d->din[1] & 3) || (d->dout[1] & 3)) return 0;
-    if ((d->w_off[1] & 3) || (d->w_off[2] & 3) || (d->act_off[0] & 3)) return 0;
+    if ((d->w_off[1] & 3) || (d->w_off[2] & 3) || (d->act_off[0] & 3) || (d->b_off[0] & 3)) return 0;
     return 1;
 }
 
 int clhip_internal_fc_tail(const clhip_fc_chain* d, const float* params, float* acts, int N, const int64_t* labels,
                            int reduction, int col_off, int ncols, float* dlogits, float* fcdz, float* loss_out, double* stats,
-                           void* row_scratch, unsigned* counter, int do_loss, int do_bwd, hipStream_t s) {
+                           void* row_scratch, unsigned* counter, int do_loss, int do_bwd, const float* h1_slabs, int live,
+                           hipStream_t s) {
     FcTail t;
-    t.w2 = d->w_off[1]; t.b2 = d->b_off[1]; t.w3 = d->w_off[2]; t.b3 = d->b_off[2];
-    t.d1 = d->din[1]; t.d2 = d->dout[1]; t.d3 = d->dout[2]; t.relu2 = d->relu[1]; t.relu3 = d->relu[2];
-    t.a2 = d->act_off[1]; t.a3 = d->act_off[2]; t.dz1 = d->dz_off[0]; t.dz2 = d->dz_off[1];
+    t.w2 = d->w_off[1]; t.b2 = d->b_off[1]; t.w3 = d->w_off[2]; t.b3 = d->b_off[2]; t.b1 = d->b_off[0];
+    t.d1 = d->din[1]; t.d2 = d->dout[1]; t.d3 = d->dout[2]; t.relu1 = d->relu[0]; t.relu2 = d->relu[1]; t.relu3 = d->relu[2];
+    t.a1 = d->act_off[0]; t.a2 = d->act_off[1]; t.a3 = d->act_off[2]; t.dz1 = d->dz_off[0]; t.dz2 = d->dz_off[1];
+    if (live <= 0) h1_slabs = nullptr;
     float* row_loss = static_cast<float*>(row_scratch);
     int* row_ok = reinterpret_cast<int*>(row_loss + N);
     hipLaunchKernelGGL(fc_tail_kernel, dim3((N + 31) / 32), dim3(256), 0, s, t, params, acts + d->act_off[0], acts, N, labels,
-                       reduction, col_off, ncols, dlogits, fcdz, loss_out, stats, row_loss, row_ok, counter, do_loss, do_bwd);
+                       reduction, col_off, ncols, dlogits, fcdz, loss_out, stats, row_loss, row_ok, counter, do_loss, do_bwd,
+                       h1_slabs, live);
     CLHIP_LAUNCH_CHECK();
     return 0;
 }

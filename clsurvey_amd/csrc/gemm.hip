@@ -5,100 +5,12 @@
 // output tiles and a long K: K is split across blocks into workspace slabs that a second kernel
 // sums in fixed order (deterministic) and finishes with the bias / ReLU / ReLU-mask epilogue.
 #include "common.hpp"
+#include "gemm_body.hpp"
 
 namespace {
 
-constexpr int TM = 64, TN = 64, BK = 32, LD = 65;
-
-// AK: A is contiguous along k (sak == 1); BKc: B is contiguous along k (sbk == 1)
-template <bool AK, bool BKc>
-__global__ __launch_bounds__(256) void gemm_mfma_kernel(
-    const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
-    int M, int N, int K, long sam, long sak, long sbk, long sbn, int n_tiles, int splits, int k_per_split,
-    const float* __restrict__ bias, const float* __restrict__ mask_src, int relu) {
-    __shared__ float as[BK * LD];
-    __shared__ float bs[BK * LD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave & 1, wn = wave >> 1, li = lane & 31, kk = lane >> 5;
-    const int split = blockIdx.x % splits;
-    const int tile = blockIdx.x / splits;
-    const int tn = tile % n_tiles, tm = tile / n_tiles;
-    const int m0 = tm * TM, n0 = tn * TN;
-    const int k_begin = split * k_per_split;
-    const int k_end = min(K, k_begin + k_per_split);
-
-    floatx16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-
-    // register-staged software pipeline: chunk t+1 is in flight while chunk t feeds the MFMAs
-    constexpr int A_IT = (TM * BK) / 256, B_IT = (TN * BK) / 256;
-    float ar[A_IT], br[B_IT];
-    auto load_chunk = [&](int k0) {
-#pragma unroll
-        for (int j = 0; j < A_IT; ++j) {
-            int e = tid + 256 * j;
-            int ml, kl;
-            if (AK) { ml = e / BK; kl = e - ml * BK; } else { kl = e / TM; ml = e - kl * TM; }
-            int m = m0 + ml, k = k0 + kl;
-            ar[j] = (m < M && k < k_end) ? a[(long)m * sam + (long)k * sak] : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < B_IT; ++j) {
-            int e = tid + 256 * j;
-            int nl, kl;
-            if (BKc) { nl = e / BK; kl = e - nl * BK; } else { kl = e / TN; nl = e - kl * TN; }
-            int n = n0 + nl, k = k0 + kl;
-            br[j] = (n < N && k < k_end) ? b[(long)k * sbk + (long)n * sbn] : 0.f;
-        }
-    };
-    auto store_chunk = [&]() {
-#pragma unroll
-        for (int j = 0; j < A_IT; ++j) {
-            int e = tid + 256 * j;
-            int ml, kl;
-            if (AK) { ml = e / BK; kl = e - ml * BK; } else { kl = e / TM; ml = e - kl * TM; }
-            as[kl * LD + ml] = ar[j];
-        }
-#pragma unroll
-        for (int j = 0; j < B_IT; ++j) {
-            int e = tid + 256 * j;
-            int nl, kl;
-            if (BKc) { nl = e / BK; kl = e - nl * BK; } else { kl = e / TN; nl = e - kl * TN; }
-            bs[kl * LD + nl] = br[j];
-        }
-    };
-    if (k_begin < k_end) load_chunk(k_begin);
-    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-        __syncthreads();
-        store_chunk();
-        __syncthreads();
-        if (k0 + BK < k_end) load_chunk(k0 + BK);
-#pragma unroll
-        for (int k2 = 0; k2 < BK; k2 += 2) {
-            float av = as[(k2 + kk) * LD + wm * 32 + li];
-            float bv = bs[(k2 + kk) * LD + wn * 32 + li];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-        }
-    }
-
-    const int n = n0 + wn * 32 + li;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        int m = m0 + wm * 32 + mfma32_row(r, lane);
-        if (m < M && n < N) {
-            float v = acc[r];
-            if (splits == 1) {
-                if (bias) v += bias[n];
-                if (relu) v = fmaxf(v, 0.f);
-                if (mask_src) v = mask_src[(size_t)m * N + n] > 0.f ? v : 0.f;
-                out[(size_t)m * N + n] = v;
-            } else {
-                out[((size_t)split * M + m) * N + n] = v;
-            }
-        }
-    }
-}
+template <bool AK, bool BKc, int BKT = BK>
+__global__ __launch_bounds__(256) void gemm_mfma_kernel(clhip_gemm_args g) { gemm_tile<AK, BKc, BKT>(g, blockIdx.x); }
 
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                                  size_t mn, int N, int splits,
@@ -155,8 +67,11 @@ int gemm_launch(const float* a, const float* b, float* out, int M, int N, int K,
     int k_per_split = (((K + splits - 1) / splits) + BK - 1) / BK * BK;
     int m_tiles = (M + TM - 1) / TM, n_tiles = (N + TN - 1) / TN;
     float* dst = splits == 1 ? out : static_cast<float*>(ws);
-    hipLaunchKernelGGL((gemm_mfma_kernel<AK, BKc>), dim3((unsigned)(m_tiles * n_tiles * splits)), dim3(256), 0, s,
-                       a, b, dst, M, N, K, sam, sak, sbk, sbn, n_tiles, splits, k_per_split, bias, mask_src, relu);
+    const clhip_gemm_args g{a, b, dst, M, N, K, sam, sak, sbk, sbn, n_tiles, splits, k_per_split, bias, mask_src, relu};
+    if (k_per_split <= 128 && K > BK)
+        hipLaunchKernelGGL((gemm_mfma_kernel<AK, BKc, 128>), dim3((unsigned)(m_tiles * n_tiles * splits)), dim3(256), 0, s, g);
+    else
+        hipLaunchKernelGGL((gemm_mfma_kernel<AK, BKc>), dim3((unsigned)(m_tiles * n_tiles * splits)), dim3(256), 0, s, g);
     CLHIP_LAUNCH_CHECK();
     if (splits > 1) {
         hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(ew_grid(mn, 256)), dim3(256), 0, s,
@@ -167,6 +82,40 @@ int gemm_launch(const float* a, const float* b, float* out, int M, int N, int K,
 }
 
 }  // namespace
+
+// Forward GEMM of a Linear layer WITHOUT the split-K reduction: the slabs stay in ws as [split][M][O] and the caller
+// (fc_tail_kernel) sums the *live slabs in ascending order, adds the bias and applies the ReLU while it stages its row
+// block — exactly gemm_splitk_reduce_kernel's arithmetic (slabs past *live hold zeros).  *live = 0: the shape runs
+// unsplit, nothing was launched, use clhip_fc_fwd.
+int clhip_internal_fc_fwd_partial(const float* x, const float* w, int M, int I, int O, void* ws, size_t ws_bytes, int* live,
+                                  hipStream_t s) {
+    *live = 0;
+    const int splits = choose_splits(M, O, I);
+    const size_t mn = (size_t)M * O;
+    if (splits <= 1 || !ws || ws_bytes < mn * splits * sizeof(float)) return 0;
+    const int k_per_split = (((I + splits - 1) / splits) + BK - 1) / BK * BK;
+    const int m_tiles = (M + TM - 1) / TM, n_tiles = (O + TN - 1) / TN;
+    const clhip_gemm_args g{x, w, static_cast<float*>(ws), M, O, I, (long)I, 1L, 1L, (long)I, n_tiles, splits, k_per_split,
+                     nullptr, nullptr, 0};
+    if (k_per_split <= 128)
+        hipLaunchKernelGGL((gemm_mfma_kernel<true, true, 128>), dim3((unsigned)(m_tiles * n_tiles * splits)), dim3(256), 0, s, g);
+    else
+        hipLaunchKernelGGL((gemm_mfma_kernel<true, true>), dim3((unsigned)(m_tiles * n_tiles * splits)), dim3(256), 0, s, g);
+    CLHIP_LAUNCH_CHECK();
+    *live = (I + k_per_split - 1) / k_per_split;
+    return 0;
+}
+
+// Backward-data GEMM of a Linear layer as clhip_gemm_args for a combined launch (fc_chain.hip); 0 blocks: the shape would be split
+// over K, use clhip_fc_bwd_data.
+int clhip_internal_fc_bwd_data_args(const float* dy, const float* w, const float* relu_src, float* dx, int M, int I, int O,
+                                    clhip_gemm_args* args_out) {
+    if (choose_splits(M, I, O) != 1) return 0;
+    const int m_tiles = (M + TM - 1) / TM, n_tiles = (I + TN - 1) / TN;
+    const int k_per_split = (O + BK - 1) / BK * BK;
+    *args_out = clhip_gemm_args{dy, w, dx, M, I, O, (long)O, 1L, (long)I, 1L, n_tiles, 1, k_per_split, nullptr, relu_src, 0};
+    return m_tiles * n_tiles;
+}
 
 extern "C" {
 
