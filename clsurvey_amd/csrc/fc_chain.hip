@@ -253,6 +253,9 @@ __global__ __launch_bounds__(256) void fc_tail_kernel(FcTail t, const float* __r
     }
     __syncthreads();
 
+#if defined(CLHIP_TAIL_STOP) && CLHIP_TAIL_STOP == 1
+    return;
+#endif
     const int n0 = wave * 32, n = n0 + li;
     floatx16 acc;
     // ---- h2 = relu(h1 . W2^T + b2): wave w owns columns 32w .. 32w+31 of h2
@@ -270,6 +273,9 @@ __global__ __launch_bounds__(256) void fc_tail_kernel(FcTail t, const float* __r
             if (m < N && n < t.d2) acts[t.a2 + (size_t)m * t.d2 + n] = v;
         }
     }
+#if defined(CLHIP_TAIL_STOP) && CLHIP_TAIL_STOP == 2
+    return;
+#endif
     __syncthreads();
     // ---- logits = h2 . W3^T + b3 (one column tile: d3 <= 32)
     if (wave == 0) {
@@ -286,6 +292,9 @@ __global__ __launch_bounds__(256) void fc_tail_kernel(FcTail t, const float* __r
             if (m < N && li < t.d3) acts[t.a3 + (size_t)m * t.d3 + li] = v;
         }
     }
+#if defined(CLHIP_TAIL_STOP) && CLHIP_TAIL_STOP == 3
+    return;
+#endif
     if (!do_loss) return;
     __syncthreads();
     // ---- softmax cross-entropy per row: the per-row text of softmax_ce_rows_lds_kernel (loss.hip) — keep in sync
@@ -340,6 +349,9 @@ __global__ __launch_bounds__(256) void fc_tail_kernel(FcTail t, const float* __r
         const int row = e / ld, c = e - row * ld;
         if (m0 + row < N) dlogits[(size_t)(m0 + row) * ld + c] = zs[row * ZL + c];
     }
+#if defined(CLHIP_TAIL_STOP) && CLHIP_TAIL_STOP == 4
+    return;
+#endif
     if (do_bwd) {
         // ---- dz2 = (dlogits . W3) masked by h2 > 0: K = d3 padded to 32 (zs columns >= d3 and W3s rows >= d3 are zero)
         if (n0 < K2) {
@@ -365,6 +377,9 @@ __global__ __launch_bounds__(256) void fc_tail_kernel(FcTail t, const float* __r
             }
         }
     }
+#if defined(CLHIP_TAIL_STOP) && CLHIP_TAIL_STOP == 5
+    return;
+#endif
     // ---- totals: the last workgroup to arrive sums the per-row values in softmax_ce_rows_lds_kernel's order
     __threadfence();
     __syncthreads();
@@ -407,10 +422,7 @@ __global__ __launch_bounds__(256) void fc_bwd_combo_kernel(clhip_gemm_args g, in
                                                            const float* __restrict__ x, int N, const float* __restrict__ acts,
                                                            const float* __restrict__ dlogits, const float* __restrict__ dz,
                                                            float* __restrict__ grads) {
-    if ((int)blockIdx.x < gemm_blocks) {
-        if (g.k_per_split <= 128 && g.K > 32) gemm_tile<true, false, 128>(g, blockIdx.x);
-        else gemm_tile<true, false>(g, blockIdx.x);
-    }
+    if ((int)blockIdx.x < gemm_blocks) gemm_tile<true, false>(g, blockIdx.x);
     else fc_chain_wgrad_block(c, tm, x, N, acts, dlogits, dz, grads, (int)blockIdx.x - gemm_blocks);
 }
 

@@ -68,10 +68,7 @@ int gemm_launch(const float* a, const float* b, float* out, int M, int N, int K,
     int m_tiles = (M + TM - 1) / TM, n_tiles = (N + TN - 1) / TN;
     float* dst = splits == 1 ? out : static_cast<float*>(ws);
     const clhip_gemm_args g{a, b, dst, M, N, K, sam, sak, sbk, sbn, n_tiles, splits, k_per_split, bias, mask_src, relu};
-    if (k_per_split <= 128 && K > BK)
-        hipLaunchKernelGGL((gemm_mfma_kernel<AK, BKc, 128>), dim3((unsigned)(m_tiles * n_tiles * splits)), dim3(256), 0, s, g);
-    else
-        hipLaunchKernelGGL((gemm_mfma_kernel<AK, BKc>), dim3((unsigned)(m_tiles * n_tiles * splits)), dim3(256), 0, s, g);
+    hipLaunchKernelGGL((gemm_mfma_kernel<AK, BKc>), dim3((unsigned)(m_tiles * n_tiles * splits)), dim3(256), 0, s, g);
     CLHIP_LAUNCH_CHECK();
     if (splits > 1) {
         hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(ew_grid(mn, 256)), dim3(256), 0, s,
@@ -97,10 +94,7 @@ int clhip_internal_fc_fwd_partial(const float* x, const float* w, int M, int I, 
     const int m_tiles = (M + TM - 1) / TM, n_tiles = (O + TN - 1) / TN;
     const clhip_gemm_args g{x, w, static_cast<float*>(ws), M, O, I, (long)I, 1L, 1L, (long)I, n_tiles, splits, k_per_split,
                      nullptr, nullptr, 0};
-    if (k_per_split <= 128)
-        hipLaunchKernelGGL((gemm_mfma_kernel<true, true, 128>), dim3((unsigned)(m_tiles * n_tiles * splits)), dim3(256), 0, s, g);
-    else
-        hipLaunchKernelGGL((gemm_mfma_kernel<true, true>), dim3((unsigned)(m_tiles * n_tiles * splits)), dim3(256), 0, s, g);
+    hipLaunchKernelGGL((gemm_mfma_kernel<true, true>), dim3((unsigned)(m_tiles * n_tiles * splits)), dim3(256), 0, s, g);
     CLHIP_LAUNCH_CHECK();
     *live = (I + k_per_split - 1) / k_per_split;
     return 0;

@@ -9,9 +9,10 @@ constexpr int TM = 64, TN = 64, BK = 32, LD = 65;
 
 // AK: A is contiguous along k (sak == 1); BKc: B is contiguous along k (sbk == 1)
 // one 64x64 output tile (and K split) of the strided GEMM; `block` = tile * splits + split
-// BKT: depth of a staged chunk.  32 by default; 128 when the whole k range of a block is at most 128 (the batch-200
-// classifier shapes): everything is loaded in one go, one barrier, 64 MFMAs — the chunked loop pays a global-load latency
-// and two barriers per 32 of k.  The MFMA sequence (and so every bit of the result) does not depend on BKT.
+// BKT: depth of a staged chunk (32).  Staging the whole k range of the batch-200 classifier shapes at once (BKT = 128, one
+// barrier, 64 MFMAs) was measured SLOWER than four pipelined 32-deep chunks: 11.5 vs 8.4 us forward, 14.1 vs 10.8 us
+// backward-data — the 64 scalar loads per thread in one burst take longer to land than the chunked loop hides.  The MFMA
+// sequence (and so every bit of the result) does not depend on BKT.
 template <bool AK, bool BKc, int BKT = BK>
 __device__ __forceinline__ void gemm_tile(const clhip_gemm_args& g, int block) {
     const float* __restrict__ a = g.a; const float* __restrict__ b = g.b; float* __restrict__ out = g.out;
