@@ -798,6 +798,195 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_relu_pool_kernel(
     }
 }
 
+// First layer for rows of whole 64-pixel runs (Tiny-ImageNet: W = 64): the pool window in ONE lane.
+//
+// In the kernel above a lane owns pixel column li, so the horizontal pool partner lives in lane^1: two DPP moves (+ their
+// hazard nops) per accumulator register, both lanes of a pair compute the same window, and the results take a detour
+// through an LDS slab to leave as 16-byte stores.  Measured by ablation (N = 200): that epilogue is ~25 us of VALU / LDS
+// issue next to ~21 us of MFMA, and the two do not overlap well on one SIMD.
+// Here lane li owns columns 2 li and 2 li + 1 of image rows h and h + 1 as FOUR accumulators (row x column parity), i.e. a
+// wave covers 2 rows x 64 columns x 32 output channels per unit: the 2x2 window is acc[0][0], acc[0][1], acc[1][0],
+// acc[1][1] of the same register and lane — no cross-lane traffic, no redundant lanes (half the VALU work per pooled
+// pixel), and register r of the 32 lanes of a half-wave IS a 128-byte run of the pooled row: it is stored directly.
+// Same arithmetic and scan order as above => the same bits (values and arg-max codes).
+//   unit = (row pair, 32-channel half): 56 MFMAs.  Units are dealt to the 1024 SIMDs of the chip as contiguous ranges (12 or
+//   13 each at N = 200), split over the two resident waves of a SIMD (512-thread blocks, one per CU): the balance of the
+//   old kernel, and consecutive units of a wave share their staged halo (two channel halves per row pair).
+#ifndef CLHIP_C3W64
+#define CLHIP_C3W64 1
+#endif
+constexpr int W6_TWP = 67;                          // odd row stride: the two taps of a k-pair sit on different banks
+constexpr int W6_PLANE = 4 * W6_TWP;                // 4 halo rows per channel
+constexpr int W6_HALO = 3 * W6_PLANE;               // 804 floats per wave and buffer
+
+template <bool FULL>       // FULL: every block owns 64 real output channels (no per-store channel predicate)
+__global__ __launch_bounds__(512) void conv3x3_c3w64_relu_pool_kernel(
+    const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
+    float* __restrict__ out, uint8_t* __restrict__ pool_idx, int N, int Cout, int H, int W,
+    int tiles_w, int row_pairs, int ntiles) {
+    __shared__ float halo_s[8 * 2 * W6_HALO];
+    __shared__ float bias_s[KT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kk = lane >> 5;
+    const int ko0 = blockIdx.y * KT;
+    if (tid < KT) bias_s[tid] = (bias && ko0 + tid < Cout) ? bias[ko0 + tid] : 0.f;
+
+    // K order and pairing: as in conv3x3_c3_relu_pool_kernel (the two taps of a pair differ by a fixed LDS offset)
+    float a[2][14];
+    auto tap = [&](int j, int& c, int& r, int& s) -> bool {
+        if (j < 9) { c = j / 3; s = j - 3 * c; r = kk; return true; }
+        if (j < 12) { c = j - 9; r = 2; s = kk; return true; }
+        if (j == 12) { c = kk; r = 2; s = 2; return true; }
+        c = 2; r = 2; s = 2; return kk == 0;
+    };
+#pragma unroll
+    for (int j = 0; j < 14; ++j) {
+        int c, r, s2;
+        const bool real = tap(j, c, r, s2);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int ch = ko0 + 32 * half + li;
+            a[half][j] = (real && ch < Cout) ? wt[(size_t)ch * 27 + c * 9 + r * 3 + s2] : 0.f;
+        }
+    }
+    const int b_row = 2 * li + kk * W6_TWP, b_col = 2 * li + kk, b_pln = 2 * li + kk * W6_PLANE;
+    auto b_addr = [&](int j) -> int {               // LDS offset of tap (j, kk) for image row 0, even column of the lane
+        if (j < 9) return b_row + (j / 3) * W6_PLANE + (j % 3);
+        if (j < 12) return b_col + (j - 9) * W6_PLANE + 2 * W6_TWP;
+        if (j == 12) return b_pln + 2 * W6_TWP + 2;
+        return 2 * li + 2 * W6_PLANE + 2 * W6_TWP + 2;              // kk = 1 reads the same finite value; its A is 0
+    };
+
+    // units of this wave
+    const int simd = blockIdx.x * 4 + (wave & 3), nsimd = gridDim.x * 4;
+    const int units = 2 * ntiles;
+    const int per = units / nsimd, rem = units - per * nsimd;
+    const int s_start = simd * per + min(simd, rem), s_cnt = per + (simd < rem ? 1 : 0);
+    const int first = (s_cnt + 1) >> 1;
+    const int u0 = __builtin_amdgcn_readfirstlane((wave >> 2) ? s_start + first : s_start);
+    const int u1 = __builtin_amdgcn_readfirstlane((wave >> 2) ? s_start + s_cnt : s_start + first);
+
+    // staging of a [3][4][66] halo (rows h-1 .. h+2, columns w0-1 .. w0+64): lane l loads column w0 + l of the 12
+    // (channel, row) lines, lanes 0..23 the two border columns; out-of-image elements read as zero (buffer range check)
+    const size_t plane_hw = (size_t)H * W;
+    const __amdgpu_buffer_rsrc_t r_x = clhip_rsrc(x, (size_t)N * 3 * plane_hw * 4);
+    float sv[13];
+    const int e_line = lane >> 1, e_side = lane & 1, e_c = e_line >> 2, e_rr = e_line & 3;
+    auto tile_coords = [&](int t, int& n, int& h, int& w0) {
+        const int tw = t % tiles_w, q = t / tiles_w;
+        const int rp = q % row_pairs;
+        n = q / row_pairs; h = 2 * rp; w0 = tw * 64;
+    };
+    auto load_tile = [&](int t) {
+        int n, h, w0;
+        tile_coords(t, n, h, w0);
+        const int base = (n * 3 * H + h - 1) * W + w0;          // element (n, c = 0, row h - 1, column w0); may be negative
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const int c = i >> 2, rr = i & 3;
+            const bool ok = (unsigned)(h - 1 + rr) < (unsigned)H;
+            sv[i] = clhip_buf_load(r_x, ok ? (base + (c * H + rr) * W + lane) * 4 : CLHIP_OOB, 0);
+        }
+        const int ecol = w0 + (e_side ? 64 : -1);
+        const bool eok = lane < 24 && (unsigned)(h - 1 + e_rr) < (unsigned)H && (unsigned)ecol < (unsigned)W;
+        sv[12] = clhip_buf_load(r_x, eok ? ((n * 3 * H + h - 1) * W + (e_c * H + e_rr) * W + ecol) * 4 : CLHIP_OOB, 0);
+    };
+    float* hw_s = halo_s + wave * (2 * W6_HALO);
+    auto store_tile = [&](int buf) {
+        float* d = hw_s + buf * W6_HALO;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) d[(i >> 2) * W6_PLANE + (i & 3) * W6_TWP + 1 + lane] = sv[i];
+        if (lane < 24) d[e_c * W6_PLANE + e_rr * W6_TWP + (e_side ? 65 : 0)] = sv[12];
+    };
+
+    const int OH = H >> 1, OW = W >> 1;
+    const int chw = OH * OW;
+    const __amdgpu_buffer_rsrc_t r_o = clhip_rsrc(out, (size_t)N * Cout * chw * 4);
+    const __amdgpu_buffer_rsrc_t r_i = clhip_rsrc(pool_idx, (size_t)N * Cout * chw);
+    __syncthreads();                                // bias_s
+    if (u0 >= u1) return;
+    int t_cur = u0 >> 1;
+    const int t_last = (u1 - 1) >> 1;
+    int buf = 0;
+    load_tile(t_cur);
+    store_tile(0);
+    if (t_cur < t_last) load_tile(t_cur + 1);
+    for (int u = u0; u < u1; ++u) {
+        const int t = u >> 1, half = u & 1;
+        if (t != t_cur) {                           // next row pair: its halo was loaded while the previous one computed
+            buf ^= 1;
+            store_tile(buf);
+            t_cur = t;
+            if (t_cur < t_last) load_tile(t_cur + 1);
+        }
+        float ac[14];
+#pragma unroll
+        for (int j = 0; j < 14; ++j) ac[j] = half ? a[1][j] : a[0][j];
+        floatx16 acc[2][2];
+        const float* xs = hw_s + buf * W6_HALO;
+        float b[2][2][14];
+#pragma unroll
+        for (int j = 0; j < 14; ++j)
+#pragma unroll
+            for (int row = 0; row < 2; ++row)
+#pragma unroll
+                for (int par = 0; par < 2; ++par) b[row][par][j] = xs[b_addr(j) + row * W6_TWP + par];
+        __builtin_amdgcn_sched_barrier(0);          // all LDS reads in flight before the first MFMA
+        {   // first k-pair: C operand is the constant 0 (no 64 v_mov to clear the accumulators)
+            const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[0], b[0][0][0], zero, 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[0], b[0][1][0], zero, 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[0], b[1][0][0], zero, 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[0], b[1][1][0], zero, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 1; j < 14; ++j) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[j], b[0][0][j], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[j], b[0][1][j], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[j], b[1][0][j], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[j], b[1][1][j], acc[1][1], 0, 0, 0);
+        }
+        // epilogue: window = {(h, w), (h, w+1), (h+1, w), (h+1, w+1)}, first maximum in that scan order wins (ATen
+        // max_pool2d); lanes 0-31 store the pooled run of channel c, lanes 32-63 that of channel c + 4
+        int n, h, w0;
+        tile_coords(t, n, h, w0);
+        const int cbase = ko0 + 32 * half;
+        const int obase = ((n * Cout + cbase) * OH + (h >> 1)) * OW + (w0 >> 1);      // scalar part of the output offset
+        const int ovoff = (4 * kk * chw + li);                                        // lane part (elements)
+        const float* bias_k = bias_s + 32 * half + 4 * kk;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c0 = (r & 3) + 8 * (r >> 2);
+            const float bv = bias_k[c0];
+            const float tl = fmaxf(acc[0][0][r] + bv, 0.f), tr = fmaxf(acc[0][1][r] + bv, 0.f);
+            const float bl = fmaxf(acc[1][0][r] + bv, 0.f), br = fmaxf(acc[1][1][r] + bv, 0.f);
+            float m = tl; int am = 0;
+            if (tr > m) { m = tr; am = 1; }
+            if (bl > m) { m = bl; am = 2; }
+            if (br > m) { m = br; am = 3; }
+            const bool cok = FULL || cbase + c0 + 4 * kk < Cout;
+            clhip_buf_store(m, r_o, cok ? ovoff * 4 : CLHIP_OOB, (obase + c0 * chw) * 4);
+            clhip_buf_store_u8((uint8_t)am, r_i, cok ? ovoff : CLHIP_OOB, obase + c0 * chw);
+        }
+    }
+}
+
+int launch_c3w64_pool(const float* x, const float* wt, const float* bias, float* out, uint8_t* idx,
+                      int N, int Cout, int H, int W, hipStream_t s) {
+    const int tiles_w = W / 64, row_pairs = H / 2;
+    const long long ntiles = (long long)tiles_w * row_pairs * N;
+    const int kts = (Cout + KT - 1) / KT;
+    long long gx = 256;                             // one 8-wave block per CU
+    if (gx * 8 > 2 * ntiles) gx = (2 * ntiles + 7) / 8;
+    if (Cout % KT == 0)
+        hipLaunchKernelGGL(conv3x3_c3w64_relu_pool_kernel<true>, dim3((unsigned)gx, (unsigned)kts), dim3(512), 0, s,
+                           x, wt, bias, out, idx, N, Cout, H, W, tiles_w, row_pairs, (int)ntiles);
+    else
+        hipLaunchKernelGGL(conv3x3_c3w64_relu_pool_kernel<false>, dim3((unsigned)gx, (unsigned)kts), dim3(512), 0, s,
+                           x, wt, bias, out, idx, N, Cout, H, W, tiles_w, row_pairs, (int)ntiles);
+    CLHIP_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_c3_pool(const float* x, const float* wt, const float* bias, float* out, uint8_t* idx,
                    int N, int Cout, int H, int W, hipStream_t s) {
     const int tiles_w = W / C3_TW, tiles_h = (H + C3_TH - 1) / C3_TH;
@@ -844,6 +1033,9 @@ int clhip_conv3x3_relu_pool_fwd(const float* x, const float* w, const float* b, 
     if (!x || !w || !y_pool || !idx_u8 || N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1))
         return CLHIP_EINVAL;
     hipStream_t s = as_stream(stream);
+    if (CLHIP_C3W64 && C == 3 && W % 64 == 0 && H % 2 == 0 && (size_t)N * 3 * H * W < ((size_t)1 << 29) &&
+        (size_t)N * K * (H / 2) * (W / 2) < ((size_t)1 << 29))
+        return launch_c3w64_pool(x, w, b, y_pool, idx_u8, N, K, H, W, s);
     if (C == 3 && W % C3_TW == 0) return launch_c3_pool(x, w, b, y_pool, idx_u8, N, K, H, W, s);
 
     if (C <= 4) return launch_conv<4, 0, false>(x, w, b, nullptr, y_pool, N, C, K, H, W, K, C, 1, s, idx_u8);
