@@ -614,6 +614,148 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_smallc_kernel(
     }
 }
 
+// First layer with the fused max-pool backward, rows of whole 32-pixel tiles: the un-pooled gradient is never built.
+//
+// The kernel above expands every pooled gradient into its 2x2 window in LDS (4 compares + 4 selects + 4 LDS writes per
+// pooled element, two block barriers per 64-pixel stage) before 16 MFMAs per wave can run: 0.44 MFMA-busy.  Here the A
+// operand of an MFMA (32 channels x the two pixels 2wp, 2wp+1 of image row h0 + wh) is formed in registers: lane
+// (channel, kk) holds the pooled gradient g and arg-max code of window wp of ITS channel (16 windows of a stage = four
+// 16-byte loads + one 16-byte load of codes per lane) and supplies  a = (code == 2 wh + kk) ? g : 0.  The x halo of the
+// wave's image row (3 channels x 3 rows x 34 columns) is wave-private in LDS, double buffered: no block barrier in the
+// stage loop, the four waves drift apart.  Stage order, pixel-pair order, the f64 bias sums and the final addition of the
+// two row halves are those of conv3x3_wgrad_smallc_kernel<32, 2> => every slab holds the same bits.
+#ifndef CLHIP_U3
+#define CLHIP_U3 1
+#endif
+constexpr int U3_TWP = 35, U3_PLANE = 3 * U3_TWP, U3_HALO = 3 * U3_PLANE + 5;      // 320 floats per wave and buffer
+
+__global__ __launch_bounds__(256) void conv3x3_wgrad_c3_unpool_kernel(
+    const float* __restrict__ x, const float* __restrict__ dyp, float* __restrict__ part,
+    int N, int C, int K, int H, int W, int tiles_w, int tiles_h, int total_stages, int splits, size_t slab_stride,
+    const uint8_t* __restrict__ pool_idx) {
+    __shared__ float halo[4 * 2 * U3_HALO];
+    __shared__ float red[2 * 16 * 64 + 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave & 1, wh = wave >> 1;
+    const int li = lane & 31, kk = lane >> 5;
+    const int split = blockIdx.x % splits;
+    const int kt = blockIdx.x / splits;
+    const int k0 = kt * KT;
+    const int per = total_stages / splits, extra = total_stages % splits;
+    const int st_begin = split * per + min(split, extra);
+    const int st_end = st_begin + per + (split < extra ? 1 : 0);
+
+    floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    double bsum = 0.0;
+
+    const int ncol = C * 9;
+    int col_off = 0;
+    if (li < ncol) {
+        const int cc = li / 9, rs = li - cc * 9;
+        col_off = cc * U3_PLANE + (rs / 3) * U3_TWP + (rs % 3);
+    }
+    float* xs_w = halo + wave * (2 * U3_HALO);
+    const int OH = H >> 1, OW = W >> 1;
+    const int k = k0 + wk * 32 + li;
+    const bool kok = k < K;
+    const unsigned want = 2 * wh + kk;
+    const __amdgpu_buffer_rsrc_t r_dy = clhip_rsrc(dyp, (size_t)N * K * OH * OW * 4);
+    const __amdgpu_buffer_rsrc_t r_ix = clhip_rsrc(pool_idx, (size_t)N * K * OH * OW);
+    const __amdgpu_buffer_rsrc_t r_x = clhip_rsrc(x, (size_t)N * C * H * W * 4);
+    // halo element e = lane + 64 j of [3 channels][3 rows][34 columns]
+    int xe_c[5], xe_r[5], xe_w[5], xe_dst[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int e = lane + 64 * j;
+        const int c = e / 102, rem = e - c * 102, row = rem / 34, col = rem - row * 34;
+        xe_c[j] = (e < 306 && c < C) ? c : -1; xe_r[j] = row; xe_w[j] = col;
+        xe_dst[j] = e < 306 ? c * U3_PLANE + row * U3_TWP + col : 3 * U3_PLANE + (lane & 3);       // spare words behind the planes
+    }
+    struct Stage { float4 g[4]; clhip_u32x4 code; float xr[5]; };
+
+    int cur_n, cur_th, cur_tw;
+    {
+        const int st0 = st_begin < st_end ? st_begin : 0;
+        cur_tw = st0 % tiles_w;
+        const int t0 = st0 / tiles_w;
+        cur_th = t0 % tiles_h;
+        cur_n = t0 / tiles_h;
+    }
+    auto load_stage = [&](Stage& S) {
+        const int n = cur_n, h0 = cur_th * 2, w0 = cur_tw * 32;
+        if (++cur_tw == tiles_w) { cur_tw = 0; if (++cur_th == tiles_h) { cur_th = 0; ++cur_n; } }
+        const int o = ((n * K + k) * OH + (h0 >> 1)) * OW + (w0 >> 1);         // 16 pooled windows of this lane's channel
+#pragma unroll
+        for (int j = 0; j < 4; ++j) S.g[j] = clhip_buf_load4(r_dy, kok ? (o + 4 * j) * 4 : CLHIP_OOB, 0);
+        S.code = __builtin_amdgcn_raw_buffer_load_b128(r_ix, kok ? o : CLHIP_OOB, 0, 0);
+        const int hrow = h0 + wh;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int ih = hrow - 1 + xe_r[j], iw = w0 - 1 + xe_w[j];
+            const bool ok = xe_c[j] >= 0 && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+            S.xr[j] = clhip_buf_load(r_x, ok ? (((n * C + xe_c[j]) * H + ih) * W + iw) * 4 : CLHIP_OOB, 0);
+        }
+    };
+    auto store_x = [&](const Stage& S, int buf) {
+        float* d = xs_w + buf * U3_HALO;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) d[xe_dst[j]] = S.xr[j];
+    };
+    auto compute = [&](const Stage& S, int buf) {
+        const float* bp = xs_w + buf * U3_HALO + col_off + kk;
+#pragma unroll
+        for (int wp = 0; wp < 16; ++wp) {
+            const float g = wp & 2 ? (wp & 1 ? S.g[wp >> 2].w : S.g[wp >> 2].z) : (wp & 1 ? S.g[wp >> 2].y : S.g[wp >> 2].x);
+            const unsigned word = S.code[wp >> 2];
+            const unsigned code = (word >> (8 * (wp & 3))) & 0xffu;
+            const float a = code == want ? g : 0.f;
+            bsum += (double)a;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[2 * wp], acc, 0, 0, 0);
+        }
+    };
+
+    if (st_begin < st_end) {
+        Stage SA, SB;
+        load_stage(SA);
+        store_x(SA, 0);
+        int st = st_begin;
+        while (true) {
+            if (st + 1 < st_end) load_stage(SB);
+            compute(SA, 0);
+            if (st + 1 >= st_end) break;
+            store_x(SB, 1);
+            ++st;
+            if (st + 1 < st_end) load_stage(SA);
+            compute(SB, 1);
+            if (st + 1 >= st_end) break;
+            store_x(SA, 0);
+            ++st;
+        }
+    }
+    // combine the two row halves through LDS, fixed order: half 0 + half 1 (as conv3x3_wgrad_smallc_kernel)
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (wh == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wk * 16 + r) * 64 + lane] = acc[r];
+        if (kk == 0) red[2048 + wk * 32 + li] = (float)bsum;
+    }
+    __syncthreads();
+    if (wh == 0) {
+        float* slab = part + (size_t)split * slab_stride;
+        if (li < ncol) {
+            const int cc = li / 9, rs = li - cc * 9;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kr = k0 + wk * 32 + mfma32_row(r, lane);
+                if (kr < K) slab[((size_t)rs * K + kr) * C + cc] = acc[r] + red[(wk * 16 + r) * 64 + lane];
+            }
+        }
+        if (kk == 0 && kok) slab[(size_t)9 * K * C + k] = (float)(bsum + (double)red[2048 + wk * 32 + li]);
+    }
+}
+
 // Fixed-order reduction of the partial slabs in ONE launch (the two tiny launches it replaces were launch-latency
 // bound: 12 us per layer and pass).  Block = 64 consecutive elements x 16 split-lanes: lane j sums its contiguous
 // range of splits in order (f64), the 16 partials meet in LDS and are added in order j = 0..15 — the same two-level
@@ -762,7 +904,10 @@ static int bwd_weight_impl(const float* x, const float* dy, const uint8_t* unpoo
     const bool smallc = (C * 9 <= 32);
     unsigned grid = (unsigned)(p.k_tiles * p.c_tiles * p.splits);
 #define WG_ARGS x, dy, part, N, C, K, H, W, p.tiles_w, p.tiles_h, p.total_stages, p.splits
-    if (smallc) {
+    if (CLHIP_U3 && smallc && unpool_idx && p.TW == 32 && W % 32 == 0 && aligned16(dy) && aligned16(unpool_idx) &&
+        (size_t)N * K * H * W < ((size_t)1 << 31) && (size_t)N * C * H * W < ((size_t)1 << 29)) {
+        hipLaunchKernelGGL(conv3x3_wgrad_c3_unpool_kernel, dim3(grid), dim3(256), 0, s, WG_ARGS, p.slab, unpool_idx);
+    } else if (smallc) {
         if (p.TW == 32) hipLaunchKernelGGL((conv3x3_wgrad_smallc_kernel<32, 2>), dim3(grid), dim3(256), 0, s, WG_ARGS, p.slab, unpool_idx);
         else if (p.TW == 16) hipLaunchKernelGGL((conv3x3_wgrad_smallc_kernel<16, 4>), dim3(grid), dim3(256), 0, s, WG_ARGS, p.slab, unpool_idx);
         else hipLaunchKernelGGL((conv3x3_wgrad_smallc_kernel<8, 8>), dim3(grid), dim3(256), 0, s, WG_ARGS, p.slab, unpool_idx);

@@ -11,5 +11,7 @@ for shape in ((200, 3, 64, 64, 64), (5, 3, 70, 12, 64), (3, 3, 64, 64, 128)):
     w = (0.2 * torch.randn(K, C, 3, 3, generator=g)).cuda()
     b = (0.1 * torch.randn(K, generator=g)).cuda()
     y, i = ops.conv3x3_relu_pool_fwd(x, w, b)
-    out[shape] = (y.cpu(), i.cpu())
+    dyp = torch.randn(y.shape, generator=g).cuda() * (y > 0)
+    dw, db = ops.conv3x3_bwd_weight_unpool(x, dyp, i)
+    out[shape] = (y.cpu(), i.cpu(), dw.cpu(), db.cpu())
 torch.save(out, sys.argv[1])

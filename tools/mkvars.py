@@ -4,4 +4,4 @@ from clsurvey_amd import build as b
 src = sys.argv[1]
 for spec in sys.argv[2:]:
     name, defs = spec.split("=", 1) if "=" in spec else (spec, "CLHIP_ABL_" + spec.upper())
-    print(b.build_variant(name, [src], defs.split(","), verbose=False))
+    print(b.build_variant(name, src.split("+"), defs.split(","), verbose=False))
