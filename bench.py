@@ -96,6 +96,8 @@ def parse():
 def conv_instance(C, H, W, N, K, mode, pool, unpool=False):
     """Name of the kernel the library launches for this layer (mirrors launch_conv / clhip_conv3x3_relu_pool_fwd in
     csrc/conv3x3.hip), so that the roofline entry can be matched against the rocprofv3 kernel stats in profiles/."""
+    if mode == 0 and pool and C == 3 and W % 64 == 0 and H % 2 == 0:
+        return "conv3x3_c3w64_relu_pool_kernel<%s>" % ("true" if K % 64 == 0 else "false")
     if mode == 0 and pool and C == 3 and W % 32 == 0:
         return "conv3x3_c3_relu_pool_kernel"
     kts = (K + 63) // 64
@@ -157,7 +159,8 @@ def time_kernels(eng, x, N, iters):
         if C == 3 and pool:
             t_w = timed(lambda: ops.conv3x3_bwd_weight_slabs(xin, dyp, idx))
             rows.append(dict(kernel="conv3x3_bwd_weight_unpool", layer=layer, flops=fl, sec=t_w,
-                             instance="conv3x3_wgrad_smallc_kernel", alg_bytes=4.0 * N * H * W * (C + K / 4.0)))
+                             instance="conv3x3_wgrad_c3_unpool_kernel" if W % 32 == 0 else "conv3x3_wgrad_smallc_kernel",
+                             alg_bytes=4.0 * N * H * W * (C + K / 4.0)))
         elif pool:
             t_w = timed(lambda: ops.conv3x3_bwd_weight_slabs(xin, dyp, idx))
             rows.append(dict(kernel="conv3x3_bwd_weight_unpool", layer=layer, flops=fl, sec=t_w,
@@ -596,6 +599,7 @@ def main():
             out["config"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         if world == 1 and not args.no_sweep:
             out["sweep"] = bounded_sweep(local_rank, cpu_threads=0 if args.no_cpu_baseline else out["cpu_baseline"]["cores"])
+            out["sweep_s"] = {"gpu": out["sweep"].get("gpu_s"), "cpu": out["sweep"].get("cpu_s")}      # same bounded sweep, both sides
         print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()          # rank 0 was still timing kernels: tear the communicator down together

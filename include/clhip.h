@@ -293,7 +293,13 @@ int clhip_net_forward(void* handle, const float* params, const float* x, int N, 
 int clhip_net_backward(void* handle, const float* params, float* grads, const float* x, int N, void* ws,
                        const float* dlogits, void* stream);
 /* loss_kind 0: CE mean, 1: CE sum, 2: sum of squared logits.  grads == NULL => forward + loss only
- * (validation / test).  stats as in clhip_softmax_ce.                                        */
+ * (validation / test).  stats as in clhip_softmax_ce.
+ * Small classifiers (Linear-ReLU-Linear-ReLU-Linear, hidden widths <= 128, <= 32 logits, no dropout inside) run
+ * everything behind the first Linear layer's GEMM — split-K sum, Linear 2-3, the loss, backward-data down to the first
+ * layer's output — as ONE launch, and the first layer's backward-data GEMM together with all Linear weight gradients as
+ * another; results are bit-identical to the per-layer launches (CLHIP_FC_TAIL=0 at plan creation selects those).  The
+ * fused launch keeps a 4-byte arrival counter in device memory owned by the plan: do not run ONE plan on two streams at
+ * the same time (its activations live in one workspace, so that was never meaningful).                             */
 int clhip_net_loss_step(void* handle, const float* params, float* grads, const float* x,
                         const int64_t* labels_i64, int N, int loss_kind, void* ws, float* loss_out,
                         double* stats, float* logits_out, void* stream);
