@@ -35,9 +35,13 @@ struct Geo {
     static constexpr int BP = TW * TH * NB;          // pixels per block tile
     static constexpr int TWP = TW + 2;               // halo row length
     static constexpr int PLANE = NB * (TH + 2) * TWP;  // floats per staged channel plane
-    static constexpr int NT = BP / 64;               // 32-pixel subtiles per wave
-    static_assert(BP == 64 || BP == 128, "block tile must hold 64 or 128 pixels");
-    static_assert(32 % TW == 0 || TW == 32, "TW must divide 32");
+    static constexpr int NT = (BP + 63) / 64;        // 32-pixel subtiles per wave
+    // DENSE: the tile is one whole TW x TH plane whose pixels are dealt to the lanes in linear order (pixel q = 32 s + li,
+    // slots past TW*TH idle) instead of as rows of a power-of-two rectangle: a 13x13 plane (AlexNet's 3x3 layers,
+    // models/net.py:96-125) fills 169 of 192 slots; 16x8 tiles covered 169 of 256.
+    static constexpr bool DENSE = (32 % TW != 0 && TW != 32);
+    static_assert(DENSE || BP == 64 || BP == 128, "block tile must hold 64 or 128 pixels");
+    static_assert(!DENSE || (NB == 1 && BP <= 192), "dense tiles: one plane of at most 192 pixels");
 };
 
 // Subtile s (32 pixels) / lane li -> pixel of the block tile.  With a fused 2x2 max-pool every 2x2 window must
@@ -51,6 +55,7 @@ __device__ __forceinline__ void tile_pixel(int s, int li, bool pool, int& nb, in
     } else {
         const int q = 32 * s + li;
         tw = q % TW; th = (q / TW) % TH; nb = q / (TW * TH);
+        if ((32 % TW != 0 && TW != 32) && q >= TW * TH) { nb = 0; th = TH; tw = 0; }     // idle slot of a dense tile: row TH is outside the image (never stored) but inside the halo plane
     }
 }
 
@@ -595,6 +600,9 @@ int launch_conv(const float* in, const float* wt, const float* bias, const float
 #endif
     const bool big = (pix / 128) * kts >= CLHIP_BIG_MIN;
 #define GEO(TW_, TH_, NB_) launch_geo<TW_, TH_, NB_, CK, MODE, VEC, UNPOOL>(in, wt, bias, mask_src, out, N, Cin, Cout, H, W, Kw, Cw, relu, s, pool_idx)
+    if constexpr (!VEC && !UNPOOL) {
+        if (H == 13 && W == 13 && !pool_idx) return GEO(13, 13, 1);      // whole-plane dense tile
+    }
     if (W > 16) return big ? GEO(32, 4, 1) : GEO(32, 2, 1);
     if (W > 8) return big ? GEO(16, 8, 1) : GEO(16, 4, 1);
     return (big && H > 4) ? GEO(8, 8, 2) : GEO(8, 8, 1);
