@@ -82,6 +82,8 @@ SIGNATURES = {
     "clhip_net_set_dropout": (_i, [_p, _i, _p, _l]),
     "clhip_net_set_bn": (_i, [_p, _i, _p, _p, _f, _f]),
     "clhip_net_set_training": (_i, [_p, _i]),
+    "clhip_net_probe": (_i, [_p, _i]),
+    "clhip_net_probe_read": (_i, [_p, C.POINTER(_f), C.POINTER(_i)]),
     "clhip_net_layer_input": (_i, [_p, _i, _p, _p]),
     "clhip_net_layer_pool_idx": (_i, [_p, _i, _p, _p]),
     "clhip_net_set_input_grad": (_i, [_p, _i, _p]),

@@ -67,20 +67,28 @@ __device__ __forceinline__ void tile_pixel(int s, int li, bool pool, int& nb, in
 // UNPOOL (MODE 1, VEC only): `in` is the gradient w.r.t. the 2x2-max-POOLED output [N][Cin][H/2][W/2] and `pool_idx` the
 // 2-bit arg-max codes of the forward pass; the un-pooled gradient tile is rebuilt while it is staged into LDS (fused
 // max_pool2d backward: the 4x larger tensor is never written nor read, and its kernel launch disappears).
+template <int TW, int TH, int NB, int CK>
+struct ConvLds {
+    static constexpr int BUF_FLOATS = CK * 9 * LDW + CK * Geo<TW, TH, NB>::PLANE;
+    static constexpr int FLOATS = 2 * BUF_FLOATS;
+};
+
+// The kernel body for block `bid` of a launch whose images start at `img0` (see conv3x3_mfma_mixed_kernel); `lds` and
+// `bias_s` are the launching kernel's shared arrays.
 template <int TW, int TH, int NB, int CK, int MODE, bool VEC, bool UNPOOL = false>
-__global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel(
+__device__ __forceinline__ void conv3x3_mfma_body(
     const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
     const float* __restrict__ mask_src, float* __restrict__ out,
     int N, int Cin, int Cout, int H, int W, int Kw, int Cw, int relu,
-    int tiles_w, int tiles_h, int n_pix_tiles, uint8_t* __restrict__ pool_idx) {
+    int tiles_w, int tiles_h, int n_pix_tiles, uint8_t* __restrict__ pool_idx,
+    const int bid, const int img0, float* __restrict__ lds, float* __restrict__ bias_s) {
     using G = Geo<TW, TH, NB>;
     static_assert(!UNPOOL || (MODE == 1 && VEC), "the fused un-pool lives in the 16-byte staging of backward-data");
     const bool pool = !UNPOOL && pool_idx != nullptr;     // MODE 0 only: out = 2x2-max-pooled relu(conv), idx = argmax
     constexpr int WS_FLOATS = CK * 9 * LDW;
     constexpr int XS_FLOATS = CK * G::PLANE;
     constexpr int BUF_FLOATS = WS_FLOATS + XS_FLOATS;
-    __shared__ float lds[2 * BUF_FLOATS];
-    __shared__ float bias_s[KT];
+    static_assert(BUF_FLOATS == ConvLds<TW, TH, NB, CK>::BUF_FLOATS, "shared-array size of the launching kernel");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -95,13 +103,12 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
 
     // block -> (output-channel tile, pixel tile); pixel tile fastest so concurrently resident
     // blocks share one weight slice in L2.
-    const int bid = blockIdx.x;
     const int kt = bid / n_pix_tiles;
     const int pt = bid - kt * n_pix_tiles;
     const int tw_i = pt % tiles_w;
     const int th_i = (pt / tiles_w) % tiles_h;
     const int ng = pt / (tiles_w * tiles_h);
-    const int n0 = ng * NB, h0 = th_i * TH, w0 = tw_i * TW;
+    const int n0 = img0 + ng * NB, h0 = th_i * TH, w0 = tw_i * TW;
     const int ko0 = kt * KT;        // first output channel of this block
     if (MODE == 0 && threadIdx.x < KT) bias_s[threadIdx.x] = (bias && ko0 + (int)threadIdx.x < Cout) ? bias[ko0 + threadIdx.x] : 0.f;
 
@@ -572,6 +579,40 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel
 }
 
 template <int TW, int TH, int NB, int CK, int MODE, bool VEC, bool UNPOOL = false>
+__global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_kernel(
+    const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
+    const float* __restrict__ mask_src, float* __restrict__ out,
+    int N, int Cin, int Cout, int H, int W, int Kw, int Cw, int relu,
+    int tiles_w, int tiles_h, int n_pix_tiles, uint8_t* __restrict__ pool_idx) {
+    __shared__ float lds[ConvLds<TW, TH, NB, CK>::FLOATS];
+    __shared__ float bias_s[KT];
+    conv3x3_mfma_body<TW, TH, NB, CK, MODE, VEC, UNPOOL>(in, wt, bias, mask_src, out, N, Cin, Cout, H, W, Kw, Cw, relu, tiles_w, tiles_h,
+                                                         n_pix_tiles, pool_idx, (int)blockIdx.x, 0, lds, bias_s);
+}
+
+// Two tile geometries in ONE launch: blocks [0, blocks_a) cover images [0, n_a) with TWxTHa tiles, the rest cover images
+// [n_a, N) with TWxTHb tiles (half the pixels).  1600 equal blocks on 256 CUs leave a quarter of the chip a seventh block
+// while the rest idles (layer 2 of small_VGG9 at N = 200 ran at 94 TFLOP/s, at N = 192 — whole rounds — at 104): the odd
+// images go out as half-size tiles that fill the last round evenly.  Same per-element arithmetic in either geometry.
+template <int TW, int THa, int THb, int CK, int MODE, bool VEC, bool UNPOOL = false>
+__global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_mixed_kernel(
+    const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
+    const float* __restrict__ mask_src, float* __restrict__ out,
+    int N, int Cin, int Cout, int H, int W, int Kw, int Cw, int relu,
+    int tiles_w, int tiles_ha, int tiles_hb, int n_a, int blocks_a, uint8_t* __restrict__ pool_idx) {
+    __shared__ float lds[ConvLds<TW, THa, 1, CK>::FLOATS];
+    __shared__ float bias_s[KT];
+    static_assert(ConvLds<TW, THb, 1, CK>::FLOATS <= ConvLds<TW, THa, 1, CK>::FLOATS, "the larger geometry sizes the LDS");
+    if ((int)blockIdx.x < blocks_a)
+        conv3x3_mfma_body<TW, THa, 1, CK, MODE, VEC, UNPOOL>(in, wt, bias, mask_src, out, n_a, Cin, Cout, H, W, Kw, Cw, relu, tiles_w,
+                                                              tiles_ha, tiles_w * tiles_ha * n_a, pool_idx, (int)blockIdx.x, 0, lds, bias_s);
+    else
+        conv3x3_mfma_body<TW, THb, 1, CK, MODE, VEC, UNPOOL>(in, wt, bias, mask_src, out, N, Cin, Cout, H, W, Kw, Cw, relu, tiles_w,
+                                                              tiles_hb, tiles_w * tiles_hb * (N - n_a), pool_idx,
+                                                              (int)blockIdx.x - blocks_a, n_a, lds, bias_s);
+}
+
+template <int TW, int TH, int NB, int CK, int MODE, bool VEC, bool UNPOOL = false>
 int launch_geo(const float* in, const float* wt, const float* bias, const float* mask_src, float* out,
                int N, int Cin, int Cout, int H, int W, int Kw, int Cw, int relu, hipStream_t s, uint8_t* pool_idx) {
     int tiles_w = (W + TW - 1) / TW, tiles_h = (H + TH - 1) / TH, ngrp = (N + NB - 1) / NB;
@@ -598,10 +639,31 @@ int launch_conv(const float* in, const float* wt, const float* bias, const float
 #ifndef CLHIP_BIG_MIN
 #define CLHIP_BIG_MIN 300
 #endif
+#ifndef CLHIP_MIXED_TILES
+#define CLHIP_MIXED_TILES 1
+#endif
     const bool big = (pix / 128) * kts >= CLHIP_BIG_MIN;
 #define GEO(TW_, TH_, NB_) launch_geo<TW_, TH_, NB_, CK, MODE, VEC, UNPOOL>(in, wt, bias, mask_src, out, N, Cin, Cout, H, W, Kw, Cw, relu, s, pool_idx)
     if constexpr (!VEC && !UNPOOL) {
         if (H == 13 && W == 13 && !pool_idx) return GEO(13, 13, 1);      // whole-plane dense tile
+    }
+    if constexpr (VEC) {
+        if (W > 16 && big && CLHIP_MIXED_TILES) {
+            // whole launch rounds of 128-pixel tiles, the remaining images as 64-pixel tiles (conv3x3_mfma_mixed_kernel)
+            const int tw_n = (W + 31) / 32, tha = (H + 3) / 4, thb = (H + 1) / 2;
+            const long long per_img = (long long)tw_n * tha * kts, total = per_img * N, rem = total % 256;
+            if (total > 256 && rem != 0 && rem <= 192) {
+                const int imgs_b = (int)((rem + per_img - 1) / per_img), n_a = N - imgs_b;
+                const long long blocks_a = per_img * n_a, blocks_b = (long long)tw_n * thb * kts * imgs_b;
+                if (n_a > 0 && blocks_a + blocks_b <= 0x7fffffffLL) {
+                    hipLaunchKernelGGL((conv3x3_mfma_mixed_kernel<32, 4, 2, CK, MODE, VEC, UNPOOL>), dim3((unsigned)(blocks_a + blocks_b)),
+                                       dim3(256), 0, s, in, wt, bias, mask_src, out, N, Cin, Cout, H, W, Kw, Cw, relu, tw_n, tha, thb, n_a,
+                                       (int)blocks_a, pool_idx);
+                    CLHIP_LAUNCH_CHECK();
+                    return 0;
+                }
+            }
+        }
     }
     if (W > 16) return big ? GEO(32, 4, 1) : GEO(32, 2, 1);
     if (W > 8) return big ? GEO(16, 8, 1) : GEO(16, 4, 1);

@@ -46,6 +46,8 @@ struct LayerPlan {
     size_t drop_off;       // float offset of that buffer in ws
 };
 
+constexpr unsigned PROBE_RING = 64;
+
 struct NetPlan {
     std::vector<LayerPlan> layers;
     int max_batch, in_c, in_h, in_w, n_classes;
@@ -66,6 +68,11 @@ struct NetPlan {
     // layers fc_first+1 .. end forward + cross-entropy + backward-data down to dz(h1) in one launch (fc_tail_kernel); the
     // arrival counter of its last-workgroup reduction is the plan's own 4 bytes of device memory (zero between launches),
     // so a plan must not run on two streams at once (it never could: the activations live in one workspace)
+    // measurement probe (clhip_net_probe): HIP events around the forward launch(es) of one layer, a ring of PROBE_RING
+    // pairs so that recording never waits for the GPU
+    int probe_layer;
+    unsigned probe_count;
+    std::vector<hipEvent_t> probe_ev;
     bool fc_tail, no_combo;
     unsigned* tail_counter;
     size_t off_rows;
@@ -79,6 +86,7 @@ struct NetPlan {
         for (hipEvent_t e : ev_wg) (void)hipEventDestroy(e);
         if (side) (void)hipStreamDestroy(side);
         if (tail_counter) (void)hipFree(tail_counter);
+        for (hipEvent_t e : probe_ev) (void)hipEventDestroy(e);
     }
 };
 
@@ -267,6 +275,8 @@ int clhip_net_create(const clhip_layer_desc* descs, int n_layers, int max_batch,
             p->side = nullptr;
         }
     }
+    p->probe_layer = -1;
+    p->probe_count = 0;
     p->fc_tail = false;
     p->no_combo = false;
     p->tail_counter = nullptr;
@@ -332,6 +342,41 @@ int clhip_net_set_input_grad(void* handle, int layer, const float* extra) {
     return 0;
 }
 
+// Measurement: time the forward launch(es) of plan layer `layer` with HIP events on the stream they are issued on
+// (layer < 0: off).  clhip_net_probe_read waits for the recorded launches and returns their average duration over the
+// last (at most 64) forward passes, then clears the count.
+int clhip_net_probe(void* handle, int layer) {
+    NetPlan* p = static_cast<NetPlan*>(handle);
+    if (!p || layer >= (int)p->layers.size()) return CLHIP_EINVAL;
+    if (layer >= 0 && p->probe_ev.empty()) {
+        p->probe_ev.resize(2 * PROBE_RING);
+        for (hipEvent_t& e : p->probe_ev)
+            if (hipEventCreate(&e) != hipSuccess) { p->probe_ev.clear(); return CLHIP_ENOTSUP; }
+    }
+    p->probe_layer = layer;
+    p->probe_count = 0;
+    return 0;
+}
+
+int clhip_net_probe_read(void* handle, float* avg_us, int* count) {
+    NetPlan* p = static_cast<NetPlan*>(handle);
+    if (!p || !avg_us || !count) return CLHIP_EINVAL;
+    const unsigned n = p->probe_count < PROBE_RING ? p->probe_count : PROBE_RING;
+    double sum = 0.0;
+    for (unsigned i = 0; i < n; ++i) {
+        const unsigned slot = (p->probe_count - 1 - i) % PROBE_RING;
+        float ms = 0.f;
+        hipError_t e = hipEventSynchronize(p->probe_ev[2 * slot + 1]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, p->probe_ev[2 * slot], p->probe_ev[2 * slot + 1]);
+        if (e != hipSuccess) return (int)e;
+        sum += ms;
+    }
+    *avg_us = n ? (float)(sum / n * 1e3) : 0.f;
+    *count = (int)n;
+    p->probe_count = 0;
+    return 0;
+}
+
 int clhip_net_set_training(void* handle, int training) {
     NetPlan* p = static_cast<NetPlan*>(handle);
     if (!p) return CLHIP_EINVAL;
@@ -373,6 +418,12 @@ static int net_forward_impl(void* handle, const float* params, const float* x, i
     for (size_t li = 0; li < n_run; ++li) {
         const LayerPlan& L = p->layers[li];
         float* y = acts + L.act_off;
+        const bool probed = (int)li == p->probe_layer && !p->probe_ev.empty();
+        if (probed) (void)hipEventRecord(p->probe_ev[2 * (p->probe_count % PROBE_RING)], as_stream(stream));
+        struct ProbeEnd {       // closes the pair when the layer's launches are issued (every exit of the loop body)
+            NetPlan* p; bool on; hipStream_t s;
+            ~ProbeEnd() { if (on) { (void)hipEventRecord(p->probe_ev[2 * (p->probe_count % PROBE_RING) + 1], s); ++p->probe_count; } }
+        } probe_end{p, probed, as_stream(stream)};
         if (L.drop && L.has_drop_buf) {       // masked copy: backward reads it as this layer's input, cur stays intact
             float* dropped = acts + L.drop_off;
             rc = drop_copy(cur, dropped, L.drop, L.drop_stride, L.in_elems, N, as_stream(stream));

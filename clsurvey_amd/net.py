@@ -296,6 +296,17 @@ class NetEngine:
             for bn in self.bns.values():
                 bn.num_batches_tracked += 1
 
+    def probe(self, layer):
+        """Measurement: HIP events around the forward launch(es) of plan layer `layer` from now on (None: off)."""
+        check(_lib.lib().clhip_net_probe(self._h, -1 if layer is None else int(layer)), "clhip_net_probe")
+
+    def probe_read(self):
+        """(average microseconds, passes covered) of the probed layer's forward launch since the last read (at most 64)."""
+        import ctypes as C
+        us, n = C.c_float(0.0), C.c_int(0)
+        check(_lib.lib().clhip_net_probe_read(self._h, C.byref(us), C.byref(n)), "clhip_net_probe_read")
+        return float(us.value), int(n.value)
+
     def _auto_drop(self, n):
         """nn.Dropout semantics (fresh Bernoulli(1-p)/(1-p) mask per element per pass while model.training, identity in
         eval mode) for the Dropout modules of the plan; drawn with torch's device generator."""

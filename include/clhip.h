@@ -273,6 +273,12 @@ int clhip_net_set_dropout(void* handle, int layer, const float* mask, long row_s
  * (nn.Module.train / eval). */
 int clhip_net_set_bn(void* handle, int layer, float* running_mean, float* running_var, float momentum, float eps);
 int clhip_net_set_training(void* handle, int training);
+/* Measurement only (bench.py's roofline object): HIP events around the forward launch(es) of plan layer `layer`, recorded
+ * on the stream of each clhip_net_forward / clhip_net_loss_step call into a ring of 64 pairs (layer < 0: off).
+ * clhip_net_probe_read waits for the recorded launches, returns their average duration in microseconds and how many
+ * passes it covers, and restarts the count. */
+int clhip_net_probe(void* handle, int layer);
+int clhip_net_probe_read(void* handle, float* avg_us, int* count);
 /* Where the arg-max bytes of a max-pooled conv layer live after a forward: byte offset into ws and bytes per
  * sample ([cout][oh][ow], window position r*k + c, first maximum wins).  With the saved activations
  * (clhip_net_layer_input) this is every non-linear decision the backward pass will use — what a parity harness
