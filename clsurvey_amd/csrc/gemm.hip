@@ -47,6 +47,148 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ d
     }
 }
 
+// ---------------------------------------------------------------------------------------------- wide layers
+// 128x128 output tile for the big classifiers (AlexNet: 9216 -> 4096 -> 4096 at batch 128, models/net.py:96-125): a wave
+// owns 2x2 accumulators (one LDS read per MFMA instead of two), a block moves half the operand bytes per flop of the 64x64
+// tile (with 128 rows the batch is ONE row tile: the 151 MB weight matrix is read once per pass, not twice), and the
+// operand that is contiguous in memory is fetched with 16-byte loads.  Same k order per output element inside a split; the
+// split partition differs from the 64x64 kernel's (deterministic either way).
+constexpr int WT = 128, WLD = WT + 1;
+
+template <bool AK, bool BKc>
+__global__ __launch_bounds__(256) void gemm_wide_kernel(clhip_gemm_args g) {
+    const float* __restrict__ a = g.a; const float* __restrict__ b = g.b; float* __restrict__ out = g.out;
+    const int M = g.M, N = g.N, K = g.K, n_tiles = g.n_tiles, splits = g.splits, k_per_split = g.k_per_split, relu = g.relu;
+    const long sam = g.sam, sak = g.sak, sbk = g.sbk, sbn = g.sbn;
+    const float* __restrict__ bias = g.bias; const float* __restrict__ mask_src = g.mask_src;
+    __shared__ float as[BK * WLD];
+    __shared__ float bs[BK * WLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1, li = lane & 31, kk = lane >> 5;
+    const int split = blockIdx.x % splits;
+    const int tile = blockIdx.x / splits;
+    const int tn = tile % n_tiles, tm = tile / n_tiles;
+    const int m0 = tm * WT, n0 = tn * WT;
+    const int k_begin = split * k_per_split;
+    const int k_end = min(K, k_begin + k_per_split);
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][c][r] = 0.f;
+
+    // 128 x 32 floats per operand and chunk = 1024 float4 = 4 per thread.  K-contiguous operand: thread -> (row e / 8,
+    // k4 = 4 (e % 8)); row-contiguous operand: thread -> (k = e / 32, row4 = 4 (e % 32)).
+    float4 ar[4], br[4];
+    const float4* zero4 = reinterpret_cast<const float4*>(clhip_zero16);      // out-of-range elements are loaded FROM 16 zero bytes (address select)
+    auto load_chunk = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = tid + 256 * j;
+            if (AK) {
+                const int ml = e >> 3, k = k0 + 4 * (e & 7), m = m0 + ml;
+                ar[j] = *((m < M && k < k_end) ? reinterpret_cast<const float4*>(a + (long)m * sam + k) : zero4);    // k_end % 4 == 0
+            } else {
+                const int kl = e >> 5, m = m0 + 4 * (e & 31), k = k0 + kl;
+                ar[j] = *((m < M && k < k_end) ? reinterpret_cast<const float4*>(a + (long)k * sak + m) : zero4);    // M % 4 == 0
+            }
+            if (BKc) {
+                const int nl = e >> 3, k = k0 + 4 * (e & 7), n = n0 + nl;
+                br[j] = *((n < N && k < k_end) ? reinterpret_cast<const float4*>(b + (long)n * sbn + k) : zero4);
+            } else {
+                const int kl = e >> 5, n = n0 + 4 * (e & 31), k = k0 + kl;
+                br[j] = *((n < N && k < k_end) ? reinterpret_cast<const float4*>(b + (long)k * sbk + n) : zero4);    // N % 4 == 0
+            }
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = tid + 256 * j;
+            if (AK) {
+                float* d = as + (4 * (e & 7)) * WLD + (e >> 3);
+                d[0] = ar[j].x; d[WLD] = ar[j].y; d[2 * WLD] = ar[j].z; d[3 * WLD] = ar[j].w;
+            } else {
+                float* d = as + (e >> 5) * WLD + 4 * (e & 31);
+                d[0] = ar[j].x; d[1] = ar[j].y; d[2] = ar[j].z; d[3] = ar[j].w;
+            }
+            if (BKc) {
+                float* d = bs + (4 * (e & 7)) * WLD + (e >> 3);
+                d[0] = br[j].x; d[WLD] = br[j].y; d[2 * WLD] = br[j].z; d[3 * WLD] = br[j].w;
+            } else {
+                float* d = bs + (e >> 5) * WLD + 4 * (e & 31);
+                d[0] = br[j].x; d[1] = br[j].y; d[2] = br[j].z; d[3] = br[j].w;
+            }
+        }
+    };
+    if (k_begin < k_end) load_chunk(k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+        __syncthreads();
+        store_chunk();
+        __syncthreads();
+        if (k0 + BK < k_end) load_chunk(k0 + BK);
+#pragma unroll
+        for (int k2 = 0; k2 < BK; k2 += 2) {
+            float av[2], bv[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) av[q] = as[(k2 + kk) * WLD + q * 64 + wm * 32 + li];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) bv[c] = bs[(k2 + kk) * WLD + c * 64 + wn * 32 + li];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) acc[q][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[c], acc[q][c], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int n = n0 + c * 64 + wn * 32 + li;
+        if (n >= N) continue;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + q * 64 + wm * 32 + mfma32_row(r, lane);
+                if (m < M) {
+                    float v = acc[q][c][r];
+                    if (splits == 1) {
+                        if (bias) v += bias[n];
+                        if (relu) v = fmaxf(v, 0.f);
+                        if (mask_src) v = mask_src[(size_t)m * N + n] > 0.f ? v : 0.f;
+                        out[(size_t)m * N + n] = v;
+                    } else {
+                        out[((size_t)split * M + m) * N + n] = v;
+                    }
+                }
+            }
+    }
+}
+
+// wide tiles: at least one full row tile and eight column tiles, 16-byte loads possible on both operands
+bool wide_ok(const float* a, const float* b, int M, int N, int K, long sam, long sak, long sbk, long sbn, bool AK, bool BKc) {
+#ifdef CLHIP_NO_WIDE_GEMM
+    return false;
+#endif
+    if (M < WT || N < 8 * WT || (K & 3)) return false;
+    if (!aligned16(a) || !aligned16(b)) return false;
+    if (AK ? (sam & 3) : ((sak & 3) || (M & 3))) return false;
+    if (BKc ? (sbn & 3) : ((sbk & 3) || (N & 3))) return false;
+    return true;
+}
+
+int choose_splits_wide(int M, int N, int K) {
+    int tiles = ((M + WT - 1) / WT) * ((N + WT - 1) / WT);
+    int s = 512 / tiles;
+    int max_by_k = K / 128;
+    if (s > max_by_k) s = max_by_k;
+    if (s > 32) s = 32;
+    if (s < 1) s = 1;
+    return s;
+}
+
 int choose_splits(int M, int N, int K) {
     int tiles = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
     int s = 512 / tiles;
@@ -61,14 +203,17 @@ template <bool AK, bool BKc>
 int gemm_launch(const float* a, const float* b, float* out, int M, int N, int K, long sam, long sak, long sbk,
                 long sbn, const float* bias, const float* mask_src, int relu, void* ws, size_t ws_bytes,
                 hipStream_t s) {
-    int splits = choose_splits(M, N, K);
+    const bool wide = wide_ok(a, b, M, N, K, sam, sak, sbk, sbn, AK, BKc);
+    int splits = wide ? choose_splits_wide(M, N, K) : choose_splits(M, N, K);
     size_t mn = (size_t)M * N;
     if (splits > 1 && (!ws || ws_bytes < mn * splits * sizeof(float))) splits = 1;
     int k_per_split = (((K + splits - 1) / splits) + BK - 1) / BK * BK;
-    int m_tiles = (M + TM - 1) / TM, n_tiles = (N + TN - 1) / TN;
+    const int T = wide ? WT : TM;
+    int m_tiles = (M + T - 1) / T, n_tiles = (N + T - 1) / T;
     float* dst = splits == 1 ? out : static_cast<float*>(ws);
     const clhip_gemm_args g{a, b, dst, M, N, K, sam, sak, sbk, sbn, n_tiles, splits, k_per_split, bias, mask_src, relu};
-    hipLaunchKernelGGL((gemm_mfma_kernel<AK, BKc>), dim3((unsigned)(m_tiles * n_tiles * splits)), dim3(256), 0, s, g);
+    if (wide) hipLaunchKernelGGL((gemm_wide_kernel<AK, BKc>), dim3((unsigned)(m_tiles * n_tiles * splits)), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_mfma_kernel<AK, BKc>), dim3((unsigned)(m_tiles * n_tiles * splits)), dim3(256), 0, s, g);
     CLHIP_LAUNCH_CHECK();
     if (splits > 1) {
         hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(ew_grid(mn, 256)), dim3(256), 0, s,
@@ -115,9 +260,10 @@ extern "C" {
 
 size_t clhip_fc_ws(int M, int I, int O) {
     if (M <= 0 || I <= 0 || O <= 0) return 0;
-    size_t a = (size_t)M * O * choose_splits(M, O, I);   // forward
-    size_t b = (size_t)M * I * choose_splits(M, I, O);   // backward-data
-    size_t c = (size_t)O * I * choose_splits(O, I, M);   // backward-weight
+    auto sp = [](int m, int n, int k) { const int u = choose_splits(m, n, k), v = choose_splits_wide(m, n, k); return u > v ? u : v; };
+    size_t a = (size_t)M * O * sp(M, O, I);   // forward
+    size_t b = (size_t)M * I * sp(M, I, O);   // backward-data
+    size_t c = (size_t)O * I * sp(O, I, M);   // backward-weight
     size_t m = a > b ? a : b;
     return (m > c ? m : c) * sizeof(float);
 }
