@@ -96,6 +96,32 @@ __global__ __launch_bounds__(PB) void maxpool_bwd_kernel(const float* __restrict
 // x 8 rows: no integer divisions (the general kernel does three 64-bit ones per element), window ranges by shifts when
 // the stride is 2.  Windows are visited in the same (oh, ow) order => the same sums.  AlexNet's 3x3 / 2 pools
 // (models/net.py:96-125), the pooled plane (gradient + arg-max bytes) staged once in LDS: 104 -> 49 us per launch at N = 128.
+// Forward for a compile-time window / stride: one block per plane, 32 columns x 8 rows of threads, no integer divisions;
+// the same scan order (first maximum wins, NaN propagates) => the same values and codes as maxpool_fwd_kernel.
+template <int K, int S>
+__global__ __launch_bounds__(PB) void maxpool_fwd_ks_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            uint8_t* __restrict__ idx, int H, int W, int OH, int OW) {
+    const size_t nc = blockIdx.x;
+    const float* xp = x + nc * H * W;
+    float* yp = y + nc * OH * OW;
+    uint8_t* ip = idx + nc * OH * OW;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int oh = ty; oh < OH; oh += PB / 32)
+        for (int ow = tx; ow < OW; ow += 32) {
+            const float* p = xp + (oh * S) * W + ow * S;
+            float m = p[0]; int a = 0;
+#pragma unroll
+            for (int r = 0; r < K; ++r)
+#pragma unroll
+                for (int c = 0; c < K; ++c) {
+                    const float v = p[r * W + c];
+                    if (v > m || v != v) { m = v; a = r * K + c; }
+                }
+            yp[oh * OW + ow] = m;
+            ip[oh * OW + ow] = (uint8_t)a;
+        }
+}
+
 constexpr int POOL_LDS_MAX = 1024;      // pooled plane (gradient + arg-max) staged in LDS: OH * OW <= 1024
 template <int K, int S>
 __global__ __launch_bounds__(PB) void maxpool_bwd_ks_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx,
@@ -148,6 +174,11 @@ int clhip_maxpool_fwd(const float* x, float* y, uint8_t* idx_u8, int NC, int H, 
     if (!x || !y || !idx_u8 || NC <= 0 || k < 1 || k > 15 || stride < 1 || H < k || W < k) return CLHIP_EINVAL;
     const int OH = (H - k) / stride + 1, OW = (W - k) / stride + 1;
     const size_t total = (size_t)NC * OH * OW;
+    if (k == 3 && stride == 2) {
+        hipLaunchKernelGGL((maxpool_fwd_ks_kernel<3, 2>), dim3((unsigned)NC), dim3(PB), 0, as_stream(stream), x, y, idx_u8, H, W, OH, OW);
+        CLHIP_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(total, PB)), dim3(PB), 0, as_stream(stream), x, y, idx_u8, total, H, W, OH, OW, k, stride);
     CLHIP_LAUNCH_CHECK();
     return 0;
