@@ -18,7 +18,7 @@
 
 namespace {
 
-constexpr int TM = 64, TN = 64, BK = 32, LD = 65;
+constexpr int TM = 64, TN = 64, BK = 32;
 constexpr int TAB_MAX = 256;           // taps per kernel window (R*S): AlexNet max 11*11 = 121
 
 struct ConvP { int N, C, H, W, K, R, S, st, pad, OH, OW; };
