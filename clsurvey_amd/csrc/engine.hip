@@ -47,6 +47,9 @@ struct LayerPlan {
 };
 
 constexpr unsigned PROBE_RING = 64;
+#ifndef CLHIP_OVERLAP_DEFAULT
+#define CLHIP_OVERLAP_DEFAULT 0
+#endif
 
 struct NetPlan {
     std::vector<LayerPlan> layers;
@@ -79,6 +82,7 @@ struct NetPlan {
     // backward (optional, CLHIP_WGRAD_OVERLAP=1): the weight-gradient launches of the conv layers run on a side stream
     // next to the backward-data launch of the same layer (both only read dy)
     bool overlap;
+    int overlap_mode;        // 0 off, 1 every conv layer (CLHIP_WGRAD_OVERLAP=1), 2 only layers whose launches under-fill the chip
     hipStream_t side;
     std::vector<hipEvent_t> ev_dy, ev_wg;      // per layer: dy ready (main -> side), weight gradient done (side -> main)
     ~NetPlan() {
@@ -259,10 +263,15 @@ int clhip_net_create(const clhip_layer_desc* descs, int n_layers, int max_batch,
     // Measured on small_VGG9 (N = 200): 2.59 ms per bench step with the overlap against 2.45 ms without (the two
     // MFMA-bound kernels only take slots from each other); AlexNet N = 128: 9.65 vs 9.76 ms.  Hence off unless
     // CLHIP_WGRAD_OVERLAP=1; results are identical either way (same kernels, same order per stream).
+    // Round 2 tried the side stream for the DEEP layers only (planes of 16x16 and smaller at batch 200: ~400 blocks, 1.5 per
+    // CU, SIMD time left unused) with the slab reductions still deferred: 2.125 against 2.076 ms per step — the event
+    // hand-offs and the two launches taking each other's slots cost more than the idle time they fill.  So: off by default;
+    // CLHIP_WGRAD_OVERLAP=1 every conv layer, =2 the deep layers only.
     const char* ov = getenv("CLHIP_WGRAD_OVERLAP");
     bool any_bn = false;
     for (const LayerPlan& L : p->layers) any_bn = any_bn || L.bn;
-    if (ov && ov[0] == '1' && !any_bn) {      // BatchNorm backward shares `scratch` with the weight-gradient launches
+    p->overlap_mode = (ov && ov[0] == '1') ? 1 : (ov && ov[0] == '2') ? 2 : CLHIP_OVERLAP_DEFAULT;
+    if (p->overlap_mode && !any_bn) {         // BatchNorm backward shares `scratch` with the weight-gradient launches
         // needs a device: plans made on a host without one (shape tests) simply stay single-stream
         if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) == hipSuccess) {
             p->overlap = true;
@@ -534,7 +543,13 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
     const int top = (int)p->layers.size() - 1;
     float* fcdz = reinterpret_cast<float*>(base + p->off_fcdz);
     hipStream_t main_s = as_stream(stream);
-    const bool ov = p->overlap;
+    const bool ov = p->overlap && p->overlap_mode == 1;          // every layer on the side stream: immediate reductions
+    const bool ov_small = p->overlap && p->overlap_mode == 2;    // only the under-filled deep layers; slabs stay deferred
+    auto side_ok = [&](int layer) {
+        if (ov) return true;
+        const LayerPlan& Ls = p->layers[layer];
+        return ov_small && Ls.type == 0 && Ls.wg3 && Ls.h * Ls.w <= 256;
+    };
     hipEvent_t pending[2] = {nullptr, nullptr};      // side-stream reader of g[b] that must finish before g[b] is rewritten
     hipEvent_t last_side = nullptr;
     int taken = -1;
@@ -551,7 +566,7 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
     };
     // run `launch(stream)` (a weight-gradient launch reading dy = g[dy_buf]) on the side stream once main has produced dy
     auto on_side = [&](int layer, int dy_buf, auto&& launch) -> int {
-        if (!ov) return launch(stream);
+        if (!side_ok(layer)) return launch(stream);
         hipError_t e = hipEventRecord(p->ev_dy[layer], main_s);
         if (e == hipSuccess) e = hipStreamWaitEvent(p->side, p->ev_dy[layer], 0);
         if (e != hipSuccess) return (int)e;
@@ -704,13 +719,13 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
             }
         }
     }
+    if (last_side) {      // join: every slab / gradient of the side stream is complete on the caller's stream from here on
+        hipError_t e = hipStreamWaitEvent(main_s, last_side, 0);
+        if (e != hipSuccess) return (int)e;
+    }
     if (n_jobs) {
         rc = clhip_internal_wgrad_reduce_multi(jobs, n_jobs, main_s);
         if (rc) return rc;
-    }
-    if (last_side) {      // join: every gradient is complete on the caller's stream when this returns
-        hipError_t e = hipStreamWaitEvent(main_s, last_side, 0);
-        if (e != hipSuccess) return (int)e;
     }
     return 0;
 }

@@ -1,8 +1,6 @@
 #!/bin/bash
-set -u
-mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_gpu_parity.py -q -x -p no:cacheprovider -k "engine or alexnet or gem or golden" 2>&1 | tail -5
-echo "== overlap on";  timeout 300 python bench.py --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | tee gpurun_out/ov_on.json | cut -c1-400
-echo "== overlap off"; CLHIP_WGRAD_OVERLAP=0 timeout 300 python bench.py --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | tee gpurun_out/ov_off.json | cut -c1-400
-echo "== alexnet on";  timeout 300 python tools/alexnet_step.py 128 10 2>&1 | tail -1
-echo "== alexnet off"; CLHIP_WGRAD_OVERLAP=0 timeout 300 python tools/alexnet_step.py 128 10 2>&1 | tail -1
+for m in 2 0; do
+  echo "== CLHIP_WGRAD_OVERLAP=$m"
+  CLHIP_WGRAD_OVERLAP=$m timeout 200 python bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-configs --no-sweep 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"
+done
+timeout 900 python -m pytest tests/test_gpu_framework.py tests/test_gpu_parity.py -x -q -k "g10 or g17 or g18 or determin or net or engine or full_size" 2>&1 | tail -3
