@@ -16,6 +16,11 @@
 // The 3x3 pad-1 stride-1 VGG layers never come here (conv3x3.hip is 2-3x faster on them).
 #include "common.hpp"
 
+#ifdef CLHIP_TRACE
+__device__ unsigned long long* g_c2trace = nullptr;      // tuning aid: per-wave cycle sums of the loop phases
+#define C2_NOW() __builtin_amdgcn_s_memtime()
+#endif
+
 namespace {
 
 constexpr int TM = 64, TN = 64, BK = 32;
@@ -32,7 +37,7 @@ enum { OP_FWD = 0, OP_DGRAD = 1, OP_WGRAD = 2 };
 // Ablation of the 192 x 64 tile on AlexNet's conv2 forward (N = 128): MFMA phase alone 486 us, gathers alone 405 us
 // (5.9 TB/s of 4-byte requests out of L2), together 751 us.  The k order of every output element is the same for every tile.
 template <int OP, int RT, int CT>
-__global__ __launch_bounds__(256) void conv2d_gemm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(256, 2) void conv2d_gemm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ dy, float* __restrict__ out, ConvP p,
                                                          int M, int Nn, int Kd, int n_tiles, int splits, int k_per_split,
                                                          const float* __restrict__ bias, const float* __restrict__ mask_src,
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(256) void conv2d_gemm_kernel(const float* __restric
     // 1000 us for AlexNet's conv2 at N = 128)
     int ach = 0, ars = 0;
     if (OP == OP_DGRAD) { const int k = k_begin + (tid & 31); ach = k / RS; ars = k - ach * RS; }
-    int wcol_off[ITB], wcol_r[ITB], wcol_s[ITB];              // WGRAD: (c, r, s) of this thread's 8 CT columns
+    int wcol_off[ITB], wcol_rs[ITB];                          // WGRAD: (c, r, s) of this thread's 8 CT columns (r | s << 8)
     if (OP == OP_FWD) {
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
@@ -118,10 +123,10 @@ __global__ __launch_bounds__(256) void conv2d_gemm_kernel(const float* __restric
 #pragma unroll
         for (int j = 0; j < ITB; ++j) {
             const int n = n0 + (tid >> 5) + 8 * j;
-            wcol_off[j] = CLHIP_OOB; wcol_r[j] = 0; wcol_s[j] = 0;
+            wcol_off[j] = CLHIP_OOB; wcol_rs[j] = 0;
             if (n < Nn) {
                 const int c = n / RS, rs = n - c * RS, r = rs / p.S, s = rs - r * p.S;
-                wcol_off[j] = c * HW + r * p.W + s; wcol_r[j] = r; wcol_s[j] = s;
+                wcol_off[j] = c * HW + r * p.W + s; wcol_rs[j] = r | (s << 8);
             }
         }
     }
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(256) void conv2d_gemm_kernel(const float* __restric
             for (int j = 0; j < ITA; ++j) {
                 const int e = tid + 256 * j, ml = e / BK, kl = e - ml * BK;
                 const int m = m0 + ml, k = k0 + kl;
-                ar[j] = clhip_buf_load(rs_w, (m < M && k < k_end) ? (m * Kd + k) * 4 : CLHIP_OOB, 0);
+                ar[j] = clhip_buf_load(rs_w, ((m < M) & (k < k_end)) ? (m * Kd + k) * 4 : CLHIP_OOB, 0);
             }
 #pragma unroll
             for (int j = 0; j < IT; ++j) {
@@ -152,12 +157,11 @@ __global__ __launch_bounds__(256) void conv2d_gemm_kernel(const float* __restric
                 const int tap_off = bch[j] * HW + r * p.W + sx;
 #pragma unroll
                 for (int c = 0; c < CT; ++c) {
-                    int off = CLHIP_OOB;
-                    if (k < k_end && pix_base[c] != CLHIP_OOB) {
-                        const int h = pix_h[c] + r, ww = pix_w[c] + sx;
-                        if ((unsigned)h < (unsigned)p.H && (unsigned)ww < (unsigned)p.W) off = (pix_base[c] + tap_off) * 4;
-                    }
-                    br[c * IT + j] = clhip_buf_load(rs_x, off, 0);
+                    // predicates combined with & (no short circuit): v_cmp + s_and + ONE v_cndmask on the offset instead of an
+                    // exec-mask branch per element — the branchy form made ISSUING a chunk's gathers cost as much as its MFMAs
+                    const int h = pix_h[c] + r, ww = pix_w[c] + sx;
+                    const bool ok = (k < k_end) & (pix_base[c] != CLHIP_OOB) & ((unsigned)h < (unsigned)p.H) & ((unsigned)ww < (unsigned)p.W);
+                    br[c * IT + j] = clhip_buf_load(rs_x, ok ? (pix_base[c] + tap_off) * 4 : CLHIP_OOB, 0);
                 }
                 brs[j] += step_r; bch[j] += step_q;
                 if (brs[j] >= RS) { brs[j] -= RS; ++bch[j]; }
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(256) void conv2d_gemm_kernel(const float* __restric
 #pragma unroll
                 for (int j = 0; j < ITA; ++j) {
                     const int m = m0 + (tid >> 5) + 8 * j;
-                    ar[j] = clhip_buf_load(rs_w, (m < M && kok) ? (base + 8 * j * RS) * 4 : CLHIP_OOB, 0);
+                    ar[j] = clhip_buf_load(rs_w, ((m < M) & kok) ? (base + 8 * j * RS) * 4 : CLHIP_OOB, 0);
                 }
                 ars += step_r; ach += step_q;
                 if (ars >= RS) { ars -= RS; ++ach; }
@@ -181,17 +185,17 @@ __global__ __launch_bounds__(256) void conv2d_gemm_kernel(const float* __restric
                 const int rs = tab_rs[brs[j]];
 #pragma unroll
                 for (int c = 0; c < CT; ++c) {
-                    int off = CLHIP_OOB;
-                    if (k < k_end && pix_base[c] != CLHIP_OOB) {
-                        const int th = pix_h[c] - (rs >> 8), tw = pix_w[c] - (rs & 255);
-                        if (p.st == 1) {                 // uniform branch: no integer divisions on the stride-1 layers
-                            if ((unsigned)th < (unsigned)p.OH && (unsigned)tw < (unsigned)p.OW)
-                                off = (pix_base[c] + bch[j] * OHW + th * p.OW + tw) * 4;
-                        } else if (th >= 0 && tw >= 0) {
-                            const int oh = th / p.st, ow = tw / p.st;
-                            if (oh * p.st == th && ow * p.st == tw && oh < p.OH && ow < p.OW)
-                                off = (pix_base[c] + bch[j] * OHW + oh * p.OW + ow) * 4;
-                        }
+                    const int th = pix_h[c] - (rs >> 8), tw = pix_w[c] - (rs & 255);
+                    const bool live = (k < k_end) & (pix_base[c] != CLHIP_OOB);
+                    int off;
+                    if (p.st == 1) {                 // uniform branch: no integer divisions on the stride-1 layers
+                        const bool ok = live & ((unsigned)th < (unsigned)p.OH) & ((unsigned)tw < (unsigned)p.OW);
+                        off = ok ? (pix_base[c] + bch[j] * OHW + th * p.OW + tw) * 4 : CLHIP_OOB;
+                    } else {
+                        const int ths = th < 0 ? 0 : th, tws = tw < 0 ? 0 : tw;
+                        const int oh = ths / p.st, ow = tws / p.st;
+                        const bool ok = live & (th >= 0) & (tw >= 0) & (oh * p.st == th) & (ow * p.st == tw) & (oh < p.OH) & (ow < p.OW);
+                        off = ok ? (pix_base[c] + bch[j] * OHW + oh * p.OW + ow) * 4 : CLHIP_OOB;
                     }
                     br[c * IT + j] = clhip_buf_load(rs_dy, off, 0);
                 }
@@ -219,16 +223,13 @@ __global__ __launch_bounds__(256) void conv2d_gemm_kernel(const float* __restric
 #pragma unroll
             for (int j = 0; j < ITA; ++j) {
                 const int m = m0 + (tid >> 5) + 8 * j;
-                ar[j] = clhip_buf_load(rs_dy, (a_base != CLHIP_OOB && m < M) ? (a_base + m * OHW) * 4 : CLHIP_OOB, 0);
+                ar[j] = clhip_buf_load(rs_dy, ((a_base != CLHIP_OOB) & (m < M)) ? (a_base + m * OHW) * 4 : CLHIP_OOB, 0);
             }
 #pragma unroll
             for (int j = 0; j < ITB; ++j) {
-                int off = CLHIP_OOB;
-                if (b_base != CLHIP_OOB && wcol_off[j] != CLHIP_OOB) {
-                    const int h = ih0 + wcol_r[j], ww = iw0 + wcol_s[j];
-                    if ((unsigned)h < (unsigned)p.H && (unsigned)ww < (unsigned)p.W) off = (b_base + wcol_off[j]) * 4;
-                }
-                br[j] = clhip_buf_load(rs_x, off, 0);
+                const int h = ih0 + (wcol_rs[j] & 255), ww = iw0 + (wcol_rs[j] >> 8);
+                const bool ok = (b_base != CLHIP_OOB) & (wcol_off[j] != CLHIP_OOB) & ((unsigned)h < (unsigned)p.H) & ((unsigned)ww < (unsigned)p.W);
+                br[j] = clhip_buf_load(rs_x, ok ? (b_base + wcol_off[j]) * 4 : CLHIP_OOB, 0);
             }
         }
     };
@@ -249,12 +250,25 @@ __global__ __launch_bounds__(256) void conv2d_gemm_kernel(const float* __restric
         }
     };
 
+#ifdef CLHIP_TRACE
+    unsigned long long t_b1 = 0, t_st = 0, t_b2 = 0, t_ld = 0, t_mf = 0;
+    const unsigned long long t_begin = C2_NOW();
+#define C2_T(acc_) do { __builtin_amdgcn_s_waitcnt(0xc07f); const unsigned long long n__ = C2_NOW(); acc_ += n__ - t_last; t_last = n__; } while (0)
+    unsigned long long t_last = t_begin;
+#else
+#define C2_T(acc_) do {} while (0)
+#endif
     if (k_begin < k_end) load_chunk(k_begin);
     for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+        C2_T(t_mf);
         __syncthreads();
+        C2_T(t_b1);
         store_chunk();
+        C2_T(t_st);
         __syncthreads();
+        C2_T(t_b2);
         if (k0 + BK < k_end) load_chunk(k0 + BK);
+        C2_T(t_ld);
 #pragma unroll
         for (int k2 = 0; k2 < BK; k2 += 2) {
             float bv[CT], av[RT];
@@ -269,6 +283,13 @@ __global__ __launch_bounds__(256) void conv2d_gemm_kernel(const float* __restric
         }
     }
 
+#ifdef CLHIP_TRACE
+    C2_T(t_mf);
+    if (g_c2trace && lane == 0 && blockIdx.x < 4096) {
+        unsigned long long* t = g_c2trace + ((size_t)blockIdx.x * 4 + wave) * 8;
+        t[0] = t_begin; t[1] = t_last; t[2] = t_b1; t[3] = t_st; t[4] = t_b2; t[5] = t_ld; t[6] = t_mf; t[7] = (k_end - k_begin) / BK;
+    }
+#endif
     // ---- epilogue: reg r of lane l = C[m0 + 64 q + wm*32 + row(r)][n0 + 64 c + wn*32 + li]
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
@@ -372,11 +393,12 @@ int row_tiles(int M) {
     return best;
 }
 // two column tiles pay off next to two or three row tiles (measured on AlexNet's layers at N = 128: weight gradients
-// 5-17 % faster); with one row tile the wider gather costs more than it saves (conv2 backward-data 952 vs 854 us)
-int col_tiles(int M, int Nn) { return (row_tiles(M) >= 2 && Nn > 64) ? 2 : 1; }
+// 5-17 % faster) and, once the gather predicates were branch-free, for forward / backward-data with one row tile too
+// (conv1 forward 302 -> 274 us, conv2 backward-data 797 -> 772 us; conv1's weight gradient loses: 300 -> 326 us)
+int col_tiles(int M, int Nn, bool wgrad = false) { return ((row_tiles(M) >= 2 || !wgrad) && Nn > 64) ? 2 : 1; }
 
 int wgrad_splits(int M, int Nn, long Kd) {
-    const int rt = row_tiles(M), ct = col_tiles(M, Nn);
+    const int rt = row_tiles(M), ct = col_tiles(M, Nn, true);
     const int tiles = ((M + TM * rt - 1) / (TM * rt)) * ((Nn + TN * ct - 1) / (TN * ct));
     long s = (rt * ct > 1 ? 512 : 1024) / tiles;
     const long by_k = Kd / 256;
@@ -445,7 +467,7 @@ int clhip_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* d
     const size_t mn = (size_t)M * Nn;
     if (ws_bytes < mn * splits * sizeof(float) || (db && ws_bytes < (size_t)K * BIAS_SPLIT * sizeof(double))) return CLHIP_ENOSPC;
     const int k_per_split = (int)(((Kd + splits - 1) / splits + BK - 1) / BK * BK);
-    const int rt = row_tiles(M), ct = col_tiles(M, Nn);
+    const int rt = row_tiles(M), ct = col_tiles(M, Nn, true);
     const int n_tiles = (Nn + TN * ct - 1) / (TN * ct), m_tiles = (M + TM * rt - 1) / (TM * rt);
     hipStream_t s = as_stream(stream);
 #define CLHIP_C2_GO(RT_, CT_) hipLaunchKernelGGL((conv2d_gemm_kernel<OP_WGRAD, RT_, CT_>), dim3((unsigned)(m_tiles * n_tiles * splits)), dim3(256), 0, s, x, nullptr, dy, \
@@ -465,5 +487,12 @@ int clhip_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* d
     }
     return 0;
 }
+
+#ifdef CLHIP_TRACE
+int clhip_debug_set_conv2d_trace(void* p) {
+    unsigned long long* q = static_cast<unsigned long long*>(p);
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_c2trace), &q, sizeof(q));
+}
+#endif
 
 }  // extern "C"
