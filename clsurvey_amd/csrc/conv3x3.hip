@@ -957,7 +957,7 @@ __global__ __launch_bounds__(512) void conv3x3_c3w64_relu_pool_kernel(
             sv[i] = clhip_buf_load(r_x, ok ? (base + (c * H + rr) * W + lane) * 4 : CLHIP_OOB, 0);
         }
         const int ecol = w0 + (e_side ? 64 : -1);
-        const bool eok = lane < 24 && (unsigned)(h - 1 + e_rr) < (unsigned)H && (unsigned)ecol < (unsigned)W;
+        const bool eok = (lane < 24) & ((unsigned)(h - 1 + e_rr) < (unsigned)H) & ((unsigned)ecol < (unsigned)W);      // & : no exec-mask branch
         sv[12] = clhip_buf_load(r_x, eok ? ((n * 3 * H + h - 1) * W + (e_c * H + e_rr) * W + ecol) * 4 : CLHIP_OOB, 0);
     };
     float* hw_s = halo_s + wave * (2 * W6_HALO);

@@ -694,7 +694,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_c3_unpool_kernel(
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
             const int ih = hrow - 1 + xe_r[j], iw = w0 - 1 + xe_w[j];
-            const bool ok = xe_c[j] >= 0 && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+            const bool ok = (xe_c[j] >= 0) & ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W);      // & : no exec-mask branch
             S.xr[j] = clhip_buf_load(r_x, ok ? (((n * C + xe_c[j]) * H + ih) * W + iw) * 4 : CLHIP_OOB, 0);
         }
     };
