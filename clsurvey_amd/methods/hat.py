@@ -21,9 +21,13 @@ def _stream():
 class HatNet(nn.Module):
     """Same parameter tree as vgg_hat.Net (vgg_hat.py:14-81): convs, conv_embs, fcs, fc_embs, classifier."""
 
+    first_drop = False           # alexnet_hat.Net: relu(fc(drop(x))) instead of drop(relu(fc(x))) (vgg_hat.py:110-114)
+
     def __init__(self, rawmodel, inputsize, taskcla, uniform_init=True):
         super().__init__()
         self.taskcla = taskcla
+        self.pool_geometry = None    # (kernel, stride) of the raw model's first MaxPool2d: one pool module serves all (:41-44)
+        self.drop_p = 0.0            # p of the raw classifier's first Dropout; 0 = none (:47, :61-62)
         self.convs, self.conv_embs = nn.ModuleList(), nn.ModuleList()
         self.fcs, self.fc_embs = nn.ModuleList(), nn.ModuleList()
         self.classifier = nn.ModuleList()
@@ -35,7 +39,13 @@ class HatNet(nn.Module):
                 self.conv_embs.append(nn.Embedding(len(taskcla), mod.out_channels))
                 conv_idx += 1
             elif isinstance(mod, nn.MaxPool2d):
+                if self.pool_geometry is None:
+                    one = lambda v: v if isinstance(v, int) else v[0]
+                    self.pool_geometry = (one(mod.kernel_size), one(mod.stride))
                 self.maxpool_idxs.append(conv_idx - 1)
+        for mod in rawmodel.classifier.children():
+            if isinstance(mod, nn.Dropout) and self.drop_p == 0.0:
+                self.drop_p = float(mod.p)
         fcs = [m for m in rawmodel.classifier.children() if isinstance(m, nn.Linear)]
         for i, mod in enumerate(fcs):
             if i < len(fcs) - 1:
@@ -56,18 +66,36 @@ class HatNet(nn.Module):
     def plain_view(self):
         """features / classifier Sequentials over the SAME Conv2d / Linear modules (for NetEngine)."""
         feats = []
+        pk, ps = getattr(self, "pool_geometry", None) or (2, 2)
         for i, c in enumerate(self.convs):
             feats += [c, nn.ReLU(inplace=True)]
             if i in self.maxpool_idxs:
-                feats.append(nn.MaxPool2d(2, 2))
+                feats.append(nn.MaxPool2d(pk, ps))
         cls = []
+        drop_p = getattr(self, "drop_p", 0.0)
         for f in self.fcs:
+            if drop_p > 0 and self.first_drop:
+                cls.append(nn.Dropout(drop_p))
             cls += [f, nn.ReLU(True)]
+            if drop_p > 0 and not self.first_drop:
+                cls.append(nn.Dropout(drop_p))
         cls.append(self.classifier[0])
         view = nn.Module()
         view.features = nn.Sequential(*feats)
         view.classifier = nn.Sequential(*cls)
         return view
+
+
+class HatNetAlexnet(HatNet):
+    """alexnet_hat.Net (networks/alexnet_hat.py:4-13): the same dynamic construction over torchvision's AlexNet tree, dropout
+    IN FRONT of each gated Linear layer, no warm-up, a 6x6 feature map behind the convolutions."""
+    first_drop = True
+
+    def __init__(self, *args, **kwargs):
+        kwargs["uniform_init"] = True
+        super().__init__(*args, **kwargs)
+        self.enable_warmup = False
+        assert self.smid == 6
 
 
 class HatEngine:
@@ -93,7 +121,8 @@ class HatEngine:
     def _R(self, li):
         """inner repeat of layer li's input-channel index in its weight layout [K][C][R]."""
         if li < self.nc:
-            return 9
+            w = self.layers[li].weight
+            return int(w.shape[2] * w.shape[3])
         if li == self.nc:
             return self.net.smid * self.net.smid
         return 1
@@ -183,7 +212,8 @@ def init_masks(hat, current_task, smax):
         return out
     for i, conv in enumerate(net.convs):
         pre = mask_pre[i - 1] if i > 0 else None
-        mask_back["convs.%d.weight" % i] = bm(mask_pre[i], pre, tuple(conv.weight.shape), conv.in_channels, 9)
+        mask_back["convs.%d.weight" % i] = bm(mask_pre[i], pre, tuple(conv.weight.shape), conv.in_channels,
+                                              int(conv.weight.shape[2] * conv.weight.shape[3]))
         mask_back["convs.%d.bias" % i] = bm(mask_pre[i], None, tuple(conv.bias.shape), 1, 1)      # :275-276
     for i, fc in enumerate(net.fcs):
         pre = mask_pre[nc + i - 1] if i > 0 else mask_pre[nc - 1]

@@ -46,6 +46,8 @@ class _Pass:
 
     def run(self, t, loader, train):
         o = self.o
+        o.model.train(train)             # hat.py:201 / :257 — the plan executor reads the mode (Dropout masks) from the
+        o.hat.view.train(train)          # module tree it was built over, the HatNet's plain view
         self.stats.zero_()
         self.reg.zero_()
         seen, nb = 0, len(loader)
@@ -208,8 +210,13 @@ def main(overwrite_args, device="cuda"):
     args.task_idx = args.task_count - 1
     if args.approach != "hat":
         raise NotImplementedError("Method {} not implemented!".format(args.approach))   # pathnet: out of scope
-    if "VGG" not in args.model_name:
-        raise NotImplementedError("HAT on the HIP path covers the VGG family (vgg_hat.py), not: " + args.model_name)
+    if "VGG" in args.model_name:
+        make_net = H.HatNet                          # run.py:59-60
+    elif "alexnet" in args.model_name:
+        make_net = H.HatNetAlexnet                   # run.py:62-63
+    else:
+        raise NotImplementedError("HAT on the HIP path covers the VGG family and AlexNet (vgg_hat.py, alexnet_hat.py), not: "
+                                  + args.model_name)
 
     dsets = load_task_datasets(args.dataset_path)
     args.task_imgfolders = dsets
@@ -220,7 +227,7 @@ def main(overwrite_args, device="cuda"):
     prev = torch.load(args.prev_model_path, weights_only=False)
     if args.is_scratch_model:
         assert args.task_idx == 0
-        net = H.HatNet(prev, inputsize, taskcla).to(device)         # first task: wrap the raw VGG (run.py:84-92)
+        net = make_net(prev, inputsize, taskcla).to(device)          # first task: wrap the raw model (run.py:84-92)
     else:
         net = prev.to(device)
     trainer = HatTrainer(net, args.output, args, inputsize, joint=not args.finetune_mode, device=device)
