@@ -265,3 +265,36 @@ def test_traffic_json_names_the_kernel_bench_reports():
     assert bench.measured_traffic("conv3x3_relu_pool_fwd", "64x64@32", 200, inst) == e["hbm_bytes_per_launch"]
     assert bench.measured_traffic("conv3x3_relu_pool_fwd", "64x64@32", 200, "conv3x3_mfma_kernel<other>") is None
     assert t["conv3x3_bwd_data_unpool 64x64@32 N=200"]["instance"] == bench.conv_instance(64, 32, 32, 200, 64, 1, False, True)
+
+
+def test_hat_alexnet_net_structure():
+    """HatNetAlexnet (methods/HAT/networks/alexnet_hat.py:4-13 over vgg_hat.Net, vgg_hat.py:18-81): the parameter tree of the
+    reference's dynamic construction over torchvision's AlexNet module tree, its single shared pool geometry and Dropout, and
+    the plan view the executor is built over: Dropout IN FRONT of each gated Linear layer (first_drop), 3x3/2 pools behind
+    convolutions 0, 1 and 4, the raw convolution geometries untouched."""
+    import torch.nn as nn
+    from clsurvey_amd import models
+    from clsurvey_amd.methods import hat as HT
+    net = HT.HatNetAlexnet(models.AlexNet(num_classes=7), (3, 224, 224), [(0, 7), (1, 7)])
+    names = [n for n, _ in net.named_parameters()]
+    assert names[:4] == ["convs.0.weight", "convs.0.bias", "convs.1.weight", "convs.1.bias"]
+    assert [n for n in names if "embs" in n] == ["conv_embs.%d.weight" % i for i in range(5)] + ["fc_embs.0.weight", "fc_embs.1.weight"]
+    assert names[-2:] == ["classifier.0.weight", "classifier.0.bias"]
+    assert net.maxpool_idxs == [0, 1, 4] and net.pool_geometry == (3, 2) and net.drop_p == 0.5
+    assert net.smid == 6 and net.enable_warmup is False and net.first_drop is True
+    assert all(e.weight.shape == (2, c.out_channels) for e, c in zip(net.conv_embs, net.convs))
+    view = net.plain_view()
+    feats = list(view.features.children())
+    assert [type(m).__name__ for m in feats] == ["Conv2d", "ReLU", "MaxPool2d", "Conv2d", "ReLU", "MaxPool2d", "Conv2d", "ReLU",
+                                                  "Conv2d", "ReLU", "Conv2d", "ReLU", "MaxPool2d"]
+    assert feats[0] is net.convs[0] and feats[0].kernel_size == (11, 11) and feats[0].stride == (4, 4) and feats[3].kernel_size == (5, 5)
+    assert all(m.kernel_size == 3 and m.stride == 2 for m in feats if isinstance(m, nn.MaxPool2d))
+    cls = list(view.classifier.children())
+    assert [type(m).__name__ for m in cls] == ["Dropout", "Linear", "ReLU", "Dropout", "Linear", "ReLU", "Linear"]
+    assert cls[1] is net.fcs[0] and cls[-1] is net.classifier[0]
+    # the VGG variant keeps vgg_hat's order: Dropout (if the raw model has one) BEHIND relu(fc(x))
+    vgg = HT.HatNet(models.parse_model_name("small_VGG9_cl_128_128_DROP", (64, 64), 5), (3, 64, 64), [(0, 5)])
+    assert [type(m).__name__ for m in vgg.plain_view().classifier.children()] == ["Linear", "ReLU", "Dropout", "Linear", "ReLU", "Dropout", "Linear"]
+    plain = HT.HatNet(models.parse_model_name("small_VGG9_cl_128_128", (64, 64), 5), (3, 64, 64), [(0, 5)])
+    assert [type(m).__name__ for m in plain.plain_view().classifier.children()] == ["Linear", "ReLU", "Linear", "ReLU", "Linear"]
+    assert all(m.kernel_size == 2 for m in plain.plain_view().features.children() if isinstance(m, nn.MaxPool2d))
