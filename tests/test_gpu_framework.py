@@ -936,3 +936,40 @@ def test_teacher_forced_omega_matches_reference_g19(tmp_path, golden):
         out = fn(m.to("cuda"), task1)
         worst = _g19_compare(g, tag, out, 1e-3)
         print("G19 %s: worst Omega element %.2e of its tensor's maximum" % (tag, worst))
+
+
+def test_hat_alexnet_through_driver(tmp_path):
+    """HAT on an AlexNet-structured base model (run.py:62-63 -> networks/alexnet_hat.py; narrow so the test stays small, 6x6
+    feature map as the net asserts) on 224x224 tasks through the two-phase driver with --test: the trainer picks
+    HatNetAlexnet, trains without the warm-up phase under nn.Dropout semantics (masks while training, none in the validation
+    and test passes), and the saved wrapper reloads with its embeddings and plan."""
+    from clsurvey_amd import models
+    from clsurvey_amd.framework import driver
+    from clsurvey_amd.framework.tasks import SyntheticTaskSequence
+    from clsurvey_amd.methods import hat as HT
+    from clsurvey_amd.methods import method as M
+    root = str(tmp_path)
+    ds = SyntheticTaskSequence(os.path.join(root, "data"), task_count=2, classes_per_task=4, sizes=(96, 24, 24), hw=224,
+                               noise=0.4, name="tiny224")
+    torch.manual_seed(0)
+    m = models.AlexNet(num_classes=4, widths=(16, 24, 32, 32, 16), fc=128, feat_hw=6)
+    for mod in m.modules():
+        if isinstance(mod, (torch.nn.Linear, torch.nn.Conv2d)):
+            torch.nn.init.kaiming_normal_(mod.weight, nonlinearity="relu")
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.1
+    os.makedirs(os.path.join(root, "models"), exist_ok=True)
+    torch.save(m, os.path.join(root, "models", "alexnet_scratch.pth.tar"))
+    hat = M.parse("HAT")
+    hat.hyperparams["smax"], hat.hyperparams["c"] = 50.0, 0.75
+    out = driver.main(["alexnet_scratch", "--lr_grid", "1e-2,3e-3", "--num_epochs", "8", "--batch_size", "24", "--saving_freq", "100",
+                       "--method_name", "HAT", "--results_root", root, "--test"], method=hat, dataset=ds)
+    res = out["results"]
+    assert sorted(res) == [0, 1]
+    accs = [a for i in res for a in res[i]["seq_res"][i]]
+    assert all(0.0 <= a <= 100.0 for a in accs)
+    # (plumbing only: with seven gated layers at sigma(s e) ~ 0.5 early in every epoch this narrow net does not leave chance
+    #  level on 96 samples in 8 epochs, and diverges at HAT's default LR of 0.05; the arithmetic of the step is pinned by G21)
+    mt = torch.load(out["model_paths"][-1], weights_only=False)
+    assert isinstance(mt, HT.HatNetAlexnet) and mt.enable_warmup is False and mt.smid == 6 and abs(mt.drop_p - 0.1) < 1e-9
+    assert len(mt.conv_embs) == 5 and len(mt.fc_embs) == 2 and mt.conv_embs[0].weight.shape[0] == 2
