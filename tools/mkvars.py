@@ -1,4 +1,5 @@
-"""Build experimental variants libclhip_<name>.so: mkvars.py <source.hip> name=DEF1,DEF2=val ..."""
+"""Build experimental variants libclhip_<name>.so (selected at run time with CLHIP_LIB=<path>; tuning only):
+    PYTHONPATH=. python tools/mkvars.py <source.hip>[+<source2.hip>] name=DEF1,DEF2=val ..."""
 import sys
 from clsurvey_amd import build as b
 src = sys.argv[1]
