@@ -110,6 +110,13 @@ def conv_instance(C, H, W, N, K, mode, pool, unpool=False):
         total = ((W + 31) // 32) * ((H + 3) // 4) * kts * N
         if total > 256 and 0 < total % 256 <= 192:          # whole rounds of 128-pixel tiles + the odd images as 64-pixel tiles
             return "conv3x3_mfma_mixed_kernel<32, 4, 2, " + tail
+    if W <= 16 and big and H > 4 and vec:
+        w16 = W > 8
+        nba = 1 if w16 else 2
+        per_unit = ((W + (15 if w16 else 7)) // (16 if w16 else 8)) * ((H + 7) // 8) * kts
+        total = per_unit * ((N + nba - 1) // nba)
+        if total >= 512 and 0 < total % 256 <= 192 and N % nba == 0:
+            return ("conv3x3_mfma_mixed2_kernel<16, 8, 1, 4, 1, " if w16 else "conv3x3_mfma_mixed2_kernel<8, 8, 2, 8, 1, ") + tail
     if W > 16:
         geo = (32, 4, 1) if big else (32, 2, 1)
     elif W > 8:

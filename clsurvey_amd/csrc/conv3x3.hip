@@ -612,6 +612,27 @@ __global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_mixed_
                                                               (int)blockIdx.x - blocks_a, n_a, lds, bias_s);
 }
 
+// The same for the deeper layers: 16-wide planes (16x8 + 16x4 tiles) and 8x8 planes (two images per tile + one image per
+// tile).  base_VGG9 / wide_VGG9 at N = 200 launch 800 or 1600 of the large tiles there: 3.125 or 6.25 per CU.
+template <int TW, int THa, int NBa, int THb, int NBb, int CK, int MODE, bool VEC, bool UNPOOL = false>
+__global__ __launch_bounds__(256, CLHIP_CONV_MIN_WAVES) void conv3x3_mfma_mixed2_kernel(
+    const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
+    const float* __restrict__ mask_src, float* __restrict__ out,
+    int N, int Cin, int Cout, int H, int W, int Kw, int Cw, int relu,
+    int tiles_w, int tiles_ha, int tiles_hb, int n_a, int blocks_a, uint8_t* __restrict__ pool_idx) {
+    constexpr int FA = ConvLds<TW, THa, NBa, CK>::FLOATS, FB = ConvLds<TW, THb, NBb, CK>::FLOATS;
+    __shared__ float lds[FA > FB ? FA : FB];
+    __shared__ float bias_s[KT];
+    if ((int)blockIdx.x < blocks_a)
+        conv3x3_mfma_body<TW, THa, NBa, CK, MODE, VEC, UNPOOL>(in, wt, bias, mask_src, out, n_a, Cin, Cout, H, W, Kw, Cw, relu, tiles_w,
+                                                                tiles_ha, tiles_w * tiles_ha * ((n_a + NBa - 1) / NBa), pool_idx,
+                                                                (int)blockIdx.x, 0, lds, bias_s);
+    else
+        conv3x3_mfma_body<TW, THb, NBb, CK, MODE, VEC, UNPOOL>(in, wt, bias, mask_src, out, N, Cin, Cout, H, W, Kw, Cw, relu, tiles_w,
+                                                                tiles_hb, tiles_w * tiles_hb * ((N - n_a + NBb - 1) / NBb), pool_idx,
+                                                                (int)blockIdx.x - blocks_a, n_a, lds, bias_s);
+}
+
 template <int TW, int TH, int NB, int CK, int MODE, bool VEC, bool UNPOOL = false>
 int launch_geo(const float* in, const float* wt, const float* bias, const float* mask_src, float* out,
                int N, int Cin, int Cout, int H, int W, int Kw, int Cw, int relu, hipStream_t s, uint8_t* pool_idx) {
@@ -659,6 +680,33 @@ int launch_conv(const float* in, const float* wt, const float* bias, const float
                     hipLaunchKernelGGL((conv3x3_mfma_mixed_kernel<32, 4, 2, CK, MODE, VEC, UNPOOL>), dim3((unsigned)(blocks_a + blocks_b)),
                                        dim3(256), 0, s, in, wt, bias, mask_src, out, N, Cin, Cout, H, W, Kw, Cw, relu, tw_n, tha, thb, n_a,
                                        (int)blocks_a, pool_idx);
+                    CLHIP_LAUNCH_CHECK();
+                    return 0;
+                }
+            }
+        }
+    }
+    if constexpr (VEC) {
+        if (W <= 16 && big && H > 4 && CLHIP_MIXED_TILES) {
+            // (a launch of fewer than two full rounds gains nothing: the remainder is then most of the work)
+            const bool w16 = W > 8;
+            const int TWx = w16 ? 16 : 8, tw_n = (W + TWx - 1) / TWx, nba = w16 ? 1 : 2;
+            const int tha = w16 ? (H + 7) / 8 : (H + 7) / 8, thb = w16 ? (H + 3) / 4 : (H + 7) / 8;
+            const long long per_unit = (long long)tw_n * tha * kts;               // blocks per nba images
+            const long long units = (N + nba - 1) / nba, total = per_unit * units, rem = total % 256;
+            if (total >= 512 && rem != 0 && rem <= 192 && N % nba == 0) {
+                const long long units_b = (rem + per_unit - 1) / per_unit;
+                const int n_a = (int)((units - units_b) * nba), imgs_b = N - n_a;
+                const long long blocks_a = per_unit * (units - units_b), blocks_b = (long long)tw_n * thb * kts * imgs_b;
+                if (n_a > 0 && blocks_a + blocks_b <= 0x7fffffffLL) {
+                    if (w16)
+                        hipLaunchKernelGGL((conv3x3_mfma_mixed2_kernel<16, 8, 1, 4, 1, CK, MODE, VEC, UNPOOL>), dim3((unsigned)(blocks_a + blocks_b)),
+                                           dim3(256), 0, s, in, wt, bias, mask_src, out, N, Cin, Cout, H, W, Kw, Cw, relu, tw_n, tha, thb, n_a,
+                                           (int)blocks_a, pool_idx);
+                    else
+                        hipLaunchKernelGGL((conv3x3_mfma_mixed2_kernel<8, 8, 2, 8, 1, CK, MODE, VEC, UNPOOL>), dim3((unsigned)(blocks_a + blocks_b)),
+                                           dim3(256), 0, s, in, wt, bias, mask_src, out, N, Cin, Cout, H, W, Kw, Cw, relu, tw_n, tha, thb, n_a,
+                                           (int)blocks_a, pool_idx);
                     CLHIP_LAUNCH_CHECK();
                     return 0;
                 }

@@ -1587,3 +1587,38 @@ def test_fused_unpool_is_bitwise_maxpool_backward(N, C, K, hw):
     ws, splits = ops.conv3x3_bwd_weight_slabs(x, dy)
     dw2, db2 = ops.conv3x3_bwd_weight_reduce(ws, splits, K, C)
     assert torch.equal(dw2, dw_ref) and torch.equal(db2, db_ref)
+
+
+@pytest.mark.parametrize("N,C,K,h,hw", [(200, 128, 128, 16, 16), (200, 64, 128, 16, 16), (200, 512, 512, 8, 8), (200, 256, 512, 8, 8),
+                                         (150, 128, 128, 12, 16)])      # last: ragged height, rows 12-15 of the 8-row tiles idle
+def test_two_geometry_launch_is_bitwise_per_chunk(N, C, K, h, hw):
+    """At the base/wide_VGG9 widths and N = 200 (BASELINE configs[2], [4]) the 16x16 / 8x8 layers launch TWO tile
+    geometries in one grid (the tail of the batch in half-height / single-image tiles, so the last round fills the CUs).
+    The per-pixel arithmetic does not depend on the tile an output falls in: the whole-batch result must equal, BIT FOR
+    BIT, the same op run on 40-image chunks (few enough blocks that the one-geometry launch is taken), for forward,
+    forward + pool (values and arg-max codes), backward-data and backward-data through the fused un-pool; and the
+    forward must agree with torch's fp32 conv."""
+    from clsurvey_amd import ops
+    gen = np.random.RandomState(N + C + K + hw)
+    x = rnd(gen, N, C, h, hw).to(dev())
+    w = (rnd(gen, K, C, 3, 3) * 0.05).to(dev())
+    b = rnd(gen, K).to(dev())
+    y = ops.conv3x3_fwd(x, w, b)
+    ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)).float()
+    assert_close(y, ref, tol=1e-4)
+    if hw % 2 == 0:
+        yp, idx = ops.conv3x3_relu_pool_fwd(x, w, b)
+        dyp = rnd(gen, *yp.shape).to(dev()) * (yp > 0)
+        dxu = ops.conv3x3_bwd_data_unpool(dyp, idx, w, x)
+    dy = rnd(gen, N, K, h, hw).to(dev()) * (y > 0)
+    w2 = (rnd(gen, K, C, 3, 3) * 0.05).to(dev())       # dgrad runs with Cout' = C: its own k-tile count
+    dx = ops.conv3x3_bwd_data(dy, w2, x)
+    step = 40 if N % 40 == 0 else 30
+    for i in range(0, N, step):
+        s = slice(i, i + step)
+        assert torch.equal(y[s], ops.conv3x3_fwd(x[s].contiguous(), w, b)), i
+        assert torch.equal(dx[s], ops.conv3x3_bwd_data(dy[s].contiguous(), w2, x[s].contiguous())), i
+        if hw % 2 == 0:
+            yc, ic = ops.conv3x3_relu_pool_fwd(x[s].contiguous(), w, b)
+            assert torch.equal(yp[s], yc) and torch.equal(idx[s], ic), i
+            assert torch.equal(dxu[s], ops.conv3x3_bwd_data_unpool(dyp[s].contiguous(), ic, w, x[s].contiguous())), i
