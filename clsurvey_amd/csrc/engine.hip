@@ -358,9 +358,17 @@ int clhip_net_probe(void* handle, int layer) {
     NetPlan* p = static_cast<NetPlan*>(handle);
     if (!p || layer >= (int)p->layers.size()) return CLHIP_EINVAL;
     if (layer >= 0 && p->probe_ev.empty()) {
-        p->probe_ev.resize(2 * PROBE_RING);
-        for (hipEvent_t& e : p->probe_ev)
-            if (hipEventCreate(&e) != hipSuccess) { p->probe_ev.clear(); return CLHIP_ENOTSUP; }
+        std::vector<hipEvent_t> made;
+        made.reserve(2 * PROBE_RING);
+        for (unsigned i = 0; i < 2 * PROBE_RING; ++i) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) {
+                for (hipEvent_t m : made) (void)hipEventDestroy(m);
+                return CLHIP_ENOTSUP;
+            }
+            made.push_back(e);
+        }
+        p->probe_ev.swap(made);
     }
     p->probe_layer = layer;
     p->probe_count = 0;
