@@ -434,3 +434,72 @@ def test_g19_oracle_importance_on_the_reference_checkpoint(golden):
                 flat = flat[np.sort(np.random.RandomState(19).choice(flat.size, 8192, replace=False))]
             ref = g["%s_omega%d" % (tag, i)]
             assert float(np.abs(flat - ref).max()) <= 2e-5 * float(g["%s_stats%d" % (tag, i)][1]), (tag, i)
+
+
+def test_g20_hat_oracle_at_wide_vgg9_widths(golden):
+    """The HAT oracle at config 5's real widths (wide_VGG9_cl_512_512, 3x64x64, batch 8) against the reference's
+    unchanged vgg_hat.Net / Appr.criterion / HAT_SGD run of fixture G20: logits, loss, gates in full, gradients and
+    updated parameters at the fixture's sampled positions with their float64 checksums.  First step only (s = 3.1):
+    the second enters with parameters that already differ in the last bits (see tests/test_gpu_wide.py)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import g20_common as C
+    from oracle import hat_ref as H
+    g = golden("G20_wide_widths")
+    smax, lamb, t, lr, mom, wd = [float(v) for v in g["hat64_hyper"]]
+    t = int(t)
+    names = [str(n) for n in g["hat64_param_names"]]
+    widths = [v for v in C.WIDE if v != "M"]
+    pool_after, n_conv = set(), 0
+    for v in C.WIDE:
+        if v == "M":
+            pool_after.add(n_conv - 1)
+        else:
+            n_conv += 1
+    assert pool_after == {0, 1, 3, 5}
+    fc_in = widths[-1] * (64 // 16) ** 2
+
+    def shape(n):
+        kind, idx, leaf = n.split(".")
+        i = int(idx)
+        if kind == "convs":
+            return (widths[i], 3 if i == 0 else widths[i - 1], 3, 3) if leaf == "weight" else (widths[i],)
+        if kind == "conv_embs":
+            return (3, widths[i])
+        if kind == "fcs":
+            return (C.FC[i], fc_in if i == 0 else C.FC[i - 1]) if leaf == "weight" else (C.FC[i],)
+        if kind == "fc_embs":
+            return (3, C.FC[i])
+        return (C.NCLS, C.FC[-1]) if leaf == "weight" else (C.NCLS,)
+
+    P = {n: T(a) for n, a in zip(names, C.fill_params([(n, shape(n)) for n in names], 2001))}
+    mask_pre, mask_back = H.init_masks(P, t, smax)
+    x, y = (T(a) for a in C.batch(2100, 8, 64))
+    leaf = {n: v.clone().requires_grad_(True) for n, v in P.items()}
+    logits, mk = H.forward(leaf, pool_after, t, x, 3.1)
+    loss, reg = H.criterion(logits, y, mk, mask_pre, lamb)
+    loss.backward()
+    close(logits.detach(), g["hat64_s0_logits"], rtol=1e-4)
+    loss_ref, reg_ref = g["hat64_s0_loss"]
+    assert abs(float(loss.detach()) - loss_ref) <= 1e-5 * abs(loss_ref) and abs(float(reg.detach()) - reg_ref) <= 1e-5 * abs(reg_ref) + 1e-7
+    for i, m in enumerate(mk):
+        close(m.detach(), g["hat64_s0_mask%d" % i].reshape(-1), rtol=1e-6)
+
+    def check(tag, tensor, seed, tol):
+        d = C.digest(tensor.detach().numpy(), seed)
+        ref_v, ref_s = g[tag + "__v"], g[tag + "__s"]
+        assert d["v"].shape == ref_v.shape and d["s"][2] == ref_s[2], tag
+        assert np.abs(d["v"] - ref_v).max() <= tol * max(np.abs(ref_v).max(), 1e-30), tag
+        assert abs(d["s"][0] - ref_s[0]) <= tol * max(ref_s[1], 1e-30), tag
+
+    n_grad = 0
+    for j, n in enumerate(names):
+        if "hat64_s0_grad_%s__v" % n in g.files:
+            check("hat64_s0_grad_" + n, leaf[n].grad, 2200 + j, 2e-4)
+            n_grad += 1
+        new, _, _ = H.hat_sgd_step(n, P[n], leaf[n].grad, None, mask_back, t, 3.1, smax, lr, mom, wd, first=True)
+        if "embs" in n:
+            new = torch.clamp(new, -6, 6)
+        check("hat64_s0_theta_" + n, new, 2300 + j, 1e-5)
+    assert n_grad == len(names)
