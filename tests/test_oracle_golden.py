@@ -503,3 +503,64 @@ def test_g20_hat_oracle_at_wide_vgg9_widths(golden):
             new = torch.clamp(new, -6, 6)
         check("hat64_s0_theta_" + n, new, 2300 + j, 1e-5)
     assert n_grad == len(names)
+
+
+def test_g20_packnet_oracle_at_wide_vgg9_widths(golden):
+    """PackNet's batch step (methods/packnet/main.py:164-198: forward on the current head, backward, foreign gradients and
+    shared biases to zero, PacknetSGD with momentum, pruned weights to zero) restated with the oracle's pieces (vgg_ref +
+    packnet_ref) at wide_VGG9 widths, 3x64x64, two batches of 8, against the reference's unchanged run of fixture G20:
+    updated parameters at the sampled positions / checksums, the zero bitmap of every shared layer bit-exact."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import g20_common as C
+    from oracle import packnet_ref as PK
+    g = golden("G20_wide_widths")
+    tag, seed, hw, nb = "pack64", 3000, 64, 8
+    lr, mom, wd = [float(v) for v in g[tag + "_hyper"][:3]]
+    names = [str(n) for n in g[tag + "_param_names"]]
+    widths = [v for v in C.WIDE if v != "M"]
+    seq_idx = [0, 3, 6, 8, 11, 13, 17, 19]                 # Conv2d / Linear positions inside `shared`
+    assert [i + 1 for i in seq_idx] == g[tag + "_layout"].tolist()        # .modules() counts the Sequential itself
+
+    def shape(n):
+        kind, idx, leaf = n.split(".")
+        if kind == "classifiers":
+            return (C.NCLS, C.FC[-1]) if leaf == "weight" else (C.NCLS,)
+        j = seq_idx.index(int(idx))
+        if j < 6:
+            return (widths[j], 3 if j == 0 else widths[j - 1], 3, 3) if leaf == "weight" else (widths[j],)
+        fin = widths[-1] * (hw // 16) ** 2 if j == 6 else C.FC[0]
+        return (C.FC[j - 6], fin) if leaf == "weight" else (C.FC[j - 6],)
+
+    theta = dict(zip(names, C.fill_params([(n, shape(n)) for n in names], seed)))
+    owner = {"shared.%d.weight" % i: C.owner_mask(seed + 100 + i + 1, shape("shared.%d.weight" % i)) for i in seq_idx}
+    for n, m in owner.items():
+        theta[n] = PK.make_pruned_zero(theta[n], m)
+    frozen = {n: theta[n].copy() for n in owner}
+    order = ["shared.%d.%s" % (i, leaf) for i in seq_idx for leaf in ("weight", "bias")] + ["classifiers.1.weight", "classifiers.1.bias"]
+    bufs = {n: None for n in names}
+    for step in range(2):
+        x, y = (T(a) for a in C.batch(seed + 10 + step, nb, hw))
+        logits, _, grads, _ = vgg_ref.loss_and_grads([T(theta[n]) for n in order], C.WIDE, x, y, "ce_mean")
+        err = 100.0 * float((logits.argmax(1) != y).sum()) / nb
+        assert abs(err - float(g["%s_s%d_err" % (tag, step)][0])) <= 1e-6
+        for n, gr in zip(order, grads):
+            gr = gr.numpy()
+            if n in owner:
+                gr = PK.make_grads_zero(gr, owner[n], 2)
+            elif n.startswith("shared"):
+                gr = np.zeros_like(gr)                                  # prune.py:91-93: shared biases stay fixed
+            theta[n], bufs[n] = PK.packnet_sgd_step(theta[n], gr, bufs[n], lr, mom, wd, first=(step == 0))
+            if n in owner:
+                theta[n] = PK.make_pruned_zero(theta[n], owner[n])
+        for j, n in enumerate(names):
+            d = C.digest(theta[n], seed + 300 + j)
+            ref_v, ref_s = g["%s_s%d_theta_%s__v" % (tag, step, n)], g["%s_s%d_theta_%s__s" % (tag, step, n)]
+            assert d["v"].shape == ref_v.shape and d["s"][2] == ref_s[2], n
+            assert np.abs(d["v"] - ref_v).max() <= 2e-5 * max(np.abs(ref_v).max(), 1e-30), (step, n)
+            assert abs(d["s"][0] - ref_s[0]) <= 2e-5 * max(ref_s[1], 1e-30), (step, n)
+            if n in owner:
+                assert C.zero_pattern(theta[n]) == str(g["%s_s%d_zeros_%s" % (tag, step, n)]), n
+    for n, m in owner.items():
+        assert np.array_equal(theta[n][m == 1], frozen[n][m == 1]), n           # the earlier task's weights: bit-exact
