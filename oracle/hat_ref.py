@@ -1,6 +1,7 @@
 """Oracle: HAT forward / criterion / back-masks / HAT_SGD step (torch-CPU fp32 restatement).
 
-Restates methods/HAT/networks/vgg_hat.py:83-127 (forward, mask), :258-295 (get_view_for),
+Restates methods/HAT/networks/vgg_hat.py:83-127 (forward, mask; alexnet_hat.py:4-13 is the same net with the Dropout in
+front of each gated Linear layer), :258-295 (get_view_for),
 approaches/hat.py:58-89 (init_masks), :285-299 (criterion) and HAT_utils.py:192-250 (HAT_SGD.step).
 Parameters come as dicts keyed like the reference's named_parameters():
   convs.<i>.weight/bias, conv_embs.<i>.weight, fcs.<i>.weight/bias, fc_embs.<i>.weight,
@@ -26,18 +27,27 @@ def masks(P, t, s):
     return out
 
 
-def forward(P, pool_after, t, x, s):
-    """vgg_hat.py:83-119. pool_after: set of conv indices followed by a 2x2 max-pool."""
+def forward(P, pool_after, t, x, s, conv_geo=None, pool=(2, 2), drop=None, first_drop=False):
+    """vgg_hat.py:83-119. pool_after: set of conv indices followed by the net's max-pool.
+    conv_geo: (stride, padding) per convolution (default: the VGG 3x3 / 1 / 1); pool: (kernel, stride) of the one
+    MaxPool2d module the net shares (vgg_hat.py:41-44); drop: one keep-mask (already scaled by 1 / (1 - p)) per gated
+    Linear layer, or None in eval mode; first_drop: alexnet_hat.py:12-13 — relu(fc(drop(x))) — instead of the VGG
+    order drop(relu(fc(x))) (vgg_hat.py:110-114)."""
     nc, nf = n_layers(P)
     mk = masks(P, t, s)
     for i in range(nc):
-        x = F.relu(F.conv2d(x, P["convs.%d.weight" % i], P["convs.%d.bias" % i], padding=1))
+        stride, pad = conv_geo[i] if conv_geo is not None else (1, 1)
+        x = F.relu(F.conv2d(x, P["convs.%d.weight" % i], P["convs.%d.bias" % i], stride=stride, padding=pad))
         if i in pool_after:
-            x = F.max_pool2d(x, 2, 2)
+            x = F.max_pool2d(x, pool[0], pool[1])
         x = x * mk[i].view(1, -1, 1, 1)
     x = x.reshape(x.shape[0], -1)
     for i in range(nf):
+        if drop is not None and first_drop:
+            x = x * drop[i]
         x = F.relu(F.linear(x, P["fcs.%d.weight" % i], P["fcs.%d.bias" % i]))
+        if drop is not None and not first_drop:
+            x = x * drop[i]
         x = x * mk[nc + i]
     return F.linear(x, P["classifier.0.weight"], P["classifier.0.bias"]), mk
 

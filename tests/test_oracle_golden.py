@@ -564,3 +564,71 @@ def test_g20_packnet_oracle_at_wide_vgg9_widths(golden):
                 assert C.zero_pattern(theta[n]) == str(g["%s_s%d_zeros_%s" % (tag, step, n)]), n
     for n, m in owner.items():
         assert np.array_equal(theta[n][m == 1], frozen[n][m == 1]), n           # the earlier task's weights: bit-exact
+
+
+def test_g21_hat_alexnet_oracle(golden):
+    """The HAT oracle on AlexNet (alexnet_hat.Net: 11x11/4, 5x5, 3x3 convolutions, 3x3/2 max-pools, Dropout in FRONT of
+    each gated Linear layer) at 3x224x224 against the reference's unchanged code (fixture G21): eval-mode logits and gates
+    at s = smax; one training step under the fixture's Dropout masks — logits, loss, sampled gradients and updated
+    parameters.  Same ATen kernels on both sides: 1e-5, no decision flips."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import g20_common as C
+    from oracle import hat_ref as H
+    g = golden("G21_hat_alexnet")
+    smax, lamb, t, lr, mom, wd = [float(v) for v in g["hyper"]]
+    t, nb = int(t), 4
+    names = [str(n) for n in g["param_names"]]
+    convs = [(64, 3, 11), (192, 64, 5), (384, 192, 3), (256, 384, 3), (256, 256, 3)]       # models/net.py:96-125 (torchvision AlexNet)
+    geo = [(4, 2), (1, 2), (1, 1), (1, 1), (1, 1)]
+    fcs = [(4096, 256 * 6 * 6), (4096, 4096)]
+
+    def shape(n):
+        kind, idx, leaf = n.split(".")
+        i = int(idx)
+        if kind == "convs":
+            return (convs[i][0], convs[i][1], convs[i][2], convs[i][2]) if leaf == "weight" else (convs[i][0],)
+        if kind == "conv_embs":
+            return (3, convs[i][0])
+        if kind == "fcs":
+            return fcs[i] if leaf == "weight" else (fcs[i][0],)
+        if kind == "fc_embs":
+            return (3, fcs[i][0])
+        return (C.NCLS, 4096) if leaf == "weight" else (C.NCLS,)
+
+    P = {n: T(a) for n, a in zip(names, C.fill_params([(n, shape(n)) for n in names], 5001))}
+    kw = dict(conv_geo=geo, pool=(3, 2), first_drop=True)
+    x, y = (T(a) for a in C.batch(5100, nb, 224))
+    with torch.no_grad():
+        logits, mk = H.forward(P, {0, 1, 4}, t, x, smax, **kw)
+    close(logits, g["eval_logits"], rtol=1e-5)
+    for i, m in enumerate(mk):
+        close(m, g["eval_mask%d" % i].reshape(-1), rtol=1e-6)
+    # one training step under the reference's Dropout masks
+    mask_pre, mask_back = H.init_masks(P, t, smax)
+    gen = np.random.RandomState(5200)
+    drop = [T((gen.rand(nb, d) < 0.5).astype(np.float32) * 2.0) for d in (256 * 6 * 6, 4096)]
+    loss_ref, reg_ref, s = [float(v) for v in g["train_loss"]]
+    x, y = (T(a) for a in C.batch(5101, nb, 224))
+    leaf = {n: v.clone().requires_grad_(True) for n, v in P.items()}
+    logits, mk = H.forward(leaf, {0, 1, 4}, t, x, s, drop=drop, **kw)
+    loss, reg = H.criterion(logits, y, mk, mask_pre, lamb)
+    loss.backward()
+    close(logits.detach(), g["train_logits"], rtol=1e-5)
+    assert abs(float(loss.detach()) - loss_ref) <= 1e-5 * abs(loss_ref) and abs(float(reg.detach()) - reg_ref) <= 1e-5 * abs(reg_ref) + 1e-7
+
+    def check(tag, tensor, seed, tol):
+        d = C.digest(tensor.detach().numpy(), seed)
+        ref_v, ref_s = g[tag + "__v"], g[tag + "__s"]
+        assert d["v"].shape == ref_v.shape and d["s"][2] == ref_s[2], tag
+        assert np.abs(d["v"] - ref_v).max() <= tol * max(np.abs(ref_v).max(), 1e-30), tag
+        assert abs(d["s"][0] - ref_s[0]) <= tol * max(ref_s[1], 1e-30), tag
+
+    for j, n in enumerate(names):
+        if "train_grad_%s__v" % n in g.files:
+            check("train_grad_" + n, leaf[n].grad, 5300 + j, 1e-4)
+        new, _, _ = H.hat_sgd_step(n, P[n], leaf[n].grad, None, mask_back, t, s, smax, lr, mom, wd, first=True)
+        if "embs" in n:
+            new = torch.clamp(new, -6, 6)
+        check("train_theta_" + n, new, 5400 + j, 1e-5)
