@@ -32,7 +32,6 @@ import numpy as np
 import torch
 
 from ..methods import method as methods
-from ..methods import train_common as tc
 
 RUNMODES = ["first_task_basemodel_dump", "timing_mode", "debug"]
 

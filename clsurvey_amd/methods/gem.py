@@ -10,7 +10,6 @@ host in float64 (clsurvey_amd.methods.qp, restating quadprog's Goldfarb-Idnani).
 import copy
 import ctypes as C
 
-import numpy as np
 import torch
 import torch.nn as nn
 

@@ -3,12 +3,9 @@ configuration norm='L2', b1=False: methods/method.py:748)."""
 import os
 import time
 
-import torch
-from ..data import load_task_datasets
 import torch.nn as nn
 
-from .. import ops
-from ..data import DeviceLoader
+from ..data import DeviceLoader, load_task_datasets
 from ..net import NetEngine
 from ..optim import Objective_After_SGD, Weight_Regularized_SGD, arena_reg_params
 from . import train_common as tc

@@ -7,8 +7,6 @@ Parameters come as dicts keyed like the reference's named_parameters():
   convs.<i>.weight/bias, conv_embs.<i>.weight, fcs.<i>.weight/bias, fc_embs.<i>.weight,
   classifier.0.weight/bias
 """
-import math
-
 import torch
 import torch.nn.functional as F
 

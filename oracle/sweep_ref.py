@@ -9,7 +9,6 @@ best-validation model saved, and the final top-1 evaluation of every model on ev
 The pickled artefacts are plain nn.Modules of standard torch layers (the wire format between the framework's layers), so
 the first-task model written by the GPU run is a valid starting point here.
 """
-import copy
 import os
 from collections import OrderedDict
 
