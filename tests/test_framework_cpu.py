@@ -298,3 +298,66 @@ def test_hat_alexnet_net_structure():
     plain = HT.HatNet(models.parse_model_name("small_VGG9_cl_128_128", (64, 64), 5), (3, 64, 64), [(0, 5)])
     assert [type(m).__name__ for m in plain.plain_view().classifier.children()] == ["Linear", "ReLU", "Linear", "ReLU", "Linear"]
     assert all(m.kernel_size == 2 for m in plain.plain_view().features.children() if isinstance(m, nn.MaxPool2d))
+
+
+def test_plugin_surface_matches_reference_g22():
+    """The method objects the framework driver works with, against the reference's methods/method.py taken as DATA
+    (fixture G22, tests/golden/make_g22.py): for every --method_name on this path the class, name / eval_name / category /
+    extra_hyperparams_count, the hyper-parameter dict(s) in order with their defaults, the plain instance attributes and
+    every hook the reference object offers; and set_hyperparams() on the override strings the reference accepts.
+    Where the reference stops with a TypeError (a single bare value, or a 'def' placeholder: its parser drops the
+    placeholder before it counts positions) the build applies the meaning the reference's docstring states; where the
+    reference stores an empty list for 'def' inside a ';' list the build keeps the default — both deliberate, both asserted."""
+    import json
+    import pytest
+    from clsurvey_amd.methods import method as M
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "G22_method_table.json")) as f:
+        table = json.load(f)
+    pairs = lambda d: [[str(k), _plain(v)] for k, v in d.items()] if d is not None else None      # noqa: E731
+
+    def _plain(v):
+        if isinstance(v, dict):
+            return pairs(v)
+        if isinstance(v, (list, tuple)):
+            return [_plain(x) for x in v]
+        return v
+
+    for name, ref in table["methods"].items():
+        m = M.parse(name)
+        assert type(m).__name__ == ref["class"], name
+        assert (m.name, m.eval_name, m.extra_hyperparams_count) == (ref["name"], ref["eval_name"], ref["extra_hyperparams_count"]), name
+        assert getattr(m.category, "name", str(m.category)) == ref["category"], name
+        assert pairs(m.hyperparams) == ref["hyperparams"], name
+        assert pairs(getattr(m, "static_hyperparams", None)) == ref["static_hyperparams"], name
+        for k, v in ref["instance_attrs"].items():
+            assert _plain(getattr(m, k)) == v, (name, k)
+        for hook in ref["hooks"]:
+            assert callable(getattr(m, hook, None)), (name, hook)
+        for case in ref["overrides"]:
+            mm = M.parse(name)
+            M.set_hyperparams(mm, case["text"], static_params=case["static"])
+            got = pairs(mm.static_hyperparams if case["static"] else mm.hyperparams)
+            default = ref["static_hyperparams"] if case["static"] else ref["hyperparams"]
+            if "result" in case and "def" not in case["text"]:
+                assert got == case["result"], (name, case)
+                assert pairs(mm.init_hyperparams) == case["init_hyperparams"], (name, case)
+                continue
+            # the repaired cases: positional meaning, 'def' / empty slots keep the default
+            want = [list(kv) for kv in default]
+            fields = [f for f in case["text"].split(";") if f.strip()]
+            if len(fields) == 1:
+                slots = [t.strip() for t in fields[0].split(",")]
+                vals = [None if t in ("def", "") else float(t) for t in slots]
+            else:
+                vals = []
+                for fld in fields:
+                    nums = [float(t) for t in fld.split(",") if t.strip() not in ("def", "")]
+                    vals.append(None if not nums else nums[0] if len(nums) == 1 else nums)
+            for i, v in enumerate(vals[:len(want)]):
+                if v is not None:
+                    want[i][1] = v
+            assert got == want, (name, case, got, want)
+    for name, exc in table["unparseable"]:
+        with pytest.raises(NotImplementedError):
+            M.parse(name)
+        assert exc == "NotImplementedError"
