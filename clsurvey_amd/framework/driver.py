@@ -88,7 +88,8 @@ def set_random(seed=7):
 
 
 def float_to_scientific_str(v):
-    return "{:.1e}".format(v)
+    """utilities/utils.py: one decimal, capital E — 'lr=1.0E-02' is the node directory a reference tree holds (fixture G23)."""
+    return "{:.1E}".format(v)
 
 
 class StoragePolicy(object):

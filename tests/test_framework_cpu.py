@@ -361,3 +361,26 @@ def test_plugin_surface_matches_reference_g22():
         with pytest.raises(NotImplementedError):
             M.parse(name)
         assert exc == "NotImplementedError"
+
+
+def test_lr_grid_decisions_match_reference_g23():
+    """Phase 1 of the framework (framework/lr_grid_train.py:9-160) on 36 seeded accuracy tables (1-3 iterations per LR,
+    ties, all-zero tables), three storage policies each, plus an interrupted run resumed from grid_checkpoint.pth: the
+    build's lr_grid_single_task must take the reference's decisions — best LR, best (iteration-averaged) accuracy, the
+    winning node directory, the directories left on disk, the checkpointed accuracy lists, the nodes trained again after
+    the interruption (fixture G23: the reference's unchanged function over the same stand-in method)."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import g23_common as G
+    from clsurvey_amd.framework import driver
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "G23_lr_grid_decisions.json")) as f:
+        ref = json.load(f)
+    assert ref["lrs"] == G.LRS and ref["modes"] == G.MODES
+    mine = json.loads(json.dumps(G.generate(driver.lr_grid_single_task)))          # tuples -> lists, as stored
+    assert len(mine) == len(ref["tables"]) == 36
+    for i, (a, b) in enumerate(zip(mine, ref["tables"])):
+        assert a["acc"] == b["acc"] and a["iterations"] == b["iterations"]
+        for mode in G.MODES:
+            assert a["modes"][mode] == b["modes"][mode], (i, mode, a["modes"][mode], b["modes"][mode])
+        assert a["resumed"] == b["resumed"], (i, a["resumed"], b["resumed"])
