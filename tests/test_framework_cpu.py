@@ -384,3 +384,27 @@ def test_lr_grid_decisions_match_reference_g23():
         for mode in G.MODES:
             assert a["modes"][mode] == b["modes"][mode], (i, mode, a["modes"][mode], b["modes"][mode])
         assert a["resumed"] == b["resumed"], (i, a["resumed"], b["resumed"])
+
+
+def test_stability_decay_matches_reference_g24():
+    """Phase 2 of the framework (framework_train.py:76-166) through 24 scenarios — 1 / 2 / 3 hyper-parameters, a method with
+    its own decay operator, thresholds met at once / after some decays / never — against the reference's unchanged
+    HyperparameterFramework + Manager over the same stand-in method (fixture G24): the hyper-parameters of every training
+    call, the framework state, hyperparams.pth.tar, SUCCESS.FLAG, the files left in TASK_TRAINING and the surviving model;
+    a second run on the finished tree (skipped); a run that dies after k attempts (exit code 1, as the reference) and its
+    continuation by fresh objects from the checkpoint."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import g24_common as G
+    from clsurvey_amd.framework import driver
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "G24_stability_decay.json")) as f:
+        ref = json.load(f)["tables"]
+    mine = json.loads(json.dumps(G.generate(driver.HyperparameterFramework, driver.Manager)))
+    assert len(mine) == len(ref) == 24
+    for i, (a, b) in enumerate(zip(mine, ref)):
+        assert a["scenario"] == b["scenario"]
+        for key in ("fresh", "again", "interrupted", "resumed"):
+            assert (key in a) == (key in b), (i, key)
+            if key in a:
+                assert a[key] == b[key], (i, key, a[key], b[key])
