@@ -438,12 +438,50 @@ def eval_all_models_all_tasks(args, manager, ds_paths, model_paths):
         args.eval_model_path = model_paths[trained_model_idx]
         return manager.method.inference_eval(args, manager)
 
-    table = {n: evaluate(*pq) for n, pq in enumerate(pairs) if n % world == rank}
-    if world > 1:
-        table = shard.gather_scalars(table)
-    acc_of = {pq: table[n] for n, pq in enumerate(pairs)}
+    debug = bool(getattr(args, "debug", False))
+    overwrite = bool(getattr(args, "test_overwrite_mode", False))
+
+    def out_file(dataset_index):
+        return os.path.join(args.out_path, get_perf_output_filename(manager.method.eval_name, dataset_index))
+
+    def save(dataset_index, seq_acc, seq_forgetting):
+        perf = {manager.method.eval_name: {"seq_res": seq_acc, "seq_forgetting": seq_forgetting, "seq_head_acc": []}}
+        if not debug:
+            os.makedirs(args.out_path, exist_ok=True)
+            torch.save(perf, out_file(dataset_index))
+        return perf[manager.method.eval_name]
+
     out = {}
-    os.makedirs(args.out_path, exist_ok=True)
+    if world == 1:
+        # eval.py:146-247 as it runs: a finished task is never re-evaluated outside overwrite mode (and ends the run), a
+        # model whose evaluation fails ends its task's sequence (what was measured is kept), a task with no result at all
+        # ends the run; debug mode writes nothing
+        for dataset_index in tasks:
+            args.eval_dset_idx = dataset_index
+            if not overwrite and not debug and os.path.exists(out_file(dataset_index)):
+                print("EVAL already done, can only rerun in overwrite mode")
+                break
+            seq_acc, seq_forgetting = {dataset_index: []}, {dataset_index: []}
+            for trained_model_idx in range(dataset_index, len(ds_paths)):
+                try:
+                    accuracy = evaluate(dataset_index, trained_model_idx)
+                except Exception:
+                    print("ERROR in Testing model, trained until TASK ", str(trained_model_idx + 1))
+                    print("Aborting testing on further models")
+                    traceback.print_exc(5)
+                    break
+                seq_acc[dataset_index].append(accuracy)
+                if trained_model_idx > dataset_index:
+                    seq_forgetting[dataset_index].append(seq_acc[dataset_index][0] - accuracy)
+            if not seq_acc[dataset_index]:
+                print("TESTING ERROR: no accuracy for task", dataset_index + 1, "- no results saved")
+                break
+            out[dataset_index] = save(dataset_index, seq_acc, seq_forgetting)
+        return out
+    # sharded: every (task, model) pair is independent work; a failing evaluation stops the run on its rank
+    table = {n: evaluate(*pq) for n, pq in enumerate(pairs) if n % world == rank}
+    table = shard.gather_scalars(table)
+    acc_of = {pq: table[n] for n, pq in enumerate(pairs)}
     for dataset_index in tasks:
         seq_acc, seq_forgetting = {dataset_index: []}, {dataset_index: []}
         for trained_model_idx in range(dataset_index, len(ds_paths)):
@@ -451,9 +489,7 @@ def eval_all_models_all_tasks(args, manager, ds_paths, model_paths):
             seq_acc[dataset_index].append(accuracy)
             if trained_model_idx > dataset_index:
                 seq_forgetting[dataset_index].append(seq_acc[dataset_index][0] - accuracy)
-        perf = {manager.method.eval_name: {"seq_res": seq_acc, "seq_forgetting": seq_forgetting, "seq_head_acc": []}}
-        torch.save(perf, os.path.join(args.out_path, get_perf_output_filename(manager.method.eval_name, dataset_index)))
-        out[dataset_index] = perf[manager.method.eval_name]
+        out[dataset_index] = save(dataset_index, seq_acc, seq_forgetting)
     return out
 
 
@@ -476,6 +512,9 @@ def first_task_modelname(args):
     name = ["e={}".format(args.num_epochs), "bs={}".format(args.batch_size), "lr={}".format(sorted(args.lr_grid))]
     if args.weight_decay != 0:
         name.append("L2={}".format(args.weight_decay))
+    for tag in ("BN", "DROP"):          # a regularised architecture gets its own first-task model (net.py:47-51, this order)
+        if tag in args.model_name:
+            name.append(tag)
     return "_".join(name)
 
 

@@ -408,3 +408,25 @@ def test_stability_decay_matches_reference_g24():
             assert (key in a) == (key in b), (i, key)
             if key in a:
                 assert a[key] == b[key], (i, key, a[key], b[key])
+
+
+def test_eval_driver_and_names_match_reference_g25():
+    """The evaluation driver (framework/eval.py:146-247) and the experiment / first-task-model names (utilities/utils.py
+    get_exp_name, models/net.py get_init_modelname) against the reference's unchanged functions taken as data (fixture G25):
+    which (task, model) pairs are evaluated with which paths and what the result files hold — whole sequence, task window,
+    an evaluation failing on a later / the first model of a task, an existing result file with and without overwrite mode,
+    debug mode — and the two name strings for six argument sets (weight decay, DROP / BN architectures, list-valued
+    static hyper-parameters, a method without hyper-parameters)."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import g25_common as G
+    from clsurvey_amd.framework import driver
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "G25_eval_and_names.json")) as f:
+        ref = json.load(f)
+    assert G.names(driver.get_exp_name, driver.first_task_modelname) == ref["names"]
+    mine = json.loads(json.dumps(G.evals(driver.eval_all_models_all_tasks, driver.get_perf_output_filename)))
+    for a, b in zip(mine, ref["evals"]):
+        assert a["tag"] == b["tag"]
+        assert a["calls"] == b["calls"], (a["tag"], a["calls"], b["calls"])
+        assert a["files"] == b["files"], (a["tag"], a["files"], b["files"])
