@@ -115,7 +115,7 @@ class Manager(object):
         self.current_task_dataset_path = None
         self.best_finetuned_model_path = None
         self.autoencoder_model_path = None
-        self.reg_sets = []
+        # (reg_sets appears with the second task, framework_train.py:253, as in the reference)
 
     def set_dataset(self, args, rnd_transform=False):
         if hasattr(self.method, "grid_datafetch"):
