@@ -466,3 +466,52 @@ def test_single_task_orchestration_matches_reference_g26():
                     r.pop("best_model_path"), r.pop("heuristic_exp_dir")
         assert a == b, (i, a, b)
     assert repaired == 3
+
+
+def test_epoch_loops_match_reference_g27():
+    """The shared epoch loop (methods/train_common.train_model) in the four configurations the methods use it in, against
+    the reference's four train_model variants run on a scripted network (fixture G27): best accuracy returned, epochs run,
+    learning rate per epoch (x0.1 after five epochs without a new best, stop after more than ten — ten for SI, which also
+    runs one epoch more), NaN-loss abort (not in plain SGD), checkpoint every saving_freq epochs and what it holds, the
+    best model's epoch, resume from epoch.pth.tar with fresh objects, save_models_mode off.  The engine is a stand-in that
+    does what NetEngine.loss_step does to the loop: forward, batch-mean loss and hit count into the stats buffer."""
+    import json
+    import sys
+    import torch.nn.functional as F
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import g27_common as G
+    from clsurvey_amd.methods import train_common as tc
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "G27_epoch_loops.json")) as f:
+        ref = json.load(f)["runs"]
+
+    class Engine:
+        device = torch.device("cpu")
+
+        def __init__(self, model):
+            self.model = model
+
+        def loss_step(self, x, y, kind, backward=True, stats=None):
+            assert kind == "ce_mean"
+            out = self.model(x)
+            loss = F.cross_entropy(out, y)
+            if backward:
+                self.model.zero_grad()
+                loss.backward()
+            stats[0] += float(loss.detach())
+            stats[1] += int((out.argmax(1) == y).sum())
+
+    def train(variant, model, opt, lr, loaders, sizes, num_epochs, exp_dir, resume, saving_freq, save_models_mode):
+        eng = Engine(model)
+        if variant == "sgd":          # methods/finetune.py:59-61
+            return tc.train_model(model, eng, opt, lr, loaders, sizes, num_epochs, exp_dir, resume, saving_freq=saving_freq,
+                                  step_fn=opt.step, save_models_mode=save_models_mode, abort_on_bad_loss=False)
+        if variant == "si":           # methods/si.py:79-80
+            return tc.train_model(model, eng, opt, lr, loaders, sizes, num_epochs, exp_dir, resume, saving_freq=saving_freq,
+                                  early_stop="ge", extra_epoch=True)
+        return tc.train_model(model, eng, opt, lr, loaders, sizes, num_epochs, exp_dir, resume, saving_freq=saving_freq)   # ewc.py:121, mas.py:96
+
+    mine = json.loads(json.dumps(G.generate(train)))
+    assert len(mine) == len(ref) == 21
+    for a, b in zip(mine, ref):
+        assert (a["tag"], a["variant"]) == (b["tag"], b["variant"])
+        assert a == b, (a["tag"], a["variant"], a, b)
