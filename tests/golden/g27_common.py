@@ -12,7 +12,7 @@ import torch.nn.functional as F
 
 C, B, NT, NV = 4, 4, 2, 2                      # classes, batch size, train / val batches per epoch
 SIZES = {"train": B * NT, "val": B * NV}
-VARIANTS = ["sgd", "ewc", "mas", "si"]         # Finetune/train_SGD.py, EWC/train_EWC.py, MAS/train_MAS.py, SI/train_SI.py
+VARIANTS = ["sgd", "ewc", "mas", "si", "lwf"]  # Finetune/train_SGD.py, EWC/train_EWC.py, MAS/train_MAS.py, SI/train_SI.py, LwF/main_LWF.py
 
 _plateau = [0.25, 0.5] + [0.5] * 40
 _rising = [min(1.0, 0.125 * (i + 1)) for i in range(8)] + [1.0] * 40
@@ -51,6 +51,21 @@ class ScriptedNet(nn.Module):
         return logits
 
 
+class ScriptedLwf(ScriptedNet):
+    """the same network behind LwF's interface: a list of logits per head, the new task's head last (main_LWF.py:176-178)"""
+
+    def forward(self, x):
+        new = super().forward(x)
+        return [0.0 * new.detach() + 0.0 * self.w, new]
+
+
+class ScriptedTeacher(nn.Module):
+    """the frozen previous model: one old head, constant logits"""
+
+    def forward(self, x):
+        return [torch.zeros(x.shape[0], C)]
+
+
 class LogSGD(torch.optim.SGD):
     """SGD that accepts the reg_params argument of the penalised optimizers and logs the LR of every step."""
 
@@ -85,11 +100,13 @@ def _files(exp_dir):
             out[f]["model_calls"] = int(c["state_dict"]["calls"])
         elif f == "best_model.pth.tar":
             out[f] = {"model_calls": int(torch.load(os.path.join(exp_dir, f), weights_only=False).calls)}
+        elif f == "preprocess_time.pth.tar":
+            out[f] = {}                                    # (a wall-clock value: presence only)
     return out
 
 
 def run_once(train, variant, sc, exp_dir, num_epochs, resume):
-    model = ScriptedNet(sc["val"], sc["nan_at"])
+    model = (ScriptedLwf if variant == "lwf" else ScriptedNet)(sc["val"], sc["nan_at"])
     opt = LogSGD(model.parameters(), lr=0.01)
     _, best = train(variant, model, opt, 0.01, loaders(), dict(SIZES), num_epochs, exp_dir, resume, sc["saving_freq"],
                     sc["save_models_mode"])

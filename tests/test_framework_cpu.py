@@ -470,7 +470,7 @@ def test_single_task_orchestration_matches_reference_g26():
 
 def test_epoch_loops_match_reference_g27():
     """The shared epoch loop (methods/train_common.train_model) in the four configurations the methods use it in, against
-    the reference's four train_model variants run on a scripted network (fixture G27): best accuracy returned, epochs run,
+    the reference's four train_model variants and LwF's train_model_lwf run on a scripted network (fixture G27): best accuracy returned, epochs run,
     learning rate per epoch (x0.1 after five epochs without a new best, stop after more than ten — ten for SI, which also
     runs one epoch more), NaN-loss abort (not in plain SGD), checkpoint every saving_freq epochs and what it holds, the
     best model's epoch, resume from epoch.pth.tar with fresh objects, save_models_mode off.  The engine is a stand-in that
@@ -500,7 +500,27 @@ def test_epoch_loops_match_reference_g27():
             stats[0] += float(loss.detach())
             stats[1] += int((out.argmax(1) == y).sum())
 
+    class LwfEngine(Engine):          # LwfEngine.step: task CE + hits into stats, backward of the whole objective
+        def step(self, x, y, teacher_logits, T, reg_lambda, backward=True, stats=None):
+            out = self.model(x)[-1]
+            loss = F.cross_entropy(out, y)
+            if backward:
+                assert teacher_logits is not None and teacher_logits.shape == (x.shape[0], G.C)
+                self.model.zero_grad()
+                loss.backward()
+            stats[0] += float(loss.detach())
+            stats[1] += int((out.argmax(1) == y).sum())
+
+    class Teacher:
+        @staticmethod
+        def logits(x):
+            return torch.zeros(x.shape[0], G.C)
+
     def train(variant, model, opt, lr, loaders, sizes, num_epochs, exp_dir, resume, saving_freq, save_models_mode):
+        if variant == "lwf":          # methods/lwf.py: fine_tune_SGD_LwF -> train_model_lwf
+            from clsurvey_amd.methods import lwf
+            return lwf.train_model_lwf(model, G.ScriptedTeacher(), opt, lr, loaders, sizes, num_epochs, exp_dir, resume,
+                                       temperature=2, saving_freq=saving_freq, reg_lambda=1, engine=LwfEngine(model), teacher=Teacher)
         eng = Engine(model)
         if variant == "sgd":          # methods/finetune.py:59-61
             return tc.train_model(model, eng, opt, lr, loaders, sizes, num_epochs, exp_dir, resume, saving_freq=saving_freq,
@@ -511,7 +531,7 @@ def test_epoch_loops_match_reference_g27():
         return tc.train_model(model, eng, opt, lr, loaders, sizes, num_epochs, exp_dir, resume, saving_freq=saving_freq)   # ewc.py:121, mas.py:96
 
     mine = json.loads(json.dumps(G.generate(train)))
-    assert len(mine) == len(ref) == 21
+    assert len(mine) == len(ref) == 26
     for a, b in zip(mine, ref):
         assert (a["tag"], a["variant"]) == (b["tag"], b["variant"])
         assert a == b, (a["tag"], a["variant"], a, b)
