@@ -85,6 +85,7 @@ def set_random(seed=7):
         torch.cuda.manual_seed_all(seed)
     random.seed(seed)
     np.random.seed(seed)
+    os.environ["PYTHONHASHSEED"] = str(seed)
 
 
 def float_to_scientific_str(v):
