@@ -40,6 +40,12 @@ def describe(m):
             "hyperparams": plain(m.hyperparams),
             "static_hyperparams": plain(getattr(m, "static_hyperparams", None)),
             "instance_attrs": {k: plain(v) for k, v in sorted(vars(m).items())},
+            # class-level switches the drivers read with hasattr / getattr (start_scratch, wrap_first_task_model, no_framework,
+            # grid_chkpt, ...): every public attribute of a plain type that is not one of the fields above
+            "flags": {k: getattr(m, k) for k in sorted(dir(m))
+                      if not k.startswith("_") and k not in ("name", "eval_name", "category", "extra_hyperparams_count", "hyperparams",
+                                                             "static_hyperparams") and k not in vars(m)
+                      and isinstance(getattr(m, k), (bool, int, float, str))},
             "hooks": [h for h in HOOKS if callable(getattr(m, h, None))]}
 
 
