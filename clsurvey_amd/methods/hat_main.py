@@ -140,7 +140,8 @@ class HatTrainer:
         min_epochs = int(self.nepochs / 2)                                   # first task only (hat.py:163-165)
 
         for e in range(first_epoch, self.nepochs):
-            self.lamb = WARMUP_LAMB if warmup else self.post_lamb
+            if self.joint:                                                   # (the phase-1 search has no regulariser: hat_finetune.py:68-71)
+                self.lamb = WARMUP_LAMB if warmup else self.post_lamb
             t0 = time.time()
             tr_loss, tr_acc = self.train_epoch(t, loaders["train"])
             ms = 1000 * self.sbatch * (time.time() - t0) / len(loaders["train"])

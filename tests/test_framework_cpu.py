@@ -616,3 +616,54 @@ def test_trainer_calls_match_reference_g28():
                 assert xa[k] == xb[k], (key, ca["callee"], k, xa[k], xb[k])
         assert a["args"] == b["args"], (key, a["args"], b["args"])
         assert a["manager"] == b["manager"], (key, a["manager"], b["manager"])
+
+
+def test_hat_trainer_loops_match_reference_g29():
+    """HatTrainer.train (methods/hat_main.py) against the epoch loops of the reference's two HAT trainers (approaches/hat.py
+    joint training, hat_finetune.py phase-1 search) with train_epoch / eval replaced by table look-ups on both sides
+    (fixture G29, 24 scenarios: first / later task, warm-up on / off, plateau / mixed / rising accuracies, resume): learning
+    rate and lambda of every epoch (warm-up LR and lambda 0 for the first 11 epochs of a first task, the decay that follows
+    a warm-up starting from the warm-up LR — the reference's arithmetic, kept), epochs run (patience 30, LR / 2 at 15 left,
+    suspended below nepochs / 2 on the first task), best accuracy, checkpoint contents, the model kept.
+    One asserted difference: the reference's phase-1 trainer cannot resume — it formats chkpt['warmup'], a key its own
+    checkpoint does not have (hat_finetune.py:54) — the build's continues from the checkpoint."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import g29_common as G
+    from clsurvey_amd.methods import hat_main as HM
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "G29_hat_trainer_loops.json")) as f:
+        ref = json.load(f)["runs"]
+
+    class Scripted(HM.HatTrainer):
+        def __init__(self, model, exp_dir, args, joint):          # HatTrainer.__init__ minus the HatEngine (no device here)
+            self.model, self.exp_dir, self.joint = model, exp_dir, joint
+            self.sbatch, self.base_lr = args.batch_size, args.lr
+            self.save_freq, self.weight_decay = args.save_freq, args.weight_decay
+            self.smax, self.post_lamb = args.parameter
+            self.lamb = None
+            self.nepochs = args.nepochs + (0 if joint else HM.WARMUP_EPOCHS)
+            self.optimizer = None
+            self.mask_pre, self.mask_back = None, {}
+
+        def init_masks(self, current_task, smax):
+            return None, {}
+
+    def make_trainer(joint, model, exp_dir, nepochs, args):
+        args.nepochs = nepochs
+        return Scripted(model, exp_dir, args, joint)
+
+    mine = json.loads(json.dumps(G.generate(make_trainer)))
+    assert len(mine) == len(ref) == 24
+    unresumable = 0
+    for a, b in zip(mine, ref):
+        assert a["scenario"] == b["scenario"]
+        if "raises" in b["run"]:
+            unresumable += 1
+            assert not b["scenario"]["joint"] and b["scenario"]["resume_after"] and b["run"]["raises"] == "KeyError"
+            assert a["first"] == b["first"]
+            r = a["run"]                                           # continues: first logged epoch follows the checkpoint's
+            assert r["epochs"][0]["epoch"] == a["first"]["files"]["epoch.pth.tar"]["e"] + 1 and r["best_acc"] >= a["first"]["best_acc"]
+            continue
+        assert a == b, (a["scenario"], a, b)
+    assert unresumable == 2
