@@ -667,3 +667,29 @@ def test_hat_trainer_loops_match_reference_g29():
             continue
         assert a == b, (a["scenario"], a, b)
     assert unresumable == 2
+
+
+def test_packnet_session_loops_match_reference_g30():
+    """packnet_main.Manager.train / prune against the reference's Manager (methods/packnet/main.py:234-339) with do_epoch /
+    eval as table look-ups and the pruner a logger on both sides (fixture G30): learning rate per epoch (x0.1 in the epoch
+    that follows five strictly worse validations — every epoch restarts from args.lr —, stop after more than ten), epoch
+    numbering of a resumed session, what train() returns, the order pre-prune eval -> prune -> check -> post-prune eval ->
+    retraining -> check, and every file with its fields (best / epoch checkpoints carry the counters the session STARTED
+    with, as the reference's do; the .json error history)."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import g30_common as G
+    from types import SimpleNamespace
+    from clsurvey_amd.methods import packnet_main as PM
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "G30_packnet_loops.json")) as f:
+        ref = json.load(f)["runs"]
+
+    def extra(m):        # what the build's Manager has besides the common fields: the plan executor (its arena feeds prune()'s optimizer)
+        return {"_mode": lambda training: None, "_mask_arena": None,
+                "engine": SimpleNamespace(arena=SimpleNamespace(params=list(m.model.parameters())))}
+
+    mine = json.loads(json.dumps(G.generate(PM.Manager, extra, lambda m: torch.optim.SGD(m.model.parameters(), lr=m.args.lr, momentum=0.9))))
+    assert [r["tag"] for r in mine] == [r["tag"] for r in ref]
+    for a, b in zip(mine, ref):
+        assert a == b, (a["tag"], a, b)
