@@ -12,7 +12,7 @@ import torch.nn.functional as F
 
 C, B, NT, NV = 4, 4, 2, 2                      # classes, batch size, train / val batches per epoch
 SIZES = {"train": B * NT, "val": B * NV}
-VARIANTS = ["sgd", "ewc", "mas", "si", "lwf"]  # Finetune/train_SGD.py, EWC/train_EWC.py, MAS/train_MAS.py, SI/train_SI.py, LwF/main_LWF.py
+VARIANTS = ["sgd", "ewc", "mas", "si", "lwf", "imm"]  # Finetune/train_SGD.py, EWC/train_EWC.py, MAS/train_MAS.py, SI/train_SI.py, LwF/main_LWF.py, IMM/train_L2transfer.py
 
 _plateau = [0.25, 0.5] + [0.5] * 40
 _rising = [min(1.0, 0.125 * (i + 1)) for i in range(8)] + [1.0] * 40

@@ -534,13 +534,16 @@ def test_epoch_loops_match_reference_g27():
         if variant == "sgd":          # methods/finetune.py:59-61
             return tc.train_model(model, eng, opt, lr, loaders, sizes, num_epochs, exp_dir, resume, saving_freq=saving_freq,
                                   step_fn=opt.step, save_models_mode=save_models_mode, abort_on_bad_loss=False)
+        if variant == "imm":          # methods/imm.py:66-67
+            return tc.train_model(model, eng, opt, lr, loaders, sizes, num_epochs, exp_dir, resume, saving_freq=saving_freq,
+                                  abort_on_bad_loss=False)
         if variant == "si":           # methods/si.py:79-80
             return tc.train_model(model, eng, opt, lr, loaders, sizes, num_epochs, exp_dir, resume, saving_freq=saving_freq,
                                   early_stop="ge", extra_epoch=True)
         return tc.train_model(model, eng, opt, lr, loaders, sizes, num_epochs, exp_dir, resume, saving_freq=saving_freq)   # ewc.py:121, mas.py:96
 
     mine = json.loads(json.dumps(G.generate(train)))
-    assert len(mine) == len(ref) == 26
+    assert len(mine) == len(ref) == 31
     for a, b in zip(mine, ref):
         assert (a["tag"], a["variant"]) == (b["tag"], b["variant"])
         assert a == b, (a["tag"], a["variant"], a, b)
