@@ -40,9 +40,7 @@ def train_model(model, args, dset_sizes, resume="", save_models_mode=False, savi
     if os.path.isfile(resume):
         checkpoint = torch.load(resume, weights_only=False)
         start_epoch = checkpoint["epoch"]
-        with torch.no_grad():
-            for p, (_, v) in zip(model.net.parameters(), checkpoint["state_dict"].items()):
-                p.copy_(v)
+        model.net.load_state_dict(checkpoint["state_dict"])      # in place, by name: parameters and buffers
         optimizer.load_state_dict(checkpoint["optimizer"])
         best_acc, lr, val_beat_counts = checkpoint["best_acc"], checkpoint["lr"], checkpoint["val_beat_counts"]
     os.makedirs(exp_dir, exist_ok=True)

@@ -696,3 +696,21 @@ def test_packnet_session_loops_match_reference_g30():
     assert [r["tag"] for r in mine] == [r["tag"] for r in ref]
     for a, b in zip(mine, ref):
         assert a == b, (a["tag"], a, b)
+
+
+def test_rehearsal_epoch_loop_matches_reference_g31():
+    """gem_main.train_model against the reference's rehearsal trainer loop (methods/rehearsal/train_rehearsal.py:57-199) over a
+    scripted GEM wrapper (fixture G31), observe and observe_FT modes: learning rate per epoch, stop after more than ten
+    epochs without a new best, exit on a NaN loss, the best model written when the loop ends (also with save_models_mode
+    off), checkpoint every saving_freq epochs with its fields, resume by fresh objects."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import g31_common as G
+    from clsurvey_amd.methods import gem_main as GM
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "G31_rehearsal_loop.json")) as f:
+        ref = json.load(f)["runs"]
+    mine = json.loads(json.dumps(G.generate(GM.train_model, with_paths=False)))
+    assert len(mine) == len(ref) == 10
+    for a, b in zip(mine, ref):
+        assert a == b, (a["tag"], a["finetune"], a, b)
