@@ -12,7 +12,7 @@ import torch.nn.functional as F
 
 C, B, NT, NV = 4, 4, 2, 2                      # classes, batch size, train / val batches per epoch
 SIZES = {"train": B * NT, "val": B * NV}
-VARIANTS = ["sgd", "ewc", "mas", "si", "lwf", "imm"]  # Finetune/train_SGD.py, EWC/train_EWC.py, MAS/train_MAS.py, SI/train_SI.py, LwF/main_LWF.py, IMM/train_L2transfer.py
+VARIANTS = ["sgd", "ewc", "mas", "si", "lwf", "imm", "ebll"]  # Finetune/train_SGD.py, EWC/train_EWC.py, MAS/train_MAS.py, SI/train_SI.py, LwF/main_LWF.py, IMM/train_L2transfer.py, EBLL/Finetune_SGD_EBLL.py
 
 _plateau = [0.25, 0.5] + [0.5] * 40
 _rising = [min(1.0, 0.125 * (i + 1)) for i in range(8)] + [1.0] * 40
@@ -57,6 +57,19 @@ class ScriptedLwf(ScriptedNet):
     def forward(self, x):
         new = super().forward(x)
         return [0.0 * new.detach() + 0.0 * self.w, new]
+
+
+class ScriptedEbll(ScriptedNet):
+    """EBLL's interface: (logits per head, codes per old task) — Finetune_SGD_EBLL.py:318"""
+
+    def forward(self, x):
+        new = super().forward(x)
+        return [0.0 * new.detach() + 0.0 * self.w, new], [torch.zeros(x.shape[0], 3) + 0.0 * self.w]
+
+
+class ScriptedEbllTeacher(nn.Module):
+    def forward(self, x):
+        return [torch.zeros(x.shape[0], C)], [torch.zeros(x.shape[0], 3)]
 
 
 class ScriptedTeacher(nn.Module):
@@ -106,7 +119,7 @@ def _files(exp_dir):
 
 
 def run_once(train, variant, sc, exp_dir, num_epochs, resume):
-    model = (ScriptedLwf if variant == "lwf" else ScriptedNet)(sc["val"], sc["nan_at"])
+    model = {"lwf": ScriptedLwf, "ebll": ScriptedEbll}.get(variant, ScriptedNet)(sc["val"], sc["nan_at"])
     opt = LogSGD(model.parameters(), lr=0.01)
     _, best = train(variant, model, opt, 0.01, loaders(), dict(SIZES), num_epochs, exp_dir, resume, sc["saving_freq"],
                     sc["save_models_mode"])

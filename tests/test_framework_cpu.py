@@ -534,6 +534,29 @@ def test_epoch_loops_match_reference_g27():
         if variant == "sgd":          # methods/finetune.py:59-61
             return tc.train_model(model, eng, opt, lr, loaders, sizes, num_epochs, exp_dir, resume, saving_freq=saving_freq,
                                   step_fn=opt.step, save_models_mode=save_models_mode, abort_on_bad_loss=False)
+        if variant == "ebll":         # methods/ebll.py: fine_tune_SGD_EBLL -> train_model_ebll
+            from clsurvey_amd.methods import ebll
+
+            class EbllEngine(Engine):
+                def step(self, x, y, target_logits, target_codes, T, reg_lambda, reg_alpha, backward=True, stats=None):
+                    out = self.model(x)[0][-1]
+                    loss = F.cross_entropy(out, y)
+                    if backward:
+                        assert target_logits is not None and target_codes is not None
+                        self.model.zero_grad()
+                        loss.backward()
+                    stats[0] += float(loss.detach())
+                    stats[1] += int((out.argmax(1) == y).sum())
+                    return loss.detach(), torch.zeros(())
+
+            class EbllTeacher:
+                @staticmethod
+                def targets(x):
+                    return torch.zeros(x.shape[0], G.C), torch.zeros(x.shape[0], 3)
+
+            return ebll.train_model_ebll(model, G.ScriptedEbllTeacher(), opt, lr, loaders, sizes, num_epochs, exp_dir, resume,
+                                         temperature=2, reg_alpha=1e-6, saving_freq=saving_freq, reg_lambda=1,
+                                         engine=EbllEngine(model), teacher=EbllTeacher)
         if variant == "imm":          # methods/imm.py:66-67
             return tc.train_model(model, eng, opt, lr, loaders, sizes, num_epochs, exp_dir, resume, saving_freq=saving_freq,
                                   abort_on_bad_loss=False)
@@ -543,7 +566,7 @@ def test_epoch_loops_match_reference_g27():
         return tc.train_model(model, eng, opt, lr, loaders, sizes, num_epochs, exp_dir, resume, saving_freq=saving_freq)   # ewc.py:121, mas.py:96
 
     mine = json.loads(json.dumps(G.generate(train)))
-    assert len(mine) == len(ref) == 31
+    assert len(mine) == len(ref) == 36
     for a, b in zip(mine, ref):
         assert (a["tag"], a["variant"]) == (b["tag"], b["variant"])
         assert a == b, (a["tag"], a["variant"], a, b)
