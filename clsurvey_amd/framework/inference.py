@@ -30,12 +30,14 @@ def test_model(method, model, dataset_path, target_task_head_idx, target_head=No
     in which case the head index addresses that list) or the wrapper's own head index, and the classifier's last slot.
     Images stay on the device; hits are counted there and read once."""
     heads = None if target_head is None else (target_head if isinstance(target_head, list) else [target_head])
+    if heads is not None:                                    # inference.py:15-18
+        assert target_task_head_idx == 0, "Only EBLL, LWF have heads in model itself, here head idx indicates target_headlist idx"
     if hasattr(model, "classifier"):
         final_layer_idx = str(len(model.classifier._modules) - 1)
     model.eval()
     model = model.to(device)
     dsets = load_task_datasets(dataset_path)
-    split = subset if subset in dsets else "val"            # task files without a test split are scored on val
+    split = subset if "test" in dsets else "val"            # a task file without a test split is scored on val (inference.py:27-33)
     holder = SimpleNamespace(task_imgfolders=dsets, batch_size=batch_size, model=model, heads=heads,
                              current_head_idx=target_task_head_idx, final_layer_idx=final_layer_idx, task_idx=task_idx)
     hits = torch.zeros((), dtype=torch.int64, device=device)
