@@ -91,3 +91,24 @@ def evals(eval_all_models_all_tasks, perf_filename):
         out.append({"tag": c["tag"], "calls": meth.calls, "files": files})
         shutil.rmtree(root)
     return out
+
+
+# ---------------------------------------------------------------------------------------------- adopting the grid winner
+def adopt(grid_poststep):
+    """Methods without a phase 2 (finetuning, IMM): grid_poststep(args, manager) makes the winning grid node the task's
+    model and links TASK_TRAINING to it (method.py:1028-1041).  Run twice (a re-run finds the link in place)."""
+    root = tempfile.mkdtemp()
+    out = []
+    try:
+        for winner in ("lr=1.0E-03", "lr=5.0E-03_it1"):
+            node = os.path.join(root, "task_2", "FT_LR_GRIDSEARCH", winner)
+            os.makedirs(node, exist_ok=True)
+            mgr = SimpleNamespace(parent_exp_dir=root, best_exp_grid_node_dirname=node, previous_task_model_path="before")
+            grid_poststep(SimpleNamespace(task_counter=2), mgr)
+            link = os.path.join(root, "task_2", "TASK_TRAINING")
+            out.append({"is_link": os.path.islink(link), "target": os.readlink(link),
+                        "resolves_to": os.path.relpath(os.path.realpath(link), root),
+                        "previous_task_model_path": os.path.relpath(mgr.previous_task_model_path, root)})
+    finally:
+        shutil.rmtree(root)
+    return out

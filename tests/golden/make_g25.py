@@ -22,8 +22,10 @@ if __name__ == "__main__":
     import framework.eval as FE
     import models.net as MN
     import utilities.utils as U
+    import methods.method as RM
     data = {"names": G.names(U.get_exp_name, MN.get_init_modelname),
-            "evals": G.evals(FE.eval_all_models_all_tasks, U.get_perf_output_filename)}
+            "evals": G.evals(FE.eval_all_models_all_tasks, U.get_perf_output_filename),
+            "adopt": G.adopt(RM.Finetune.grid_poststep)}
     path = os.path.join(HERE, "G25_eval_and_names.json")
     with open(path, "w") as f:
         json.dump(data, f, indent=0)

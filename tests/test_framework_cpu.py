@@ -434,6 +434,9 @@ def test_eval_driver_and_names_match_reference_g25():
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "G25_eval_and_names.json")) as f:
         ref = json.load(f)
     assert G.names(driver.get_exp_name, driver.first_task_modelname) == ref["names"]
+    from clsurvey_amd.methods import method as M
+    assert G.adopt(M.parse("finetuning").grid_poststep) == ref["adopt"]          # the TASK_TRAINING link of the grid-only methods
+    assert G.adopt(M.parse("meanIMM").grid_poststep) == ref["adopt"]
     mine = json.loads(json.dumps(G.evals(driver.eval_all_models_all_tasks, driver.get_perf_output_filename)))
     for a, b in zip(mine, ref["evals"]):
         assert a["tag"] == b["tag"]
