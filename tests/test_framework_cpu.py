@@ -740,3 +740,29 @@ def test_rehearsal_epoch_loop_matches_reference_g31():
     assert len(mine) == len(ref) == 10
     for a, b in zip(mine, ref):
         assert a == b, (a["tag"], a["finetune"], a, b)
+
+
+def test_ebll_autoencoder_grid_matches_reference_g32():
+    """EBLL.prestep (the autoencoder grid on the previous task, method.py:835-908) against the reference's unchanged method over
+    a stand-in autoencoder trainer (fixture G32), six accuracy tables: which nodes are trained with which arguments and in
+    which directories, which directories are kept, the model path handed to phase 2, the grid checkpoint — fresh, again on
+    the finished tree (nothing retrained), interrupted after two nodes, continued."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import g32_common as G
+    from clsurvey_amd.methods import ebll as E
+    from clsurvey_amd.methods import method as M
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "G32_ebll_autoencoder_grid.json")) as f:
+        ref = json.load(f)["tables"]
+
+    def install(trainer):
+        saved = E.fine_tune_Adam_Autoencoder
+        E.fine_tune_Adam_Autoencoder = trainer
+        return lambda: setattr(E, "fine_tune_Adam_Autoencoder", saved)
+
+    mine = json.loads(json.dumps(G.generate(lambda: M.parse("EBLL"), install)))
+    assert list(mine) == list(ref)
+    for tag in ref:
+        for stage in ("fresh", "again", "interrupted", "continued"):
+            assert mine[tag][stage] == ref[tag][stage], (tag, stage, mine[tag][stage], ref[tag][stage])
