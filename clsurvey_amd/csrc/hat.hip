@@ -155,6 +155,177 @@ __global__ __launch_bounds__(HB) void clamp_kernel(float* __restrict__ x, size_t
     for (size_t i = (size_t)blockIdx.x * HB + threadIdx.x; i < n; i += stride) x[i] = fminf(fmaxf(x[i], lo), hi);
 }
 
+
+// ------------------------------------------------------------------------------------------------ whole-net launches
+// One training batch of HAT used to cost ~100 parameter-sized launches next to the ~35 of the net itself (rocprofv3,
+// profiles/r03a_hat_kernel_stats.csv: 26 x hat_sgd_apply at 21 us each — every thread summed up to 1024 f64 partials alone —
+// 26 x prep, 8 x each of gate / scale / reg-sums / weight-grad / emb-grad / clamp / fill): 0.9 ms of a 6.4 ms step on
+// wide_VGG9.  The *_multi entry points take job tables (passed by value as kernel arguments, <= HAT_JOBS per launch) and
+// do the same arithmetic in 6 launches per batch.
+constexpr int HAT_JOBS = 40;
+
+struct SgdJob { float* theta; float* grad; float* buf; const float* mask_back; size_t n; int is_emb; int first_block; int n_blocks; int pad; };
+struct SgdJobs { int n; int pad; SgdJob j[HAT_JOBS]; };
+
+__device__ __forceinline__ int job_of_block(const SgdJobs& J, int b) {
+    int k = 0;
+    for (int i = 1; i < J.n; ++i) k = (b >= J.j[i].first_block) ? i : k;
+    return k;
+}
+
+__global__ __launch_bounds__(HB) void hat_sgd_prep_multi_kernel(SgdJobs J, float wd, int compensate, float s, float smax,
+                                                                float thres_cosh, double* __restrict__ partial) {
+    __shared__ double part[HB];
+    const SgdJob& jb = J.j[job_of_block(J, blockIdx.x)];
+    const float* __restrict__ theta = jb.theta;
+    float* __restrict__ grad = jb.grad;
+    const float* __restrict__ mask_back = jb.mask_back;
+    const size_t n = jb.n, stride = (size_t)jb.n_blocks * HB;
+    const int is_emb = jb.is_emb;
+    double ss = 0.0;
+    for (size_t i = (size_t)(blockIdx.x - jb.first_block) * HB + threadIdx.x; i < n; i += stride) {
+        float g = grad[i], th = theta[i];
+        if (wd != 0.f && !is_emb) g += wd * th;
+        if (mask_back) g *= mask_back[i];
+        if (is_emb && compensate) {
+            float x = fminf(fmaxf(s * th, -thres_cosh), thres_cosh);
+            float num = coshf(x) + 1.f, den = coshf(th) + 1.f;
+            g *= smax / s * num / den;
+        }
+        grad[i] = g;
+        ss += (double)g * (double)g;
+    }
+    part[threadIdx.x] = ss;
+    __syncthreads();
+    for (int o = HB / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = part[0];
+}
+
+// clip_grad_norm_ per parameter: the block adds its parameter's <= HB partials as a fixed tree (one per thread), then
+// applies momentum SGD and, on embeddings, the clamp of hat.py:238-240 (thres_emb > 0).
+__global__ __launch_bounds__(HB) void hat_sgd_apply_multi_kernel(SgdJobs J, float lr, float momentum, int first, int do_clip,
+                                                                 float clipgrad, float thres_emb,
+                                                                 const double* __restrict__ partial) {
+    __shared__ double part[HB];
+    const SgdJob& jb = J.j[job_of_block(J, blockIdx.x)];
+    float coef = 1.f;
+    if (do_clip) {
+        part[threadIdx.x] = (int)threadIdx.x < jb.n_blocks ? partial[jb.first_block + threadIdx.x] : 0.0;
+        __syncthreads();
+        for (int o = HB / 2; o > 0; o >>= 1) {
+            if (threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+            __syncthreads();
+        }
+        const float norm = (float)sqrt(part[0]);
+        const float c = clipgrad / (norm + 1e-6f);
+        if (c < 1.f) coef = c;
+    }
+    float* __restrict__ theta = jb.theta;
+    float* __restrict__ grad = jb.grad;
+    float* __restrict__ buf = jb.buf;
+    const size_t n = jb.n, stride = (size_t)jb.n_blocks * HB;
+    const bool clamp = jb.is_emb && thres_emb > 0.f;
+    for (size_t i = (size_t)(blockIdx.x - jb.first_block) * HB + threadIdx.x; i < n; i += stride) {
+        float g = grad[i] * coef;
+        grad[i] = g;
+        float b = (momentum != 0.f) ? (first ? g : buf[i] * momentum + g) : g;
+        if (momentum != 0.f) buf[i] = b;
+        float th = theta[i] - lr * b;
+        theta[i] = clamp ? fminf(fmaxf(th, -thres_emb), thres_emb) : th;
+    }
+}
+
+struct GateJobs { int n; int pad; clhip_hat_gate_job j[HAT_JOBS]; };
+// ONE block: every layer's gate a = sigmoid(s * E[t]) and the two sums of the regulariser (hat.py:285-299), layers and
+// elements in a fixed order.
+__global__ __launch_bounds__(HB) void hat_gates_multi_kernel(GateJobs J, float s, double* __restrict__ sums) {
+    __shared__ double p0[HB], p1[HB];
+    double s0 = 0, s1 = 0;
+    for (int l = 0; l < J.n; ++l) {
+        const clhip_hat_gate_job& jb = J.j[l];
+        for (int i = threadIdx.x; i < jb.n; i += HB) {
+            const float a = 1.f / (1.f + expf(-s * jb.emb_row[i]));
+            jb.gate[i] = a;
+            const float aux = jb.mask_pre ? 1.f - jb.mask_pre[i] : 1.f;
+            s0 += (double)(a * aux);
+            s1 += (double)aux;
+        }
+    }
+    p0[threadIdx.x] = s0; p1[threadIdx.x] = s1;
+    __syncthreads();
+    for (int o = HB / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { p0[threadIdx.x] += p0[threadIdx.x + o]; p1[threadIdx.x] += p1[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && sums) { sums[0] = p0[0]; sums[1] = p1[0]; }
+}
+
+struct ScaleJob { const float* w; const float* gate; float* out; size_t total, C, R; int first_block; int n_blocks; };
+struct ScaleJobs { int n; int pad; ScaleJob j[HAT_JOBS]; };
+__global__ __launch_bounds__(HB) void hat_scale_multi_kernel(ScaleJobs J) {
+    int k = 0;
+    for (int i = 1; i < J.n; ++i) k = ((int)blockIdx.x >= J.j[i].first_block) ? i : k;
+    const ScaleJob& jb = J.j[k];
+    const float* __restrict__ w = jb.w;
+    const float* __restrict__ gate = jb.gate;
+    float* __restrict__ out = jb.out;
+    const size_t stride = (size_t)jb.n_blocks * HB, R = jb.R, C = jb.C;
+    for (size_t i = (size_t)(blockIdx.x - jb.first_block) * HB + threadIdx.x; i < jb.total; i += stride)
+        out[i] = gate ? w[i] * gate[(i / R) % C] : w[i];
+}
+
+struct WgJob { float* g; const float* w; const float* gate; float* dgate; int K, C, R, first_block; };
+struct WgJobs { int n; int pad; WgJob j[HAT_JOBS]; };
+// one block per (layer, input channel c), as hat_weight_grad_kernel; in place on the gradient
+__global__ __launch_bounds__(HB) void hat_weight_grad_multi_kernel(WgJobs J) {
+    __shared__ double part[HB];
+    int k = 0;
+    for (int i = 1; i < J.n; ++i) k = ((int)blockIdx.x >= J.j[i].first_block) ? i : k;
+    const WgJob& jb = J.j[k];
+    const int c = blockIdx.x - jb.first_block, C = jb.C, R = jb.R;
+    float* __restrict__ g = jb.g;
+    const float* __restrict__ w = jb.w;
+    const float a = jb.gate[c];
+    double s = 0.0;
+    const int n = jb.K * R;
+    for (int i = threadIdx.x; i < n; i += HB) {
+        const int kk = i / R, r = i - kk * R;
+        const size_t o = ((size_t)kk * C + c) * R + r;
+        const float gv = g[o];
+        s += (double)gv * (double)w[o];
+        g[o] = gv * a;
+    }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = HB / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) jb.dgate[c] = (float)part[0];
+}
+
+struct EmbJobs { int n; int pad; clhip_hat_emb_job j[HAT_JOBS]; };
+// grid.x = layers: the dense [rows][n] embedding gradient of a layer, zero except row t (what autograd leaves in
+// nn.Embedding.weight.grad); lamb / count with count read on the device when the caller has not got it
+__global__ __launch_bounds__(HB) void hat_emb_grads_multi_kernel(EmbJobs J, float s, float lamb, float count,
+                                                                 const double* __restrict__ sums) {
+    const clhip_hat_emb_job& jb = J.j[blockIdx.x];
+    const float loc = lamb / (count > 0.f ? count : (float)sums[1]);
+    for (int i = threadIdx.x; i < jb.rows * jb.n; i += HB) {
+        const int row = i / jb.n, c = i - row * jb.n;
+        float v = 0.f;
+        if (row == jb.t) {
+            const float aux = jb.mask_pre ? 1.f - jb.mask_pre[c] : 1.f;
+            const float ai = jb.gate[c];
+            v = (jb.dgate[c] + loc * aux) * (s * ai * (1.f - ai));
+        }
+        jb.demb[i] = v;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -221,6 +392,108 @@ int clhip_hat_sgd_step(float* theta, float* grad, float* buf, const float* mask_
     CLHIP_LAUNCH_CHECK();
     hipLaunchKernelGGL(hat_sgd_apply_kernel, dim3(blocks), dim3(HB), 0, st, theta, grad, buf, n, lr, momentum, first, !finetune,
                        clipgrad, partial, blocks);
+    CLHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+size_t clhip_hat_sgd_multi_ws(int n_params) { return (size_t)(n_params > 0 ? n_params : 1) * HB * sizeof(double); }
+
+int clhip_hat_sgd_step_multi(const clhip_hat_param* params, int n_params, float lr, float momentum, float wd, int finetune,
+                             float s, float smax, float thres_cosh, float clipgrad, float thres_emb, int first, void* ws,
+                             size_t ws_bytes, void* stream) {
+    if (!params || n_params <= 0 || !ws || ws_bytes < clhip_hat_sgd_multi_ws(n_params)) return CLHIP_EINVAL;
+    for (int i = 0; i < n_params; ++i)
+        if (!params[i].theta || !params[i].grad || !params[i].buf || params[i].n == 0) return CLHIP_EINVAL;
+    hipStream_t st = as_stream(stream);
+    double* partial = static_cast<double*>(ws);
+    for (int base = 0; base < n_params; base += HAT_JOBS) {
+        SgdJobs J;
+        J.n = n_params - base < HAT_JOBS ? n_params - base : HAT_JOBS;
+        J.pad = 0;
+        int blocks = 0;
+        for (int i = 0; i < J.n; ++i) {
+            const clhip_hat_param& p = params[base + i];
+            size_t nb = (p.n + (size_t)HB * 16 - 1) / ((size_t)HB * 16);       // ~16 elements per thread, <= HB blocks per parameter
+            if (nb < 1) nb = 1;
+            if (nb > HB) nb = HB;
+            J.j[i] = SgdJob{p.theta, p.grad, p.buf, p.mask_back, p.n, p.is_emb, blocks, (int)nb, 0};
+            blocks += (int)nb;
+        }
+        double* part = partial + (size_t)base * HB;
+        hipLaunchKernelGGL(hat_sgd_prep_multi_kernel, dim3(blocks), dim3(HB), 0, st, J, wd, !finetune, s, smax, thres_cosh, part);
+        CLHIP_LAUNCH_CHECK();
+        hipLaunchKernelGGL(hat_sgd_apply_multi_kernel, dim3(blocks), dim3(HB), 0, st, J, lr, momentum, first, !finetune, clipgrad,
+                           thres_emb, part);
+        CLHIP_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+int clhip_hat_gates_multi(const clhip_hat_gate_job* jobs, int n_jobs, float s, double* sums2, void* stream) {
+    if (!jobs || n_jobs <= 0 || n_jobs > HAT_JOBS) return CLHIP_EINVAL;
+    GateJobs J;
+    J.n = n_jobs; J.pad = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        if (!jobs[i].emb_row || !jobs[i].gate || jobs[i].n <= 0) return CLHIP_EINVAL;
+        J.j[i] = jobs[i];
+    }
+    hipLaunchKernelGGL(hat_gates_multi_kernel, dim3(1), dim3(HB), 0, as_stream(stream), J, s, sums2);
+    CLHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+int clhip_hat_scale_weights_multi(const clhip_hat_layer* layers, int n_layers, void* stream) {
+    if (!layers || n_layers <= 0) return CLHIP_EINVAL;
+    for (int base = 0; base < n_layers; base += HAT_JOBS) {
+        ScaleJobs J;
+        J.n = n_layers - base < HAT_JOBS ? n_layers - base : HAT_JOBS;
+        J.pad = 0;
+        int blocks = 0;
+        for (int i = 0; i < J.n; ++i) {
+            const clhip_hat_layer& l = layers[base + i];
+            if (!l.w || !l.out || l.K == 0 || l.C == 0 || l.R == 0) return CLHIP_EINVAL;
+            const size_t total = l.K * l.C * l.R;
+            size_t nb = (total + (size_t)HB * 16 - 1) / ((size_t)HB * 16);
+            if (nb < 1) nb = 1;
+            if (nb > 512) nb = 512;
+            J.j[i] = ScaleJob{l.w, l.gate_in, l.out, total, l.C, l.R, blocks, (int)nb};
+            blocks += (int)nb;
+        }
+        hipLaunchKernelGGL(hat_scale_multi_kernel, dim3(blocks), dim3(HB), 0, as_stream(stream), J);
+        CLHIP_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+int clhip_hat_weight_grads_multi(const clhip_hat_wgrad_job* jobs, int n_jobs, void* stream) {
+    if (!jobs || n_jobs <= 0) return CLHIP_EINVAL;
+    for (int base = 0; base < n_jobs; base += HAT_JOBS) {
+        WgJobs J;
+        J.n = n_jobs - base < HAT_JOBS ? n_jobs - base : HAT_JOBS;
+        J.pad = 0;
+        int blocks = 0;
+        for (int i = 0; i < J.n; ++i) {
+            const clhip_hat_wgrad_job& w = jobs[base + i];
+            if (!w.g || !w.w || !w.gate_in || !w.dgate_in || w.K <= 0 || w.C <= 0 || w.R <= 0) return CLHIP_EINVAL;
+            J.j[i] = WgJob{w.g, w.w, w.gate_in, w.dgate_in, w.K, w.C, w.R, blocks};
+            blocks += w.C;
+        }
+        hipLaunchKernelGGL(hat_weight_grad_multi_kernel, dim3(blocks), dim3(HB), 0, as_stream(stream), J);
+        CLHIP_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+int clhip_hat_emb_grads_multi(const clhip_hat_emb_job* jobs, int n_jobs, float s, float lamb, float count, const double* sums2,
+                              void* stream) {
+    if (!jobs || n_jobs <= 0 || n_jobs > HAT_JOBS || (count <= 0.f && !sums2)) return CLHIP_EINVAL;
+    EmbJobs J;
+    J.n = n_jobs; J.pad = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        if (!jobs[i].dgate || !jobs[i].gate || !jobs[i].demb || jobs[i].n <= 0 || jobs[i].rows <= 0) return CLHIP_EINVAL;
+        J.j[i] = jobs[i];
+    }
+    hipLaunchKernelGGL(hat_emb_grads_multi_kernel, dim3(n_jobs), dim3(HB), 0, as_stream(stream), J, s, lamb, count, sums2);
     CLHIP_LAUNCH_CHECK();
     return 0;
 }

@@ -242,6 +242,32 @@ int clhip_hat_sgd_step(float* theta, float* grad, float* buf, const float* mask_
                        float clipgrad, int first, void* ws, size_t ws_bytes, void* stream);
 int clhip_clamp(float* x, size_t n, float lo, float hi, void* stream);
 
+/* The same arithmetic for a whole net per launch (job tables on the host, copied into the kernel arguments): one HAT
+ * training batch is gates + regulariser sums (1 launch), W' for every layer (1), [the net's own plan], dW / dgate for every
+ * gated layer (1), embedding gradients (1), HAT_SGD.step over every parameter incl. the embedding clamp (2).
+ *   hat_gates_multi        gate_l = sigmoid(s * emb_row_l); sums2[0] = sum gate*(1-mask_pre), sums2[1] = sum (1-mask_pre)
+ *                          (written, not accumulated; sums2 may be NULL)
+ *   hat_scale_weights_multi  out = w * gate_in[c] per layer (gate_in NULL => copy: biases, the first layer)
+ *   hat_weight_grads_multi   in place: dgate_in[c] = sum_{k,r} g*w ; g *= gate_in[c]
+ *   hat_emb_grads_multi      demb[rows][n] = 0 except row t = (dgate + lamb/count*(1-mask_pre)) * s*a*(1-a); count <= 0 reads
+ *                            sums2[1] on the device (no host synchronisation)
+ *   hat_sgd_step_multi       HAT_utils.py:192-250 per parameter (clip_grad_norm_ is per parameter) + clamp of the embeddings to
+ *                            +-thres_emb when thres_emb > 0 (hat.py:238-240); ws: clhip_hat_sgd_multi_ws(n_params) bytes   */
+typedef struct { float* theta; float* grad; float* buf; const float* mask_back; size_t n; int is_emb; int reserved; } clhip_hat_param;
+typedef struct { const float* emb_row; float* gate; const float* mask_pre; int n; int reserved; } clhip_hat_gate_job;
+typedef struct { const float* w; const float* gate_in; float* out; size_t K, C, R; } clhip_hat_layer;
+typedef struct { float* g; const float* w; const float* gate_in; float* dgate_in; int K, C, R, reserved; } clhip_hat_wgrad_job;
+typedef struct { const float* dgate; const float* gate; const float* mask_pre; float* demb; int n, rows, t, reserved; } clhip_hat_emb_job;
+size_t clhip_hat_sgd_multi_ws(int n_params);
+int clhip_hat_sgd_step_multi(const clhip_hat_param* params, int n_params, float lr, float momentum, float wd, int finetune,
+                             float s, float smax, float thres_cosh, float clipgrad, float thres_emb, int first, void* ws,
+                             size_t ws_bytes, void* stream);
+int clhip_hat_gates_multi(const clhip_hat_gate_job* jobs, int n_jobs, float s, double* sums2, void* stream);
+int clhip_hat_scale_weights_multi(const clhip_hat_layer* layers, int n_layers, void* stream);
+int clhip_hat_weight_grads_multi(const clhip_hat_wgrad_job* jobs, int n_jobs, void* stream);
+int clhip_hat_emb_grads_multi(const clhip_hat_emb_job* jobs, int n_jobs, float s, float lamb, float count, const double* sums2,
+                              void* stream);
+
 /* ------------------------------------------------------------------ static-plan net executor
  * One call per pass for VGG-style nets instead of one Python dispatch per op
  * (replaces `outputs = model(inputs); loss.backward()` of EWC/train_EWC.py:181-187,

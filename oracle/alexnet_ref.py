@@ -108,3 +108,106 @@ def sgd_momentum_step(params, grads, bufs, lr, momentum=0.9):
         for i, (p, g) in enumerate(zip(params, grads)):
             bufs[i] = g.clone() if bufs[i] is None else bufs[i] * momentum + g
             p.sub_(lr * bufs[i])
+
+
+# ------------------------------------------------------------------------------------------------ decision-forced evaluation
+def _pool_windows(z, k, s):
+    """[N,C,H,W] -> [N,C,OH,OW,k*k], window position r*k + c (the scan order of a k x k window)."""
+    w = z.unfold(2, k, s).unfold(3, k, s)
+    return w.reshape(w.shape[0], w.shape[1], w.shape[2], w.shape[3], k * k)
+
+
+def forward_forced(model, x, masks, decisions):
+    """`forward` with every non-linear DECISION taken from `decisions` instead of from the data (the module-tree form of
+    oracle.vgg_ref.forward_forced): one dict per Conv2d / hidden Linear in forward order, {'mask': bool, shaped like that
+    block's output (after its max-pool, if any)} for the ReLU, plus {'idx': int64 [N,C,OH,OW]} (window position r*k + c
+    passed on) where a MaxPool2d follows.  Max-pooling commutes with ReLU, so relu -> pool is evaluated as
+    gather(z, idx) * mask.  With the data's own decisions this IS `forward`; with another evaluation's decisions it is the
+    piecewise-linear branch that evaluation took, so two fp32 evaluation orders that disagree on a near-tie can be
+    compared at rounding level.  Returns (logits, [pre-activation per block, before pool / ReLU])."""
+    masks = masks or {}
+    di, b, pre = 0, 0, []
+    feats = list(model.features.children())
+    i = 0
+    while i < len(feats):
+        m = feats[i]
+        if isinstance(m, nn.Dropout):
+            if di in masks:
+                x = x * masks[di].to(x.dtype)
+            di += 1
+            i += 1
+            continue
+        assert isinstance(m, nn.Conv2d), type(m)
+        z = F.conv2d(x, m.weight, m.bias, m.stride, m.padding)
+        i += 1
+        if i < len(feats) and isinstance(feats[i], nn.BatchNorm2d):
+            bn = feats[i]
+            z = F.batch_norm(z, bn.running_mean.clone(), bn.running_var.clone(), bn.weight, bn.bias, bn.training, bn.momentum, bn.eps)
+            i += 1
+        relu = i < len(feats) and isinstance(feats[i], nn.ReLU)
+        i += 1 if relu else 0
+        pre.append(z)
+        d = decisions[b]
+        b += 1
+        if i < len(feats) and isinstance(feats[i], nn.MaxPool2d):
+            mp = feats[i]
+            k = mp.kernel_size if isinstance(mp.kernel_size, int) else mp.kernel_size[0]
+            s = mp.stride if isinstance(mp.stride, int) else mp.stride[0]
+            z = torch.gather(_pool_windows(z, k, s), 4, d["idx"].unsqueeze(-1)).squeeze(-1)
+            i += 1
+        x = z * d["mask"].to(z.dtype) if relu else z
+    x = torch.flatten(x, 1)
+    cls = list(model.classifier.children())
+    i = 0
+    while i < len(cls):
+        m = cls[i]
+        if isinstance(m, nn.Dropout):
+            if di in masks:
+                x = x * masks[di].to(x.dtype)
+            di += 1
+            i += 1
+            continue
+        assert isinstance(m, nn.Linear), type(m)
+        x = F.linear(x, m.weight, m.bias)
+        i += 1
+        if i < len(cls) and isinstance(cls[i], nn.ReLU):
+            pre.append(x)
+            x = x * decisions[b]["mask"].to(x.dtype)
+            b += 1
+            i += 1
+    return x, pre
+
+
+def loss_and_grads_forced(model, x, y, masks, decisions):
+    """(loss, logits, grads, pre-activations) of mean cross-entropy on the branch `decisions` selects."""
+    params = list(model.parameters())
+    logits, pre = forward_forced(model, x, masks, decisions)
+    loss = F.cross_entropy(logits, y)
+    grads = torch.autograd.grad(loss, params)
+    return loss.detach(), logits.detach(), [g.detach() for g in grads], [z.detach() for z in pre]
+
+
+def own_decisions(model, pre):
+    """The decisions the pre-activations `pre` of forward_forced imply themselves (first maximum of a window wins)."""
+    out, b = [], 0
+    feats = list(model.features.children())
+    for i, m in enumerate(feats):
+        if not isinstance(m, nn.Conv2d):
+            continue
+        z = pre[b]
+        b += 1
+        j = i + 1
+        while j < len(feats) and isinstance(feats[j], (nn.BatchNorm2d, nn.ReLU)):
+            j += 1
+        if j < len(feats) and isinstance(feats[j], nn.MaxPool2d):
+            mp = feats[j]
+            k = mp.kernel_size if isinstance(mp.kernel_size, int) else mp.kernel_size[0]
+            s = mp.stride if isinstance(mp.stride, int) else mp.stride[0]
+            win = _pool_windows(z, k, s)
+            idx = win.argmax(4)
+            out.append({"idx": idx, "mask": torch.gather(win, 4, idx.unsqueeze(-1)).squeeze(-1) > 0, "k": k, "s": s})
+        else:
+            out.append({"mask": z > 0})
+    for z in pre[b:]:
+        out.append({"mask": z > 0})
+    return out

@@ -25,25 +25,43 @@ def masks(P, t, s):
     return out
 
 
-def forward(P, pool_after, t, x, s, conv_geo=None, pool=(2, 2), drop=None, first_drop=False):
+def forward(P, pool_after, t, x, s, conv_geo=None, pool=(2, 2), drop=None, first_drop=False, decisions=None, pre=None):
     """vgg_hat.py:83-119. pool_after: set of conv indices followed by the net's max-pool.
     conv_geo: (stride, padding) per convolution (default: the VGG 3x3 / 1 / 1); pool: (kernel, stride) of the one
     MaxPool2d module the net shares (vgg_hat.py:41-44); drop: one keep-mask (already scaled by 1 / (1 - p)) per gated
     Linear layer, or None in eval mode; first_drop: alexnet_hat.py:12-13 — relu(fc(drop(x))) — instead of the VGG
-    order drop(relu(fc(x))) (vgg_hat.py:110-114)."""
+    order drop(relu(fc(x))) (vgg_hat.py:110-114).
+    decisions (optional, test infrastructure): one dict per conv / gated Linear layer, {'mask': bool like the layer's
+    output after its pool, 'idx': int64 window position r*k + c for pooled layers} — the ReLU / arg-max DECISIONS of
+    another evaluation of the same step; the layer is then evaluated on that piecewise-linear branch (relu -> pool as
+    gather(z, idx) * mask, see oracle.alexnet_ref.forward_forced).  pre (optional list): receives every pre-activation."""
     nc, nf = n_layers(P)
     mk = masks(P, t, s)
     for i in range(nc):
         stride, pad = conv_geo[i] if conv_geo is not None else (1, 1)
-        x = F.relu(F.conv2d(x, P["convs.%d.weight" % i], P["convs.%d.bias" % i], stride=stride, padding=pad))
-        if i in pool_after:
-            x = F.max_pool2d(x, pool[0], pool[1])
+        z = F.conv2d(x, P["convs.%d.weight" % i], P["convs.%d.bias" % i], stride=stride, padding=pad)
+        if pre is not None:
+            pre.append(z)
+        if decisions is None:
+            x = F.relu(z)
+            if i in pool_after:
+                x = F.max_pool2d(x, pool[0], pool[1])
+        else:
+            d = decisions[i]
+            if i in pool_after:
+                win = z.unfold(2, pool[0], pool[1]).unfold(3, pool[0], pool[1])
+                win = win.reshape(win.shape[0], win.shape[1], win.shape[2], win.shape[3], pool[0] * pool[0])
+                z = torch.gather(win, 4, d["idx"].unsqueeze(-1)).squeeze(-1)
+            x = z * d["mask"].to(z.dtype)
         x = x * mk[i].view(1, -1, 1, 1)
     x = x.reshape(x.shape[0], -1)
     for i in range(nf):
         if drop is not None and first_drop:
             x = x * drop[i]
-        x = F.relu(F.linear(x, P["fcs.%d.weight" % i], P["fcs.%d.bias" % i]))
+        z = F.linear(x, P["fcs.%d.weight" % i], P["fcs.%d.bias" % i])
+        if pre is not None:
+            pre.append(z)
+        x = F.relu(z) if decisions is None else z * decisions[nc + i]["mask"].to(z.dtype)
         if drop is not None and not first_drop:
             x = x * drop[i]
         x = x * mk[nc + i]

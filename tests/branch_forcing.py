@@ -1,0 +1,30 @@
+"""Test infrastructure shared by the GPU parity tests: reading the executor's non-linear decisions back."""
+
+
+def engine_decisions(eng, n):
+    """The ReLU masks and max-pool arg-max codes of the executor's last forward, one dict per plan layer that has a
+    ReLU, shaped for oracle.alexnet_ref.forward_forced.  (The saved activation behind a Dropout is already masked: a
+    dropped element reads as 'off', which is the same product.)"""
+    out = []
+    c, h, w = eng.in_shape
+    for li, (kind, m, relu, pool) in enumerate(eng.layers):
+        if kind == "conv":
+            ks, st, pd = m.kernel_size[0], m.stride[0], m.padding[0]
+            c, h, w = m.out_channels, (h + 2 * pd - ks) // st + 1, (w + 2 * pd - ks) // st + 1
+            if pool:
+                pk, ps = pool if isinstance(pool, tuple) else (2, 2)
+                h, w = (h - pk) // ps + 1, (w - pk) // ps + 1
+            shape = (n, c, h, w)
+        else:
+            c, h, w = m.out_features, 1, 1
+            shape = (n, c)
+        if not relu:
+            assert li == len(eng.layers) - 1
+            continue
+        d = {"mask": (eng.layer_input(li + 1, n).view(shape) > 0).cpu()}
+        if li + 1 in eng._masks:              # a Dropout sits between this block and the next layer
+            d["dropped"] = (eng._masks[li + 1].cpu() == 0).expand(n, -1).reshape(shape)
+        if pool:
+            d["idx"] = eng.pool_idx(li, n).view(shape).cpu().long()
+        out.append(d)
+    return out

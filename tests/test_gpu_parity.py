@@ -233,6 +233,45 @@ def build_engine(cfg, fc, ncls, hw, params, max_batch):
     return m, eng
 
 
+def _vgg_decisions(eng, cfg, N, hw):
+    """ReLU masks / pool arg-max codes of the executor's last forward in the layout of oracle.vgg_ref.forward_forced."""
+    decisions = []
+    h, j, li = hw, 0, 0
+    while j < len(cfg):
+        k = cfg[j]
+        pooled = j + 1 < len(cfg) and cfg[j + 1] == "M"
+        oh = h // 2 if pooled else h
+        act = eng.layer_input(li + 1, N).view(N, k, oh, oh).cpu()
+        d = {"mask": act > 0}
+        if pooled:
+            d["idx"] = eng.pool_idx(li, N).view(N, k, oh, oh).cpu().long()
+        decisions.append(d)
+        h, j, li = oh, j + (2 if pooled else 1), li + 1
+    for f in range(2):
+        decisions.append({"mask": eng.layer_input(li + 1, N).cpu() > 0})
+        li += 1
+    return decisions
+
+
+def _vgg_flips(cfg, decisions, pre):
+    """Decisions of the executor that differ from what the fp64 pre-activations `pre` imply; each must be a near-tie."""
+    flips = 0
+    for b, (dg, do, z) in enumerate(zip(decisions, vgg_ref.own_decisions(cfg, pre), pre)):
+        tie = 1e-4 * float(z.abs().max())
+        if "idx" in dg:
+            win = vgg_ref._windows(z)
+            zg = torch.gather(win, 4, dg["idx"].unsqueeze(-1)).squeeze(-1)
+            zo = torch.gather(win, 4, do["idx"].unsqueeze(-1)).squeeze(-1)
+            moved = (dg["idx"] != do["idx"]) & (dg["mask"] | do["mask"])
+            flips += int(moved.sum())
+            assert not moved.any() or float((zo - zg)[moved].abs().max()) <= tie, "block %d: arg-max differs off a tie" % b
+            z = zg
+        off = dg["mask"] != (z > 0)
+        flips += int(off.sum())
+        assert not off.any() or float(z[off].abs().max()) <= tie, "block %d: ReLU decision differs off a tie" % b
+    return flips
+
+
 @pytest.mark.parametrize("kind", ["ce_mean", "ce_sum", "mse_sum_zero"])
 def test_engine_matches_reference_golden_g1(golden, kind):
     g = golden("G1_vgg_fwd_bwd")
@@ -310,21 +349,7 @@ def test_engine_full_size_vs_oracle(name, N, hw):
     # the ReLU masks and pool arg-max codes read back from the plan executor), where EVERY gradient element must agree to
     # 1e-3 of the tensor's scale (measured: <= 2e-5); and the decisions themselves are judged separately: wherever the
     # GPU's differ from what the fp64 pre-activations imply, the element must be a near-tie.
-    decisions, shapes = [], []
-    c, h, j, li = 3, hw, 0, 0
-    while j < len(cfg):
-        k = cfg[j]
-        pooled = j + 1 < len(cfg) and cfg[j + 1] == "M"
-        oh = h // 2 if pooled else h
-        act = eng.layer_input(li + 1, N).view(N, k, oh, oh).cpu()
-        d = {"mask": act > 0}
-        if pooled:
-            d["idx"] = eng.pool_idx(li, N).view(N, k, oh, oh).cpu().long()
-        decisions.append(d)
-        c, h, j, li = k, oh, j + (2 if pooled else 1), li + 1
-    for f in range(2):
-        decisions.append({"mask": eng.layer_input(li + 1, N).cpu() > 0})
-        li += 1
+    decisions = _vgg_decisions(eng, cfg, N, hw)
     lo_f, loss_f, grads_f, pre = vgg_ref.loss_and_grads_forced(p64, cfg, x.double(), y, "ce_sum", decisions)
     assert float((logits.double().cpu() - lo_f).abs().max()) <= 1e-4 * max(1.0, float(lo_f.abs().max()))
     worst = 0.0
@@ -332,25 +357,7 @@ def test_engine_full_size_vs_oracle(name, N, hw):
         err = float((p.grad.double().cpu() - gf).abs().max()) / max(float(gf.abs().max()), 1e-30)
         worst = max(worst, err)
         assert err <= 1e-4, "grad %d: %.3e of its scale on the GPU's own branch (north_star: 1e-3)" % (i, err)
-    own = vgg_ref.own_decisions(cfg, pre)
-    flips = 0
-    for b, (dg, do, z) in enumerate(zip(decisions, own, pre)):
-        tie = 1e-4 * float(z.abs().max())
-        if "idx" in dg:
-            win = vgg_ref._windows(z)
-            zg = torch.gather(win, 4, dg["idx"].unsqueeze(-1)).squeeze(-1)
-            zo = torch.gather(win, 4, do["idx"].unsqueeze(-1)).squeeze(-1)
-            # the pool runs on ReLU outputs: where the whole window is <= 0 the code is 0 by convention and carries no
-            # gradient; only windows that pass something on count
-            moved = (dg["idx"] != do["idx"]) & (dg["mask"] | do["mask"])
-            flips += int(moved.sum())
-            assert float((zo - zg)[moved].abs().max()) <= tie if moved.any() else True, "block %d: arg-max differs off a tie" % b
-            z_sel = zg
-        else:
-            z_sel = z
-        off = dg["mask"] != (z_sel > 0)
-        flips += int(off.sum())
-        assert float(z_sel[off].abs().max()) <= tie if off.any() else True, "block %d: ReLU decision differs off a tie" % b
+    flips = _vgg_flips(cfg, decisions, pre)
     print("%s N=%d hw=%d: worst gradient element %.2e of scale on the forced branch; %d near-tie decisions differ from fp64"
           % (name, N, hw, worst, flips))
     del deep
@@ -424,7 +431,15 @@ def test_penalised_sgd_golden_g5(golden):
 
 
 def test_si_golden_g4(golden):
+    """Elastic_SGD.step x 3 + update_reg_params (SI/train_SI.py:28-126, :301-364) against the reference's tensors (G4).
+    theta, init_val: 2e-4 directly.  The path integral w = -sum(grad * delta theta) and the Omega consolidated from it
+    inherit every ReLU / arg-max near-tie of three forward passes, so their arithmetic is judged where it can be judged
+    at rounding level: an fp64 run of the oracle (oracle.regularizers_ref.si_step on oracle.vgg_ref gradients) that
+    takes the executor's own branch in every pass must reproduce theta, w and Omega to 1e-4 of each tensor's scale
+    (north_star: 1e-3); the decisions that differ from the fp64 ones are counted and must be near-ties; and with no
+    differing decision the reference's fp32 tensors are matched to 1e-3 directly."""
     from clsurvey_amd import ops
+    from oracle import regularizers_ref as R
     g = golden("G4_si")
     for tag, wd in (("wd0", 0.0), ("wd1", 1e-4)):
         params = [torch.from_numpy(g["%s_p%d" % (tag, i)]) for i in range(18)]
@@ -435,18 +450,35 @@ def test_si_golden_g4(golden):
         A.load("init_val", {p: torch.from_numpy(g["%s_init%d" % (tag, i)]) for i, p in enumerate(plist)})
         buf, w = A.buffer("buf"), A.buffer("w")
         w.zero_()
+        th64 = [p.double() for p in params]
+        om64 = [torch.from_numpy(g["%s_omega%d" % (tag, i)]).double() for i in range(18)]
+        iv64 = [torch.from_numpy(g["%s_init%d" % (tag, i)]).double() for i in range(18)]
+        w64, b64 = [torch.zeros_like(t) for t in th64], [None] * 18
+        flips = 0
         for s in range(3):
-            x = torch.from_numpy(g["%s_x%d" % (tag, s)]).to(dev())
-            y = torch.from_numpy(g["%s_y%d" % (tag, s)]).to(dev())
-            eng.loss_step(x, y, "ce_mean", True)
+            x = torch.from_numpy(g["%s_x%d" % (tag, s)])
+            y = torch.from_numpy(g["%s_y%d" % (tag, s)])
+            eng.loss_step(x.to(dev()), y.to(dev()), "ce_mean", True)
+            dec = _vgg_decisions(eng, TINY, 8, 32)
+            _, _, g64, pre = vgg_ref.loss_and_grads_forced(th64, TINY, x.double(), y, "ce_mean", dec)
+            flips += _vgg_flips(TINY, dec, pre)
             ops.si_step(A.theta, A.grad, A.aux["omega"], A.aux["init_val"], w, buf, 400, 1e-2, 0.9, wd, s == 0)
+            new = [R.si_step(t, gi, o, iv, wi, bi, 400, 1e-2, 0.9, wd, s == 0)
+                   for t, gi, o, iv, wi, bi in zip(th64, g64, om64, iv64, w64, b64)]
+            th64, b64, w64 = [n[0] for n in new], [n[1] for n in new], [n[2] for n in new]
+        direct = 1e-3 if flips == 0 else 2e-3
         for i, p in enumerate(plist):
             assert_close(p.data, torch.from_numpy(g["%s_s2_theta%d" % (tag, i)]), what="theta %d" % i)
-            assert_close(A.view("w", p), torch.from_numpy(g["%s_s2_w%d" % (tag, i)]), tol=2e-3, what="w %d" % i)
+            assert_close(A.view("w", p), torch.from_numpy(g["%s_s2_w%d" % (tag, i)]), tol=direct, what="w %d" % i)
+            assert_close(p.data.double(), th64[i], tol=1e-5, what="theta %d on the executor's branch" % i)
+            assert_close(A.view("w", p).double(), w64[i], tol=1e-4, what="w %d on the executor's branch" % i)
         ops.si_consolidate(A.aux["omega"], w, A.theta, A.aux["init_val"])
         for i, p in enumerate(plist):
-            assert_close(A.view("omega", p), torch.from_numpy(g["%s_cons_omega%d" % (tag, i)]), tol=2e-3, what="omega %d" % i)
+            o64, _, _ = R.si_consolidate(om64[i], w64[i], th64[i], iv64[i])
+            assert_close(A.view("omega", p).double(), o64, tol=1e-4, what="omega %d on the executor's branch" % i)
+            assert_close(A.view("omega", p), torch.from_numpy(g["%s_cons_omega%d" % (tag, i)]), tol=direct, what="omega %d" % i)
             assert_close(A.view("init_val", p), torch.from_numpy(g["%s_cons_init%d" % (tag, i)]), what="init %d" % i)
+        print("G4 %s: %d near-tie decisions differ from fp64 over 3 passes" % (tag, flips))
 
 
 def test_packnet_masks_bit_exact_g7(golden):
@@ -920,19 +952,51 @@ def _small_alexnet(ncls=10, seed=0):
     return m, copy.deepcopy(m)
 
 
-def _flip_aware_grads(eng, model, grads_ref, what, tol=2e-3):
-    """Per-tensor max-abs error relative to the tensor's max magnitude; a handful of ReLU / max-pool decisions may flip
-    between two fp32 summation orders, which moves single rows by ~1e-2 (see test_engine_full_size_vs_oracle)."""
+from branch_forcing import engine_decisions as _engine_decisions  # noqa: E402
+
+
+def _forced_branch_grads(eng, model, ref, x, y, masks, what, tol=1e-4, n_bias_before_bn=0):
+    """north_star: 1e-3 relative on fp32.  A ReLU / arg-max decision within rounding of a tie may come out differently in two
+    fp32 evaluation orders and then moves a row of the dW below it by ~1/sqrt(#pixels) — so the arithmetic is judged
+    with the decisions held fixed (as test_engine_full_size_vs_oracle does for the plain VGGs): an fp64 evaluation of the
+    oracle on the branch the executor took (oracle.alexnet_ref.forward_forced) must match EVERY gradient element to `tol`
+    of its tensor's scale, and the decisions are judged separately: wherever the executor's differ from what the fp64
+    pre-activations imply, the element must be a near-tie.  Returns (worst element error, decisions that differ)."""
+    import copy
+    from oracle import alexnet_ref
+    n = x.shape[0]
+    decisions = _engine_decisions(eng, n)
+    ref64 = copy.deepcopy(ref).double()
+    ref64.train(ref.training)
+    m64 = {k: v.double() for k, v in masks.items()} if masks else None
+    _, _, grads, pre = alexnet_ref.loss_and_grads_forced(ref64, x.double(), y, m64, decisions)
+    gmax = max(float(g.abs().max()) for g in grads)
     worst = 0.0
-    # a bias in front of a BatchNorm has an exactly-zero true gradient (both sides hold rounding noise): measure against
-    # at least 1e-4 of the largest gradient entry of the net
-    floor = 1e-4 * max(float(g.abs().max()) for g in grads_ref)
-    for (name, p), g in zip(model.named_parameters(), grads_ref):
-        got = eng.arena.view("grad", p).cpu()
-        e = float((got.double() - g.double()).abs().max() / max(float(g.abs().max()), floor))
+    for (name, p), g in zip(model.named_parameters(), grads):
+        got = eng.arena.view("grad", p).double().cpu()
+        # a bias in front of a BatchNorm has an exactly-zero true gradient (the executor holds rounding noise there):
+        # such tensors are measured against 5e-3 of the net's largest gradient entry
+        e = float((got - g).abs().max() / max(float(g.abs().max()), 5e-3 * gmax))
         worst = max(worst, e)
-        assert e <= tol, "%s: grad %s rel err %.3e" % (what, name, e)
-    return worst
+        assert e <= tol, "%s: grad %s %.3e of its scale on the executor's own branch (north_star: 1e-3)" % (what, name, e)
+    flips = 0
+    for b, (dg, do, z) in enumerate(zip(decisions, alexnet_ref.own_decisions(ref64, pre), pre)):
+        tie = 1e-4 * float(z.abs().max())
+        if "idx" in dg:
+            win = alexnet_ref._pool_windows(z, do["k"], do["s"])
+            zg = torch.gather(win, 4, dg["idx"].unsqueeze(-1)).squeeze(-1)
+            zo = torch.gather(win, 4, do["idx"].unsqueeze(-1)).squeeze(-1)
+            moved = (dg["idx"] != do["idx"]) & (dg["mask"] | do["mask"])       # all-non-positive windows carry no gradient
+            flips += int(moved.sum())
+            assert not moved.any() or float((zo - zg)[moved].abs().max()) <= tie, "%s block %d: arg-max differs off a tie" % (what, b)
+            z = zg
+        off = dg["mask"] != (z > 0)
+        if "dropped" in dg:                   # elements a Dropout removed read 'off' in the saved activation; no gradient there
+            off &= ~dg["dropped"]
+        flips += int(off.sum())
+        assert not off.any() or float(z[off].abs().max()) <= tie, "%s block %d: ReLU decision differs off a tie" % (what, b)
+    print("%s: worst gradient element %.2e of scale on the executor's branch; %d near-tie decisions differ from fp64" % (what, worst, flips))
+    return worst, flips
 
 
 @pytest.mark.parametrize("mode", ["eval", "per_sample", "shared_row"])
@@ -964,7 +1028,7 @@ def test_engine_alexnet_small_vs_oracle(mode):
     rl, rlog, rg = alexnet_ref.loss_and_grads(ref, x, y, masks)
     assert_close(logits.cpu(), rlog, what="logits")
     assert abs(float(loss) - float(rl)) <= 2e-4 * max(1.0, abs(float(rl)))
-    _flip_aware_grads(eng, model, rg, mode)
+    _forced_branch_grads(eng, model, ref, x, y, masks, "small alexnet " + mode)
     # switching the masks off again gives the eval-mode logits
     eng.set_dropout(5, None)
     eng.set_dropout(6, None)
@@ -1024,7 +1088,7 @@ def test_alexnet_full_size_vs_oracle():
     loss, logits = eng.loss_step(x.to(dev()), y.to(dev()), "ce_mean", True, want_logits=True)
     assert_close(logits.cpu(), rlog, what="logits")
     assert abs(float(loss) - float(rl)) <= 2e-4 * max(1.0, abs(float(rl)))
-    _flip_aware_grads(eng, model, rg, "alexnet 224")
+    _forced_branch_grads(eng, model, ref, x, y, {0: m0, 1: m1}, "alexnet 224")
 
 
 def test_alexnet_autograd_bridge_gradients():
@@ -1155,8 +1219,9 @@ def test_engine_vgg_drop_variant_vs_oracle():
     rl, rlog, rg = alexnet_ref.loss_and_grads(ref, x, y, {0: m0, 1: m1})
     assert_close(logits.cpu(), rlog, what="logits")
     # a 64x64 VGG has ~1e6 ReLU / pool decisions per batch; the handful that flip between two fp32 summation orders move
-    # the early conv gradients by a few 1e-3 of their max (measured 2.4e-3 on features.0.weight)
-    _flip_aware_grads(eng, model, rg, "vgg drop", tol=1e-2)
+    # the early conv gradients by a few 1e-3 of their max against the fp32 oracle (measured 2.4e-3 on features.0.weight),
+    # so the gradients are judged on the executor's own branch
+    _forced_branch_grads(eng, model, ref, x, y, {0: m0, 1: m1}, "vgg drop")
     model.eval()
     eng.auto_dropout = True
     assert_close(eng.forward(x.to(dev())).cpu(), alexnet_ref.forward(ref, x).detach(), what="eval")
@@ -1236,7 +1301,7 @@ def test_engine_vgg_bn_variant_vs_oracle():
     rl, rlog, rg = alexnet_ref.loss_and_grads(ref, x, y)
     assert_close(logits.cpu(), rlog, what="train logits")
     assert abs(float(loss) - float(rl)) <= 2e-4 * max(1.0, abs(float(rl)))
-    _flip_aware_grads(eng, model, rg, "vgg bn", tol=5e-3)
+    _forced_branch_grads(eng, model, ref, x, y, None, "vgg bn")
     for (name, b), (_, rb) in zip(model.named_buffers(), ref.named_buffers()):
         if b.dtype == torch.float32:
             assert_close(b.cpu(), rb, tol=1e-4, what=name)
