@@ -319,8 +319,7 @@ def extra_configs(dev, N, steps):
 
         def hat_step():
             hat.step(1, x, y, 400.0, mask_pre, 2.5, count, backward=True)          # hat.py:200-249
-            opt.step(hn, mask_back, 1, 400.0, 50, 800.0, 10000)
-            H.clamp_embeddings(hn, 6.0)
+            opt.step(hn, mask_back, 1, 400.0, 50, 800.0, 10000, thres_emb=6.0)
         out["hat_step_wide_vgg9_%d" % hw] = entry(
             _timed_loop(hat_step, st), nb, nb * step_fl,
             "HAT training batch of task 2 (gates, gated fwd + CE + reg, bwd, HAT_SGD, clamp), wide_VGG9_cl_512_512 %dx%d N=%d" % (hw, hw, nb))

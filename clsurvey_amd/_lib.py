@@ -13,6 +13,26 @@ _z = C.c_size_t
 _l = C.c_long
 
 
+class HatParam(C.Structure):                       # clhip_hat_param
+    _fields_ = [("theta", _p), ("grad", _p), ("buf", _p), ("mask_back", _p), ("n", _z), ("is_emb", _i), ("reserved", _i)]
+
+
+class HatGateJob(C.Structure):                     # clhip_hat_gate_job
+    _fields_ = [("emb_row", _p), ("gate", _p), ("mask_pre", _p), ("n", _i), ("reserved", _i)]
+
+
+class HatLayer(C.Structure):                       # clhip_hat_layer
+    _fields_ = [("w", _p), ("gate_in", _p), ("out", _p), ("K", _z), ("C", _z), ("R", _z)]
+
+
+class HatWgradJob(C.Structure):                    # clhip_hat_wgrad_job
+    _fields_ = [("g", _p), ("w", _p), ("gate_in", _p), ("dgate_in", _p), ("K", _i), ("C", _i), ("R", _i), ("reserved", _i)]
+
+
+class HatEmbJob(C.Structure):                      # clhip_hat_emb_job
+    _fields_ = [("dgate", _p), ("gate", _p), ("mask_pre", _p), ("demb", _p), ("n", _i), ("rows", _i), ("t", _i), ("reserved", _i)]
+
+
 class LayerDesc(C.Structure):
     _fields_ = [("type", _i), ("cin", _i), ("cout", _i), ("relu", _i), ("pool", _i),
                 ("w_off", _l), ("b_off", _l), ("ksize", _i), ("stride", _i), ("pad", _i), ("pool_k", _i), ("pool_s", _i),
@@ -70,6 +90,12 @@ SIGNATURES = {
     "clhip_hat_sgd_ws": (_z, []),
     "clhip_hat_sgd_step": (_i, [_p, _p, _p, _p, _z, _f, _f, _f, _i, _i, _f, _f, _f, _f, _i, _p, _z, _p]),
     "clhip_clamp": (_i, [_p, _z, _f, _f, _p]),
+    "clhip_hat_sgd_multi_ws": (_z, [_i]),
+    "clhip_hat_sgd_step_multi": (_i, [_p, _i, _f, _f, _f, _i, _f, _f, _f, _f, _f, _i, _p, _z, _p]),
+    "clhip_hat_gates_multi": (_i, [_p, _i, _f, _p, _p]),
+    "clhip_hat_scale_weights_multi": (_i, [_p, _i, _p]),
+    "clhip_hat_weight_grads_multi": (_i, [_p, _i, _p]),
+    "clhip_hat_emb_grads_multi": (_i, [_p, _i, _f, _f, _f, _p, _p]),
     "clhip_softmax_ce_slice": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
     "clhip_net_loss_step_slice": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "clhip_axpy": (_i, [_p, _p, _z, _f, _i, _p]),

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(HB) void hat_gates_multi_kernel(GateJobs J, float s
         if (threadIdx.x < o) { p0[threadIdx.x] += p0[threadIdx.x + o]; p1[threadIdx.x] += p1[threadIdx.x + o]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0 && sums) { sums[0] = p0[0]; sums[1] = p1[0]; }
+    if (threadIdx.x == 0 && sums) { sums[0] = p0[0]; sums[1] = p1[0]; sums[2] = p0[0] / p1[0]; }
 }
 
 struct ScaleJob { const float* w; const float* gate; float* out; size_t total, C, R; int first_block; int n_blocks; };

@@ -113,10 +113,30 @@ class HatEngine:
         self.nc = len(net.convs)
         self.gate = [torch.zeros(e.weight.shape[1], device=self.device) for e in self.embs]
         self.dgate = [torch.zeros_like(g) for g in self.gate]
-        self.reg_sums = torch.zeros(2, dtype=torch.float64, device=self.device)
-        self.ws = torch.zeros(_lib.lib().clhip_hat_sgd_ws(), dtype=torch.uint8, device=self.device)
+        self.reg_sums = torch.zeros(3, dtype=torch.float64, device=self.device)      # sum a(1-m), sum (1-m), their ratio
         for e in self.embs:
             e.weight.grad = torch.zeros_like(e.weight.data)
+        # static job tables of the whole-net launches (every pointer below is fixed for the engine's lifetime)
+        jobs = []
+        for li, mod in enumerate(self.layers):
+            w, b = mod.weight, mod.bias
+            ow, nw = self.A.slot(w)
+            gin = self.gate[li - 1] if li > 0 else None
+            R = self._R(li)
+            Cg = gin.numel() if gin is not None else nw // (w.shape[0] * R)
+            jobs.append(_lib.HatLayer(self.A.theta[ow:ow + nw].data_ptr(), gin.data_ptr() if gin is not None else None,
+                                      self.scaled[ow:ow + nw].data_ptr(), w.shape[0], Cg, R))
+            ob, nbias = self.A.slot(b)
+            jobs.append(_lib.HatLayer(self.A.theta[ob:ob + nbias].data_ptr(), None, self.scaled[ob:ob + nbias].data_ptr(), nbias, 1, 1))
+        self._scale_jobs = (_lib.HatLayer * len(jobs))(*jobs)
+        wg = []
+        for li in range(1, len(self.layers)):
+            w = self.layers[li].weight
+            ow, nw = self.A.slot(w)
+            gin = self.gate[li - 1]
+            wg.append(_lib.HatWgradJob(self.A.grad[ow:ow + nw].data_ptr(), self.A.theta[ow:ow + nw].data_ptr(), gin.data_ptr(),
+                                       self.dgate[li - 1].data_ptr(), w.shape[0], gin.numel(), self._R(li), 0))
+        self._wgrad_jobs = (_lib.HatWgradJob * len(wg))(*wg)
 
     def _R(self, li):
         """inner repeat of layer li's input-channel index in its weight layout [K][C][R]."""
@@ -127,27 +147,25 @@ class HatEngine:
             return self.net.smid * self.net.smid
         return 1
 
-    def gates(self, t, s):
-        L = _lib.lib()
-        for e, g in zip(self.embs, self.gate):
-            row = e.weight.data[t]
-            check(L.clhip_hat_gate(row.data_ptr(), row.numel(), float(s), g.data_ptr(), _stream()), "clhip_hat_gate")
+    def gates(self, t, s, mask_pre=None, sums=None):
+        """gate_l = sigmoid(s * E_l[t]) for every layer in ONE launch (vgg_hat.py:121-127); with `sums` (2 doubles on the
+        device) also the regulariser's sum gate * (1 - mask_pre) and sum (1 - mask_pre) (hat.py:285-299)."""
+        jobs = (_lib.HatGateJob * len(self.embs))()
+        for l, (e, g) in enumerate(zip(self.embs, self.gate)):
+            n = g.numel()
+            jobs[l] = _lib.HatGateJob(e.weight.data.data_ptr() + 4 * n * int(t), g.data_ptr(),
+                                      mask_pre[l].data_ptr() if mask_pre is not None else None, n, 0)
+        check(_lib.lib().clhip_hat_gates_multi(jobs, len(self.embs), float(s), sums.data_ptr() if sums is not None else None,
+                                               _stream()), "clhip_hat_gates_multi")
         return self.gate
 
     def masks_at(self, t, s):
         return [g.clone() for g in self.gates(t, s)]
 
     def _scale_weights(self):
-        L = _lib.lib()
-        self.scaled.copy_(self.A.theta)                      # biases (and layer 0) as they are
-        for li in range(1, len(self.layers)):
-            w = self.layers[li].weight.data
-            off, n = self.A.slot(self.layers[li].weight)
-            gin = self.gate[li - 1]
-            R = self._R(li)
-            K, Cg = w.shape[0], gin.numel()
-            check(L.clhip_hat_scale_weight(w.data_ptr(), gin.data_ptr(), self.scaled[off:off + n].data_ptr(), K, Cg, R,
-                                           _stream()), "clhip_hat_scale_weight")
+        """W' = W * gate_in[c] for every layer, biases and the first layer copied: ONE launch over the arena."""
+        check(_lib.lib().clhip_hat_scale_weights_multi(self._scale_jobs, len(self._scale_jobs), _stream()),
+              "clhip_hat_scale_weights_multi")
 
     def forward(self, t, x, s):
         """vgg_hat.Net.forward logits for task t at gate slope s (inference: s = smax)."""
@@ -161,35 +179,23 @@ class HatEngine:
 
     def step(self, t, x, y, s, mask_pre=None, lamb=0.0, count=None, backward=True, stats=None, want_logits=False):
         """Returns (ce_loss[1] device, reg device scalar (lamb*reg), logits|None). With backward=True all
-        .grad fields (convs, fcs, head in the arena; embeddings dense with row t filled) are set."""
+        .grad fields (convs, fcs, head in the arena; embeddings dense with row t filled) are set.  Six launches next to
+        the net's own plan, no host synchronisation (count = None reads the regulariser's denominator on the device)."""
         L = _lib.lib()
-        self.gates(t, s)
+        self.gates(t, s, mask_pre, self.reg_sums)
         self._scale_weights()
         ce, logits = self.engine.loss_step(x, y, "ce_mean", backward, stats, want_logits, params=self.scaled)
-        self.reg_sums.zero_()
-        for l, g in enumerate(self.gate):
-            mp = mask_pre[l] if mask_pre is not None else None
-            check(L.clhip_hat_reg_sums(g.data_ptr(), mp.data_ptr() if mp is not None else None, g.numel(),
-                                       self.reg_sums.data_ptr(), _stream()), "clhip_hat_reg_sums")
-        reg = lamb * self.reg_sums[0] / self.reg_sums[1]
+        reg = lamb * self.reg_sums[2]
         if backward:
-            if count is None:
-                count = float(self.reg_sums[1].item())
-            for li in range(1, len(self.layers)):
-                wmod = self.layers[li]
-                off, n = self.A.slot(wmod.weight)
-                gw = self.A.grad[off:off + n]
-                gin = self.gate[li - 1]
-                check(L.clhip_hat_weight_grad(gw.data_ptr(), wmod.weight.data.data_ptr(), gin.data_ptr(), gw.data_ptr(),
-                                              self.dgate[li - 1].data_ptr(), wmod.weight.shape[0], gin.numel(),
-                                              self._R(li), _stream()), "clhip_hat_weight_grad")
+            check(L.clhip_hat_weight_grads_multi(self._wgrad_jobs, len(self._wgrad_jobs), _stream()), "clhip_hat_weight_grads_multi")
+            jobs = (_lib.HatEmbJob * len(self.embs))()
             for l, e in enumerate(self.embs):
-                e.weight.grad.zero_()
-                mp = mask_pre[l] if mask_pre is not None else None
-                row = e.weight.grad[t]
-                check(L.clhip_hat_emb_grad(self.dgate[l].data_ptr(), self.gate[l].data_ptr(),
-                                           mp.data_ptr() if mp is not None else None, row.numel(), float(s),
-                                           float(lamb) / count, row.data_ptr(), _stream()), "clhip_hat_emb_grad")
+                rows, n = e.weight.shape
+                jobs[l] = _lib.HatEmbJob(self.dgate[l].data_ptr(), self.gate[l].data_ptr(),
+                                         mask_pre[l].data_ptr() if mask_pre is not None else None, e.weight.grad.data_ptr(),
+                                         n, rows, int(t), 0)
+            check(L.clhip_hat_emb_grads_multi(jobs, len(self.embs), float(s), float(lamb), float(count) if count else 0.0,
+                                              self.reg_sums.data_ptr(), _stream()), "clhip_hat_emb_grads_multi")
         return ce, reg, logits
 
 
@@ -231,27 +237,37 @@ class HAT_SGD(torch.optim.Optimizer):
                                       nesterov=nesterov))
         self._ws = None
 
-    def step(self, model, mask_back, t, s=None, thres_cosh=None, smax=None, clipgrad=None, finetune=False, closure=None):
+    def step(self, model, mask_back, t, s=None, thres_cosh=None, smax=None, clipgrad=None, finetune=False, closure=None,
+             thres_emb=None):
+        """HAT_utils.py:192-250 for every parameter in two launches (clip_grad_norm_ stays per parameter); thres_emb also
+        applies the embedding clamp that follows optimizer.step in the reference's batch loop (hat.py:238-240)."""
         L = _lib.lib()
         for group in self.param_groups:
+            rows, fresh = [], []
             for p, (name, modp) in zip(group["params"], model.named_parameters()):
                 assert modp is p
                 if p.grad is None:
                     continue
-                if self._ws is None:
-                    self._ws = torch.zeros(L.clhip_hat_sgd_ws(), dtype=torch.uint8, device=p.device)
                 st = self.state[p]
                 first = "momentum_buffer" not in st
                 if first:
                     st["momentum_buffer"] = torch.zeros_like(p.data)
+                fresh.append(first)
                 mb = mask_back.get(name) if t > 0 else None
-                check(L.clhip_hat_sgd_step(p.data.data_ptr(), p.grad.data.data_ptr(), st["momentum_buffer"].data_ptr(),
-                                           mb.data_ptr() if mb is not None else None, p.numel(), float(group["lr"]),
-                                           float(group["momentum"]), float(group["weight_decay"]), int("embs" in name),
-                                           int(finetune), float(s or 0.0), float(smax or 0.0), float(thres_cosh or 0.0),
-                                           float(clipgrad or 0.0),
-                                           int(first), self._ws.data_ptr(), self._ws.numel(), _stream()),
-                      "clhip_hat_sgd_step")
+                rows.append(_lib.HatParam(p.data.data_ptr(), p.grad.data.data_ptr(), st["momentum_buffer"].data_ptr(),
+                                          mb.data_ptr() if mb is not None else None, p.numel(), int("embs" in name), 0))
+            if not rows:
+                continue
+            if any(fresh) and not all(fresh):
+                raise RuntimeError("HAT_SGD: parameters joined the optimizer after its first step")
+            if self._ws is None or self._ws.numel() < L.clhip_hat_sgd_multi_ws(len(rows)):
+                self._ws = torch.zeros(L.clhip_hat_sgd_multi_ws(len(rows)), dtype=torch.uint8, device=group["params"][0].device)
+            table = (_lib.HatParam * len(rows))(*rows)
+            check(L.clhip_hat_sgd_step_multi(table, len(rows), float(group["lr"]), float(group["momentum"]),
+                                             float(group["weight_decay"]), int(finetune), float(s or 0.0), float(smax or 0.0),
+                                             float(thres_cosh or 0.0), float(clipgrad or 0.0), float(thres_emb or 0.0),
+                                             int(fresh[0]), self._ws.data_ptr(), self._ws.numel(), _stream()),
+                  "clhip_hat_sgd_step_multi")
         return None
 
 

@@ -64,8 +64,7 @@ class _Pass:
                 _, reg, _ = o.hat.step(t, images, targets, s, o.mask_pre, o.lamb, budget, backward=train, stats=self.stats)
                 self.reg += reg.double() * bs
                 if train:
-                    o.optimizer.step(o.model, o.mask_back, t, s, THRES_COSH, o.smax, CLIPGRAD)
-                    H.clamp_embeddings(o.model, float(THRES_EMB))
+                    o.optimizer.step(o.model, o.mask_back, t, s, THRES_COSH, o.smax, CLIPGRAD, thres_emb=float(THRES_EMB))
             seen += bs
         s = self.stats.cpu()
         ce, acc = float(s[0]) / seen, float(s[1]) / seen

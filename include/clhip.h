@@ -246,7 +246,7 @@ int clhip_clamp(float* x, size_t n, float lo, float hi, void* stream);
  * training batch is gates + regulariser sums (1 launch), W' for every layer (1), [the net's own plan], dW / dgate for every
  * gated layer (1), embedding gradients (1), HAT_SGD.step over every parameter incl. the embedding clamp (2).
  *   hat_gates_multi        gate_l = sigmoid(s * emb_row_l); sums2[0] = sum gate*(1-mask_pre), sums2[1] = sum (1-mask_pre)
- *                          (written, not accumulated; sums2 may be NULL)
+ *                          and sums2[2] = their ratio (3 doubles, written, not accumulated; sums2 may be NULL)
  *   hat_scale_weights_multi  out = w * gate_in[c] per layer (gate_in NULL => copy: biases, the first layer)
  *   hat_weight_grads_multi   in place: dgate_in[c] = sum_{k,r} g*w ; g *= gate_in[c]
  *   hat_emb_grads_multi      demb[rows][n] = 0 except row t = (dgate + lamb/count*(1-mask_pre)) * s*a*(1-a); count <= 0 reads

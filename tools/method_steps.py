@@ -49,8 +49,7 @@ else:
         count = float(sum(float((1 - mp).sum().item()) for mp in mask_pre))
         def step():
             hat.step(1, x, y, 400.0, mask_pre, 2.5, count, backward=True)
-            opt.step(hn, mask_back, 1, 400.0, 50, 800.0, 10000)
-            H.clamp_embeddings(hn, 6.0)
+            opt.step(hn, mask_back, 1, 400.0, 50, 800.0, 10000, thres_emb=6.0)
 for _ in range(2):
     step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
