@@ -42,6 +42,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+PEAK_HBM_TBPS = 8.0            # MI355X_MICROARCH.md: HBM3E
 SMALL = [64, "M", 64, "M", 64, 64, "M", 128, 128, "M"]
 
 
@@ -89,7 +90,9 @@ def parse():
     ap.add_argument("--kernel-iters", type=int, default=20)
     ap.add_argument("--config-steps", type=int, default=8, help="timed steps per entry of the `configs` object")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` object (BASELINE configs 3-5)")
-    ap.add_argument("--no-sweep", action="store_true", help="skip the bounded GPU / CPU sweep pair")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the full 10-task EWC sweep and its GPU / CPU pair")
+    ap.add_argument("--sweep-tasks", type=int, default=10)
+    ap.add_argument("--sweep-epochs", type=int, default=70)
     return ap.parse_args()
 
 
@@ -248,6 +251,79 @@ def module_flops_per_image(model, hw):
     return fwd, 3 * fwd - first
 
 
+def hbm_kernels(dev, n=57_823_240, iters=10):
+    """The HBM-bound regulariser / optimizer / gradient-memory kernels on an AlexNet-sized parameter arena (57.8 M floats:
+    BASELINE configs[3]'s model; on the 0.6-9 M-parameter VGG9s the same launches are latency-bound): achieved TB/s =
+    algorithmic bytes per parameter (SURVEY 8d / DESIGN 4) x n / HIP-event time, and its fraction of the 8 TB/s HBM3E peak
+    (MI355X_MICROARCH.md)."""
+    import ctypes as C
+    from clsurvey_amd import _lib, ops
+    from clsurvey_amd.methods import packnet as PK
+    t = {k: torch.rand(n, device=dev) * 1e-2 for k in ("theta", "grad", "omega", "init", "buf", "w", "out")}
+    G = torch.randn((6, n), device=dev)
+    mask = torch.randint(1, 3, (n,), device=dev, dtype=torch.int64).to(torch.uint8)
+    L = _lib.lib()
+    ws = torch.zeros(L.clhip_gem_gram_ws(16), dtype=torch.uint8, device=dev)
+    gram = torch.zeros(256, dtype=torch.float64, device=dev)
+    rows5 = (C.c_int * 5)(0, 1, 2, 3, 4)
+    v5 = (C.c_float * 5)(0.5, 1.0, -0.5, 0.25, 2.0)
+    st = torch.cuda.current_stream().cuda_stream
+    cases = [
+        ("reg_sgd_step", "EWC / MAS Weight_Regularized_SGD.step (train_EWC.py:23-86)", 28,
+         lambda: ops.reg_sgd_step(t["theta"], t["grad"], t["omega"], t["init"], t["buf"], 400.0, 1e-3, 0.9, 0.0, False)),
+        ("fisher_accum", "diag_fisher Omega += g^2 / len (main_EWC.py:155)", 12, lambda: ops.fisher_accum(t["omega"], t["grad"], 8000.0)),
+        ("mas_accum", "MAS Omega running mean of |g| (train_MAS.py:167-173)", 12, lambda: ops.mas_accum(t["omega"], t["grad"], 3, 200)),
+        ("si_step", "Elastic_SGD.step + path integral (train_SI.py:28-126)", 36,
+         lambda: ops.si_step(t["theta"], t["grad"], t["omega"], t["init"], t["w"], t["buf"], 400.0, 1e-3, 0.9, 0.0, False)),
+        ("si_consolidate", "update_reg_params (train_SI.py:301-364)", 28, lambda: ops.si_consolidate(t["omega"], t["w"], t["theta"], t["init"])),
+        ("packnet_sgd_step", "PackNet do_batch tail: foreign grads -> 0, PacknetSGD, pruned -> 0 (packnet/main.py:187-193)", 25,
+         lambda: PK.fused_batch_tail(t["theta"], t["grad"], t["buf"], mask, 2, 1e-3, 0.9, 0.0, False)),
+        ("gem_store_grad", "GEM store_grad: G[t] = g (gem.py:38-55)", 8,
+         lambda: L.clhip_axpy(G[5].data_ptr(), t["grad"].data_ptr(), n, C.c_float(1.0), 1, st)),
+        ("gem_gram", "GEM Gram of 5 gradient rows, f64, one pass (gem.py:275-277 + QP inputs)", 20,
+         lambda: L.clhip_gem_gram(G.data_ptr(), n, rows5, 5, n, gram.data_ptr(), ws.data_ptr(), ws.numel(), st)),
+        ("gem_project", "GEM projection g + sum v_i G_i, 5 rows (gem.py:78-79)", 28,
+         lambda: L.clhip_gem_project(G.data_ptr(), n, rows5, v5, 5, t["grad"].data_ptr(), t["out"].data_ptr(), n, st)),
+    ]
+    out = []
+    for name, what, bpp, fn in cases:
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / iters
+        out.append({"kernel": name, "what": what, "n_params": n, "algorithmic_bytes_per_param": bpp, "us": us,
+                    "achieved_TBps": bpp * n / us / 1e6, "frac_of_hbm_peak": bpp * n / us / 1e6 / PEAK_HBM_TBPS})
+    return out
+
+
+def conv_backward_roofline(dev, N, iters=5):
+    """north_star: '>= 40 % MFMA utilisation on the VGG conv backward'.  Per VGG9 width: every backward launch of one pass
+    (backward-data and weight-gradient slabs, as the plan executor issues them) timed with HIP events; the dominant one
+    and the whole backward as fractions of the fp32-MFMA peak."""
+    from clsurvey_amd import models, net
+    out = {}
+    x = torch.randn((N, 3, 64, 64), device=dev)
+    for name, model_name in (("small_VGG9", "small_VGG9_cl_128_128"), ("base_VGG9", "base_VGG9_cl_512_512"),
+                             ("wide_VGG9", "wide_VGG9_cl_512_512")):
+        eng = net.NetEngine(models.parse_model_name(model_name, (64, 64), 20), N, (3, 64, 64), dev)
+        rows = [r for r in time_kernels(eng, x, N, iters) if "bwd" in r["kernel"]]
+        dom = max(rows, key=lambda r: r["sec"])
+        fl, sec = sum(r["flops"] for r in rows), sum(r["sec"] for r in rows)
+        out[name] = {"dominant_backward_launch": "%s, layer %s [%s]" % (dom["kernel"], dom["layer"], dom["instance"]),
+                     "dominant_us": dom["sec"] * 1e6, "dominant_tflops": dom["flops"] / dom["sec"] / 1e12,
+                     "dominant_frac_of_f32_mfma_peak": dom["flops"] / dom["sec"] / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                     "all_backward_launches_us": sec * 1e6, "all_backward_tflops": fl / sec / 1e12,
+                     "all_backward_frac_of_f32_mfma_peak": fl / sec / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                     "worst_backward_launch_frac": min(r["flops"] / r["sec"] / 1e12 / PEAK_F32_MFMA_TFLOPS for r in rows)}
+        del eng
+    return out
+
+
 def extra_configs(dev, N, steps):
     """BASELINE.json configs 3-5 on this GPU: a short loop of each config's own hot path (inputs resident in HBM).
     TFLOP/s = algorithmic FLOPs of the step (train / importance pass = 3 x forward - first-layer backward-data) / time."""
@@ -344,60 +420,192 @@ def extra_configs(dev, N, steps):
             ms, imgs, imgs * step_fl,
             "GEM observe (%d memory passes of %d exemplars + the batch of %d, Gram, QP, projection, SGD), AlexNet 224x224" % (past, mem, nb))
     out["alexnet_mflop_per_image_fwd"] = fwd_fl / 1e6
+    del gem, m, x
+    torch.cuda.empty_cache()
+    out["hbm_kernels"] = hbm_kernels(dev)
+    torch.cuda.empty_cache()
+    out["conv_backward"] = conv_backward_roofline(dev, N)
     return out
 
 
-def bounded_sweep(dev_index, cpu_threads, sizes=(1600, 400, 400), epochs=2, lr_grid="1e-2,1e-3"):
-    """BASELINE.json's 'full-sweep wall-clock' on a bounded 2-task EWC sweep at Tiny-ImageNet image shape (3x64x64, 20
-    classes per task): what framework/main.py runs for `small_VGG9_cl_128_128 --method_name EWC --test` (phase-1 LR grid,
-    stability decay with the Fisher pass, evaluation of every model on every task) starting from the shared first-task
-    model — once through the build's driver on the GPU, once through the SAME driver with the CPU oracle's EWC method
-    (oracle/sweep_ref.py) on the host cores.  Task files, grid, epoch cap, batch size and decay rule are identical; the
-    first-task model is trained once on the GPU outside both timed regions and given to both."""
+class _PassCounter:
+    """Counts the images every DeviceLoader hands out while active, split by loader size: the training split (and the
+    Fisher pass over the previous task's training split) is forward + backward, everything smaller is forward only."""
+
+    def __init__(self, n_train):
+        from clsurvey_amd import data as D
+        self.D, self.n_train, self.counts = D, n_train, {"train": 0, "eval": 0}
+        self._orig = D.DeviceLoader.__iter__
+
+    def __enter__(self):
+        orig, counts, n_train = self._orig, self.counts, self.n_train
+
+        def counting(loader):
+            for x, y in orig(loader):
+                counts["train" if loader.n >= n_train else "eval"] += x.shape[0]
+                yield x, y
+        self.D.DeviceLoader.__iter__ = counting
+        return self.counts
+
+    def __exit__(self, *exc):
+        self.D.DeviceLoader.__iter__ = self._orig
+
+
+def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epochs=70,
+               pair_sizes=(4000, 1000, 500), pair_epochs=2):
+    """BASELINE.json's second metric ('full-sweep wall-clock'), two measurements.
+
+    `gpu_s`: what framework/main.py runs for `small_VGG9_cl_128_128 --method_name EWC --test` with the reference's defaults
+    (5-value LR grid, 70-epoch cap with the count-based LR drop / early stop, batch 200, drop margin 0.2, decay 0.5, up to
+    10 attempts per task) on a `tasks`-task sequence of Tiny-ImageNet's shape (20 classes, 8000 / 2000 / 1000 images of
+    3x64x64 per task; learnable class prototypes + noise, there is no dataset on the box), through the build's driver on
+    this GPU: SI first-task model (main.py:226-241), then per task phase-1 LR grid, Fisher pass, stability decay, and at the
+    end every model evaluated on every task (eval.py:146-247).  Measured end to end, task files already written.
+
+    `pair`: the SAME bounded piece of that sweep run on both sides with the decisions fixed — one task of
+    `pair_sizes` images from the first-task model the GPU trained (outside both timed regions), ONE learning rate, a
+    `pair_epochs`-epoch cap, exactly one stability-decay attempt, evaluation of both models: build's driver + HIP path on
+    the GPU, the same driver + the CPU oracle's EWC (oracle/sweep_ref.py) on the host cores.  Same task files, same start
+    model, same seeds; accuracies of both sides are reported next to each other.
+
+    `cpu_s_extrapolated`: the CPU leg of the pair timed its forward+backward+update loops and its forward-only loops
+    separately; the GPU sweep's counted image passes of each kind are priced at those two measured host rates.  It is an
+    extrapolation and says so; `pair.cpu_s / pair.gpu_s` is the measured like-for-like ratio."""
     import contextlib
     import io
     import shutil
     import tempfile
     from clsurvey_amd.framework import driver
+    from clsurvey_amd.framework.tasks import SyntheticTaskSequence
     from clsurvey_amd.methods import method as M
     root = tempfile.mkdtemp(prefix="clhip_sweep_")
-    spec = "2,20,%d,%d,%d,64" % sizes
-    common = ["small_VGG9_cl_128_128", "--lr_grid", lr_grid, "--num_epochs", str(epochs), "--batch_size", "200",
-              "--saving_freq", "1000", "--synthetic", spec, "--device", "cuda:%d" % dev_index]
-    res = {"what": "2-task EWC sweep, small_VGG9_cl_128_128, %d/%d/%d images of 3x64x64 per task, LR grid {%s}, %d-epoch cap, "
-                   "batch 200, --test" % (sizes + (lr_grid, epochs))}
+    model = "small_VGG9_cl_128_128"
+    res = {"what": "%d-task EWC sweep, %s, %d/%d/%d images of 3x64x64 per task, 20 classes, the reference's defaults "
+                   "(LR grid {1e-2,5e-3,1e-3,5e-4,1e-4}, %d-epoch cap, batch 200, drop margin 0.2, --test)"
+                   % ((tasks, model) + tuple(sizes) + (epochs,))}
     quiet = io.StringIO()
     try:
+        # ---- the full sweep on the GPU
         groot = os.path.join(root, "gpu")
-        with contextlib.redirect_stdout(quiet):
-            driver.main(common + ["--results_root", groot, "--method_name", "SI", "--runmode", "first_task_basemodel_dump"],
-                        method=M.parse("SI"))
+        ds = SyntheticTaskSequence(os.path.join(groot, "data"), task_count=tasks, classes_per_task=20, sizes=tuple(sizes), hw=64,
+                                   name="synthetic_tiny_imagenet")
+        t0 = time.perf_counter()
+        for i in range(1, tasks + 1):
+            ds.get_task_dataset_path(str(i))
+        res["task_files_s (not counted)"] = time.perf_counter() - t0
+        common = [model, "--num_epochs", str(epochs), "--results_root", groot, "--device", "cuda:%d" % dev_index]
+        with contextlib.redirect_stdout(quiet), _PassCounter(sizes[0]) as counts:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            out = driver.main(common + ["--results_root", groot, "--method_name", "EWC", "--test"], method=M.parse("EWC"))
+            driver.main(common + ["--method_name", "SI", "--runmode", "first_task_basemodel_dump"], method=M.parse("SI"), dataset=ds)
+            torch.cuda.synchronize()
+            res["gpu_first_task_s"] = time.perf_counter() - t0
+            out = driver.main(common + ["--method_name", "EWC", "--test"], method=M.parse("EWC"), dataset=ds)
             torch.cuda.synchronize()
             res["gpu_s"] = time.perf_counter() - t0
-        res["gpu_attempts"] = out["frameworks"][-1].attempts + 1
-        res["gpu_task_accuracies"] = [out["results"][i]["seq_res"][i][-1] for i in sorted(out["results"])]
+        r = out["results"]
+        res["gpu_image_passes"] = dict(counts)
+        res["gpu_attempts_per_task"] = [hf.attempts + 1 for hf in out["frameworks"] if hf is not None]
+        res["gpu_final_accuracies"] = [r[i]["seq_res"][i][-1] for i in sorted(r)]          # task i under the LAST model
+        res["gpu_first_accuracies"] = [r[i]["seq_res"][i][0] for i in sorted(r)]           # task i right after training it
+        res["gpu_avg_accuracy"] = float(np.mean(res["gpu_final_accuracies"]))
+        res["gpu_avg_forgetting"] = float(np.mean([r[i]["seq_forgetting"][i][-1] for i in sorted(r) if r[i]["seq_forgetting"][i]] or [0.0]))
+        res["chance_accuracy"] = 100.0 / 20
+        # ---- the like-for-like pair
         if cpu_threads:
             from oracle import sweep_ref
-            croot = os.path.join(root, "cpu")
+            proot, croot = os.path.join(root, "pair_gpu"), os.path.join(root, "pair_cpu")
+            spec = "2,20,%d,%d,%d,64" % tuple(pair_sizes)
+            pcommon = [model, "--num_epochs", str(pair_epochs), "--batch_size", "200", "--saving_freq", "1000", "--synthetic", spec,
+                       "--device", "cuda:%d" % dev_index]
+            with contextlib.redirect_stdout(quiet):
+                # first-task model of the pair's own sequence: trained on the GPU to convergence, outside both timed regions
+                driver.main([model, "--num_epochs", str(epochs), "--synthetic", spec, "--device", "cuda:%d" % dev_index,
+                             "--results_root", proot, "--method_name", "SI", "--runmode", "first_task_basemodel_dump"],
+                            method=M.parse("SI"))
+            # the first-task model's directory name carries the epoch cap and the LR grid (models/net.py:39-53): file it under
+            # the name the pair's own arguments produce
+            from types import SimpleNamespace
+            si_dir = os.path.join(proot, "train", "synthetic_tiny_imagenet", "SI", model, "gridsearch", "first_task_basemodel")
+            (trained_as,) = os.listdir(si_dir)
+            os.rename(os.path.join(si_dir, trained_as), os.path.join(si_dir, driver.first_task_modelname(SimpleNamespace(
+                num_epochs=pair_epochs, batch_size=200, lr_grid=[1e-2], weight_decay=0, model_name=model))))
+            fixed = ["--lr_grid", "1e-2", "--max_attempts_per_task", "1", "--method_name", "EWC", "--test"]
+            pair = {"what": "task 2 of a 2-task sequence (%d/%d/%d images), from the same first-task model: LR grid {1e-2}, %d-epoch "
+                            "cap, Fisher pass, ONE stability-decay attempt (kept whatever it scores), both models evaluated"
+                            % (tuple(pair_sizes) + (pair_epochs,))}
             for sub in ("data", "models", os.path.join("train", "synthetic_tiny_imagenet", "SI")):
-                shutil.copytree(os.path.join(groot, sub), os.path.join(croot, sub))
+                shutil.copytree(os.path.join(proot, sub), os.path.join(croot, sub))
+            with contextlib.redirect_stdout(quiet), _PassCounter(pair_sizes[0]) as pcounts:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                gout = driver.main(pcommon + fixed + ["--results_root", proot], method=M.parse("EWC"))
+                torch.cuda.synchronize()
+                pair["gpu_s"] = time.perf_counter() - t0
+            pair["gpu_image_passes"] = dict(pcounts)
+            pair["gpu_accuracies"] = {i: gout["results"][i]["seq_res"][i] for i in sorted(gout["results"])}
             torch.set_num_threads(cpu_threads)      # the thread count that won cpu_baseline's probe on this host
             meth = sweep_ref.OracleEWC("small_VGG9")
             with contextlib.redirect_stdout(quiet):
                 t0 = time.perf_counter()
-                cout = driver.main(common + ["--results_root", croot, "--method_name", "EWC", "--test"], method=meth)
-                res["cpu_s"] = time.perf_counter() - t0
-            res["cpu_attempts"] = cout["frameworks"][-1].attempts + 1
-            res["cpu_image_passes"] = dict(meth.image_passes)
-            res["cpu_task_accuracies"] = [cout["results"][i]["seq_res"][i][-1] for i in sorted(cout["results"])]
-            res["cpu_threads"] = torch.get_num_threads()
-            res["gpu_over_cpu_wall_clock"] = res["cpu_s"] / res["gpu_s"]
+                cout = driver.main(pcommon + fixed + ["--results_root", croot], method=meth)
+                pair["cpu_s"] = time.perf_counter() - t0
+            pair["cpu_image_passes"] = dict(meth.image_passes)
+            pair["cpu_accuracies"] = {i: cout["results"][i]["seq_res"][i] for i in sorted(cout["results"])}
+            pair["cpu_threads"] = torch.get_num_threads()
+            pair["attempts"] = {"gpu": gout["frameworks"][-1].attempts + 1, "cpu": cout["frameworks"][-1].attempts + 1}
+            pair["max_accuracy_gap_points"] = max(abs(a - b) for i in pair["gpu_accuracies"]
+                                                  for a, b in zip(pair["gpu_accuracies"][i], pair["cpu_accuracies"][i]))
+            pair["gpu_over_cpu_wall_clock"] = pair["cpu_s"] / pair["gpu_s"]
+            res["pair"] = pair
+            tr_rate = meth.image_passes["train"] / max(meth.seconds["train"], 1e-9)
+            ev_rate = meth.image_passes["eval"] / max(meth.seconds["eval"], 1e-9)
+            res["cpu_rates_images_per_s"] = {"forward_backward_update": tr_rate, "forward_only": ev_rate}
+            res["cpu_s_extrapolated"] = counts["train"] / tr_rate + counts["eval"] / ev_rate
+            res["cpu_s_extrapolated_how"] = ("GPU sweep's image passes (%d forward+backward, %d forward-only) at the two host rates "
+                                             "the pair's CPU leg measured on this box; not run" % (counts["train"], counts["eval"]))
+            res["gpu_over_cpu_wall_clock"] = res["cpu_s_extrapolated"] / res["gpu_s"]
     finally:
         shutil.rmtree(root, ignore_errors=True)
     return res
+
+
+def sharded_sweep(dev_index, world, epochs=3, sizes=(2000, 500, 500)):
+    """N > 1: SURVEY 8(e) as the build runs it — `driver.main(... --shard)` on a bounded 2-task EWC sequence: phase-1 grid
+    nodes spread over the ranks (all_gather of accuracies, winner's model files broadcast from the rank that trained it),
+    speculative stability decay (one attempt per rank in flight, accepted attempt's files broadcast), evaluation pairs
+    spread over the ranks (all_gather).  Every rank calls this; returns {seconds, nodes, fill factor, collective traffic of
+    this rank} — models and metrics only, nothing on the per-batch path."""
+    import contextlib
+    import io
+    import shutil
+    import tempfile
+    from clsurvey_amd.framework import driver, shard
+    from clsurvey_amd.methods import method as M
+    root = tempfile.mkdtemp(prefix="clhip_shard_")
+    spec = "2,20,%d,%d,%d,64" % tuple(sizes)
+    common = ["small_VGG9_cl_128_128", "--num_epochs", str(epochs), "--synthetic", spec, "--device", "cuda:%d" % dev_index,
+              "--results_root", root, "--shard"]
+    before = dict(shard.STATS)
+    quiet = io.StringIO()
+    try:
+        with contextlib.redirect_stdout(quiet):
+            shard.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            driver.main(common + ["--method_name", "SI", "--runmode", "first_task_basemodel_dump"], method=M.parse("SI"))
+            out = driver.main(common + ["--method_name", "EWC", "--test"], method=M.parse("EWC"))
+            torch.cuda.synchronize()
+            shard.barrier()
+            dt = time.perf_counter() - t0
+        hf = out["frameworks"][-1]
+        return {"what": "driver.main --shard: SI first-task grid + EWC task 2 (5-LR grid, speculative stability decay, sharded "
+                        "evaluation), %d/%d/%d images per task, %d-epoch cap" % (tuple(sizes) + (epochs,)),
+                "seconds": dt, "grid_nodes_per_task": 5, "fill_factor": shard.fill_factor(5, world),
+                "attempts_task2": hf.attempts + 1, "accuracies": {i: r["seq_res"][i] for i, r in sorted(out["results"].items())},
+                "collectives_this_rank": {k: shard.STATS[k] - before[k] for k in shard.STATS}}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def host_cpu():
@@ -600,6 +808,9 @@ def main():
     }
     if grid is not None:
         out["grid"] = grid
+    if dist and not args.no_sweep:
+        # second number of the N > 1 line: the sharded framework itself on a bounded task sequence (every rank takes part)
+        out["grid"]["sharded_driver"] = sharded_sweep(local_rank, world)
     if rank == 0:
         rows = time_kernels(eng, data_x[:N].contiguous(), N, args.kernel_iters)
         agg = {}
@@ -636,8 +847,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(N, args.cpu_steps)
             out["config"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         if world == 1 and not args.no_sweep:
-            out["sweep"] = bounded_sweep(local_rank, cpu_threads=0 if args.no_cpu_baseline else out["cpu_baseline"]["cores"])
-            out["sweep_s"] = {"gpu": out["sweep"].get("gpu_s"), "cpu": out["sweep"].get("cpu_s")}      # same bounded sweep, both sides
+            out["sweep"] = full_sweep(local_rank, cpu_threads=0 if args.no_cpu_baseline else out["cpu_baseline"]["cores"],
+                                      tasks=args.sweep_tasks, epochs=args.sweep_epochs)
+            out["sweep_s"] = {"gpu": out["sweep"].get("gpu_s"), "cpu_extrapolated": out["sweep"].get("cpu_s_extrapolated"),
+                              "pair_gpu": out["sweep"].get("pair", {}).get("gpu_s"), "pair_cpu": out["sweep"].get("pair", {}).get("cpu_s")}
         print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()          # rank 0 was still timing kernels: tear the communicator down together

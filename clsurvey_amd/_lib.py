@@ -126,10 +126,6 @@ SIGNATURES = {
     "clhip_net_forward": (_i, [_p, _p, _p, _i, _p, _p, _p]),
     "clhip_net_backward": (_i, [_p, _p, _p, _p, _i, _p, _p, _p]),
     "clhip_net_loss_step": (_i, [_p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p]),
-    "clhip_dbg_conv3x3_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
-    "clhip_dbg_conv3x3_bwd_data": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
-    "clhip_dbg_conv3x3_bwd_weight": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
-    "clhip_dbg_mfma_probe": (_i, [_p, _p]),
 }
 
 _lib = None

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libclhip.so")
 SOURCES = ["elementwise.hip", "loss.hip", "pool.hip", "conv3x3.hip", "conv3x3_wgrad.hip", "conv2d.hip", "bn.hip", "gemm.hip", "fc_chain.hip",
-           "packnet.hip", "hat.hip", "gem.hip", "engine.hip", "debug_naive.hip"]
+           "packnet.hip", "hat.hip", "gem.hip", "engine.hip"]
 # -pragma-unroll-threshold: the software-pipelined conv loops are fully unrolled by `#pragma unroll` (one piece of
 # staging work per MFMA slot, all register-array indices constant); at the default threshold hipcc silently stops
 # unrolling the largest instance and its operand registers land in scratch / LDS.
@@ -60,6 +60,27 @@ def build(force=False, verbose=True):
     return OUT
 
 
+TEST_LIB_SRC = os.path.join(HERE, "..", "tests", "csrc", "debug_naive.hip")
+TEST_LIB = os.path.join(HERE, "..", "tests", "libclhip_dbg.so")
+
+
+def build_test_lib(force=False, verbose=True):
+    """tests/libclhip_dbg.so: the naive triage kernels and the MFMA fragment probe of tests/csrc/debug_naive.hip — test
+    infrastructure, deliberately not linked into the product library."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    stamp = TEST_LIB + ".sha256"
+    want = _fingerprint([TEST_LIB_SRC, os.path.join(CSRC, "common.hpp"), os.path.join(HERE, "..", "include", "clhip.h")], FLAGS)
+    have = open(stamp).read().strip() if os.path.exists(stamp) and os.path.exists(TEST_LIB) else ""
+    if force or have != want:
+        cmd = [hipcc] + FLAGS + ["-shared", "-o", TEST_LIB, TEST_LIB_SRC]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        with open(stamp, "w") as f:
+            f.write(want + "\n")
+    return TEST_LIB
+
+
 def build_variant(name, src, defines, verbose=True):
     """Experimental variant: recompile ONE source with extra -D flags and link libclhip_<name>.so.
     Selected at run time with CLHIP_LIB=<path> (tools/ only; the product always loads libclhip.so)."""
@@ -84,3 +105,4 @@ def build_variant(name, src, defines, verbose=True):
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    build_test_lib(force="--force" in sys.argv)

@@ -71,7 +71,8 @@ def build_parser():
     p.add_argument("--shard", action="store_true",
                    help="one process per GPU (torch.distributed.run): grid nodes, decay attempts and evaluations are "
                         "spread over the ranks; each rank writes under <results_root>/rank<r>")
-    p.add_argument("--no_speculation", action="store_true", help="with --shard: keep phase 2 sequential on every rank")
+    p.add_argument("--no_speculation", action="store_true",
+                   help="with --shard: phase 2 runs sequentially on rank 0 only; its model and state are broadcast")
     p.add_argument("--synthetic", type=str, default=None,
                    help="command-line runs: tasks,classes,train,val,test,hw of a synthetic task sequence "
                         "(clsurvey_amd.framework.tasks), e.g. 10,20,8000,2000,1000,64 = Tiny-ImageNet's shape")
@@ -166,6 +167,8 @@ def lr_grid_single_task(args, manager, save_models_mode="keep_none", train_node=
     grid_checkpoint_file = os.path.join(manager.ft_parent_exp_dir, "grid_checkpoint.pth")
     if os.path.exists(grid_checkpoint_file):
         processed_lrs = torch.load(grid_checkpoint_file, weights_only=False)["processed_lrs"]
+    if getattr(manager, "sync_processed", None) is not None:       # sharded grid: one table of finished nodes for all ranks
+        processed_lrs = manager.sync_processed(processed_lrs)
     args.presteps_elapsed_time = 0
     if hasattr(manager.method, "grid_prestep"):
         manager.method.grid_prestep(args, manager)
@@ -282,6 +285,9 @@ class HyperparameterFramework(object):
             return
         args.presteps_elapsed_time = 0
         sharded = getattr(manager, "speculative", False)
+        if getattr(manager, "sequential_on_rank0", False):
+            self._sequential_on_rank0(args, manager, finetune_acc)
+            return
         if hasattr(manager.method, "prestep"):
             if sharded:
                 self._prestep_on_rank0(args, manager)
@@ -290,6 +296,10 @@ class HyperparameterFramework(object):
         if sharded:
             self._speculative_decay(args, manager, finetune_acc)
             return
+        self._sequential_decay(args, manager, finetune_acc)
+
+    def _sequential_decay(self, args, manager, finetune_acc):
+        """framework_train.py:100-136."""
         max_attempts = args.max_attempts_per_task
         converged = False
         while not converged and self.attempts < max_attempts:
@@ -318,6 +328,39 @@ class HyperparameterFramework(object):
         manager.best_model_path = os.path.join(manager.heuristic_exp_dir, "best_model.pth.tar")
         manager.create_success_token(manager.heuristic_exp_dir)
 
+    def _sequential_on_rank0(self, args, manager, finetune_acc):
+        """--shard --no_speculation: prestep and the sequential phase 2 run on rank 0 ONLY; its task directory (model,
+        hyperparams, success token) and the framework state are then broadcast, so every rank enters the next task's
+        sharded grid from the same model and the same hyper-parameters."""
+        from . import shard
+        rank, _ = shard.rank_world()
+        err = None
+        if rank == 0:
+            try:
+                if hasattr(manager.method, "prestep"):
+                    manager.method.prestep(args, manager)
+                self._sequential_decay(args, manager, finetune_acc)
+            except BaseException as e:                   # incl. the SystemExit of a failed training: reported collectively
+                traceback.print_exc()
+                err = e
+        shard.all_ok(err is None, "sequential phase 2 on rank 0")
+        if rank != 0:
+            shutil.rmtree(manager.heuristic_exp_dir, ignore_errors=True)
+        shard.broadcast_files(manager.heuristic_exp_dir, 0)
+        state = shard.broadcast_object({"state": self._get_state(), "trace": self.trace,
+                                        "autoencoder": (os.path.relpath(manager.autoencoder_model_path, manager.parent_exp_dir)
+                                                        if manager.autoencoder_model_path else None)} if rank == 0 else None, 0)
+        if rank != 0:
+            self._restore_state(state["state"])
+            self.trace = state["trace"]
+            if state["autoencoder"]:
+                manager.autoencoder_model_path = os.path.join(manager.parent_exp_dir, state["autoencoder"])
+                shard.broadcast_files(os.path.dirname(manager.autoencoder_model_path), 0)
+        elif state["autoencoder"]:
+            shard.broadcast_files(os.path.dirname(manager.autoencoder_model_path), 0)
+        manager.method.hyperparams = self.hyperparams
+        manager.best_model_path = os.path.join(manager.heuristic_exp_dir, "best_model.pth.tar")
+
     @staticmethod
     def _prestep_on_rank0(args, manager):
         """A prestep trains something of its own (EBLL: the autoencoder grid on the previous task) and publishes it as
@@ -339,7 +382,7 @@ class HyperparameterFramework(object):
         hyperparams.pth.tar in the state the sequential loop reaches when the same attempts succeed / fail."""
         from . import shard
         threshold = finetune_acc * args.inv_drop_margin
-        while True:
+        while self.attempts < args.max_attempts_per_task:      # (a checkpoint restored at the attempt limit trains nothing more)
             t0 = time.time()
             accs, accepted = shard.speculative_round(self, args, manager, finetune_acc)
             upto = accepted if accepted is not None else max(accs)
@@ -479,8 +522,20 @@ def eval_all_models_all_tasks(args, manager, ds_paths, model_paths):
                 break
             out[dataset_index] = save(dataset_index, seq_acc, seq_forgetting)
         return out
-    # sharded: every (task, model) pair is independent work; a failing evaluation stops the run on its rank
-    table = {n: evaluate(*pq) for n, pq in enumerate(pairs) if n % world == rank}
+    # sharded: every (task, model) pair is independent work; a failing evaluation stops the run on EVERY rank
+    if not overwrite and not debug:                                # eval.py:158-162, decided on rank 0's tree for all ranks
+        done = shard.broadcast_object([i for i in tasks if os.path.exists(out_file(i))] if rank == 0 else None, 0)
+        if done:
+            print("EVAL already done, can only rerun in overwrite mode")
+            tasks = [i for i in tasks if i < min(done)]
+            pairs = [(i, j) for i in tasks for j in range(i, len(ds_paths))]
+    table, err = {}, None
+    try:
+        table = {n: evaluate(*pq) for n, pq in enumerate(pairs) if n % world == rank}
+    except Exception as e:
+        traceback.print_exc()
+        err = e
+    shard.all_ok(err is None, "evaluation")
     table = shard.gather_scalars(table)
     acc_of = {pq: table[n] for n, pq in enumerate(pairs)}
     for dataset_index in tasks:
@@ -521,7 +576,7 @@ def first_task_modelname(args):
 
 def main(argv=None, method=None, dataset=None, train_node_factory=None):
     args = build_parser().parse_args(argv)
-    speculative = False
+    speculative = sequential_on_rank0 = False
     if args.shard:
         from . import shard
         rank, world = shard.init_from_env()
@@ -529,6 +584,7 @@ def main(argv=None, method=None, dataset=None, train_node_factory=None):
             args.results_root = os.path.join(args.results_root, "rank%d" % rank)
             train_node_factory = train_node_factory or shard.sharded_grid_factory()
             speculative = not args.no_speculation
+            sequential_on_rank0 = args.no_speculation
     if dataset is None and args.synthetic:
         from .tasks import SyntheticTaskSequence
         n_tasks, n_cls, n_tr, n_va, n_te, hw = [int(v) for v in args.synthetic.split(",")]
@@ -574,9 +630,8 @@ def main(argv=None, method=None, dataset=None, train_node_factory=None):
     elif args.debug:                                            # main.py:269-277
         args.finetune_iterations, args.num_epochs, args.saving_freq = 1, 1, 200
         args.batch_size, args.mem_per_task = 200, 20
-        # (the reference also writes args.lrs = [0.01] here, which its task loop overwrites with the full grid before
-        # anything reads it; the quick go-through it is meant to be runs ONE learning rate in this build)
-        args.lr_grid = args.boot_lr_grid = [0.01]
+        # (the reference also writes args.lrs = [0.01] here, main.py:276, which its task loop overwrites with the full
+        # grid before anything reads it: a reference debug run trains every LR of the grid, and so does this one)
     if hasattr(method, "train_args_overwrite"):
         method.train_args_overwrite(args)
     methods.set_hyperparams(method, args.hyperparams)
@@ -606,6 +661,7 @@ def main(argv=None, method=None, dataset=None, train_node_factory=None):
                             "other methods.\nManually remove model for a new dump:{}".format(dumped))
     manager = Manager(dataset, method, prev, parent_exp_dir, base_model)
     manager.speculative = speculative
+    manager.sequential_on_rank0 = sequential_on_rank0
     ds_paths, model_paths, frameworks = [], [], []
     for task_counter in range(args.starting_task_count, args.max_task_count + 1):
         args.task_counter = task_counter

@@ -30,6 +30,10 @@ import torch
 import torch.distributed as dist
 
 
+# traffic of this process's collectives since import (bench.py --gpus N reports it: models and metrics only)
+STATS = {"broadcast_calls": 0, "broadcast_bytes": 0, "all_gather_calls": 0, "all_gather_bytes": 0, "all_reduce_calls": 0}
+
+
 def rank_world():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
@@ -76,12 +80,14 @@ def gather_scalars(values):
     n = torch.tensor([len(values)], dtype=torch.int64, device=_dev())
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n)
+    STATS["all_gather_calls"] += 2
     m = max(int(c.item()) for c in counts)
     buf = torch.full((max(m, 1), 2), -1.0, dtype=torch.float64, device=_dev())
     for j, (k, v) in enumerate(sorted(values.items())):
         buf[j, 0], buf[j, 1] = float(k), float(v)
     bufs = [torch.zeros_like(buf) for _ in range(world)]
     dist.all_gather(bufs, buf)
+    STATS["all_gather_bytes"] += world * (8 + buf.numel() * 8)
     out = {}
     for b in bufs:
         for k, v in b.cpu().tolist():
@@ -98,6 +104,8 @@ def broadcast_model(model, src=0):
     params = [p.data for p in model.parameters()]
     flat = torch.cat([p.reshape(-1).to(_dev(), torch.float32) for p in params])
     dist.broadcast(flat, src=src)
+    STATS["broadcast_calls"] += 1
+    STATS["broadcast_bytes"] += flat.numel() * 4
     off = 0
     for p in params:
         n = p.numel()
@@ -120,6 +128,8 @@ def broadcast_bytes(payload, src):
         buf = torch.zeros(size, dtype=torch.uint8, device=_dev())
     if size:
         dist.broadcast(buf, src=src)
+    STATS["broadcast_calls"] += 2 if size else 1
+    STATS["broadcast_bytes"] += 8 + size
     return bytes(buf.cpu().numpy().tobytes())
 
 
@@ -161,6 +171,22 @@ def barrier():
         dist.barrier()
 
 
+def all_ok(ok, what=""):
+    """Collective error check behind a sharded stage: every rank reports whether ITS part went through; if any did not,
+    EVERY rank raises (a rank that failed alone would leave the others waiting in the next collective until the
+    communicator times out, with no diagnostic)."""
+    rank, world = rank_world()
+    if world > 1:
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=_dev())
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        STATS["all_reduce_calls"] += 1
+        everyone = bool(int(flag.item()))
+    else:
+        everyone = bool(ok)
+    if not everyone:
+        raise RuntimeError("sharded stage failed on %s%s" % ("this rank" if not ok else "another rank", (": " + what) if what else ""))
+
+
 # ------------------------------------------------------------------------------------------------ phase 1
 def sharded_grid_factory():
     """train_node factory for driver.main(): every rank trains the grid nodes assigned to it, the accuracies are
@@ -180,15 +206,21 @@ def sharded_grid_factory():
             return os.path.join(manager.ft_parent_exp_dir, d)
 
         def run_all():
-            mine = {}
-            for i, (lr, it) in enumerate(nodes):
-                if owner[i] != rank:
-                    continue
-                driver.set_random(it)
-                manager.gridsearch_exp_dir = node_dir(lr, it)
-                os.makedirs(manager.gridsearch_exp_dir, exist_ok=True)
-                _, acc = manager.method.grid_train(args, manager, lr)
-                mine[i] = acc
+            mine, err = {}, None
+            try:
+                for i, (lr, it) in enumerate(nodes):
+                    if owner[i] != rank:
+                        continue
+                    driver.set_random(it)
+                    manager.gridsearch_exp_dir = node_dir(lr, it)
+                    os.makedirs(manager.gridsearch_exp_dir, exist_ok=True)
+                    _, acc = manager.method.grid_train(args, manager, lr)
+                    mine[i] = acc
+            except Exception as e:                        # reported collectively below
+                import traceback
+                traceback.print_exc()
+                err = e
+            all_ok(err is None, "phase-1 grid node")
             table.update(gather_scalars(mine))
 
         def train_node(lr, it):
@@ -203,6 +235,9 @@ def sharded_grid_factory():
             src = next(owner[i] for i, (lr, it) in enumerate(nodes) if node_dir(lr, it) == best_dir)
             broadcast_files(best_dir, src)
         manager.after_grid = after_grid
+        # every rank replays the grid over ONE table of finished nodes — rank 0's checkpoint — so that the decision to
+        # train (a collective) is taken by all ranks or by none (a resumed run may hold different checkpoints per rank)
+        manager.sync_processed = lambda processed: broadcast_object(processed, 0)
         manager.grid_fill_factor = fill_factor(len(nodes), world)
         return train_node
     return factory
@@ -227,7 +262,7 @@ def speculative_round(hf, args, manager, finetune_acc):
     from . import driver
     rank, world = rank_world()
     k = hf.attempts + rank
-    mine = {}
+    mine, err = {}, None
     if k < args.max_attempts_per_task:
         twin = decayed_copy(hf, args, manager, rank)
         driver.set_random(1000 * int(args.task_counter) + k)
@@ -236,8 +271,14 @@ def speculative_round(hf, args, manager, finetune_acc):
         shutil.rmtree(manager.heuristic_exp_dir, ignore_errors=True)
         os.makedirs(manager.heuristic_exp_dir, exist_ok=True)
         manager.method.hyperparams = twin.hyperparams
-        _, acc = manager.method.train(args, manager, twin.hyperparams)
-        mine[k] = acc
+        try:
+            _, acc = manager.method.train(args, manager, twin.hyperparams)
+            mine[k] = acc
+        except Exception as e:
+            import traceback
+            traceback.print_exc()
+            err = e
+    all_ok(err is None, "phase-2 attempt %d" % k)
     accs = gather_scalars(mine)
     threshold = finetune_acc * args.inv_drop_margin
     ok = sorted(kk for kk, a in accs.items() if a >= threshold)

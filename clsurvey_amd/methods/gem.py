@@ -4,8 +4,8 @@ fill_buffer / manage_memory) with the exemplar ring buffer held as TENSORS in HB
 The reference stores exemplar *paths* and re-decodes n_memories JPEGs for every past task on every
 training batch (gem.py:233-235); here memory[t] is a device tensor and a past-task pass is
 ceil(n_memories / batch) engine calls.  Gradients of a task are one contiguous row of G (the
-ParamArena gradient is flat), the QP inputs come from ONE Gram-matrix pass, the tiny QP runs on the
-host in float64 (clsurvey_amd.methods.qp, restating quadprog's Goldfarb-Idnani).
+ParamArena gradient is flat), the QP inputs come from ONE Gram-matrix pass and the tiny QP (quadprog's Goldfarb-Idnani)
+runs on the device in float64 (clhip_gem_qp) — no host round trip per batch.
 """
 import copy
 import ctypes as C
@@ -18,7 +18,6 @@ from .._lib import check
 from ..data import DeviceLoader, TensorTaskDataset
 from ..net import NetEngine
 from ..optim import SGD
-from . import qp
 
 
 def _stream():
@@ -73,7 +72,8 @@ class GemNet:
         self._gram = torch.zeros(16 * 16, dtype=torch.float64, device=self.device)
         self._v = torch.zeros(16, dtype=torch.float64, device=self.device)          # QP solution, stays on the device
         self._info = torch.zeros(2, dtype=torch.int32, device=self.device)          # {violated constraints, status}
-        self.qp_on_device = True
+        self._qp_bad = torch.zeros(1, dtype=torch.int32, device=self.device)        # sticky: solves that did not report 'ok'
+        self.host_qp = None          # tests only: a host solver f(gram, t, rows, margin) -> v replaces the device QP
         self.stats = torch.zeros(2, dtype=torch.float64, device=self.device)
 
     def init_setup(self, args=None, lr=None, weight_decay=None, memory_strength=None):
@@ -104,7 +104,7 @@ class GemNet:
         """gem.py:183-186: torch.bernoulli(fill(p_retain)) / p_retain over one sample's features (device generator)."""
         return torch.full((n,), p_retain_unit, dtype=torch.float32, device=self.device).bernoulli_().div_(p_retain_unit)
 
-    _TRANSIENT = ("engine", "A", "G", "_gram_ws", "_gram", "_v", "_info", "stats", "opt", "dropout_masks")
+    _TRANSIENT = ("engine", "A", "G", "_gram_ws", "_gram", "_v", "_info", "_qp_bad", "host_qp", "stats", "opt", "dropout_masks")
 
     def __getstate__(self):
         return {k: v for k, v in self.__dict__.items() if k not in self._TRANSIENT}
@@ -180,7 +180,16 @@ class GemNet:
         check(L.clhip_gem_project_dev(self.G.data_ptr(), self.G.shape[1], idx, self._v.data_ptr(), self._info.data_ptr(), m - 1,
                                       self.G[t].data_ptr(), self.A.grad.data_ptr(), self.A.numel, _stream()),
               "clhip_gem_project_dev")
+        self._qp_bad += self._info[1:2]          # status 1 (iteration limit) / 2 (infeasible) must not pass silently
         return self._info[0].clone()
+
+    def check_qp_status(self):
+        """Raise if any projection since the last call ended without a solution (the reference's quadprog raises in that
+        batch; here the status is a device counter read once per epoch, no synchronisation per batch)."""
+        bad = int(self._qp_bad.item())
+        self._qp_bad.zero_()
+        if bad:
+            raise RuntimeError("GEM: project2cone2's QP reported iteration limit / infeasibility (status sum %d)" % bad)
 
     def project(self, rows, v, t):
         m = len(rows)
@@ -214,15 +223,15 @@ class GemNet:
         if len(self.observed_tasks) > 1:
             self._axpy(self.G[t], assign=True)                       # store_grad (:272)
             rows = list(self.observed_tasks[:-1]) + [t]
-            if self.qp_on_device:
+            if self.host_qp is None:
                 batch_stats["projected_grads"] = [self.project_on_device(rows[:-1], t)]     # device counter, no sync
-            else:                                                     # host cross-check path (tests)
+            else:                                                     # injected host solver (cross-check in the tests)
                 gram = self.gram(rows)
                 dotp = gram[-1, :-1]                                  # g . G_tt (:275-276)
                 viol = int((dotp < 0).sum())
                 if viol != 0:
                     batch_stats["projected_grads"] = [viol]
-                    v = qp.project2cone2_coefficients(gram, len(rows) - 1, list(range(len(rows) - 1)), self.margin)
+                    v = self.host_qp(gram, len(rows) - 1, list(range(len(rows) - 1)), self.margin)
                     self.project(rows[:-1], v, t)                     # project2cone2 + overwrite_grad (:278-283)
         self.opt.step()
         return loss, self.stats[1], batch_stats

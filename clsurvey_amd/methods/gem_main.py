@@ -75,7 +75,13 @@ def train_model(model, args, dset_sizes, resume="", save_models_mode=False, savi
             epoch_acc = float(running_corrects.item()) / dset_sizes[phase]
             print("{} Loss: {:.4f} Acc: {:.4f}".format(phase, epoch_loss, epoch_acc))
             if projected:
-                print("projected_grads = {}".format([int(v) for v in projected]))    # device counters: read once per epoch
+                # one entry per batch, zeros included, as train_rehearsal.py:153-167 prints it; the device counters are
+                # stacked and read ONCE per epoch
+                dev_counts = [v for v in projected if torch.is_tensor(v)]
+                host = iter(torch.stack([v.reshape(()) for v in dev_counts]).cpu().tolist()) if dev_counts else iter(())
+                print("projected_grads = {}".format([int(next(host)) if torch.is_tensor(v) else int(v) for v in projected]))
+                if hasattr(model, "check_qp_status"):
+                    model.check_qp_status()
             if math.isnan(epoch_loss):
                 print("Canceling because Nan LOSS")         # train_rehearsal.py:139-141 (checked per phase here)
                 return model, best_acc

@@ -365,19 +365,6 @@ int clhip_gem_qp(const double* gram_f64, int m, double margin, double eps, doubl
 int clhip_gem_project_dev(const float* G, size_t ld, const int* row_idx_host, const double* v_dev_f64, const int* info_dev,
                           int m, const float* g, float* out, size_t n, void* stream);
 
-/* ------------------------------------------------------------------ debug reference kernels
- * Direct (one thread per output, no MFMA/LDS) convolutions used only by tests to triage the
- * MFMA kernels on the device.  Same signatures as the production entry points.              */
-int clhip_dbg_conv3x3_fwd(const float* x, const float* w, const float* b, float* y,
-                          int N, int C, int K, int H, int W, int relu, void* stream);
-int clhip_dbg_conv3x3_bwd_data(const float* dy, const float* w, const float* relu_src, float* dx,
-                               int N, int C, int K, int H, int W, void* stream);
-int clhip_dbg_conv3x3_bwd_weight(const float* x, const float* dy, float* dw, float* db,
-                                 int N, int C, int K, int H, int W, void* stream);
-/* MFMA fragment-layout probe: out[2][32][32]: D of the 32x32x2 f32 MFMA for rank-1 A,B patterns per k slice,
- * stored through the documented fragment map (see csrc/debug_naive.hip).                   */
-int clhip_dbg_mfma_probe(float* out_2048, void* stream);
-
 #ifdef __cplusplus
 }
 #endif

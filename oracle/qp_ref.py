@@ -1,4 +1,5 @@
-"""Goldfarb-Idnani dual active-set solver for the small strictly convex QP of GEM.
+"""TEST INFRASTRUCTURE ONLY (never imported by the product: the product solves this QP on the device, clhip_gem_qp) —
+Goldfarb-Idnani dual active-set solver for the small strictly convex QP of GEM, host float64.
 
 The reference calls quadprog.solve_qp(P, q, G, h) (quadprog==0.1.6, not vendored; call site
 rehearsal/model/gem.py:78), which implements D. Goldfarb & A. Idnani, "A numerically stable dual method

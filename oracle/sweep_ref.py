@@ -10,6 +10,7 @@ The pickled artefacts are plain nn.Modules of standard torch layers (the wire fo
 the first-task model written by the GPU run is a valid starting point here.
 """
 import os
+import time
 from collections import OrderedDict
 
 import torch
@@ -47,6 +48,7 @@ class OracleEWC:
         self.hyperparams = OrderedDict([("lambda", 400)])
         self.cfg = vgg_ref.CFGS[cfg_name]
         self.image_passes = {"train": 0, "eval": 0}
+        self.seconds = {"train": 0.0, "eval": 0.0}           # host seconds spent in forward+backward+update / forward-only loops
 
     # ------------------------------------------------------------------ shared epoch loop
     def _fit(self, model, params, omega, init, lam, lr, dsets, args, exp_dir):
@@ -58,6 +60,7 @@ class OracleEWC:
                 break
             if count == 5:
                 lr *= 0.1
+            t0 = time.perf_counter()
             for x, y in _batches(dsets["train"], args.batch_size, True):
                 _, _, grads, _ = vgg_ref.loss_and_grads(params, self.cfg, x, y, "ce_mean")
                 stepped = [R.reg_sgd_step(t, g, o, iv, b, lam, lr, 0.9, args.weight_decay, first)
@@ -65,11 +68,14 @@ class OracleEWC:
                 params, bufs = [s[0] for s in stepped], [s[1] for s in stepped]
                 first = False
                 self.image_passes["train"] += x.shape[0]
+            t1 = time.perf_counter()
             hits = 0
             with torch.no_grad():
                 for x, y in _batches(dsets["val"], args.batch_size, True):
                     hits += int((vgg_ref.forward(params, self.cfg, x).argmax(1) == y).sum())
                     self.image_passes["eval"] += x.shape[0]
+            self.seconds["train"] += t1 - t0
+            self.seconds["eval"] += time.perf_counter() - t1
             acc = hits / float(len(dsets["val"]))
             if acc > best_acc:
                 best_acc, count = acc, 0
@@ -98,8 +104,10 @@ class OracleEWC:
         prev = torch.load(manager.reg_sets[-1], weights_only=False)["train"]
         model = torch.load(manager.previous_task_model_path, map_location="cpu", weights_only=False)
         theta = _params_of(model)
+        t0 = time.perf_counter()
         fisher = R.diag_fisher(theta, self.cfg, list(_batches(prev, args.batch_size, False)), len(prev))
         self.image_passes["train"] += len(prev)
+        self.seconds["train"] += time.perf_counter() - t0
         older = getattr(model, "oracle_omega", None)                   # omega accumulated over the earlier tasks
         omega = [f if o is None else o + f for f, o in zip(fisher, older or [None] * len(fisher))]
         init = [t.clone() for t in theta]
@@ -120,8 +128,10 @@ class OracleEWC:
         head_model = torch.load(args.head_paths, map_location="cpu", weights_only=False)
         params = _params_of(model)[:-2] + _params_of(head_model)[-2:]
         hits = 0
+        t0 = time.perf_counter()
         with torch.no_grad():
             for x, y in _batches(split, args.batch_size, False):
                 hits += int((vgg_ref.forward(params, self.cfg, x).argmax(1) == y).sum())
                 self.image_passes["eval"] += x.shape[0]
+        self.seconds["eval"] += time.perf_counter() - t0
         return 100.0 * hits / len(split)

@@ -1,4 +1,28 @@
-"""Test infrastructure shared by the GPU parity tests: reading the executor's non-linear decisions back."""
+"""Test infrastructure shared by the GPU parity tests: reading the executor's non-linear decisions back; the test-only
+device library."""
+import ctypes as C
+import os
+
+_DBG = None
+
+
+def dbg_lib():
+    """tests/libclhip_dbg.so (naive triage convolutions + MFMA fragment probe, tests/csrc/debug_naive.hip)."""
+    global _DBG
+    if _DBG is None:
+        from clsurvey_amd import _lib, build
+        _lib.lib()                                   # maps torch's HIP runtime first (see _lib.lib)
+        path = build.TEST_LIB if os.path.exists(build.TEST_LIB) else build.build_test_lib(verbose=False)
+        h = C.CDLL(os.path.abspath(path))
+        p, i = C.c_void_p, C.c_int
+        for name, args in (("clhip_dbg_conv3x3_fwd", [p, p, p, p, i, i, i, i, i, i, p]),
+                           ("clhip_dbg_conv3x3_bwd_data", [p, p, p, p, i, i, i, i, i, p]),
+                           ("clhip_dbg_conv3x3_bwd_weight", [p, p, p, p, i, i, i, i, i, p]),
+                           ("clhip_dbg_mfma_probe", [p, p])):
+            fn = getattr(h, name)
+            fn.restype, fn.argtypes = i, args
+        _DBG = h
+    return _DBG
 
 
 def engine_decisions(eng, n):

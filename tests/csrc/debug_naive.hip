@@ -1,7 +1,20 @@
 // Test-only device kernels: direct convolutions (one thread per output element, plain loops)
 // and an MFMA fragment-layout probe.  They exist so a parity failure on the GPU box can be
 // triaged between "harness / layout contract" and "MFMA kernel" in ONE gpurun call.
-#include "common.hpp"
+// Built into tests/libclhip_dbg.so (clsurvey_amd/build.py: build_test_lib); NOT part of libclhip.so.
+#include "../../clsurvey_amd/csrc/common.hpp"
+
+extern "C" {
+int clhip_dbg_conv3x3_fwd(const float* x, const float* w, const float* b, float* y, int N, int C, int K, int H, int W, int relu,
+                          void* stream);
+int clhip_dbg_conv3x3_bwd_data(const float* dy, const float* w, const float* relu_src, float* dx, int N, int C, int K, int H,
+                               int W, void* stream);
+int clhip_dbg_conv3x3_bwd_weight(const float* x, const float* dy, float* dw, float* db, int N, int C, int K, int H, int W,
+                                 void* stream);
+// MFMA fragment-layout probe: out[2][32][32]: D of the 32x32x2 f32 MFMA for rank-1 A, B patterns per k slice, stored through
+// the documented fragment map
+int clhip_dbg_mfma_probe(float* out_2048, void* stream);
+}
 
 namespace {
 

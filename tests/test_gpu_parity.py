@@ -37,9 +37,9 @@ def rnd(gen, *shape, scale=1.0):
 
 
 def test_mfma_fragment_layout_probe():
-    from clsurvey_amd import _lib
+    from branch_forcing import dbg_lib
     out = torch.zeros(2048, device=dev())
-    assert _lib.lib().clhip_dbg_mfma_probe(out.data_ptr(), None) == 0
+    assert dbg_lib().clhip_dbg_mfma_probe(out.data_ptr(), None) == 0
     torch.cuda.synchronize()
     o = out.cpu().view(2, 32, 32)
     i = torch.arange(1, 33, dtype=torch.float32)
@@ -82,7 +82,8 @@ def test_conv3x3_fwd_bwd(shape, impl):
         dxm = ops.conv3x3_bwd_data(dpd, wd, msrc)
         assert_close(dxm, xr.grad * (msrc.cpu() > 0), what="bwd_data+mask")
     else:
-        L = _lib.lib()
+        from branch_forcing import dbg_lib
+        L = dbg_lib()
         y = torch.empty(N, K, H, W, device=d)
         dx = torch.empty(N, C, H, W, device=d)
         dw = torch.empty(K, C, 3, 3, device=d)
@@ -1547,12 +1548,12 @@ def test_gem_qp_on_device_vs_host_and_scipy():
     """clhip_gem_qp (Goldfarb-Idnani in f64 on the device, fed by a Gram matrix that never leaves HBM) on 240 random
     problems of project2cone2's form (gem.py:58-80): well conditioned, rank deficient (fewer parameters than tasks: only
     eps*I keeps P definite), near-collinear memory gradients, many / no violated constraints, margins 0 / 0.5 / 1.
-    Judged by (a) the host restatement methods/qp.py, (b) scipy's bounded least squares on the Cholesky factor (an
+    Judged by (a) the host restatement oracle/qp_ref.py, (b) scipy's bounded least squares on the Cholesky factor (an
     independent algorithm), (c) the KKT conditions.  Parity with quadprog 0.1.6 itself stays unpinned (package absent)."""
     import ctypes as C
     from scipy.optimize import lsq_linear
     from clsurvey_amd import _lib
-    from clsurvey_amd.methods import qp
+    from oracle import qp_ref as qp
     L = _lib.lib()
     rs = np.random.RandomState(58)
     gram_d = torch.zeros(16 * 16, dtype=torch.float64, device=dev())
@@ -1608,12 +1609,13 @@ def test_gem_observe_device_qp_equals_host_path():
     bit for bit (the coefficients are rounded to fp32 at the same place) and the same parameters after the step."""
     from clsurvey_amd.methods.gem import GemNet, extend_head
     from clsurvey_amd import models
+    from oracle import qp_ref
     outs = []
     for on_device in (True, False):
         torch.manual_seed(4)
         m = extend_head(models.parse_model_name("small_VGG9_cl_128_128", (32, 32), 4), 12)
         gem = GemNet(m, 12, 3, [4, 4, 4], 16, 1e-2, 0.0, 0.5, batch_size=16, in_shape=(3, 32, 32), device=dev())
-        gem.qp_on_device = on_device
+        gem.host_qp = None if on_device else qp_ref.project2cone2_coefficients     # the host cross-check path is injected
         gen = torch.Generator().manual_seed(9)
         counts = []
         for t in range(3):

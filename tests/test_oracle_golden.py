@@ -210,7 +210,7 @@ def test_g6_gem_oracle_and_product_qp(golden):
     """gem.py store/overwrite/project2cone2 (reference, QP via scipy stand-in) vs the oracle (active-set
     enumeration) and the product's Goldfarb-Idnani solver.  quadprog parity itself is unpinned."""
     from oracle import gem_ref as GR
-    from clsurvey_amd.methods import qp
+    from oracle import qp_ref as qp
     g = golden("G6_gem")
     shapes = [(4, 3, 3, 3), (4,), (6, 4), (6,)]
     G = np.zeros_like(g["G"])

@@ -138,6 +138,45 @@ def _worker(rank, world, port, tmp):
     assert p_hf.attempts == s_hf.attempts == 3 and dict(p_hf.hyperparams) == dict(s_hf.hyperparams)
     assert p_hf.trace == s_hf.trace and p_model == s_model
 
+    # --- --no_speculation: phase 2 runs on rank 0 ONLY, every rank ends with rank 0's model bytes and framework state
+    meth4 = _DecayMethod()
+    mg4 = driver.Manager(_DS(), meth4, "prev", os.path.join(tmp, "rank%d" % rank, "seq0"), None)
+    mg4.speculative, mg4.sequential_on_rank0 = False, True
+    hf4 = driver.HyperparameterFramework(meth4)
+    hf4.stabilityDecay(_args(), mg4, 1e-3, finetune_acc=0.25)
+    assert (len(meth4.calls) > 0) == (rank == 0), (rank, meth4.calls)
+    with open(os.path.join(mg4.heuristic_exp_dir, "best_model.pth.tar"), "rb") as f:
+        mine = f.read()
+    assert shard.broadcast_bytes(mine, 0) == mine                   # identical best_model bytes on all ranks
+    assert dict(hf4.hyperparams) == dict(seq_hf.hyperparams) and hf4.attempts == seq_hf.attempts and hf4.trace == seq_hf.trace
+    assert os.path.exists(mg4.get_success_token_path(mg4.heuristic_exp_dir)) and mg4.best_model_path.startswith(os.path.join(tmp, "rank%d" % rank))
+
+    # --- a failure on ONE rank ends the stage on EVERY rank (no rank is left waiting in the next collective)
+    class _Failing(_GridMethod):
+        def grid_train(self, args, manager, lr):
+            if self.rank == 1:
+                raise ValueError("node failed on rank 1")
+            return super().grid_train(args, manager, lr)
+    mf = _Failing(rank)
+    mgf = driver.Manager(_DS(), mf, "prev", os.path.join(tmp, "rank%d" % rank, "fail"), None)
+    af = _args()
+    try:
+        driver.lr_grid_single_task(af, mgf, "all", train_node=shard.sharded_grid_factory()(af, mgf))
+        raise AssertionError("the failing grid went through on rank %d" % rank)
+    except RuntimeError as e:
+        assert "sharded stage failed" in str(e)
+
+    # --- resumed run with different checkpoints per rank: rank 0's table decides for everyone (no one-sided collective)
+    mr = _GridMethod(rank)
+    mgr2 = driver.Manager(_DS(), mr, "prev", os.path.join(tmp, "rank%d" % rank, "resume"), None)
+    ar = _args()
+    ft = os.path.join(mgr2.parent_exp_dir, "task_1", "FT_LR_GRIDSEARCH")
+    os.makedirs(ft)
+    if rank == 1:       # rank 1 believes the whole grid is done; rank 0 has nothing
+        torch.save({"processed_lrs": {lr: {"acc": [a]} for lr, a in _GRID_ACC.items()}}, os.path.join(ft, "grid_checkpoint.pth"))
+    best_lr, best_acc = driver.lr_grid_single_task(ar, mgr2, "all", train_node=shard.sharded_grid_factory()(ar, mgr2))
+    assert (best_lr, best_acc) == (5e-3, 0.9) and mr.trained == ([1e-2, 1e-3, 1e-4] if rank == 0 else [5e-3, 5e-4])
+
     # --- sharded evaluation: pairs split over the ranks, same table everywhere
     class EvalMethod:
         name = eval_name = "evalfake"

@@ -21,6 +21,8 @@ def _worker(rank, world, port, tmp, ndev):
     from clsurvey_amd.framework import driver, shard
     from clsurvey_amd.methods import method as M
     assert shard.init_from_env("nccl" if ndev >= world else "gloo") == (rank, world)
+    if ndev >= 2:                 # a box with two devices MUST carry this test over RCCL (one rank per GPU), never over gloo
+        assert torch.distributed.get_backend() == "nccl" and torch.cuda.current_device() == rank
     common = ["small_VGG9_cl_128_128", "--lr_grid", "1e-2,3e-3,1e-3", "--num_epochs", "6", "--batch_size", "40",
               "--saving_freq", "100", "--results_root", tmp, "--synthetic", "2,4,160,40,40,32", "--shard",
               "--device", "cuda:%d" % (rank % ndev)]

@@ -14,7 +14,17 @@ r = d["roofline"]
 print(d["value"], d["ms_per_step"], r["kernel"], r["avg_launch_us"], r["back_to_back_us"], r["frac"], r["traffic"])
 print(d.get("cpu_baseline", {}).get("value"), d["config"].get("gpu_over_cpu"), d.get("sweep_s"))
 for k, v in (d.get("configs") or {}).items():
-    if isinstance(v, dict): print(k, round(v["ms_per_step"], 3), round(v["images_per_s"]), round(v["frac_of_f32_mfma_peak"], 3))
+    if isinstance(v, dict) and "ms_per_step" in v: print(k, round(v["ms_per_step"], 3), round(v["images_per_s"]), round(v["frac_of_f32_mfma_peak"], 3))
 for row in list(csv.DictReader(open("gpurun_out/${TAG}_kernel_stats.csv")))[:3]:
     print(row["Name"][:90], row["Calls"], float(row["AverageNs"]) / 1000)
+PY
+python - <<PY
+import json
+d = json.loads(open("gpurun_out/${TAG}_bench.json").read().strip().splitlines()[-1])
+c = d.get("configs") or {}
+for r in c.get("hbm_kernels", []): print(r["kernel"], round(r["us"], 1), "us", round(r["achieved_TBps"], 2), "TB/s", round(r["frac_of_hbm_peak"], 3))
+for k, v in (c.get("conv_backward") or {}).items(): print(k, {a: (round(b, 3) if isinstance(b, float) else b) for a, b in v.items()})
+s = d.get("sweep") or {}
+print({k: v for k, v in s.items() if k not in ("what", "pair")})
+print(s.get("pair"))
 PY
