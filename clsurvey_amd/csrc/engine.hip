@@ -37,6 +37,7 @@ struct LayerPlan {
     size_t z_off;          // bn: float offset of the convolution output (pre-BatchNorm) in ws
     size_t stat_off;       // bn: float offset of save_mean[cout], save_invstd[cout]
     float* rmean; float* rvar; float bn_momentum, bn_eps;
+    int wino_f, wino_d;        // forward / backward-data through Winograd F(2x2,3x3) (wino.hip) instead of the direct kernels
     int wg3;                   // weight gradient on the 3x3 kernel (else the general gather-GEMM)
     size_t wg_off, wg_bytes;   // this layer's own weight-gradient slabs (3x3 layers; reduced for all layers at once)
     const float* extra_grad;   // added to the gradient w.r.t. this layer's input (side branches: clhip_net_set_input_grad)
@@ -45,6 +46,13 @@ struct LayerPlan {
     int has_drop_buf;      // the masked input gets its own buffer (the un-masked activation stays readable: side branches)
     size_t drop_off;       // float offset of that buffer in ws
 };
+
+constexpr long long WINO_MIN_UNITS = 640;
+// CLHIP_WINO=0 keeps every layer on the direct kernels (A/B measurements, triage)
+static bool wino_enabled() {
+    const char* e = std::getenv("CLHIP_WINO");
+    return !(e && e[0] == '0');
+}
 
 constexpr unsigned PROBE_RING = 64;
 #ifndef CLHIP_OVERLAP_DEFAULT
@@ -59,6 +67,8 @@ struct NetPlan {
     size_t idx_bytes;
     size_t grad_floats;      // one ping-pong gradient buffer
     size_t scratch_bytes;    // wgrad / fc split-K scratch
+    size_t wino_bytes;       // transformed weights of the layer in flight (Winograd path)
+    size_t off_wino;
     size_t total_bytes;
     // derived offsets (bytes) inside ws
     size_t off_acts, off_idx, off_g0, off_g1, off_scratch, off_dlogits, off_loss, off_fcdz, off_wg;
@@ -150,7 +160,7 @@ int clhip_net_create(const clhip_layer_desc* descs, int n_layers, int max_batch,
     p->in_elems = (size_t)in_c * in_h * in_w;
     int c = in_c, h = in_h, w = in_w;
     size_t feat = p->in_elems;
-    size_t acts = 0, idxb = 0, gmax = 0, scratch = 0, wg_total = 0;
+    size_t acts = 0, idxb = 0, gmax = 0, scratch = 0, wg_total = 0, wino_ws = 0;
     int n_wg = 0;
     bool seen_fc = false;
     for (int i = 0; i < n_layers; ++i) {
@@ -198,6 +208,17 @@ int clhip_net_create(const clhip_layer_desc* descs, int n_layers, int max_batch,
                              : clhip_conv2d_bwd_weight_ws(max_batch, L.cin, L.h, L.w, L.cout, L.ks, L.ks, L.st, L.pd);
             if (s > scratch) scratch = s;
             if (L.wg3) { L.wg_off = wg_total; L.wg_bytes = align_up(s, 256); wg_total += L.wg_bytes; ++n_wg; }
+            // Winograd path: 2.25x fewer matrix instructions, but a wave's work unit is 32 channels x 32 TILES (128
+            // pixels) with 256 accumulator registers, one wave per SIMD: it needs enough units to fill most of the 1024 SIMDs
+            // (measured at N = 200: 64->64 @16x16, 800 units, 1.26x the direct kernel; 128->128 @8x8, 400 units, 0.8x)
+            if (vgg && !L.bn && wino_enabled()) {
+                const long long tiles = (long long)max_batch * (L.h / 2) * (L.w / 2);
+                auto units = [&](int kout) { return ((tiles + 31) / 32) * ((kout + 31) / 32); };
+                L.wino_f = clhip_internal_wino_ok(L.cin, L.cout, L.h, L.w) && units(L.cout) >= WINO_MIN_UNITS;
+                L.wino_d = i > 0 && clhip_internal_wino_ok(L.cout, L.cin, L.h, L.w) && units(L.cin) >= WINO_MIN_UNITS;
+                if (L.wino_f && clhip_internal_wino_ws(L.cin, L.cout) > wino_ws) wino_ws = clhip_internal_wino_ws(L.cin, L.cout);
+                if (L.wino_d && clhip_internal_wino_ws(L.cout, L.cin) > wino_ws) wino_ws = clhip_internal_wino_ws(L.cout, L.cin);
+            }
             if (L.out_elems > gmax) gmax = L.out_elems;
             if (L.in_elems > gmax) gmax = L.in_elems;
             h = oh; w = ow;
@@ -226,6 +247,8 @@ int clhip_net_create(const clhip_layer_desc* descs, int n_layers, int max_batch,
     p->off_g0 = off; off += align_up(p->grad_floats * 4, 256);
     p->off_g1 = off; off += align_up(p->grad_floats * 4, 256);
     p->off_scratch = off; off += align_up(scratch, 256);
+    p->wino_bytes = wino_ws;
+    p->off_wino = off; off += align_up(wino_ws, 256);
     p->off_dlogits = off; off += align_up((size_t)max_batch * p->n_classes * 4, 256);
     p->off_loss = off; off += 256;
     // fused classifier
@@ -478,12 +501,16 @@ static int net_forward_impl(void* handle, const float* params, const float* x, i
             if (L.pool && L.relu) {
                 // conv + bias + ReLU + max-pool in one kernel; the pre-pool tensor is never materialised
                 float* pl = acts + L.pool_off;
-                rc = clhip_conv3x3_relu_pool_fwd(cur, params + L.w_off, params + L.b_off, pl, idx + L.idx_off, N, L.cin,
-                                                 L.cout, L.h, L.w, stream);
+                rc = L.wino_f ? clhip_internal_wino_conv(0, cur, params + L.w_off, params + L.b_off, nullptr, pl, idx + L.idx_off, 0, N,
+                                                         L.cin, L.cout, L.h, L.w, 1, base + p->off_wino, p->wino_bytes, as_stream(stream))
+                              : clhip_conv3x3_relu_pool_fwd(cur, params + L.w_off, params + L.b_off, pl, idx + L.idx_off, N, L.cin,
+                                                            L.cout, L.h, L.w, stream);
                 if (rc) return rc;
                 cur = pl;
             } else {
-                rc = clhip_conv3x3_fwd(cur, params + L.w_off, params + L.b_off, y, N, L.cin, L.cout, L.h, L.w, L.relu, stream);
+                rc = L.wino_f ? clhip_internal_wino_conv(0, cur, params + L.w_off, params + L.b_off, nullptr, y, nullptr, 0, N, L.cin,
+                                                         L.cout, L.h, L.w, L.relu, base + p->off_wino, p->wino_bytes, as_stream(stream))
+                              : clhip_conv3x3_fwd(cur, params + L.w_off, params + L.b_off, y, N, L.cin, L.cout, L.h, L.w, L.relu, stream);
                 if (rc) return rc;
                 cur = y;
                 if (L.pool) {
@@ -674,7 +701,10 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
             else if (rc != CLHIP_ENOTSUP) return rc;
             if (wdone && i > 0 && !L.drop && !L.extra_grad) {
                 gout_d = take(); gout_d_buf = taken;
-                rc = clhip_conv3x3_bwd_data_unpool(gin, idx + L.idx_off, params + L.w_off, xin, gout_d, N, L.cin, L.cout, L.h, L.w, stream);
+                rc = L.wino_d ? clhip_internal_wino_conv(1, gin, params + L.w_off, nullptr, xin, gout_d, idx + L.idx_off, 1, N, L.cout,
+                                                         L.cin, L.h, L.w, 0, base + p->off_wino, p->wino_bytes, as_stream(stream))
+                              : clhip_conv3x3_bwd_data_unpool(gin, idx + L.idx_off, params + L.w_off, xin, gout_d, N, L.cin, L.cout, L.h,
+                                                              L.w, stream);
                 if (rc == 0) ddone = true;
                 else if (rc != CLHIP_ENOTSUP) return rc;
             }
@@ -713,7 +743,10 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
             gin = gout_d; gin_buf = gout_d_buf;
         } else if (i > 0) {
             float* gout = take();
-            rc = vgg ? clhip_conv3x3_bwd_data(gy, params + L.w_off, xin, gout, N, L.cin, L.cout, L.h, L.w, stream)
+            rc = (vgg && L.wino_d)
+                     ? clhip_internal_wino_conv(1, gy, params + L.w_off, nullptr, xin, gout, nullptr, 0, N, L.cout, L.cin, L.h, L.w, 0,
+                                                base + p->off_wino, p->wino_bytes, as_stream(stream))
+                 : vgg ? clhip_conv3x3_bwd_data(gy, params + L.w_off, xin, gout, N, L.cin, L.cout, L.h, L.w, stream)
                      : clhip_conv2d_bwd_data(gy, params + L.w_off, xin, gout, N, L.cin, L.h, L.w, L.cout, L.ks, L.ks, L.st, L.pd, stream);
             if (rc) return rc;
             gin = gout; gin_buf = taken;

@@ -1,0 +1,393 @@
+// 3x3 pad-1 convolution by Winograd F(2x2, 3x3) on v_mfma_f32_32x32x2_f32  (forward and backward-data).
+//
+// The direct kernels of conv3x3.hip spend 9 MFMAs per (32 out-channels x 32 pixels x 2 in-channels); they are bound by
+// the matrix pipe (0.7-0.8 of the fp32-MFMA peak on the large layers), so the only way to make those layers much faster is
+// to issue fewer MFMAs.  F(2x2, 3x3) computes a 2x2 output tile from a 4x4 input tile with 16 multiplies instead of 36:
+//     Y = A^T [ (G g G^T) .* (B^T d B) ] A            (Lavin & Gray, "Fast Algorithms for Convolutional Neural Networks")
+// Summed over input channels the element-wise product becomes 16 independent GEMMs  M_f[k][tile] = sum_c U_f[k][c] V_f[c][tile],
+// i.e. 16 MFMAs per (32 out-channels x 32 TILES = 128 pixels x 2 in-channels): 2.25x fewer matrix instructions per pixel.
+// Everything else is fused into the one kernel (nothing but x, the pre-transformed weights and y touches HBM):
+//   * U = G g G^T is formed once per call by a small kernel into [k-tile][chunk][f][c][k] (the LDS image of a chunk, so
+//     that staging a chunk's weights is a straight 32 KB copy),
+//   * the input transform B^T d B runs in registers: a lane owns one tile of one channel (MFMA B operand: lane = tile,
+//     k-pair half = channel), reads its 4x4 window from the LDS halo plane (8 ds_read_b64) and forms the 16 frequency
+//     values with 32 adds — next to 16 MFMAs (1024 matrix cycles) that is ~12 % extra issue time,
+//   * the output transform A^T M A runs in registers too: accumulator register r of the 16 frequency accumulators of a
+//     lane is (out-channel r, this lane's tile) in every one of them, so the 2x2 outputs come from 24 adds per register,
+//     and the 2x2 max-pool of VGGSlim.py:32 is a maximum over four values the lane already holds (no shuffles).
+// fp32 throughout; transform constants are 0, +-1, +-0.5 (exact), so the result differs from a direct fp32 convolution by
+// rounding only (measured ~1e-6 of the output scale; north_star: 1e-3).
+//
+// Block = 4 waves = (2 halves of 64 out-channels) x (2 groups of 32 tiles); a wave holds 16 x 16 = 256 accumulator
+// registers (one wave per SIMD, like the weight-gradient kernel).  Tiles of a block: TCB x TRB tiles of NIMG images.
+#include "common.hpp"
+
+namespace {
+
+constexpr int WKT = 64;      // out channels per block
+constexpr int WCK = 8;       // in channels per chunk
+constexpr int W_FLOATS = 16 * WCK * WKT;          // 8192 floats = 32 KB: U tile of one chunk [f][c][k]
+
+template <int TCB, int TRB, int NIMG>
+struct WGeoW {
+    static_assert(TCB * TRB * NIMG == 64, "64 tiles per block");
+    static constexpr int PW = 2 * TCB + 2;                 // halo plane row length (even)
+    static constexpr int PR = 2 * TRB + 2;                 // halo plane rows per image
+    static constexpr int PLANE = NIMG * PR * PW;           // floats per channel
+    static constexpr int X_FLOATS = WCK * PLANE;
+    static constexpr int BUF = W_FLOATS + X_FLOATS;
+};
+
+// U[kt][chunk][f][c][k] = (G g G^T)[f] of g = w[k][c] (MODE 0) or of the 180-degree-rotated w[c][k] (MODE 1: backward-data,
+// where the kernel's "input channels" are the convolution's output channels).  Ko / Ci: channel counts as the KERNEL sees them.
+__global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Ko, int Ci,
+                                                          int mode, int n_chunks) {
+    const int total = ((Ko + WKT - 1) / WKT) * n_chunks * WCK * WKT;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int k_l = i % WKT, c_l = (i / WKT) % WCK, chunk = (i / (WKT * WCK)) % n_chunks, kt = i / (WKT * WCK * n_chunks);
+        const int k = kt * WKT + k_l, c = chunk * WCK + c_l;
+        float g[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                float v = 0.f;
+                if (k < Ko && c < Ci)
+                    v = mode == 0 ? w[((size_t)k * Ci + c) * 9 + r * 3 + s]
+                                  : w[((size_t)c * Ko + k) * 9 + (2 - r) * 3 + (2 - s)];     // w[c_out = c][c_in = k], flipped
+                g[r][s] = v;
+            }
+        // t = G g  (4x3), u = t G^T (4x4);  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+        float t[4][3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            t[0][s] = g[0][s];
+            t[1][s] = 0.5f * (g[0][s] + g[1][s] + g[2][s]);
+            t[2][s] = 0.5f * (g[0][s] - g[1][s] + g[2][s]);
+            t[3][s] = g[2][s];
+        }
+        float* dst = U + ((size_t)(kt * n_chunks + chunk) * 16 * WCK + c_l) * WKT + k_l;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float u0 = t[a][0], u1 = 0.5f * (t[a][0] + t[a][1] + t[a][2]), u2 = 0.5f * (t[a][0] - t[a][1] + t[a][2]), u3 = t[a][2];
+            dst[(size_t)(4 * a + 0) * WCK * WKT] = u0;
+            dst[(size_t)(4 * a + 1) * WCK * WKT] = u1;
+            dst[(size_t)(4 * a + 2) * WCK * WKT] = u2;
+            dst[(size_t)(4 * a + 3) * WCK * WKT] = u3;
+        }
+    }
+}
+
+// MODE 0: forward   — out = [relu](conv(in, w) + bias), optionally 2x2-max-pooled with arg-max codes (pool_idx != NULL)
+// MODE 1: backward-data — in = dy (Cin = the layer's out channels), out = dx (* (mask_src > 0) when mask_src != NULL);
+//         UNPOOL: `in` is the gradient w.r.t. the POOLED output + the forward's arg-max codes (fused max_pool2d backward)
+template <int TCB, int TRB, int NIMG, int MODE, bool UNPOOL>
+__global__ __launch_bounds__(256, 1) void wino_conv_kernel(
+    const float* __restrict__ in, const float* __restrict__ U, const float* __restrict__ bias,
+    const float* __restrict__ mask_src, float* __restrict__ out, uint8_t* __restrict__ pool_idx,
+    int N, int Cin, int Cout, int H, int W, int relu, int tiles_w, int tiles_h, int n_pix_blocks) {
+    using G = WGeoW<TCB, TRB, NIMG>;
+    __shared__ __attribute__((aligned(16))) float lds[2 * G::BUF];
+    __shared__ float bias_s[WKT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave & 1, wp = wave >> 1;
+    const int li = lane & 31, kk = lane >> 5;
+
+    const int kt = blockIdx.x / n_pix_blocks, pb = blockIdx.x - kt * n_pix_blocks;
+    const int bw = pb % tiles_w, bh = (pb / tiles_w) % tiles_h, ng = pb / (tiles_w * tiles_h);
+    const int n0 = ng * NIMG, h0 = bh * 2 * TRB, w0 = bw * 2 * TCB;
+    const int ko0 = kt * WKT;
+    const int n_chunks = (Cin + WCK - 1) / WCK;
+    if (MODE == 0 && tid < WKT) bias_s[tid] = (bias && ko0 + tid < Cout) ? bias[ko0 + tid] : 0.f;
+
+    const int Hi = UNPOOL ? H >> 1 : H, Wi = UNPOOL ? W >> 1 : W;          // geometry of the tensor `in` points at
+    const size_t plane_in = (size_t)Hi * Wi;
+    const float* in_blk = in + (size_t)n0 * Cin * plane_in;
+    const __amdgpu_buffer_rsrc_t rs_x = clhip_rsrc(in_blk, (size_t)(N - n0) * Cin * plane_in * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rs_i = clhip_rsrc(UNPOOL ? pool_idx + (size_t)n0 * Cin * plane_in : pool_idx,
+                                                   UNPOOL ? (size_t)(N - n0) * Cin * plane_in : 0);
+    const __amdgpu_buffer_rsrc_t rs_u = clhip_rsrc(U + (size_t)kt * n_chunks * W_FLOATS, (size_t)n_chunks * W_FLOATS * sizeof(float));
+
+    // ------------------------------------------------------------------ staging (registers -> LDS, one chunk ahead)
+    // weights: straight copy of 2048 float4; activations: one scalar per halo-plane element (raw buffer loads: padding,
+    // image tails and channel tails read 0 through the OFFSET predicate — never a branch, never a select on a loaded value).
+    // A chunk's staging is cut into UNITS of one instruction each, issued one per MFMA slot (see the pipeline below).
+    constexpr int W_IT = W_FLOATS / 4 / 256;                         // 8
+    constexpr int X_IT = (G::X_FLOATS + 255) / 256;
+    constexpr int NU = W_IT + X_IT;
+    float4 wv[W_IT];
+    float xr[X_IT];
+    unsigned xi[UNPOOL ? X_IT : 1];
+    int xoff[X_IT], xcl[X_IT], xcode[UNPOOL ? X_IT : 1];
+#pragma unroll
+    for (int j = 0; j < X_IT; ++j) {
+        const int e = tid + 256 * j;
+        xoff[j] = CLHIP_OOB;
+        xcl[j] = 1 << 20;                                            // "channel" of a slot past the plane: never < Cin
+        if (e < G::X_FLOATS) {
+            const int cl = e / G::PLANE, rem = e - cl * G::PLANE;
+            const int col = rem % G::PW, rr = rem / G::PW;
+            const int row = rr % G::PR, nb = rr / G::PR;
+            const int n = n0 + nb, h = h0 - 1 + row, w = w0 - 1 + col;
+            xcl[j] = cl;
+            if (n < N && h >= 0 && h < H && w >= 0 && w < W) {
+                if constexpr (UNPOOL) {
+                    xoff[j] = (int)(((size_t)nb * Cin + cl) * plane_in) + (h >> 1) * Wi + (w >> 1);     // ELEMENT offset
+                    xcode[j] = ((h & 1) << 1) | (w & 1);
+                } else {
+                    xoff[j] = ((int)(((size_t)nb * Cin + cl) * plane_in) + h * W + w) * 4;
+                }
+            }
+        }
+    }
+    // unit u of chunk `chunk` -> staging registers.  Chunks past the end: the weight tile of the last chunk is re-read
+    // (never used), the activation offsets fail the channel test and read 0.
+    auto load_unit = [&](int u, int chunk) {
+        const int cw = chunk < n_chunks ? chunk : n_chunks - 1;
+        if (u < W_IT) {
+            wv[u] = clhip_buf_load4(rs_u, (tid + 256 * u) * 16, cw * W_FLOATS * 4);
+        } else {
+            const int j = u - W_IT;
+            const int c0 = chunk * WCK;
+            const int xb = cw * WCK * (int)plane_in;                 // wave-uniform scalar offset
+            const bool ok = c0 + xcl[j] < Cin;                       // per lane: goes into the vector offset only
+            if constexpr (UNPOOL) {
+                xr[j] = clhip_buf_load(rs_x, ok && xoff[j] != CLHIP_OOB ? xoff[j] * 4 : CLHIP_OOB, xb * 4);
+                xi[j] = clhip_buf_load_u8(rs_i, ok ? xoff[j] : CLHIP_OOB, xb);
+            } else {
+                xr[j] = clhip_buf_load(rs_x, ok ? xoff[j] : CLHIP_OOB, xb * 4);
+            }
+        }
+    };
+    auto store_unit = [&](int u, int bo) {
+        if (u < W_IT) {
+            float* wd = lds + bo + 4 * (tid + 256 * u);
+            *reinterpret_cast<floatx4*>(wd) = floatx4{wv[u].x, wv[u].y, wv[u].z, wv[u].w};
+        } else {
+            const int j = u - W_IT;
+            float* xs = lds + bo + W_FLOATS;
+            if (256 * (j + 1) <= G::X_FLOATS || tid + 256 * j < G::X_FLOATS) {
+                if constexpr (UNPOOL) xs[tid + 256 * j] = ((int)xi[j] == xcode[j]) ? xr[j] : 0.f;
+                else xs[tid + 256 * j] = xr[j];
+            }
+        }
+    };
+
+    // this lane's tile: index t = 32 * wp + li over (image, tile row, tile column)
+    const int t_idx = 32 * wp + li;
+    const int t_img = t_idx / (TRB * TCB), t_row = (t_idx / TCB) % TRB, t_col = t_idx % TCB;
+    const int d_off = W_FLOATS + kk * G::PLANE + (t_img * G::PR + 2 * t_row) * G::PW + 2 * t_col;     // even: 8-byte aligned
+    const int a_off = kk * WKT + wk * 32 + li;
+
+    floatx16 acc[16];
+#pragma unroll
+    for (int f = 0; f < 16; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+    // ------------------------------------------------------------------ pipeline
+    // One wave per SIMD: nothing hides a stall, so every piece of non-matrix work rides in the shadow of an MFMA "slot"
+    // (64 matrix cycles each, order pinned by sched_barrier): while pair p's 16 MFMAs issue, slot f
+    //   * reads weight fragment f of pair p + 1                                    (1 ds_read_b32),
+    //   * f < 8:  reads one 8-byte half-row of pair p + 1's 4x4 window              (1 ds_read_b64),
+    //   * f = 8..11 / 12..15: row / column half of the input transform B^T d B of pair p + 1 (4 v_add each),
+    //   * pair 0: LDS writes of chunk c + 1, pairs 1-2: global loads of chunk c + 2   (one unit per slot),
+    // with ONE barrier per chunk behind the first MFMA of the last pair (every read of the current buffer has been issued
+    // and waited for by then; the writes of chunk c + 1 were issued during pair 0).
+    constexpr int NP = WCK / 2;
+    float av[2][16], vv[2][16], tt[16];
+    float2 dn[8];
+    auto rd_a = [&](const float* buf, int pair, int f, int slot) { av[slot][f] = buf[a_off + 2 * pair * WKT + f * WCK * WKT]; };
+    auto rd_d = [&](const float* buf, int pair, int h) {
+        dn[h] = *reinterpret_cast<const float2*>(buf + d_off + 2 * pair * G::PLANE + (h >> 1) * G::PW + 2 * (h & 1));
+    };
+    auto d_at = [&](int r, int j) { return (j & 1) ? dn[2 * r + (j >> 1)].y : dn[2 * r + (j >> 1)].x; };
+    auto row_tf = [&](int j) {           // column j of t = B^T d
+        tt[0 * 4 + j] = d_at(0, j) - d_at(2, j);
+        tt[1 * 4 + j] = d_at(1, j) + d_at(2, j);
+        tt[2 * 4 + j] = d_at(2, j) - d_at(1, j);
+        tt[3 * 4 + j] = d_at(1, j) - d_at(3, j);
+    };
+    auto col_tf = [&](int i, int slot) { // row i of V = t B
+        vv[slot][4 * i + 0] = tt[4 * i + 0] - tt[4 * i + 2];
+        vv[slot][4 * i + 1] = tt[4 * i + 1] + tt[4 * i + 2];
+        vv[slot][4 * i + 2] = tt[4 * i + 2] - tt[4 * i + 1];
+        vv[slot][4 * i + 3] = tt[4 * i + 1] - tt[4 * i + 3];
+    };
+
+#pragma unroll
+    for (int u = 0; u < NU; ++u) load_unit(u, 0);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) store_unit(u, 0);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) load_unit(u, 1);
+    __syncthreads();
+#pragma unroll
+    for (int f = 0; f < 16; ++f) rd_a(lds, 0, f, 0);
+#pragma unroll
+    for (int h = 0; h < 8; ++h) rd_d(lds, 0, h);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) row_tf(j);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) col_tf(i, 0);
+
+    static_assert(NU <= 32, "two store units per slot of pair 0, one load unit per slot of pairs 1-2");
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        const int bo = (chunk & 1) * G::BUF, bn = G::BUF - bo;
+        const float* cur = lds + bo;
+        const float* nxt = lds + bn;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const float* nb = (p + 1 < NP) ? cur : nxt;
+            const int np = (p + 1) % NP, ns = (p + 1) & 1, cs = p & 1;
+#pragma unroll
+            for (int f = 0; f < 16; ++f) {
+                acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cs][f], vv[cs][f], acc[f], 0, 0, 0);
+                if (p == NP - 1 && f == 0) __syncthreads();
+#ifndef WINO_ABL_NOLDS
+                rd_a(nb, np, f, ns);
+#endif
+#ifndef WINO_ABL_NOLDS
+                if (f < 8) rd_d(nb, np, f);
+#endif
+                if (f < 8) {}
+#ifndef WINO_ABL_NOTF
+                else if (f < 12) row_tf(f - 8);
+                else col_tf(f - 12, ns);
+#endif
+                // (no inner loops over units: every register-array index must be a constant once p and f are unrolled,
+                // otherwise the staging arrays are demoted to LDS-backed storage and each load is waited for at once)
+#ifndef WINO_ABL_NOSTAGE
+                if (p == 0) {
+                    if (2 * f < NU) store_unit(2 * f, bn);
+                    if (2 * f + 1 < NU) store_unit(2 * f + 1, bn);
+                } else if (p <= 2) {
+                    if ((p - 1) * 16 + f < NU) load_unit((p - 1) * 16 + f, chunk + 2);
+                }
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // ------------------------------------------------------------------ epilogue: Y = A^T M A per accumulator register
+    // register r of lane l = (out channel kb + rch(r), tile l) in every frequency accumulator
+    const int kb = ko0 + wk * 32 + 4 * kk;
+    auto rch = [](int r) { return (r & 3) + 8 * (r >> 2); };
+    const int n = n0 + t_img, oh = h0 + 2 * t_row, ow = w0 + 2 * t_col;
+    const bool tile_ok = n < N && oh < H && ow < W;                 // H, W even: a tile is inside or outside as a whole
+    const bool pool = MODE == 0 && pool_idx != nullptr;
+    const size_t chw = (size_t)H * W;
+    const int OH = H >> 1, OW = W >> 1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float u0[4], u1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u0[j] = acc[j][r] + acc[4 + j][r] + acc[8 + j][r];
+            u1[j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
+        }
+        float y00 = u0[0] + u0[1] + u0[2], y01 = u0[1] - u0[2] - u0[3];
+        float y10 = u1[0] + u1[1] + u1[2], y11 = u1[1] - u1[2] - u1[3];
+        const int k = kb + rch(r);
+        const bool ok = tile_ok && k < Cout;
+        if (MODE == 0) {
+            const float b = bias_s[wk * 32 + 4 * kk + rch(r)];
+            y00 += b; y01 += b; y10 += b; y11 += b;
+            if (relu) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
+            if (pool) {
+                float m = y00; int a = 0;              // first maximum in ATen's scan order wins
+                if (y01 > m) { m = y01; a = 1; }
+                if (y10 > m) { m = y10; a = 2; }
+                if (y11 > m) { m = y11; a = 3; }
+                if (ok) {
+                    const size_t o = ((size_t)n * Cout + k) * OH * OW + (size_t)(oh >> 1) * OW + (ow >> 1);
+                    out[o] = m;
+                    pool_idx[o] = (uint8_t)a;
+                }
+                continue;
+            }
+        }
+        if (ok) {
+            const size_t o = ((size_t)n * Cout + k) * chw + (size_t)oh * W + ow;
+            if (MODE == 1 && mask_src) {
+                const float2 m0 = *reinterpret_cast<const float2*>(mask_src + o), m1 = *reinterpret_cast<const float2*>(mask_src + o + W);
+                y00 = m0.x > 0.f ? y00 : 0.f; y01 = m0.y > 0.f ? y01 : 0.f;
+                y10 = m1.x > 0.f ? y10 : 0.f; y11 = m1.y > 0.f ? y11 : 0.f;
+            }
+            *reinterpret_cast<float2*>(out + o) = make_float2(y00, y01);
+            *reinterpret_cast<float2*>(out + o + W) = make_float2(y10, y11);
+        }
+    }
+}
+
+template <int MODE, bool UNPOOL>
+int launch_wino(const float* in, const float* U, const float* bias, const float* mask_src, float* out, uint8_t* pool_idx,
+                int N, int Cin, int Cout, int H, int W, int relu, hipStream_t s) {
+    const int kts = (Cout + WKT - 1) / WKT;
+#define WINO_GEO(TCB_, TRB_, NIMG_)                                                                                          \
+    do {                                                                                                                      \
+        const int tiles_w = (W / 2 + TCB_ - 1) / TCB_, tiles_h = (H / 2 + TRB_ - 1) / TRB_, ngrp = (N + NIMG_ - 1) / NIMG_;   \
+        const long long npb = (long long)tiles_w * tiles_h * ngrp, blocks = npb * kts;                                        \
+        if (blocks <= 0 || blocks > 0x7fffffffLL) return CLHIP_EINVAL;                                                        \
+        hipLaunchKernelGGL((wino_conv_kernel<TCB_, TRB_, NIMG_, MODE, UNPOOL>), dim3((unsigned)blocks), dim3(256), 0, s, in, U, \
+                           bias, mask_src, out, pool_idx, N, Cin, Cout, H, W, relu, tiles_w, tiles_h, (int)npb);              \
+    } while (0)
+    if (W >= 32) WINO_GEO(16, 4, 1);
+    else if (W >= 16) WINO_GEO(8, 8, 1);
+    else WINO_GEO(4, 4, 4);
+#undef WINO_GEO
+    CLHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+// shapes this path takes: even H, W (2x2 output tiles), W % 2 == 0 for the 8-byte stores, channel counts in whole chunks
+bool clhip_internal_wino_ok(int Cin, int Cout, int H, int W) {
+    return Cin % WCK == 0 && Cin >= 16 && Cout % 32 == 0 && H % 2 == 0 && W % 2 == 0 && H >= 4 && W >= 8;
+}
+
+size_t clhip_internal_wino_ws(int Cin, int Cout) {
+    return (size_t)((Cout + WKT - 1) / WKT) * ((Cin + WCK - 1) / WCK) * W_FLOATS * sizeof(float);
+}
+
+// forward (mode 0) / backward-data (mode 1) through the Winograd path.  ws: clhip_internal_wino_ws(Cin, Cout) bytes.
+// For backward-data the caller passes Cin = the layer's OUT channels (channels of dy), Cout = its IN channels; `w` is the
+// layer's weight tensor [K][C][3][3] in both modes.
+int clhip_internal_wino_conv(int mode, const float* in, const float* w, const float* bias, const float* mask_src, float* out,
+                             uint8_t* pool_idx, int unpool, int N, int Cin, int Cout, int H, int W, int relu, void* ws,
+                             size_t ws_bytes, hipStream_t s) {
+    if (!in || !w || !out || !ws || !clhip_internal_wino_ok(Cin, Cout, H, W) || ws_bytes < clhip_internal_wino_ws(Cin, Cout))
+        return CLHIP_EINVAL;
+    float* U = static_cast<float*>(ws);
+    const int n_chunks = (Cin + WCK - 1) / WCK;
+    const int total = ((Cout + WKT - 1) / WKT) * n_chunks * WCK * WKT;
+    hipLaunchKernelGGL(wino_weight_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w, U, Cout, Cin, mode, n_chunks);
+    CLHIP_LAUNCH_CHECK();
+    if (mode == 0) return launch_wino<0, false>(in, U, bias, nullptr, out, pool_idx, N, Cin, Cout, H, W, relu, s);
+    if (unpool) return launch_wino<1, true>(in, U, nullptr, mask_src, out, pool_idx, N, Cin, Cout, H, W, 0, s);
+    return launch_wino<1, false>(in, U, nullptr, mask_src, out, nullptr, N, Cin, Cout, H, W, 0, s);
+}
+
+extern "C" {
+
+size_t clhip_conv3x3_wino_ws(int C, int K) {
+    const size_t a = clhip_internal_wino_ws(C, K), b = clhip_internal_wino_ws(K, C);
+    return a > b ? a : b;
+}
+
+int clhip_conv3x3_wino_fwd(const float* x, const float* w, const float* b, float* y, uint8_t* idx_u8_or_null, int N, int C, int K,
+                           int H, int W, int relu, void* ws, size_t ws_bytes, void* stream) {
+    if (N <= 0 || !clhip_internal_wino_ok(C, K, H, W)) return CLHIP_ENOTSUP;
+    return clhip_internal_wino_conv(0, x, w, b, nullptr, y, idx_u8_or_null, 0, N, C, K, H, W, relu, ws, ws_bytes, as_stream(stream));
+}
+
+int clhip_conv3x3_wino_bwd_data(const float* dy, const uint8_t* idx_u8_or_null, const float* w, const float* relu_src, float* dx,
+                                int N, int C, int K, int H, int W, void* ws, size_t ws_bytes, void* stream) {
+    if (N <= 0 || !clhip_internal_wino_ok(K, C, H, W)) return CLHIP_ENOTSUP;
+    return clhip_internal_wino_conv(1, dy, w, nullptr, relu_src, dx, const_cast<uint8_t*>(idx_u8_or_null), idx_u8_or_null != nullptr,
+                                    N, K, C, H, W, 0, ws, ws_bytes, as_stream(stream));
+}
+
+}  // extern "C"

@@ -215,6 +215,20 @@ int clhip_mask_weight_zero(float* w, const uint8_t* mask_u8, size_t n, int mode,
 int clhip_packnet_sgd_step(float* theta, float* grad, float* buf, const uint8_t* mask_u8, size_t n, int cur,
                            float lr, float momentum, float wd, int first, void* stream);
 
+/* ------------------------------------------------------------------ 3x3 convolution by Winograd F(2x2, 3x3)
+ * The same operators as clhip_conv3x3_fwd / _relu_pool_fwd / _bwd_data / _bwd_data_unpool (VGGSlim.py:27-40 and their
+ * autograd backward) with 2.25x fewer matrix instructions per pixel: input / weight / output transforms fused into ONE
+ * kernel (csrc/wino.hip), fp32, results equal to the direct kernels' up to rounding (~1e-6 of the output scale).
+ * Shapes: C % 8 == 0, C >= 16, K % 32 == 0, H and W even (CLHIP_ENOTSUP otherwise: callers fall back to the direct
+ * kernels).  idx_u8 != NULL on the forward: y is the 2x2-max-pooled activation [N][K][H/2][W/2] + arg-max codes;
+ * idx_u8 != NULL on backward-data: dy is the gradient w.r.t. that pooled activation (fused max_pool2d backward).
+ * ws: clhip_conv3x3_wino_ws(C, K) bytes (the transformed weights of this call).                              */
+size_t clhip_conv3x3_wino_ws(int C, int K);
+int clhip_conv3x3_wino_fwd(const float* x, const float* w, const float* b, float* y, uint8_t* idx_u8_or_null, int N, int C, int K,
+                           int H, int W, int relu, void* ws, size_t ws_bytes, void* stream);
+int clhip_conv3x3_wino_bwd_data(const float* dy, const uint8_t* idx_u8_or_null, const float* w, const float* relu_src, float* dx,
+                                int N, int C, int K, int H, int W, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------ HAT gates / back-masks / HAT_SGD
  * methods/HAT/networks/vgg_hat.py, approaches/hat.py, HAT_utils.py.  Gates multiply layer outputs in the
  * reference (vgg_hat.py:104-116); here they are folded into the NEXT layer's weights

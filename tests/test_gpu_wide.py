@@ -89,7 +89,8 @@ def _hat_forced_branch(hat, P64, t, x, y, s, lamb, smax, what, conv_geo=None, po
             zo = torch.gather(win, 4, own.unsqueeze(-1)).squeeze(-1)
             moved = (dg["idx"] != own) & (dg["mask"] | (zo > 0))
             flips += int(moved.sum())
-            assert not moved.any() or float((zo - zg)[moved].abs().max()) <= tie, "%s block %d: arg-max differs off a tie" % (what, b)
+            gap = torch.where(dg["mask"], (zo - zg).abs(), zo.clamp_min(0.0))      # all-non-positive window on the executor: code 0 by convention
+            assert not moved.any() or float(gap[moved].max()) <= tie, "%s block %d: arg-max differs off a tie" % (what, b)
             z = zg
         off = dg["mask"] != (z > 0)
         if "dropped" in dg:

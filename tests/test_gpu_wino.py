@@ -1,0 +1,75 @@
+"""Winograd F(2x2, 3x3) convolution kernels (csrc/wino.hip) against torch CPU (the reference's arithmetic: nn.Conv2d + ReLU +
+MaxPool2d of models/VGGSlim.py:27-40 and their autograd backward) and against the direct MFMA kernels."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [  # N, C, K, H, W
+    (3, 64, 64, 32, 32), (5, 64, 64, 16, 16), (6, 64, 128, 8, 8), (9, 128, 128, 8, 8), (2, 16, 32, 8, 8),
+    (2, 24, 96, 12, 20), (3, 128, 256, 16, 16), (2, 64, 64, 64, 64), (7, 256, 256, 8, 8), (2, 32, 64, 28, 28),
+    (200, 64, 64, 32, 32), (200, 64, 64, 16, 16), (200, 128, 128, 8, 8),
+]
+
+
+def _rel(a, b):
+    return float((a.double().cpu() - b.double().cpu()).abs().max() / max(float(b.double().abs().max()), 1e-30))
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_wino_forward_and_backward_data(shape):
+    from clsurvey_amd import ops
+    N, C, K, H, W = shape
+    gen = np.random.RandomState(N * 7 + C + K + H)
+    x = torch.from_numpy(gen.standard_normal((N, C, H, W)).astype(np.float32))
+    w = torch.from_numpy((gen.standard_normal((K, C, 3, 3)) * (2.0 / (9 * C)) ** 0.5).astype(np.float32))
+    b = torch.from_numpy((gen.standard_normal((K,)) * 0.1).astype(np.float32))
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+    big = N >= 100
+    # judge: torch CPU for the small shapes, the direct MFMA kernels (themselves pinned against torch CPU) for the large ones
+    if big:
+        y_ref, z_ref = ops.conv3x3_fwd(xd, wd, bd, True), ops.conv3x3_fwd(xd, wd, bd, False)
+    else:
+        z_ref = F.conv2d(x, w, b, padding=1)
+        y_ref = F.relu(z_ref)
+    assert _rel(ops.conv3x3_wino_fwd(xd, wd, bd, relu=False), z_ref) <= 2e-5
+    y = ops.conv3x3_wino_fwd(xd, wd, bd, relu=True)
+    assert _rel(y, y_ref) <= 2e-5
+    # fused ReLU + 2x2 max-pool: value within rounding; the arg-max code must name an element that attains the maximum
+    yp, idx = ops.conv3x3_wino_fwd(xd, wd, bd, relu=True, pool=True)
+    yc = y_ref.cuda() if not big else y_ref
+    win = yc.reshape(N, K, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(N, K, H // 2, W // 2, 4)
+    assert _rel(yp, win.max(4).values) <= 2e-5
+    picked = torch.gather(win, 4, idx.long().unsqueeze(-1)).squeeze(-1)
+    assert float((picked - win.max(4).values).abs().max()) <= 2e-5 * float(yc.abs().max())
+    assert int(idx.max()) <= 3
+    if C % 32 or K < 16:
+        return              # backward-data runs the same kernel with the channel roles swapped: its own shape domain
+    # backward-data (+ ReLU mask of the producing layer), plain and from the pooled gradient
+    dy = torch.from_numpy(gen.standard_normal((N, K, H, W)).astype(np.float32))
+    msrc = torch.from_numpy(gen.standard_normal((N, C, H, W)).astype(np.float32))
+    dyd, md = dy.cuda(), msrc.cuda()
+    if big:
+        dx_ref = ops.conv3x3_bwd_data(dyd, wd)
+    else:
+        dx_ref = F.conv_transpose2d(dy, w, padding=1)
+    assert _rel(ops.conv3x3_wino_bwd_data(dyd, wd), dx_ref) <= 2e-5
+    dxm = ops.conv3x3_wino_bwd_data(dyd, wd, relu_src=md)
+    assert _rel(dxm, dx_ref.cuda() * (md > 0)) <= 2e-5
+    dyp = torch.from_numpy(gen.standard_normal((N, K, H // 2, W // 2)).astype(np.float32)).cuda()
+    code = torch.from_numpy(gen.randint(0, 4, size=(N, K, H // 2, W // 2)).astype(np.uint8)).cuda()
+    dy_full = ops.maxpool2_bwd(dyp, code)
+    ref_u = ops.conv3x3_bwd_data(dy_full, wd, md)
+    assert _rel(ops.conv3x3_wino_bwd_data(dyp, wd, relu_src=md, idx=code), ref_u) <= 2e-5
+
+
+def test_wino_refuses_shapes_outside_its_domain():
+    from clsurvey_amd import ops, _lib
+    x = torch.zeros(1, 3, 8, 8, device="cuda")
+    with pytest.raises(_lib.ClhipError):
+        ops.conv3x3_wino_fwd(x, torch.zeros(32, 3, 3, 3, device="cuda"), torch.zeros(32, device="cuda"))
+    x = torch.zeros(1, 16, 13, 13, device="cuda")
+    with pytest.raises(_lib.ClhipError):
+        ops.conv3x3_wino_fwd(x, torch.zeros(32, 16, 3, 3, device="cuda"), torch.zeros(32, device="cuda"))
