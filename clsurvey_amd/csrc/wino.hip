@@ -7,8 +7,8 @@
 // Summed over input channels the element-wise product becomes 16 independent GEMMs  M_f[k][tile] = sum_c U_f[k][c] V_f[c][tile],
 // i.e. 16 MFMAs per (32 out-channels x 32 TILES = 128 pixels x 2 in-channels): 2.25x fewer matrix instructions per pixel.
 // Everything else is fused into the one kernel (nothing but x, the pre-transformed weights and y touches HBM):
-//   * U = G g G^T is formed once per call by a small kernel into [k-tile][chunk][f][c][k] (the LDS image of a chunk, so
-//     that staging a chunk's weights is a straight 32 KB copy),
+//   * U = G g G^T is formed once per call by a small kernel into [k-tile][chunk][c][k][f] (the LDS image of a chunk, so
+//     that staging a chunk's weights is a straight 40 KB copy and a lane reads its 16 frequencies with 4 ds_read_b128),
 //   * the input transform B^T d B runs in registers: a lane owns one tile of one channel (MFMA B operand: lane = tile,
 //     k-pair half = channel), reads its 4x4 window from the LDS halo plane (8 ds_read_b64) and forms the 16 frequency
 //     values with 32 adds — next to 16 MFMAs (1024 matrix cycles) that is ~12 % extra issue time,
@@ -26,7 +26,9 @@ namespace {
 
 constexpr int WKT = 64;      // out channels per block
 constexpr int WCK = 8;       // in channels per chunk
-constexpr int W_FLOATS = 16 * WCK * WKT;          // 8192 floats = 32 KB: U tile of one chunk [f][c][k]
+constexpr int WFP = 20;      // floats per (channel, out-channel) in the U tile: 16 frequencies + 4 pad — an 80-byte stride makes
+                             // the 16-byte reads of 16 consecutive lanes land on 64 distinct LDS banks
+constexpr int W_FLOATS = WCK * WKT * WFP;         // 10240 floats = 40 KB: U tile of one chunk [c][k][f]
 
 template <int TCB, int TRB, int NIMG>
 struct WGeoW {
@@ -38,7 +40,7 @@ struct WGeoW {
     static constexpr int BUF = W_FLOATS + X_FLOATS;
 };
 
-// U[kt][chunk][f][c][k] = (G g G^T)[f] of g = w[k][c] (MODE 0) or of the 180-degree-rotated w[c][k] (MODE 1: backward-data,
+// U[kt][chunk][c][k][f (16 of WFP)] = (G g G^T)[f] of g = w[k][c] (MODE 0) or of the 180-degree-rotated w[c][k] (MODE 1: backward-data,
 // where the kernel's "input channels" are the convolution's output channels).  Ko / Ci: channel counts as the KERNEL sees them.
 __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Ko, int Ci,
                                                           int mode, int n_chunks) {
@@ -66,15 +68,11 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
             t[2][s] = 0.5f * (g[0][s] - g[1][s] + g[2][s]);
             t[3][s] = g[2][s];
         }
-        float* dst = U + ((size_t)(kt * n_chunks + chunk) * 16 * WCK + c_l) * WKT + k_l;
+        float4* dst = reinterpret_cast<float4*>(U + (((size_t)(kt * n_chunks + chunk) * WCK + c_l) * WKT + k_l) * WFP);
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const float u0 = t[a][0], u1 = 0.5f * (t[a][0] + t[a][1] + t[a][2]), u2 = 0.5f * (t[a][0] - t[a][1] + t[a][2]), u3 = t[a][2];
-            dst[(size_t)(4 * a + 0) * WCK * WKT] = u0;
-            dst[(size_t)(4 * a + 1) * WCK * WKT] = u1;
-            dst[(size_t)(4 * a + 2) * WCK * WKT] = u2;
-            dst[(size_t)(4 * a + 3) * WCK * WKT] = u3;
-        }
+        for (int a = 0; a < 4; ++a)
+            dst[a] = make_float4(t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]), t[a][2]);
+        dst[4] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
@@ -112,24 +110,22 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(
     // weights: straight copy of 2048 float4; activations: one scalar per halo-plane element (raw buffer loads: padding,
     // image tails and channel tails read 0 through the OFFSET predicate — never a branch, never a select on a loaded value).
     // A chunk's staging is cut into UNITS of one instruction each, issued one per MFMA slot (see the pipeline below).
-    constexpr int W_IT = W_FLOATS / 4 / 256;                         // 8
+    constexpr int W_IT = W_FLOATS / 4 / 256;                         // 10
     constexpr int X_IT = (G::X_FLOATS + 255) / 256;
     constexpr int NU = W_IT + X_IT;
     float4 wv[W_IT];
     float xr[X_IT];
     unsigned xi[UNPOOL ? X_IT : 1];
-    int xoff[X_IT], xcl[X_IT], xcode[UNPOOL ? X_IT : 1];
+    int xoff[X_IT], xcode[UNPOOL ? X_IT : 1];
 #pragma unroll
     for (int j = 0; j < X_IT; ++j) {
         const int e = tid + 256 * j;
         xoff[j] = CLHIP_OOB;
-        xcl[j] = 1 << 20;                                            // "channel" of a slot past the plane: never < Cin
         if (e < G::X_FLOATS) {
             const int cl = e / G::PLANE, rem = e - cl * G::PLANE;
             const int col = rem % G::PW, rr = rem / G::PW;
             const int row = rr % G::PR, nb = rr / G::PR;
             const int n = n0 + nb, h = h0 - 1 + row, w = w0 - 1 + col;
-            xcl[j] = cl;
             if (n < N && h >= 0 && h < H && w >= 0 && w < W) {
                 if constexpr (UNPOOL) {
                     xoff[j] = (int)(((size_t)nb * Cin + cl) * plane_in) + (h >> 1) * Wi + (w >> 1);     // ELEMENT offset
@@ -140,22 +136,20 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(
             }
         }
     }
-    // unit u of chunk `chunk` -> staging registers.  Chunks past the end: the weight tile of the last chunk is re-read
-    // (never used), the activation offsets fail the channel test and read 0.
+    // unit u of chunk `chunk` -> staging registers.  Cin is a whole number of chunks (clhip_internal_wino_ok), so a live
+    // chunk needs no channel predicate; the two prefetches past the last chunk re-read it (never used).
     auto load_unit = [&](int u, int chunk) {
         const int cw = chunk < n_chunks ? chunk : n_chunks - 1;
         if (u < W_IT) {
             wv[u] = clhip_buf_load4(rs_u, (tid + 256 * u) * 16, cw * W_FLOATS * 4);
         } else {
             const int j = u - W_IT;
-            const int c0 = chunk * WCK;
             const int xb = cw * WCK * (int)plane_in;                 // wave-uniform scalar offset
-            const bool ok = c0 + xcl[j] < Cin;                       // per lane: goes into the vector offset only
             if constexpr (UNPOOL) {
-                xr[j] = clhip_buf_load(rs_x, ok && xoff[j] != CLHIP_OOB ? xoff[j] * 4 : CLHIP_OOB, xb * 4);
-                xi[j] = clhip_buf_load_u8(rs_i, ok ? xoff[j] : CLHIP_OOB, xb);
+                xr[j] = clhip_buf_load(rs_x, xoff[j] != CLHIP_OOB ? xoff[j] * 4 : CLHIP_OOB, xb * 4);
+                xi[j] = clhip_buf_load_u8(rs_i, xoff[j], xb);
             } else {
-                xr[j] = clhip_buf_load(rs_x, ok ? xoff[j] : CLHIP_OOB, xb * 4);
+                xr[j] = clhip_buf_load(rs_x, xoff[j], xb * 4);
             }
         }
     };
@@ -177,7 +171,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(
     const int t_idx = 32 * wp + li;
     const int t_img = t_idx / (TRB * TCB), t_row = (t_idx / TCB) % TRB, t_col = t_idx % TCB;
     const int d_off = W_FLOATS + kk * G::PLANE + (t_img * G::PR + 2 * t_row) * G::PW + 2 * t_col;     // even: 8-byte aligned
-    const int a_off = kk * WKT + wk * 32 + li;
+    const int a_off = (kk * WKT + wk * 32 + li) * WFP;
 
     floatx16 acc[16];
 #pragma unroll
@@ -186,33 +180,40 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(
         for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
 
     // ------------------------------------------------------------------ pipeline
-    // One wave per SIMD: nothing hides a stall, so every piece of non-matrix work rides in the shadow of an MFMA "slot"
-    // (64 matrix cycles each, order pinned by sched_barrier): while pair p's 16 MFMAs issue, slot f
-    //   * reads weight fragment f of pair p + 1                                    (1 ds_read_b32),
-    //   * f < 8:  reads one 8-byte half-row of pair p + 1's 4x4 window              (1 ds_read_b64),
-    //   * f = 8..11 / 12..15: row / column half of the input transform B^T d B of pair p + 1 (4 v_add each),
-    //   * pair 0: LDS writes of chunk c + 1, pairs 1-2: global loads of chunk c + 2   (one unit per slot),
+    // One wave per SIMD: nothing hides a stall, and on this part every VALU / LDS instruction issues from the port the
+    // fp32 MFMAs use (ablation on 512->512 @8x8: MFMAs alone 246 us, + transforms 63, + LDS reads 70, + staging 40), so the
+    // loop is written to need FEW instructions per MFMA and each of them rides behind one MFMA "slot" (order pinned by
+    // sched_barrier): while pair p's 16 MFMAs issue, slot f
+    //   * f < 4:      reads one row of pair p + 1's 4x4 window                       (2 ds_read_b64),
+    //   * f = 4..7:   reads four weight frequencies of pair p + 1                    (1 ds_read_b128),
+    //   * f = 8..11 / 12..15: row / column half of the input transform B^T d B of pair p + 1 (packed fp32 adds),
+    //   * pair 0: LDS writes of chunk c + 1, pairs 1-2: global loads of chunk c + 2    (one or two units per slot),
     // with ONE barrier per chunk behind the first MFMA of the last pair (every read of the current buffer has been issued
     // and waited for by then; the writes of chunk c + 1 were issued during pair 0).
+    typedef float f2 __attribute__((ext_vector_type(2)));
     constexpr int NP = WCK / 2;
-    float av[2][16], vv[2][16], tt[16];
-    float2 dn[8];
-    auto rd_a = [&](const float* buf, int pair, int f, int slot) { av[slot][f] = buf[a_off + 2 * pair * WKT + f * WCK * WKT]; };
-    auto rd_d = [&](const float* buf, int pair, int h) {
-        dn[h] = *reinterpret_cast<const float2*>(buf + d_off + 2 * pair * G::PLANE + (h >> 1) * G::PW + 2 * (h & 1));
+    floatx4 av[2][4];            // [pipeline slot][frequency quad]
+    float vv[2][16];
+    f2 dlo[4], dhi[4], tlo[4], thi[4];       // window rows / row-transformed rows as (col 0, col 1) and (col 2, col 3)
+    auto rd_a = [&](const float* abase, int pair, int q, int slot) {
+        av[slot][q] = *reinterpret_cast<const floatx4*>(abase + 2 * pair * WKT * WFP + 4 * q);
     };
-    auto d_at = [&](int r, int j) { return (j & 1) ? dn[2 * r + (j >> 1)].y : dn[2 * r + (j >> 1)].x; };
-    auto row_tf = [&](int j) {           // column j of t = B^T d
-        tt[0 * 4 + j] = d_at(0, j) - d_at(2, j);
-        tt[1 * 4 + j] = d_at(1, j) + d_at(2, j);
-        tt[2 * 4 + j] = d_at(2, j) - d_at(1, j);
-        tt[3 * 4 + j] = d_at(1, j) - d_at(3, j);
+    auto rd_d = [&](const float* dbase, int pair, int r) {
+        dlo[r] = *reinterpret_cast<const f2*>(dbase + 2 * pair * G::PLANE + r * G::PW);
+        dhi[r] = *reinterpret_cast<const f2*>(dbase + 2 * pair * G::PLANE + r * G::PW + 2);
     };
-    auto col_tf = [&](int i, int slot) { // row i of V = t B
-        vv[slot][4 * i + 0] = tt[4 * i + 0] - tt[4 * i + 2];
-        vv[slot][4 * i + 1] = tt[4 * i + 1] + tt[4 * i + 2];
-        vv[slot][4 * i + 2] = tt[4 * i + 2] - tt[4 * i + 1];
-        vv[slot][4 * i + 3] = tt[4 * i + 1] - tt[4 * i + 3];
+    auto row_tf = [&](int i) {           // row i of t = B^T d, both column pairs
+        if (i == 0) { tlo[0] = dlo[0] - dlo[2]; thi[0] = dhi[0] - dhi[2]; }
+        if (i == 1) { tlo[1] = dlo[1] + dlo[2]; thi[1] = dhi[1] + dhi[2]; }
+        if (i == 2) { tlo[2] = dlo[2] - dlo[1]; thi[2] = dhi[2] - dhi[1]; }
+        if (i == 3) { tlo[3] = dlo[1] - dlo[3]; thi[3] = dhi[1] - dhi[3]; }
+    };
+    auto col_tf = [&](int i, int slot) { // row i of V = t B:  (V0, V3) = (t0, t1) - (t2, t3);  (V1, V2) = (t1 + t2, t2 - t1)
+        const f2 o = tlo[i] - thi[i];
+        vv[slot][4 * i + 0] = o.x;
+        vv[slot][4 * i + 3] = o.y;
+        vv[slot][4 * i + 1] = tlo[i].y + thi[i].x;
+        vv[slot][4 * i + 2] = thi[i].x - tlo[i].y;
     };
 
 #pragma unroll
@@ -223,48 +224,42 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(
     for (int u = 0; u < NU; ++u) load_unit(u, 1);
     __syncthreads();
 #pragma unroll
-    for (int f = 0; f < 16; ++f) rd_a(lds, 0, f, 0);
+    for (int q = 0; q < 4; ++q) rd_a(lds + a_off, 0, q, 0);
 #pragma unroll
-    for (int h = 0; h < 8; ++h) rd_d(lds, 0, h);
+    for (int r = 0; r < 4; ++r) rd_d(lds + d_off, 0, r);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) row_tf(j);
+    for (int i = 0; i < 4; ++i) row_tf(i);
 #pragma unroll
     for (int i = 0; i < 4; ++i) col_tf(i, 0);
 
     static_assert(NU <= 32, "two store units per slot of pair 0, one load unit per slot of pairs 1-2");
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
         const int bo = (chunk & 1) * G::BUF, bn = G::BUF - bo;
-        const float* cur = lds + bo;
-        const float* nxt = lds + bn;
+        const float* a_cur = lds + bo + a_off;
+        const float* d_cur = lds + bo + d_off;
+        const float* a_nxt = lds + bn + a_off;
+        const float* d_nxt = lds + bn + d_off;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            const float* nb = (p + 1 < NP) ? cur : nxt;
+            const float* ab = (p + 1 < NP) ? a_cur : a_nxt;
+            const float* db = (p + 1 < NP) ? d_cur : d_nxt;
             const int np = (p + 1) % NP, ns = (p + 1) & 1, cs = p & 1;
 #pragma unroll
             for (int f = 0; f < 16; ++f) {
-                acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cs][f], vv[cs][f], acc[f], 0, 0, 0);
+                acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cs][f >> 2][f & 3], vv[cs][f], acc[f], 0, 0, 0);
                 if (p == NP - 1 && f == 0) __syncthreads();
-#ifndef WINO_ABL_NOLDS
-                rd_a(nb, np, f, ns);
-#endif
-#ifndef WINO_ABL_NOLDS
-                if (f < 8) rd_d(nb, np, f);
-#endif
-                if (f < 8) {}
-#ifndef WINO_ABL_NOTF
+                if (f < 4) rd_d(db, np, f);                 // (window first: the transform at slot 8 needs it landed)
+                else if (f < 8) rd_a(ab, np, f - 4, ns);
                 else if (f < 12) row_tf(f - 8);
                 else col_tf(f - 12, ns);
-#endif
                 // (no inner loops over units: every register-array index must be a constant once p and f are unrolled,
                 // otherwise the staging arrays are demoted to LDS-backed storage and each load is waited for at once)
-#ifndef WINO_ABL_NOSTAGE
                 if (p == 0) {
                     if (2 * f < NU) store_unit(2 * f, bn);
                     if (2 * f + 1 < NU) store_unit(2 * f + 1, bn);
                 } else if (p <= 2) {
                     if ((p - 1) * 16 + f < NU) load_unit((p - 1) * 16 + f, chunk + 2);
                 }
-#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
