@@ -470,7 +470,7 @@ def _base_model_file(root, name="small_VGG9_cl_128_128"):
 
 
 def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epochs=70,
-               pair_sizes=(2000, 500, 500), pair_epochs=2):
+               pair_sizes=(2000, 500, 500), pair_epochs=3, pair_batch=50):
     """BASELINE.json's second metric ('full-sweep wall-clock'), two measurements.
 
     `gpu_s`: what framework/main.py runs for `small_VGG9_cl_128_128 --method_name EWC --test` with the reference's defaults
@@ -536,7 +536,7 @@ def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epoch
             from oracle import sweep_ref
             proot, croot = os.path.join(root, "pair_gpu"), os.path.join(root, "pair_cpu")
             spec = "2,20,%d,%d,%d,64" % tuple(pair_sizes)
-            pcommon = [model, "--num_epochs", str(pair_epochs), "--batch_size", "200", "--saving_freq", "1000", "--synthetic", spec,
+            pcommon = [model, "--num_epochs", str(pair_epochs), "--batch_size", str(pair_batch), "--saving_freq", "1000", "--synthetic", spec,
                        "--device", "cuda:%d" % dev_index]
             _base_model_file(proot)
             with contextlib.redirect_stdout(quiet):
@@ -550,11 +550,12 @@ def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epoch
             si_dir = os.path.join(proot, "train", "synthetic_tiny_imagenet", "SI", model, "gridsearch", "first_task_basemodel")
             (trained_as,) = os.listdir(si_dir)
             os.rename(os.path.join(si_dir, trained_as), os.path.join(si_dir, driver.first_task_modelname(SimpleNamespace(
-                num_epochs=pair_epochs, batch_size=200, lr_grid=[1e-2], weight_decay=0, model_name=model))))
+                num_epochs=pair_epochs, batch_size=pair_batch, lr_grid=[1e-2], weight_decay=0, model_name=model))))
             fixed = ["--lr_grid", "1e-2", "--max_attempts_per_task", "1", "--method_name", "EWC", "--test"]
             pair = {"what": "task 2 of a 2-task sequence (%d/%d/%d images), from the same first-task model: LR grid {1e-2}, %d-epoch "
-                            "cap, Fisher pass, ONE stability-decay attempt (kept whatever it scores), both models evaluated"
-                            % (tuple(pair_sizes) + (pair_epochs,))}
+                            "cap, batch %d (so that the few epochs hold enough SGD steps to leave chance), Fisher pass, ONE "
+                            "stability-decay attempt (kept whatever it scores), both models evaluated"
+                            % (tuple(pair_sizes) + (pair_epochs, pair_batch))}
             for sub in ("data", "models", os.path.join("train", "synthetic_tiny_imagenet", "SI")):
                 shutil.copytree(os.path.join(proot, sub), os.path.join(croot, sub))
             with contextlib.redirect_stdout(quiet), _PassCounter(pair_sizes[0]) as pcounts:

@@ -119,6 +119,10 @@ int clhip_internal_wgrad_reduce_multi(const clhip_wgrad_job* jobs, int n, hipStr
 // wino.hip: 3x3 convolution by Winograd F(2x2, 3x3) (forward / backward-data); see the file's header
 bool clhip_internal_wino_ok(int Cin, int Cout, int H, int W);
 size_t clhip_internal_wino_ws(int Cin, int Cout);
+bool clhip_internal_wino_wgrad_ok(int C, int K, int H, int W);
+size_t clhip_internal_wino_wgrad_ws(int N, int C, int K, int H, int W);
+int clhip_internal_wino_wgrad_partial(const float* x, const float* dy, const uint8_t* unpool_idx, float* dw, float* db, int N, int C,
+                                      int K, int H, int W, void* ws, size_t ws_bytes, hipStream_t s, clhip_wgrad_job* job);
 int clhip_internal_wino_conv(int mode, const float* in, const float* w, const float* bias, const float* mask_src, float* out,
                              uint8_t* pool_idx, int unpool, int N, int Cin, int Cout, int H, int W, int relu, void* ws,
                              size_t ws_bytes, hipStream_t s);

@@ -37,7 +37,7 @@ struct LayerPlan {
     size_t z_off;          // bn: float offset of the convolution output (pre-BatchNorm) in ws
     size_t stat_off;       // bn: float offset of save_mean[cout], save_invstd[cout]
     float* rmean; float* rvar; float bn_momentum, bn_eps;
-    int wino_f, wino_d;        // forward / backward-data through Winograd F(2x2,3x3) (wino.hip) instead of the direct kernels
+    int wino_f, wino_d, wino_w;  // forward / backward-data / weight gradient through Winograd F(2x2,3x3) (wino.hip) instead of the direct kernels
     int wg3;                   // weight gradient on the 3x3 kernel (else the general gather-GEMM)
     size_t wg_off, wg_bytes;   // this layer's own weight-gradient slabs (3x3 layers; reduced for all layers at once)
     const float* extra_grad;   // added to the gradient w.r.t. this layer's input (side branches: clhip_net_set_input_grad)
@@ -216,6 +216,18 @@ int clhip_net_create(const clhip_layer_desc* descs, int n_layers, int max_batch,
                 auto units = [&](int kout) { return ((tiles + 31) / 32) * ((kout + 31) / 32); };
                 L.wino_f = clhip_internal_wino_ok(L.cin, L.cout, L.h, L.w) && units(L.cout) >= WINO_MIN_UNITS;
                 L.wino_d = i > 0 && clhip_internal_wino_ok(L.cout, L.cin, L.h, L.w) && units(L.cin) >= WINO_MIN_UNITS;
+                // weight gradient: the reduction (tiles) splits over ~256 blocks per 64x64 (k, c) tile; each block needs a
+                // few 16-tile stages to amortise its 256-accumulator epilogue (measured: 12.5 stages per block 1.44x, 3.1 0.6x)
+                if (clhip_internal_wino_wgrad_ok(L.cin, L.cout, L.h, L.w)) {
+                    const int kc = (L.cin / 64) * (L.cout / 64), splits = (256 + kc - 1) / kc;
+                    const long long stages = (long long)max_batch * ((L.w / 2 + (L.w >= 16 ? 7 : 3)) / (L.w >= 16 ? 8 : 4)) *
+                                             ((L.h / 2 + (L.w >= 16 ? 1 : 3)) / (L.w >= 16 ? 2 : 4));
+                    L.wino_w = stages >= 8LL * splits;
+                    if (L.wino_w && L.wg3) {          // its slabs live in this layer's weight-gradient region
+                        const size_t ww = clhip_internal_wino_wgrad_ws(max_batch, L.cin, L.cout, L.h, L.w);
+                        if (ww > L.wg_bytes) { wg_total += align_up(ww, 256) - L.wg_bytes; L.wg_bytes = align_up(ww, 256); }
+                    }
+                }
                 if (L.wino_f && clhip_internal_wino_ws(L.cin, L.cout) > wino_ws) wino_ws = clhip_internal_wino_ws(L.cin, L.cout);
                 if (L.wino_d && clhip_internal_wino_ws(L.cout, L.cin) > wino_ws) wino_ws = clhip_internal_wino_ws(L.cout, L.cin);
             }
@@ -690,6 +702,12 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
             // layer: the small-C kernel; others: the 16-byte staging paths).  The 4x larger un-pooled tensor and the
             // clhip_maxpool2_bwd launch disappear.
             rc = on_side(i, gin_buf, [&](void* st) {
+                if (defer && L.wino_w) {
+                    const int r = clhip_internal_wino_wgrad_partial(xin, gin, idx + L.idx_off, grads + L.w_off, grads + L.b_off, N, L.cin,
+                                                                    L.cout, L.h, L.w, base + p->off_wg + L.wg_off, L.wg_bytes,
+                                                                    as_stream(st), &jobs[n_jobs]);
+                    if (r != CLHIP_ENOTSUP && r != CLHIP_ENOSPC) return r;
+                }
                 if (defer)
                     return clhip_internal_conv3x3_wgrad_partial(xin, gin, idx + L.idx_off, grads + L.w_off, grads + L.b_off, N, L.cin,
                                                                 L.cout, L.h, L.w, base + p->off_wg + L.wg_off, L.wg_bytes, st,
@@ -728,6 +746,12 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
         }
         if (!wdone) {
             rc = on_side(i, gy_buf, [&](void* st) {
+                if (L.wg3 && defer && L.wino_w) {
+                    const int r = clhip_internal_wino_wgrad_partial(xin, gy, nullptr, grads + L.w_off, grads + L.b_off, N, L.cin, L.cout,
+                                                                    L.h, L.w, base + p->off_wg + L.wg_off, L.wg_bytes, as_stream(st),
+                                                                    &jobs[n_jobs]);
+                    if (r != CLHIP_ENOTSUP && r != CLHIP_ENOSPC) return r;
+                }
                 if (L.wg3 && defer)
                     return clhip_internal_conv3x3_wgrad_partial(xin, gy, nullptr, grads + L.w_off, grads + L.b_off, N, L.cin, L.cout, L.h,
                                                                 L.w, base + p->off_wg + L.wg_off, L.wg_bytes, st, &jobs[n_jobs]);

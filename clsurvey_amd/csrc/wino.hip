@@ -316,6 +316,253 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// dL/dg = G^T [ (A dY A^T) .* (B^T d B) ] G  summed over tiles and images: 16 GEMMs  M_f[k][c] = sum_tiles DY_f[k][tile] V_f[c][tile]
+// with the TILES as the reduction dimension (two per MFMA): D rows = 32 out-channels (A operand: lane = k, half = tile of the
+// pair), D cols = 32 in-channels (B operand: lane = c).  Both operands are transformed in registers from raw LDS tiles —
+// a lane reads the 2x2 dy tile of its out-channel (2 ds_read_b64) and the 4x4 x window of its in-channel (8 ds_read_b64)
+// and forms 16 + 16 frequency values with 12 + 32 adds next to 16 MFMAs; the direct kernel (conv3x3_wgrad.hip) issues 36
+// MFMAs for the same two tiles.  The reduction over (image, tile) is split across blocks exactly like the direct kernel's:
+// every block applies the output transform G^T M G in registers and writes a partial [9][K][C] (+ [K] bias sums) slab
+// of the SAME format, so the fixed-order slab reduction (wgrad_reduce_multi) serves both.
+// Signs: A dY A^T has rows / columns 3 negated (A = [[1,0],[1,1],[1,-1],[0,-1]]); the kernel accumulates with the un-negated
+// values and flips M_f for f in row 3 xor column 3 inside the output transform.
+template <int TCS, int TRS, int NIS>
+struct WGeoG {
+    static constexpr int TILES = TCS * TRS * NIS;          // 16 tiles per stage
+    static_assert(TILES == 16, "16 tiles per stage");
+    static constexpr int DW = 2 * TCS, DR = 2 * TRS;       // dy tile of one image: DR rows x DW cols
+    static constexpr int DPIX = NIS * DR * DW;             // 64 pixels
+    static constexpr int LDP = DPIX + 2;                   // dy row stride per out-channel (8-byte units odd => conflict-free b64)
+    static constexpr int PW = DW + 2, PR = DR + 2;
+    static constexpr int PLANE = NIS * PR * PW;
+    static constexpr int PLANEP = (PLANE % 4 == 2) ? PLANE : PLANE + 2;      // even, PLANEP / 2 odd
+    static_assert((LDP / 2) % 2 == 1 && (PLANEP / 2) % 2 == 1, "lane strides must be odd in 8-byte units");
+    static constexpr int DY_FLOATS = WKT * LDP, X_FLOATS = WKT * PLANEP;
+    static constexpr int BUF = DY_FLOATS + X_FLOATS;
+};
+
+template <int TCS, int TRS, int NIS, bool UNPOOL>
+__global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, const uint8_t* __restrict__ unpool_idx,
+    int N, int C, int K, int H, int W, int tiles_w, int tiles_h, int total_stages, int splits, int c_tiles, size_t slab_stride) {
+    using G = WGeoG<TCS, TRS, NIS>;
+    __shared__ __attribute__((aligned(16))) float lds[2 * G::BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave & 1, wc = wave >> 1;
+    const int li = lane & 31, kk = lane >> 5;
+    const int split = blockIdx.x % splits, tile = blockIdx.x / splits;
+    const int ct = tile % c_tiles, kt = tile / c_tiles;
+    const int k0 = kt * WKT, c0 = ct * WKT;
+    const int per = total_stages / splits, extra = total_stages % splits;
+    const int st_begin = split * per + min(split, extra);
+    const int st_end = st_begin + per + (split < extra ? 1 : 0);
+    const int Hd = UNPOOL ? H >> 1 : H, Wd = UNPOOL ? W >> 1 : W;          // geometry of the tensor `dy` points at
+    const int plane_hw = H * W, plane_dy = Hd * Wd;
+
+    // ------------------------------------------------------------------ staging units (one scalar raw buffer load each)
+    // dy: thread -> pixel q = tid & 63 of out-channel (tid >> 6) + 4 j;  x: thread -> halo-plane position tid % PLANE of
+    // in-channel (tid / PLANE) + CPT j  (threads past CPT * PLANE idle): every per-unit index is base + j * constant, so the
+    // staging needs a handful of registers instead of six index arrays
+    constexpr int DY_IT = WKT * G::DPIX / 256;                        // 16
+    constexpr int CPT = 256 / G::PLANE;                               // channels staged per pass
+    static_assert(CPT >= 1 && WKT % CPT == 0, "whole passes over the 64 in-channels");
+    constexpr int X_IT = WKT / CPT;
+    constexpr int NU = DY_IT + X_IT;
+    float dyr[DY_IT], xr[X_IT];
+    unsigned dyi[UNPOOL ? DY_IT : 1];
+    const int dq = tid & 63, dkl = tid >> 6;
+    const int d_nb = dq / (G::DR * G::DW), d_r = (dq / G::DW) % G::DR, d_c = dq % G::DW;
+    const int dy_e0 = UNPOOL ? ((d_nb * K + dkl) * plane_dy + (d_r >> 1) * Wd + (d_c >> 1)) : ((d_nb * K + dkl) * plane_dy + d_r * W + d_c);
+    const int dy_dst0 = dkl * G::LDP + dq;
+    const int d_code = ((d_r & 1) << 1) | (d_c & 1);
+    const bool x_thr = tid < CPT * G::PLANE;
+    const int x_cl = tid / G::PLANE, x_rem = tid - x_cl * G::PLANE;
+    const int x_col = x_rem % G::PW, x_rr = x_rem / G::PW, x_row = x_rr % G::PR, x_nb = x_rr / G::PR;
+    const int x_e0 = (x_nb * C + x_cl) * plane_hw + x_row * W + x_col;     // relative to the (image, halo origin) base
+    const int x_dst0 = G::DY_FLOATS + x_cl * G::PLANEP + x_rem;
+    // stage -> (image group, tile-row block, tile-col block)
+    int ld_n0 = 0, ld_h0 = 0, ld_w0 = 0;
+    bool dy_ok = false, x_ok = false;
+    __amdgpu_buffer_rsrc_t rs_dy = clhip_rsrc(dy, 0), rs_x = clhip_rsrc(x, 0), rs_di = clhip_rsrc(x, 0);
+    auto begin_stage = [&](int st) {
+        const bool live = st < st_end;
+        const int s = live ? st : st_begin;
+        const int bw = s % tiles_w, bh = (s / tiles_w) % tiles_h, ng = s / (tiles_w * tiles_h);
+        ld_n0 = ng * NIS; ld_h0 = bh * G::DR; ld_w0 = bw * G::DW;
+        const int org_dy = UNPOOL ? (ld_h0 >> 1) * Wd + (ld_w0 >> 1) : ld_h0 * W + ld_w0;
+        const float* dyb = dy + ((size_t)ld_n0 * K + k0) * plane_dy + org_dy;
+        const long long dy_left = ((long long)(N - ld_n0) * K - k0) * plane_dy - org_dy;
+        rs_dy = clhip_rsrc(dyb, live && dy_left > 0 ? (size_t)dy_left * 4 : 0);
+        if constexpr (UNPOOL) rs_di = clhip_rsrc(unpool_idx + ((size_t)ld_n0 * K + k0) * plane_dy + org_dy, live && dy_left > 0 ? (size_t)dy_left : 0);
+        const long long org_x = (long long)ld_h0 * W + ld_w0 - W - 1;
+        const float* xb = x + ((size_t)ld_n0 * C + c0) * plane_hw + org_x;
+        const long long x_left = ((long long)(N - ld_n0) * C - c0) * plane_hw - org_x;
+        rs_x = clhip_rsrc(xb, live && x_left > 0 ? (size_t)x_left * 4 : 0);
+        dy_ok = ld_n0 + d_nb < N && ld_h0 + d_r < H && ld_w0 + d_c < W;
+        const int h = ld_h0 - 1 + x_row, w = ld_w0 - 1 + x_col;
+        x_ok = x_thr && ld_n0 + x_nb < N && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+    };
+    auto load_unit = [&](int u) {
+        if (u < DY_IT) {
+            const int e = dy_e0 + u * 4 * plane_dy;
+            dyr[u] = clhip_buf_load(rs_dy, dy_ok ? e * 4 : CLHIP_OOB, 0);
+            if constexpr (UNPOOL) dyi[u] = clhip_buf_load_u8(rs_di, dy_ok ? e : CLHIP_OOB, 0);
+        } else {
+            const int j = u - DY_IT;
+            xr[j] = clhip_buf_load(rs_x, x_ok ? (x_e0 + j * CPT * plane_hw) * 4 : CLHIP_OOB, 0);
+        }
+    };
+    auto store_unit = [&](int u, int bo) {
+        if (u < DY_IT) {
+            float v = dyr[u];
+            if constexpr (UNPOOL) v = ((int)dyi[u] == d_code) ? v : 0.f;
+            lds[bo + dy_dst0 + u * 4 * G::LDP] = v;
+        } else {
+            const int j = u - DY_IT;
+            if (x_thr) lds[bo + x_dst0 + j * CPT * G::PLANEP] = xr[j];
+        }
+    };
+
+    floatx16 acc[16];
+#pragma unroll
+    for (int f = 0; f < 16; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+    float bsum = 0.f;
+
+    // lane operands: A = dy tile of out-channel wk*32 + li, B = x window of in-channel wc*32 + li; tile t = 2 * step + kk
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    constexpr int NSTEP = G::TILES / 2;
+    const int a_lane = (wk * 32 + li) * G::LDP;
+    const int b_lane = G::DY_FLOATS + (wc * 32 + li) * G::PLANEP;
+    auto tile_off = [&](int step, int& doff, int& xo) {
+        const int t = 2 * step + kk;
+        const int ti = t / (TRS * TCS), tr = (t / TCS) % TRS, tc = t % TCS;
+        doff = (ti * G::DR + 2 * tr) * G::DW + 2 * tc;
+        xo = (ti * G::PR + 2 * tr) * G::PW + 2 * tc;
+    };
+    int doffs[NSTEP], xoffs[NSTEP];
+#pragma unroll
+    for (int sidx = 0; sidx < NSTEP; ++sidx) tile_off(sidx, doffs[sidx], xoffs[sidx]);
+    f2 ya[2], xlo[4], xhi[4];            // raw dy tile rows / x window rows of the NEXT step
+    float av[2][16], vv[2][16];
+    auto rd = [&](const float* buf, int step, int which) {       // which: 0 dy rows, 1..4 x rows
+        if (which == 0) {
+            ya[0] = *reinterpret_cast<const f2*>(buf + a_lane + doffs[step]);
+            ya[1] = *reinterpret_cast<const f2*>(buf + a_lane + doffs[step] + G::DW);
+        } else {
+            const int r = which - 1;
+            xlo[r] = *reinterpret_cast<const f2*>(buf + b_lane + xoffs[step] + r * G::PW);
+            xhi[r] = *reinterpret_cast<const f2*>(buf + b_lane + xoffs[step] + r * G::PW + 2);
+        }
+    };
+    f2 tlo[4], thi[4];
+    auto tf = [&](int part, int slot) {
+        if (part == 0) {                                            // A dY A^T without the negations (see header)
+            const float a = ya[0].x, b = ya[0].y, c = ya[1].x, d = ya[1].y;
+            bsum += (a + b) + (c + d);
+            const float r1p = a + c, r1q = b + d, r2p = a - c, r2q = b - d;
+            float* o = av[slot];
+            o[0] = a;   o[1] = a + b;     o[2] = a - b;     o[3] = b;
+            o[4] = r1p; o[5] = r1p + r1q; o[6] = r1p - r1q; o[7] = r1q;
+            o[8] = r2p; o[9] = r2p + r2q; o[10] = r2p - r2q; o[11] = r2q;
+            o[12] = c;  o[13] = c + d;    o[14] = c - d;    o[15] = d;
+        } else if (part == 1) {                                     // rows of B^T d
+            tlo[0] = xlo[0] - xlo[2]; thi[0] = xhi[0] - xhi[2];
+            tlo[1] = xlo[1] + xlo[2]; thi[1] = xhi[1] + xhi[2];
+        } else if (part == 2) {
+            tlo[2] = xlo[2] - xlo[1]; thi[2] = xhi[2] - xhi[1];
+            tlo[3] = xlo[1] - xlo[3]; thi[3] = xhi[1] - xhi[3];
+        } else {                                                     // rows part - 3 .. of (B^T d) B
+            const int i = part - 3;
+            const f2 o = tlo[i] - thi[i];
+            vv[slot][4 * i + 0] = o.x;
+            vv[slot][4 * i + 3] = o.y;
+            vv[slot][4 * i + 1] = tlo[i].y + thi[i].x;
+            vv[slot][4 * i + 2] = thi[i].x - tlo[i].y;
+        }
+    };
+
+    if (st_begin < st_end) {
+        begin_stage(st_begin);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) load_unit(u);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) store_unit(u, 0);
+        begin_stage(st_begin + 1);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) load_unit(u);
+        __syncthreads();
+#pragma unroll
+        for (int w5 = 0; w5 < 5; ++w5) rd(lds, 0, w5);
+#pragma unroll
+        for (int part = 0; part < 7; ++part) tf(part, 0);
+    }
+    static_assert(NU <= 48, "staging units fit the slots of three steps");
+    for (int st = st_begin; st < st_end; ++st) {
+        const int bo = ((st - st_begin) & 1) * G::BUF, bn = G::BUF - bo;
+        const float* cur = lds + bo;
+        const float* nxt = lds + bn;
+#pragma unroll
+        for (int step = 0; step < NSTEP; ++step) {
+            const float* nb = (step + 1 < NSTEP) ? cur : nxt;
+            const int nstep = (step + 1) % NSTEP, ns = (step + 1) & 1, cs = step & 1;
+#pragma unroll
+            for (int f = 0; f < 16; ++f) {
+                acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cs][f], vv[cs][f], acc[f], 0, 0, 0);
+                if (step == NSTEP - 1 && f == 0) __syncthreads();
+                if (f < 5) rd(nb, nstep, f);
+                else if (f >= 8 && f < 15) tf(f - 8, ns);
+                // staging: LDS writes of stage st + 1 during steps 0-2, global loads of stage st + 2 during steps 3-5
+                if (step < 3) { if (step * 16 + f < NU) store_unit(step * 16 + f, bn); }
+                else if (step < 6) {
+                    if (step == 3 && f == 0) begin_stage(st + 2);
+                    if ((step - 3) * 16 + f < NU) load_unit((step - 3) * 16 + f);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // ------------------------------------------------------------------ output transform  dW = G^T M' G  per accumulator register
+    // register r of lane l = (k = k0 + wk*32 + row(r, l), c = c0 + wc*32 + li); M'_f carries the sign (-1)^{[i == 3] + [j == 3]}
+    float* slab = part + (size_t)split * slab_stride;
+    const int cidx = c0 + wc * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float m[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m[i][j] = ((i == 3) != (j == 3)) ? -acc[4 * i + j][r] : acc[4 * i + j][r];
+        float t[3][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float s12 = 0.5f * (m[1][j] + m[2][j]);
+            t[0][j] = m[0][j] + s12;
+            t[1][j] = 0.5f * (m[1][j] - m[2][j]);
+            t[2][j] = s12 + m[3][j];
+        }
+        const int k = k0 + wk * 32 + mfma32_row(r, lane);
+        if (k < K && cidx < C) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float s12 = 0.5f * (t[a][1] + t[a][2]);
+                slab[((size_t)(3 * a + 0) * K + k) * C + cidx] = t[a][0] + s12;
+                slab[((size_t)(3 * a + 1) * K + k) * C + cidx] = 0.5f * (t[a][1] - t[a][2]);
+                slab[((size_t)(3 * a + 2) * K + k) * C + cidx] = s12 + t[a][3];
+            }
+        }
+    }
+    if (ct == 0 && wc == 0) {
+        bsum += __shfl_xor(bsum, 32, 64);
+        const int k = k0 + wk * 32 + li;
+        if (kk == 0 && k < K) slab[(size_t)9 * K * C + k] = bsum;
+    }
+}
+
 template <int MODE, bool UNPOOL>
 int launch_wino(const float* in, const float* U, const float* bias, const float* mask_src, float* out, uint8_t* pool_idx,
                 int N, int Cin, int Cout, int H, int W, int relu, hipStream_t s) {
@@ -365,6 +612,47 @@ int clhip_internal_wino_conv(int mode, const float* in, const float* w, const fl
     return launch_wino<1, false>(in, U, nullptr, mask_src, out, nullptr, N, Cin, Cout, H, W, 0, s);
 }
 
+// ---- weight gradient through the Winograd path: slabs only, in the format of conv3x3_wgrad.hip (see wino_wgrad_kernel)
+bool clhip_internal_wino_wgrad_ok(int C, int K, int H, int W) {
+    return C % WKT == 0 && K % WKT == 0 && H % 2 == 0 && W % 2 == 0 && H >= 4 && W >= 8;
+}
+
+// slabs the launch below wants (it takes fewer when the workspace is smaller)
+size_t clhip_internal_wino_wgrad_ws(int N, int C, int K, int H, int W) {
+    if (N <= 0 || !clhip_internal_wino_wgrad_ok(C, K, H, W)) return 0;
+    const int kc_tiles = (K / WKT) * (C / WKT);
+    return ((size_t)9 * K * C + K) * (size_t)((256 + kc_tiles - 1) / kc_tiles) * sizeof(float);
+}
+
+int clhip_internal_wino_wgrad_partial(const float* x, const float* dy, const uint8_t* unpool_idx, float* dw, float* db, int N, int C,
+                                      int K, int H, int W, void* ws, size_t ws_bytes, hipStream_t s, clhip_wgrad_job* job) {
+    if (!x || !dy || !dw || !ws || !job || N <= 0) return CLHIP_EINVAL;
+    if (!clhip_internal_wino_wgrad_ok(C, K, H, W)) return CLHIP_ENOTSUP;
+    if ((size_t)N * K * H * W >= ((size_t)1 << 29) || (size_t)N * C * H * W >= ((size_t)1 << 29)) return CLHIP_ENOTSUP;   // 32-bit byte offsets
+    const bool wide = W >= 16;
+    const int TCS = wide ? 8 : 4, TRS = wide ? 2 : 4;
+    const int tiles_w = (W / 2 + TCS - 1) / TCS, tiles_h = (H / 2 + TRS - 1) / TRS;
+    const long long total = (long long)tiles_w * tiles_h * N;
+    if (total > 0x7fffffffLL) return CLHIP_ENOTSUP;
+    const int kc_tiles = (K / WKT) * (C / WKT);
+    const size_t slab = (size_t)9 * K * C + K;
+    long long splits = (256 + kc_tiles - 1) / kc_tiles;
+    if (splits > total) splits = total;
+    const long long cap = (long long)(ws_bytes / (slab * sizeof(float)));
+    if (cap < 1) return CLHIP_ENOSPC;
+    if (splits > cap) splits = cap;
+    float* part = static_cast<float*>(ws);
+    const unsigned grid = (unsigned)(kc_tiles * splits);
+#define WG(TCS_, TRS_, UNP_) hipLaunchKernelGGL((wino_wgrad_kernel<TCS_, TRS_, 1, UNP_>), dim3(grid), dim3(256), 0, s, x, dy, part,      \
+                                                unpool_idx, N, C, K, H, W, tiles_w, tiles_h, (int)total, (int)splits, C / WKT, slab)
+    if (wide) { if (unpool_idx) WG(8, 2, true); else WG(8, 2, false); }
+    else { if (unpool_idx) WG(4, 4, true); else WG(4, 4, false); }
+#undef WG
+    CLHIP_LAUNCH_CHECK();
+    *job = clhip_wgrad_job{part, dw, db, K, C, (int)splits};
+    return 0;
+}
+
 extern "C" {
 
 size_t clhip_conv3x3_wino_ws(int C, int K) {
@@ -383,6 +671,20 @@ int clhip_conv3x3_wino_bwd_data(const float* dy, const uint8_t* idx_u8_or_null, 
     if (N <= 0 || !clhip_internal_wino_ok(K, C, H, W)) return CLHIP_ENOTSUP;
     return clhip_internal_wino_conv(1, dy, w, nullptr, relu_src, dx, const_cast<uint8_t*>(idx_u8_or_null), idx_u8_or_null != nullptr,
                                     N, K, C, H, W, 0, ws, ws_bytes, as_stream(stream));
+}
+
+
+size_t clhip_conv3x3_wino_bwd_weight_ws(int N, int C, int K, int H, int W) {
+    const size_t a = clhip_internal_wino_wgrad_ws(N, C, K, H, W), b = clhip_conv3x3_bwd_weight_ws(N, C, K, H, W);
+    return a > b ? a : b;
+}
+
+int clhip_conv3x3_wino_bwd_weight(const float* x, const float* dy, const uint8_t* idx_u8_or_null, float* dw, float* db, int N, int C,
+                                  int K, int H, int W, void* ws, size_t ws_bytes, void* stream) {
+    clhip_wgrad_job job;
+    int rc = clhip_internal_wino_wgrad_partial(x, dy, idx_u8_or_null, dw, db, N, C, K, H, W, ws, ws_bytes, as_stream(stream), &job);
+    if (rc) return rc;
+    return clhip_conv3x3_bwd_weight_reduce(ws, dw, db, K, C, job.splits, stream);
 }
 
 }  // extern "C"

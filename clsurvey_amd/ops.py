@@ -85,6 +85,20 @@ def conv3x3_wino_bwd_data(dy, w, relu_src=None, idx=None):
     return dx
 
 
+def conv3x3_wino_bwd_weight(x, dy, idx=None):
+    """clhip_conv3x3_wino_bwd_weight: (dw, db) of the 3x3 convolution (idx: dy is the POOLED gradient + arg-max codes)."""
+    _chk(x, dy)
+    N, C, H, W = x.shape
+    K = dy.shape[1]
+    L = _lib.lib()
+    ws = torch.empty(L.clhip_conv3x3_wino_bwd_weight_ws(N, C, K, H, W), dtype=torch.uint8, device=x.device)
+    dw = torch.empty((K, C, 3, 3), dtype=torch.float32, device=x.device)
+    db = torch.empty((K,), dtype=torch.float32, device=x.device)
+    check(L.clhip_conv3x3_wino_bwd_weight(_ptr(x), _ptr(dy), _ptr(idx) if idx is not None else None, _ptr(dw), _ptr(db), N, C, K, H, W,
+                                          _ptr(ws), ws.numel(), _stream()), "clhip_conv3x3_wino_bwd_weight")
+    return dw, db
+
+
 def conv3x3_relu_pool_fwd(x, w, b):
     """fused conv + bias + ReLU + 2x2 max-pool: returns (y_pool, idx_u8)."""
     _chk(x, w, b)

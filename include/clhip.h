@@ -228,6 +228,12 @@ int clhip_conv3x3_wino_fwd(const float* x, const float* w, const float* b, float
                            int H, int W, int relu, void* ws, size_t ws_bytes, void* stream);
 int clhip_conv3x3_wino_bwd_data(const float* dy, const uint8_t* idx_u8_or_null, const float* w, const float* relu_src, float* dx,
                                 int N, int C, int K, int H, int W, void* ws, size_t ws_bytes, void* stream);
+/* dW, db of the same convolution through the Winograd weight-gradient form G^T[(A dY A^T).*(B^T d B)]G (C % 64 == 0,
+ * K % 64 == 0, even H, W; CLHIP_ENOTSUP otherwise).  ws: clhip_conv3x3_wino_bwd_weight_ws(N, C, K, H, W) bytes — partial slabs in
+ * the format of clhip_conv3x3_bwd_weight_slabs, summed in a fixed order (deterministic).  idx_u8 != NULL: dy is the POOLED gradient. */
+size_t clhip_conv3x3_wino_bwd_weight_ws(int N, int C, int K, int H, int W);
+int clhip_conv3x3_wino_bwd_weight(const float* x, const float* dy, const uint8_t* idx_u8_or_null, float* dw, float* db, int N, int C,
+                                  int K, int H, int W, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ HAT gates / back-masks / HAT_SGD
  * methods/HAT/networks/vgg_hat.py, approaches/hat.py, HAT_utils.py.  Gates multiply layer outputs in the

@@ -73,3 +73,35 @@ def test_wino_refuses_shapes_outside_its_domain():
     x = torch.zeros(1, 16, 13, 13, device="cuda")
     with pytest.raises(_lib.ClhipError):
         ops.conv3x3_wino_fwd(x, torch.zeros(32, 16, 3, 3, device="cuda"), torch.zeros(32, device="cuda"))
+
+
+WG_SHAPES = [(3, 64, 64, 32, 32), (5, 64, 64, 16, 16), (6, 64, 128, 8, 8), (4, 128, 64, 8, 8), (2, 64, 64, 12, 20), (2, 64, 128, 28, 28),
+             (3, 128, 256, 16, 16), (200, 64, 64, 32, 32), (200, 64, 64, 16, 16), (200, 128, 128, 8, 8)]
+
+
+@pytest.mark.parametrize("shape", WG_SHAPES)
+def test_wino_weight_gradient(shape):
+    """dW, db through G^T[(A dY A^T).*(B^T d B)]G against torch CPU autograd (small shapes) / the direct MFMA kernel (large),
+    plain and from the POOLED gradient + arg-max codes; repeated calls are bitwise equal (fixed-order slab reduction)."""
+    from clsurvey_amd import ops
+    N, C, K, H, W = shape
+    gen = np.random.RandomState(N * 11 + C + K + W)
+    x = torch.from_numpy(gen.standard_normal((N, C, H, W)).astype(np.float32))
+    dy = torch.from_numpy(gen.standard_normal((N, K, H, W)).astype(np.float32))
+    xd, dyd = x.cuda(), dy.cuda()
+    if N >= 100:
+        dw_ref, db_ref = ops.conv3x3_bwd_weight(xd, dyd)
+    else:
+        w = torch.zeros(K, C, 3, 3, requires_grad=True)
+        b = torch.zeros(K, requires_grad=True)
+        F.conv2d(x, w, b, padding=1).backward(dy)
+        dw_ref, db_ref = w.grad, b.grad
+    dw, db = ops.conv3x3_wino_bwd_weight(xd, dyd)
+    assert _rel(dw, dw_ref) <= 5e-5 and _rel(db, db_ref) <= 5e-5, (_rel(dw, dw_ref), _rel(db, db_ref))
+    dw2, db2 = ops.conv3x3_wino_bwd_weight(xd, dyd)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    dyp = torch.from_numpy(gen.standard_normal((N, K, H // 2, W // 2)).astype(np.float32)).cuda()
+    code = torch.from_numpy(gen.randint(0, 4, size=(N, K, H // 2, W // 2)).astype(np.uint8)).cuda()
+    dw_u_ref, db_u_ref = ops.conv3x3_bwd_weight(xd, ops.maxpool2_bwd(dyp, code))
+    dw_u, db_u = ops.conv3x3_wino_bwd_weight(xd, dyp, idx=code)
+    assert _rel(dw_u, dw_u_ref) <= 5e-5 and _rel(db_u, db_u_ref) <= 5e-5

@@ -27,6 +27,8 @@ for C, K, hw in ((64, 64, 32), (64, 64, 16), (64, 128, 8), (128, 128, 8), (64, 1
     rows = [("fwd", lambda: ops.conv3x3_fwd(x, w, b, True), lambda: ops.conv3x3_wino_fwd(x, w, b, True)),
             ("fwd+pool", lambda: ops.conv3x3_relu_pool_fwd(x, w, b), lambda: ops.conv3x3_wino_fwd(x, w, b, True, pool=True)),
             ("bwd_data", lambda: ops.conv3x3_bwd_data(dy, w, x), lambda: ops.conv3x3_wino_bwd_data(dy, w, x))]
+    if C % 64 == 0 and K % 64 == 0:
+        rows.append(("bwd_weight", lambda: ops.conv3x3_bwd_weight(x, dy), lambda: ops.conv3x3_wino_bwd_weight(x, dy)))
     out = "%4dx%-4d@%-3d" % (C, K, hw)
     for name, direct, wino in rows:
         td, tw = timed(direct), timed(wino)
