@@ -136,9 +136,10 @@ def time_kernels(eng, x, N, iters):
     rows = []
     stream = torch.cuda.current_stream()
     cur = x
-    for kind, m, relu, pool in eng.layers:
+    for li, (kind, m, relu, pool) in enumerate(eng.layers):
         if kind != "conv":
             break
+        paths = eng.layer_paths(li)          # the kernels the plan executor launches for this layer (Winograd or direct)
         C, K = m.in_channels, m.out_channels
         H, W = cur.shape[2], cur.shape[3]
         y = ops.conv3x3_fwd(cur, m.weight.data, m.bias.data, True)
@@ -158,16 +159,21 @@ def time_kernels(eng, x, N, iters):
 
         xin = cur
         layer = "%dx%d@%d" % (C, K, H)
+        wino_geo = "16, 4, 1" if W >= 32 else ("8, 8, 1" if W >= 16 else "4, 4, 4")
         if pool:
             yp, idx = ops.conv3x3_relu_pool_fwd(xin, m.weight.data, m.bias.data)
-            t_f = timed(lambda: ops.conv3x3_relu_pool_fwd(xin, m.weight.data, m.bias.data))
-            rows.append(dict(kernel="conv3x3_relu_pool_fwd", layer=layer, flops=fl, sec=t_f,
-                             instance=conv_instance(C, H, W, N, K, 0, True),
+            t_f = timed((lambda: ops.conv3x3_wino_fwd(xin, m.weight.data, m.bias.data, True, pool=True)) if paths["fwd"] else
+                        (lambda: ops.conv3x3_relu_pool_fwd(xin, m.weight.data, m.bias.data)))
+            rows.append(dict(kernel="conv3x3_relu_pool_fwd", layer=layer, li=li, kind="fwd", flops=fl, sec=t_f, winograd=paths["fwd"],
+                             instance=("wino_conv_kernel<%s, 0, false> (+ wino_weight_kernel)" % wino_geo) if paths["fwd"]
+                             else conv_instance(C, H, W, N, K, 0, True),
                              alg_bytes=4.0 * N * H * W * (C + K / 4.0) + 1.0 * N * K * H * W / 4))
         else:
-            t_f = timed(lambda: ops.conv3x3_fwd(xin, m.weight.data, m.bias.data, True))
-            rows.append(dict(kernel="conv3x3_fwd", layer=layer, flops=fl, sec=t_f,
-                             instance=conv_instance(C, H, W, N, K, 0, False), alg_bytes=4.0 * N * H * W * (C + K)))
+            t_f = timed((lambda: ops.conv3x3_wino_fwd(xin, m.weight.data, m.bias.data, True)) if paths["fwd"] else
+                        (lambda: ops.conv3x3_fwd(xin, m.weight.data, m.bias.data, True)))
+            rows.append(dict(kernel="conv3x3_fwd", layer=layer, li=li, kind="fwd", flops=fl, sec=t_f, winograd=paths["fwd"],
+                             instance=("wino_conv_kernel<%s, 0, false> (+ wino_weight_kernel)" % wino_geo) if paths["fwd"]
+                             else conv_instance(C, H, W, N, K, 0, False), alg_bytes=4.0 * N * H * W * (C + K)))
         if pool:
             dyp = torch.randn_like(yp)
         # the slab kernel alone, as the plan executor launches it (the slabs of all layers are reduced by ONE
@@ -175,27 +181,36 @@ def time_kernels(eng, x, N, iters):
         # both backward kernels take the POOLED gradient + arg-max bytes and rebuild the un-pooled tile while staging
         if C == 3 and pool:
             t_w = timed(lambda: ops.conv3x3_bwd_weight_slabs(xin, dyp, idx))
-            rows.append(dict(kernel="conv3x3_bwd_weight_unpool", layer=layer, flops=fl, sec=t_w,
+            rows.append(dict(kernel="conv3x3_bwd_weight_unpool", layer=layer, li=li, kind="bwd_weight", flops=fl, sec=t_w, winograd=False,
                              instance="conv3x3_wgrad_c3_unpool_kernel" if W % 32 == 0 else "conv3x3_wgrad_smallc_kernel",
                              alg_bytes=4.0 * N * H * W * (C + K / 4.0)))
         elif pool:
-            t_w = timed(lambda: ops.conv3x3_bwd_weight_slabs(xin, dyp, idx))
-            rows.append(dict(kernel="conv3x3_bwd_weight_unpool", layer=layer, flops=fl, sec=t_w,
-                             instance="conv3x3_wgrad_kernel<..., UNPOOL=true> (slabs; reduction deferred)",
+            # (the Winograd entry point times slabs + its own reduction launch; inside a pass the reduction is deferred)
+            t_w = timed((lambda: ops.conv3x3_wino_bwd_weight(xin, dyp, idx)) if paths["bwd_weight"] else
+                        (lambda: ops.conv3x3_bwd_weight_slabs(xin, dyp, idx)))
+            rows.append(dict(kernel="conv3x3_bwd_weight_unpool", layer=layer, li=li, kind="bwd_weight", flops=fl, sec=t_w, winograd=paths["bwd_weight"],
+                             instance="wino_wgrad_kernel<..., UNPOOL=true> (slabs + reduction)" if paths["bwd_weight"]
+                             else "conv3x3_wgrad_kernel<..., UNPOOL=true> (slabs; reduction deferred)",
                              alg_bytes=4.0 * N * H * W * (C + K / 4.0) + 1.0 * N * K * H * W / 4))
         else:
-            t_w = timed(lambda: ops.conv3x3_bwd_weight_slabs(xin, dy))
-            rows.append(dict(kernel="conv3x3_bwd_weight", layer=layer, flops=fl, sec=t_w,
-                             instance="conv3x3_wgrad_kernel (slabs; reduction deferred)", alg_bytes=4.0 * N * H * W * (C + K)))
+            t_w = timed((lambda: ops.conv3x3_wino_bwd_weight(xin, dy)) if paths["bwd_weight"] else
+                        (lambda: ops.conv3x3_bwd_weight_slabs(xin, dy)))
+            rows.append(dict(kernel="conv3x3_bwd_weight", layer=layer, li=li, kind="bwd_weight", flops=fl, sec=t_w, winograd=paths["bwd_weight"],
+                             instance="wino_wgrad_kernel (slabs + reduction)" if paths["bwd_weight"]
+                             else "conv3x3_wgrad_kernel (slabs; reduction deferred)", alg_bytes=4.0 * N * H * W * (C + K)))
         if C > 3 and pool:
-            t_d = timed(lambda: ops.conv3x3_bwd_data_unpool(dyp, idx, m.weight.data, xin))
-            rows.append(dict(kernel="conv3x3_bwd_data_unpool", layer=layer, flops=fl, sec=t_d,
-                             instance=conv_instance(K, H, W, N, C, 1, False, True),
+            t_d = timed((lambda: ops.conv3x3_wino_bwd_data(dyp, m.weight.data, xin, idx)) if paths["bwd_data"] else
+                        (lambda: ops.conv3x3_bwd_data_unpool(dyp, idx, m.weight.data, xin)))
+            rows.append(dict(kernel="conv3x3_bwd_data_unpool", layer=layer, li=li, kind="bwd_data", flops=fl, sec=t_d, winograd=paths["bwd_data"],
+                             instance=("wino_conv_kernel<%s, 1, true> (+ wino_weight_kernel)" % wino_geo) if paths["bwd_data"]
+                             else conv_instance(K, H, W, N, C, 1, False, True),
                              alg_bytes=4.0 * N * H * W * (2 * C + K / 4.0) + 1.0 * N * K * H * W / 4))
         elif C > 3:
-            t_d = timed(lambda: ops.conv3x3_bwd_data(dy, m.weight.data, xin))
-            rows.append(dict(kernel="conv3x3_bwd_data", layer=layer, flops=fl, sec=t_d,
-                             instance=conv_instance(K, H, W, N, C, 1, False), alg_bytes=4.0 * N * H * W * (2 * C + K)))
+            t_d = timed((lambda: ops.conv3x3_wino_bwd_data(dy, m.weight.data, xin)) if paths["bwd_data"] else
+                        (lambda: ops.conv3x3_bwd_data(dy, m.weight.data, xin)))
+            rows.append(dict(kernel="conv3x3_bwd_data", layer=layer, li=li, kind="bwd_data", flops=fl, sec=t_d, winograd=paths["bwd_data"],
+                             instance=("wino_conv_kernel<%s, 1, false> (+ wino_weight_kernel)" % wino_geo) if paths["bwd_data"]
+                             else conv_instance(K, H, W, N, C, 1, False), alg_bytes=4.0 * N * H * W * (2 * C + K)))
         cur = ops.maxpool2_fwd(y)[0] if pool else y
     return rows
 
@@ -757,20 +772,14 @@ def main():
     step(0, True)
     for i in range(args.warmup):
         step(i + 1)
-    # HIP events around the dominant launch INSIDE the timed steps (layer 2 forward: conv + ReLU + pool, the largest launch
-    # of a pass), on the stream it is issued on: clhip_net_probe keeps a ring of event pairs, read after the loop
-    conv_idx = [i for i, (kind, m, relu, pool) in enumerate(eng.layers) if kind == "conv"]
-    probe_layer = None
-    if rank == 0 and len(conv_idx) > 1:
-        hw = 64
-        best = -1.0
-        for i in conv_idx:
-            m, pool = eng.layers[i][1], eng.layers[i][3]
-            fl = 2.0 * 9 * m.in_channels * m.out_channels * hw * hw
-            if fl > best:
-                best, probe_layer = fl, i
-            hw = hw // 2 if pool else hw
-        eng.probe(probe_layer)
+    # The dominant launch of a pass (longest single launch, found by timing every conv launch of the plan back to back) is
+    # then timed INSIDE the timed steps: clhip_net_probe_kind keeps a ring of HIP event pairs around that layer's forward /
+    # backward-data / weight-gradient launch on the stream it is issued on, read after the loop
+    rows, dom = None, None
+    if rank == 0:
+        rows = time_kernels(eng, data_x[:N].contiguous(), N, args.kernel_iters)
+        dom = max(rows, key=lambda r: r["sec"])
+        eng.probe(dom["li"], dom["kind"])
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -807,8 +816,8 @@ def main():
         dt = float(t.item())
     if not torch.isfinite(A.theta).all():
         raise SystemExit("non-finite parameters after the timed run")
-    probed_us, probed_n = eng.probe_read() if probe_layer is not None else (0.0, 0)
-    if probe_layer is not None:
+    probed_us, probed_n = eng.probe_read() if dom is not None else (0.0, 0)
+    if dom is not None:
         eng.probe(None)
 
     fwd_fl, step_fl = algorithmic_flops_per_image(SMALL, (128, 128), 20, 64)
@@ -834,16 +843,11 @@ def main():
         # second number of the N > 1 line: the sharded framework itself on a bounded task sequence (every rank takes part)
         out["grid"]["sharded_driver"] = sharded_sweep(local_rank, world)
     if rank == 0:
-        rows = time_kernels(eng, data_x[:N].contiguous(), N, args.kernel_iters)
         agg = {}
         for r in rows:
             a = agg.setdefault(r["kernel"], dict(flops=0.0, sec=0.0, launches=0))
             a["flops"] += r["flops"]; a["sec"] += r["sec"]; a["launches"] += 1
-        dom = max(rows, key=lambda r: r["sec"])          # the single launch that costs most per pass
-        # its duration inside the timed steps when the probe sat on that layer's forward launch (it does for the VGG9s);
-        # the back-to-back microbenchmark of the same launch otherwise (and always reported next to it)
-        fwd_rows = [r for r in rows if r["kernel"] in ("conv3x3_relu_pool_fwd", "conv3x3_fwd")]     # one per conv layer, in order
-        in_situ = probed_n > 0 and probe_layer is not None and fwd_rows[conv_idx.index(probe_layer)] is dom
+        in_situ = probed_n > 0
         dom_sec = probed_us * 1e-6 if in_situ else dom["sec"]
         ach = dom["flops"] / dom_sec / 1e12
         out["roofline"] = {"bound": "mfma", "kernel": "%s [%s, layer %s, N=%d]" % (dom["instance"], dom["kernel"], dom["layer"], N),
@@ -853,12 +857,17 @@ def main():
                            "algorithmic_gflop_per_launch": dom["flops"] / 1e9,
                            "algorithmic_bytes_per_launch": dom["alg_bytes"],
                            "avg_launch_us": dom_sec * 1e6,
-                           "avg_launch_how": ("HIP events around this launch inside the timed steps (clhip_net_probe), last %d passes" % probed_n)
+                           "avg_launch_how": ("HIP events around this launch inside the timed steps (clhip_net_probe_kind), last %d passes" % probed_n)
                                              if in_situ else "HIP events around %d back-to-back launches after the timed steps" % args.kernel_iters,
                            "back_to_back_us": dom["sec"] * 1e6,
+                           # Winograd F(2x2,3x3) launches issue 16 instead of 36 multiplies per 2x2 output tile and channel pair:
+                           # `achieved` prices the ALGORITHMIC flops of the convolution, this the flops the matrix
+                           # pipe really executes
+                           "winograd": bool(dom.get("winograd")),
+                           "mfma_issued_tflops": ach * (16.0 / 36.0 if dom.get("winograd") else 1.0),
                            "per_kernel": {k: {"tflops": v["flops"] / v["sec"] / 1e12, "us_per_step_pass": v["sec"] * 1e6}
                                           for k, v in agg.items()},
-                           "per_layer": [{"kernel": r["kernel"], "layer": r["layer"], "instance": r["instance"],
+                           "per_layer": [{"kernel": r["kernel"], "layer": r["layer"], "instance": r["instance"], "winograd": bool(r.get("winograd")),
                                           "us": r["sec"] * 1e6, "tflops": r["flops"] / r["sec"] / 1e12} for r in rows]}
         if world == 1 and not args.no_configs:
             del eng

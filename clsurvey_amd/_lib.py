@@ -117,6 +117,8 @@ SIGNATURES = {
     "clhip_net_probe_read": (_i, [_p, C.POINTER(_f), C.POINTER(_i)]),
     "clhip_net_layer_input": (_i, [_p, _i, _p, _p]),
     "clhip_net_layer_pool_idx": (_i, [_p, _i, _p, _p]),
+    "clhip_net_layer_paths": (_i, [_p, _i]),
+    "clhip_net_probe_kind": (_i, [_p, _i, _i]),
     "clhip_net_set_input_grad": (_i, [_p, _i, _p]),
     "clhip_sigmoid_fwd": (_i, [_p, _p, _z, _p]),
     "clhip_sigmoid_bwd": (_i, [_p, _p, _p, _z, _p]),

@@ -84,6 +84,7 @@ struct NetPlan {
     // measurement probe (clhip_net_probe): HIP events around the forward launch(es) of one layer, a ring of PROBE_RING
     // pairs so that recording never waits for the GPU
     int probe_layer;
+    int probe_kind;          // 0 forward, 1 backward-data, 2 weight-gradient launch(es) of probe_layer
     unsigned probe_count;
     std::vector<hipEvent_t> probe_ev;
     bool fc_tail, no_combo;
@@ -320,6 +321,7 @@ int clhip_net_create(const clhip_layer_desc* descs, int n_layers, int max_batch,
         }
     }
     p->probe_layer = -1;
+    p->probe_kind = 0;
     p->probe_count = 0;
     p->fc_tail = false;
     p->no_combo = false;
@@ -379,6 +381,13 @@ int clhip_net_layer_pool_idx(void* handle, int layer, size_t* ws_byte_off, size_
     return 0;
 }
 
+int clhip_net_layer_paths(void* handle, int layer) {
+    NetPlan* p = static_cast<NetPlan*>(handle);
+    if (!p || layer < 0 || layer >= (int)p->layers.size()) return CLHIP_EINVAL;
+    const LayerPlan& L = p->layers[layer];
+    return (L.wino_f ? 1 : 0) | (L.wino_d ? 2 : 0) | (L.wino_w ? 4 : 0);
+}
+
 int clhip_net_set_input_grad(void* handle, int layer, const float* extra) {
     NetPlan* p = static_cast<NetPlan*>(handle);
     if (!p || layer <= 0 || layer >= (int)p->layers.size()) return CLHIP_EINVAL;
@@ -406,8 +415,16 @@ int clhip_net_probe(void* handle, int layer) {
         p->probe_ev.swap(made);
     }
     p->probe_layer = layer;
+    p->probe_kind = 0;
     p->probe_count = 0;
     return 0;
+}
+
+int clhip_net_probe_kind(void* handle, int layer, int kind) {
+    if (kind < 0 || kind > 2) return CLHIP_EINVAL;
+    const int rc = clhip_net_probe(handle, layer);
+    if (rc == 0) static_cast<NetPlan*>(handle)->probe_kind = kind;
+    return rc;
 }
 
 int clhip_net_probe_read(void* handle, float* avg_us, int* count) {
@@ -470,7 +487,7 @@ static int net_forward_impl(void* handle, const float* params, const float* x, i
     for (size_t li = 0; li < n_run; ++li) {
         const LayerPlan& L = p->layers[li];
         float* y = acts + L.act_off;
-        const bool probed = (int)li == p->probe_layer && !p->probe_ev.empty();
+        const bool probed = (int)li == p->probe_layer && p->probe_kind == 0 && !p->probe_ev.empty();
         if (probed) (void)hipEventRecord(p->probe_ev[2 * (p->probe_count % PROBE_RING)], as_stream(stream));
         struct ProbeEnd {       // closes the pair when the layer's launches are issued (every exit of the loop body)
             NetPlan* p; bool on; hipStream_t s;
@@ -694,6 +711,12 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
         int gy_buf = gin_buf;
         bool wdone = false;
         bool ddone = false;
+        // measurement probe around this layer's backward-data / weight-gradient launch(es) (clhip_net_probe_kind)
+        auto probe_on = [&](int kind) { return i == p->probe_layer && p->probe_kind == kind && !p->probe_ev.empty(); };
+        auto probe_begin = [&](int kind) { if (probe_on(kind)) (void)hipEventRecord(p->probe_ev[2 * (p->probe_count % PROBE_RING)], main_s); };
+        auto probe_end = [&](int kind) {
+            if (probe_on(kind)) { (void)hipEventRecord(p->probe_ev[2 * (p->probe_count % PROBE_RING) + 1], main_s); ++p->probe_count; }
+        };
         float* gout_d = nullptr;
         int gout_d_buf = -1;
         if (vgg && pool22 && !L.bn && L.wg3) {
@@ -701,6 +724,7 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
             // the POOLED gradient + the arg-max codes while staging it, when their kernels support the shape (first
             // layer: the small-C kernel; others: the 16-byte staging paths).  The 4x larger un-pooled tensor and the
             // clhip_maxpool2_bwd launch disappear.
+            probe_begin(2);
             rc = on_side(i, gin_buf, [&](void* st) {
                 if (defer && L.wino_w) {
                     const int r = clhip_internal_wino_wgrad_partial(xin, gin, idx + L.idx_off, grads + L.w_off, grads + L.b_off, N, L.cin,
@@ -715,15 +739,16 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
                 return clhip_conv3x3_bwd_weight_unpool(xin, gin, idx + L.idx_off, grads + L.w_off, grads + L.b_off, N, L.cin, L.cout,
                                                        L.h, L.w, scratch, p->scratch_bytes, st);
             });
-            if (rc == 0) { wdone = true; if (defer) ++n_jobs; }
+            if (rc == 0) { wdone = true; if (defer) ++n_jobs; probe_end(2); }
             else if (rc != CLHIP_ENOTSUP) return rc;
             if (wdone && i > 0 && !L.drop && !L.extra_grad) {
                 gout_d = take(); gout_d_buf = taken;
+                probe_begin(1);
                 rc = L.wino_d ? clhip_internal_wino_conv(1, gin, params + L.w_off, nullptr, xin, gout_d, idx + L.idx_off, 1, N, L.cout,
                                                          L.cin, L.h, L.w, 0, base + p->off_wino, p->wino_bytes, as_stream(stream))
                               : clhip_conv3x3_bwd_data_unpool(gin, idx + L.idx_off, params + L.w_off, xin, gout_d, N, L.cin, L.cout, L.h,
                                                               L.w, stream);
-                if (rc == 0) ddone = true;
+                if (rc == 0) { ddone = true; probe_end(1); }
                 else if (rc != CLHIP_ENOTSUP) return rc;
             }
         }
@@ -745,6 +770,7 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
             if (rc) return rc;
         }
         if (!wdone) {
+            probe_begin(2);
             rc = on_side(i, gy_buf, [&](void* st) {
                 if (L.wg3 && defer && L.wino_w) {
                     const int r = clhip_internal_wino_wgrad_partial(xin, gy, nullptr, grads + L.w_off, grads + L.b_off, N, L.cin, L.cout,
@@ -761,18 +787,21 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
                                                      L.st, L.pd, scratch, p->scratch_bytes, st);
             });
             if (rc) return rc;
+            probe_end(2);
             if (L.wg3 && defer) ++n_jobs;
         }
         if (i > 0 && ddone) {
             gin = gout_d; gin_buf = gout_d_buf;
         } else if (i > 0) {
             float* gout = take();
+            probe_begin(1);
             rc = (vgg && L.wino_d)
                      ? clhip_internal_wino_conv(1, gy, params + L.w_off, nullptr, xin, gout, nullptr, 0, N, L.cout, L.cin, L.h, L.w, 0,
                                                 base + p->off_wino, p->wino_bytes, as_stream(stream))
                  : vgg ? clhip_conv3x3_bwd_data(gy, params + L.w_off, xin, gout, N, L.cin, L.cout, L.h, L.w, stream)
                      : clhip_conv2d_bwd_data(gy, params + L.w_off, xin, gout, N, L.cin, L.h, L.w, L.cout, L.ks, L.ks, L.st, L.pd, stream);
             if (rc) return rc;
+            probe_end(1);
             gin = gout; gin_buf = taken;
             if (L.drop) {
                 rc = drop_scale(gout, L.drop, L.drop_stride, L.in_elems, N, main_s);

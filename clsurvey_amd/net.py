@@ -275,6 +275,13 @@ class NetEngine:
         check(_lib.lib().clhip_net_layer_pool_idx(self._h, int(layer), C.byref(off), C.byref(elems)), "clhip_net_layer_pool_idx")
         return self.ws[off.value:off.value + n * elems.value].view(n, elems.value)
 
+    def layer_paths(self, layer):
+        """{'fwd', 'bwd_data', 'bwd_weight'} -> True where the plan runs the layer's kernel through the Winograd path."""
+        bits = _lib.lib().clhip_net_layer_paths(self._h, int(layer))
+        if bits < 0:
+            raise RuntimeError("clhip_net_layer_paths(%d)" % layer)
+        return {"fwd": bool(bits & 1), "bwd_data": bool(bits & 2), "bwd_weight": bool(bits & 4)}
+
     def set_input_grad(self, layer, extra):
         """extra [N][in_elems] (or None) is added to the gradient w.r.t. layer_input(layer) in the following backward
         passes; if that activation is a ReLU output the caller masks extra with (activation > 0) first."""
@@ -296,9 +303,11 @@ class NetEngine:
             for bn in self.bns.values():
                 bn.num_batches_tracked += 1
 
-    def probe(self, layer):
-        """Measurement: HIP events around the forward launch(es) of plan layer `layer` from now on (None: off)."""
-        check(_lib.lib().clhip_net_probe(self._h, -1 if layer is None else int(layer)), "clhip_net_probe")
+    def probe(self, layer, kind="fwd"):
+        """Measurement: HIP events around the forward ('fwd'), backward-data ('bwd_data') or weight-gradient ('bwd_weight')
+        launch(es) of plan layer `layer` from now on (None: off)."""
+        k = {"fwd": 0, "bwd_data": 1, "bwd_weight": 2}[kind]
+        check(_lib.lib().clhip_net_probe_kind(self._h, -1 if layer is None else int(layer), k), "clhip_net_probe_kind")
 
     def probe_read(self):
         """(average microseconds, passes covered) of the probed layer's forward launch since the last read (at most 64)."""

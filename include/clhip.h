@@ -324,12 +324,17 @@ int clhip_net_set_training(void* handle, int training);
  * clhip_net_probe_read waits for the recorded launches, returns their average duration in microseconds and how many
  * passes it covers, and restarts the count. */
 int clhip_net_probe(void* handle, int layer);
+/* the same around the layer's backward-data (kind 1) or weight-gradient (kind 2) launch(es); kind 0 = clhip_net_probe */
+int clhip_net_probe_kind(void* handle, int layer, int kind);
 int clhip_net_probe_read(void* handle, float* avg_us, int* count);
 /* Where the arg-max bytes of a max-pooled conv layer live after a forward: byte offset into ws and bytes per
  * sample ([cout][oh][ow], window position r*k + c, first maximum wins).  With the saved activations
  * (clhip_net_layer_input) this is every non-linear decision the backward pass will use — what a parity harness
  * needs to judge gradients independently of ReLU / arg-max near-ties.  EINVAL for layers without a pool.   */
 int clhip_net_layer_pool_idx(void* handle, int layer, size_t* ws_byte_off, size_t* elems_per_sample);
+/* Which kernels the plan chose for a layer (measurement harnesses time the same ones): bit 0 forward, bit 1 backward-data, bit 2
+ * weight gradient through the Winograd F(2x2,3x3) path (csrc/wino.hip) instead of the direct MFMA kernels; < 0 on error. */
+int clhip_net_layer_paths(void* handle, int layer);
 
 /* Side branches off a plan (EBLL's code layers on the flattened features, AlexNet_EBLL.py:110-117): the INPUT activation
  * of plan layer `layer` (> 0) lives at float offset *ws_float_off of the workspace after a forward (in_elems floats per

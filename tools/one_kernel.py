@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Run ONE conv entry point a few times (for rocprofv3 --pmc passes).
-usage: python tools/one_kernel.py {c3pool|fwdpool|fwd|dgrad|dgrad_unpool|wgrad} N C K HW [iters]"""
+usage: python tools/one_kernel.py {c3pool|fwdpool|fwd|dgrad|dgrad_unpool|wgrad|wino_fwdpool|wino_fwd|wino_dgrad|wino_dgrad_unpool|
+wino_wgrad|wino_wgrad_unpool} N C K HW [iters]"""
 import os
 import sys
 
@@ -20,7 +21,10 @@ dy = torch.randn(N, K, HW, HW, device=dev)
 yp, idx = ops.conv3x3_relu_pool_fwd(x, w, b)
 dyp = torch.randn_like(yp)
 fn = {"dgrad_unpool": lambda: ops.conv3x3_bwd_data_unpool(dyp, idx, w, x), "c3pool": lambda: ops.conv3x3_relu_pool_fwd(x, w, b), "fwdpool": lambda: ops.conv3x3_relu_pool_fwd(x, w, b), "fwd": lambda: ops.conv3x3_fwd(x, w, b, True),
-      "dgrad": lambda: ops.conv3x3_bwd_data(dy, w, x), "wgrad": lambda: ops.conv3x3_bwd_weight(x, dy)}[kind]
+      "dgrad": lambda: ops.conv3x3_bwd_data(dy, w, x), "wgrad": lambda: ops.conv3x3_bwd_weight(x, dy),
+      "wino_fwdpool": lambda: ops.conv3x3_wino_fwd(x, w, b, True, pool=True), "wino_fwd": lambda: ops.conv3x3_wino_fwd(x, w, b, True),
+      "wino_dgrad": lambda: ops.conv3x3_wino_bwd_data(dy, w, x), "wino_dgrad_unpool": lambda: ops.conv3x3_wino_bwd_data(dyp, w, x, idx),
+      "wino_wgrad": lambda: ops.conv3x3_wino_bwd_weight(x, dy), "wino_wgrad_unpool": lambda: ops.conv3x3_wino_bwd_weight(x, dyp, idx)}[kind]
 for _ in range(iters):
     fn()
 torch.cuda.synchronize()
