@@ -485,7 +485,7 @@ def _base_model_file(root, name="small_VGG9_cl_128_128"):
 
 
 def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epochs=70,
-               pair_sizes=(2000, 500, 500), pair_epochs=3, pair_batch=50):
+               pair_sizes=(2000, 500, 500), pair_epochs=3, pair_batch=50, pair_noise=0.3):
     """BASELINE.json's second metric ('full-sweep wall-clock'), two measurements.
 
     `gpu_s`: what framework/main.py runs for `small_VGG9_cl_128_128 --method_name EWC --test` with the reference's defaults
@@ -550,7 +550,7 @@ def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epoch
         if cpu_threads:
             from oracle import sweep_ref
             proot, croot = os.path.join(root, "pair_gpu"), os.path.join(root, "pair_cpu")
-            spec = "2,20,%d,%d,%d,64" % tuple(pair_sizes)
+            spec = "2,20,%d,%d,%d,64,%g" % (tuple(pair_sizes) + (pair_noise,))
             pcommon = [model, "--num_epochs", str(pair_epochs), "--batch_size", str(pair_batch), "--saving_freq", "1000", "--synthetic", spec,
                        "--device", "cuda:%d" % dev_index]
             _base_model_file(proot)
@@ -568,9 +568,9 @@ def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epoch
                 num_epochs=pair_epochs, batch_size=pair_batch, lr_grid=[1e-2], weight_decay=0, model_name=model))))
             fixed = ["--lr_grid", "1e-2", "--max_attempts_per_task", "1", "--method_name", "EWC", "--test"]
             pair = {"what": "task 2 of a 2-task sequence (%d/%d/%d images), from the same first-task model: LR grid {1e-2}, %d-epoch "
-                            "cap, batch %d (so that the few epochs hold enough SGD steps to leave chance), Fisher pass, ONE "
-                            "stability-decay attempt (kept whatever it scores), both models evaluated"
-                            % (tuple(pair_sizes) + (pair_epochs, pair_batch))}
+                            "cap, batch %d and pixel noise %g instead of 1.0 (so that the few epochs the CPU leg can afford leave "
+                            "chance), Fisher pass, ONE stability-decay attempt (kept whatever it scores), both models evaluated"
+                            % (tuple(pair_sizes) + (pair_epochs, pair_batch, pair_noise))}
             for sub in ("data", "models", os.path.join("train", "synthetic_tiny_imagenet", "SI")):
                 shutil.copytree(os.path.join(proot, sub), os.path.join(croot, sub))
             with contextlib.redirect_stdout(quiet), _PassCounter(pair_sizes[0]) as pcounts:

@@ -74,7 +74,7 @@ def build_parser():
     p.add_argument("--no_speculation", action="store_true",
                    help="with --shard: phase 2 runs sequentially on rank 0 only; its model and state are broadcast")
     p.add_argument("--synthetic", type=str, default=None,
-                   help="command-line runs: tasks,classes,train,val,test,hw of a synthetic task sequence "
+                   help="command-line runs: tasks,classes,train,val,test,hw[,noise] of a synthetic task sequence "
                         "(clsurvey_amd.framework.tasks), e.g. 10,20,8000,2000,1000,64 = Tiny-ImageNet's shape")
     return p
 
@@ -587,9 +587,10 @@ def main(argv=None, method=None, dataset=None, train_node_factory=None):
             sequential_on_rank0 = args.no_speculation
     if dataset is None and args.synthetic:
         from .tasks import SyntheticTaskSequence
-        n_tasks, n_cls, n_tr, n_va, n_te, hw = [int(v) for v in args.synthetic.split(",")]
+        fields = args.synthetic.split(",")
+        n_tasks, n_cls, n_tr, n_va, n_te, hw = [int(v) for v in fields[:6]]
         dataset = SyntheticTaskSequence(os.path.join(args.results_root, "data"), task_count=n_tasks, classes_per_task=n_cls,
-                                        sizes=(n_tr, n_va, n_te), hw=hw)
+                                        sizes=(n_tr, n_va, n_te), hw=hw, noise=float(fields[6]) if len(fields) > 6 else 1.0)
     set_random(7)                                                 # utils.init -> set_random()
     if method is None:
         method = methods.parse(args.method_name)
