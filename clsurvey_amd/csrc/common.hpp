@@ -117,6 +117,10 @@ int clhip_internal_conv3x3_wgrad_partial(const float* x, const float* dy, const 
 int clhip_internal_wgrad_reduce_multi(const clhip_wgrad_job* jobs, int n, hipStream_t s);
 
 // wino.hip: 3x3 convolution by Winograd F(2x2, 3x3) (forward / backward-data); see the file's header
+struct clhip_wino_wt { const float* w; float* U; int Ko, Ci, mode, pad; };
+int clhip_internal_wino_weights(const clhip_wino_wt* jobs, int n, hipStream_t s);
+int clhip_internal_wino_conv_u(int mode, const float* in, const float* U, const float* bias, const float* mask_src, float* out,
+                               uint8_t* pool_idx, int unpool, int N, int Cin, int Cout, int H, int W, int relu, hipStream_t s);
 bool clhip_internal_wino_ok(int Cin, int Cout, int H, int W);
 size_t clhip_internal_wino_ws(int Cin, int Cout);
 bool clhip_internal_wino_wgrad_ok(int C, int K, int H, int W);

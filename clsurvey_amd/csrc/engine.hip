@@ -37,6 +37,7 @@ struct LayerPlan {
     size_t z_off;          // bn: float offset of the convolution output (pre-BatchNorm) in ws
     size_t stat_off;       // bn: float offset of save_mean[cout], save_invstd[cout]
     float* rmean; float* rvar; float bn_momentum, bn_eps;
+    size_t wino_uf, wino_ud;     // byte offsets of this layer's transformed weights (forward / backward-data) in the plan's Winograd region
     int wino_f, wino_d, wino_w;  // forward / backward-data / weight gradient through Winograd F(2x2,3x3) (wino.hip) instead of the direct kernels
     int wg3;                   // weight gradient on the 3x3 kernel (else the general gather-GEMM)
     size_t wg_off, wg_bytes;   // this layer's own weight-gradient slabs (3x3 layers; reduced for all layers at once)
@@ -229,8 +230,9 @@ int clhip_net_create(const clhip_layer_desc* descs, int n_layers, int max_batch,
                         if (ww > L.wg_bytes) { wg_total += align_up(ww, 256) - L.wg_bytes; L.wg_bytes = align_up(ww, 256); }
                     }
                 }
-                if (L.wino_f && clhip_internal_wino_ws(L.cin, L.cout) > wino_ws) wino_ws = clhip_internal_wino_ws(L.cin, L.cout);
-                if (L.wino_d && clhip_internal_wino_ws(L.cout, L.cin) > wino_ws) wino_ws = clhip_internal_wino_ws(L.cout, L.cin);
+                // every Winograd layer keeps its own transformed weights: ONE transform launch per pass fills them all
+                if (L.wino_f) { L.wino_uf = wino_ws; wino_ws += align_up(clhip_internal_wino_ws(L.cin, L.cout), 256); }
+                if (L.wino_d) { L.wino_ud = wino_ws; wino_ws += align_up(clhip_internal_wino_ws(L.cout, L.cin), 256); }
             }
             if (L.out_elems > gmax) gmax = L.out_elems;
             if (L.in_elems > gmax) gmax = L.in_elems;
@@ -472,14 +474,32 @@ static bool tail_usable(const NetPlan* p, const float* params, const void* ws, i
            (size_t)N * (p->n_classes | 1) <= 12288;        // the range in which the per-layer path uses softmax_ce_rows_lds_kernel
 }
 
+// transformed weights of every Winograd layer (forward set, backward-data set, or both) in one launch
+static int wino_prepare(NetPlan* p, const float* params, char* base, bool fwd, bool bwd, hipStream_t s) {
+    clhip_wino_wt jobs[64];
+    int n = 0;
+    for (const LayerPlan& L : p->layers) {
+        if (L.type != 0) continue;
+        if (fwd && L.wino_f && n < 64)
+            jobs[n++] = clhip_wino_wt{params + L.w_off, reinterpret_cast<float*>(base + p->off_wino + L.wino_uf), L.cout, L.cin, 0, 0};
+        if (bwd && L.wino_d && n < 64)
+            jobs[n++] = clhip_wino_wt{params + L.w_off, reinterpret_cast<float*>(base + p->off_wino + L.wino_ud), L.cin, L.cout, 1, 0};
+    }
+    return clhip_internal_wino_weights(jobs, n, s);
+}
+
 static int net_forward_impl(void* handle, const float* params, const float* x, int N, void* ws, float* logits_out,
-                            void* stream, int tail, int* slabs_live = nullptr) {
+                            void* stream, int tail, int* slabs_live = nullptr, bool prep_bwd = false) {
     NetPlan* p = static_cast<NetPlan*>(handle);
     if (!p || !params || !x || !ws || N <= 0 || N > p->max_batch) return CLHIP_EINVAL;
     char* base = static_cast<char*>(ws);
     float* acts = reinterpret_cast<float*>(base + p->off_acts);
     uint8_t* idx = reinterpret_cast<uint8_t*>(base + p->off_idx);
     void* scratch = base + p->off_scratch;
+    if (p->wino_bytes) {
+        int rcw = wino_prepare(p, params, base, true, prep_bwd, as_stream(stream));
+        if (rcw) return rcw;
+    }
     const float* cur = x;
     int rc;
     const size_t n_run = tail ? (size_t)p->fc_first + 1 : p->layers.size();
@@ -530,15 +550,17 @@ static int net_forward_impl(void* handle, const float* params, const float* x, i
             if (L.pool && L.relu) {
                 // conv + bias + ReLU + max-pool in one kernel; the pre-pool tensor is never materialised
                 float* pl = acts + L.pool_off;
-                rc = L.wino_f ? clhip_internal_wino_conv(0, cur, params + L.w_off, params + L.b_off, nullptr, pl, idx + L.idx_off, 0, N,
-                                                         L.cin, L.cout, L.h, L.w, 1, base + p->off_wino, p->wino_bytes, as_stream(stream))
+                rc = L.wino_f ? clhip_internal_wino_conv_u(0, cur, reinterpret_cast<const float*>(base + p->off_wino + L.wino_uf),
+                                                           params + L.b_off, nullptr, pl, idx + L.idx_off, 0, N, L.cin, L.cout, L.h, L.w, 1,
+                                                           as_stream(stream))
                               : clhip_conv3x3_relu_pool_fwd(cur, params + L.w_off, params + L.b_off, pl, idx + L.idx_off, N, L.cin,
                                                             L.cout, L.h, L.w, stream);
                 if (rc) return rc;
                 cur = pl;
             } else {
-                rc = L.wino_f ? clhip_internal_wino_conv(0, cur, params + L.w_off, params + L.b_off, nullptr, y, nullptr, 0, N, L.cin,
-                                                         L.cout, L.h, L.w, L.relu, base + p->off_wino, p->wino_bytes, as_stream(stream))
+                rc = L.wino_f ? clhip_internal_wino_conv_u(0, cur, reinterpret_cast<const float*>(base + p->off_wino + L.wino_uf),
+                                                           params + L.b_off, nullptr, y, nullptr, 0, N, L.cin, L.cout, L.h, L.w, L.relu,
+                                                           as_stream(stream))
                               : clhip_conv3x3_fwd(cur, params + L.w_off, params + L.b_off, y, N, L.cin, L.cout, L.h, L.w, L.relu, stream);
                 if (rc) return rc;
                 cur = y;
@@ -592,7 +614,7 @@ int clhip_net_forward(void* handle, const float* params, const float* x, int N, 
 // clhip_net_forward on the same ws.  Writes every parameter gradient into `grads` (same offsets
 // as params; overwritten, not accumulated).
 static int net_backward_impl(void* handle, const float* params, float* grads, const float* x, int N, void* ws,
-                             const float* dlogits, void* stream, bool tail_done) {
+                             const float* dlogits, void* stream, bool tail_done, bool wino_ready = false) {
     NetPlan* p = static_cast<NetPlan*>(handle);
     if (!p || !params || !grads || !x || !ws || !dlogits || N <= 0 || N > p->max_batch) return CLHIP_EINVAL;
     char* base = static_cast<char*>(ws);
@@ -607,6 +629,10 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
     const int top = (int)p->layers.size() - 1;
     float* fcdz = reinterpret_cast<float*>(base + p->off_fcdz);
     hipStream_t main_s = as_stream(stream);
+    if (p->wino_bytes && !wino_ready) {           // a backward on its own: the forward of the same call did not transform for it
+        rc = wino_prepare(p, params, base, false, true, main_s);
+        if (rc) return rc;
+    }
     const bool ov = p->overlap && p->overlap_mode == 1;          // every layer on the side stream: immediate reductions
     const bool ov_small = p->overlap && p->overlap_mode == 2;    // only the under-filled deep layers; slabs stay deferred
     auto side_ok = [&](int layer) {
@@ -744,8 +770,8 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
             if (wdone && i > 0 && !L.drop && !L.extra_grad) {
                 gout_d = take(); gout_d_buf = taken;
                 probe_begin(1);
-                rc = L.wino_d ? clhip_internal_wino_conv(1, gin, params + L.w_off, nullptr, xin, gout_d, idx + L.idx_off, 1, N, L.cout,
-                                                         L.cin, L.h, L.w, 0, base + p->off_wino, p->wino_bytes, as_stream(stream))
+                rc = L.wino_d ? clhip_internal_wino_conv_u(1, gin, reinterpret_cast<const float*>(base + p->off_wino + L.wino_ud), nullptr,
+                                                           xin, gout_d, idx + L.idx_off, 1, N, L.cout, L.cin, L.h, L.w, 0, as_stream(stream))
                               : clhip_conv3x3_bwd_data_unpool(gin, idx + L.idx_off, params + L.w_off, xin, gout_d, N, L.cin, L.cout, L.h,
                                                               L.w, stream);
                 if (rc == 0) { ddone = true; probe_end(1); }
@@ -796,8 +822,8 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
             float* gout = take();
             probe_begin(1);
             rc = (vgg && L.wino_d)
-                     ? clhip_internal_wino_conv(1, gy, params + L.w_off, nullptr, xin, gout, nullptr, 0, N, L.cout, L.cin, L.h, L.w, 0,
-                                                base + p->off_wino, p->wino_bytes, as_stream(stream))
+                     ? clhip_internal_wino_conv_u(1, gy, reinterpret_cast<const float*>(base + p->off_wino + L.wino_ud), nullptr, xin, gout,
+                                                  nullptr, 0, N, L.cout, L.cin, L.h, L.w, 0, as_stream(stream))
                  : vgg ? clhip_conv3x3_bwd_data(gy, params + L.w_off, xin, gout, N, L.cin, L.cout, L.h, L.w, stream)
                      : clhip_conv2d_bwd_data(gy, params + L.w_off, xin, gout, N, L.cin, L.h, L.w, L.cout, L.ks, L.ks, L.st, L.pd, stream);
             if (rc) return rc;
@@ -846,7 +872,7 @@ int clhip_net_loss_step_slice(void* handle, const float* params, float* grads, c
         // backward-data chain down to dz(h1); backward resumes at the first Linear layer
         if (loss_kind != 0 && loss_kind != 1) return CLHIP_EINVAL;
         int live = 0;
-        int rc = net_forward_impl(handle, params, x, N, ws, nullptr, stream, 1, &live);
+        int rc = net_forward_impl(handle, params, x, N, ws, nullptr, stream, 1, &live, grads != nullptr);
         if (rc) return rc;
         float* acts = reinterpret_cast<float*>(base + p->off_acts);
         rc = clhip_internal_fc_tail(&p->chain, params, acts, N, labels, loss_kind, col_off, nc, dlogits,
@@ -859,10 +885,10 @@ int clhip_net_loss_step_slice(void* handle, const float* params, float* grads, c
                                           hipMemcpyDeviceToDevice, as_stream(stream));
             if (e != hipSuccess) return (int)e;
         }
-        if (grads) rc = net_backward_impl(handle, params, grads, x, N, ws, dlogits, stream, true);
+        if (grads) rc = net_backward_impl(handle, params, grads, x, N, ws, dlogits, stream, true, true);
         return rc;
     }
-    int rc = net_forward_impl(handle, params, x, N, ws, logits_out, stream, 0);
+    int rc = net_forward_impl(handle, params, x, N, ws, logits_out, stream, 0, nullptr, grads != nullptr);
     if (rc) return rc;
     const LayerPlan& last = p->layers.back();
     const float* logits = reinterpret_cast<float*>(base + p->off_acts) + last.act_off;
@@ -870,7 +896,7 @@ int clhip_net_loss_step_slice(void* handle, const float* params, float* grads, c
     else rc = clhip_softmax_ce_slice(logits, labels, N, p->n_classes, col_off, ncols > 0 ? ncols : p->n_classes - col_off,
                                      loss_kind, dlogits, loss_dev, stats, stream);
     if (rc) return rc;
-    if (grads) rc = clhip_net_backward(handle, params, grads, x, N, ws, dlogits, stream);
+    if (grads) rc = net_backward_impl(handle, params, grads, x, N, ws, dlogits, stream, false, true);
     return rc;
 }
 

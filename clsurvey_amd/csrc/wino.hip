@@ -76,6 +76,50 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
     }
 }
 
+// The same for several (layer, mode) pairs in ONE launch: the plan executor transforms the weights of every Winograd layer of a
+// pass at its start (six ~5 us launches per pass of small_VGG9 were 3 % of the step).
+constexpr int WT_JOBS = 24;
+struct WtJobs { int n; int pad; clhip_wino_wt j[WT_JOBS]; int first[WT_JOBS + 1]; };
+
+__device__ __forceinline__ void wino_weight_one(const float* __restrict__ w, float* __restrict__ U, int Ko, int Ci, int mode,
+                                                int n_chunks, int i) {
+    const int k_l = i % WKT, c_l = (i / WKT) % WCK, chunk = (i / (WKT * WCK)) % n_chunks, kt = i / (WKT * WCK * n_chunks);
+    const int k = kt * WKT + k_l, c = chunk * WCK + c_l;
+    float g[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            float v = 0.f;
+            if (k < Ko && c < Ci)
+                v = mode == 0 ? w[((size_t)k * Ci + c) * 9 + r * 3 + s] : w[((size_t)c * Ko + k) * 9 + (2 - r) * 3 + (2 - s)];
+            g[r][s] = v;
+        }
+    float t[4][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        t[0][s] = g[0][s];
+        t[1][s] = 0.5f * (g[0][s] + g[1][s] + g[2][s]);
+        t[2][s] = 0.5f * (g[0][s] - g[1][s] + g[2][s]);
+        t[3][s] = g[2][s];
+    }
+    float4* dst = reinterpret_cast<float4*>(U + (((size_t)(kt * n_chunks + chunk) * WCK + c_l) * WKT + k_l) * WFP);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+        dst[a] = make_float4(t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]), t[a][2]);
+    dst[4] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__global__ __launch_bounds__(256) void wino_weight_multi_kernel(WtJobs J) {
+    int jb = 0;
+    for (int i = 1; i < J.n; ++i) jb = ((int)blockIdx.x >= J.first[i]) ? i : jb;
+    const clhip_wino_wt& q = J.j[jb];
+    const int n_chunks = (q.Ci + WCK - 1) / WCK;
+    const int total = ((q.Ko + WKT - 1) / WKT) * n_chunks * WCK * WKT;
+    const int i = ((int)blockIdx.x - J.first[jb]) * 256 + threadIdx.x;
+    if (i < total) wino_weight_one(q.w, q.U, q.Ko, q.Ci, q.mode, n_chunks, i);
+}
+
 // MODE 0: forward   — out = [relu](conv(in, w) + bias), optionally 2x2-max-pooled with arg-max codes (pool_idx != NULL)
 // MODE 1: backward-data — in = dy (Cin = the layer's out channels), out = dx (* (mask_src > 0) when mask_src != NULL);
 //         UNPOOL: `in` is the gradient w.r.t. the POOLED output + the forward's arg-max codes (fused max_pool2d backward)
@@ -597,6 +641,39 @@ size_t clhip_internal_wino_ws(int Cin, int Cout) {
 // forward (mode 0) / backward-data (mode 1) through the Winograd path.  ws: clhip_internal_wino_ws(Cin, Cout) bytes.
 // For backward-data the caller passes Cin = the layer's OUT channels (channels of dy), Cout = its IN channels; `w` is the
 // layer's weight tensor [K][C][3][3] in both modes.
+// the convolution alone, on weights already transformed into U (clhip_internal_wino_weights or the single-layer kernel)
+int clhip_internal_wino_conv_u(int mode, const float* in, const float* U, const float* bias, const float* mask_src, float* out,
+                               uint8_t* pool_idx, int unpool, int N, int Cin, int Cout, int H, int W, int relu, hipStream_t s) {
+    if (!in || !U || !out || !clhip_internal_wino_ok(Cin, Cout, H, W)) return CLHIP_EINVAL;
+    if (mode == 0) return launch_wino<0, false>(in, U, bias, nullptr, out, pool_idx, N, Cin, Cout, H, W, relu, s);
+    if (unpool) return launch_wino<1, true>(in, U, nullptr, mask_src, out, pool_idx, N, Cin, Cout, H, W, 0, s);
+    return launch_wino<1, false>(in, U, nullptr, mask_src, out, nullptr, N, Cin, Cout, H, W, 0, s);
+}
+
+// U for several (weights, mode) pairs in one launch (jobs: host array; Ko / Ci are the channel counts as the KERNEL sees them)
+int clhip_internal_wino_weights(const clhip_wino_wt* jobs, int n, hipStream_t s) {
+    if (n <= 0) return 0;
+    if (!jobs) return CLHIP_EINVAL;
+    for (int base = 0; base < n; base += WT_JOBS) {
+        WtJobs J;
+        J.n = n - base < WT_JOBS ? n - base : WT_JOBS;
+        J.pad = 0;
+        int blocks = 0;
+        for (int i = 0; i < J.n; ++i) {
+            const clhip_wino_wt& q = jobs[base + i];
+            if (!q.w || !q.U || q.Ko <= 0 || q.Ci <= 0) return CLHIP_EINVAL;
+            J.j[i] = q;
+            J.first[i] = blocks;
+            const int total = ((q.Ko + WKT - 1) / WKT) * ((q.Ci + WCK - 1) / WCK) * WCK * WKT;
+            blocks += (total + 255) / 256;
+        }
+        J.first[J.n] = blocks;
+        hipLaunchKernelGGL(wino_weight_multi_kernel, dim3(blocks), dim3(256), 0, s, J);
+        CLHIP_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 int clhip_internal_wino_conv(int mode, const float* in, const float* w, const float* bias, const float* mask_src, float* out,
                              uint8_t* pool_idx, int unpool, int N, int Cin, int Cout, int H, int W, int relu, void* ws,
                              size_t ws_bytes, hipStream_t s) {
@@ -607,9 +684,7 @@ int clhip_internal_wino_conv(int mode, const float* in, const float* w, const fl
     const int total = ((Cout + WKT - 1) / WKT) * n_chunks * WCK * WKT;
     hipLaunchKernelGGL(wino_weight_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w, U, Cout, Cin, mode, n_chunks);
     CLHIP_LAUNCH_CHECK();
-    if (mode == 0) return launch_wino<0, false>(in, U, bias, nullptr, out, pool_idx, N, Cin, Cout, H, W, relu, s);
-    if (unpool) return launch_wino<1, true>(in, U, nullptr, mask_src, out, pool_idx, N, Cin, Cout, H, W, 0, s);
-    return launch_wino<1, false>(in, U, nullptr, mask_src, out, nullptr, N, Cin, Cout, H, W, 0, s);
+    return clhip_internal_wino_conv_u(mode, in, U, bias, mask_src, out, pool_idx, unpool, N, Cin, Cout, H, W, relu, s);
 }
 
 // ---- weight gradient through the Winograd path: slabs only, in the format of conv3x3_wgrad.hip (see wino_wgrad_kernel)
