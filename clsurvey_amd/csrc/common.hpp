@@ -34,6 +34,14 @@ static __device__ __attribute__((aligned(16))) float clhip_zero16[4] = {0.f, 0.f
 // predicate costs one v_cndmask on the 32-bit offset instead of a select on the value (which waits for the load) or
 // an exec-mask branch.  num_records is clipped so that CLHIP_OOB is always out of range.
 constexpr int CLHIP_OOB = (int)0x80000000;
+
+// 2x2 max-pool arg-max bytes of the fused conv + ReLU + pool kernels: 0..3 = window position (row-major, first maximum in
+// ATen's scan order), CLHIP_POOL_DEAD = the window's maximum after ReLU is not positive.  max_pool2d backward routes the
+// gradient to the arg-max position and ReLU backward then multiplies it by (output > 0) (VGGSlim.py:32,38): for a dead
+// window that is 0 at every position, so the consumers' `code == position` tests implement BOTH backward operators and
+// the backward-data kernel of the NEXT layer needs no (input > 0) mask (52 MB of reads per launch on layer 2 of the
+// bench model, measured 21 us of 146).  clhip_maxpool2_fwd keeps producing plain arg-max bytes (no ReLU knowledge).
+constexpr int CLHIP_POOL_DEAD = 4;
 typedef unsigned int clhip_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t clhip_rsrc(const void* p, size_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes > 0x7fffffffull ? 0x7fffffff : (int)bytes, 0x00020000);

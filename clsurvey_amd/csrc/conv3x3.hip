@@ -530,6 +530,7 @@ __device__ __forceinline__ void conv3x3_mfma_body(
                 if (tr > m) { m = tr; a = 1; }
                 if (bl > m) { m = bl; a = 2; }
                 if (br > m) { m = br; a = 3; }
+                if (!(m > 0.f)) a = CLHIP_POOL_DEAD;      // ReLU folded into the code: no window position takes a gradient
                 const bool okr = ok && (kfull || kb + rch(r) < Cout);
                 const int eo = eoff + rch(r) * chw;
                 clhip_buf_store(m, rs_o, okr ? eo * 4 : CLHIP_OOB, 0);
@@ -886,6 +887,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_relu_pool_kernel(
                 if (tr > m) { m = tr; am = 1; }
                 if (bl > m) { m = bl; am = 2; }
                 if (br > m) { m = br; am = 3; }
+                if (!(m > 0.f)) am = CLHIP_POOL_DEAD;
                 acc[half][0][r] = m;                           // results stay in the accumulator registers ...
                 acc[half][1][r] = __int_as_float(am);
             }
@@ -1081,6 +1083,7 @@ __global__ __launch_bounds__(512) void conv3x3_c3w64_relu_pool_kernel(
             if (tr > m) { m = tr; am = 1; }
             if (bl > m) { m = bl; am = 2; }
             if (br > m) { m = br; am = 3; }
+            if (!(m > 0.f)) am = CLHIP_POOL_DEAD;
             const bool cok = FULL || cbase + c0 + 4 * kk < Cout;
             clhip_buf_store(m, r_o, cok ? ovoff * 4 : CLHIP_OOB, (obase + c0 * chw) * 4);
             clhip_buf_store_u8((uint8_t)am, r_i, cok ? ovoff : CLHIP_OOB, obase + c0 * chw);

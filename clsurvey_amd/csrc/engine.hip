@@ -677,6 +677,14 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
             xin = acts + ((P.type == 0 && P.pool) ? P.pool_off : P.act_off);
             if (L.drop && L.has_drop_buf) xin = acts + L.drop_off;
         }
+        // ReLU mask of this layer's backward-data, (input > 0).  Not needed when the input is the pooled output of a fused
+        // conv + ReLU + pool launch: its arg-max bytes mark the windows without a positive maximum (CLHIP_POOL_DEAD) and
+        // the un-pooling consumers of the gradient drop them (common.hpp)
+        const float* xmask = xin;
+        if (i > 0 && L.type == 0 && !L.drop) {
+            const LayerPlan& P = p->layers[i - 1];
+            if (P.type == 0 && !P.bn && P.ks == 3 && P.st == 1 && P.pd == 1 && P.pool && P.pk == 2 && P.ps == 2 && P.relu) xmask = nullptr;
+        }
         if (L.type == 1 && tail_done && i > p->fc_first) {
             // the fused tail has already left dz of this layer's input in its fcdz slot
             gin = fcdz + p->chain.dz_off[i - p->fc_first - 1];
@@ -771,8 +779,8 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
                 gout_d = take(); gout_d_buf = taken;
                 probe_begin(1);
                 rc = L.wino_d ? clhip_internal_wino_conv_u(1, gin, reinterpret_cast<const float*>(base + p->off_wino + L.wino_ud), nullptr,
-                                                           xin, gout_d, idx + L.idx_off, 1, N, L.cout, L.cin, L.h, L.w, 0, as_stream(stream))
-                              : clhip_conv3x3_bwd_data_unpool(gin, idx + L.idx_off, params + L.w_off, xin, gout_d, N, L.cin, L.cout, L.h,
+                                                           xmask, gout_d, idx + L.idx_off, 1, N, L.cout, L.cin, L.h, L.w, 0, as_stream(stream))
+                              : clhip_conv3x3_bwd_data_unpool(gin, idx + L.idx_off, params + L.w_off, xmask, gout_d, N, L.cin, L.cout, L.h,
                                                               L.w, stream);
                 if (rc == 0) { ddone = true; probe_end(1); }
                 else if (rc != CLHIP_ENOTSUP) return rc;
@@ -822,10 +830,10 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
             float* gout = take();
             probe_begin(1);
             rc = (vgg && L.wino_d)
-                     ? clhip_internal_wino_conv_u(1, gy, reinterpret_cast<const float*>(base + p->off_wino + L.wino_ud), nullptr, xin, gout,
+                     ? clhip_internal_wino_conv_u(1, gy, reinterpret_cast<const float*>(base + p->off_wino + L.wino_ud), nullptr, xmask, gout,
                                                   nullptr, 0, N, L.cout, L.cin, L.h, L.w, 0, as_stream(stream))
-                 : vgg ? clhip_conv3x3_bwd_data(gy, params + L.w_off, xin, gout, N, L.cin, L.cout, L.h, L.w, stream)
-                     : clhip_conv2d_bwd_data(gy, params + L.w_off, xin, gout, N, L.cin, L.h, L.w, L.cout, L.ks, L.ks, L.st, L.pd, stream);
+                 : vgg ? clhip_conv3x3_bwd_data(gy, params + L.w_off, xmask, gout, N, L.cin, L.cout, L.h, L.w, stream)
+                     : clhip_conv2d_bwd_data(gy, params + L.w_off, xmask, gout, N, L.cin, L.h, L.w, L.cout, L.ks, L.ks, L.st, L.pd, stream);
             if (rc) return rc;
             probe_end(1);
             gin = gout; gin_buf = taken;

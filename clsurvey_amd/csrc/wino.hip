@@ -339,6 +339,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(
                 if (y01 > m) { m = y01; a = 1; }
                 if (y10 > m) { m = y10; a = 2; }
                 if (y11 > m) { m = y11; a = 3; }
+                if (relu && !(m > 0.f)) a = CLHIP_POOL_DEAD;   // ReLU folded into the code (see common.hpp)
                 if (ok) {
                     const size_t o = ((size_t)n * Cout + k) * OH * OW + (size_t)(oh >> 1) * OW + (ow >> 1);
                     out[o] = m;

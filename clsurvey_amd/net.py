@@ -270,7 +270,8 @@ class NetEngine:
 
     def pool_idx(self, layer, n):
         """[n][elems] uint8 view of the arg-max codes (window position r*k + c) the last forward stored for the
-        max-pooled conv layer `layer`."""
+        max-pooled conv layer `layer`.  The fused conv + ReLU + 2x2-pool kernels write 4 (no position) for a window whose
+        maximum after ReLU is not positive: no gradient passes through it (csrc/common.hpp, CLHIP_POOL_DEAD)."""
         off, elems = C.c_size_t(), C.c_size_t()
         check(_lib.lib().clhip_net_layer_pool_idx(self._h, int(layer), C.byref(off), C.byref(elems)), "clhip_net_layer_pool_idx")
         return self.ws[off.value:off.value + n * elems.value].view(n, elems.value)

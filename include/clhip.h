@@ -46,7 +46,10 @@ int clhip_conv3x3_fwd(const float* x, const float* w, const float* b, float* y,
                       int N, int C, int K, int H, int W, int relu, void* stream);
 
 /* Fused conv + bias + ReLU + 2x2/2 max-pool (VGGSlim.py:32-38): y_pool[N][K][H/2][W/2], idx_u8 = argmax
- * (0..3).  The pre-pool activation is never written (the first layer's would be 210 MB per batch).      */
+ * (0..3), or 4 for a window whose maximum after ReLU is not positive: max_pool2d backward followed by ReLU backward
+ * (VGGSlim.py:32,38) passes nothing through such a window, so every consumer of the codes (`code == position`) applies
+ * both, and backward-data of the NEXT layer may be called with relu_src = NULL.  The pre-pool activation is never
+ * written (the first layer's would be 210 MB per batch).                                                    */
 int clhip_conv3x3_relu_pool_fwd(const float* x, const float* w, const float* b, float* y_pool, uint8_t* idx_u8,
                                 int N, int C, int K, int H, int W, void* stream);
 
@@ -87,7 +90,8 @@ int clhip_conv3x3_bwd_weight_unpool(const float* x, const float* dy_pool, const 
 
 /* ------------------------------------------------------------------ max-pool 2x2 stride 2
  * nn.MaxPool2d(2, 2) — models/VGGSlim.py:32. idx_u8 holds the argmax (0..3, row-major in the
- * window, first maximum wins as in ATen).  H, W are the INPUT sizes (even).                */
+ * window, first maximum wins as in ATen).  H, W are the INPUT sizes (even).  The backward kernel
+ * also takes the fused kernels' code 4 ("no positive maximum": the window gets no gradient).        */
 int clhip_maxpool2_fwd(const float* x, float* y, uint8_t* idx_u8, int NC, int H, int W, void* stream);
 int clhip_maxpool2_bwd(const float* dy, const uint8_t* idx_u8, float* dx, int NC, int H, int W,
                        void* stream);

@@ -25,6 +25,13 @@ def dbg_lib():
     return _DBG
 
 
+def live_codes(idx):
+    """Arg-max bytes of the fused conv + ReLU + pool kernels -> window positions: code 4 (CLHIP_POOL_DEAD, the window's
+    maximum after ReLU is not positive, no gradient goes through it) reads as position 0, the arg-max ATen reports for an
+    all-zero window; the ReLU mask of the same block switches the window off in the forced-branch oracles."""
+    return idx.where(idx < 4, idx.new_zeros(()))
+
+
 def engine_decisions(eng, n):
     """The ReLU masks and max-pool arg-max codes of the executor's last forward, one dict per plan layer that has a
     ReLU, shaped for oracle.alexnet_ref.forward_forced.  (The saved activation behind a Dropout is already masked: a
@@ -50,5 +57,7 @@ def engine_decisions(eng, n):
             d["dropped"] = (eng._masks[li + 1].cpu() == 0).expand(n, -1).reshape(shape)
         if pool:
             d["idx"] = eng.pool_idx(li, n).view(shape).cpu().long()
+            if (pool if isinstance(pool, tuple) else (2, 2)) == (2, 2):     # only the fused 2x2 kernels write the dead code
+                d["idx"] = live_codes(d["idx"])
         out.append(d)
     return out

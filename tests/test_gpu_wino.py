@@ -42,9 +42,14 @@ def test_wino_forward_and_backward_data(shape):
     yc = y_ref.cuda() if not big else y_ref
     win = yc.reshape(N, K, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(N, K, H // 2, W // 2, 4)
     assert _rel(yp, win.max(4).values) <= 2e-5
-    picked = torch.gather(win, 4, idx.long().unsqueeze(-1)).squeeze(-1)
+    # (code 4 = the window has no positive maximum after ReLU: ReLU folded into the code, csrc/common.hpp)
+    assert torch.equal(idx == 4, yp == 0)
+    live = idx.long().where(idx < 4, torch.zeros((), dtype=torch.long, device=idx.device))
+    picked = torch.gather(win, 4, live.unsqueeze(-1)).squeeze(-1)
     assert float((picked - win.max(4).values).abs().max()) <= 2e-5 * float(yc.abs().max())
-    assert int(idx.max()) <= 3
+    assert int(idx.max()) <= 4
+    ypn, idxn = ops.conv3x3_wino_fwd(xd, wd, bd, relu=False, pool=True)           # without ReLU the codes are plain arg-max bytes
+    assert int(idxn.max()) <= 3
     if C % 32 or K < 16:
         return              # backward-data runs the same kernel with the channel roles swapped: its own shape domain
     # backward-data (+ ReLU mask of the producing layer), plain and from the pooled gradient
@@ -59,7 +64,7 @@ def test_wino_forward_and_backward_data(shape):
     dxm = ops.conv3x3_wino_bwd_data(dyd, wd, relu_src=md)
     assert _rel(dxm, dx_ref.cuda() * (md > 0)) <= 2e-5
     dyp = torch.from_numpy(gen.standard_normal((N, K, H // 2, W // 2)).astype(np.float32)).cuda()
-    code = torch.from_numpy(gen.randint(0, 4, size=(N, K, H // 2, W // 2)).astype(np.uint8)).cuda()
+    code = torch.from_numpy(gen.randint(0, 5, size=(N, K, H // 2, W // 2)).astype(np.uint8)).cuda()
     dy_full = ops.maxpool2_bwd(dyp, code)
     ref_u = ops.conv3x3_bwd_data(dy_full, wd, md)
     assert _rel(ops.conv3x3_wino_bwd_data(dyp, wd, relu_src=md, idx=code), ref_u) <= 2e-5
@@ -101,7 +106,7 @@ def test_wino_weight_gradient(shape):
     dw2, db2 = ops.conv3x3_wino_bwd_weight(xd, dyd)
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
     dyp = torch.from_numpy(gen.standard_normal((N, K, H // 2, W // 2)).astype(np.float32)).cuda()
-    code = torch.from_numpy(gen.randint(0, 4, size=(N, K, H // 2, W // 2)).astype(np.uint8)).cuda()
+    code = torch.from_numpy(gen.randint(0, 5, size=(N, K, H // 2, W // 2)).astype(np.uint8)).cuda()
     dw_u_ref, db_u_ref = ops.conv3x3_bwd_weight(xd, ops.maxpool2_bwd(dyp, code))
     dw_u, db_u = ops.conv3x3_wino_bwd_weight(xd, dyp, idx=code)
     assert _rel(dw_u, dw_u_ref) <= 5e-5 and _rel(db_u, db_u_ref) <= 5e-5
