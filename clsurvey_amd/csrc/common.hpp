@@ -124,6 +124,11 @@ int clhip_internal_conv3x3_wgrad_partial(const float* x, const float* dy, const 
                                          int C, int K, int H, int W, void* ws, size_t ws_bytes, void* stream, clhip_wgrad_job* job);
 int clhip_internal_wgrad_reduce_multi(const clhip_wgrad_job* jobs, int n, hipStream_t s);
 
+// convkk.hip: K x K stride-1 convolution on small maps with the plane staged in LDS (AlexNet's 5x5 layer); mode 0 forward, 1 backward-data
+bool clhip_internal_convkk_ok(int N, int Cin, int Cout, int H, int W, int R, int S, int stride, int pad);
+int clhip_internal_convkk(int mode, const float* in, const float* w, const float* bias, const float* mask_src, float* out, int N,
+                          int Cin, int Cout, int H, int W, int relu, hipStream_t s);
+
 // wino.hip: 3x3 convolution by Winograd F(2x2, 3x3) (forward / backward-data); see the file's header
 struct clhip_wino_wt { const float* w; float* U; int Ko, Ci, mode, pad; };
 int clhip_internal_wino_weights(const clhip_wino_wt* jobs, int n, hipStream_t s);

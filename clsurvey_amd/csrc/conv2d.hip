@@ -15,6 +15,7 @@
 // registers and stepped by 32 per chunk (no divisions in the loop), pixel decodes are done once per thread.
 // The 3x3 pad-1 stride-1 VGG layers never come here (conv3x3.hip is 2-3x faster on them).
 #include "common.hpp"
+#include <cstdlib>
 
 #ifdef CLHIP_TRACE
 __device__ unsigned long long* g_c2trace = nullptr;      // tuning aid: per-wave cycle sums of the loop phases
@@ -408,6 +409,12 @@ int wgrad_splits(int M, int Nn, long Kd) {
     return (int)s;
 }
 
+// CLHIP_CONVKK=0 keeps every layer on the gather-GEMM (A/B measurements)
+bool halo_kernel() {
+    static const bool on = [] { const char* e = getenv("CLHIP_CONVKK"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 }  // namespace
 
 extern "C" {
@@ -424,6 +431,8 @@ int clhip_conv2d_fwd(const float* x, const float* w, const float* b, float* y, i
                      int stride, int pad, int relu, void* stream) {
     int OH, OW;
     if (!x || !w || !y || !conv_ok(N, C, H, W, K, R, S, stride, pad, OH, OW)) return CLHIP_EINVAL;
+    if (halo_kernel() && clhip_internal_convkk_ok(N, C, K, H, W, R, S, stride, pad))        // 5x5 on small maps: plane staged in LDS
+        return clhip_internal_convkk(0, x, w, b, nullptr, y, N, C, K, H, W, relu, as_stream(stream));
     if (R * S > TAB_MAX) return CLHIP_ENOTSUP;
     const ConvP p{N, C, H, W, K, R, S, stride, pad, OH, OW};
     const int M = K, Nn = N * OH * OW, Kd = C * R * S;
@@ -442,6 +451,8 @@ int clhip_conv2d_bwd_data(const float* dy, const float* w, const float* relu_src
                           int R, int S, int stride, int pad, void* stream) {
     int OH, OW;
     if (!dy || !w || !dx || !conv_ok(N, C, H, W, K, R, S, stride, pad, OH, OW)) return CLHIP_EINVAL;
+    if (halo_kernel() && clhip_internal_convkk_ok(N, K, C, H, W, R, S, stride, pad))        // (stride 1, pad K/2: OH = H, OW = W)
+        return clhip_internal_convkk(1, dy, w, nullptr, relu_src, dx, N, K, C, H, W, 0, as_stream(stream));
     if (R * S > TAB_MAX) return CLHIP_ENOTSUP;
     const ConvP p{N, C, H, W, K, R, S, stride, pad, OH, OW};
     const int M = C, Nn = N * H * W, Kd = K * R * S;

@@ -894,6 +894,15 @@ def test_lwf_loss_kernel_and_engine_golden_g14(golden):
     (2, 192, 7, 7, 384, 3, 1, 1),      # conv3 (3x3, but through the general kernel)
     (5, 7, 9, 13, 10, 3, 2, 0),        # odd everything, stride 2, no padding
     (2, 16, 12, 12, 33, 4, 3, 1),
+    # 5x5 pad 2 on small maps: the LDS-halo kernel (convkk.hip) — two pixel parts per plane, partial last subtile, one part,
+    # a single 32-channel row tile, a wide flat map; then shapes it refuses (channel tails, too wide), which stay on the gather-GEMM
+    (3, 64, 27, 27, 192, 5, 1, 2),
+    (2, 8, 27, 27, 32, 5, 1, 2),
+    (4, 12, 13, 13, 64, 5, 1, 2),
+    (2, 4, 7, 28, 96, 5, 1, 2),
+    (1, 16, 28, 20, 32, 5, 1, 2),
+    (2, 6, 9, 9, 10, 5, 1, 2),
+    (1, 4, 30, 30, 32, 5, 1, 2),
 ])
 def test_conv2d_general(shape):
     import torch.nn.functional as F
