@@ -214,7 +214,7 @@ int clhip_net_create(const clhip_layer_desc* descs, int n_layers, int max_batch,
             // pixels) with 256 accumulator registers, one wave per SIMD: it needs enough units to fill most of the 1024 SIMDs
             // (measured at N = 200: 64->64 @16x16, 800 units, 1.26x the direct kernel; 128->128 @8x8, 400 units, 0.8x)
             if (vgg && !L.bn && wino_enabled()) {
-                const long long tiles = (long long)max_batch * (L.h / 2) * (L.w / 2);
+                const long long tiles = (long long)max_batch * ((L.h + 1) / 2) * ((L.w + 1) / 2);
                 auto units = [&](int kout) { return ((tiles + 31) / 32) * ((kout + 31) / 32); };
                 L.wino_f = clhip_internal_wino_ok(L.cin, L.cout, L.h, L.w) && units(L.cout) >= WINO_MIN_UNITS;
                 L.wino_d = i > 0 && clhip_internal_wino_ok(L.cout, L.cin, L.h, L.w) && units(L.cin) >= WINO_MIN_UNITS;
@@ -222,12 +222,16 @@ int clhip_net_create(const clhip_layer_desc* descs, int n_layers, int max_batch,
                 // few 16-tile stages to amortise its 256-accumulator epilogue (measured: 12.5 stages per block 1.44x, 3.1 0.6x)
                 if (clhip_internal_wino_wgrad_ok(L.cin, L.cout, L.h, L.w)) {
                     const int kc = (L.cin / 64) * (L.cout / 64), splits = (256 + kc - 1) / kc;
-                    const long long stages = (long long)max_batch * ((L.w / 2 + (L.w >= 16 ? 7 : 3)) / (L.w >= 16 ? 8 : 4)) *
-                                             ((L.h / 2 + (L.w >= 16 ? 1 : 3)) / (L.w >= 16 ? 2 : 4));
+                    const long long stages = (long long)max_batch * (((L.w + 1) / 2 + (L.w >= 16 ? 7 : 3)) / (L.w >= 16 ? 8 : 4)) *
+                                             (((L.h + 1) / 2 + (L.w >= 16 ? 1 : 3)) / (L.w >= 16 ? 2 : 4));
                     L.wino_w = stages >= 8LL * splits;
-                    if (L.wino_w && L.wg3) {          // its slabs live in this layer's weight-gradient region
+                    if (L.wino_w) {                   // its slabs live in this layer's weight-gradient region
                         const size_t ww = clhip_internal_wino_wgrad_ws(max_batch, L.cin, L.cout, L.h, L.w);
-                        if (ww > L.wg_bytes) { wg_total += align_up(ww, 256) - L.wg_bytes; L.wg_bytes = align_up(ww, 256); }
+                        if (L.wg3) {
+                            if (ww > L.wg_bytes) { wg_total += align_up(ww, 256) - L.wg_bytes; L.wg_bytes = align_up(ww, 256); }
+                        } else {                      // (AlexNet's 13x13 layers: the direct path is the gather-GEMM, which has no slabs)
+                            L.wg_off = wg_total; L.wg_bytes = align_up(ww, 256); wg_total += L.wg_bytes; ++n_wg;
+                        }
                     }
                 }
                 // every Winograd layer keeps its own transformed weights: ONE transform launch per pass fills them all
@@ -528,7 +532,10 @@ static int net_forward_impl(void* handle, const float* params, const float* x, i
             // general geometry (AlexNet) and BatchNorm layers: separate conv (+bias, ReLU), BatchNorm and pool kernels
             float* zc = L.bn ? acts + L.z_off : y;
             const int crelu = L.bn ? 0 : L.relu;
-            rc = vgg ? clhip_conv3x3_fwd(cur, params + L.w_off, params + L.b_off, zc, N, L.cin, L.cout, L.h, L.w, crelu, stream)
+            rc = (vgg && L.wino_f)
+                     ? clhip_internal_wino_conv_u(0, cur, reinterpret_cast<const float*>(base + p->off_wino + L.wino_uf), params + L.b_off,
+                                                  nullptr, zc, nullptr, 0, N, L.cin, L.cout, L.h, L.w, crelu, as_stream(stream))
+                 : vgg ? clhip_conv3x3_fwd(cur, params + L.w_off, params + L.b_off, zc, N, L.cin, L.cout, L.h, L.w, crelu, stream)
                      : clhip_conv2d_fwd(cur, params + L.w_off, params + L.b_off, zc, N, L.cin, L.h, L.w, L.cout, L.ks, L.ks, L.st,
                                         L.pd, crelu, stream);
             if (rc) return rc;
@@ -804,17 +811,21 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
             if (rc) return rc;
         }
         if (!wdone) {
+            bool job = false;                 // this layer left slabs for the deferred reduction
             probe_begin(2);
             rc = on_side(i, gy_buf, [&](void* st) {
-                if (L.wg3 && defer && L.wino_w) {
+                if (defer && L.wino_w && L.wg_bytes) {
                     const int r = clhip_internal_wino_wgrad_partial(xin, gy, nullptr, grads + L.w_off, grads + L.b_off, N, L.cin, L.cout,
                                                                     L.h, L.w, base + p->off_wg + L.wg_off, L.wg_bytes, as_stream(st),
                                                                     &jobs[n_jobs]);
+                    if (r == 0) job = true;
                     if (r != CLHIP_ENOTSUP && r != CLHIP_ENOSPC) return r;
                 }
-                if (L.wg3 && defer)
+                if (L.wg3 && defer) {
+                    job = true;
                     return clhip_internal_conv3x3_wgrad_partial(xin, gy, nullptr, grads + L.w_off, grads + L.b_off, N, L.cin, L.cout, L.h,
                                                                 L.w, base + p->off_wg + L.wg_off, L.wg_bytes, st, &jobs[n_jobs]);
+                }
                 return L.wg3 ? clhip_conv3x3_bwd_weight(xin, gy, grads + L.w_off, grads + L.b_off, N, L.cin, L.cout, L.h, L.w, scratch,
                                                       p->scratch_bytes, st)
                            : clhip_conv2d_bwd_weight(xin, gy, grads + L.w_off, grads + L.b_off, N, L.cin, L.h, L.w, L.cout, L.ks, L.ks,
@@ -822,7 +833,7 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
             });
             if (rc) return rc;
             probe_end(2);
-            if (L.wg3 && defer) ++n_jobs;
+            if (job) ++n_jobs;
         }
         if (i > 0 && ddone) {
             gin = gout_d; gin_buf = gout_d_buf;

@@ -123,12 +123,16 @@ __global__ __launch_bounds__(256) void wino_weight_multi_kernel(WtJobs J) {
 // MODE 0: forward   — out = [relu](conv(in, w) + bias), optionally 2x2-max-pooled with arg-max codes (pool_idx != NULL)
 // MODE 1: backward-data — in = dy (Cin = the layer's out channels), out = dx (* (mask_src > 0) when mask_src != NULL);
 //         UNPOOL: `in` is the gradient w.r.t. the POOLED output + the forward's arg-max codes (fused max_pool2d backward)
-template <int TCB, int TRB, int NIMG, int MODE, bool UNPOOL>
+//         ROWPACK (TRB = 1): the block's NIMG "images" are NIMG consecutive TILE ROWS of the (image, tile row) list — odd maps
+//         (AlexNet's 13 x 13: 7 x 7 tiles) fill 49 of 56 tile slots instead of 49 of 64; odd H / W: the last tile row / column
+//         is half outside (its inputs read 0, its outputs are not stored; 4-byte stores, rows of odd length are not 8-byte aligned)
+template <int TCB, int TRB, int NIMG, int MODE, bool UNPOOL, bool ROWPACK = false>
 __global__ __launch_bounds__(256, 1) void wino_conv_kernel(
     const float* __restrict__ in, const float* __restrict__ U, const float* __restrict__ bias,
     const float* __restrict__ mask_src, float* __restrict__ out, uint8_t* __restrict__ pool_idx,
     int N, int Cin, int Cout, int H, int W, int relu, int tiles_w, int tiles_h, int n_pix_blocks) {
     using G = WGeoW<TCB, TRB, NIMG>;
+    static_assert(!ROWPACK || (TRB == 1 && !UNPOOL), "row packing: one tile row per entity, no fused un-pooling");
     __shared__ __attribute__((aligned(16))) float lds[2 * G::BUF];
     __shared__ float bias_s[WKT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -137,7 +141,9 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(
 
     const int kt = blockIdx.x / n_pix_blocks, pb = blockIdx.x - kt * n_pix_blocks;
     const int bw = pb % tiles_w, bh = (pb / tiles_w) % tiles_h, ng = pb / (tiles_w * tiles_h);
-    const int n0 = ng * NIMG, h0 = bh * 2 * TRB, w0 = bw * 2 * TCB;
+    // ROWPACK: tiles_h = tile rows per image, entity v = v0 + nb = (image v / tiles_h, tile row v % tiles_h); offsets relative to image n0
+    const int v0 = ROWPACK ? pb * NIMG : 0;
+    const int n0 = ROWPACK ? v0 / tiles_h : ng * NIMG, h0 = ROWPACK ? 0 : bh * 2 * TRB, w0 = ROWPACK ? 0 : bw * 2 * TCB;
     const int ko0 = kt * WKT;
     const int n_chunks = (Cin + WCK - 1) / WCK;
     if (MODE == 0 && tid < WKT) bias_s[tid] = (bias && ko0 + tid < Cout) ? bias[ko0 + tid] : 0.f;
@@ -169,13 +175,16 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(
             const int cl = e / G::PLANE, rem = e - cl * G::PLANE;
             const int col = rem % G::PW, rr = rem / G::PW;
             const int row = rr % G::PR, nb = rr / G::PR;
-            const int n = n0 + nb, h = h0 - 1 + row, w = w0 - 1 + col;
+            int n = n0 + nb, h = h0 - 1 + row;
+            const int w = w0 - 1 + col;
+            if constexpr (ROWPACK) { const int v = v0 + nb; n = v / tiles_h; h = 2 * (v - n * tiles_h) - 1 + row; }
+            const int nr = n - n0;                                       // image relative to the block's base pointer
             if (n < N && h >= 0 && h < H && w >= 0 && w < W) {
                 if constexpr (UNPOOL) {
-                    xoff[j] = (int)(((size_t)nb * Cin + cl) * plane_in) + (h >> 1) * Wi + (w >> 1);     // ELEMENT offset
+                    xoff[j] = (int)(((size_t)nr * Cin + cl) * plane_in) + (h >> 1) * Wi + (w >> 1);     // ELEMENT offset
                     xcode[j] = ((h & 1) << 1) | (w & 1);
                 } else {
-                    xoff[j] = ((int)(((size_t)nb * Cin + cl) * plane_in) + h * W + w) * 4;
+                    xoff[j] = ((int)(((size_t)nr * Cin + cl) * plane_in) + h * W + w) * 4;
                 }
             }
         }
@@ -313,8 +322,12 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(
     // register r of lane l = (out channel kb + rch(r), tile l) in every frequency accumulator
     const int kb = ko0 + wk * 32 + 4 * kk;
     auto rch = [](int r) { return (r & 3) + 8 * (r >> 2); };
-    const int n = n0 + t_img, oh = h0 + 2 * t_row, ow = w0 + 2 * t_col;
+    int n = n0 + t_img, oh = h0 + 2 * t_row;
+    const int ow = w0 + 2 * t_col;
+    if constexpr (ROWPACK) { const int v = v0 + t_img; n = v / tiles_h; oh = 2 * (v - n * tiles_h); }
     const bool tile_ok = n < N && oh < H && ow < W;                 // H, W even: a tile is inside or outside as a whole
+    const bool odd = (H | W) & 1;                                   // uniform; the last tile row / column may be half outside
+    const bool row1 = oh + 1 < H, col1 = ow + 1 < W;
     const bool pool = MODE == 0 && pool_idx != nullptr;
     const size_t chw = (size_t)H * W;
     const int OH = H >> 1, OW = W >> 1;
@@ -348,7 +361,19 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(
                 continue;
             }
         }
-        if (ok) {
+        if (ok && odd) {
+            const size_t o = ((size_t)n * Cout + k) * chw + (size_t)oh * W + ow;
+            if (MODE == 1 && mask_src) {
+                y00 = mask_src[o] > 0.f ? y00 : 0.f;
+                if (col1) y01 = mask_src[o + 1] > 0.f ? y01 : 0.f;
+                if (row1) y10 = mask_src[o + W] > 0.f ? y10 : 0.f;
+                if (row1 && col1) y11 = mask_src[o + W + 1] > 0.f ? y11 : 0.f;
+            }
+            out[o] = y00;
+            if (col1) out[o + 1] = y01;
+            if (row1) out[o + W] = y10;
+            if (row1 && col1) out[o + W + 1] = y11;
+        } else if (ok) {
             const size_t o = ((size_t)n * Cout + k) * chw + (size_t)oh * W + ow;
             if (MODE == 1 && mask_src) {
                 const float2 m0 = *reinterpret_cast<const float2*>(mask_src + o), m1 = *reinterpret_cast<const float2*>(mask_src + o + W);
@@ -614,12 +639,24 @@ int launch_wino(const float* in, const float* U, const float* bias, const float*
     const int kts = (Cout + WKT - 1) / WKT;
 #define WINO_GEO(TCB_, TRB_, NIMG_)                                                                                          \
     do {                                                                                                                      \
-        const int tiles_w = (W / 2 + TCB_ - 1) / TCB_, tiles_h = (H / 2 + TRB_ - 1) / TRB_, ngrp = (N + NIMG_ - 1) / NIMG_;   \
+        const int tiles_w = ((W + 1) / 2 + TCB_ - 1) / TCB_, tiles_h = ((H + 1) / 2 + TRB_ - 1) / TRB_, ngrp = (N + NIMG_ - 1) / NIMG_; \
         const long long npb = (long long)tiles_w * tiles_h * ngrp, blocks = npb * kts;                                        \
         if (blocks <= 0 || blocks > 0x7fffffffLL) return CLHIP_EINVAL;                                                        \
         hipLaunchKernelGGL((wino_conv_kernel<TCB_, TRB_, NIMG_, MODE, UNPOOL>), dim3((unsigned)blocks), dim3(256), 0, s, in, U, \
                            bias, mask_src, out, pool_idx, N, Cin, Cout, H, W, relu, tiles_w, tiles_h, (int)npb);              \
     } while (0)
+    if constexpr (!UNPOOL) {
+        if (((H | W) & 1) && W <= 16) {
+            // odd maps up to 16 wide (AlexNet's 13 x 13): 8 consecutive tile rows of the (image, tile row) list per block
+            const int trt = (H + 1) / 2;
+            const long long npb = ((long long)N * trt + 7) / 8, blocks = npb * kts;
+            if (blocks <= 0 || blocks > 0x7fffffffLL) return CLHIP_EINVAL;
+            hipLaunchKernelGGL((wino_conv_kernel<8, 1, 8, MODE, false, true>), dim3((unsigned)blocks), dim3(256), 0, s, in, U, bias,
+                               mask_src, out, nullptr, N, Cin, Cout, H, W, relu, 1, trt, (int)npb);
+            CLHIP_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (W >= 32) WINO_GEO(16, 4, 1);
     else if (W >= 16) WINO_GEO(8, 8, 1);
     else WINO_GEO(4, 4, 4);
@@ -630,9 +667,12 @@ int launch_wino(const float* in, const float* U, const float* bias, const float*
 
 }  // namespace
 
-// shapes this path takes: even H, W (2x2 output tiles), W % 2 == 0 for the 8-byte stores, channel counts in whole chunks
+// shapes this path takes: channel counts in whole chunks; even H, W (2x2 output tiles, 8-byte stores), or odd maps 9..16 wide
+// through the row-packed geometry (no fused pooling there: callers pass pool_idx / unpool only for even maps)
 bool clhip_internal_wino_ok(int Cin, int Cout, int H, int W) {
-    return Cin % WCK == 0 && Cin >= 16 && Cout % 32 == 0 && H % 2 == 0 && W % 2 == 0 && H >= 4 && W >= 8;
+    if (Cin % WCK || Cin < 16 || Cout % 32 || H < 4 || W < 8) return false;
+    if (((H | W) & 1) == 0) return true;
+    return W > 8 && W <= 16;
 }
 
 size_t clhip_internal_wino_ws(int Cin, int Cout) {
@@ -646,6 +686,7 @@ size_t clhip_internal_wino_ws(int Cin, int Cout) {
 int clhip_internal_wino_conv_u(int mode, const float* in, const float* U, const float* bias, const float* mask_src, float* out,
                                uint8_t* pool_idx, int unpool, int N, int Cin, int Cout, int H, int W, int relu, hipStream_t s) {
     if (!in || !U || !out || !clhip_internal_wino_ok(Cin, Cout, H, W)) return CLHIP_EINVAL;
+    if (((H | W) & 1) && (pool_idx || unpool)) return CLHIP_ENOTSUP;
     if (mode == 0) return launch_wino<0, false>(in, U, bias, nullptr, out, pool_idx, N, Cin, Cout, H, W, relu, s);
     if (unpool) return launch_wino<1, true>(in, U, nullptr, mask_src, out, pool_idx, N, Cin, Cout, H, W, 0, s);
     return launch_wino<1, false>(in, U, nullptr, mask_src, out, nullptr, N, Cin, Cout, H, W, 0, s);
@@ -690,7 +731,7 @@ int clhip_internal_wino_conv(int mode, const float* in, const float* w, const fl
 
 // ---- weight gradient through the Winograd path: slabs only, in the format of conv3x3_wgrad.hip (see wino_wgrad_kernel)
 bool clhip_internal_wino_wgrad_ok(int C, int K, int H, int W) {
-    return C % WKT == 0 && K % WKT == 0 && H % 2 == 0 && W % 2 == 0 && H >= 4 && W >= 8;
+    return C % WKT == 0 && K % WKT == 0 && H >= 4 && W >= 8;      // odd H / W: half-outside tiles stage zeros (no fused un-pooling there)
 }
 
 // slabs the launch below wants (it takes fewer when the workspace is smaller)
@@ -707,12 +748,15 @@ int clhip_internal_wino_wgrad_partial(const float* x, const float* dy, const uin
     if ((size_t)N * K * H * W >= ((size_t)1 << 29) || (size_t)N * C * H * W >= ((size_t)1 << 29)) return CLHIP_ENOTSUP;   // 32-bit byte offsets
     const bool wide = W >= 16;
     const int TCS = wide ? 8 : 4, TRS = wide ? 2 : 4;
-    const int tiles_w = (W / 2 + TCS - 1) / TCS, tiles_h = (H / 2 + TRS - 1) / TRS;
+    if (((H | W) & 1) && unpool_idx) return CLHIP_ENOTSUP;
+    const int tiles_w = ((W + 1) / 2 + TCS - 1) / TCS, tiles_h = ((H + 1) / 2 + TRS - 1) / TRS;
     const long long total = (long long)tiles_w * tiles_h * N;
     if (total > 0x7fffffffLL) return CLHIP_ENOTSUP;
     const int kc_tiles = (K / WKT) * (C / WKT);
     const size_t slab = (size_t)9 * K * C + K;
-    long long splits = (256 + kc_tiles - 1) / kc_tiles;
+    // one block per CU: the largest split count that keeps the grid within 256 blocks (18 (k, c) tiles x 15 splits = 270 blocks
+    // ran as two rounds on AlexNet's 192 -> 384 layer: 405 us against 215 us with 14 splits)
+    long long splits = kc_tiles >= 256 ? 1 : 256 / kc_tiles;
     if (splits > total) splits = total;
     const long long cap = (long long)(ws_bytes / (slab * sizeof(float)));
     if (cap < 1) return CLHIP_ENOSPC;

@@ -11,11 +11,29 @@ SHAPES = [  # N, C, K, H, W
     (3, 64, 64, 32, 32), (5, 64, 64, 16, 16), (6, 64, 128, 8, 8), (9, 128, 128, 8, 8), (2, 16, 32, 8, 8),
     (2, 24, 96, 12, 20), (3, 128, 256, 16, 16), (2, 64, 64, 64, 64), (7, 256, 256, 8, 8), (2, 32, 64, 28, 28),
     (200, 64, 64, 32, 32), (200, 64, 64, 16, 16), (200, 128, 128, 8, 8),
+    # odd maps (AlexNet's 13 x 13 layers, models/net.py:96-125): row-packed geometry, half-outside last tile row / column
+    (4, 32, 64, 13, 13), (3, 64, 32, 13, 13), (2, 16, 32, 9, 15), (5, 64, 64, 11, 13), (3, 32, 32, 13, 16), (37, 192, 384, 13, 13),
 ]
 
 
 def _rel(a, b):
     return float((a.double().cpu() - b.double().cpu()).abs().max() / max(float(b.double().abs().max()), 1e-30))
+
+
+def _check_fused_pool(ops, xd, wd, bd, y_ref, N, K, H, W, big):
+    # fused ReLU + 2x2 max-pool: value within rounding; the arg-max code must name an element that attains the maximum
+    yp, idx = ops.conv3x3_wino_fwd(xd, wd, bd, relu=True, pool=True)
+    yc = y_ref.cuda() if not big else y_ref
+    win = yc.reshape(N, K, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(N, K, H // 2, W // 2, 4)
+    assert _rel(yp, win.max(4).values) <= 2e-5
+    # (code 4 = the window has no positive maximum after ReLU: ReLU folded into the code, csrc/common.hpp)
+    assert torch.equal(idx == 4, yp == 0)
+    live = idx.long().where(idx < 4, torch.zeros((), dtype=torch.long, device=idx.device))
+    picked = torch.gather(win, 4, live.unsqueeze(-1)).squeeze(-1)
+    assert float((picked - win.max(4).values).abs().max()) <= 2e-5 * float(yc.abs().max())
+    assert int(idx.max()) <= 4
+    ypn, idxn = ops.conv3x3_wino_fwd(xd, wd, bd, relu=False, pool=True)           # without ReLU the codes are plain arg-max bytes
+    assert int(idxn.max()) <= 3
 
 
 @pytest.mark.parametrize("shape", SHAPES)
@@ -37,19 +55,9 @@ def test_wino_forward_and_backward_data(shape):
     assert _rel(ops.conv3x3_wino_fwd(xd, wd, bd, relu=False), z_ref) <= 2e-5
     y = ops.conv3x3_wino_fwd(xd, wd, bd, relu=True)
     assert _rel(y, y_ref) <= 2e-5
-    # fused ReLU + 2x2 max-pool: value within rounding; the arg-max code must name an element that attains the maximum
-    yp, idx = ops.conv3x3_wino_fwd(xd, wd, bd, relu=True, pool=True)
-    yc = y_ref.cuda() if not big else y_ref
-    win = yc.reshape(N, K, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(N, K, H // 2, W // 2, 4)
-    assert _rel(yp, win.max(4).values) <= 2e-5
-    # (code 4 = the window has no positive maximum after ReLU: ReLU folded into the code, csrc/common.hpp)
-    assert torch.equal(idx == 4, yp == 0)
-    live = idx.long().where(idx < 4, torch.zeros((), dtype=torch.long, device=idx.device))
-    picked = torch.gather(win, 4, live.unsqueeze(-1)).squeeze(-1)
-    assert float((picked - win.max(4).values).abs().max()) <= 2e-5 * float(yc.abs().max())
-    assert int(idx.max()) <= 4
-    ypn, idxn = ops.conv3x3_wino_fwd(xd, wd, bd, relu=False, pool=True)           # without ReLU the codes are plain arg-max bytes
-    assert int(idxn.max()) <= 3
+    odd = bool((H | W) & 1)
+    if not odd:
+        _check_fused_pool(ops, xd, wd, bd, y_ref, N, K, H, W, big)
     if C % 32 or K < 16:
         return              # backward-data runs the same kernel with the channel roles swapped: its own shape domain
     # backward-data (+ ReLU mask of the producing layer), plain and from the pooled gradient
@@ -63,6 +71,8 @@ def test_wino_forward_and_backward_data(shape):
     assert _rel(ops.conv3x3_wino_bwd_data(dyd, wd), dx_ref) <= 2e-5
     dxm = ops.conv3x3_wino_bwd_data(dyd, wd, relu_src=md)
     assert _rel(dxm, dx_ref.cuda() * (md > 0)) <= 2e-5
+    if odd:
+        return              # no 2x2 pooling on odd maps
     dyp = torch.from_numpy(gen.standard_normal((N, K, H // 2, W // 2)).astype(np.float32)).cuda()
     code = torch.from_numpy(gen.randint(0, 5, size=(N, K, H // 2, W // 2)).astype(np.uint8)).cuda()
     dy_full = ops.maxpool2_bwd(dyp, code)
@@ -75,13 +85,14 @@ def test_wino_refuses_shapes_outside_its_domain():
     x = torch.zeros(1, 3, 8, 8, device="cuda")
     with pytest.raises(_lib.ClhipError):
         ops.conv3x3_wino_fwd(x, torch.zeros(32, 3, 3, 3, device="cuda"), torch.zeros(32, device="cuda"))
-    x = torch.zeros(1, 16, 13, 13, device="cuda")
+    x = torch.zeros(1, 16, 21, 21, device="cuda")         # odd maps wider than 16 (9..16 go through the row-packed geometry)
     with pytest.raises(_lib.ClhipError):
         ops.conv3x3_wino_fwd(x, torch.zeros(32, 16, 3, 3, device="cuda"), torch.zeros(32, device="cuda"))
 
 
 WG_SHAPES = [(3, 64, 64, 32, 32), (5, 64, 64, 16, 16), (6, 64, 128, 8, 8), (4, 128, 64, 8, 8), (2, 64, 64, 12, 20), (2, 64, 128, 28, 28),
-             (3, 128, 256, 16, 16), (200, 64, 64, 32, 32), (200, 64, 64, 16, 16), (200, 128, 128, 8, 8)]
+             (3, 128, 256, 16, 16), (200, 64, 64, 32, 32), (200, 64, 64, 16, 16), (200, 128, 128, 8, 8),
+             (6, 64, 64, 13, 13), (3, 128, 64, 9, 11), (4, 64, 128, 15, 16), (40, 192, 384, 13, 13)]
 
 
 @pytest.mark.parametrize("shape", WG_SHAPES)
@@ -105,6 +116,8 @@ def test_wino_weight_gradient(shape):
     assert _rel(dw, dw_ref) <= 5e-5 and _rel(db, db_ref) <= 5e-5, (_rel(dw, dw_ref), _rel(db, db_ref))
     dw2, db2 = ops.conv3x3_wino_bwd_weight(xd, dyd)
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    if (H | W) & 1:
+        return              # no 2x2 pooling on odd maps
     dyp = torch.from_numpy(gen.standard_normal((N, K, H // 2, W // 2)).astype(np.float32)).cuda()
     code = torch.from_numpy(gen.randint(0, 5, size=(N, K, H // 2, W // 2)).astype(np.uint8)).cuda()
     dw_u_ref, db_u_ref = ops.conv3x3_bwd_weight(xd, ops.maxpool2_bwd(dyp, code))
