@@ -259,12 +259,13 @@ def test_traffic_json_names_the_kernel_bench_reports():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     t = json.load(open(os.path.join(root, "profiles", "traffic.json")))
-    inst = bench.conv_instance(64, 32, 32, 200, 64, 0, True)
+    inst = bench.wino_conv_instance(32, 0, False)         # layer 2 of the bench model runs through the Winograd kernels (plan: >= 640 units)
     e = t["conv3x3_relu_pool_fwd 64x64@32 N=200"]
     assert e["instance"] == inst, (e["instance"], inst)
     assert bench.measured_traffic("conv3x3_relu_pool_fwd", "64x64@32", 200, inst) == e["hbm_bytes_per_launch"]
     assert bench.measured_traffic("conv3x3_relu_pool_fwd", "64x64@32", 200, "conv3x3_mfma_kernel<other>") is None
-    assert t["conv3x3_bwd_data_unpool 64x64@32 N=200"]["instance"] == bench.conv_instance(64, 32, 32, 200, 64, 1, False, True)
+    assert e["direct_kernel_round2"]["instance"] == bench.conv_instance(64, 32, 32, 200, 64, 0, True)
+    assert t["conv3x3_bwd_data_unpool 64x64@32 N=200"]["instance"] == bench.wino_conv_instance(32, 1, True)
 
 
 def test_hat_alexnet_net_structure():
