@@ -132,7 +132,7 @@ def conv_instance(C, H, W, N, K, mode, pool, unpool=False):
 def wino_conv_instance(W, mode, unpool):
     """Instance name of the Winograd forward (mode 0) / backward-data (mode 1) launch for a W-wide even map (csrc/wino.hip, launch_wino)."""
     geo = "16, 4, 1" if W >= 32 else ("8, 8, 1" if W >= 16 else "4, 4, 4")
-    return "wino_conv_kernel<%s, %d, %s> (+ wino_weight_kernel)" % (geo, mode, "true" if unpool else "false")
+    return "wino_conv_kernel<%s, %d, %s, false> (+ wino_weight_kernel)" % (geo, mode, "true" if unpool else "false")
 
 
 def time_kernels(eng, x, N, iters):
