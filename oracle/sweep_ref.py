@@ -30,9 +30,23 @@ def _store(model, params):
     return model
 
 
+def _order(n, shuffle):
+    """Sample order of one pass of torch.utils.data.DataLoader(dataset, batch_size, shuffle) — what the reference's loops
+    iterate (Finetune/main_SGD.py, EWC/main_EWC.py:138-157): every iterator first draws its worker base seed from the global
+    generator (_BaseDataLoaderIter.__init__), a shuffling one then seeds a private generator from the global one
+    (RandomSampler.__iter__) and draws the permutation from that.  Following the protocol draw for draw keeps this oracle on
+    the same batches as any other restatement of those loops that starts from the same seed."""
+    torch.empty((), dtype=torch.int64).random_()
+    if not shuffle:
+        return torch.arange(n)
+    g = torch.Generator()
+    g.manual_seed(int(torch.empty((), dtype=torch.int64).random_().item()))
+    return torch.randperm(n, generator=g)
+
+
 def _batches(dset, batch_size, shuffle):
     n = len(dset)
-    order = torch.randperm(n) if shuffle else torch.arange(n)
+    order = _order(n, shuffle)
     x, y = dset.x.cpu(), dset.y.cpu()
     for i in range(0, n, batch_size):
         idx = order[i:i + batch_size]
@@ -130,7 +144,7 @@ class OracleEWC:
         hits = 0
         t0 = time.perf_counter()
         with torch.no_grad():
-            for x, y in _batches(split, args.batch_size, False):
+            for x, y in _batches(split, args.batch_size, True):             # (framework/inference.py:27 shuffles its test loader)
                 hits += int((vgg_ref.forward(params, self.cfg, x).argmax(1) == y).sum())
                 self.image_passes["eval"] += x.shape[0]
         self.seconds["eval"] += time.perf_counter() - t0
