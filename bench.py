@@ -129,8 +129,10 @@ def conv_instance(C, H, W, N, K, mode, pool, unpool=False):
     return "conv3x3_mfma_kernel<%d, %d, %d, " % geo + tail
 
 
-def wino_conv_instance(W, mode, unpool):
+def wino_conv_instance(W, mode, unpool, N=None, kout=None):
     """Instance name of the Winograd forward (mode 0) / backward-data (mode 1) launch for a W-wide even map (csrc/wino.hip, launch_wino)."""
+    if W == 8 and N is not None and ((N * 16 + 31) // 32) * ((kout + 31) // 32) < 640:
+        return "wino_conv16_kernel<%d, %s, %d> (+ wino_weight_kernel)" % (mode, "true" if unpool else "false", 1 if N * ((kout + 31) // 32) <= 512 else 2)
     geo = "16, 4, 1" if W >= 32 else ("8, 8, 1" if W >= 16 else "4, 4, 4")
     return "wino_conv_kernel<%s, %d, %s, false> (+ wino_weight_kernel)" % (geo, mode, "true" if unpool else "false")
 
@@ -176,14 +178,14 @@ def time_kernels(eng, x, N, iters):
             t_f = timed((lambda: ops.conv3x3_wino_fwd(xin, m.weight.data, m.bias.data, True, pool=True)) if paths["fwd"] else
                         (lambda: ops.conv3x3_relu_pool_fwd(xin, m.weight.data, m.bias.data)))
             rows.append(dict(kernel="conv3x3_relu_pool_fwd", layer=layer, li=li, kind="fwd", flops=fl, sec=t_f, winograd=paths["fwd"],
-                             instance=wino_conv_instance(W, 0, False) if paths["fwd"]
+                             instance=wino_conv_instance(W, 0, False, N, K) if paths["fwd"]
                              else conv_instance(C, H, W, N, K, 0, True),
                              alg_bytes=4.0 * N * H * W * (C + K / 4.0) + 1.0 * N * K * H * W / 4))
         else:
             t_f = timed((lambda: ops.conv3x3_wino_fwd(xin, m.weight.data, m.bias.data, True)) if paths["fwd"] else
                         (lambda: ops.conv3x3_fwd(xin, m.weight.data, m.bias.data, True)))
             rows.append(dict(kernel="conv3x3_fwd", layer=layer, li=li, kind="fwd", flops=fl, sec=t_f, winograd=paths["fwd"],
-                             instance=wino_conv_instance(W, 0, False) if paths["fwd"]
+                             instance=wino_conv_instance(W, 0, False, N, K) if paths["fwd"]
                              else conv_instance(C, H, W, N, K, 0, False), alg_bytes=4.0 * N * H * W * (C + K)))
         if pool:
             dyp = torch.randn_like(yp)
@@ -213,14 +215,14 @@ def time_kernels(eng, x, N, iters):
             t_d = timed((lambda: ops.conv3x3_wino_bwd_data(dyp, m.weight.data, xmask, idx)) if paths["bwd_data"] else
                         (lambda: ops.conv3x3_bwd_data_unpool(dyp, idx, m.weight.data, xmask)))
             rows.append(dict(kernel="conv3x3_bwd_data_unpool", layer=layer, li=li, kind="bwd_data", flops=fl, sec=t_d, winograd=paths["bwd_data"],
-                             instance=wino_conv_instance(W, 1, True) if paths["bwd_data"]
+                             instance=wino_conv_instance(W, 1, True, N, C) if paths["bwd_data"]
                              else conv_instance(K, H, W, N, C, 1, False, True),
                              alg_bytes=4.0 * N * H * W * ((2 if xmask is not None else 1) * C + K / 4.0) + 1.0 * N * K * H * W / 4))
         elif C > 3:
             t_d = timed((lambda: ops.conv3x3_wino_bwd_data(dy, m.weight.data, xmask)) if paths["bwd_data"] else
                         (lambda: ops.conv3x3_bwd_data(dy, m.weight.data, xmask)))
             rows.append(dict(kernel="conv3x3_bwd_data", layer=layer, li=li, kind="bwd_data", flops=fl, sec=t_d, winograd=paths["bwd_data"],
-                             instance=wino_conv_instance(W, 1, False) if paths["bwd_data"]
+                             instance=wino_conv_instance(W, 1, False, N, C) if paths["bwd_data"]
                              else conv_instance(K, H, W, N, C, 1, False), alg_bytes=4.0 * N * H * W * ((2 if xmask is not None else 1) * C + K)))
         cur = ops.maxpool2_fwd(y)[0] if pool else y
     return rows

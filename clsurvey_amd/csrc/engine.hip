@@ -49,6 +49,7 @@ struct LayerPlan {
 };
 
 constexpr long long WINO_MIN_UNITS = 640;
+constexpr long long WINO16_MIN_UNITS = 384;      // waves of the 8 x 8 variant (wino.hip, wino_conv16_kernel)
 // CLHIP_WINO=0 keeps every layer on the direct kernels (A/B measurements, triage)
 static bool wino_enabled() {
     const char* e = std::getenv("CLHIP_WINO");
@@ -216,8 +217,13 @@ int clhip_net_create(const clhip_layer_desc* descs, int n_layers, int max_batch,
             if (vgg && !L.bn && wino_enabled()) {
                 const long long tiles = (long long)max_batch * ((L.h + 1) / 2) * ((L.w + 1) / 2);
                 auto units = [&](int kout) { return ((tiles + 31) / 32) * ((kout + 31) / 32); };
-                L.wino_f = clhip_internal_wino_ok(L.cin, L.cout, L.h, L.w) && units(L.cout) >= WINO_MIN_UNITS;
-                L.wino_d = i > 0 && clhip_internal_wino_ok(L.cout, L.cin, L.h, L.w) && units(L.cin) >= WINO_MIN_UNITS;
+                // (8 x 8 maps: the 16x16x4-MFMA variant has 16-tile units, one image x 32 channels per wave)
+                auto enough = [&](int kout) {
+                    if (units(kout) >= WINO_MIN_UNITS) return true;
+                    return L.h == 8 && L.w == 8 && (long long)max_batch * ((kout + 31) / 32) >= WINO16_MIN_UNITS;
+                };
+                L.wino_f = clhip_internal_wino_ok(L.cin, L.cout, L.h, L.w) && enough(L.cout);
+                L.wino_d = i > 0 && clhip_internal_wino_ok(L.cout, L.cin, L.h, L.w) && enough(L.cin);
                 // weight gradient: the reduction (tiles) splits over ~256 blocks per 64x64 (k, c) tile; each block needs a
                 // few 16-tile stages to amortise its 256-accumulator epilogue (measured: 12.5 stages per block 1.44x, 3.1 0.6x)
                 if (clhip_internal_wino_wgrad_ok(L.cin, L.cout, L.h, L.w)) {

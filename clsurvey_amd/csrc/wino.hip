@@ -633,10 +633,264 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ 8 x 8 maps, few units
+// The kernel above gives a wave 32 out-channels x 32 TILES (256 accumulators): a 128 -> 128 layer on 8 x 8 maps at N = 200
+// has only 400 such units for 1024 SIMDs and ran at 0.75x the direct kernel.  This variant computes the same F(2x2, 3x3)
+// product on v_mfma_f32_16x16x4_f32 (16 out-channels x 16 tiles x 4 in-channels, 32 cycles): a wave owns ONE image (its
+// 4 x 4 tiles) x 32 out-channels (two 16-row MFMA tiles sharing the transformed input), 128 accumulator registers, twice as
+// many units.  A lane is (tile i = lane & 15, channel q = lane >> 4 of the current channel quad): it reads its 4x4 window
+// (8 ds_read_b64), forms 16 frequency values (32 adds) and feeds them to 2 x 16 MFMAs; A operands are its 16 frequencies of
+// U[c = q][k = 16 kt + i] (4 ds_read_b128 per row tile) — the U layout, the weight-transform kernels and the epilogue
+// arithmetic are the ones of the kernel above.  Same slot pipeline: 16 slots of two MFMAs per channel quad, each followed by
+// one piece of the next quad's operand work; LDS writes of chunk c + 1 during quad 0, global loads of chunk c + 2 during
+// quad 1, one barrier per 8-channel chunk.  D layout of the 16x16x4 MFMA: register r of lane l = D[row 4 (l >> 4) + r][col l & 15].
+typedef float floatx4v __attribute__((ext_vector_type(4)));
+
+// KT2 = 16-row MFMA tiles per wave: 2 -> block = 2 images x 64 out-channels (wave = image wp, channel half wk);
+//       1 -> block = 1 image x 64 out-channels (wave = channel quarter): twice the waves for layers with few out-channels
+template <int MODE, bool UNPOOL, int KT2>
+__global__ __launch_bounds__(256, 1) void wino_conv16_kernel(
+    const float* __restrict__ in, const float* __restrict__ U, const float* __restrict__ bias,
+    const float* __restrict__ mask_src, float* __restrict__ out, uint8_t* __restrict__ pool_idx,
+    int N, int Cin, int Cout, int relu) {
+    constexpr int H = 8, W = 8, NIMG = KT2;
+    constexpr int PW = 10, PR = 10, PLANE = NIMG * PR * PW;           // halo planes of the block's two images, per channel
+    constexpr int X_FLOATS = WCK * PLANE, BUF = W_FLOATS + X_FLOATS;
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
+    __shared__ float bias_s[WKT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = KT2 == 2 ? wave & 1 : wave, wp = KT2 == 2 ? wave >> 1 : 0;      // wk: 32- (KT2 = 2) or 16-channel slice of the block's 64
+    constexpr int KW = 16 * KT2;                                                     // out channels per wave
+    const int ti = lane & 15, q = lane >> 4;
+    const int n_grp = (N + NIMG - 1) / NIMG;
+    const int kt = blockIdx.x / n_grp, ng = blockIdx.x - kt * n_grp;
+    const int n0 = ng * NIMG, ko0 = kt * WKT;
+    const int n_chunks = (Cin + WCK - 1) / WCK;
+    if (MODE == 0 && tid < WKT) bias_s[tid] = (bias && ko0 + tid < Cout) ? bias[ko0 + tid] : 0.f;
+
+    constexpr int Hi = UNPOOL ? H >> 1 : H, Wi = UNPOOL ? W >> 1 : W;
+    constexpr int plane_in = Hi * Wi;
+    const float* in_blk = in + (size_t)n0 * Cin * plane_in;
+    const __amdgpu_buffer_rsrc_t rs_x = clhip_rsrc(in_blk, (size_t)(N - n0) * Cin * plane_in * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rs_i = clhip_rsrc(UNPOOL ? pool_idx + (size_t)n0 * Cin * plane_in : pool_idx,
+                                                   UNPOOL ? (size_t)(N - n0) * Cin * plane_in : 0);
+    const __amdgpu_buffer_rsrc_t rs_u = clhip_rsrc(U + (size_t)kt * n_chunks * W_FLOATS, (size_t)n_chunks * W_FLOATS * sizeof(float));
+
+    // ---- staging units (as above: one instruction each, weights = straight 16-byte copy, activations = one scalar per halo element)
+    constexpr int W_IT = W_FLOATS / 4 / 256;                         // 10
+    constexpr int X_IT = (X_FLOATS + 255) / 256;                     // 7
+    constexpr int NU = W_IT + X_IT;
+    float4 wv[W_IT];
+    float xr[X_IT];
+    unsigned xi[UNPOOL ? X_IT : 1];
+    int xoff[X_IT], xcode[UNPOOL ? X_IT : 1];
+#pragma unroll
+    for (int j = 0; j < X_IT; ++j) {
+        const int e = tid + 256 * j;
+        xoff[j] = CLHIP_OOB;
+        if (e < X_FLOATS) {
+            const int cl = e / PLANE, rem = e - cl * PLANE;
+            const int col = rem % PW, rr = rem / PW;
+            const int row = rr % PR, nb = rr / PR;
+            const int h = row - 1, w = col - 1;
+            if (n0 + nb < N && h >= 0 && h < H && w >= 0 && w < W) {
+                if constexpr (UNPOOL) {
+                    xoff[j] = (nb * Cin + cl) * plane_in + (h >> 1) * Wi + (w >> 1);     // ELEMENT offset
+                    xcode[j] = ((h & 1) << 1) | (w & 1);
+                } else {
+                    xoff[j] = ((nb * Cin + cl) * plane_in + h * W + w) * 4;
+                }
+            }
+        }
+    }
+    auto load_unit = [&](int u, int chunk) {
+        const int cw = chunk < n_chunks ? chunk : n_chunks - 1;
+        if (u < W_IT) {
+            wv[u] = clhip_buf_load4(rs_u, (tid + 256 * u) * 16, cw * W_FLOATS * 4);
+        } else {
+            const int j = u - W_IT;
+            const int xb = cw * WCK * plane_in;
+            if constexpr (UNPOOL) {
+                xr[j] = clhip_buf_load(rs_x, xoff[j] != CLHIP_OOB ? xoff[j] * 4 : CLHIP_OOB, xb * 4);
+                xi[j] = clhip_buf_load_u8(rs_i, xoff[j], xb);
+            } else {
+                xr[j] = clhip_buf_load(rs_x, xoff[j], xb * 4);
+            }
+        }
+    };
+    auto store_unit = [&](int u, int bo) {
+        if (u < W_IT) {
+            float* wd = lds + bo + 4 * (tid + 256 * u);
+            *reinterpret_cast<floatx4*>(wd) = floatx4{wv[u].x, wv[u].y, wv[u].z, wv[u].w};
+        } else {
+            const int j = u - W_IT;
+            float* xs = lds + bo + W_FLOATS;
+            if (256 * (j + 1) <= X_FLOATS || tid + 256 * j < X_FLOATS) {
+                if constexpr (UNPOOL) xs[tid + 256 * j] = ((int)xi[j] == xcode[j]) ? xr[j] : 0.f;
+                else xs[tid + 256 * j] = xr[j];
+            }
+        }
+    };
+
+    // this lane's tile: image wp of the block, tile (t_row, t_col) = (ti >> 2, ti & 3); channel q of a quad
+    const int t_row = ti >> 2, t_col = ti & 3;
+    const int d_off = W_FLOATS + q * PLANE + (wp * PR + 2 * t_row) * PW + 2 * t_col;        // even: 8-byte aligned
+    const int a_off = (q * WKT + wk * KW + ti) * WFP;                                      // + 16 * WFP: second row tile
+
+    floatx4v acc[KT2][16];
+#pragma unroll
+    for (int k2 = 0; k2 < KT2; ++k2)
+#pragma unroll
+        for (int f = 0; f < 16; ++f) acc[k2][f] = floatx4v{0.f, 0.f, 0.f, 0.f};
+
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    constexpr int NQ = WCK / 4;                                      // channel quads per chunk
+    floatx4 av[2][KT2][4];         // [pipeline slot][row tile][frequency quad]
+    float vv[2][16];
+    f2 dlo[4], dhi[4], tlo[4], thi[4];
+    auto rd_a = [&](const float* abase, int quad, int k2, int fq, int slot) {
+        av[slot][k2][fq] = *reinterpret_cast<const floatx4*>(abase + 4 * quad * WKT * WFP + k2 * 16 * WFP + 4 * fq);
+    };
+    auto rd_d = [&](const float* dbase, int quad, int r) {
+        dlo[r] = *reinterpret_cast<const f2*>(dbase + 4 * quad * PLANE + r * PW);
+        dhi[r] = *reinterpret_cast<const f2*>(dbase + 4 * quad * PLANE + r * PW + 2);
+    };
+    auto row_tf = [&](int i) {
+        if (i == 0) { tlo[0] = dlo[0] - dlo[2]; thi[0] = dhi[0] - dhi[2]; }
+        if (i == 1) { tlo[1] = dlo[1] + dlo[2]; thi[1] = dhi[1] + dhi[2]; }
+        if (i == 2) { tlo[2] = dlo[2] - dlo[1]; thi[2] = dhi[2] - dhi[1]; }
+        if (i == 3) { tlo[3] = dlo[1] - dlo[3]; thi[3] = dhi[1] - dhi[3]; }
+    };
+    auto col_tf = [&](int i, int slot) {
+        const f2 o = tlo[i] - thi[i];
+        vv[slot][4 * i + 0] = o.x;
+        vv[slot][4 * i + 3] = o.y;
+        vv[slot][4 * i + 1] = tlo[i].y + thi[i].x;
+        vv[slot][4 * i + 2] = thi[i].x - tlo[i].y;
+    };
+
+#pragma unroll
+    for (int u = 0; u < NU; ++u) load_unit(u, 0);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) store_unit(u, 0);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) load_unit(u, 1);
+    __syncthreads();
+#pragma unroll
+    for (int fq = 0; fq < 4; ++fq) { rd_a(lds + a_off, 0, 0, fq, 0); if (KT2 == 2) rd_a(lds + a_off, 0, KT2 - 1, fq, 0); }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rd_d(lds + d_off, 0, r);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) row_tf(i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) col_tf(i, 0);
+
+    static_assert(NQ == 2 && NU <= 32 && (KT2 == 1 || KT2 == 2), "stores: two units per slot of quad 0; loads: up to two units per slot of quad 1");
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        const int bo = (chunk & 1) * BUF, bn = BUF - bo;
+        const float* a_cur = lds + bo + a_off;
+        const float* d_cur = lds + bo + d_off;
+        const float* a_nxt = lds + bn + a_off;
+        const float* d_nxt = lds + bn + d_off;
+#pragma unroll
+        for (int p = 0; p < NQ; ++p) {
+            const float* ab = (p + 1 < NQ) ? a_cur : a_nxt;
+            const float* db = (p + 1 < NQ) ? d_cur : d_nxt;
+            const int np = (p + 1) % NQ, ns = (p + 1) & 1, cs = p & 1;
+#pragma unroll
+            for (int f = 0; f < 16; ++f) {
+                acc[0][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cs][0][f >> 2][f & 3], vv[cs][f], acc[0][f], 0, 0, 0);
+                if (KT2 == 2) acc[KT2 - 1][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cs][KT2 - 1][f >> 2][f & 3], vv[cs][f], acc[KT2 - 1][f], 0, 0, 0);
+                if (p == NQ - 1 && f == 0) __syncthreads();
+                if (f < 4) { rd_d(db, np, f); rd_a(ab, np, 0, f, ns); }
+                else if (f < 8) { if (KT2 == 2) rd_a(ab, np, KT2 - 1, f - 4, ns); }
+                else if (f < 12) row_tf(f - 8);
+                else col_tf(f - 12, ns);
+                if (p == 0) {
+                    if (2 * f < NU) store_unit(2 * f, bn);
+                    if (2 * f + 1 < NU) store_unit(2 * f + 1, bn);
+                } else {
+                    if (f < NU) load_unit(f, chunk + 2);
+                    if (16 + f < NU) load_unit(16 + f, chunk + 2);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // ---- epilogue: register r of acc[k2][f] = (out channel ko0 + 32 wk + 16 k2 + 4 q + r, this lane's tile)
+    const int n = n0 + wp, oh = 2 * t_row, ow = 2 * t_col;
+    const bool tile_ok = n < N;
+    const bool pool = MODE == 0 && pool_idx != nullptr;
+    constexpr int chw = H * W, OH = H >> 1, OW = W >> 1;
+#pragma unroll
+    for (int k2 = 0; k2 < KT2; ++k2)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float u0[4], u1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u0[j] = acc[k2][j][r] + acc[k2][4 + j][r] + acc[k2][8 + j][r];
+            u1[j] = acc[k2][4 + j][r] - acc[k2][8 + j][r] - acc[k2][12 + j][r];
+        }
+        float y00 = u0[0] + u0[1] + u0[2], y01 = u0[1] - u0[2] - u0[3];
+        float y10 = u1[0] + u1[1] + u1[2], y11 = u1[1] - u1[2] - u1[3];
+        const int kl = wk * KW + k2 * 16 + 4 * q + r;
+        const int k = ko0 + kl;
+        const bool ok = tile_ok && k < Cout;
+        if (MODE == 0) {
+            const float b = bias_s[kl];
+            y00 += b; y01 += b; y10 += b; y11 += b;
+            if (relu) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
+            if (pool) {
+                float m = y00; int a = 0;
+                if (y01 > m) { m = y01; a = 1; }
+                if (y10 > m) { m = y10; a = 2; }
+                if (y11 > m) { m = y11; a = 3; }
+                if (relu && !(m > 0.f)) a = CLHIP_POOL_DEAD;
+                if (ok) {
+                    const size_t o = ((size_t)n * Cout + k) * OH * OW + (size_t)(oh >> 1) * OW + (ow >> 1);
+                    out[o] = m;
+                    pool_idx[o] = (uint8_t)a;
+                }
+                continue;
+            }
+        }
+        if (ok) {
+            const size_t o = ((size_t)n * Cout + k) * chw + (size_t)oh * W + ow;
+            if (MODE == 1 && mask_src) {
+                const float2 m0 = *reinterpret_cast<const float2*>(mask_src + o), m1 = *reinterpret_cast<const float2*>(mask_src + o + W);
+                y00 = m0.x > 0.f ? y00 : 0.f; y01 = m0.y > 0.f ? y01 : 0.f;
+                y10 = m1.x > 0.f ? y10 : 0.f; y11 = m1.y > 0.f ? y11 : 0.f;
+            }
+            *reinterpret_cast<float2*>(out + o) = make_float2(y00, y01);
+            *reinterpret_cast<float2*>(out + o + W) = make_float2(y10, y11);
+        }
+    }
+}
+
+// units of the 32-tile kernel a layer has; below this the 8 x 8 variant takes 8 x 8 maps
+constexpr long long WINO16_BELOW_UNITS = 640;
+
 template <int MODE, bool UNPOOL>
 int launch_wino(const float* in, const float* U, const float* bias, const float* mask_src, float* out, uint8_t* pool_idx,
                 int N, int Cin, int Cout, int H, int W, int relu, hipStream_t s) {
     const int kts = (Cout + WKT - 1) / WKT;
+    if (H == 8 && W == 8 && ((long long)N * 16 + 31) / 32 * ((Cout + 31) / 32) < WINO16_BELOW_UNITS) {
+        // waves of 32 channels x one image; layers with few out-channels take 16-channel waves instead (twice as many)
+        const bool narrow = (long long)N * ((Cout + 31) / 32) <= 512;
+        const long long blocks = (long long)(narrow ? N : (N + 1) / 2) * kts;
+        if (blocks <= 0 || blocks > 0x7fffffffLL) return CLHIP_EINVAL;
+        if (narrow)
+            hipLaunchKernelGGL((wino_conv16_kernel<MODE, UNPOOL, 1>), dim3((unsigned)blocks), dim3(256), 0, s, in, U, bias, mask_src, out,
+                               pool_idx, N, Cin, Cout, relu);
+        else
+            hipLaunchKernelGGL((wino_conv16_kernel<MODE, UNPOOL, 2>), dim3((unsigned)blocks), dim3(256), 0, s, in, U, bias, mask_src, out,
+                               pool_idx, N, Cin, Cout, relu);
+        CLHIP_LAUNCH_CHECK();
+        return 0;
+    }
 #define WINO_GEO(TCB_, TRB_, NIMG_)                                                                                          \
     do {                                                                                                                      \
         const int tiles_w = ((W + 1) / 2 + TCB_ - 1) / TCB_, tiles_h = ((H + 1) / 2 + TRB_ - 1) / TRB_, ngrp = (N + NIMG_ - 1) / NIMG_; \

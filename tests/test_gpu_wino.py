@@ -11,6 +11,7 @@ SHAPES = [  # N, C, K, H, W
     (3, 64, 64, 32, 32), (5, 64, 64, 16, 16), (6, 64, 128, 8, 8), (9, 128, 128, 8, 8), (2, 16, 32, 8, 8),
     (2, 24, 96, 12, 20), (3, 128, 256, 16, 16), (2, 64, 64, 64, 64), (7, 256, 256, 8, 8), (2, 32, 64, 28, 28),
     (200, 64, 64, 32, 32), (200, 64, 64, 16, 16), (200, 128, 128, 8, 8),
+    (131, 128, 128, 8, 8), (200, 64, 128, 8, 8),        # 8 x 8 maps with few units: the 16x16x4-MFMA variant, both wave shapes, odd image count
     # odd maps (AlexNet's 13 x 13 layers, models/net.py:96-125): row-packed geometry, half-outside last tile row / column
     (4, 32, 64, 13, 13), (3, 64, 32, 13, 13), (2, 16, 32, 9, 15), (5, 64, 64, 11, 13), (3, 32, 32, 13, 16), (37, 192, 384, 13, 13),
 ]
