@@ -21,6 +21,7 @@
 // Block = 4 waves = (2 halves of 64 out-channels) x (2 groups of 32 tiles); a wave holds 16 x 16 = 256 accumulator
 // registers (one wave per SIMD, like the weight-gradient kernel).  Tiles of a block: TCB x TRB tiles of NIMG images.
 #include "common.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -870,6 +871,212 @@ __global__ __launch_bounds__(256, 1) void wino_conv16_kernel(
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ 16-tile waves, two blocks per CU
+// The 32-tile kernel keeps 256 accumulators per wave, so ONE wave runs per SIMD and nothing covers its prologue (first
+// global loads), its barriers and its epilogue (output transform, bias / ReLU / pool, stores): on a 64-channel layer (8 chunks)
+// those are about a third of a unit's time.  This kernel has the 16x16x4-MFMA wave of wino_conv16_kernel on ANY even map: a wave
+// is TC x TR = 16 tiles x 32 out-channels (128 accumulators), a block 64 out-channels x (TC x 2 TR) tiles of one image, LDS
+// holds 4-channel chunks (23 KB, double-buffered) and the kernel stays under 256 registers — two blocks share a CU, each
+// SIMD has two waves, one issues MFMAs while the other waits, transforms or stores.  No hand-placed slots: the work of a
+// chunk is read operands -> transform -> 32 MFMAs, the compiler orders it, the second wave fills the gaps.
+template <int TC, int TR, int MODE, bool UNPOOL>
+__global__ __launch_bounds__(256, 2) void wino_conv16g_kernel(
+    const float* __restrict__ in, const float* __restrict__ U, const float* __restrict__ bias,
+    const float* __restrict__ mask_src, float* __restrict__ out, uint8_t* __restrict__ pool_idx,
+    int N, int Cin, int Cout, int H, int W, int relu, int tiles_w, int tiles_h, int n_pix_blocks) {
+    static_assert(TC * TR == 16, "16 tiles per wave");
+    constexpr int CQ = 4;                                             // in channels per chunk = one MFMA k-quad
+    constexpr int PW = 2 * TC + 2, PR = 4 * TR + 2, PLANE = PR * PW;
+    constexpr int WQ_FLOATS = CQ * WKT * WFP;                         // 5120 floats: half of a U chunk (channels are its outer index)
+    constexpr int X_FLOATS = CQ * PLANE, BUF = WQ_FLOATS + X_FLOATS;
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
+    __shared__ float bias_s[WKT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave & 1, wp = wave >> 1;
+    const int ti = lane & 15, q = lane >> 4;
+    const int kt = blockIdx.x / n_pix_blocks, pb = blockIdx.x - kt * n_pix_blocks;
+    const int bw = pb % tiles_w, bh = (pb / tiles_w) % tiles_h, n = pb / (tiles_w * tiles_h);
+    const int h0 = bh * 4 * TR, w0 = bw * 2 * TC;
+    const int ko0 = kt * WKT;
+    const int n_chunks = Cin / CQ;                                    // Cin is a whole number of 8-channel U chunks
+    if (MODE == 0 && tid < WKT) bias_s[tid] = (bias && ko0 + tid < Cout) ? bias[ko0 + tid] : 0.f;
+
+    const int Hi = UNPOOL ? H >> 1 : H, Wi = UNPOOL ? W >> 1 : W;
+    const int plane_in = Hi * Wi;
+    const float* in_img = in + (size_t)n * Cin * plane_in;
+    const __amdgpu_buffer_rsrc_t rs_x = clhip_rsrc(in_img, (size_t)Cin * plane_in * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rs_i = clhip_rsrc(UNPOOL ? pool_idx + (size_t)n * Cin * plane_in : pool_idx, UNPOOL ? (size_t)Cin * plane_in : 0);
+    const __amdgpu_buffer_rsrc_t rs_u = clhip_rsrc(U + (size_t)kt * n_chunks * WQ_FLOATS, (size_t)n_chunks * WQ_FLOATS * sizeof(float));
+
+    constexpr int W_IT = WQ_FLOATS / 4 / 256;                         // 5
+    constexpr int X_IT = (X_FLOATS + 255) / 256;
+    float4 wv[W_IT];
+    float xr[X_IT];
+    unsigned xi[UNPOOL ? X_IT : 1];
+    int xoff[X_IT], xcode[UNPOOL ? X_IT : 1];
+#pragma unroll
+    for (int j = 0; j < X_IT; ++j) {
+        const int e = tid + 256 * j;
+        xoff[j] = CLHIP_OOB;
+        if (e < X_FLOATS) {
+            const int cl = e / PLANE, rem = e - cl * PLANE;
+            const int col = rem % PW, row = rem / PW;
+            const int h = h0 - 1 + row, w = w0 - 1 + col;
+            if (h >= 0 && h < H && w >= 0 && w < W) {
+                if constexpr (UNPOOL) {
+                    xoff[j] = cl * plane_in + (h >> 1) * Wi + (w >> 1);       // ELEMENT offset
+                    xcode[j] = ((h & 1) << 1) | (w & 1);
+                } else {
+                    xoff[j] = (cl * plane_in + h * W + w) * 4;
+                }
+            }
+        }
+    }
+    auto load_chunk = [&](int chunk) {
+        const int cw = chunk < n_chunks ? chunk : n_chunks - 1;
+#pragma unroll
+        for (int u = 0; u < W_IT; ++u) wv[u] = clhip_buf_load4(rs_u, (tid + 256 * u) * 16, cw * WQ_FLOATS * 4);
+        const int xb = cw * CQ * plane_in;
+#pragma unroll
+        for (int j = 0; j < X_IT; ++j) {
+            if constexpr (UNPOOL) {
+                xr[j] = clhip_buf_load(rs_x, xoff[j] != CLHIP_OOB ? xoff[j] * 4 : CLHIP_OOB, xb * 4);
+                xi[j] = clhip_buf_load_u8(rs_i, xoff[j], xb);
+            } else {
+                xr[j] = clhip_buf_load(rs_x, xoff[j], xb * 4);
+            }
+        }
+    };
+    auto store_chunk = [&](int bo) {
+#pragma unroll
+        for (int u = 0; u < W_IT; ++u)
+            *reinterpret_cast<floatx4*>(lds + bo + 4 * (tid + 256 * u)) = floatx4{wv[u].x, wv[u].y, wv[u].z, wv[u].w};
+        float* xs = lds + bo + WQ_FLOATS;
+#pragma unroll
+        for (int j = 0; j < X_IT; ++j)
+            if (256 * (j + 1) <= X_FLOATS || tid + 256 * j < X_FLOATS) {
+                if constexpr (UNPOOL) xs[tid + 256 * j] = ((int)xi[j] == xcode[j]) ? xr[j] : 0.f;
+                else xs[tid + 256 * j] = xr[j];
+            }
+    };
+
+    const int t_row = wp * TR + ti / TC, t_col = ti % TC;            // this lane's tile inside the block's TC x 2 TR tiles
+    const int d_off = WQ_FLOATS + q * PLANE + 2 * t_row * PW + 2 * t_col;      // even: 8-byte aligned
+    const int a_off = (q * WKT + wk * 32 + ti) * WFP;
+
+    floatx4v acc[2][16];
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+        for (int f = 0; f < 16; ++f) acc[k2][f] = floatx4v{0.f, 0.f, 0.f, 0.f};
+
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    load_chunk(0);
+    store_chunk(0);
+    load_chunk(1);
+    __syncthreads();
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        const int bo = (chunk & 1) * BUF;
+        // chunk + 1 (in registers since the previous iteration) -> the other buffer (its readers finished before the last barrier)
+        store_chunk(BUF - bo);
+        load_chunk(chunk + 2);
+        const float* ab = lds + bo + a_off;
+        const float* db = lds + bo + d_off;
+        f2 dlo[4], dhi[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dlo[r] = *reinterpret_cast<const f2*>(db + r * PW);
+            dhi[r] = *reinterpret_cast<const f2*>(db + r * PW + 2);
+        }
+        floatx4 a0[4], a1[4];
+#pragma unroll
+        for (int fq = 0; fq < 4; ++fq) {
+            a0[fq] = *reinterpret_cast<const floatx4*>(ab + 4 * fq);
+            a1[fq] = *reinterpret_cast<const floatx4*>(ab + 16 * WFP + 4 * fq);
+        }
+        // V = B^T d B
+        f2 tlo[4], thi[4];
+        tlo[0] = dlo[0] - dlo[2]; thi[0] = dhi[0] - dhi[2];
+        tlo[1] = dlo[1] + dlo[2]; thi[1] = dhi[1] + dhi[2];
+        tlo[2] = dlo[2] - dlo[1]; thi[2] = dhi[2] - dhi[1];
+        tlo[3] = dlo[1] - dlo[3]; thi[3] = dhi[1] - dhi[3];
+        float vv[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f2 o = tlo[i] - thi[i];
+            vv[4 * i + 0] = o.x;
+            vv[4 * i + 3] = o.y;
+            vv[4 * i + 1] = tlo[i].y + thi[i].x;
+            vv[4 * i + 2] = thi[i].x - tlo[i].y;
+        }
+#pragma unroll
+        for (int f = 0; f < 16; ++f) {
+            acc[0][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[f >> 2][f & 3], vv[f], acc[0][f], 0, 0, 0);
+            acc[1][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[f >> 2][f & 3], vv[f], acc[1][f], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: register r of acc[k2][f] = (out channel ko0 + 32 wk + 16 k2 + 4 q + r, this lane's tile)
+    const int oh = h0 + 2 * t_row, ow = w0 + 2 * t_col;
+    const bool tile_ok = oh < H && ow < W;
+    const bool pool = MODE == 0 && pool_idx != nullptr;
+    const size_t chw = (size_t)H * W;
+    const int OH = H >> 1, OW = W >> 1;
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float u0[4], u1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u0[j] = acc[k2][j][r] + acc[k2][4 + j][r] + acc[k2][8 + j][r];
+            u1[j] = acc[k2][4 + j][r] - acc[k2][8 + j][r] - acc[k2][12 + j][r];
+        }
+        float y00 = u0[0] + u0[1] + u0[2], y01 = u0[1] - u0[2] - u0[3];
+        float y10 = u1[0] + u1[1] + u1[2], y11 = u1[1] - u1[2] - u1[3];
+        const int kl = wk * 32 + k2 * 16 + 4 * q + r;
+        const int k = ko0 + kl;
+        const bool ok = tile_ok && k < Cout;
+        if (MODE == 0) {
+            const float b = bias_s[kl];
+            y00 += b; y01 += b; y10 += b; y11 += b;
+            if (relu) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
+            if (pool) {
+                float m = y00; int a = 0;
+                if (y01 > m) { m = y01; a = 1; }
+                if (y10 > m) { m = y10; a = 2; }
+                if (y11 > m) { m = y11; a = 3; }
+                if (relu && !(m > 0.f)) a = CLHIP_POOL_DEAD;
+                if (ok) {
+                    const size_t o = ((size_t)n * Cout + k) * OH * OW + (size_t)(oh >> 1) * OW + (ow >> 1);
+                    out[o] = m;
+                    pool_idx[o] = (uint8_t)a;
+                }
+                continue;
+            }
+        }
+        if (ok) {
+            const size_t o = ((size_t)n * Cout + k) * chw + (size_t)oh * W + ow;
+            if (MODE == 1 && mask_src) {
+                const float2 m0 = *reinterpret_cast<const float2*>(mask_src + o), m1 = *reinterpret_cast<const float2*>(mask_src + o + W);
+                y00 = m0.x > 0.f ? y00 : 0.f; y01 = m0.y > 0.f ? y01 : 0.f;
+                y10 = m1.x > 0.f ? y10 : 0.f; y11 = m1.y > 0.f ? y11 : 0.f;
+            }
+            *reinterpret_cast<float2*>(out + o) = make_float2(y00, y01);
+            *reinterpret_cast<float2*>(out + o + W) = make_float2(y10, y11);
+        }
+    }
+}
+
+// CLHIP_WINO16G=0 keeps even maps >= 16 wide on the 32-tile kernel (A/B measurements; N = 200: 64->64 @32x32 forward 126 -> 109 us,
+// backward-data 136 -> 110; 256->256 @16x16 357 -> 317 = 190 TFLOP/s algorithmic)
+static bool wino16g_on() {
+    static const bool on = [] { const char* e = getenv("CLHIP_WINO16G"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 // units of the 32-tile kernel a layer has; below this the 8 x 8 variant takes 8 x 8 maps
 constexpr long long WINO16_BELOW_UNITS = 640;
 
@@ -888,6 +1095,15 @@ int launch_wino(const float* in, const float* U, const float* bias, const float*
         else
             hipLaunchKernelGGL((wino_conv16_kernel<MODE, UNPOOL, 2>), dim3((unsigned)blocks), dim3(256), 0, s, in, U, bias, mask_src, out,
                                pool_idx, N, Cin, Cout, relu);
+        CLHIP_LAUNCH_CHECK();
+        return 0;
+    }
+    if (wino16g_on() && W >= 16 && !((H | W) & 1)) {
+        const int tiles_w = (W / 2 + 7) / 8, tiles_h = (H / 2 + 3) / 4;
+        const long long npb = (long long)tiles_w * tiles_h * N, blocks = npb * kts;
+        if (blocks <= 0 || blocks > 0x7fffffffLL) return CLHIP_EINVAL;
+        hipLaunchKernelGGL((wino_conv16g_kernel<8, 2, MODE, UNPOOL>), dim3((unsigned)blocks), dim3(256), 0, s, in, U, bias, mask_src, out,
+                           pool_idx, N, Cin, Cout, H, W, relu, tiles_w, tiles_h, (int)npb);
         CLHIP_LAUNCH_CHECK();
         return 0;
     }
