@@ -133,10 +133,7 @@ def wino_conv_instance(W, mode, unpool, N=None, kout=None):
     """Instance name of the Winograd forward (mode 0) / backward-data (mode 1) launch for a W-wide even map (csrc/wino.hip, launch_wino)."""
     if W == 8 and N is not None and ((N * 16 + 31) // 32) * ((kout + 31) // 32) < 640:
         return "wino_conv16_kernel<%d, %s, %d> (+ wino_weight_kernel)" % (mode, "true" if unpool else "false", 1 if N * ((kout + 31) // 32) <= 512 else 2)
-    if W >= 16:
-        return "wino_conv16g_kernel<8, 2, %d, %s> (+ wino_weight_kernel)" % (mode, "true" if unpool else "false")
-    geo = "4, 4, 4"
-    return "wino_conv_kernel<%s, %d, %s, false> (+ wino_weight_kernel)" % (geo, mode, "true" if unpool else "false")
+    return "wino_conv16g_kernel<%s, %d, %s> (+ wino_weight_kernel)" % ("8, 2, 4" if W >= 16 else "4, 4, 4", mode, "true" if unpool else "false")
 
 
 def time_kernels(eng, x, N, iters):

@@ -880,14 +880,22 @@ __global__ __launch_bounds__(256, 1) void wino_conv16_kernel(
 // holds 4-channel chunks (23 KB, double-buffered) and the kernel stays under 256 registers — two blocks share a CU, each
 // SIMD has two waves, one issues MFMAs while the other waits, transforms or stores.  No hand-placed slots: the work of a
 // chunk is read operands -> transform -> 32 MFMAs, the compiler orders it, the second wave fills the gaps.
-template <int TC, int TR, int MODE, bool UNPOOL>
+// Geometry: the block's TC x 2 TR tiles are 2 TR / EROWS ENTITIES of EROWS tile rows each, every entity with its own halo band
+// of 2 EROWS + 2 rows; entities are numbered over (image, row group of the image):
+//   EROWS = 2 TR      one entity = a (TC x 2 TR)-tile region of one image                     (even maps >= 16 wide: <8, 2, 4>)
+//   EROWS = TR = 4    two entities = two whole 8 x 8 images                                   (<4, 4, 4>)
+//   EROWS = 1         four consecutive tile rows of the (image, tile row) list, odd maps 9..16 wide (AlexNet's 13 x 13: <8, 2, 1>;
+//                     49 of 56 tile slots busy; half-outside tiles read 0 and store nothing, 4-byte stores)
+template <int TC, int TR, int EROWS, int MODE, bool UNPOOL>
 __global__ __launch_bounds__(256, 2) void wino_conv16g_kernel(
     const float* __restrict__ in, const float* __restrict__ U, const float* __restrict__ bias,
     const float* __restrict__ mask_src, float* __restrict__ out, uint8_t* __restrict__ pool_idx,
     int N, int Cin, int Cout, int H, int W, int relu, int tiles_w, int tiles_h, int n_pix_blocks) {
     static_assert(TC * TR == 16, "16 tiles per wave");
     constexpr int CQ = 4;                                             // in channels per chunk = one MFMA k-quad
-    constexpr int PW = 2 * TC + 2, PR = 4 * TR + 2, PLANE = PR * PW;
+    constexpr int NE = 2 * TR / EROWS;                                // entities per block
+    static_assert(NE * EROWS == 2 * TR && (NE == 1 || !UNPOOL || EROWS == 4), "whole entities");
+    constexpr int PW = 2 * TC + 2, PRE = 2 * EROWS + 2, PLANE = NE * PRE * PW;
     constexpr int WQ_FLOATS = CQ * WKT * WFP;                         // 5120 floats: half of a U chunk (channels are its outer index)
     constexpr int X_FLOATS = CQ * PLANE, BUF = WQ_FLOATS + X_FLOATS;
     __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
@@ -896,17 +904,19 @@ __global__ __launch_bounds__(256, 2) void wino_conv16g_kernel(
     const int wk = wave & 1, wp = wave >> 1;
     const int ti = lane & 15, q = lane >> 4;
     const int kt = blockIdx.x / n_pix_blocks, pb = blockIdx.x - kt * n_pix_blocks;
-    const int bw = pb % tiles_w, bh = (pb / tiles_w) % tiles_h, n = pb / (tiles_w * tiles_h);
-    const int h0 = bh * 4 * TR, w0 = bw * 2 * TC;
+    // tiles_h = row groups (entities) per image; entity v = (image v / tiles_h, group v % tiles_h); offsets relative to image nb0
+    const int bw = pb % tiles_w, v0 = (pb / tiles_w) * NE;
+    const int nb0 = v0 / tiles_h, w0 = bw * 2 * TC;
     const int ko0 = kt * WKT;
     const int n_chunks = Cin / CQ;                                    // Cin is a whole number of 8-channel U chunks
     if (MODE == 0 && tid < WKT) bias_s[tid] = (bias && ko0 + tid < Cout) ? bias[ko0 + tid] : 0.f;
 
     const int Hi = UNPOOL ? H >> 1 : H, Wi = UNPOOL ? W >> 1 : W;
     const int plane_in = Hi * Wi;
-    const float* in_img = in + (size_t)n * Cin * plane_in;
-    const __amdgpu_buffer_rsrc_t rs_x = clhip_rsrc(in_img, (size_t)Cin * plane_in * sizeof(float));
-    const __amdgpu_buffer_rsrc_t rs_i = clhip_rsrc(UNPOOL ? pool_idx + (size_t)n * Cin * plane_in : pool_idx, UNPOOL ? (size_t)Cin * plane_in : 0);
+    const float* in_img = in + (size_t)nb0 * Cin * plane_in;
+    const __amdgpu_buffer_rsrc_t rs_x = clhip_rsrc(in_img, (size_t)(N - nb0) * Cin * plane_in * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rs_i = clhip_rsrc(UNPOOL ? pool_idx + (size_t)nb0 * Cin * plane_in : pool_idx,
+                                                   UNPOOL ? (size_t)(N - nb0) * Cin * plane_in : 0);
     const __amdgpu_buffer_rsrc_t rs_u = clhip_rsrc(U + (size_t)kt * n_chunks * WQ_FLOATS, (size_t)n_chunks * WQ_FLOATS * sizeof(float));
 
     constexpr int W_IT = WQ_FLOATS / 4 / 256;                         // 5
@@ -921,14 +931,16 @@ __global__ __launch_bounds__(256, 2) void wino_conv16g_kernel(
         xoff[j] = CLHIP_OOB;
         if (e < X_FLOATS) {
             const int cl = e / PLANE, rem = e - cl * PLANE;
-            const int col = rem % PW, row = rem / PW;
-            const int h = h0 - 1 + row, w = w0 - 1 + col;
-            if (h >= 0 && h < H && w >= 0 && w < W) {
+            const int col = rem % PW, rr = rem / PW;
+            const int row = rr % PRE, v = v0 + rr / PRE;
+            const int nn = v / tiles_h, g = v - nn * tiles_h;
+            const int h = g * 2 * EROWS - 1 + row, w = w0 - 1 + col;
+            if (nn < N && h >= 0 && h < H && w >= 0 && w < W) {
                 if constexpr (UNPOOL) {
-                    xoff[j] = cl * plane_in + (h >> 1) * Wi + (w >> 1);       // ELEMENT offset
+                    xoff[j] = ((nn - nb0) * Cin + cl) * plane_in + (h >> 1) * Wi + (w >> 1);       // ELEMENT offset
                     xcode[j] = ((h & 1) << 1) | (w & 1);
                 } else {
-                    xoff[j] = (cl * plane_in + h * W + w) * 4;
+                    xoff[j] = (((nn - nb0) * Cin + cl) * plane_in + h * W + w) * 4;
                 }
             }
         }
@@ -961,8 +973,9 @@ __global__ __launch_bounds__(256, 2) void wino_conv16g_kernel(
             }
     };
 
-    const int t_row = wp * TR + ti / TC, t_col = ti % TC;            // this lane's tile inside the block's TC x 2 TR tiles
-    const int d_off = WQ_FLOATS + q * PLANE + 2 * t_row * PW + 2 * t_col;      // even: 8-byte aligned
+    const int t_rowb = wp * TR + ti / TC, t_col = ti % TC;           // this lane's tile inside the block's TC x 2 TR tiles
+    const int t_ent = t_rowb / EROWS, t_row = t_rowb % EROWS;        // its entity and its row inside the entity
+    const int d_off = WQ_FLOATS + q * PLANE + (t_ent * PRE + 2 * t_row) * PW + 2 * t_col;      // even: 8-byte aligned
     const int a_off = (q * WKT + wk * 32 + ti) * WFP;
 
     floatx4v acc[2][16];
@@ -1019,8 +1032,11 @@ __global__ __launch_bounds__(256, 2) void wino_conv16g_kernel(
     }
 
     // ---- epilogue: register r of acc[k2][f] = (out channel ko0 + 32 wk + 16 k2 + 4 q + r, this lane's tile)
-    const int oh = h0 + 2 * t_row, ow = w0 + 2 * t_col;
-    const bool tile_ok = oh < H && ow < W;
+    const int tv = v0 + t_ent, n = tv / tiles_h;
+    const int oh = (tv - n * tiles_h) * 2 * EROWS + 2 * t_row, ow = w0 + 2 * t_col;
+    const bool tile_ok = n < N && oh < H && ow < W;
+    const bool odd = (H | W) & 1;                                   // uniform; the last tile row / column may be half outside
+    const bool row1 = oh + 1 < H, col1 = ow + 1 < W;
     const bool pool = MODE == 0 && pool_idx != nullptr;
     const size_t chw = (size_t)H * W;
     const int OH = H >> 1, OW = W >> 1;
@@ -1057,7 +1073,19 @@ __global__ __launch_bounds__(256, 2) void wino_conv16g_kernel(
                 continue;
             }
         }
-        if (ok) {
+        if (ok && odd) {
+            const size_t o = ((size_t)n * Cout + k) * chw + (size_t)oh * W + ow;
+            if (MODE == 1 && mask_src) {
+                y00 = mask_src[o] > 0.f ? y00 : 0.f;
+                if (col1) y01 = mask_src[o + 1] > 0.f ? y01 : 0.f;
+                if (row1) y10 = mask_src[o + W] > 0.f ? y10 : 0.f;
+                if (row1 && col1) y11 = mask_src[o + W + 1] > 0.f ? y11 : 0.f;
+            }
+            out[o] = y00;
+            if (col1) out[o + 1] = y01;
+            if (row1) out[o + W] = y10;
+            if (row1 && col1) out[o + W + 1] = y11;
+        } else if (ok) {
             const size_t o = ((size_t)n * Cout + k) * chw + (size_t)oh * W + ow;
             if (MODE == 1 && mask_src) {
                 const float2 m0 = *reinterpret_cast<const float2*>(mask_src + o), m1 = *reinterpret_cast<const float2*>(mask_src + o + W);
@@ -1098,14 +1126,24 @@ int launch_wino(const float* in, const float* U, const float* bias, const float*
         CLHIP_LAUNCH_CHECK();
         return 0;
     }
-    if (wino16g_on() && W >= 16 && !((H | W) & 1)) {
-        const int tiles_w = (W / 2 + 7) / 8, tiles_h = (H / 2 + 3) / 4;
-        const long long npb = (long long)tiles_w * tiles_h * N, blocks = npb * kts;
-        if (blocks <= 0 || blocks > 0x7fffffffLL) return CLHIP_EINVAL;
-        hipLaunchKernelGGL((wino_conv16g_kernel<8, 2, MODE, UNPOOL>), dim3((unsigned)blocks), dim3(256), 0, s, in, U, bias, mask_src, out,
-                           pool_idx, N, Cin, Cout, H, W, relu, tiles_w, tiles_h, (int)npb);
-        CLHIP_LAUNCH_CHECK();
-        return 0;
+    if (wino16g_on()) {
+        // 16-tile waves, two blocks per CU (wino_conv16g_kernel): every shape of this path except 8 x 8 maps with so few units
+        // that the one-image waves of wino_conv16_kernel (above) spread better
+#define WINO_16G(TC_, TR_, ER_, UNP_)                                                                                          \
+        do {                                                                                                                   \
+            const int tiles_w = ((W + 1) / 2 + TC_ - 1) / TC_, groups = ((H + 1) / 2 + ER_ - 1) / ER_;                          \
+            constexpr int NE_ = 2 * TR_ / ER_;                                                                                  \
+            const long long npb = (((long long)N * groups + NE_ - 1) / NE_) * tiles_w, blocks = npb * kts;                      \
+            if (blocks <= 0 || blocks > 0x7fffffffLL) return CLHIP_EINVAL;                                                      \
+            hipLaunchKernelGGL((wino_conv16g_kernel<TC_, TR_, ER_, MODE, UNP_>), dim3((unsigned)blocks), dim3(256), 0, s, in, U, \
+                               bias, mask_src, out, pool_idx, N, Cin, Cout, H, W, relu, tiles_w, groups, (int)npb);             \
+            CLHIP_LAUNCH_CHECK();                                                                                               \
+            return 0;                                                                                                           \
+        } while (0)
+        if ((H | W) & 1) { if (W <= 16) WINO_16G(8, 2, 1, false); }
+        else if (W >= 16) WINO_16G(8, 2, 4, UNPOOL);
+        else if (H == 8 && W == 8) WINO_16G(4, 4, 4, UNPOOL);
+#undef WINO_16G
     }
 #define WINO_GEO(TCB_, TRB_, NIMG_)                                                                                          \
     do {                                                                                                                      \

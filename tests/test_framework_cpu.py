@@ -266,7 +266,7 @@ def test_traffic_json_names_the_kernel_bench_reports():
     assert bench.measured_traffic("conv3x3_relu_pool_fwd", "64x64@32", 200, "conv3x3_mfma_kernel<other>") is None
     assert e["direct_kernel_round2"]["instance"] == bench.conv_instance(64, 32, 32, 200, 64, 0, True)
     assert t["conv3x3_bwd_data_unpool 64x64@32 N=200"]["instance"] == bench.wino_conv_instance(32, 1, True)
-    assert "wino_conv16g_kernel<8, 2, 1, true>" in bench.wino_conv_instance(32, 1, True)
+    assert "wino_conv16g_kernel<8, 2, 4, 1, true>" in bench.wino_conv_instance(32, 1, True)
 
 
 def test_hat_alexnet_net_structure():
