@@ -497,7 +497,7 @@ def _base_model_file(root, name="small_VGG9_cl_128_128"):
 
 
 def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epochs=70,
-               pair_sizes=(2000, 500, 500), pair_epochs=3, pair_batch=50, pair_noise=0.3, pair_lambda=10.0):
+               pair_sizes=(2000, 500, 500), pair_epochs=3, pair_batch=50, pair_noise=0.3, pair_lambda=10.0, pair_lr="2e-3"):
     """BASELINE.json's second metric ('full-sweep wall-clock'), two measurements.
 
     `gpu_s`: what framework/main.py runs for `small_VGG9_cl_128_128 --method_name EWC --test` with the reference's defaults
@@ -573,14 +573,17 @@ def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epoch
                 # batch size and LR, so the driver finds it under the name both legs look for), outside both timed regions.
                 # (A first-task model trained to the 70-epoch cap is saturated on this easy data: three epochs at 1e-2 do not
                 # move a new head off chance on EITHER side, measured — and a comparison at chance says nothing.)
-                driver.main(pcommon + ["--lr_grid", "1e-2", "--results_root", proot, "--method_name", "SI", "--runmode",
+                driver.main(pcommon + ["--lr_grid", pair_lr, "--results_root", proot, "--method_name", "SI", "--runmode",
                                        "first_task_basemodel_dump"], method=M.parse("SI"))
-            fixed = ["--lr_grid", "1e-2", "--max_attempts_per_task", "1", "--hyperparams", "%g" % pair_lambda, "--method_name", "EWC", "--test"]
-            pair = {"what": "task 2 of a 2-task sequence (%d/%d/%d images), from the same first-task model: LR grid {1e-2}, %d-epoch "
+            fixed = ["--lr_grid", pair_lr, "--max_attempts_per_task", "1", "--hyperparams", "%g" % pair_lambda, "--method_name", "EWC", "--test"]
+            pair = {"what": "task 2 of a 2-task sequence (%d/%d/%d images), from the same first-task model: LR grid {%s}, %d-epoch "
                             "cap, batch %d and pixel noise %g instead of 1.0 (so that the few epochs the CPU leg can afford leave "
                             "chance; the first-task model is trained with the same 3-epoch cap), Fisher pass, ONE stability-decay attempt at "
                             "lambda = %g (where the sweep's halvings of 400 end up; at 400 three epochs do not move task 2 off chance "
-                            "on either side and the comparison says nothing), both models evaluated" % (tuple(pair_sizes) + (pair_epochs, pair_batch, pair_noise, pair_lambda))}
+                            "on either side and the comparison says nothing), both models evaluated.  Same task files, start model, batches and "
+                            "head initialisation on both sides (the oracle follows torch DataLoader's RNG protocol) and the same importance "
+                            "weights (omega_sum); phase 1 agrees, the penalised phase 2 amplifies rounding differences (the CPU leg alone "
+                            "moves by 3-10 points between 16 and 32 threads), so its accuracies are comparable, not equal" % (tuple(pair_sizes) + (pair_lr, pair_epochs, pair_batch, pair_noise, pair_lambda))}
             for sub in ("data", "models", os.path.join("train", "synthetic_tiny_imagenet", "SI")):
                 shutil.copytree(os.path.join(proot, sub), os.path.join(croot, sub))
             with contextlib.redirect_stdout(quiet), _PassCounter(pair_sizes[0]) as pcounts:
@@ -602,6 +605,11 @@ def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epoch
             pair["cpu_threads"] = torch.get_num_threads()
             pair["phase1_val_accuracy"] = {"gpu": [a for _, _, a in gout["manager"].grid_trace], "cpu": [a for _, _, a in cout["manager"].grid_trace]}
             pair["phase2_val_accuracy"] = {"gpu": [a for _, a, _ in gout["frameworks"][-1].trace], "cpu": [a for _, a, _ in cout["frameworks"][-1].trace]}
+            # the importance weights both sides trained task 2 against (sum over all parameters of the Fisher diagonal of task 1)
+            gm = torch.load(gout["model_paths"][-1], map_location="cpu", weights_only=False)
+            cm = torch.load(cout["model_paths"][-1], map_location="cpu", weights_only=False)
+            pair["omega_sum"] = {"gpu": float(sum(float(v["omega"].double().sum()) for k, v in gm.reg_params.items() if isinstance(v, dict))),
+                                 "cpu": float(sum(float(o.double().sum()) for o in cm.oracle_omega))}
             pair["trainings_in_phase2"] = {"gpu": len(gout["frameworks"][-1].trace), "cpu": len(cout["frameworks"][-1].trace)}
             pair["max_accuracy_gap_points"] = max(abs(a - b) for i in pair["gpu_accuracies"]
                                                   for a, b in zip(pair["gpu_accuracies"][i], pair["cpu_accuracies"][i]))

@@ -13,6 +13,9 @@ for m in small base wide; do
   bash tools/gpu_mfma_util.sh ${m}_VGG9_cl_$([ $m = small ] && echo 128_128 || echo 512_512) $TAG/mfma_util_$m > /dev/null 2>&1
 done
 timeout 300 python tools/wino_bench.py 10 2>&1 | grep -v amdgpu.ids > gpurun_out/$TAG/wino_bench.txt
+timeout 300 python tools/wino_bench.py 10 alex 2>&1 | grep -v amdgpu.ids >> gpurun_out/$TAG/wino_bench.txt
+timeout 300 python tools/conv2d_bench.py 10 2>&1 | grep -v amdgpu.ids > gpurun_out/$TAG/conv2d_bench.txt
+bash tools/gpu_alex.sh $TAG/alexnet 2>&1 | grep -v amdgpu.ids > gpurun_out/$TAG/alexnet_step.txt
 for spec in "hat 64" "packnet 64" "mas 64" "si 64" "hat 224"; do
   set -- $spec
   d=$P/gpurun_out/$TAG/$1$2_prof
