@@ -136,6 +136,20 @@ def wino_conv_instance(W, mode, unpool, N=None, kout=None):
     return "wino_conv16g_kernel<%s, %d, %s> (+ wino_weight_kernel)" % ("8, 2, 4" if W >= 16 else "4, 4, 4", mode, "true" if unpool else "false")
 
 
+def wino_wgrad_instance(N, C, K, H, W, unpool):
+    """Instance name of the Winograd weight-gradient launch (csrc/wino.hip, clhip_internal_wino_wgrad_partial): layers with fewer
+    than 8 sixteen-tile stages per 64 x 64-tile block take the 32 x 32-tile pixel-split kernel."""
+    wide = W >= 16
+    tcs, trs = (8, 2) if wide else (4, 4)
+    total = ((W // 2 + tcs - 1) // tcs) * ((H // 2 + trs - 1) // trs) * N
+    kc = (K // 64) * (C // 64)
+    splits = min(1 if kc >= 256 else 256 // kc, total)
+    u = "true" if unpool else "false"
+    if total < 8 * splits:
+        return "wino_wgrad_ps_kernel<%d, %d, %s> (slabs + reduction)" % (tcs, trs, u)
+    return "wino_wgrad_kernel<%d, %d, 1, %s> (slabs + reduction)" % (tcs, trs, u)
+
+
 def time_kernels(eng, x, N, iters):
     """Per-layer HIP-event timing of the conv launches of one pass, as the plan executor issues them (fused
     ReLU+pool forward on pooled layers, first-layer weight gradient straight from the pooled gradient)."""
@@ -201,14 +215,14 @@ def time_kernels(eng, x, N, iters):
             t_w = timed((lambda: ops.conv3x3_wino_bwd_weight(xin, dyp, idx)) if paths["bwd_weight"] else
                         (lambda: ops.conv3x3_bwd_weight_slabs(xin, dyp, idx)))
             rows.append(dict(kernel="conv3x3_bwd_weight_unpool", layer=layer, li=li, kind="bwd_weight", flops=fl, sec=t_w, winograd=paths["bwd_weight"],
-                             instance="wino_wgrad_kernel<..., UNPOOL=true> (slabs + reduction)" if paths["bwd_weight"]
+                             instance=wino_wgrad_instance(N, C, K, H, W, True) if paths["bwd_weight"]
                              else "conv3x3_wgrad_kernel<..., UNPOOL=true> (slabs; reduction deferred)",
                              alg_bytes=4.0 * N * H * W * (C + K / 4.0) + 1.0 * N * K * H * W / 4))
         else:
             t_w = timed((lambda: ops.conv3x3_wino_bwd_weight(xin, dy)) if paths["bwd_weight"] else
                         (lambda: ops.conv3x3_bwd_weight_slabs(xin, dy)))
             rows.append(dict(kernel="conv3x3_bwd_weight", layer=layer, li=li, kind="bwd_weight", flops=fl, sec=t_w, winograd=paths["bwd_weight"],
-                             instance="wino_wgrad_kernel (slabs + reduction)" if paths["bwd_weight"]
+                             instance=wino_wgrad_instance(N, C, K, H, W, False) if paths["bwd_weight"]
                              else "conv3x3_wgrad_kernel (slabs; reduction deferred)", alg_bytes=4.0 * N * H * W * (C + K)))
         if C > 3 and pool:
             t_d = timed((lambda: ops.conv3x3_wino_bwd_data(dyp, m.weight.data, xmask, idx)) if paths["bwd_data"] else

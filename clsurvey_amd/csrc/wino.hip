@@ -1108,6 +1108,255 @@ static bool wino16g_on() {
 // units of the 32-tile kernel a layer has; below this the 8 x 8 variant takes 8 x 8 maps
 constexpr long long WINO16_BELOW_UNITS = 640;
 
+
+// ------------------------------------------------------------------------------------------------ weight gradient of small layers
+// wino_wgrad_kernel gives a block a 64 x 64 (k, c) tile and 256 accumulators per wave: a 64 -> 64 layer on 16 x 16 maps has
+// ONE such tile, so all parallelism must come from splitting the tile list 256 ways — 3 stages and one 147 KB slab per block,
+// which is why those layers stayed on the direct kernel (whose pixel-split form has the same shape as this one).  Here a block
+// owns a 32 x 32 (k, c) tile; its four waves are (2 in-channel halves of 16) x (2 halves of every 16-tile stage); a wave
+// reduces its 8 tiles of the stage with two v_mfma_f32_16x16x4_f32 steps into 32 k x 16 c x 16 frequencies = 128 accumulators.
+// Four times as many (k, c) tiles -> a quarter of the splits, 4x the stages per block and a 36 KB slab; under 256 registers and
+// 64 KB of LDS two blocks share a CU.  At the end the two tile-halves exchange half of their accumulators through LDS (the wave
+// of half p finishes row tile p: a two-term sum, order-free), transform G^T M G and write the slab — the [9][K][C] (+ [K])
+// format of conv3x3_wgrad.hip, reduced by the same fixed-order launch.
+template <int TCS, int TRS>
+struct WGeoP {
+    static_assert(TCS * TRS == 16 && (TCS & (TCS - 1)) == 0, "16 tiles per stage, tile of a step by shifts");
+    static constexpr int KB = 32, CB = 32;                 // (k, c) tile of a block
+    static constexpr int DW = 2 * TCS, DR = 2 * TRS;
+    static constexpr int DPIX = DR * DW;                   // 64 pixels
+    static constexpr int LDP = DPIX + 2;
+    static constexpr int PW = DW + 2, PR = DR + 2;
+    static constexpr int PLANE = PR * PW;
+    static constexpr int PLANEP = (PLANE % 4 == 2) ? PLANE : PLANE + 2;
+    static_assert((LDP / 2) % 2 == 1 && (PLANEP / 2) % 2 == 1, "lane strides must be odd in 8-byte units");
+    static constexpr int DY_FLOATS = KB * LDP, X_FLOATS = CB * PLANEP;
+    static constexpr int BUF = DY_FLOATS + X_FLOATS;
+    static constexpr int XCH = 4 * 65 * 64;                // exchange area: per wave 64 accumulators + 1 bias sum, 64 lanes
+    static constexpr int LDS_FLOATS = 2 * BUF > XCH ? 2 * BUF : XCH;
+};
+
+template <int TCS, int TRS, bool UNPOOL>
+__global__ __launch_bounds__(256, 2) void wino_wgrad_ps_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, const uint8_t* __restrict__ unpool_idx,
+    int N, int C, int K, int H, int W, int tiles_w, int tiles_h, int total_stages, int splits, int c_tiles, size_t slab_stride) {
+    using G = WGeoP<TCS, TRS>;
+    __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave & 1, wp = wave >> 1;
+    const int li = lane & 15, q = lane >> 4;
+    const int split = blockIdx.x % splits, tile = blockIdx.x / splits;
+    const int ct = tile % c_tiles, kt = tile / c_tiles;
+    const int k0 = kt * G::KB, c0 = ct * G::CB;
+    const int per = total_stages / splits, extra = total_stages % splits;
+    const int st_begin = split * per + min(split, extra);
+    const int st_end = st_begin + per + (split < extra ? 1 : 0);
+    const int Hd = UNPOOL ? H >> 1 : H, Wd = UNPOOL ? W >> 1 : W;
+    const int plane_hw = H * W, plane_dy = Hd * Wd;
+
+    // ---- staging: dy 32 k x 64 pixels (pooled: 32 k x 16 pooled pixels + codes, 2x2 windows rebuilt on the way into LDS),
+    //      x 32 c x halo plane; every per-unit index is base + j * constant
+    constexpr int DQ = UNPOOL ? G::DPIX / 4 : G::DPIX, DKS = 256 / DQ;
+    constexpr int DY_IT = G::KB / DKS;                                  // 8 : 2
+    constexpr int DWp = UNPOOL ? G::DW / 2 : G::DW;
+    constexpr int CPT = 256 / G::PLANE;
+    static_assert(CPT >= 1 && G::CB % CPT == 0, "whole passes over the 32 in-channels");
+    constexpr int X_IT = G::CB / CPT;
+    float dyr[DY_IT], xr[X_IT];
+    unsigned dyi[UNPOOL ? DY_IT : 1];
+    const int dq = tid % DQ, dkl = tid / DQ;
+    const int d_r = dq / DWp, d_c = dq % DWp;
+    const int dy_e0 = dkl * plane_dy + d_r * Wd + d_c;
+    const int dy_dst0 = UNPOOL ? dkl * G::LDP + 2 * d_r * G::DW + 2 * d_c : dkl * G::LDP + dq;
+    const bool x_thr = tid < CPT * G::PLANE;
+    const int x_cl = tid / G::PLANE, x_rem = tid - x_cl * G::PLANE;
+    const int x_col = x_rem % G::PW, x_row = x_rem / G::PW;
+    const int x_e0 = x_cl * plane_hw + x_row * W + x_col;
+    const int x_dst0 = G::DY_FLOATS + x_cl * G::PLANEP + x_rem;
+    bool dy_ok = false, x_ok = false;
+    __amdgpu_buffer_rsrc_t rs_dy = clhip_rsrc(dy, 0), rs_x = clhip_rsrc(x, 0), rs_di = clhip_rsrc(x, 0);
+    auto begin_stage = [&](int st) {
+        const bool live = st < st_end;
+        const int s = live ? st : st_begin;
+        const int bw = s % tiles_w, bh = (s / tiles_w) % tiles_h, n = s / (tiles_w * tiles_h);
+        const int h0 = bh * G::DR, w0 = bw * G::DW;
+        const int org_dy = UNPOOL ? (h0 >> 1) * Wd + (w0 >> 1) : h0 * W + w0;
+        const float* dyb = dy + ((size_t)n * K + k0) * plane_dy + org_dy;
+        const long long dy_left = ((long long)(N - n) * K - k0) * plane_dy - org_dy;
+        rs_dy = clhip_rsrc(dyb, live && dy_left > 0 ? (size_t)dy_left * 4 : 0);
+        if constexpr (UNPOOL) rs_di = clhip_rsrc(unpool_idx + ((size_t)n * K + k0) * plane_dy + org_dy, live && dy_left > 0 ? (size_t)dy_left : 0);
+        const long long org_x = (long long)h0 * W + w0 - W - 1;
+        const float* xb = x + ((size_t)n * C + c0) * plane_hw + org_x;
+        const long long x_left = ((long long)(N - n) * C - c0) * plane_hw - org_x;
+        rs_x = clhip_rsrc(xb, live && x_left > 0 ? (size_t)x_left * 4 : 0);
+        dy_ok = h0 + (UNPOOL ? 2 * d_r : d_r) < H && w0 + (UNPOOL ? 2 * d_c : d_c) < W;
+        const int h = h0 - 1 + x_row, w = w0 - 1 + x_col;
+        x_ok = x_thr && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+    };
+    auto load_stage = [&]() {
+#pragma unroll
+        for (int u = 0; u < DY_IT; ++u) {
+            const int e = dy_e0 + u * DKS * plane_dy;
+            dyr[u] = clhip_buf_load(rs_dy, dy_ok ? e * 4 : CLHIP_OOB, 0);
+            if constexpr (UNPOOL) dyi[u] = clhip_buf_load_u8(rs_di, dy_ok ? e : CLHIP_OOB, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < X_IT; ++j) xr[j] = clhip_buf_load(rs_x, x_ok ? (x_e0 + j * CPT * plane_hw) * 4 : CLHIP_OOB, 0);
+    };
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    auto store_stage = [&](int bo) {
+#pragma unroll
+        for (int u = 0; u < DY_IT; ++u) {
+            const float v = dyr[u];
+            if constexpr (UNPOOL) {
+                const int cde = (int)dyi[u];
+                float* d = lds + bo + dy_dst0 + u * DKS * G::LDP;                         // even offset: 8-byte aligned
+                *reinterpret_cast<f2*>(d) = f2{cde == 0 ? v : 0.f, cde == 1 ? v : 0.f};
+                *reinterpret_cast<f2*>(d + G::DW) = f2{cde == 2 ? v : 0.f, cde == 3 ? v : 0.f};
+            } else {
+                lds[bo + dy_dst0 + u * DKS * G::LDP] = v;
+            }
+        }
+        if (x_thr) {
+#pragma unroll
+            for (int j = 0; j < X_IT; ++j) lds[bo + x_dst0 + j * CPT * G::PLANEP] = xr[j];
+        }
+    };
+
+    floatx4v acc[2][16];
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+        for (int f = 0; f < 16; ++f) acc[k2][f] = floatx4v{0.f, 0.f, 0.f, 0.f};
+    float bsum[2] = {0.f, 0.f};
+
+    const int a_lane = li * G::LDP;                                   // out-channel li (+ 16 rows: the second row tile)
+    const int b_lane = G::DY_FLOATS + (wc * 16 + li) * G::PLANEP;     // in-channel 16 wc + li
+    // A dY A^T without the negations of rows / columns 3 (folded into the output transform)
+    auto dy_tf = [&](const float* p, float (&o)[16], float& bs) {
+        const f2 y0 = *reinterpret_cast<const f2*>(p), y1 = *reinterpret_cast<const f2*>(p + G::DW);
+        const float a = y0.x, b = y0.y, c = y1.x, d = y1.y;
+        bs += (a + b) + (c + d);
+        const float r1p = a + c, r1q = b + d, r2p = a - c, r2q = b - d;
+        o[0] = a;   o[1] = a + b;     o[2] = a - b;     o[3] = b;
+        o[4] = r1p; o[5] = r1p + r1q; o[6] = r1p - r1q; o[7] = r1q;
+        o[8] = r2p; o[9] = r2p + r2q; o[10] = r2p - r2q; o[11] = r2q;
+        o[12] = c;  o[13] = c + d;    o[14] = c - d;    o[15] = d;
+    };
+
+    if (st_begin < st_end) {
+        begin_stage(st_begin);
+        load_stage();
+        store_stage(0);
+        begin_stage(st_begin + 1);
+        load_stage();
+        __syncthreads();
+    }
+    for (int st = st_begin; st < st_end; ++st) {
+        const int bo = ((st - st_begin) & 1) * G::BUF;
+        store_stage(G::BUF - bo);            // stage st + 1 (loaded during the previous iteration) -> the other buffer
+        begin_stage(st + 2);
+        load_stage();
+        const float* cur = lds + bo;
+#pragma unroll 1
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int t = 4 * (2 * wp + s2) + q, tr = t / TCS, tc = t % TCS;      // this lane's tile of the step
+            const int doff = 2 * tr * G::DW + 2 * tc, xoff_s = 2 * tr * G::PW + 2 * tc;
+            f2 xlo[4], xhi[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                xlo[r] = *reinterpret_cast<const f2*>(cur + b_lane + xoff_s + r * G::PW);
+                xhi[r] = *reinterpret_cast<const f2*>(cur + b_lane + xoff_s + r * G::PW + 2);
+            }
+            f2 tlo[4], thi[4];
+            tlo[0] = xlo[0] - xlo[2]; thi[0] = xhi[0] - xhi[2];
+            tlo[1] = xlo[1] + xlo[2]; thi[1] = xhi[1] + xhi[2];
+            tlo[2] = xlo[2] - xlo[1]; thi[2] = xhi[2] - xhi[1];
+            tlo[3] = xlo[1] - xlo[3]; thi[3] = xhi[1] - xhi[3];
+            float vv[16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f2 o = tlo[i] - thi[i];
+                vv[4 * i + 0] = o.x;
+                vv[4 * i + 3] = o.y;
+                vv[4 * i + 1] = tlo[i].y + thi[i].x;
+                vv[4 * i + 2] = thi[i].x - tlo[i].y;
+            }
+            float av[16];
+            dy_tf(cur + a_lane + doff, av, bsum[0]);
+#pragma unroll
+            for (int f = 0; f < 16; ++f) acc[0][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f], vv[f], acc[0][f], 0, 0, 0);
+            dy_tf(cur + a_lane + 16 * G::LDP + doff, av, bsum[1]);
+#pragma unroll
+            for (int f = 0; f < 16; ++f) acc[1][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f], vv[f], acc[1][f], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- the two tile-halves of an in-channel half exchange: wave (wc, wp) keeps row tile wp and receives the partner's part of it
+    {
+        float* mine = lds + wave * (65 * 64);
+#pragma unroll
+        for (int f = 0; f < 16; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mine[(4 * f + r) * 64 + lane] = wp == 0 ? acc[1][f][r] : acc[0][f][r];
+        mine[64 * 64 + lane] = wp == 0 ? bsum[1] : bsum[0];
+    }
+    __syncthreads();
+    floatx4v fin[16];
+    float bfin;
+    {
+        const float* theirs = lds + (wc + 2 * (1 - wp)) * (65 * 64);
+#pragma unroll
+        for (int f = 0; f < 16; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) fin[f][r] = (wp == 0 ? acc[0][f][r] : acc[1][f][r]) + theirs[(4 * f + r) * 64 + lane];
+        bfin = (wp == 0 ? bsum[0] : bsum[1]) + theirs[64 * 64 + lane];
+    }
+
+    // ---- output transform dW = G^T M' G: register r of fin[f] of lane (li, q) = (k = k0 + 16 wp + 4 q + r, c = c0 + 16 wc + li)
+    float* slab = part + (size_t)split * slab_stride;
+    const int cidx = c0 + wc * 16 + li;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float m[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m[i][j] = ((i == 3) != (j == 3)) ? -fin[4 * i + j][r] : fin[4 * i + j][r];
+        float t[3][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float s12 = 0.5f * (m[1][j] + m[2][j]);
+            t[0][j] = m[0][j] + s12;
+            t[1][j] = 0.5f * (m[1][j] - m[2][j]);
+            t[2][j] = s12 + m[3][j];
+        }
+        const int k = k0 + wp * 16 + 4 * q + r;
+        if (k < K && cidx < C) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float s12 = 0.5f * (t[a][1] + t[a][2]);
+                slab[((size_t)(3 * a + 0) * K + k) * C + cidx] = t[a][0] + s12;
+                slab[((size_t)(3 * a + 1) * K + k) * C + cidx] = 0.5f * (t[a][1] - t[a][2]);
+                slab[((size_t)(3 * a + 2) * K + k) * C + cidx] = s12 + t[a][3];
+            }
+        }
+    }
+    if (ct == 0 && wc == 0) {            // bias sums: lanes of one li hold four tiles' partial sums of out-channel 16 wp + li
+        bfin += __shfl_xor(bfin, 16, 64);
+        bfin += __shfl_xor(bfin, 32, 64);
+        const int k = k0 + wp * 16 + li;
+        if (q == 0 && k < K) slab[(size_t)9 * K * C + k] = bfin;
+    }
+}
+
+// CLHIP_WGRAD_PS=0 keeps small layers off the pixel-split Winograd weight gradient (A/B measurements)
+static bool wgrad_ps_on() {
+    static const bool on = [] { const char* e = getenv("CLHIP_WGRAD_PS"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 template <int MODE, bool UNPOOL>
 int launch_wino(const float* in, const float* U, const float* bias, const float* mask_src, float* out, uint8_t* pool_idx,
                 int N, int Cin, int Cout, int H, int W, int relu, hipStream_t s) {
@@ -1270,6 +1519,22 @@ int clhip_internal_wino_wgrad_partial(const float* x, const float* dy, const uin
     if (cap < 1) return CLHIP_ENOSPC;
     if (splits > cap) splits = cap;
     float* part = static_cast<float*>(ws);
+    if (wgrad_ps_on() && total < 8 * splits) {
+        // few stages per 64 x 64 tile block: 32 x 32 tiles, a quarter of the splits, two blocks per CU (wino_wgrad_ps_kernel)
+        const int kc32 = (K / 32) * (C / 32);
+        long long sp = kc32 >= 512 ? 1 : 512 / kc32;
+        if (sp > total) sp = total;
+        if (sp > cap) sp = cap;
+        const unsigned gridp = (unsigned)(kc32 * sp);
+#define WGP(TCS_, TRS_, UNP_) hipLaunchKernelGGL((wino_wgrad_ps_kernel<TCS_, TRS_, UNP_>), dim3(gridp), dim3(256), 0, s, x, dy, part, \
+                                                 unpool_idx, N, C, K, H, W, tiles_w, tiles_h, (int)total, (int)sp, C / 32, slab)
+        if (wide) { if (unpool_idx) WGP(8, 2, true); else WGP(8, 2, false); }
+        else { if (unpool_idx) WGP(4, 4, true); else WGP(4, 4, false); }
+#undef WGP
+        CLHIP_LAUNCH_CHECK();
+        *job = clhip_wgrad_job{part, dw, db, K, C, (int)sp};
+        return 0;
+    }
     const unsigned grid = (unsigned)(kc_tiles * splits);
 #define WG(TCS_, TRS_, UNP_) hipLaunchKernelGGL((wino_wgrad_kernel<TCS_, TRS_, 1, UNP_>), dim3(grid), dim3(256), 0, s, x, dy, part,      \
                                                 unpool_idx, N, C, K, H, W, tiles_w, tiles_h, (int)total, (int)splits, C / WKT, slab)
