@@ -1258,7 +1258,7 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_ps_kernel(
         begin_stage(st + 2);
         load_stage();
         const float* cur = lds + bo;
-#pragma unroll 1
+#pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             const int t = 4 * (2 * wp + s2) + q, tr = t / TCS, tc = t % TCS;      // this lane's tile of the step
             const int doff = 2 * tr * G::DW + 2 * tc, xoff_s = 2 * tr * G::PW + 2 * tc;
