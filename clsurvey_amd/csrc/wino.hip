@@ -20,6 +20,16 @@
 //
 // Block = 4 waves = (2 halves of 64 out-channels) x (2 groups of 32 tiles); a wave holds 16 x 16 = 256 accumulator
 // registers (one wave per SIMD, like the weight-gradient kernel).  Tiles of a block: TCB x TRB tiles of NIMG images.
+//
+// Kernels of this file, in the order they were built (all share the U layout and the weight-transform launch):
+//   wino_weight_kernel / wino_weight_multi_kernel   U = G g G^T (one layer / every Winograd layer of a pass in one launch)
+//   wino_conv_kernel        forward / backward-data, 32-tile waves on 32x32x2 MFMAs, slot-pinned pipeline — the A/B reference
+//                           behind CLHIP_WINO16G=0 since the 16-tile kernel below is faster on every shape
+//   wino_wgrad_kernel       weight gradient, 64 x 64 (k, c) tiles, 256 accumulators, slot-pinned — layers with >= 8 stages per block
+//   wino_conv16_kernel      forward / backward-data of 8 x 8 maps with few units: one image per wave on 16x16x4 MFMAs
+//   wino_conv16g_kernel     forward / backward-data, 16-tile waves on 16x16x4 MFMAs, two blocks per CU — the DEFAULT path
+//                           (even maps, 8 x 8 image pairs, odd maps 9..16 wide through row-packed tile rows)
+//   wino_wgrad_ps_kernel    weight gradient of layers with few stages per block: 32 x 32 tiles, pixel split, two blocks per CU
 #include "common.hpp"
 #include <cstdlib>
 
