@@ -138,14 +138,14 @@ def wino_conv_instance(W, mode, unpool, N=None, kout=None):
 
 def wino_wgrad_instance(N, C, K, H, W, unpool):
     """Instance name of the Winograd weight-gradient launch (csrc/wino.hip, clhip_internal_wino_wgrad_partial): layers with fewer
-    than 8 sixteen-tile stages per 64 x 64-tile block take the 32 x 32-tile pixel-split kernel."""
+    than 16 sixteen-tile stages per 64 x 64-tile block take the 32 x 32-tile pixel-split kernel."""
     wide = W >= 16
     tcs, trs = (8, 2) if wide else (4, 4)
     total = ((W // 2 + tcs - 1) // tcs) * ((H // 2 + trs - 1) // trs) * N
     kc = (K // 64) * (C // 64)
     splits = min(1 if kc >= 256 else 256 // kc, total)
     u = "true" if unpool else "false"
-    if total < 8 * splits:
+    if total < 16 * splits:
         return "wino_wgrad_ps_kernel<%d, %d, %s> (slabs + reduction)" % (tcs, trs, u)
     return "wino_wgrad_kernel<%d, %d, 1, %s> (slabs + reduction)" % (tcs, trs, u)
 

@@ -1529,8 +1529,8 @@ int clhip_internal_wino_wgrad_partial(const float* x, const float* dy, const uin
     if (cap < 1) return CLHIP_ENOSPC;
     if (splits > cap) splits = cap;
     float* part = static_cast<float*>(ws);
-    if (wgrad_ps_on() && total < 8 * splits) {
-        // few stages per 64 x 64 tile block: 32 x 32 tiles, a quarter of the splits, two blocks per CU (wino_wgrad_ps_kernel)
+    if (wgrad_ps_on() && total < 16 * splits) {          // (measured: layer 2 of the bench model, 12.5 stages per block, 99 -> 92 us; 50 stages: slower)
+        // fewer than 16 stages per 64 x 64 tile block: 32 x 32 tiles, a quarter of the splits, two blocks per CU (wino_wgrad_ps_kernel)
         const int kc32 = (K / 32) * (C / 32);
         long long sp = kc32 >= 512 ? 1 : 512 / kc32;
         if (sp > total) sp = total;
