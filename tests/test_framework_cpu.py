@@ -269,6 +269,28 @@ def test_traffic_json_names_the_kernel_bench_reports():
     assert "wino_conv16g_kernel<8, 2, 4, 1, true>" in bench.wino_conv_instance(32, 1, True)
 
 
+def test_bench_names_the_winograd_instances_the_library_launches():
+    """bench.py's per-layer table names kernel instances by restating the dispatch rules of csrc/wino.hip (launch_wino,
+    clhip_internal_wino_wgrad_partial); the names are what profiles/*kernel_stats*.csv rows are matched against."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    # forward / backward-data: 16-tile kernel by map width; 8x8 maps with few units: the one-image-per-wave variant, 16 or 32 channels per wave
+    assert bench.wino_conv_instance(32, 0, False, 200, 64).startswith("wino_conv16g_kernel<8, 2, 4, 0, false>")
+    assert bench.wino_conv_instance(16, 1, True, 200, 64).startswith("wino_conv16g_kernel<8, 2, 4, 1, true>")
+    assert bench.wino_conv_instance(8, 0, False, 200, 128).startswith("wino_conv16_kernel<0, false, 2>")      # 400 units of the 32-tile kernel
+    assert bench.wino_conv_instance(8, 1, False, 200, 64).startswith("wino_conv16_kernel<1, false, 1>")       # <= 512 waves: 16-channel waves
+    assert bench.wino_conv_instance(8, 0, False, 200, 512).startswith("wino_conv16g_kernel<4, 4, 4, 0, false>")
+    # weight gradient: fewer than 16 sixteen-tile stages per 64x64-tile block -> the pixel-split kernel
+    assert bench.wino_wgrad_instance(200, 64, 64, 32, 32, True).startswith("wino_wgrad_ps_kernel<8, 2, true>")     # 3200 stages / 256 splits
+    assert bench.wino_wgrad_instance(200, 64, 64, 16, 16, False).startswith("wino_wgrad_ps_kernel<8, 2, false>")
+    assert bench.wino_wgrad_instance(200, 128, 128, 8, 8, True).startswith("wino_wgrad_ps_kernel<4, 4, true>")
+    assert bench.wino_wgrad_instance(200, 512, 512, 8, 8, False).startswith("wino_wgrad_kernel<4, 4, 1, false>")  # 200 stages / 4 splits
+    assert bench.wino_wgrad_instance(200, 256, 256, 16, 16, False).startswith("wino_wgrad_kernel<8, 2, 1, false>")
+
+
 def test_hat_alexnet_net_structure():
     """HatNetAlexnet (methods/HAT/networks/alexnet_hat.py:4-13 over vgg_hat.Net, vgg_hat.py:18-81): the parameter tree of the
     reference's dynamic construction over torchvision's AlexNet module tree, its single shared pool geometry and Dropout, and
