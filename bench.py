@@ -93,6 +93,9 @@ def parse():
     ap.add_argument("--no-sweep", action="store_true", help="skip the full 10-task EWC sweep and its GPU / CPU pair")
     ap.add_argument("--sweep-tasks", type=int, default=10)
     ap.add_argument("--sweep-epochs", type=int, default=70)
+    ap.add_argument("--sweep-only", action="store_true", help="print only the `sweep` object (tuning the synthetic sequence)")
+    ap.add_argument("--pair-cpu-leg", type=str, default=None, help="internal: run one CPU leg of the sweep pair under this root")
+    ap.add_argument("--pair-threads", type=int, default=16)
     return ap.parse_args()
 
 
@@ -492,71 +495,137 @@ class _PassCounter:
         self.D.DeviceLoader.__iter__ = self._orig
 
 
-def _base_model_file(root, name="small_VGG9_cl_128_128"):
-    """The framework's base-model file (models/net.py:158-169 creates it once and reuses it).  torchvision's VGG initialises
-    the classifier with N(0, 0.01), from which this synthetic data needs several tens of epochs before the loss moves at all
-    — longer than the early-stop patience of train_SGD.py, so every task would end at chance.  The file is therefore
-    pre-created with a Kaiming-normal classifier (same architecture, same convolution init); every run that compares
-    accuracies starts from this one file."""
-    from clsurvey_amd import models
-    gen_state = torch.random.get_rng_state()
-    torch.manual_seed(0)
-    m = models.parse_model_name(name, (64, 64), 20)
-    for mod in m.modules():
-        if isinstance(mod, torch.nn.Linear):
-            torch.nn.init.kaiming_normal_(mod.weight, nonlinearity="relu")
-    torch.random.set_rng_state(gen_state)
-    os.makedirs(os.path.join(root, "models"), exist_ok=True)
-    torch.save(m, os.path.join(root, "models", name + ".pth.tar"))
+# ------------------------------------------------------------------------------------------------ sweep + like-for-like pair
+# Synthetic task sequence of the sweeps: clsurvey_amd.data.synthetic_task(kind="blobs") — coarse colour patterns with coarse and
+# pixel noise and OVERLAPPING classes (q = 0.7: the best possible top-1 accuracy is 71.5 % whatever the model), so that a trained
+# model keeps a non-trivial Fisher diagonal, the stability-decay loop has something to decide, and accuracies saturate at a
+# level the data sets.  Models start from torchvision's initialisation (models.py, VGGSlim.py / torchvision VGG: Kaiming
+# convolutions, N(0, 0.01) classifier), created by the driver's BaseModel as the reference's models/net.py:158-169 does.
+SWEEP_DATA = {"kind": "blobs", "noise": 0.5}
+PAIR = {"sizes": (2000, 500, 500), "epochs": 8, "batch": 50, "lr": "1e-2", "lam": 400.0}
 
 
-def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epochs=70,
-               pair_sizes=(2000, 500, 500), pair_epochs=3, pair_batch=50, pair_noise=0.3, pair_lambda=10.0, pair_lr="2e-3"):
+def _pair_args(device):
+    spec = "2,20,%d,%d,%d,64,%g,%s" % (tuple(PAIR["sizes"]) + (SWEEP_DATA["noise"], SWEEP_DATA["kind"]))
+    return ["small_VGG9_cl_128_128", "--num_epochs", str(PAIR["epochs"]), "--batch_size", str(PAIR["batch"]), "--saving_freq", "1000",
+            "--synthetic", spec, "--device", device, "--lr_grid", PAIR["lr"]]
+
+
+def _pair_fixed():
+    return ["--max_attempts_per_task", "1", "--hyperparams", "%g" % PAIR["lam"], "--method_name", "EWC", "--test"]
+
+
+def _pair_summary(out, seconds, passes):
+    """What both legs report: accuracies of every (task, model) pair, validation accuracies of both phases, omega checksum."""
+    last = torch.load(out["model_paths"][-1], map_location="cpu", weights_only=False)
+    if hasattr(last, "oracle_omega"):
+        osum = float(sum(float(o.double().sum()) for o in last.oracle_omega))
+    else:
+        osum = float(sum(float(v["omega"].double().sum()) for v in last.reg_params.values() if isinstance(v, dict)))
+    return {"seconds": seconds, "image_passes": dict(passes),
+            "accuracies": {str(i): [float(a) for a in out["results"][i]["seq_res"][i]] for i in sorted(out["results"])},
+            "forgetting": {str(i): [float(a) for a in out["results"][i]["seq_forgetting"][i]] for i in sorted(out["results"])},
+            "phase1_val_accuracy": [float(a) for _, _, a in out["manager"].grid_trace],
+            "phase2_val_accuracy": [float(a) for _, a, _ in out["frameworks"][-1].trace],
+            "trainings_in_phase2": len(out["frameworks"][-1].trace), "omega_sum": osum}
+
+
+def pair_cpu_leg(root, threads):
+    """One CPU leg of the pair (runs in its own process, `bench.py --pair-cpu-leg ROOT --pair-threads T`): the build's driver
+    with oracle/sweep_ref.py's torch-CPU EWC on `threads` host threads, from the first-task model found under ROOT."""
+    import contextlib
+    import io
+    from clsurvey_amd.framework import driver
+    from oracle import sweep_ref
+    torch.set_num_threads(threads)
+    meth = sweep_ref.OracleEWC("small_VGG9")
+    with contextlib.redirect_stdout(io.StringIO()):
+        t0 = time.perf_counter()
+        out = driver.main(_pair_args("cpu") + _pair_fixed() + ["--results_root", root], method=meth)
+        dt = time.perf_counter() - t0
+    res = _pair_summary(out, dt, meth.image_passes)
+    res["threads"] = torch.get_num_threads()
+    res["rates_images_per_s"] = {"forward_backward_update": meth.image_passes["train"] / max(meth.seconds["train"], 1e-9),
+                                 "forward_only": meth.image_passes["eval"] / max(meth.seconds["eval"], 1e-9)}
+    return res
+
+
+def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epochs=70):
     """BASELINE.json's second metric ('full-sweep wall-clock'), two measurements.
 
     `gpu_s`: what framework/main.py runs for `small_VGG9_cl_128_128 --method_name EWC --test` with the reference's defaults
-    (5-value LR grid, 70-epoch cap with the count-based LR drop / early stop, batch 200, drop margin 0.2, decay 0.5, up to
-    10 attempts per task) on a `tasks`-task sequence of Tiny-ImageNet's shape (20 classes, 8000 / 2000 / 1000 images of
-    3x64x64 per task; learnable class prototypes + noise, there is no dataset on the box), through the build's driver on
-    this GPU: SI first-task model (main.py:226-241), then per task phase-1 LR grid, Fisher pass, stability decay, and at the
-    end every model evaluated on every task (eval.py:146-247).  Measured end to end, task files already written.
+    (5-value LR grid, 70-epoch cap with the count-based LR drop / early stop, batch 200, lambda = 400, drop margin 0.2, decay
+    0.5, up to 10 attempts per task) on a `tasks`-task sequence of Tiny-ImageNet's shape (20 classes, 8000 / 2000 / 1000
+    images of 3x64x64 per task; SWEEP_DATA above, there is no dataset on the box), through the build's driver on this GPU: SI
+    first-task model (main.py:226-241), then per task phase-1 LR grid, Fisher pass, stability decay, and at the end every
+    model evaluated on every task (eval.py:146-247).  Measured end to end, task files already written.
 
-    `pair`: the SAME bounded piece of that sweep run on both sides with the decisions fixed — one task of
-    `pair_sizes` images from the first-task model the GPU trained (outside both timed regions), ONE learning rate, a
-    `pair_epochs`-epoch cap, exactly one stability-decay attempt, evaluation of both models: build's driver + HIP path on
-    the GPU, the same driver + the CPU oracle's EWC (oracle/sweep_ref.py) on the host cores.  Same task files, same start
-    model, same seeds; accuracies of both sides are reported next to each other.
+    `pair`: ONE bounded task of such a sweep on both sides — task 2 of a PAIR["sizes"] sequence from the first-task model the
+    GPU trained (outside every timed region), one learning rate, a PAIR["epochs"]-epoch cap, Fisher pass, one stability-decay
+    attempt at the reference's lambda, evaluation of both models: the build's driver + HIP path on the GPU; the same driver +
+    the CPU oracle's EWC (oracle/sweep_ref.py) on the host cores, TWICE — at the thread count that won cpu_baseline's probe and at
+    half / double of it, in two processes that run while the GPU does its sweep.  Same task files, start model, batches, head
+    initialisation.  `cpu_spread_points` = the largest accuracy difference between the two CPU legs (two summation orders of
+    the same fp32 arithmetic); `max_accuracy_gap_points` = the largest between the GPU leg and the first CPU leg.
 
-    `cpu_s_extrapolated`: the CPU leg of the pair timed its forward+backward+update loops and its forward-only loops
-    separately; the GPU sweep's counted image passes of each kind are priced at those two measured host rates.  It is an
-    extrapolation and says so; `pair.cpu_s / pair.gpu_s` is the measured like-for-like ratio."""
+    `cpu_s_extrapolated`: the GPU sweep's counted image passes priced at the two host rates (forward+backward+update, forward
+    only) the first CPU leg measured.  An extrapolation, and says so; `pair.cpu_s / pair.gpu_s` is measured like for like."""
     import contextlib
     import io
     import shutil
+    import subprocess
     import tempfile
     from clsurvey_amd.framework import driver
     from clsurvey_amd.framework.tasks import SyntheticTaskSequence
     from clsurvey_amd.methods import method as M
     root = tempfile.mkdtemp(prefix="clhip_sweep_")
     model = "small_VGG9_cl_128_128"
+    dev = "cuda:%d" % dev_index
     res = {"what": "%d-task EWC sweep, %s, %d/%d/%d images of 3x64x64 per task, 20 classes, the reference's defaults "
-                   "(LR grid {1e-2,5e-3,1e-3,5e-4,1e-4}, %d-epoch cap, batch 200, drop margin 0.2, --test); base-model file with a "
-                   "Kaiming-normal classifier (see _base_model_file)"
-                   % ((tasks, model) + tuple(sizes) + (epochs,))}
+                   "(LR grid {1e-2,5e-3,1e-3,5e-4,1e-4}, %d-epoch cap, batch 200, lambda 400, drop margin 0.2, --test); torchvision "
+                   "initialisation; synthetic 'blobs' tasks with overlapping classes (best possible accuracy 71.5 %%)"
+                   % ((tasks, model) + tuple(sizes) + (epochs,)),
+           "data": dict(SWEEP_DATA)}
     quiet = io.StringIO()
+    legs = []
     try:
-        # ---- the full sweep on the GPU (tasks == 0: only the pair below, for checks of the pair itself)
+        pair = None
+        if cpu_threads:
+            # ---- the pair: first-task model on the GPU (untimed), CPU legs started in the background, GPU leg timed
+            proot = os.path.join(root, "pair_gpu")
+            with contextlib.redirect_stdout(quiet):
+                driver.main(_pair_args(dev) + ["--results_root", proot, "--method_name", "SI", "--runmode", "first_task_basemodel_dump"],
+                            method=M.parse("SI"))
+            other = cpu_threads // 2 if cpu_threads >= 32 else min(2 * cpu_threads, os.cpu_count() or cpu_threads)
+            for t in [cpu_threads] + ([other] if other != cpu_threads else []):
+                croot = os.path.join(root, "pair_cpu_t%d" % t)
+                for sub in ("data", "models", os.path.join("train", "synthetic_tiny_imagenet", "SI")):
+                    shutil.copytree(os.path.join(proot, sub), os.path.join(croot, sub))
+                env = dict(os.environ, OMP_NUM_THREADS=str(t), MKL_NUM_THREADS=str(t))
+                legs.append((t, subprocess.Popen([sys.executable, os.path.abspath(__file__), "--pair-cpu-leg", croot, "--pair-threads", str(t)],
+                                                 stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True)))
+            with contextlib.redirect_stdout(quiet), _PassCounter(PAIR["sizes"][0]) as pcounts:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                gout = driver.main(_pair_args(dev) + _pair_fixed() + ["--results_root", proot], method=M.parse("EWC"))
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            pair = {"what": "task 2 of a 2-task sequence (%d/%d/%d images of 3x64x64, 20 classes), from the same first-task model: LR "
+                            "grid {%s}, %d-epoch cap, batch %d, Fisher pass, one stability-decay attempt at lambda = %g, both models "
+                            "evaluated; same task files, start model, batches and head initialisation on every leg"
+                            % (tuple(PAIR["sizes"]) + (PAIR["lr"], PAIR["epochs"], PAIR["batch"], PAIR["lam"])),
+                    "gpu": _pair_summary(gout, dt, pcounts)}
+        # ---- the full sweep on the GPU (tasks == 0: only the pair, for checks of the pair itself)
         counts = None
         groot = os.path.join(root, "gpu")
         if tasks > 0:
-            _base_model_file(groot)
             ds = SyntheticTaskSequence(os.path.join(groot, "data"), task_count=tasks, classes_per_task=20, sizes=tuple(sizes), hw=64,
-                                       name="synthetic_tiny_imagenet")
+                                       name="synthetic_tiny_imagenet", noise=SWEEP_DATA["noise"], kind=SWEEP_DATA["kind"])
             t0 = time.perf_counter()
             for i in range(1, tasks + 1):
                 ds.get_task_dataset_path(str(i))
             res["task_files_s (not counted)"] = time.perf_counter() - t0
-            common = [model, "--num_epochs", str(epochs), "--results_root", groot, "--device", "cuda:%d" % dev_index]
+            common = [model, "--num_epochs", str(epochs), "--results_root", groot, "--device", dev]
             with contextlib.redirect_stdout(quiet), _PassCounter(sizes[0]) as counts:
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
@@ -569,76 +638,51 @@ def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epoch
             r = out["results"]
             res["gpu_image_passes"] = dict(counts)
             res["gpu_phase2_trainings_per_task"] = [len(hf.trace) for hf in out["frameworks"] if hf is not None]
+            res["gpu_accepted_lambda_per_task"] = [float(hf.trace[-1][0]["lambda"]) for hf in out["frameworks"] if hf is not None and hf.trace]
             res["gpu_final_accuracies"] = [r[i]["seq_res"][i][-1] for i in sorted(r)]          # task i under the LAST model
             res["gpu_first_accuracies"] = [r[i]["seq_res"][i][0] for i in sorted(r)]           # task i right after training it
             res["gpu_avg_accuracy"] = float(np.mean(res["gpu_final_accuracies"]))
             res["gpu_avg_forgetting"] = float(np.mean([r[i]["seq_forgetting"][i][-1] for i in sorted(r) if r[i]["seq_forgetting"][i]] or [0.0]))
             res["chance_accuracy"] = 100.0 / 20
-        # ---- the like-for-like pair
-        if cpu_threads:
-            from oracle import sweep_ref
-            proot, croot = os.path.join(root, "pair_gpu"), os.path.join(root, "pair_cpu")
-            spec = "2,20,%d,%d,%d,64,%g" % (tuple(pair_sizes) + (pair_noise,))
-            pcommon = [model, "--num_epochs", str(pair_epochs), "--batch_size", str(pair_batch), "--saving_freq", "1000", "--synthetic", spec,
-                       "--device", "cuda:%d" % dev_index]
-            _base_model_file(proot)
-            with contextlib.redirect_stdout(quiet):
-                # first-task model of the pair's own sequence: trained on the GPU with the pair's own arguments (same epoch cap,
-                # batch size and LR, so the driver finds it under the name both legs look for), outside both timed regions.
-                # (A first-task model trained to the 70-epoch cap is saturated on this easy data: three epochs at 1e-2 do not
-                # move a new head off chance on EITHER side, measured — and a comparison at chance says nothing.)
-                driver.main(pcommon + ["--lr_grid", pair_lr, "--results_root", proot, "--method_name", "SI", "--runmode",
-                                       "first_task_basemodel_dump"], method=M.parse("SI"))
-            fixed = ["--lr_grid", pair_lr, "--max_attempts_per_task", "1", "--hyperparams", "%g" % pair_lambda, "--method_name", "EWC", "--test"]
-            pair = {"what": "task 2 of a 2-task sequence (%d/%d/%d images), from the same first-task model: LR grid {%s}, %d-epoch "
-                            "cap, batch %d and pixel noise %g instead of 1.0 (so that the few epochs the CPU leg can afford leave "
-                            "chance; the first-task model is trained with the same 3-epoch cap), Fisher pass, ONE stability-decay attempt at "
-                            "lambda = %g (where the sweep's halvings of 400 end up; at 400 three epochs do not move task 2 off chance "
-                            "on either side and the comparison says nothing), both models evaluated.  Same task files, start model, batches and "
-                            "head initialisation on both sides (the oracle follows torch DataLoader's RNG protocol) and the same importance "
-                            "weights (omega_sum); phase 1 agrees, the penalised phase 2 amplifies rounding differences (the CPU leg alone "
-                            "moves by 3-10 points between 16 and 32 threads), so its accuracies are comparable, not equal" % (tuple(pair_sizes) + (pair_lr, pair_epochs, pair_batch, pair_noise, pair_lambda))}
-            for sub in ("data", "models", os.path.join("train", "synthetic_tiny_imagenet", "SI")):
-                shutil.copytree(os.path.join(proot, sub), os.path.join(croot, sub))
-            with contextlib.redirect_stdout(quiet), _PassCounter(pair_sizes[0]) as pcounts:
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                gout = driver.main(pcommon + fixed + ["--results_root", proot], method=M.parse("EWC"))
-                torch.cuda.synchronize()
-                pair["gpu_s"] = time.perf_counter() - t0
-            pair["gpu_image_passes"] = dict(pcounts)
-            pair["gpu_accuracies"] = {i: gout["results"][i]["seq_res"][i] for i in sorted(gout["results"])}
-            torch.set_num_threads(cpu_threads)      # the thread count that won cpu_baseline's probe on this host
-            meth = sweep_ref.OracleEWC("small_VGG9")
-            with contextlib.redirect_stdout(quiet):
-                t0 = time.perf_counter()
-                cout = driver.main(pcommon + fixed + ["--results_root", croot], method=meth)
-                pair["cpu_s"] = time.perf_counter() - t0
-            pair["cpu_image_passes"] = dict(meth.image_passes)
-            pair["cpu_accuracies"] = {i: cout["results"][i]["seq_res"][i] for i in sorted(cout["results"])}
-            pair["cpu_threads"] = torch.get_num_threads()
-            pair["phase1_val_accuracy"] = {"gpu": [a for _, _, a in gout["manager"].grid_trace], "cpu": [a for _, _, a in cout["manager"].grid_trace]}
-            pair["phase2_val_accuracy"] = {"gpu": [a for _, a, _ in gout["frameworks"][-1].trace], "cpu": [a for _, a, _ in cout["frameworks"][-1].trace]}
-            # the importance weights both sides trained task 2 against (sum over all parameters of the Fisher diagonal of task 1)
-            gm = torch.load(gout["model_paths"][-1], map_location="cpu", weights_only=False)
-            cm = torch.load(cout["model_paths"][-1], map_location="cpu", weights_only=False)
-            pair["omega_sum"] = {"gpu": float(sum(float(v["omega"].double().sum()) for k, v in gm.reg_params.items() if isinstance(v, dict))),
-                                 "cpu": float(sum(float(o.double().sum()) for o in cm.oracle_omega))}
-            pair["trainings_in_phase2"] = {"gpu": len(gout["frameworks"][-1].trace), "cpu": len(cout["frameworks"][-1].trace)}
-            pair["max_accuracy_gap_points"] = max(abs(a - b) for i in pair["gpu_accuracies"]
-                                                  for a, b in zip(pair["gpu_accuracies"][i], pair["cpu_accuracies"][i]))
+            res["best_possible_accuracy"] = 100.0 * (0.7 + 0.3 / 20)
+        # ---- collect the CPU legs
+        if pair is not None:
+            cpu = []
+            for t, proc in legs:
+                try:
+                    so, se = proc.communicate(timeout=900)
+                except subprocess.TimeoutExpired:
+                    proc.kill()
+                    so, se = proc.communicate()
+                line = [ln for ln in so.splitlines() if ln.startswith("{")]
+                if proc.returncode != 0 or not line:
+                    raise RuntimeError("pair CPU leg (%d threads) failed:\n%s" % (t, se[-2000:]))
+                cpu.append(json.loads(line[-1]))
+            legs = []
+            pair["cpu"] = cpu[0]
+            if len(cpu) > 1:
+                pair["cpu_other_threads"] = cpu[1]
+
+            def gap(a, b):
+                return max(abs(x - y) for i in a["accuracies"] for x, y in zip(a["accuracies"][i], b["accuracies"][i]))
+            pair["max_accuracy_gap_points"] = gap(pair["gpu"], cpu[0])
+            pair["cpu_spread_points"] = gap(cpu[0], cpu[1]) if len(cpu) > 1 else None
+            pair["agree"] = pair["max_accuracy_gap_points"] <= max(3.0, pair["cpu_spread_points"] or 0.0)
+            pair["gpu_s"], pair["cpu_s"] = pair["gpu"]["seconds"], cpu[0]["seconds"]
+            pair["cpu_concurrency"] = "the two CPU legs (%s threads) ran side by side while the GPU ran its sweep (%d logical cores)" % (
+                " / ".join(str(c["threads"]) for c in cpu), os.cpu_count() or 0)
             pair["gpu_over_cpu_wall_clock"] = pair["cpu_s"] / pair["gpu_s"]
             res["pair"] = pair
-            tr_rate = meth.image_passes["train"] / max(meth.seconds["train"], 1e-9)
-            ev_rate = meth.image_passes["eval"] / max(meth.seconds["eval"], 1e-9)
-            res["cpu_rates_images_per_s"] = {"forward_backward_update": tr_rate, "forward_only": ev_rate}
-            if counts is None:
-                return res
-            res["cpu_s_extrapolated"] = counts["train"] / tr_rate + counts["eval"] / ev_rate
-            res["cpu_s_extrapolated_how"] = ("GPU sweep's image passes (%d forward+backward, %d forward-only) at the two host rates "
-                                             "the pair's CPU leg measured on this box; not run" % (counts["train"], counts["eval"]))
-            res["gpu_over_cpu_wall_clock"] = res["cpu_s_extrapolated"] / res["gpu_s"]
+            res["cpu_rates_images_per_s"] = cpu[0]["rates_images_per_s"]
+            if counts is not None:
+                rt = cpu[0]["rates_images_per_s"]
+                res["cpu_s_extrapolated"] = counts["train"] / rt["forward_backward_update"] + counts["eval"] / rt["forward_only"]
+                res["cpu_s_extrapolated_how"] = ("GPU sweep's image passes (%d forward+backward, %d forward-only) at the two host rates "
+                                                 "the pair's first CPU leg measured on this box; not run" % (counts["train"], counts["eval"]))
+                res["gpu_over_cpu_wall_clock"] = res["cpu_s_extrapolated"] / res["gpu_s"]
     finally:
+        for _, proc in legs:
+            proc.kill()
         shutil.rmtree(root, ignore_errors=True)
     return res
 
@@ -743,6 +787,9 @@ def cpu_baseline(batch, steps):
 
 def main():
     args = parse()
+    if args.pair_cpu_leg:                      # a CPU leg of the sweep pair, in its own process (no GPU work)
+        print(json.dumps(pair_cpu_leg(args.pair_cpu_leg, args.pair_threads)), flush=True)
+        return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -770,6 +817,10 @@ def main():
             dist.broadcast(h, src=src)
             t.copy_(h)
 
+    if args.sweep_only:
+        print(json.dumps(full_sweep(local_rank, cpu_threads=0 if args.no_cpu_baseline else 16, tasks=args.sweep_tasks,
+                                    epochs=args.sweep_epochs)), flush=True)
+        return
     from clsurvey_amd import models, net, ops
     torch.manual_seed(7 + rank)
     N = args.batch
@@ -917,7 +968,9 @@ def main():
             out["sweep"] = full_sweep(local_rank, cpu_threads=0 if args.no_cpu_baseline else out["cpu_baseline"]["cores"],
                                       tasks=args.sweep_tasks, epochs=args.sweep_epochs)
             out["sweep_s"] = {"gpu": out["sweep"].get("gpu_s"), "cpu_extrapolated": out["sweep"].get("cpu_s_extrapolated"),
-                              "pair_gpu": out["sweep"].get("pair", {}).get("gpu_s"), "pair_cpu": out["sweep"].get("pair", {}).get("cpu_s")}
+                              "pair_gpu": out["sweep"].get("pair", {}).get("gpu_s"), "pair_cpu": out["sweep"].get("pair", {}).get("cpu_s"),
+                              "pair_max_accuracy_gap_points": out["sweep"].get("pair", {}).get("max_accuracy_gap_points"),
+                              "pair_cpu_spread_points": out["sweep"].get("pair", {}).get("cpu_spread_points")}
         print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()          # rank 0 was still timing kernels: tear the communicator down together

@@ -35,6 +35,10 @@
 
 namespace {
 
+#ifndef CLHIP_W16G_PF
+#define CLHIP_W16G_PF 1      // staging pipeline of wino_conv16g_kernel, see there
+#endif
+
 constexpr int WKT = 64;      // out channels per block
 constexpr int WCK = 8;       // in channels per chunk
 constexpr int WFP = 20;      // floats per (channel, out-channel) in the U tile: 16 frequencies + 4 pad — an 80-byte stride makes
@@ -931,9 +935,11 @@ __global__ __launch_bounds__(256, 2) void wino_conv16g_kernel(
 
     constexpr int W_IT = WQ_FLOATS / 4 / 256;                         // 5
     constexpr int X_IT = (X_FLOATS + 255) / 256;
-    float4 wv[W_IT];
-    float xr[X_IT];
-    unsigned xi[UNPOOL ? X_IT : 1];
+    struct Stage {                                                    // one chunk on its way from global memory to LDS
+        float4 wv[W_IT];
+        float xr[X_IT];
+        unsigned xi[UNPOOL ? X_IT : 1];
+    };
     int xoff[X_IT], xcode[UNPOOL ? X_IT : 1];
 #pragma unroll
     for (int j = 0; j < X_IT; ++j) {
@@ -955,31 +961,31 @@ __global__ __launch_bounds__(256, 2) void wino_conv16g_kernel(
             }
         }
     }
-    auto load_chunk = [&](int chunk) {
+    auto load_chunk = [&](int chunk, Stage& st) {
         const int cw = chunk < n_chunks ? chunk : n_chunks - 1;
 #pragma unroll
-        for (int u = 0; u < W_IT; ++u) wv[u] = clhip_buf_load4(rs_u, (tid + 256 * u) * 16, cw * WQ_FLOATS * 4);
+        for (int u = 0; u < W_IT; ++u) st.wv[u] = clhip_buf_load4(rs_u, (tid + 256 * u) * 16, cw * WQ_FLOATS * 4);
         const int xb = cw * CQ * plane_in;
 #pragma unroll
         for (int j = 0; j < X_IT; ++j) {
             if constexpr (UNPOOL) {
-                xr[j] = clhip_buf_load(rs_x, xoff[j] != CLHIP_OOB ? xoff[j] * 4 : CLHIP_OOB, xb * 4);
-                xi[j] = clhip_buf_load_u8(rs_i, xoff[j], xb);
+                st.xr[j] = clhip_buf_load(rs_x, xoff[j] != CLHIP_OOB ? xoff[j] * 4 : CLHIP_OOB, xb * 4);
+                st.xi[j] = clhip_buf_load_u8(rs_i, xoff[j], xb);
             } else {
-                xr[j] = clhip_buf_load(rs_x, xoff[j], xb * 4);
+                st.xr[j] = clhip_buf_load(rs_x, xoff[j], xb * 4);
             }
         }
     };
-    auto store_chunk = [&](int bo) {
+    auto store_chunk = [&](int bo, const Stage& st) {
 #pragma unroll
         for (int u = 0; u < W_IT; ++u)
-            *reinterpret_cast<floatx4*>(lds + bo + 4 * (tid + 256 * u)) = floatx4{wv[u].x, wv[u].y, wv[u].z, wv[u].w};
+            *reinterpret_cast<floatx4*>(lds + bo + 4 * (tid + 256 * u)) = floatx4{st.wv[u].x, st.wv[u].y, st.wv[u].z, st.wv[u].w};
         float* xs = lds + bo + WQ_FLOATS;
 #pragma unroll
         for (int j = 0; j < X_IT; ++j)
             if (256 * (j + 1) <= X_FLOATS || tid + 256 * j < X_FLOATS) {
-                if constexpr (UNPOOL) xs[tid + 256 * j] = ((int)xi[j] == xcode[j]) ? xr[j] : 0.f;
-                else xs[tid + 256 * j] = xr[j];
+                if constexpr (UNPOOL) xs[tid + 256 * j] = ((int)st.xi[j] == xcode[j]) ? st.xr[j] : 0.f;
+                else xs[tid + 256 * j] = st.xr[j];
             }
     };
 
@@ -995,15 +1001,8 @@ __global__ __launch_bounds__(256, 2) void wino_conv16g_kernel(
         for (int f = 0; f < 16; ++f) acc[k2][f] = floatx4v{0.f, 0.f, 0.f, 0.f};
 
     typedef float f2 __attribute__((ext_vector_type(2)));
-    load_chunk(0);
-    store_chunk(0);
-    load_chunk(1);
-    __syncthreads();
-    for (int chunk = 0; chunk < n_chunks; ++chunk) {
-        const int bo = (chunk & 1) * BUF;
-        // chunk + 1 (in registers since the previous iteration) -> the other buffer (its readers finished before the last barrier)
-        store_chunk(BUF - bo);
-        load_chunk(chunk + 2);
+    // one chunk from LDS buffer `bo`: operands, input transform, 32 MFMAs
+    auto compute = [&](int bo) {
         const float* ab = lds + bo + a_off;
         const float* db = lds + bo + d_off;
         f2 dlo[4], dhi[4];
@@ -1038,8 +1037,52 @@ __global__ __launch_bounds__(256, 2) void wino_conv16g_kernel(
             acc[0][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[f >> 2][f & 3], vv[f], acc[0][f], 0, 0, 0);
             acc[1][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[f >> 2][f & 3], vv[f], acc[1][f], 0, 0, 0);
         }
+    };
+    // Staging pipeline.  The loads of a later chunk must be ISSUED before this chunk's MFMAs and WAITED FOR after them.
+    // Left to itself the scheduler (it minimises register pressure, 180 of the 256 registers two waves per SIMD allow) sinks
+    // the loads below the MFMAs — issued right before the barrier, waited for right after it: every chunk then pays the whole
+    // L2 / HBM latency with nothing of its own wave in flight (the loop ran at 0.42-0.55 of the matrix pipe on every layer
+    // width, round 3).  __builtin_amdgcn_sched_barrier(0) behind the issue pins the order.
+    //   CLHIP_W16G_PF = 0  the round-3 schedule (A/B reference)
+    //                   1  one register set: chunk + 2 is issued at the top of chunk's iteration, stored at the top of the next
+    //                   2  two register sets: chunk + 3 issued at the top of chunk's iteration (two iterations in flight)
+#if CLHIP_W16G_PF == 2
+    Stage sa, sb;
+    load_chunk(0, sa);
+    store_chunk(0, sa);
+    load_chunk(1, sa);
+    load_chunk(2, sb);
+    __syncthreads();
+    for (int chunk = 0; chunk < n_chunks; chunk += 2) {               // n_chunks is even (Cin is a multiple of 8)
+        store_chunk(BUF, sa);                                          // chunk + 1 -> buffer 1 (read last in iteration chunk - 1)
+        load_chunk(chunk + 3, sa);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(0);
+        __syncthreads();
+        store_chunk(0, sb);                                            // chunk + 2 -> buffer 0
+        load_chunk(chunk + 4, sb);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(BUF);
         __syncthreads();
     }
+#else
+    Stage sa;
+    load_chunk(0, sa);
+    store_chunk(0, sa);
+    load_chunk(1, sa);
+    __syncthreads();
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        const int bo = (chunk & 1) * BUF;
+        // chunk + 1 (in registers since the previous iteration) -> the other buffer (its readers finished before the last barrier)
+        store_chunk(BUF - bo, sa);
+        load_chunk(chunk + 2, sa);
+#if CLHIP_W16G_PF == 1
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        compute(bo);
+        __syncthreads();
+    }
+#endif
 
     // ---- epilogue: register r of acc[k2][f] = (out channel ko0 + 32 wk + 16 k2 + 4 q + r, this lane's tile)
     const int tv = v0 + t_ent, n = tv / tiles_h;

@@ -117,14 +117,47 @@ class DeviceLoader:
                 yield self.x.index_select(0, idx), self.y.index_select(0, idx)
 
 
-def synthetic_task(n_train, n_val, n_test, n_classes, hw=64, seed=7, noise=1.0, device="cpu"):
-    """Learnable synthetic task (class-conditional Gaussian prototypes + noise), SURVEY §8d."""
+def synthetic_task(n_train, n_val, n_test, n_classes, hw=64, seed=7, noise=1.0, device="cpu", kind="protos", blobs=None):
+    """Learnable synthetic task, SURVEY §8d.
+
+    kind="protos" (the generator every committed fixture was made with): one full-resolution Gaussian prototype per class
+    (std 0.5) + white pixel noise of std `noise`.  Linearly separable at any noise the tests use: a trained model is ~99 %
+    sure of every training image, so its Fisher diagonal is ~0 and a regulariser has nothing to hold on to.
+
+    kind="blobs" (bench.py's sweeps): image-like and NOT separable — a class prototype is a coarse g x g colour pattern
+    (std `amp`) shown at full size, disturbed by coarse noise (std `noise_lr`, per cell) and white pixel noise (std `noise`);
+    with probability 1 - q an image shows the prototype of a uniformly drawn class instead of its own (overlapping classes),
+    so the best possible top-1 accuracy is q + (1 - q) / n_classes whatever the model: accuracies saturate at a level the DATA
+    sets (two trainings that differ by rounding end at the same accuracy), the predictive distribution of a trained model
+    keeps its entropy and the Fisher diagonal / MAS importance stay well away from 0.  `blobs` = dict(g, amp, noise_lr, q)."""
     g = torch.Generator()
     g.manual_seed(seed)
-    protos = torch.randn((n_classes, 3, hw, hw), generator=g) * 0.5
+    names = [str(c) for c in range(n_classes)]
     out = {}
+    if kind == "protos":
+        protos = torch.randn((n_classes, 3, hw, hw), generator=g) * 0.5
+        for name, n in (("train", n_train), ("val", n_val), ("test", n_test)):
+            y = torch.randint(0, n_classes, (n,), generator=g)
+            x = protos[y] + noise * torch.randn((n, 3, hw, hw), generator=g)
+            out[name] = TensorTaskDataset(x.to(device), y.to(device), names)
+        return out
+    if kind != "blobs":
+        raise ValueError("synthetic_task: kind is 'protos' or 'blobs'")
+    b = dict(BLOBS_DEFAULT)
+    b.update(blobs or {})
+    cells = int(b["g"])
+    if hw % cells:
+        raise ValueError("synthetic_task: hw must be a multiple of the coarse grid g")
+    protos = torch.randn((n_classes, 3, cells, cells), generator=g) * float(b["amp"])
     for name, n in (("train", n_train), ("val", n_val), ("test", n_test)):
         y = torch.randint(0, n_classes, (n,), generator=g)
-        x = protos[y] + noise * torch.randn((n, 3, hw, hw), generator=g)
-        out[name] = TensorTaskDataset(x.to(device), y.to(device), [str(c) for c in range(n_classes)])
+        other = torch.randint(0, n_classes, (n,), generator=g)
+        shown = torch.where(torch.rand((n,), generator=g) < float(b["q"]), y, other)
+        coarse = protos[shown] + float(b["noise_lr"]) * torch.randn((n, 3, cells, cells), generator=g)
+        x = coarse.repeat_interleave(hw // cells, 2).repeat_interleave(hw // cells, 3)
+        x = x + noise * torch.randn((n, 3, hw, hw), generator=g)
+        out[name] = TensorTaskDataset(x.to(device), y.to(device), names)
     return out
+
+
+BLOBS_DEFAULT = {"g": 8, "amp": 4.0, "noise_lr": 1.2, "q": 0.7}

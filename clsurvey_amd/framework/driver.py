@@ -74,8 +74,9 @@ def build_parser():
     p.add_argument("--no_speculation", action="store_true",
                    help="with --shard: phase 2 runs sequentially on rank 0 only; its model and state are broadcast")
     p.add_argument("--synthetic", type=str, default=None,
-                   help="command-line runs: tasks,classes,train,val,test,hw[,noise] of a synthetic task sequence "
-                        "(clsurvey_amd.framework.tasks), e.g. 10,20,8000,2000,1000,64 = Tiny-ImageNet's shape")
+                   help="command-line runs: tasks,classes,train,val,test,hw[,noise[,kind]] of a synthetic task sequence "
+                        "(clsurvey_amd.framework.tasks; kind = protos | blobs, see data.synthetic_task), "
+                        "e.g. 10,20,8000,2000,1000,64 = Tiny-ImageNet's shape")
     return p
 
 
@@ -277,14 +278,19 @@ class HyperparameterFramework(object):
                                                  "TASK_TRAINING")
         if hasattr(manager.method, "train_init"):
             manager.method.train_init(args, manager)
-        if not self.load_chkpt(manager):
-            self.attempts = 0
-            self.hyperparams_backup = copy.deepcopy(self.hyperparams)
-        if os.path.exists(manager.get_success_token_path(manager.heuristic_exp_dir)):
+        sharded = getattr(manager, "speculative", False)
+        collective = sharded or getattr(manager, "sequential_on_rank0", False)
+        if collective:
+            done = self._resume_decision_from_rank0(manager)
+        else:
+            if not self.load_chkpt(manager):
+                self.attempts = 0
+                self.hyperparams_backup = copy.deepcopy(self.hyperparams)
+            done = os.path.exists(manager.get_success_token_path(manager.heuristic_exp_dir))
+        if done:
             manager.best_model_path = os.path.join(manager.heuristic_exp_dir, "best_model.pth.tar")
             return
         args.presteps_elapsed_time = 0
-        sharded = getattr(manager, "speculative", False)
         if getattr(manager, "sequential_on_rank0", False):
             self._sequential_on_rank0(args, manager, finetune_acc)
             return
@@ -297,6 +303,38 @@ class HyperparameterFramework(object):
             self._speculative_decay(args, manager, finetune_acc)
             return
         self._sequential_decay(args, manager, finetune_acc)
+
+    def _resume_decision_from_rank0(self, manager):
+        """Sharded runs: every rank keeps its own results tree, and a run killed between rank 0's success token and the
+        broadcast of its task directory (or half-way through that broadcast) leaves trees that DISAGREE about whether this
+        task is finished — on resume one rank would return early while the others enter the next collective.  So the
+        checkpoint that is restored and the 'already done' decision are rank 0's, for every rank; when the task is done
+        rank 0 sends its directory again (the other trees may hold a partial copy; tokens travel last, shard.broadcast_files)."""
+        from . import shard
+        rank, _ = shard.rank_world()
+        mine = None
+        if rank == 0:
+            loaded = self.load_chkpt(manager)
+            mine = {"loaded": loaded, "state": copy.deepcopy(self._get_state()) if loaded else None,
+                    "done": os.path.exists(manager.get_success_token_path(manager.heuristic_exp_dir))}
+        dec = shard.broadcast_object(mine, 0)
+        if dec["loaded"]:
+            if rank != 0:
+                self._restore_state(dec["state"])
+        else:
+            self.attempts = 0
+            self.hyperparams_backup = copy.deepcopy(self.hyperparams)
+        if dec["done"]:
+            if rank != 0:
+                shutil.rmtree(manager.heuristic_exp_dir, ignore_errors=True)
+            shard.broadcast_files(manager.heuristic_exp_dir, 0)
+            manager.method.hyperparams = self.hyperparams
+        elif rank != 0:
+            # a stale token of this rank's own (rank 0 says the task is NOT finished) must not survive into the retrain
+            token = manager.get_success_token_path(manager.heuristic_exp_dir)
+            if os.path.exists(token):
+                os.remove(token)
+        return dec["done"]
 
     def _sequential_decay(self, args, manager, finetune_acc):
         """framework_train.py:100-136."""
@@ -589,8 +627,10 @@ def main(argv=None, method=None, dataset=None, train_node_factory=None):
         from .tasks import SyntheticTaskSequence
         fields = args.synthetic.split(",")
         n_tasks, n_cls, n_tr, n_va, n_te, hw = [int(v) for v in fields[:6]]
+        kind = fields[7] if len(fields) > 7 else "protos"
         dataset = SyntheticTaskSequence(os.path.join(args.results_root, "data"), task_count=n_tasks, classes_per_task=n_cls,
-                                        sizes=(n_tr, n_va, n_te), hw=hw, noise=float(fields[6]) if len(fields) > 6 else 1.0)
+                                        sizes=(n_tr, n_va, n_te), hw=hw, noise=float(fields[6]) if len(fields) > 6 else 1.0,
+                                        kind=kind)
     set_random(7)                                                 # utils.init -> set_random()
     if method is None:
         method = methods.parse(args.method_name)

@@ -145,7 +145,8 @@ def broadcast_files(directory, src, patterns=("*.pth.tar", "*.pth", "*.FLAG")):
         names = sorted(n for n in os.listdir(directory) if os.path.isfile(os.path.join(directory, n))
                        and any(fnmatch.fnmatch(n, pat) for pat in patterns))
     names = broadcast_bytes("\n".join(names).encode(), src).decode().split("\n")
-    names = [n for n in names if n]
+    # tokens ("*.FLAG" marks a directory as finished) travel LAST: a copy cut short by a kill is never marked done
+    names = sorted((n for n in names if n), key=lambda n: (n.endswith(".FLAG"), n))
     if rank != src:
         os.makedirs(directory, exist_ok=True)
     for name in names:

@@ -17,7 +17,7 @@ from ..data import synthetic_task
 
 class SyntheticTaskSequence(object):
     def __init__(self, root, task_count=10, classes_per_task=20, sizes=(8000, 2000, 1000), hw=64, seed=7, noise=1.0,
-                 name="synthetic_tiny_imagenet"):
+                 name="synthetic_tiny_imagenet", kind="protos", blobs=None):
         self.name = name
         self.argname = name
         self.test_results_dir = name
@@ -31,6 +31,8 @@ class SyntheticTaskSequence(object):
         self.hw = hw
         self.seed = seed
         self.noise = noise
+        self.kind = kind
+        self.blobs = blobs
         self.n_classes = classes_per_task
 
     def get_taskname(self, task_index):
@@ -41,6 +43,6 @@ class SyntheticTaskSequence(object):
         if not os.path.exists(path):
             os.makedirs(os.path.dirname(path), exist_ok=True)
             d = synthetic_task(self.sizes[0], self.sizes[1], self.sizes[2], self.n_classes, self.hw,
-                               seed=self.seed * 1000 + int(task_name), noise=self.noise)
+                               seed=self.seed * 1000 + int(task_name), noise=self.noise, kind=self.kind, blobs=self.blobs)
             torch.save(d, path)
         return path

@@ -151,6 +151,40 @@ def _worker(rank, world, port, tmp):
     assert dict(hf4.hyperparams) == dict(seq_hf.hyperparams) and hf4.attempts == seq_hf.attempts and hf4.trace == seq_hf.trace
     assert os.path.exists(mg4.get_success_token_path(mg4.heuristic_exp_dir)) and mg4.best_model_path.startswith(os.path.join(tmp, "rank%d" % rank))
 
+    # --- resumed phase 2 whose trees DISAGREE (run killed between rank 0's success token and the broadcast of its directory):
+    #     rank 0 decides for everyone, its files arrive again, no rank trains and no rank is left in a collective alone
+    for mode in ("sequential_on_rank0", "speculative"):
+        meth5 = _DecayMethod()
+        mg5 = driver.Manager(_DS(), meth5, "prev", os.path.join(tmp, "rank%d" % rank, "resume_" + mode), None)
+        mg5.speculative, mg5.sequential_on_rank0 = mode == "speculative", mode == "sequential_on_rank0"
+        hd = os.path.join(mg5.parent_exp_dir, "task_1", "TASK_TRAINING")
+        if rank == 0:           # rank 0 finished the task before the kill ...
+            os.makedirs(hd)
+            torch.save({"a": 1.0, "b": 2.0}, os.path.join(hd, "best_model.pth.tar"))
+            done = driver.HyperparameterFramework(_DecayMethod())
+            done.attempts, done.hyperparams["a"], done.hyperparams["b"] = 3, 1.0, 2.0
+            mg5.save_hyperparams(hd, {"acc_threshold": 0.2, "val_acc": 0.33, "state": done._get_state()})
+            mg5.create_success_token(hd)
+        hf5 = driver.HyperparameterFramework(meth5)          # ... rank 1's tree is empty
+        hf5.stabilityDecay(_args(), mg5, 1e-3, finetune_acc=0.25)
+        assert meth5.calls == [], (mode, rank, meth5.calls)
+        assert hf5.attempts == 3 and dict(hf5.hyperparams) == {"a": 1.0, "b": 2.0}, (mode, rank, hf5.attempts, dict(hf5.hyperparams))
+        assert torch.load(os.path.join(hd, "best_model.pth.tar"), weights_only=False) == {"a": 1.0, "b": 2.0}
+        assert os.path.exists(mg5.get_success_token_path(hd)) and mg5.best_model_path == os.path.join(hd, "best_model.pth.tar")
+    # the other way round: only rank 1 holds a (stale) token — rank 0 says "not done", both train, the stale token is gone first
+    meth6 = _DecayMethod()
+    mg6 = driver.Manager(_DS(), meth6, "prev", os.path.join(tmp, "rank%d" % rank, "resume_stale"), None)
+    mg6.speculative = True
+    hd6 = os.path.join(mg6.parent_exp_dir, "task_1", "TASK_TRAINING")
+    if rank == 1:
+        os.makedirs(hd6)
+        torch.save({"stale": True}, os.path.join(hd6, "best_model.pth.tar"))
+        mg6.create_success_token(hd6)
+    hf6 = driver.HyperparameterFramework(meth6)
+    hf6.stabilityDecay(_args(), mg6, 1e-3, finetune_acc=0.25)
+    assert len(meth6.calls) > 0 and hf6.trace == seq_hf.trace
+    assert torch.load(os.path.join(hd6, "best_model.pth.tar"), weights_only=False) == dict(seq_hf.hyperparams)
+
     # --- a failure on ONE rank ends the stage on EVERY rank (no rank is left waiting in the next collective)
     class _Failing(_GridMethod):
         def grid_train(self, args, manager, lr):

@@ -1,0 +1,160 @@
+"""Trajectory separation: how fast do trainings that differ ONLY by floating-point rounding move apart?
+
+TEST INFRASTRUCTURE (imports oracle/).  Penalised training is a chaotic map of its start point: two fp32 evaluations of the
+same step differ in the last bit, a ReLU or pooling decision flips, and after some hundred steps the parameters differ by far
+more than any per-step tolerance.  Whether the GPU path's end-to-end accuracies may differ from a CPU run's can therefore
+not be judged by comparing the two runs with each other; the yardstick is an fp64 run of the same recipe and the distance
+at which the fp32 CPU oracle (at two thread counts: two summation orders) ends up from it.
+
+One recipe (the reference's EWC task: EWC/main_EWC.py:14-76 + train_EWC.py:23-86,164-197, restated by
+oracle/regularizers_ref.py), fixed batches, fixed start model, fixed importance weights, fixed fresh head — and runners
+that differ only in who does the arithmetic.
+"""
+import numpy as np
+import torch
+
+from oracle import regularizers_ref as R
+from oracle import vgg_ref
+
+CFG = vgg_ref.CFGS["small_VGG9"]
+
+
+def make_problem(hw=32, n_classes=4, sizes=(800, 200, 200), batch=40, steps=240, warm_steps=60, kind="blobs", seed=11):
+    """Everything the runners share.  Task-1 model theta* (warm_steps of plain SGD by the fp32 oracle from deterministic
+    Kaiming weights), its Fisher diagonal (oracle, fp32), a fresh head, the batch index lists of the task-2 training."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from g10_weights import det_weights
+    from clsurvey_amd.data import synthetic_task
+    blobs = {"g": 8, "amp": 2.0, "noise_lr": 0.8, "q": 0.8}
+    t1 = synthetic_task(sizes[0], sizes[1], sizes[2], n_classes, hw, seed=seed * 1000 + 1, noise=0.5, kind=kind, blobs=blobs)
+    t2 = synthetic_task(sizes[0], sizes[1], sizes[2], n_classes, hw, seed=seed * 1000 + 2, noise=0.5, kind=kind, blobs=blobs)
+    rs = np.random.RandomState(seed)
+    theta = [torch.from_numpy(w.copy()) for w in det_weights(ncls=n_classes, hw=hw)]
+    n = sizes[0]
+
+    def batches(count):
+        out, perm, pos = [], rs.permutation(n), 0
+        for _ in range(count):
+            if pos + batch > n:
+                perm, pos = rs.permutation(n), 0
+            out.append(torch.from_numpy(perm[pos:pos + batch].copy()))
+            pos += batch
+        return out
+    old = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        bufs, first = [None] * len(theta), True
+        for idx in batches(warm_steps):
+            _, _, g, _ = vgg_ref.loss_and_grads(theta, CFG, t1["train"].x[idx], t1["train"].y[idx], "ce_mean")
+            st = [R.reg_sgd_step(t, gi, None, None, b, 0.0, 1e-2, 0.9, 0.0, first) for t, gi, b in zip(theta, g, bufs)]
+            theta, bufs, first = [s[0] for s in st], [s[1] for s in st], False
+        fisher_batches = [(t1["train"].x[i:i + batch], t1["train"].y[i:i + batch]) for i in range(0, n, batch)]
+        omega = R.diag_fisher(theta, CFG, fisher_batches, n)
+    finally:
+        torch.set_num_threads(old)
+    head_w = torch.from_numpy((rs.standard_normal((n_classes, 128)) * (1.0 / 128) ** 0.5).astype(np.float32))
+    head_b = torch.zeros(n_classes)
+    return {"t1": t1, "t2": t2, "star": theta, "old_head": (theta[-2].clone(), theta[-1].clone()), "omega": omega,
+            "head": (head_w, head_b), "batches": batches(steps), "batch": batch, "hw": hw, "n_classes": n_classes}
+
+
+def _flat64(params):
+    return torch.cat([p.detach().double().reshape(-1).cpu() for p in params])
+
+
+def _accuracy(forward, x, y, chunk=200):
+    hits = 0
+    for i in range(0, x.shape[0], chunk):
+        hits += int((forward(x[i:i + chunk]).argmax(1).cpu() == y[i:i + chunk].cpu()).sum())
+    return hits / float(x.shape[0])
+
+
+def run_oracle(prob, dtype, threads, lam, lr, every=20, momentum=0.9, perturb=0.0):
+    """The recipe on the torch-CPU oracle in `dtype`; `perturb` (relative, deterministic sign pattern) displaces the start
+    point by that much — a stand-in for 'another rounding' where only one thread count is available."""
+    old = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        theta = [t.to(dtype).clone() for t in prob["star"][:-2]] + [prob["head"][0].to(dtype).clone(), prob["head"][1].to(dtype).clone()]
+        if perturb:
+            gen = torch.Generator().manual_seed(3)
+            theta = [t * (1 + perturb * (torch.randint(0, 2, t.shape, generator=gen).to(dtype) * 2 - 1)) for t in theta]
+        omega = [o.to(dtype) for o in prob["omega"][:-2]] + [None, None]
+        init = [t.to(dtype).clone() for t in prob["star"][:-2]] + [None, None]
+        x2, y2 = prob["t2"]["train"].x.to(dtype), prob["t2"]["train"].y
+        xv2, yv2 = prob["t2"]["val"].x.to(dtype), prob["t2"]["val"].y
+        xv1, yv1 = prob["t1"]["val"].x.to(dtype), prob["t1"]["val"].y
+        oh = [h.to(dtype) for h in prob["old_head"]]
+        bufs, first, rec = [None] * len(theta), True, []
+        for step, idx in enumerate(prob["batches"], 1):
+            _, _, g, _ = vgg_ref.loss_and_grads(theta, CFG, x2[idx], y2[idx], "ce_mean")
+            st = [R.reg_sgd_step(t, gi, o, iv, b, lam, lr, momentum, 0.0, first) for t, gi, o, iv, b in zip(theta, g, omega, init, bufs)]
+            theta, bufs, first = [s[0] for s in st], [s[1] for s in st], False
+            if step % every == 0:
+                with torch.no_grad():
+                    rec.append({"step": step, "theta": _flat64(theta),
+                                "acc_new": _accuracy(lambda x: vgg_ref.forward(theta, CFG, x), xv2, yv2),
+                                "acc_old": _accuracy(lambda x: vgg_ref.forward(theta[:-2] + oh, CFG, x), xv1, yv1)})
+        return rec
+    finally:
+        torch.set_num_threads(old)
+
+
+def run_gpu(prob, lam, lr, every=20, momentum=0.9, device="cuda"):
+    """The same recipe on the product path: NetEngine.loss_step (HIP kernels) + Weight_Regularized_SGD over the arena."""
+    from clsurvey_amd import models
+    from clsurvey_amd.net import NetEngine
+    from clsurvey_amd.optim import Weight_Regularized_SGD, arena_reg_params
+    hw, ncls = prob["hw"], prob["n_classes"]
+    model = models.parse_model_name("small_VGG9_cl_128_128", (hw, hw), ncls)
+    start = list(prob["star"][:-2]) + list(prob["head"])
+    with torch.no_grad():
+        for p, w in zip(model.parameters(), start):
+            p.copy_(w)
+    model = model.to(device)
+    params = list(model.parameters())
+    model.reg_params = {p: {"omega": o.to(device), "init_val": s.to(device)}
+                        for p, o, s in zip(params[:-2], prob["omega"][:-2], prob["star"][:-2])}
+    model.reg_params["lambda"] = lam
+    eng = NetEngine(model, max(prob["batch"], 200), (3, hw, hw), device)
+    arena_reg_params(eng.arena, model.reg_params)
+    opt = Weight_Regularized_SGD(model.parameters(), lr, momentum=momentum, weight_decay=0)
+    model.train()
+    x2, y2 = prob["t2"]["train"].x.to(device), prob["t2"]["train"].y.to(device)
+    xv2, yv2 = prob["t2"]["val"].x.to(device), prob["t2"]["val"].y
+    xv1, yv1 = prob["t1"]["val"].x.to(device), prob["t1"]["val"].y
+    oh = [h.to(device) for h in prob["old_head"]]
+    rec = []
+    for step, idx in enumerate(prob["batches"], 1):
+        idx = idx.to(device)
+        eng.loss_step(x2.index_select(0, idx), y2.index_select(0, idx), "ce_mean")
+        opt.step(model.reg_params)
+        if step % every == 0:
+            theta_now = _flat64(params)
+            acc_new = _accuracy(lambda x: eng.forward(x), xv2, yv2)
+            keep = [p.data.clone() for p in params[-2:]]
+            with torch.no_grad():                         # task 1 under the new trunk + its own head, then the new head back
+                params[-2].data.copy_(oh[0])
+                params[-1].data.copy_(oh[1])
+                acc_old = _accuracy(lambda x: eng.forward(x), xv1, yv1)
+                params[-2].data.copy_(keep[0])
+                params[-1].data.copy_(keep[1])
+            rec.append({"step": step, "theta": theta_now, "acc_new": acc_new, "acc_old": acc_old})
+    return rec
+
+
+def separation(rec, ref):
+    """relative l2 distance of the parameter vectors at every checkpoint."""
+    return [float((a["theta"] - b["theta"]).norm() / b["theta"].norm()) for a, b in zip(rec, ref)]
+
+
+def table(runs, ref_name="fp64"):
+    ref = runs[ref_name]
+    lines = ["step  " + "  ".join("%-28s" % n for n in runs)]
+    seps = {n: separation(r, ref) for n, r in runs.items()}
+    for k in range(len(ref)):
+        lines.append("%4d  " % ref[k]["step"] + "  ".join("sep %.2e new %.3f old %.3f" % (seps[n][k], runs[n][k]["acc_new"], runs[n][k]["acc_old"])
+                                                           for n in runs))
+    return "\n".join(lines), seps
