@@ -295,6 +295,65 @@ def module_flops_per_image(model, hw):
     return fwd, 3 * fwd - first
 
 
+def mfma_busy_pmc(width, instance=None):
+    """Matrix-pipe busy fraction by PMC (SQ_VALU_MFMA_BUSY_CYCLES / (32 x SQ_BUSY_CYCLES), tools/gpu_mfma_util.sh) from the
+    newest profiles/rNN_mfma_util_<width>.csv on file: {"file", "kernels": {instance: busy}} — the entry of `instance` alone
+    when given; None when no profile is on file.  Read from the committed profile, not measured in this run."""
+    import glob
+    key = {"small_VGG9": "small", "base_VGG9": "base", "wide_VGG9": "wide"}.get(width, width)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_mfma_util_%s.csv" % key)))
+    if not files:
+        return None
+    rows = {}
+    try:
+        with open(files[-1]) as f:
+            for line in f.read().splitlines()[1:]:           # kernel,dispatches,avg_us,mfma_busy,valu_active (template names hold commas)
+                k, _, _, busy, _ = line.rsplit(",", 4)
+                rows[k] = float(busy)
+    except Exception:
+        return None
+    name = os.path.basename(files[-1])
+    if instance is not None:
+        for k, v in rows.items():
+            if instance.startswith(k) or k.startswith(instance.split(" (")[0]):
+                return {"file": name, "kernel": k, "busy": v}
+        return None
+    return {"file": name, "kernels": rows}
+
+
+WINO_ISSUE = 16.0 / 36.0        # F(2x2, 3x3): 16 multiplies per 2x2 output tile and channel pair where the direct form has 36
+
+
+def step_flops_per_image(eng, hw):
+    """(algorithmic, issued) 2*MAC of one training / importance step per image — forward + backward-data (not on the first layer) +
+    weight gradient of every layer of the engine's plan — where `issued` counts a launch the plan runs through the Winograd
+    kernels (clhip_net_layer_paths) at 16/36 of its algorithmic FLOPs: what the matrix pipe really executes.  issued / time /
+    peak is a fraction of the hardware peak (<= 1 by construction); algorithmic / time / peak is the SURVEY 8(d) figure and may
+    exceed 1 on a net whose layers run Winograd."""
+    alg = iss = 0.0
+    h = hw
+    first = True
+    for li, (kind, m, relu, pool) in enumerate(eng.layers):
+        if kind == "conv":
+            ks, st, pd = m.kernel_size[0], m.stride[0], m.padding[0]
+            h = (h + 2 * pd - ks) // st + 1
+            f = 2.0 * ks * ks * m.in_channels * m.out_channels * h * h
+            paths = eng.layer_paths(li)
+            for kind_, on in (("fwd", True), ("bwd_data", not first), ("bwd_weight", True)):
+                if on:
+                    alg += f
+                    iss += f * (WINO_ISSUE if paths[kind_] else 1.0)
+            first = False
+            if pool:
+                pk, ps = pool if isinstance(pool, tuple) else (2, 2)
+                h = (h - pk) // ps + 1
+        else:
+            f = 2.0 * m.in_features * m.out_features
+            alg += 3 * f
+            iss += 3 * f
+    return alg, iss
+
+
 def hbm_kernels(dev, n=57_823_240, iters=10):
     """The HBM-bound regulariser / optimizer / gradient-memory kernels on an AlexNet-sized parameter arena (57.8 M floats:
     BASELINE configs[3]'s model; on the 0.6-9 M-parameter VGG9s the same launches are latency-bound): achieved TB/s =
@@ -357,13 +416,20 @@ def conv_backward_roofline(dev, N, iters=5):
         eng = net.NetEngine(models.parse_model_name(model_name, (64, 64), 20), N, (3, 64, 64), dev)
         rows = [r for r in time_kernels(eng, x, N, iters) if "bwd" in r["kernel"]]
         dom = max(rows, key=lambda r: r["sec"])
+
+        def issue(r):
+            return WINO_ISSUE if r.get("winograd") else 1.0
         fl, sec = sum(r["flops"] for r in rows), sum(r["sec"] for r in rows)
+        fl_iss = sum(r["flops"] * issue(r) for r in rows)
         out[name] = {"dominant_backward_launch": "%s, layer %s [%s]" % (dom["kernel"], dom["layer"], dom["instance"]),
-                     "dominant_us": dom["sec"] * 1e6, "dominant_tflops": dom["flops"] / dom["sec"] / 1e12,
-                     "dominant_frac_of_f32_mfma_peak": dom["flops"] / dom["sec"] / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                     "all_backward_launches_us": sec * 1e6, "all_backward_tflops": fl / sec / 1e12,
-                     "all_backward_frac_of_f32_mfma_peak": fl / sec / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                     "worst_backward_launch_frac": min(r["flops"] / r["sec"] / 1e12 / PEAK_F32_MFMA_TFLOPS for r in rows)}
+                     "dominant_winograd": bool(dom.get("winograd")),
+                     "dominant_us": dom["sec"] * 1e6, "dominant_algorithmic_tflops": dom["flops"] / dom["sec"] / 1e12,
+                     "dominant_mfma_issued_frac": dom["flops"] * issue(dom) / dom["sec"] / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                     "all_backward_launches_us": sec * 1e6, "all_backward_algorithmic_tflops": fl / sec / 1e12,
+                     "all_backward_algorithmic_over_f32_mfma_peak": fl / sec / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                     "all_backward_mfma_issued_frac": fl_iss / sec / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                     "worst_backward_launch_mfma_issued_frac": min(r["flops"] * issue(r) / r["sec"] / 1e12 / PEAK_F32_MFMA_TFLOPS for r in rows),
+                     "mfma_busy_pmc": mfma_busy_pmc(name)}
         del eng
     return out
 
@@ -379,9 +445,14 @@ def extra_configs(dev, N, steps):
     g = torch.Generator(device=dev)
     g.manual_seed(11)
 
-    def entry(ms, images, flops, what):
-        return {"what": what, "ms_per_step": ms, "images_per_s": images / ms * 1e3, "tflops": flops / ms / 1e9,
-                "frac_of_f32_mfma_peak": flops / ms / 1e9 / PEAK_F32_MFMA_TFLOPS}
+    def entry(ms, images, flops, what, issued=None):
+        """flops: algorithmic; issued: what the matrix pipe executes (Winograd layers at 16/36, step_flops_per_image)."""
+        e = {"what": what, "ms_per_step": ms, "images_per_s": images / ms * 1e3, "algorithmic_tflops": flops / ms / 1e9,
+             "algorithmic_over_f32_mfma_peak": flops / ms / 1e9 / PEAK_F32_MFMA_TFLOPS}
+        if issued is not None:
+            e["mfma_issued_tflops"] = issued / ms / 1e9
+            e["mfma_issued_frac"] = issued / ms / 1e9 / PEAK_F32_MFMA_TFLOPS
+        return e
 
     # ---- config 3: MAS importance pass + SI step, base_VGG9_cl_512_512, 3x64x64, batch N
     x = torch.randn((N, 3, 64, 64), generator=g, device=dev)
@@ -389,7 +460,7 @@ def extra_configs(dev, N, steps):
     m = models.parse_model_name("base_VGG9_cl_512_512", (64, 64), 20)
     eng = net.NetEngine(m, N, (3, 64, 64), dev)
     A = eng.arena
-    _, step_fl = algorithmic_flops_per_image(CFGS["base_VGG9"], (512, 512), 20, 64)
+    step_fl, step_iss = step_flops_per_image(eng, 64)
     omega, init_val, w, buf = A.buffer("omega"), A.buffer("init_val"), A.buffer("w"), A.buffer("buf")
     init_val.copy_(A.theta)
     it = [0]
@@ -404,10 +475,12 @@ def extra_configs(dev, N, steps):
         ops.si_step(A.theta, A.grad, omega, init_val, w, buf, 400.0, 1e-3, 0.9, 0.0, it[0] == 0)    # train_SI.py:28-126
         it[0] += 1
     out["mas_importance_base_vgg9"] = entry(_timed_loop(mas, steps), N, N * step_fl,
-                                            "MAS compute_importance_l2 batch (fwd + sum(out^2) + bwd + Omega running mean), base_VGG9_cl_512_512 64x64 N=%d" % N)
+                                            "MAS compute_importance_l2 batch (fwd + sum(out^2) + bwd + Omega running mean), base_VGG9_cl_512_512 64x64 N=%d" % N,
+                                            N * step_iss)
     it[0] = 0
     out["si_step_base_vgg9"] = entry(_timed_loop(si, steps), N, N * step_fl,
-                                     "SI training batch (fwd + CE + bwd + Elastic_SGD.step with path integral), base_VGG9_cl_512_512 64x64 N=%d" % N)
+                                     "SI training batch (fwd + CE + bwd + Elastic_SGD.step with path integral), base_VGG9_cl_512_512 64x64 N=%d" % N,
+                                     N * step_iss)
     del eng, A, omega, init_val, w, buf, m
 
     # ---- config 5: PackNet batch + HAT step, wide_VGG9_cl_512_512 at 64x64 (N) and 224x224 (iNaturalist geometry, N/4)
@@ -415,9 +488,9 @@ def extra_configs(dev, N, steps):
         x = torch.randn((nb, 3, hw, hw), generator=g, device=dev)
         y = torch.randint(0, 20, (nb,), generator=g, device=dev)
         st = max(2, steps // (4 if hw == 224 else 1))
-        _, step_fl = algorithmic_flops_per_image(CFGS["wide_VGG9"], (512, 512), 20, hw)
         m = models.parse_model_name("wide_VGG9_cl_512_512", (hw, hw), 20)
         eng = net.NetEngine(m, nb, (3, hw, hw), dev)
+        step_fl, step_iss = step_flops_per_image(eng, hw)
         A = eng.arena
         buf = torch.zeros_like(A.theta)
         mask = torch.randint(1, 3, (A.numel,), generator=g, device=dev, dtype=torch.int64).to(torch.uint8)   # owners 1 / 2
@@ -429,7 +502,8 @@ def extra_configs(dev, N, steps):
             first[0] = False
         out["packnet_batch_wide_vgg9_%d" % hw] = entry(
             _timed_loop(packnet, st), nb, nb * step_fl,
-            "PackNet do_batch (fwd + CE + bwd + foreign-grad zero / PacknetSGD / pruned zero fused), wide_VGG9_cl_512_512 %dx%d N=%d" % (hw, hw, nb))
+            "PackNet do_batch (fwd + CE + bwd + foreign-grad zero / PacknetSGD / pruned zero fused), wide_VGG9_cl_512_512 %dx%d N=%d" % (hw, hw, nb),
+            nb * step_iss)
         del eng, A, buf, mask
         hn = H.HatNet(m, (3, hw, hw), [(0, 20), (1, 20)]).to(dev)
         hat = H.HatEngine(hn, nb, (3, hw, hw), dev)
@@ -442,7 +516,8 @@ def extra_configs(dev, N, steps):
             opt.step(hn, mask_back, 1, 400.0, 50, 800.0, 10000, thres_emb=6.0)
         out["hat_step_wide_vgg9_%d" % hw] = entry(
             _timed_loop(hat_step, st), nb, nb * step_fl,
-            "HAT training batch of task 2 (gates, gated fwd + CE + reg, bwd, HAT_SGD, clamp), wide_VGG9_cl_512_512 %dx%d N=%d" % (hw, hw, nb))
+            "HAT training batch of task 2 (gates, gated fwd + CE + reg, bwd, HAT_SGD, clamp), wide_VGG9_cl_512_512 %dx%d N=%d" % (hw, hw, nb),
+            nb * step_iss)
         del hat, hn, opt, m
 
     # ---- config 4: GEM observe on AlexNet at 224x224 with 1 / 5 / 9 tasks in memory (mem_per_task 1024, method.py:286)
@@ -451,6 +526,7 @@ def extra_configs(dev, N, steps):
     m = extend_head(models.AlexNet(num_classes=nc), n_tasks * nc)
     fwd_fl, step_fl = module_flops_per_image(m, 224)
     gem = GemNet(m, n_tasks * nc, n_tasks, [nc] * n_tasks, mem, 1e-3, 0.0, 1.0, batch_size=nb, in_shape=(3, 224, 224), device=dev)
+    step_fl, step_iss = step_flops_per_image(gem.engine, 224)
     for past in (1, 5, 9):
         # fill the ring buffers of tasks 0..past-1 with synthetic exemplars, then observe batches of task `past`
         gem.observed_tasks, gem.old_task, gem.mem_cnt = list(range(past)), past - 1, 0
@@ -462,7 +538,8 @@ def extra_configs(dev, N, steps):
         imgs = nb + past * mem
         out["gem_observe_alexnet_%dtasks" % past] = entry(
             ms, imgs, imgs * step_fl,
-            "GEM observe (%d memory passes of %d exemplars + the batch of %d, Gram, QP, projection, SGD), AlexNet 224x224" % (past, mem, nb))
+            "GEM observe (%d memory passes of %d exemplars + the batch of %d, Gram, QP, projection, SGD), AlexNet 224x224" % (past, mem, nb),
+            imgs * step_iss)
     out["alexnet_mflop_per_image_fwd"] = fwd_fl / 1e6
     del gem, m, x
     torch.cuda.empty_cache()
@@ -908,6 +985,7 @@ def main():
         eng.probe(None)
 
     fwd_fl, step_fl = algorithmic_flops_per_image(SMALL, (128, 128), 20, 64)
+    step_iss = step_flops_per_image(eng, 64)[1]          # the same step as the matrix pipe sees it (Winograd layers at 16/36)
     imgs = 2 * N * args.steps * world
     out = {
         "metric": "images/sec (train+importance pass), EWC small_VGG9 Tiny-ImageNet task batch",
@@ -921,8 +999,9 @@ def main():
                                    "%d grid nodes of the phase-1 LR grid, one per GPU (RCCL: start-model broadcast, metric "
                                    "all_gather, winner broadcast)" % world),
                    "algorithmic_gflop_per_step": 2 * N * step_fl / 1e9,
-                   "step_tflops": 2 * N * step_fl * args.steps / dt / 1e12,
-                   "step_frac_of_f32_mfma_peak": 2 * N * step_fl * args.steps / dt / 1e12 / PEAK_F32_MFMA_TFLOPS},
+                   "step_algorithmic_tflops": 2 * N * step_fl * args.steps / dt / 1e12,
+                   "step_algorithmic_over_f32_mfma_peak": 2 * N * step_fl * args.steps / dt / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                   "step_mfma_issued_frac": 2 * N * step_iss * args.steps / dt / 1e12 / PEAK_F32_MFMA_TFLOPS},
     }
     if grid is not None:
         out["grid"] = grid
@@ -951,11 +1030,16 @@ def main():
                            # `achieved` prices the ALGORITHMIC flops of the convolution, this the flops the matrix
                            # pipe really executes
                            "winograd": bool(dom.get("winograd")),
-                           "mfma_issued_tflops": ach * (16.0 / 36.0 if dom.get("winograd") else 1.0),
+                           "mfma_issued_tflops": ach * (WINO_ISSUE if dom.get("winograd") else 1.0),
+                           "mfma_issued_frac": ach * (WINO_ISSUE if dom.get("winograd") else 1.0) / PEAK_F32_MFMA_TFLOPS,
+                           "mfma_busy_pmc": mfma_busy_pmc("small_VGG9", dom["instance"]),
                            "per_kernel": {k: {"tflops": v["flops"] / v["sec"] / 1e12, "us_per_step_pass": v["sec"] * 1e6}
                                           for k, v in agg.items()},
                            "per_layer": [{"kernel": r["kernel"], "layer": r["layer"], "instance": r["instance"], "winograd": bool(r.get("winograd")),
-                                          "us": r["sec"] * 1e6, "tflops": r["flops"] / r["sec"] / 1e12} for r in rows]}
+                                          "us": r["sec"] * 1e6, "algorithmic_tflops": r["flops"] / r["sec"] / 1e12,
+                                          "algorithmic_over_f32_mfma_peak": r["flops"] / r["sec"] / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                          "mfma_issued_frac": r["flops"] * (WINO_ISSUE if r.get("winograd") else 1.0) / r["sec"] / 1e12
+                                                              / PEAK_F32_MFMA_TFLOPS} for r in rows]}
         if world == 1 and not args.no_configs:
             del eng
             torch.cuda.empty_cache()
@@ -965,8 +1049,12 @@ def main():
             out["cpu_baseline"] = cpu_baseline(N, args.cpu_steps)
             out["config"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         if world == 1 and not args.no_sweep:
-            out["sweep"] = full_sweep(local_rank, cpu_threads=0 if args.no_cpu_baseline else out["cpu_baseline"]["cores"],
-                                      tasks=args.sweep_tasks, epochs=args.sweep_epochs)
+            try:
+                out["sweep"] = full_sweep(local_rank, cpu_threads=0 if args.no_cpu_baseline else out["cpu_baseline"]["cores"],
+                                          tasks=args.sweep_tasks, epochs=args.sweep_epochs)
+            except BaseException as e:            # (incl. the SystemExit of a failed training) the headline line is printed regardless
+                import traceback
+                out["sweep"] = {"error": "%s: %s" % (type(e).__name__, e), "traceback_tail": traceback.format_exc()[-1500:]}
             out["sweep_s"] = {"gpu": out["sweep"].get("gpu_s"), "cpu_extrapolated": out["sweep"].get("cpu_s_extrapolated"),
                               "pair_gpu": out["sweep"].get("pair", {}).get("gpu_s"), "pair_cpu": out["sweep"].get("pair", {}).get("cpu_s"),
                               "pair_max_accuracy_gap_points": out["sweep"].get("pair", {}).get("max_accuracy_gap_points"),

@@ -36,7 +36,7 @@
 namespace {
 
 #ifndef CLHIP_W16G_PF
-#define CLHIP_W16G_PF 1      // staging pipeline of wino_conv16g_kernel, see there
+#define CLHIP_W16G_PF 2      // staging pipeline of wino_conv16g_kernel, see there
 #endif
 
 constexpr int WKT = 64;      // out channels per block

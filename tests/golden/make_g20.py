@@ -1,6 +1,7 @@
 """G20: config 5 at its real widths (wide_VGG9_cl_512_512), from the reference's UNCHANGED code, dev container only.
 
   hat64      vgg_hat.Net.forward + Appr.criterion + backward + HAT_SGD.step + clamp, two batches of 8 at 3x64x64
+  hat224     and of 4 at 3x224x224, the iNaturalist geometry of BASELINE configs[4]
              (methods/HAT/networks/vgg_hat.py:83-127, approaches/hat.py, HAT_utils.py)
   pack64     packnet Manager.do_batch x2 (forward, backward, make_grads_zero, PacknetSGD.step, make_pruned_zero), batches
   pack224    of 8 at 3x64x64 and of 4 at 3x224x224 (methods/packnet/main.py:164-198, prune.py:73-112)
@@ -49,17 +50,18 @@ def load(module, seed):
     return [n for n, _ in named]
 
 
-def hat64():
+def hat(tag="hat64", hw=64, nb=8, seed=2001):
+    """seeds: parameters `seed`, batches seed + 99 + step, digests seed + 199 + j / seed + 299 + j (hat64: 2001, 2100, 2200, 2300)"""
     import methods.HAT.networks.vgg_hat as VH
     import methods.HAT.approaches.hat as HA
     import methods.HAT.HAT_utils as HU
     torch.cuda.LongTensor = torch.LongTensor
     taskcla = [(0, C.NCLS), (1, C.NCLS), (2, C.NCLS)]
-    net = VH.Net(raw_model(64), (3, 64, 64), taskcla, uniform_init=True)
-    names = load(net, 2001)
-    OUT["hat64_param_names"] = np.array(names)
+    net = VH.Net(raw_model(hw), (3, hw, hw), taskcla, uniform_init=True)
+    names = load(net, seed)
+    OUT[tag + "_param_names"] = np.array(names)
     smax, lamb, t, lr, mom, wd = 400.0, 0.75, 1, 0.05, 0.9, 1e-4
-    OUT["hat64_hyper"] = np.array([smax, lamb, t, lr, mom, wd])
+    OUT[tag + "_hyper"] = np.array([smax, lamb, t, lr, mom, wd])
     mask_pre, mask_back = HA.Appr.init_masks(t, net, smax)
     appr = HA.Appr.__new__(HA.Appr)
     appr.mask_pre, appr.lamb, appr.ce = mask_pre, lamb, nn.CrossEntropyLoss()
@@ -67,25 +69,25 @@ def hat64():
     task = torch.LongTensor([t])
     net.train()
     for step, s in enumerate((3.1, 171.0)):
-        x, y = (torch.from_numpy(a) for a in C.batch(2100 + step, 8, 64))
+        x, y = (torch.from_numpy(a) for a in C.batch(seed + 99 + step, nb, hw))
         output, masks = net.forward(task, x, s=s)
         loss, reg = appr.criterion(output, y, masks)
         opt.zero_grad()
         loss.backward()
-        OUT["hat64_s%d_logits" % step] = output.detach().numpy().copy()
-        OUT["hat64_s%d_loss" % step] = np.array([float(loss), float(reg)])
+        OUT["%s_s%d_logits" % (tag, step)] = output.detach().numpy().copy()
+        OUT["%s_s%d_loss" % (tag, step)] = np.array([float(loss), float(reg)])
         for i, mk in enumerate(masks):
-            OUT["hat64_s%d_mask%d" % (step, i)] = mk.detach().numpy().copy()
+            OUT["%s_s%d_mask%d" % (tag, step, i)] = mk.detach().numpy().copy()
         for j, (n, p) in enumerate(net.named_parameters()):
             if p.grad is not None:
-                put("hat64_s%d_grad_%s" % (step, n), p.grad, 2200 + j)
+                put("%s_s%d_grad_%s" % (tag, step, n), p.grad, seed + 199 + j)
         opt.step(net, mask_back, t, s, 50, smax, 10000)
         for n, p in net.named_parameters():
             if "embs" in n:
                 p.data = torch.clamp(p.data, -6, 6)
         for j, (n, p) in enumerate(net.named_parameters()):
-            put("hat64_s%d_theta_%s" % (step, n), p, 2300 + j)
-        print("hat64 step", step, float(loss), float(reg))
+            put("%s_s%d_theta_%s" % (tag, step, n), p, seed + 299 + j)
+        print(tag, "step", step, float(loss), float(reg))
 
 
 def pack(tag, hw, nb, seed):
@@ -128,7 +130,8 @@ def pack(tag, hw, nb, seed):
 
 
 if __name__ == "__main__":
-    hat64()
+    hat("hat64", 64, 8, 2001)
+    hat("hat224", 224, 4, 7001)
     pack("pack64", 64, 8, 3000)
     pack("pack224", 224, 4, 4000)
     path = os.path.join(HERE, "G20_wide_widths.npz")

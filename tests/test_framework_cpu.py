@@ -790,3 +790,31 @@ def test_ebll_autoencoder_grid_matches_reference_g32():
     for tag in ref:
         for stage in ("fresh", "again", "interrupted", "continued"):
             assert mine[tag][stage] == ref[tag][stage], (tag, stage, mine[tag][stage], ref[tag][stage])
+
+
+def test_model_names_match_reference_factory_g34():
+    """The regularised / deep model names (models/net.py:15-36, :133-175, VGGSlim.py:27-76): module tree, parameter order,
+    head-surgery index and initialisation of the build's `models.parse_model_name` / `driver.BaseModel` against what the
+    reference's own factory created (G34, tests/golden/make_g34.py)."""
+    import numpy as np
+    import tempfile
+    from clsurvey_amd import models
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "G34_model_names.npz"))
+    names = sorted({k.split("__")[0] for k in g.files})
+    assert names == sorted(["small_VGG9_cl_128_128_BN", "small_VGG9_cl_128_128_DROP", "small_VGG9_cl_128_128_DROP_BN",
+                            "deep_VGG22_cl_512_512"])
+    for name in names:
+        torch.manual_seed(1)
+        m = models.parse_model_name(name, (32, 32), 20)
+        tree = ["%s:%s" % (n, type(mod).__name__) for n, mod in m.named_modules() if n]
+        assert tree == [str(t) for t in g[name + "__tree"]], name
+        assert [n for n, _ in m.named_parameters()] == [str(t) for t in g[name + "__param_names"]]
+        with tempfile.TemporaryDirectory() as root:
+            assert driver.BaseModel(root, name, (32, 32), 20).last_layer_idx == int(g[name + "__last_layer_idx"][0])
+        for (pn, p), (mean, std, lo, hi) in zip(m.named_parameters(), g[name + "__init_stats"]):
+            if std == 0.0:                                  # biases 0, BatchNorm weight 1: exact
+                assert float(p.min()) == lo == float(p.max()) == hi, (name, pn)
+            else:                                           # Kaiming fan-out / N(0, 0.01): same distribution, other draw
+                assert abs(float(p.std()) - std) <= 0.1 * std and abs(float(p.mean())) <= 4 * std / p.numel() ** 0.5 + 1e-12, (name, pn)
+        assert [type(mod).__name__ for mod in m.modules() if isinstance(mod, torch.nn.Dropout)] == ["Dropout"] * sum(
+            1 for k in g.files if k.startswith(name + "__dropmask"))

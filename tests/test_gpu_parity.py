@@ -2,6 +2,8 @@
 the CPU oracle on the same seeded inputs, plus the golden fixtures generated from the reference.
 Tolerance: north_star says 1e-3 relative for fp32; we assert 2e-4 of the tensor's max magnitude
 (fp32 accumulation-order noise is ~1e-6)."""
+import copy
+
 import numpy as np
 import pytest
 import torch
@@ -25,6 +27,18 @@ def rel_err(a, b):
     b = b.detach().double().cpu()
     assert a.shape == b.shape, (a.shape, b.shape)
     return float((a - b).abs().max() / max(float(b.abs().max()), 1e-30))
+
+
+def assert_fp32_parity(got, ref32, ref64, what, base=1e-3, floor=0.0):
+    """north_star: 1e-3 relative on fp32.  `ref64` is an fp64 evaluation of the oracle graph, `ref32` the same graph in the
+    reference's own fp32 arithmetic (torch CPU).  The device result must be within 1e-3 of the fp64 value (per tensor, relative
+    to the tensor's largest entry) — or, where the reference's own fp32 result is further than that from the fp64 value (a
+    ReLU / arg-max near-tie decided differently in fp32), within 1.5x the reference's own distance."""
+    scale = max(float(ref64.abs().max()), floor, 1e-30)
+    e_dev = float((got.detach().double().cpu() - ref64).abs().max()) / scale
+    e_cpu = float((ref32.detach().double() - ref64).abs().max()) / scale
+    assert e_dev <= max(base, 1.5 * e_cpu), "%s: %.3e of its scale from the fp64 oracle (reference fp32: %.3e)" % (what, e_dev, e_cpu)
+    return e_dev, e_cpu
 
 
 def assert_close(a, b, tol=RTOL, what=""):
@@ -362,13 +376,100 @@ def test_engine_full_size_vs_oracle(name, N, hw):
         worst = max(worst, err)
         assert err <= 1e-4, "grad %d: %.3e of its scale on the GPU's own branch (north_star: 1e-3)" % (i, err)
     flips = _vgg_flips(cfg, decisions, pre)
-    print("%s N=%d hw=%d: worst gradient element %.2e of scale on the forced branch; %d near-tie decisions differ from fp64"
-          % (name, N, hw, worst, flips))
+    # ... and without forcing anything: the gradients as the executor delivers them against the fp64 oracle on the oracle's OWN
+    # branch, in the l2 norm of each tensor (a flipped near-tie moves one row by ~1/sqrt(#pixels), so the element-wise bound
+    # belongs to the forced comparison above; this one says the un-forced result is not merely right "up to branches"):
+    # l2 error <= 1e-2 of the tensor's norm, and no worse than 3x what the reference's own fp32 CPU arithmetic does
+    worst_l2 = 0.0
+    for i, (p, g32, g64) in enumerate(zip(m.parameters(), grads_ref, grads64)):
+        nrm = max(float(g64.norm()), 1e-30)
+        e_dev = float((p.grad.double().cpu() - g64).norm()) / nrm
+        e_cpu = float((g32.double() - g64).norm()) / nrm
+        worst_l2 = max(worst_l2, e_dev)
+        assert e_dev <= 1e-2 and e_dev <= max(1e-3, 3.0 * e_cpu), "grad %d un-forced: l2 %.3e (reference fp32: %.3e)" % (i, e_dev, e_cpu)
+    print("%s N=%d hw=%d: worst gradient element %.2e of scale on the forced branch; %d near-tie decisions differ from fp64; "
+          "un-forced l2 error <= %.2e" % (name, N, hw, worst, flips, worst_l2))
     del deep
     # eval-only pass leaves gradients untouched and reproduces the logits bit for bit
     before = eng.arena.grad.clone()
     _, logits2 = eng.loss_step(x.to(dev()), y.to(dev()), "ce_mean", False, want_logits=True)
     assert torch.equal(before, eng.arena.grad) and torch.equal(logits, logits2)
+
+
+def test_mas_and_si_passes_at_base_vgg9_widths():
+    """BASELINE configs[2] (MAS + SI on base_VGG9_cl_512_512) at its real widths, judged like the full-size cross-entropy
+    pass: fp64 oracle on the executor's own branch, every element within 1e-4 of its tensor's scale (north_star: 1e-3).
+      MAS: compute_importance_l2 (train_MAS.py:508-567) — sum(out^2) loss through the engine ('mse_sum_zero') and the running
+           mean of |g| (clhip_mas_accum, :167-173) over batches of 24, 24 and 19 images (the short-last-batch quirk);
+      SI:  two Elastic_SGD steps with weight decay (train_SI.py:28-126: theta, momentum, path integral w) and
+           update_reg_params (:301-364)."""
+    from clsurvey_amd import ops
+    cfg, fc, hw, N = vgg_ref.CFGS["base_VGG9"], (512, 512), 64, 24
+    params = vgg_ref.init_params(cfg, fc, 20, hw, np.random.RandomState(41))
+    with torch.no_grad():
+        for i in (-6, -4, -2):
+            params[i] *= 10.0                  # (N(0, 0.01) classifiers leave the squared-output loss at 1e-9: scale it into range)
+    gen = np.random.RandomState(42)
+    m, eng = build_engine(cfg, fc, 20, hw, params, N)
+    A = eng.arena
+    plist = list(m.parameters())
+    p64 = [p.double() for p in params]
+    # ---- MAS importance pass
+    omega = A.buffer("omega")
+    omega.zero_()
+    om64 = [torch.zeros_like(p) for p in p64]
+    flips = 0
+    for b, nb in enumerate((24, 24, 19)):
+        x = rnd(gen, nb, 3, hw, hw)
+        eng.loss_step(x.to(dev()), None, "mse_sum_zero", True)
+        dec = _vgg_decisions(eng, cfg, nb, hw)
+        _, _, g64, pre = vgg_ref.loss_and_grads_forced(p64, cfg, x.double(), None, "mse_sum_zero", dec)
+        flips += _vgg_flips(cfg, dec, pre)
+        ops.mas_accum(omega, A.grad, b, nb)
+        om64 = [R.mas_accum(o, g, b, nb) for o, g in zip(om64, g64)]
+    worst = 0.0
+    for i, p in enumerate(plist):
+        e = rel_err(A.view("omega", p).double(), om64[i])
+        worst = max(worst, e)
+        assert e <= 1e-4, "MAS omega %d: %.3e of its scale on the executor's branch" % (i, e)
+    print("MAS base_VGG9: worst omega element %.2e of scale; %d near-tie decisions differ from fp64" % (worst, flips))
+    # ---- SI: two steps + consolidation
+    om_si = [torch.from_numpy(gen.uniform(0, 2e-3, size=tuple(p.shape)).astype(np.float32)) for p in params]
+    iv_si = [p + torch.from_numpy((gen.standard_normal(tuple(p.shape)) * 1e-2 * float(p.abs().max())).astype(np.float32)) for p in params]
+    A.load("omega", {p: o for p, o in zip(plist, om_si)})
+    A.load("init_val", {p: v for p, v in zip(plist, iv_si)})
+    buf, w = A.buffer("buf"), A.buffer("w")
+    w.zero_()
+    th64, om64, iv64 = [p.double() for p in params], [o.double() for o in om_si], [v.double() for v in iv_si]
+    w64, b64 = [torch.zeros_like(t) for t in th64], [None] * len(th64)
+    flips = 0
+    for s in range(2):
+        x = rnd(gen, N, 3, hw, hw)
+        y = torch.from_numpy(gen.randint(0, 20, size=(N,)).astype(np.int64))
+        eng.loss_step(x.to(dev()), y.to(dev()), "ce_mean", True)
+        dec = _vgg_decisions(eng, cfg, N, hw)
+        # the oracle steps from the parameters the DEVICE holds (fp32 -> fp64, exact): one step of arithmetic per comparison
+        th64 = [p.data.double().cpu() for p in plist]
+        w_before = [A.view("w", p).double().cpu() for p in plist]
+        b_before = [A.view("buf", p).double().cpu() for p in plist] if s else b64
+        _, _, g64, pre = vgg_ref.loss_and_grads_forced(th64, cfg, x.double(), y, "ce_mean", dec)
+        flips += _vgg_flips(cfg, dec, pre)
+        ops.si_step(A.theta, A.grad, A.aux["omega"], A.aux["init_val"], w, buf, 400.0, 1e-2, 0.9, 1e-4, s == 0)
+        new = [R.si_step(t, gi, o, iv, wi, bi, 400.0, 1e-2, 0.9, 1e-4, s == 0)
+               for t, gi, o, iv, wi, bi in zip(th64, g64, om64, iv64, w_before, b_before)]
+        for i, p in enumerate(plist):
+            assert_close(p.data.double(), new[i][0], tol=1e-5, what="SI step %d theta %d" % (s, i))
+            assert_close(A.view("buf", p).double(), new[i][1], tol=1e-4, what="SI step %d momentum %d" % (s, i))
+            e = float((A.view("w", p).double().cpu() - new[i][2]).abs().max()) / max(float((new[i][2] - w_before[i]).abs().max()), 1e-30)
+            assert e <= 1e-4, "SI step %d path integral %d: %.3e of this step's largest contribution" % (s, i, e)
+    th64 = [p.data.double().cpu() for p in plist]
+    w64 = [A.view("w", p).double().cpu() for p in plist]
+    ops.si_consolidate(A.aux["omega"], w, A.theta, A.aux["init_val"])
+    for i, p in enumerate(plist):
+        o64, _, t64 = R.si_consolidate(om64[i], w64[i], th64[i], iv64[i])
+        assert_close(A.view("omega", p).double(), o64, tol=1e-5, what="SI consolidated omega %d" % i)
+        assert torch.equal(A.view("init_val", p).cpu(), p.data.cpu()) and float(A.view("w", p).abs().max()) == 0.0
+    print("SI base_VGG9: 2 steps + consolidation on the executor's branch; %d near-tie decisions differ from fp64" % flips)
 
 
 def test_ewc_fisher_golden_g2(golden):
@@ -470,17 +571,35 @@ def test_si_golden_g4(golden):
             new = [R.si_step(t, gi, o, iv, wi, bi, 400, 1e-2, 0.9, wd, s == 0)
                    for t, gi, o, iv, wi, bi in zip(th64, g64, om64, iv64, w64, b64)]
             th64, b64, w64 = [n[0] for n in new], [n[1] for n in new], [n[2] for n in new]
-        direct = 1e-3 if flips == 0 else 2e-3
+        # direct comparison with the reference's fp32 tensors: 1e-3 (north_star).  When one of the executor's decisions differs
+        # from the fp64 ones (a near-tie, checked above) the reference's fp32 run may sit on the other side of it, and w / Omega
+        # of that one row then differ by the row's own contribution — the per-element bound is then the reference's own
+        # distance from its fp64 value on ITS branch, x 1.5 (assert_fp32_parity), never a fixed looser number
+        th_own = [p.double() for p in params]
+        w_own, b_own = [torch.zeros_like(t) for t in th_own], [None] * 18
+        for s in range(3):
+            _, _, g_own, _ = vgg_ref.loss_and_grads(th_own, TINY, torch.from_numpy(g["%s_x%d" % (tag, s)]).double(),
+                                                    torch.from_numpy(g["%s_y%d" % (tag, s)]), "ce_mean")
+            new = [R.si_step(t, gi, o, iv, wi, bi, 400, 1e-2, 0.9, wd, s == 0)
+                   for t, gi, o, iv, wi, bi in zip(th_own, g_own, om64, iv64, w_own, b_own)]
+            th_own, b_own, w_own = [n[0] for n in new], [n[1] for n in new], [n[2] for n in new]
         for i, p in enumerate(plist):
             assert_close(p.data, torch.from_numpy(g["%s_s2_theta%d" % (tag, i)]), what="theta %d" % i)
-            assert_close(A.view("w", p), torch.from_numpy(g["%s_s2_w%d" % (tag, i)]), tol=direct, what="w %d" % i)
+            if flips == 0:
+                assert_close(A.view("w", p), torch.from_numpy(g["%s_s2_w%d" % (tag, i)]), tol=1e-3, what="w %d" % i)
+            else:
+                assert_fp32_parity(A.view("w", p), torch.from_numpy(g["%s_s2_w%d" % (tag, i)]), w_own[i], "w %d" % i)
             assert_close(p.data.double(), th64[i], tol=1e-5, what="theta %d on the executor's branch" % i)
             assert_close(A.view("w", p).double(), w64[i], tol=1e-4, what="w %d on the executor's branch" % i)
         ops.si_consolidate(A.aux["omega"], w, A.theta, A.aux["init_val"])
         for i, p in enumerate(plist):
             o64, _, _ = R.si_consolidate(om64[i], w64[i], th64[i], iv64[i])
             assert_close(A.view("omega", p).double(), o64, tol=1e-4, what="omega %d on the executor's branch" % i)
-            assert_close(A.view("omega", p), torch.from_numpy(g["%s_cons_omega%d" % (tag, i)]), tol=direct, what="omega %d" % i)
+            if flips == 0:
+                assert_close(A.view("omega", p), torch.from_numpy(g["%s_cons_omega%d" % (tag, i)]), tol=1e-3, what="omega %d" % i)
+            else:
+                o_own, _, _ = R.si_consolidate(om64[i], w_own[i], th_own[i], iv64[i])
+                assert_fp32_parity(A.view("omega", p), torch.from_numpy(g["%s_cons_omega%d" % (tag, i)]), o_own, "omega %d" % i)
             assert_close(A.view("init_val", p), torch.from_numpy(g["%s_cons_init%d" % (tag, i)]), what="init %d" % i)
         print("G4 %s: %d near-tie decisions differ from fp64 over 3 passes" % (tag, flips))
 
@@ -1121,9 +1240,10 @@ def test_alexnet_autograd_bridge_gradients():
     loss = torch.nn.functional.cross_entropy(model(x.to(dev())), y.to(dev()))
     grads = torch.autograd.grad(loss, list(model.parameters()))
     rl, _, rg = alexnet_ref.loss_and_grads(ref, x, y)
+    _, _, rg64 = alexnet_ref.loss_and_grads(copy.deepcopy(ref).double(), x.double(), y)
     assert abs(float(loss) - float(rl)) <= 2e-4 * max(1.0, abs(float(rl)))
-    for (name, _), g, r in zip(model.named_parameters(), grads, rg):
-        assert rel_err(g, r) <= 2e-3, name
+    worst = max(assert_fp32_parity(g, r, r64, name)[0] for (name, _), g, r, r64 in zip(model.named_parameters(), grads, rg, rg64))
+    print("alexnet autograd bridge: worst gradient element %.2e of its tensor's scale from the fp64 oracle" % worst)
 
 
 def test_gem_observe_alexnet_dropout_masks():
@@ -1146,11 +1266,16 @@ def test_gem_observe_alexnet_dropout_masks():
     logits = alexnet_ref.forward(ref, x, {0: m0[None], 1: m1[None]})
     rl = torch.nn.functional.cross_entropy(logits[:, 0:4], y)
     rg = torch.autograd.grad(rl, params)
+    ref64 = copy.deepcopy(ref).double()
+    l64 = torch.nn.functional.cross_entropy(alexnet_ref.forward(ref64, x.double(), {0: m0[None].double(), 1: m1[None].double()})[:, 0:4], y)
+    rg64 = torch.autograd.grad(l64, list(ref64.parameters()))
     assert abs(float(loss) - float(rl)) <= 2e-4 * max(1.0, abs(float(rl)))
-    for p_dev, p_ref, g in zip(model.parameters(), params, rg):
+    for p_dev, p_ref, g, g64 in zip(model.parameters(), params, rg, rg64):
         o, n = gem.A.slot(p_dev)
-        step = (theta0[o:o + n] - gem.A.theta[o:o + n]).view(p_ref.shape).cpu() / 0.05
-        assert rel_err(step, g) <= 2e-3
+        # (theta0 - theta1) / lr recovers the gradient to ~ulp(theta) / lr: floor the scale at what that subtraction can resolve
+        step = (theta0[o:o + n].double() - gem.A.theta[o:o + n].double()).view(p_ref.shape).cpu() / 0.05
+        resolve = float(p_ref.abs().max()) * 2.0 ** -23 / 0.05
+        assert_fp32_parity(step, g, g64, "gem step", floor=resolve * 1e3)
     # the next observe draws new masks; eval uses none
     old = m1.clone()
     gem.observe(x.to(dev()), 0, y.to(dev()))
@@ -1336,6 +1461,64 @@ def test_engine_vgg_bn_variant_vs_oracle():
             assert_close(b.cpu(), rb, tol=1e-4, what=name + " (unchanged by eval)")
 
 
+@pytest.mark.parametrize("name", ["small_VGG9_cl_128_128_BN", "small_VGG9_cl_128_128_DROP", "small_VGG9_cl_128_128_DROP_BN",
+                                  "deep_VGG22_cl_512_512"])
+def test_model_name_training_step_matches_reference_g34(golden, name):
+    """One TRAINING-MODE step (BatchNorm batch statistics + running-stat update, the reference's own Dropout masks) of the
+    model the reference's factory built for this name (models/net.py:15-36, VGGSlim.py:27-76; G34): logits, loss, every
+    gradient and the BatchNorm buffers of the engine's step on the build's `parse_model_name` model against the reference's
+    tensors — 1e-3 of each tensor's scale (north_star), 2e-3 in the tensors a counted near-tie decision touches."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import g20_common as GC
+    from clsurvey_amd import models
+    from clsurvey_amd.net import NetEngine
+    g = golden("G34_model_names")
+    k = ["small_VGG9_cl_128_128_BN", "small_VGG9_cl_128_128_DROP", "small_VGG9_cl_128_128_DROP_BN", "deep_VGG22_cl_512_512"].index(name)
+    m = models.parse_model_name(name, (32, 32), 20)
+    named = [(n, tuple(p.shape)) for n, p in m.named_parameters()]
+    assert [n for n, _ in named] == [str(t) for t in g[name + "__param_names"]]
+    mods = dict(m.named_modules())
+    with torch.no_grad():
+        for (n, p), q in zip(m.named_parameters(), GC.fill_params(named, 3400 + k)):
+            if isinstance(mods[n.rsplit(".", 1)[0]], torch.nn.BatchNorm2d):
+                q = (1.0 + 2.0 * q) if n.endswith("weight") else q
+            p.copy_(torch.from_numpy(q))
+    x, y = (torch.from_numpy(a) for a in GC.batch(3450 + k, 6, 32, 20))
+    eng = NetEngine(m, 6, (3, 32, 32), dev())
+    eng.auto_dropout = False
+    drops = sorted(eng.drops)
+    assert len(drops) == sum(1 for f in g.files if f.startswith(name + "__dropmask"))
+    for i, li in enumerate(drops):
+        eng.set_dropout(li, torch.from_numpy(g[name + "__dropmask%d" % i]).to(dev()))
+    m.train()
+    loss, logits = eng.loss_step(x.to(dev()), y.to(dev()), "ce_mean", True, want_logits=True)
+    ref_logits = torch.from_numpy(g[name + "__logits"])
+    assert_close(logits.cpu(), ref_logits, tol=1e-3, what="logits")
+    assert abs(float(loss) - float(g[name + "__loss"][0])) <= 1e-3 * max(1.0, abs(float(g[name + "__loss"][0])))
+    gmax, worst = 0.0, 0.0
+    digests = []
+    for j, (n, _) in enumerate(named):
+        v, sums = g["%s__grad_%s__v" % (name, n)], g["%s__grad_%s__s" % (name, n)]
+        got = eng.arena.view("grad", dict(m.named_parameters())[n]).detach().cpu().numpy().reshape(-1)
+        assert got.size == int(sums[2])
+        digests.append((n, got[GC.positions(got.size, 3500 + 50 * k + j)], v))
+        gmax = max(gmax, float(np.abs(v).max()))
+    for n, got, v in digests:
+        # (a convolution bias in front of a BatchNorm has an exactly-zero true gradient: measured against 1e-4 of the net's largest entry)
+        e = float(np.abs(got - v).max()) / max(float(np.abs(v).max()), 1e-4 * gmax)
+        worst = max(worst, e)
+        assert e <= 2e-3, "%s grad %s: %.3e of its scale" % (name, n, e)
+    for n, b in m.named_buffers():
+        ref = g["%s__buf_%s" % (name, n)]
+        if b.dtype == torch.float32:
+            assert_close(b.cpu(), torch.from_numpy(ref), tol=1e-4, what=n)
+        else:
+            assert int(b) == int(ref), n
+    print("%s: training-mode step vs the reference's model: worst sampled gradient deviation %.2e of scale" % (name, worst))
+
+
 def test_autograd_bridge_bn_drop_net_train_mode():
     """models.VGGSlim.forward of a '_DROP_BN' net in training mode (BatchNorm autograd bridge; Dropout p = 0 so that the
     pass is deterministic) vs torch CPU."""
@@ -1352,10 +1535,15 @@ def test_autograd_bridge_bn_drop_net_train_mode():
     loss = torch.nn.functional.cross_entropy(model(x.to(dev())), y.to(dev()))
     grads = torch.autograd.grad(loss, list(model.parameters()))
     rl, _, rg = alexnet_ref.loss_and_grads(ref, x, y)
+    ref64 = copy.deepcopy(ref).double().train()
+    _, _, rg64 = alexnet_ref.loss_and_grads(ref64, x.double(), y)
     assert abs(float(loss.detach()) - float(rl)) <= 2e-4 * max(1.0, abs(float(rl)))
-    floor = 1e-4 * max(float(r.abs().max()) for r in rg)
-    for (name, _), g, r in zip(model.named_parameters(), grads, rg):
-        assert float((g.cpu().double() - r.double()).abs().max()) <= 5e-3 * max(float(r.abs().max()), floor), name
+    # (a convolution bias in front of a BatchNorm has an exactly-zero true gradient: both sides hold rounding noise there, so
+    # every tensor is measured against at least 1e-4 of the net's largest gradient entry)
+    floor = 1e-4 * max(float(r.abs().max()) for r in rg64)
+    worst = max(assert_fp32_parity(g, r, r64, name, floor=floor)[0]
+                for (name, _), g, r, r64 in zip(model.named_parameters(), grads, rg, rg64))
+    print("_DROP_BN autograd bridge, train mode: worst gradient element %.2e of scale from the fp64 oracle" % worst)
     for (name, b), (_, rb) in zip(model.named_buffers(), ref.named_buffers()):
         if b.dtype == torch.float32:
             assert_close(b.cpu(), rb, tol=1e-4, what=name)
@@ -1531,17 +1719,20 @@ def test_ebll_step_with_dropout_on_the_features():
     m0 = torch.from_numpy((gen.random((N, 16)) < 0.5).astype(np.float32) * 2)
     m1 = torch.from_numpy((gen.random((N, 64)) < 0.5).astype(np.float32) * 2)
     lam, alpha = 3.0, 2.0
-    # ---- torch CPU
-    feat = torch.flatten(ref.features(x), 1)
-    enc0 = ref.autoencoders._modules["0"][0]
-    code = EB.encode(feat, enc0.weight, enc0.bias)
-    cls = list(ref.classifier.children())
-    h = F.relu(cls[1](feat * m0))
-    h = F.relu(cls[4](h * m1))
-    outs = [cls[6](h), cls[7](h)]
-    task, dist, closs = EB.stage2_objective(outs, [code], y, [tl], [tcode], 2.0, lam, alpha)
-    leaves = [p for n, p in ref.named_parameters() if not n.startswith("autoencoders")]
-    grads = torch.autograd.grad(task + dist + alpha * closs, leaves)
+    # ---- torch CPU, in the reference's fp32 and in fp64 (the yardstick of assert_fp32_parity)
+    def cpu(net, dt):
+        feat = torch.flatten(net.features(x.to(dt)), 1)
+        enc0 = net.autoencoders._modules["0"][0]
+        code = EB.encode(feat, enc0.weight, enc0.bias)
+        cls = list(net.classifier.children())
+        h = F.relu(cls[1](feat * m0.to(dt)))
+        h = F.relu(cls[4](h * m1.to(dt)))
+        outs = [cls[6](h), cls[7](h)]
+        task, dist, closs = EB.stage2_objective(outs, [code], y, [tl.to(dt)], [tcode.to(dt)], 2.0, lam, alpha)
+        leaves = [p for n, p in net.named_parameters() if not n.startswith("autoencoders")]
+        return feat, task, dist, closs, torch.autograd.grad(task + dist + alpha * closs, leaves)
+    feat, task, dist, closs, grads = cpu(ref, torch.float32)
+    grads64 = cpu(copy.deepcopy(ref).double(), torch.float64)[4]
     # ---- device
     w = w.to(dev())
     eng = E.EbllEngine(w, N, (3, 67, 67), dev())
@@ -1555,10 +1746,9 @@ def test_ebll_step_with_dropout_on_the_features():
     assert abs(float(code_loss) - float(closs)) <= 2e-4 * max(1.0, abs(float(closs)))
     assert_close(eng.features(N).cpu(), feat.detach(), tol=1e-5, what="un-masked features after the step")
     named = dict(w.named_parameters())
-    floor = 1e-4 * max(float(g.abs().max()) for g in grads)
-    for (name, _), g in zip([(n, p) for n, p in ref.named_parameters() if not n.startswith("autoencoders")], grads):
-        got = eng.arena.view("grad", named[name]).cpu()
-        assert float((got - g).abs().max()) <= 2e-3 * max(float(g.abs().max()), floor), name
+    floor = 1e-4 * max(float(g.abs().max()) for g in grads64)
+    for (name, _), g, g64 in zip([(n, p) for n, p in ref.named_parameters() if not n.startswith("autoencoders")], grads, grads64):
+        assert_fp32_parity(eng.arena.view("grad", named[name]), g, g64, name, floor=floor)
 
 
 def test_gem_qp_on_device_vs_host_and_scipy():

@@ -121,40 +121,42 @@ def _raw(hw):
                           classifier_dim1=C.FC[0], classifier_dim2=C.FC[1])
 
 
-def test_hat_step_wide_vgg9_g20(golden):
-    """vgg_hat.Net.forward + Appr.criterion + backward + HAT_SGD.step + clamp at wide_VGG9 widths, two batches of 8
+@pytest.mark.parametrize("tag,hw,nb,seed", [("hat64", 64, 8, 2001), ("hat224", 224, 4, 7001)])
+def test_hat_step_wide_vgg9_g20(golden, tag, hw, nb, seed):
+    """vgg_hat.Net.forward + Appr.criterion + backward + HAT_SGD.step + clamp at wide_VGG9 widths, two batches of 8 at 64 x 64
+    and of 4 at 224 x 224 (BASELINE configs[4]'s iNaturalist geometry: classifier input 512 x 14 x 14)
     (methods/HAT/networks/vgg_hat.py:83-127): second step at s = 171 (steep gates, near the end of the annealing)."""
     from clsurvey_amd.methods import hat as HT
     g = golden("G20_wide_widths")
-    smax, lamb, t, lr, mom, wd = [float(v) for v in g["hat64_hyper"]]
+    smax, lamb, t, lr, mom, wd = [float(v) for v in g[tag + "_hyper"]]
     t = int(t)
-    net = HT.HatNet(_raw(64), (3, 64, 64), [(0, C.NCLS), (1, C.NCLS), (2, C.NCLS)])
-    assert _load(net, 2001) == [str(n) for n in g["hat64_param_names"]]
-    hat = HT.HatEngine(net, 8, (3, 64, 64), DEV)
+    net = HT.HatNet(_raw(hw), (3, hw, hw), [(0, C.NCLS), (1, C.NCLS), (2, C.NCLS)])
+    assert _load(net, seed) == [str(n) for n in g[tag + "_param_names"]]
+    hat = HT.HatEngine(net, nb, (3, hw, hw), DEV)
     mask_pre, mask_back = HT.init_masks(hat, t, smax)
     opt = HT.HAT_SGD(net.parameters(), lr=lr, momentum=mom, weight_decay=wd)
     worst = 0.0
     for step, s in enumerate((3.1, 171.0)):
-        x, y = (torch.from_numpy(a).to(DEV) for a in C.batch(2100 + step, 8, 64))
+        x, y = (torch.from_numpy(a).to(DEV) for a in C.batch(seed + 99 + step, nb, hw))
         P64 = {n: p.detach().double().cpu().clone() for n, p in net.named_parameters()}
         ce, reg, logits = hat.step(t, x, y, s, mask_pre, lamb, None, True, want_logits=True)
-        g64, _ = _hat_forced_branch(hat, P64, t, x, y, s, lamb, smax, "HAT wide_VGG9 step %d" % step)
-        ref_logits = g["hat64_s%d_logits" % step]
+        g64, _ = _hat_forced_branch(hat, P64, t, x, y, s, lamb, smax, "HAT wide_VGG9 %d step %d" % (hw, step))
+        ref_logits = g["%s_s%d_logits" % (tag, step)]
         assert float(np.abs(logits.cpu().numpy() - ref_logits).max()) <= TOL * float(np.abs(ref_logits).max())
-        loss_ref, reg_ref = g["hat64_s%d_loss" % step]
+        loss_ref, reg_ref = g["%s_s%d_loss" % (tag, step)]
         assert abs(float(ce) + float(reg) - loss_ref) <= TOL * abs(loss_ref) and abs(float(reg) - reg_ref) <= 1e-5 * abs(reg_ref) + 1e-7
         for j, (n, p) in enumerate(net.named_parameters()):
-            key = "hat64_s%d_grad_%s" % (step, n)
+            key = "%s_s%d_grad_%s" % (tag, step, n)
             if key + "__v" in g.files:
-                worst = max(worst, _check(g, key, p.grad, 2200 + j, "step %d grad %s" % (step, n), flips=step > 0))
+                worst = max(worst, _check(g, key, p.grad, seed + 199 + j, "step %d grad %s" % (step, n), flips=step > 0))
         opt.step(net, mask_back, t, s, 50, smax, 10000)
         HT.clamp_embeddings(net)
         if step == 0:          # (the oracle's optimizer restatement is the first-step form: momentum buffer = gradient)
             from oracle import hat_ref
             _hat_update_on_branch(net, P64, g64, hat_ref.init_masks(P64, t, smax)[1], t, s, smax, lr, mom, wd, "HAT wide_VGG9")
         for j, (n, p) in enumerate(net.named_parameters()):
-            worst = max(worst, _check(g, "hat64_s%d_theta_%s" % (step, n), p.data, 2300 + j, "step %d theta %s" % (step, n)))
-    print("HAT wide_VGG9: worst sampled relative deviation %.2e" % worst)
+            worst = max(worst, _check(g, "%s_s%d_theta_%s" % (tag, step, n), p.data, seed + 299 + j, "step %d theta %s" % (step, n)))
+    print("HAT wide_VGG9 at %d x %d: worst sampled relative deviation %.2e" % (hw, hw, worst))
 
 
 @pytest.mark.parametrize("tag,hw,nb,seed", [("pack64", 64, 8, 3000), ("pack224", 224, 4, 4000)])

@@ -71,6 +71,11 @@ def _accuracy(forward, x, y, chunk=200):
     return hits / float(x.shape[0])
 
 
+def _due(step, every):
+    """checkpoints: after the very first step (one step of arithmetic from a shared start: no amplification yet), then every `every`."""
+    return step == 1 or step % every == 0
+
+
 def run_oracle(prob, dtype, threads, lam, lr, every=20, momentum=0.9, perturb=0.0):
     """The recipe on the torch-CPU oracle in `dtype`; `perturb` (relative, deterministic sign pattern) displaces the start
     point by that much — a stand-in for 'another rounding' where only one thread count is available."""
@@ -92,7 +97,7 @@ def run_oracle(prob, dtype, threads, lam, lr, every=20, momentum=0.9, perturb=0.
             _, _, g, _ = vgg_ref.loss_and_grads(theta, CFG, x2[idx], y2[idx], "ce_mean")
             st = [R.reg_sgd_step(t, gi, o, iv, b, lam, lr, momentum, 0.0, first) for t, gi, o, iv, b in zip(theta, g, omega, init, bufs)]
             theta, bufs, first = [s[0] for s in st], [s[1] for s in st], False
-            if step % every == 0:
+            if _due(step, every):
                 with torch.no_grad():
                     rec.append({"step": step, "theta": _flat64(theta),
                                 "acc_new": _accuracy(lambda x: vgg_ref.forward(theta, CFG, x), xv2, yv2),
@@ -131,7 +136,7 @@ def run_gpu(prob, lam, lr, every=20, momentum=0.9, device="cuda"):
         idx = idx.to(device)
         eng.loss_step(x2.index_select(0, idx), y2.index_select(0, idx), "ce_mean")
         opt.step(model.reg_params)
-        if step % every == 0:
+        if _due(step, every):
             theta_now = _flat64(params)
             acc_new = _accuracy(lambda x: eng.forward(x), xv2, yv2)
             keep = [p.data.clone() for p in params[-2:]]
@@ -146,8 +151,8 @@ def run_gpu(prob, lam, lr, every=20, momentum=0.9, device="cuda"):
 
 
 def separation(rec, ref):
-    """relative l2 distance of the parameter vectors at every checkpoint."""
-    return [float((a["theta"] - b["theta"]).norm() / b["theta"].norm()) for a, b in zip(rec, ref)]
+    """relative l2 distance of the parameter vectors at every checkpoint ('sep' where a child process already computed it)."""
+    return [a["sep"] if "sep" in a else float((a["theta"] - b["theta"]).norm() / b["theta"].norm()) for a, b in zip(rec, ref)]
 
 
 def table(runs, ref_name="fp64"):
@@ -158,3 +163,36 @@ def table(runs, ref_name="fp64"):
         lines.append("%4d  " % ref[k]["step"] + "  ".join("sep %.2e new %.3f old %.3f" % (seps[n][k], runs[n][k]["acc_new"], runs[n][k]["acc_old"])
                                                            for n in runs))
     return "\n".join(lines), seps
+
+
+def run_gpu_in_subprocess(prob, ref, lam, lr, env, every=20):
+    """run_gpu in a fresh process with `env` on top of the environment (the library's A/B switches are read once per process:
+    CLHIP_WINO=0 puts every 3x3 layer on the direct MFMA kernels, whose fp32 results are k-ordered fma chains).  Returns records
+    without the parameter vectors but with 'sep' = the separation from `ref` computed in the child."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "in.pt")
+        torch.save({"prob": prob, "ref": [r["theta"] for r in ref], "lam": lam, "lr": lr, "every": every}, path)
+        full = dict(os.environ)
+        full.update(env)
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), path], env=full, capture_output=True, text=True, timeout=900)
+        if out.returncode != 0:
+            raise RuntimeError("child run failed:\n" + out.stderr[-3000:])
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+        return json.loads(line)["records"]
+
+
+if __name__ == "__main__":
+    import json
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here))
+    job = torch.load(sys.argv[1], weights_only=False)
+    rec = run_gpu(job["prob"], job["lam"], job["lr"], every=job["every"])
+    print(json.dumps({"records": [{"step": r["step"], "acc_new": r["acc_new"], "acc_old": r["acc_old"],
+                                   "sep": float((r["theta"] - t).norm() / t.norm())} for r, t in zip(rec, job["ref"])]}))

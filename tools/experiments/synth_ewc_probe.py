@@ -54,6 +54,7 @@ def main():
     a = sys.argv[1:]
     hw, ntr, epochs, g = int(a[0]), int(a[1]), int(a[2]), int(a[3])
     amp, nlr, npx, q = float(a[4]), float(a[5]), float(a[6]), float(a[7])
+    kaiming = len(a) > 8 and a[8] == "k"
     SP.Q[0] = q
     tasks = []
     for t in range(2):
@@ -62,7 +63,7 @@ def main():
         xva, yva, _ = SP.blobs(ntr // 4, 20, hw, g, amp, nlr, npx, gen, protos)
         tasks.append((xtr, ytr, xva, yva))
     torch.manual_seed(0)
-    m1 = SP.make_net(hw, 20)
+    m1 = SP.make_net(hw, 20, kaiming)
     acc1, ep1 = fit(m1, *tasks[0], epochs, 1e-2)
     print("task 1: val %.3f after %d epochs" % (acc1, ep1), flush=True)
     # Fisher diagonal of task 1
@@ -75,7 +76,8 @@ def main():
         F.nll_loss(F.log_softmax(m1(xtr[i:i + 200]), 1), ytr[i:i + 200], reduction="sum").backward()
         for o, p in zip(omega, params):
             o += p.grad ** 2 / ntr
-    print("omega: sum %.4g max %.4g" % (sum(float(o.sum()) for o in omega), max(float(o.max()) for o in omega)), flush=True)
+    print("omega: sum %.4g max %.4g; max per tensor %s" % (sum(float(o.sum()) for o in omega), max(float(o.max()) for o in omega),
+                                                       ["%.2g" % float(o.max()) for o in omega]), flush=True)
     star = [p.detach().clone() for p in params[:-2]]
     omega = omega[:-2]
 
