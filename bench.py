@@ -96,6 +96,7 @@ def parse():
     ap.add_argument("--sweep-only", action="store_true", help="print only the `sweep` object (tuning the synthetic sequence)")
     ap.add_argument("--pair-cpu-leg", type=str, default=None, help="internal: run one CPU leg of the sweep pair under this root")
     ap.add_argument("--pair-threads", type=int, default=16)
+    ap.add_argument("--sweep-blobs", type=str, default=None, help="tuning: g,amp,noise_lr,q of the sweep's synthetic tasks")
     return ap.parse_args()
 
 
@@ -363,12 +364,14 @@ def hbm_kernels(dev, n=57_823_240, iters=10):
     from clsurvey_amd import _lib, ops
     from clsurvey_amd.methods import packnet as PK
     t = {k: torch.rand(n, device=dev) * 1e-2 for k in ("theta", "grad", "omega", "init", "buf", "w", "out")}
-    G = torch.randn((6, n), device=dev)
+    G = torch.randn((11, n), device=dev)                  # GEM gradient memory: 10 tasks + the current gradient (config 4 at its deepest)
     mask = torch.randint(1, 3, (n,), device=dev, dtype=torch.int64).to(torch.uint8)
     L = _lib.lib()
     ws = torch.zeros(L.clhip_gem_gram_ws(16), dtype=torch.uint8, device=dev)
     gram = torch.zeros(256, dtype=torch.float64, device=dev)
     rows5 = (C.c_int * 5)(0, 1, 2, 3, 4)
+    rows11 = (C.c_int * 11)(*range(11))
+    v10 = (C.c_float * 10)(*[0.5 + 0.1 * i for i in range(10)])
     v5 = (C.c_float * 5)(0.5, 1.0, -0.5, 0.25, 2.0)
     st = torch.cuda.current_stream().cuda_stream
     cases = [
@@ -382,11 +385,15 @@ def hbm_kernels(dev, n=57_823_240, iters=10):
         ("packnet_sgd_step", "PackNet do_batch tail: foreign grads -> 0, PacknetSGD, pruned -> 0 (packnet/main.py:187-193)", 25,
          lambda: PK.fused_batch_tail(t["theta"], t["grad"], t["buf"], mask, 2, 1e-3, 0.9, 0.0, False)),
         ("gem_store_grad", "GEM store_grad: G[t] = g (gem.py:38-55)", 8,
-         lambda: L.clhip_axpy(G[5].data_ptr(), t["grad"].data_ptr(), n, C.c_float(1.0), 1, st)),
+         lambda: L.clhip_axpy(G[10].data_ptr(), t["grad"].data_ptr(), n, C.c_float(1.0), 1, st)),
         ("gem_gram", "GEM Gram of 5 gradient rows, f64, one pass (gem.py:275-277 + QP inputs)", 20,
          lambda: L.clhip_gem_gram(G.data_ptr(), n, rows5, 5, n, gram.data_ptr(), ws.data_ptr(), ws.numel(), st)),
         ("gem_project", "GEM projection g + sum v_i G_i, 5 rows (gem.py:78-79)", 28,
          lambda: L.clhip_gem_project(G.data_ptr(), n, rows5, v5, 5, t["grad"].data_ptr(), t["out"].data_ptr(), n, st)),
+        ("gem_gram_11rows", "GEM Gram of 11 gradient rows (10 tasks in memory + the current gradient: config 4 at its last task), f64, one pass", 44,
+         lambda: L.clhip_gem_gram(G.data_ptr(), n, rows11, 11, n, gram.data_ptr(), ws.data_ptr(), ws.numel(), st)),
+        ("gem_project_10rows", "GEM projection g + sum v_i G_i, 10 rows (gem.py:78-79)", 48,
+         lambda: L.clhip_gem_project(G.data_ptr(), n, rows11, v10, 10, t["grad"].data_ptr(), t["out"].data_ptr(), n, st)),
     ]
     out = []
     for name, what, bpp, fn in cases:
@@ -578,12 +585,13 @@ class _PassCounter:
 # model keeps a non-trivial Fisher diagonal, the stability-decay loop has something to decide, and accuracies saturate at a
 # level the data sets.  Models start from torchvision's initialisation (models.py, VGGSlim.py / torchvision VGG: Kaiming
 # convolutions, N(0, 0.01) classifier), created by the driver's BaseModel as the reference's models/net.py:158-169 does.
-SWEEP_DATA = {"kind": "blobs", "noise": 0.5}
+SWEEP_DATA = {"kind": "blobs", "noise": 0.5, "blobs": {"g": 8, "amp": 4.0, "noise_lr": 1.2, "q": 0.7}}
 PAIR = {"sizes": (2000, 500, 500), "epochs": 8, "batch": 50, "lr": "1e-2", "lam": 400.0}
 
 
 def _pair_args(device):
-    spec = "2,20,%d,%d,%d,64,%g,%s" % (tuple(PAIR["sizes"]) + (SWEEP_DATA["noise"], SWEEP_DATA["kind"]))
+    b = SWEEP_DATA["blobs"]
+    spec = "2,20,%d,%d,%d,64,%g,%s,%g,%g,%g,%g" % (tuple(PAIR["sizes"]) + (SWEEP_DATA["noise"], SWEEP_DATA["kind"], b["g"], b["amp"], b["noise_lr"], b["q"]))
     return ["small_VGG9_cl_128_128", "--num_epochs", str(PAIR["epochs"]), "--batch_size", str(PAIR["batch"]), "--saving_freq", "1000",
             "--synthetic", spec, "--device", device, "--lr_grid", PAIR["lr"]]
 
@@ -660,9 +668,9 @@ def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epoch
     dev = "cuda:%d" % dev_index
     res = {"what": "%d-task EWC sweep, %s, %d/%d/%d images of 3x64x64 per task, 20 classes, the reference's defaults "
                    "(LR grid {1e-2,5e-3,1e-3,5e-4,1e-4}, %d-epoch cap, batch 200, lambda 400, drop margin 0.2, --test); torchvision "
-                   "initialisation; synthetic 'blobs' tasks with overlapping classes (best possible accuracy 71.5 %%)"
-                   % ((tasks, model) + tuple(sizes) + (epochs,)),
-           "data": dict(SWEEP_DATA)}
+                   "initialisation; synthetic 'blobs' tasks with overlapping classes (best possible accuracy %.1f %%)"
+                   % ((tasks, model) + tuple(sizes) + (epochs, 100.0 * (SWEEP_DATA["blobs"]["q"] + (1 - SWEEP_DATA["blobs"]["q"]) / 20))),
+           "data": {"kind": SWEEP_DATA["kind"], "noise": SWEEP_DATA["noise"], **SWEEP_DATA["blobs"]}}
     quiet = io.StringIO()
     legs = []
     try:
@@ -679,7 +687,8 @@ def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epoch
                 for sub in ("data", "models", os.path.join("train", "synthetic_tiny_imagenet", "SI")):
                     shutil.copytree(os.path.join(proot, sub), os.path.join(croot, sub))
                 env = dict(os.environ, OMP_NUM_THREADS=str(t), MKL_NUM_THREADS=str(t))
-                legs.append((t, subprocess.Popen([sys.executable, os.path.abspath(__file__), "--pair-cpu-leg", croot, "--pair-threads", str(t)],
+                legs.append((t, subprocess.Popen([sys.executable, os.path.abspath(__file__), "--pair-cpu-leg", croot, "--pair-threads", str(t), "--sweep-blobs",
+                                                  ",".join("%g" % SWEEP_DATA["blobs"][k] for k in ("g", "amp", "noise_lr", "q"))],
                                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True)))
             with contextlib.redirect_stdout(quiet), _PassCounter(PAIR["sizes"][0]) as pcounts:
                 torch.cuda.synchronize()
@@ -697,7 +706,8 @@ def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epoch
         groot = os.path.join(root, "gpu")
         if tasks > 0:
             ds = SyntheticTaskSequence(os.path.join(groot, "data"), task_count=tasks, classes_per_task=20, sizes=tuple(sizes), hw=64,
-                                       name="synthetic_tiny_imagenet", noise=SWEEP_DATA["noise"], kind=SWEEP_DATA["kind"])
+                                       name="synthetic_tiny_imagenet", noise=SWEEP_DATA["noise"], kind=SWEEP_DATA["kind"],
+                                       blobs=SWEEP_DATA["blobs"])
             t0 = time.perf_counter()
             for i in range(1, tasks + 1):
                 ds.get_task_dataset_path(str(i))
@@ -709,19 +719,32 @@ def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epoch
                 driver.main(common + ["--method_name", "SI", "--runmode", "first_task_basemodel_dump"], method=M.parse("SI"), dataset=ds)
                 torch.cuda.synchronize()
                 res["gpu_first_task_s"] = time.perf_counter() - t0
-                out = driver.main(common + ["--method_name", "EWC", "--test"], method=M.parse("EWC"), dataset=ds)
+                try:
+                    out = driver.main(common + ["--method_name", "EWC", "--test"], method=M.parse("EWC"), dataset=ds)
+                except BaseException as e:
+                    # (the reference's own loop ends the same way when every stability-decay attempt of a task diverges:
+                    # no best_model.pth.tar for the next task to start from, framework_train.py:143)
+                    lines = quiet.getvalue().splitlines()
+                    res["gpu_error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
+                    res["gpu_log_tail"] = [ln for ln in lines if "ATTEMPT" in ln or "FINETUNE DONE" in ln or "Loss" in ln][-40:]
+                    raise
                 torch.cuda.synchronize()
                 res["gpu_s"] = time.perf_counter() - t0
             r = out["results"]
             res["gpu_image_passes"] = dict(counts)
             res["gpu_phase2_trainings_per_task"] = [len(hf.trace) for hf in out["frameworks"] if hf is not None]
+            res["gpu_phase2_attempts"] = [[{"lambda": float(h["lambda"]), "val_acc": float(a), "threshold": float(th)} for h, a, th in hf.trace]
+                                          for hf in out["frameworks"] if hf is not None]
+            last = torch.load(out["model_paths"][-1], map_location="cpu", weights_only=False)
+            om = [v["omega"] for v in getattr(last, "reg_params", {}).values() if isinstance(v, dict) and "omega" in v]
+            res["gpu_omega_of_last_model"] = {"max": float(max(float(o.max()) for o in om)), "sum": float(sum(float(o.double().sum()) for o in om))} if om else None
             res["gpu_accepted_lambda_per_task"] = [float(hf.trace[-1][0]["lambda"]) for hf in out["frameworks"] if hf is not None and hf.trace]
             res["gpu_final_accuracies"] = [r[i]["seq_res"][i][-1] for i in sorted(r)]          # task i under the LAST model
             res["gpu_first_accuracies"] = [r[i]["seq_res"][i][0] for i in sorted(r)]           # task i right after training it
             res["gpu_avg_accuracy"] = float(np.mean(res["gpu_final_accuracies"]))
             res["gpu_avg_forgetting"] = float(np.mean([r[i]["seq_forgetting"][i][-1] for i in sorted(r) if r[i]["seq_forgetting"][i]] or [0.0]))
             res["chance_accuracy"] = 100.0 / 20
-            res["best_possible_accuracy"] = 100.0 * (0.7 + 0.3 / 20)
+            res["best_possible_accuracy"] = 100.0 * (SWEEP_DATA["blobs"]["q"] + (1 - SWEEP_DATA["blobs"]["q"]) / 20)
         # ---- collect the CPU legs
         if pair is not None:
             cpu = []
@@ -757,6 +780,10 @@ def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epoch
                 res["cpu_s_extrapolated_how"] = ("GPU sweep's image passes (%d forward+backward, %d forward-only) at the two host rates "
                                                  "the pair's first CPU leg measured on this box; not run" % (counts["train"], counts["eval"]))
                 res["gpu_over_cpu_wall_clock"] = res["cpu_s_extrapolated"] / res["gpu_s"]
+    except BaseException as e:
+        if "gpu_error" not in res:
+            raise
+        res["error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
     finally:
         for _, proc in legs:
             proc.kill()
@@ -864,6 +891,8 @@ def cpu_baseline(batch, steps):
 
 def main():
     args = parse()
+    if args.sweep_blobs:
+        SWEEP_DATA["blobs"] = dict(zip(("g", "amp", "noise_lr", "q"), (float(v) for v in args.sweep_blobs.split(","))))
     if args.pair_cpu_leg:                      # a CPU leg of the sweep pair, in its own process (no GPU work)
         print(json.dumps(pair_cpu_leg(args.pair_cpu_leg, args.pair_threads)), flush=True)
         return

@@ -8,6 +8,7 @@
 // 4*m bytes per parameter instead of the 4*(t+1) + 8*t*... of the numpy path.  Only the m*m doubles
 // travel to the host for the tiny QP.
 #include "common.hpp"
+#include <utility>
 
 namespace {
 
@@ -35,52 +36,103 @@ __global__ __launch_bounds__(GB) void axpy_kernel(float* __restrict__ y, const f
         y[i] = assign ? alpha * x[i] : y[i] + alpha * x[i];
 }
 
-// partial[b][pair] = sum over this block's column range of G[ri][c] * G[rj][c]   (i <= j)
-template <int M, bool VEC>
-__global__ __launch_bounds__(GB) void gram_partial_kernel(const float* __restrict__ G, size_t ld, RowSel sel, size_t n,
-                                                          double* __restrict__ partial) {
+// partial[b][pair] = sum over this block's column range of G[ri][c] * G[rj][c]   (i <= j), pair = the index in row-major
+// order of the upper triangle.
+//
+// M(M+1)/2 f64 accumulators per thread do not fit the register file beyond M = 6 (M = 16: 136 doubles = 272 registers; the
+// round-3 kernel spilled 29 .. 205 scratch instructions for M = 7 .. 16, and config 4 with 9 tasks in memory runs M = 10).
+// So the pairs are dealt out over S of the block's four WAVES (wave w holds the pairs p = w % S, w % S + S, ...; the choice is
+// uniform per wave, no divergence): the S waves of a set read the same 64 column groups (the second read of a line hits the
+// cache; HBM still sees ONE pass over G), each keeps at most 36 accumulators.
+__host__ __device__ constexpr int gram_pair_i(int M, int p) {
+    int i = 0;
+    while (p >= M - i) { p -= M - i; ++i; }
+    return i;
+}
+__host__ __device__ constexpr int gram_pair_j(int M, int p) {
+    int i = 0;
+    while (p >= M - i) { p -= M - i; ++i; }
+    return i + p;
+}
+__host__ __device__ constexpr int gram_split(int M) { return M <= 8 ? 1 : M <= 11 ? 2 : 4; }
+
+// pair K of wave group GRP: compile-time row indices (as template constants: a loop variable through a constexpr function
+// leaves the row array indexed at run time, i.e. in scratch)
+template <int M, int S, int GRP, int K>
+struct GramPair {
+    static constexpr int p = GRP + K * S, i = gram_pair_i(M, p), j = gram_pair_j(M, p);
+};
+template <int M, int S, int GRP, int... K>
+__device__ __forceinline__ void gram_acc4(double* acc, const float4* v, std::integer_sequence<int, K...>) {
+    ((acc[K] += (double)v[GramPair<M, S, GRP, K>::i].x * (double)v[GramPair<M, S, GRP, K>::j].x,
+      acc[K] += (double)v[GramPair<M, S, GRP, K>::i].y * (double)v[GramPair<M, S, GRP, K>::j].y,
+      acc[K] += (double)v[GramPair<M, S, GRP, K>::i].z * (double)v[GramPair<M, S, GRP, K>::j].z,
+      acc[K] += (double)v[GramPair<M, S, GRP, K>::i].w * (double)v[GramPair<M, S, GRP, K>::j].w), ...);
+}
+template <int M, int S, int GRP, int... K>
+__device__ __forceinline__ void gram_acc1(double* acc, const float* v, std::integer_sequence<int, K...>) {
+    ((acc[K] += (double)v[GramPair<M, S, GRP, K>::i] * (double)v[GramPair<M, S, GRP, K>::j]), ...);
+}
+
+template <int M, int S, int GRP, bool VEC>
+__device__ __forceinline__ void gram_partial_body(const float* __restrict__ G, size_t ld, const RowSel& sel, size_t n,
+                                                  double* __restrict__ partial, double* red) {
     constexpr int NP = M * (M + 1) / 2;
-    double acc[NP];
+    constexpr int NA = (NP - GRP + S - 1) / S;            // pairs GRP, GRP + S, ... of this wave
+    constexpr int NA_MAX = (NP + S - 1) / S;              // the same number of reduction rounds (barriers) in every wave
+    constexpr int COLS = GB / S;                          // column groups per block and sweep
+    double acc[NA];
 #pragma unroll
-    for (int p = 0; p < NP; ++p) acc[p] = 0.0;
-    size_t stride = (size_t)gridDim.x * GB;
+    for (int k = 0; k < NA; ++k) acc[k] = 0.0;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const size_t col0 = (size_t)blockIdx.x * COLS + (size_t)(wave / S) * 64 + lane, stride = (size_t)gridDim.x * COLS;
     const size_t n4 = VEC ? n / 4 : 0;
-    for (size_t c4 = (size_t)blockIdx.x * GB + threadIdx.x; c4 < n4; c4 += stride) {
+    for (size_t c4 = col0; c4 < n4; c4 += stride) {
         float4 v[M];
 #pragma unroll
         for (int i = 0; i < M; ++i) v[i] = reinterpret_cast<const float4*>(G + (size_t)sel.idx[i] * ld)[c4];
-        int p = 0;
-#pragma unroll
-        for (int i = 0; i < M; ++i)
-#pragma unroll
-            for (int j = i; j < M; ++j) {
-                acc[p] += (double)v[i].x * (double)v[j].x;
-                acc[p] += (double)v[i].y * (double)v[j].y;
-                acc[p] += (double)v[i].z * (double)v[j].z;
-                acc[p] += (double)v[i].w * (double)v[j].w;
-                ++p;
-            }
+        gram_acc4<M, S, GRP>(acc, v, std::make_integer_sequence<int, NA>{});
     }
-    for (size_t c = n4 * 4 + (size_t)blockIdx.x * GB + threadIdx.x; c < n; c += stride) {
+    for (size_t c = n4 * 4 + col0; c < n; c += stride) {
         float v[M];
 #pragma unroll
         for (int i = 0; i < M; ++i) v[i] = G[(size_t)sel.idx[i] * ld + c];
-        int p = 0;
-#pragma unroll
-        for (int i = 0; i < M; ++i)
-#pragma unroll
-            for (int j = i; j < M; ++j) acc[p++] += (double)v[i] * (double)v[j];
+        gram_acc1<M, S, GRP>(acc, v, std::make_integer_sequence<int, NA>{});
     }
-    __shared__ double red[GB];
-    for (int p = 0; p < NP; ++p) {
-        red[threadIdx.x] = acc[p];
+    // fixed tree: first over the wave sets (offsets that keep wave % S), then inside the wave; one pair slot per round
+#pragma unroll
+    for (int k = 0; k < NA_MAX; ++k) {
+        red[tid] = (k < NA) ? acc[k < NA ? k : 0] : 0.0;
         __syncthreads();
-        for (int o = GB / 2; o > 0; o >>= 1) {
-            if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        for (int o = GB / 2; o >= 64 * S; o >>= 1) {
+            if (tid < o) red[tid] += red[tid + o];
             __syncthreads();
         }
-        if (threadIdx.x == 0) partial[(size_t)blockIdx.x * NP + p] = red[0];
+        for (int o = 32; o > 0; o >>= 1) {
+            if (tid < 64 * S && lane < o) red[tid] += red[tid + o];
+            __syncthreads();
+        }
+        if (tid < 64 * S && lane == 0 && GRP + k * S < NP) partial[(size_t)blockIdx.x * NP + GRP + k * S] = red[tid];
         __syncthreads();
+    }
+}
+
+template <int M, bool VEC>
+__global__ __launch_bounds__(GB) void gram_partial_kernel(const float* __restrict__ G, size_t ld, RowSel sel, size_t n,
+                                                          double* __restrict__ partial) {
+    constexpr int S = gram_split(M);
+    __shared__ double red[GB];
+    const int grp = (threadIdx.x >> 6) % S;               // uniform per wave; every wave runs the same number of barriers
+    if constexpr (S == 1) {
+        gram_partial_body<M, 1, 0, VEC>(G, ld, sel, n, partial, red);
+    } else if constexpr (S == 2) {
+        if (grp) gram_partial_body<M, 2, 1, VEC>(G, ld, sel, n, partial, red);
+        else gram_partial_body<M, 2, 0, VEC>(G, ld, sel, n, partial, red);
+    } else {
+        if (grp == 0) gram_partial_body<M, 4, 0, VEC>(G, ld, sel, n, partial, red);
+        else if (grp == 1) gram_partial_body<M, 4, 1, VEC>(G, ld, sel, n, partial, red);
+        else if (grp == 2) gram_partial_body<M, 4, 2, VEC>(G, ld, sel, n, partial, red);
+        else gram_partial_body<M, 4, 3, VEC>(G, ld, sel, n, partial, red);
     }
 }
 
@@ -141,9 +193,16 @@ __global__ __launch_bounds__(GB) void project_kernel(const float* __restrict__ G
 // info[0] = number of violated constraints g.G_k < 0 (gem.py:275-277: 0 => no projection), info[1] = status (0 ok).
 constexpr int QP_MAX = 16;
 
-__device__ void qp_inverse_spd(const double (*A)[QP_MAX], int n, double (*Inv)[QP_MAX]) {
+// Every array of the solver is indexed at run time, which in registers / private memory means scratch (80 scratch
+// instructions in the round-3 build): the one lane that solves keeps its matrices in LDS instead.
+struct QpWork {
+    double G[QP_MAX][QP_MAX], Ginv[QP_MAX][QP_MAX], L[QP_MAX][QP_MAX], Li[QP_MAX][QP_MAX], S[QP_MAX][QP_MAX], B[QP_MAX][QP_MAX];
+    double a[QP_MAX], x[QP_MAX], b[QP_MAX], z[QP_MAX], r[QP_MAX], u[QP_MAX + 1];
+    int active[QP_MAX];
+};
+
+__device__ void qp_inverse_spd(const double (*A)[QP_MAX], int n, double (*Inv)[QP_MAX], double (*L)[QP_MAX], double (*Li)[QP_MAX]) {
     // Cholesky A = L L^T, Linv by forward substitution, Inv = Linv^T Linv (numpy: cholesky, inv, Linv.T @ Linv)
-    double L[QP_MAX][QP_MAX], Li[QP_MAX][QP_MAX];
     for (int i = 0; i < n; ++i)
         for (int j = 0; j <= i; ++j) {
             double s = A[i][j];
@@ -191,6 +250,7 @@ __device__ void qp_solve(double (*S)[QP_MAX], double (*B)[QP_MAX], int na, int n
 
 __global__ void gem_qp_kernel(const double* __restrict__ gram, int m, double margin, double eps, double* __restrict__ v_out,
                               int* __restrict__ info) {
+    __shared__ QpWork W;
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const int n = m - 1;                                   // unknowns = memory rows; row / column n = current gradient
     int viol = 0;
@@ -200,20 +260,22 @@ __global__ void gem_qp_kernel(const double* __restrict__ gram, int m, double mar
     for (int i = 0; i < n; ++i) v_out[i] = 0.0;
     if (viol == 0) return;
     const double tol = 1e-12;
-    double G[QP_MAX][QP_MAX], Ginv[QP_MAX][QP_MAX], a[QP_MAX], x[QP_MAX], b[QP_MAX];
+    double (*G)[QP_MAX] = W.G, (*Ginv)[QP_MAX] = W.Ginv;
+    double *a = W.a, *x = W.x, *b = W.b;
     for (int i = 0; i < n; ++i) {
         for (int j = 0; j < n; ++j) G[i][j] = 0.5 * (gram[(size_t)i * m + j] + gram[(size_t)j * m + i]) + (i == j ? eps : 0.0);
         a[i] = -gram[(size_t)i * m + n];                   // q = -M g; quadprog minimises 1/2 x^T G x - a^T x with a = q
         b[i] = margin;
     }
-    qp_inverse_spd(G, n, Ginv);
+    qp_inverse_spd(G, n, Ginv, W.L, W.Li);
     for (int i = 0; i < n; ++i) {
         double s = 0.0;
         for (int j = 0; j < n; ++j) s += Ginv[i][j] * a[j];
         x[i] = s;                                          // unconstrained minimum
     }
-    int active[QP_MAX], na = 0;
-    double u[QP_MAX + 1];
+    int* active = W.active;
+    int na = 0;
+    double* u = W.u;
     for (int it = 0; it < 200; ++it) {
         // constraints are v_i >= margin (C = I): slack s_i = x_i - b_i; most violated inactive one
         int p = -1;
@@ -230,10 +292,10 @@ __global__ void gem_qp_kernel(const double* __restrict__ gram, int m, double mar
         }
         u[na] = 0.0;
         for (int inner = 0; inner < 200; ++inner) {
-            double z[QP_MAX], r[QP_MAX];
+            double *z = W.z, *r = W.r;
             if (na > 0) {
                 // Nstar = (N^T Ginv N)^-1 N^T Ginv ; H = Ginv - Ginv N Nstar ; z = H n_p ; r = Nstar n_p   (n_p = e_p)
-                double S[QP_MAX][QP_MAX], B[QP_MAX][QP_MAX];
+                double (*S)[QP_MAX] = W.S, (*B)[QP_MAX] = W.B;
                 for (int i = 0; i < na; ++i) {
                     for (int j = 0; j < na; ++j) S[i][j] = Ginv[active[i]][active[j]];
                     for (int j = 0; j < n; ++j) B[i][j] = Ginv[active[i]][j];
@@ -274,9 +336,10 @@ template <bool VEC>
 __global__ __launch_bounds__(GB) void project_dev_kernel(const float* __restrict__ G, size_t ld, RowSel sel, const double* __restrict__ v,
                                                          const int* __restrict__ info, int m, const float* __restrict__ g,
                                                          float* __restrict__ out, size_t n) {
-    if (info[0] == 0 && out == g) return;                   // no violated constraint: the gradient stays as it is
-    double cv[MAXM];
-    for (int i = 0; i < m; ++i) cv[i] = info[0] == 0 ? 0.0 : (double)(float)v[i];     // v rounded to fp32 as torch.Tensor(x) does downstream
+    if (info[0] == 0 && out == g) return;                   // no violated constraint: the gradient stays as it is (block-uniform)
+    __shared__ double cv[MAXM];                             // (indexed at run time: LDS, not scratch)
+    if ((int)threadIdx.x < m) cv[threadIdx.x] = info[0] == 0 ? 0.0 : (double)(float)v[threadIdx.x];   // v rounded to fp32 as torch.Tensor(x) does downstream
+    __syncthreads();
     size_t stride = (size_t)gridDim.x * GB;
     const size_t n4 = VEC ? n / 4 : 0;
     for (size_t c4 = (size_t)blockIdx.x * GB + threadIdx.x; c4 < n4; c4 += stride) {
@@ -333,7 +396,7 @@ int clhip_gem_gram(const float* G, size_t ld, const int* row_idx_host, int m, si
     for (int i = 0; i < m; ++i) sel.idx[i] = row_idx_host[i];
     hipStream_t s = as_stream(stream);
     const bool vec = aligned16(G) && (ld % 4 == 0);
-    int blocks = ew_grid(vec ? n / 4 + 1 : n, GB);
+    int blocks = ew_grid(vec ? n / 4 + 1 : n, GB / gram_split(m));
     if (blocks > GRAM_BLOCKS) blocks = GRAM_BLOCKS;
     double* partial = static_cast<double*>(ws);
     switch (m) {

@@ -74,8 +74,8 @@ def build_parser():
     p.add_argument("--no_speculation", action="store_true",
                    help="with --shard: phase 2 runs sequentially on rank 0 only; its model and state are broadcast")
     p.add_argument("--synthetic", type=str, default=None,
-                   help="command-line runs: tasks,classes,train,val,test,hw[,noise[,kind]] of a synthetic task sequence "
-                        "(clsurvey_amd.framework.tasks; kind = protos | blobs, see data.synthetic_task), "
+                   help="command-line runs: tasks,classes,train,val,test,hw[,noise[,kind[,g,amp,noise_lr,q]]] of a synthetic task "
+                        "sequence (clsurvey_amd.framework.tasks; kind = protos | blobs, see data.synthetic_task), "
                         "e.g. 10,20,8000,2000,1000,64 = Tiny-ImageNet's shape")
     return p
 
@@ -628,9 +628,10 @@ def main(argv=None, method=None, dataset=None, train_node_factory=None):
         fields = args.synthetic.split(",")
         n_tasks, n_cls, n_tr, n_va, n_te, hw = [int(v) for v in fields[:6]]
         kind = fields[7] if len(fields) > 7 else "protos"
+        blobs = dict(zip(("g", "amp", "noise_lr", "q"), (float(v) for v in fields[8:12]))) or None
         dataset = SyntheticTaskSequence(os.path.join(args.results_root, "data"), task_count=n_tasks, classes_per_task=n_cls,
                                         sizes=(n_tr, n_va, n_te), hw=hw, noise=float(fields[6]) if len(fields) > 6 else 1.0,
-                                        kind=kind)
+                                        kind=kind, blobs=blobs)
     set_random(7)                                                 # utils.init -> set_random()
     if method is None:
         method = methods.parse(args.method_name)

@@ -733,19 +733,29 @@ def test_gem_gram_and_project_kernels():
     import ctypes as C
     from clsurvey_amd import _lib
     gen = np.random.RandomState(5)
-    n, ld, nt = 100003, 100008, 10
+    n, ld, nt = 100003, 100008, 16
     Gh = gen.standard_normal((nt, ld)).astype(np.float32)
     G = torch.from_numpy(Gh).to(dev())
     L = _lib.lib()
     ws = torch.zeros(L.clhip_gem_gram_ws(16), dtype=torch.uint8, device=dev())
-    for rows in ([3], [0, 2, 9], list(range(10)), [7, 1, 4, 8, 2, 6]):
+    # every row count 1..16 (one template instance each: one wave set up to 8 rows, the pairs split over 2 / 4 waves
+    # beyond), rows in any order; then the scalar path (a row stride that is not a multiple of 4 floats)
+    cases = [[3], [0, 2, 9], [7, 1, 4, 8, 2, 6]] + [list(gen.permutation(nt)[:m]) for m in range(1, 17)]
+    for rows in cases:
         m = len(rows)
         out = torch.zeros(m * m, dtype=torch.float64, device=dev())
-        idx = (C.c_int * m)(*rows)
+        idx = (C.c_int * m)(*[int(r) for r in rows])
         assert L.clhip_gem_gram(G.data_ptr(), ld, idx, m, n, out.data_ptr(), ws.data_ptr(), ws.numel(), None) == 0
         ref = Gh[rows, :n].astype(np.float64) @ Gh[rows, :n].astype(np.float64).T
         got = out.cpu().numpy().reshape(m, m)
-        assert np.abs(got - ref).max() <= 1e-10 * np.abs(ref).max()
+        assert np.abs(got - ref).max() <= 1e-10 * np.abs(ref).max(), rows
+    ld2 = ld - 1
+    G2 = torch.from_numpy(np.ascontiguousarray(Gh[:, :ld2])).to(dev())
+    for m in (2, 9, 12, 16):
+        out = torch.zeros(m * m, dtype=torch.float64, device=dev())
+        assert L.clhip_gem_gram(G2.data_ptr(), ld2, (C.c_int * m)(*range(m)), m, n, out.data_ptr(), ws.data_ptr(), ws.numel(), None) == 0
+        ref = Gh[:m, :n].astype(np.float64) @ Gh[:m, :n].astype(np.float64).T
+        assert np.abs(out.cpu().numpy().reshape(m, m) - ref).max() <= 1e-10 * np.abs(ref).max(), m
     rows, v = [0, 2, 9], [0.5, 1.25, -0.75]
     g = torch.from_numpy(gen.standard_normal(n).astype(np.float32)).to(dev())
     o = torch.empty(n, device=dev())
