@@ -96,6 +96,7 @@ def parse():
     ap.add_argument("--sweep-only", action="store_true", help="print only the `sweep` object (tuning the synthetic sequence)")
     ap.add_argument("--pair-cpu-leg", type=str, default=None, help="internal: run one CPU leg of the sweep pair under this root")
     ap.add_argument("--pair-threads", type=int, default=16)
+    ap.add_argument("--pair-pin", type=int, default=-1, help="internal: first logical CPU of this leg's affinity set (-1: not pinned)")
     ap.add_argument("--sweep-blobs", type=str, default=None, help="tuning: g,amp,noise_lr,q of the sweep's synthetic tasks")
     return ap.parse_args()
 
@@ -581,12 +582,14 @@ class _PassCounter:
 
 # ------------------------------------------------------------------------------------------------ sweep + like-for-like pair
 # Synthetic task sequence of the sweeps: clsurvey_amd.data.synthetic_task(kind="blobs") — coarse colour patterns with coarse and
-# pixel noise and OVERLAPPING classes (q = 0.7: the best possible top-1 accuracy is 71.5 % whatever the model), so that a trained
+# pixel noise and OVERLAPPING classes (q = 0.9: the best possible top-1 accuracy is 90.5 % whatever the model; measured at
+# q = 0.7 the batch-summed Fisher of main_EWC.py:138-157 grows until no lambda of the ten halvings from 400 keeps the
+# penalised SGD stable at the grid's learning rates, and the reference's loop ends without a model), so that a trained
 # model keeps a non-trivial Fisher diagonal, the stability-decay loop has something to decide, and accuracies saturate at a
 # level the data sets.  Models start from torchvision's initialisation (models.py, VGGSlim.py / torchvision VGG: Kaiming
 # convolutions, N(0, 0.01) classifier), created by the driver's BaseModel as the reference's models/net.py:158-169 does.
-SWEEP_DATA = {"kind": "blobs", "noise": 0.5, "blobs": {"g": 8, "amp": 4.0, "noise_lr": 1.2, "q": 0.7}}
-PAIR = {"sizes": (2000, 500, 500), "epochs": 8, "batch": 50, "lr": "1e-2", "lam": 400.0}
+SWEEP_DATA = {"kind": "blobs", "noise": 0.5, "blobs": {"g": 8, "amp": 4.0, "noise_lr": 1.2, "q": 0.9}}
+PAIR = {"sizes": (2000, 500, 500), "epochs": 6, "batch": 50, "lr": "1e-2", "lam": 400.0}
 
 
 def _pair_args(device):
@@ -615,7 +618,7 @@ def _pair_summary(out, seconds, passes):
             "trainings_in_phase2": len(out["frameworks"][-1].trace), "omega_sum": osum}
 
 
-def pair_cpu_leg(root, threads):
+def pair_cpu_leg(root, threads, pin_from=None):
     """One CPU leg of the pair (runs in its own process, `bench.py --pair-cpu-leg ROOT --pair-threads T`): the build's driver
     with oracle/sweep_ref.py's torch-CPU EWC on `threads` host threads, from the first-task model found under ROOT."""
     import contextlib
@@ -624,12 +627,20 @@ def pair_cpu_leg(root, threads):
     from oracle import sweep_ref
     torch.set_num_threads(threads)
     meth = sweep_ref.OracleEWC("small_VGG9")
+    pinned = None
+    if pin_from is not None and hasattr(os, "sched_setaffinity"):
+        try:                                    # its own cores: the other CPU leg runs beside this one
+            os.sched_setaffinity(0, range(pin_from, pin_from + threads))
+            pinned = [pin_from, pin_from + threads - 1]
+        except OSError:
+            pass
     with contextlib.redirect_stdout(io.StringIO()):
         t0 = time.perf_counter()
         out = driver.main(_pair_args("cpu") + _pair_fixed() + ["--results_root", root], method=meth)
         dt = time.perf_counter() - t0
     res = _pair_summary(out, dt, meth.image_passes)
     res["threads"] = torch.get_num_threads()
+    res["pinned_to_logical_cpus"] = pinned
     res["rates_images_per_s"] = {"forward_backward_update": meth.image_passes["train"] / max(meth.seconds["train"], 1e-9),
                                  "forward_only": meth.image_passes["eval"] / max(meth.seconds["eval"], 1e-9)}
     return res
@@ -682,12 +693,16 @@ def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epoch
                 driver.main(_pair_args(dev) + ["--results_root", proot, "--method_name", "SI", "--runmode", "first_task_basemodel_dump"],
                             method=M.parse("SI"))
             other = cpu_threads // 2 if cpu_threads >= 32 else min(2 * cpu_threads, os.cpu_count() or cpu_threads)
-            for t in [cpu_threads] + ([other] if other != cpu_threads else []):
+            ncpu = os.cpu_count() or 1
+            for leg_no, t in enumerate([cpu_threads] + ([other] if other != cpu_threads else [])):
                 croot = os.path.join(root, "pair_cpu_t%d" % t)
+                # (logical CPUs [0, n/4) and [n/4, n/2): distinct physical cores, on a two-socket host distinct sockets; the
+                # upper half are the SMT siblings.  Not pinned on small hosts.)
+                pin = leg_no * (ncpu // 4) if ncpu >= 4 * max(cpu_threads, other) else -1
                 for sub in ("data", "models", os.path.join("train", "synthetic_tiny_imagenet", "SI")):
                     shutil.copytree(os.path.join(proot, sub), os.path.join(croot, sub))
                 env = dict(os.environ, OMP_NUM_THREADS=str(t), MKL_NUM_THREADS=str(t))
-                legs.append((t, subprocess.Popen([sys.executable, os.path.abspath(__file__), "--pair-cpu-leg", croot, "--pair-threads", str(t), "--sweep-blobs",
+                legs.append((t, subprocess.Popen([sys.executable, os.path.abspath(__file__), "--pair-cpu-leg", croot, "--pair-threads", str(t), "--pair-pin", str(pin), "--sweep-blobs",
                                                   ",".join("%g" % SWEEP_DATA["blobs"][k] for k in ("g", "amp", "noise_lr", "q"))],
                                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True)))
             with contextlib.redirect_stdout(quiet), _PassCounter(PAIR["sizes"][0]) as pcounts:
@@ -791,12 +806,14 @@ def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epoch
     return res
 
 
-def sharded_sweep(dev_index, world, epochs=3, sizes=(2000, 500, 500)):
-    """N > 1: SURVEY 8(e) as the build runs it — `driver.main(... --shard)` on a bounded 2-task EWC sequence: phase-1 grid
-    nodes spread over the ranks (all_gather of accuracies, winner's model files broadcast from the rank that trained it),
-    speculative stability decay (one attempt per rank in flight, accepted attempt's files broadcast), evaluation pairs
-    spread over the ranks (all_gather).  Every rank calls this; returns {seconds, nodes, fill factor, collective traffic of
-    this rank} — models and metrics only, nothing on the per-batch path."""
+def sharded_sweep(dev_index, world, epochs=8, sizes=(2000, 500, 500), batch=50):
+    """SURVEY 8(e) as the build runs it — `driver.main(... --shard)` on a bounded 2-task EWC sequence of SWEEP_DATA tasks, the SAME
+    work at every world size (so that 1 -> 8 GPUs is a strong-scaling curve of the framework itself; at world 1 --shard
+    changes nothing and this is the sequential driver): phase-1 grid nodes spread over the ranks (all_gather of accuracies,
+    winner's model files broadcast from the rank that trained it), speculative stability decay (one attempt per rank in
+    flight, accepted attempt's files broadcast), evaluation pairs spread over the ranks (all_gather).  Every rank calls this;
+    returns seconds, fill factor, what THIS rank did per stage and its collective traffic — models and metrics only,
+    nothing on the per-batch path."""
     import contextlib
     import io
     import shutil
@@ -804,9 +821,10 @@ def sharded_sweep(dev_index, world, epochs=3, sizes=(2000, 500, 500)):
     from clsurvey_amd.framework import driver, shard
     from clsurvey_amd.methods import method as M
     root = tempfile.mkdtemp(prefix="clhip_shard_")
-    spec = "2,20,%d,%d,%d,64" % tuple(sizes)
-    common = ["small_VGG9_cl_128_128", "--num_epochs", str(epochs), "--synthetic", spec, "--device", "cuda:%d" % dev_index,
-              "--results_root", root, "--shard"]
+    b = SWEEP_DATA["blobs"]
+    spec = "2,20,%d,%d,%d,64,%g,%s,%g,%g,%g,%g" % (tuple(sizes) + (SWEEP_DATA["noise"], SWEEP_DATA["kind"], b["g"], b["amp"], b["noise_lr"], b["q"]))
+    common = ["small_VGG9_cl_128_128", "--num_epochs", str(epochs), "--batch_size", str(batch), "--synthetic", spec,
+              "--device", "cuda:%d" % dev_index, "--results_root", root, "--shard"]
     before = dict(shard.STATS)
     quiet = io.StringIO()
     try:
@@ -815,16 +833,27 @@ def sharded_sweep(dev_index, world, epochs=3, sizes=(2000, 500, 500)):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             driver.main(common + ["--method_name", "SI", "--runmode", "first_task_basemodel_dump"], method=M.parse("SI"))
+            t1 = time.perf_counter()
             out = driver.main(common + ["--method_name", "EWC", "--test"], method=M.parse("EWC"))
             torch.cuda.synchronize()
             shard.barrier()
             dt = time.perf_counter() - t0
         hf = out["frameworks"][-1]
-        return {"what": "driver.main --shard: SI first-task grid + EWC task 2 (5-LR grid, speculative stability decay, sharded "
-                        "evaluation), %d/%d/%d images per task, %d-epoch cap" % (tuple(sizes) + (epochs,)),
-                "seconds": dt, "grid_nodes_per_task": 5, "fill_factor": shard.fill_factor(5, world),
-                "attempts_task2": hf.attempts + 1, "accuracies": {i: r["seq_res"][i] for i, r in sorted(out["results"].items())},
-                "collectives_this_rank": {k: shard.STATS[k] - before[k] for k in shard.STATS}}
+        d = {k: shard.STATS[k] - before[k] for k in shard.STATS}
+        busy = d["grid_busy_s"] + d["decay_busy_s"] + d["eval_busy_s"]
+        return {"what": "driver.main --shard: SI first-task grid + EWC task 2 (5-LR grid, stability decay from lambda 400, "
+                        "evaluation), %d/%d/%d images of 3x64x64 per task, batch %d, %d-epoch cap — the same work at every world size"
+                        % (tuple(sizes) + (batch, epochs)),
+                "world": world, "seconds": dt, "first_task_seconds": t1 - t0,
+                "grid_nodes_per_task": 5, "fill_factor_grid": shard.fill_factor(5, world),
+                "phase2_trainings_task2": len(hf.trace), "accepted_lambda_task2": float(hf.trace[-1][0]["lambda"]) if hf.trace else None,
+                "accuracies": {i: r["seq_res"][i] for i, r in sorted(out["results"].items())},
+                "this_rank": {"grid_nodes": d["grid_nodes"], "grid_busy_s": d["grid_busy_s"],
+                              "decay_attempts": d["decay_attempts"], "decay_busy_s": d["decay_busy_s"],
+                              "eval_pairs": d["eval_pairs"], "eval_busy_s": d["eval_busy_s"],
+                              "busy_fraction": busy / dt if dt > 0 else 0.0},
+                "collectives_this_rank": {k: d[k] for k in ("broadcast_calls", "broadcast_bytes", "broadcast_s", "all_gather_calls",
+                                                            "all_gather_bytes", "all_gather_s", "all_reduce_calls", "all_reduce_s")}}
     finally:
         shutil.rmtree(root, ignore_errors=True)
 
@@ -894,7 +923,7 @@ def main():
     if args.sweep_blobs:
         SWEEP_DATA["blobs"] = dict(zip(("g", "amp", "noise_lr", "q"), (float(v) for v in args.sweep_blobs.split(","))))
     if args.pair_cpu_leg:                      # a CPU leg of the sweep pair, in its own process (no GPU work)
-        print(json.dumps(pair_cpu_leg(args.pair_cpu_leg, args.pair_threads)), flush=True)
+        print(json.dumps(pair_cpu_leg(args.pair_cpu_leg, args.pair_threads, args.pair_pin if args.pair_pin >= 0 else None)), flush=True)
         return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -1034,9 +1063,13 @@ def main():
     }
     if grid is not None:
         out["grid"] = grid
-    if dist and not args.no_sweep:
-        # second number of the N > 1 line: the sharded framework itself on a bounded task sequence (every rank takes part)
-        out["grid"]["sharded_driver"] = sharded_sweep(local_rank, world)
+    if not args.no_sweep:
+        # second number of the line at EVERY N (1 included: the anchor of the curve): the framework itself through
+        # `driver --shard` on a bounded task sequence, the same work whatever the world size (every rank takes part)
+        try:
+            out["sharded_sweep"] = sharded_sweep(local_rank, world)
+        except BaseException as e:       # the headline line is printed regardless (stage failures are collective: shard.all_ok)
+            out["sharded_sweep"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     if rank == 0:
         agg = {}
         for r in rows:

@@ -404,7 +404,10 @@ int clhip_net_layer_paths(void* handle, int layer) {
     NetPlan* p = static_cast<NetPlan*>(handle);
     if (!p || layer < 0 || layer >= (int)p->layers.size()) return CLHIP_EINVAL;
     const LayerPlan& L = p->layers[layer];
-    return (L.wino_f ? 1 : 0) | (L.wino_d ? 2 : 0) | (L.wino_w ? 4 : 0);
+    // (bit 2: the Winograd weight gradient runs only inside the deferred-reduction scheme, net_backward_impl's `defer`; and even
+    // then the kernel may hand single shapes back to the direct path — odd maps with a fused un-pool, > 2^31-byte offsets)
+    const bool defer_capable = p->n_wg > 0 && !(p->overlap && p->overlap_mode == 1);
+    return (L.wino_f ? 1 : 0) | (L.wino_d ? 2 : 0) | ((L.wino_w && defer_capable) ? 4 : 0);
 }
 
 int clhip_net_set_input_grad(void* handle, int layer, const float* extra) {
@@ -493,16 +496,16 @@ static bool tail_usable(const NetPlan* p, const float* params, const void* ws, i
 
 // transformed weights of every Winograd layer (forward set, backward-data set, or both) in one launch
 static int wino_prepare(NetPlan* p, const float* params, char* base, bool fwd, bool bwd, hipStream_t s) {
-    clhip_wino_wt jobs[64];
-    int n = 0;
+    std::vector<clhip_wino_wt> jobs;                     // (sized by the plan: a net of any depth gets every transform)
+    jobs.reserve(2 * p->layers.size());
     for (const LayerPlan& L : p->layers) {
         if (L.type != 0) continue;
-        if (fwd && L.wino_f && n < 64)
-            jobs[n++] = clhip_wino_wt{params + L.w_off, reinterpret_cast<float*>(base + p->off_wino + L.wino_uf), L.cout, L.cin, 0, 0};
-        if (bwd && L.wino_d && n < 64)
-            jobs[n++] = clhip_wino_wt{params + L.w_off, reinterpret_cast<float*>(base + p->off_wino + L.wino_ud), L.cin, L.cout, 1, 0};
+        if (fwd && L.wino_f)
+            jobs.push_back(clhip_wino_wt{params + L.w_off, reinterpret_cast<float*>(base + p->off_wino + L.wino_uf), L.cout, L.cin, 0, 0});
+        if (bwd && L.wino_d)
+            jobs.push_back(clhip_wino_wt{params + L.w_off, reinterpret_cast<float*>(base + p->off_wino + L.wino_ud), L.cin, L.cout, 1, 0});
     }
-    return clhip_internal_wino_weights(jobs, n, s);
+    return clhip_internal_wino_weights(jobs.data(), (int)jobs.size(), s);
 }
 
 static int net_forward_impl(void* handle, const float* params, const float* x, int N, void* ws, float* logits_out,
@@ -767,9 +770,13 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
         bool ddone = false;
         // measurement probe around this layer's backward-data / weight-gradient launch(es) (clhip_net_probe_kind)
         auto probe_on = [&](int kind) { return i == p->probe_layer && p->probe_kind == kind && !p->probe_ev.empty(); };
-        auto probe_begin = [&](int kind) { if (probe_on(kind)) (void)hipEventRecord(p->probe_ev[2 * (p->probe_count % PROBE_RING)], main_s); };
+        // (events go on the stream the launch is issued on: a weight-gradient launch may run on the side stream, on_side)
+        auto probe_stream = [&](int kind) { return (kind == 2 && side_ok(i)) ? p->side : main_s; };
+        auto probe_begin = [&](int kind) {
+            if (probe_on(kind)) (void)hipEventRecord(p->probe_ev[2 * (p->probe_count % PROBE_RING)], probe_stream(kind));
+        };
         auto probe_end = [&](int kind) {
-            if (probe_on(kind)) { (void)hipEventRecord(p->probe_ev[2 * (p->probe_count % PROBE_RING) + 1], main_s); ++p->probe_count; }
+            if (probe_on(kind)) { (void)hipEventRecord(p->probe_ev[2 * (p->probe_count % PROBE_RING) + 1], probe_stream(kind)); ++p->probe_count; }
         };
         float* gout_d = nullptr;
         int gout_d_buf = -1;

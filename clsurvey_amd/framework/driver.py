@@ -185,7 +185,9 @@ def lr_grid_single_task(args, manager, save_models_mode="keep_none", train_node=
             set_random(it)                                       # lr_grid_train.py:73,77
             manager.gridsearch_exp_dir = node_dir(lr, it)
             os.makedirs(manager.gridsearch_exp_dir, exist_ok=True)
-            _, acc = manager.method.grid_train(args, manager, lr)
+            from . import shard
+            with shard.busy("grid"):                             # (stage accounting only: shard.STATS, bench.py's N = 1 anchor)
+                _, acc = manager.method.grid_train(args, manager, lr)
             return acc
 
     best_acc, best_lr = 0, None
@@ -345,7 +347,9 @@ class HyperparameterFramework(object):
             t0 = time.time()
             try:
                 manager.method.hyperparams = self.hyperparams
-                model, task_lr_acc = manager.method.train(args, manager, self.hyperparams)
+                from . import shard
+                with shard.busy("decay"):
+                    model, task_lr_acc = manager.method.train(args, manager, self.hyperparams)
             except Exception:
                 traceback.print_exc()
                 sys.exit(1)
@@ -546,7 +550,8 @@ def eval_all_models_all_tasks(args, manager, ds_paths, model_paths):
             seq_acc, seq_forgetting = {dataset_index: []}, {dataset_index: []}
             for trained_model_idx in range(dataset_index, len(ds_paths)):
                 try:
-                    accuracy = evaluate(dataset_index, trained_model_idx)
+                    with shard.busy("eval"):
+                        accuracy = evaluate(dataset_index, trained_model_idx)
                 except Exception:
                     print("ERROR in Testing model, trained until TASK ", str(trained_model_idx + 1))
                     print("Aborting testing on further models")
@@ -569,7 +574,9 @@ def eval_all_models_all_tasks(args, manager, ds_paths, model_paths):
             pairs = [(i, j) for i in tasks for j in range(i, len(ds_paths))]
     table, err = {}, None
     try:
-        table = {n: evaluate(*pq) for n, pq in enumerate(pairs) if n % world == rank}
+        mine = [(n, pq) for n, pq in enumerate(pairs) if n % world == rank]
+        with shard.busy("eval", len(mine)):
+            table = {n: evaluate(*pq) for n, pq in mine}
     except Exception as e:
         traceback.print_exc()
         err = e

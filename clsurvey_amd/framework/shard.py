@@ -31,7 +31,46 @@ import torch.distributed as dist
 
 
 # traffic of this process's collectives since import (bench.py --gpus N reports it: models and metrics only)
-STATS = {"broadcast_calls": 0, "broadcast_bytes": 0, "all_gather_calls": 0, "all_gather_bytes": 0, "all_reduce_calls": 0}
+STATS = {"broadcast_calls": 0, "broadcast_bytes": 0, "broadcast_s": 0.0, "all_gather_calls": 0, "all_gather_bytes": 0,
+         "all_gather_s": 0.0, "all_reduce_calls": 0, "all_reduce_s": 0.0,
+         # seconds THIS rank spent training / evaluating inside each sharded stage (what filled its GPU), and the units it ran
+         "grid_busy_s": 0.0, "grid_nodes": 0, "decay_busy_s": 0.0, "decay_attempts": 0, "eval_busy_s": 0.0, "eval_pairs": 0}
+
+
+class busy:
+    """with shard.busy("grid"): ...   adds the block's wall-clock to STATS["grid_busy_s"] and `units` to its unit counter."""
+    _unit = {"grid": "grid_nodes", "decay": "decay_attempts", "eval": "eval_pairs"}
+
+    def __init__(self, stage, units=1):
+        self.stage, self.units = stage, units
+
+    def __enter__(self):
+        import time
+        self.t0 = time.perf_counter()
+
+    def __exit__(self, *exc):
+        import time
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        STATS[self.stage + "_busy_s"] += time.perf_counter() - self.t0
+        STATS[self._unit[self.stage]] += self.units
+
+
+class _timed:
+    """Wall-clock of a collective as this rank sees it (waiting for the slowest rank included), into STATS[key]."""
+
+    def __init__(self, key):
+        self.key = key
+
+    def __enter__(self):
+        import time
+        self.t0 = time.perf_counter()
+
+    def __exit__(self, *exc):
+        import time
+        if dist.is_initialized() and dist.get_backend() == "nccl":
+            torch.cuda.synchronize()
+        STATS[self.key] += time.perf_counter() - self.t0
 
 
 def rank_world():
@@ -79,14 +118,16 @@ def gather_scalars(values):
         return dict(values)
     n = torch.tensor([len(values)], dtype=torch.int64, device=_dev())
     counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n)
+    with _timed("all_gather_s"):
+        dist.all_gather(counts, n)
     STATS["all_gather_calls"] += 2
     m = max(int(c.item()) for c in counts)
     buf = torch.full((max(m, 1), 2), -1.0, dtype=torch.float64, device=_dev())
     for j, (k, v) in enumerate(sorted(values.items())):
         buf[j, 0], buf[j, 1] = float(k), float(v)
     bufs = [torch.zeros_like(buf) for _ in range(world)]
-    dist.all_gather(bufs, buf)
+    with _timed("all_gather_s"):
+        dist.all_gather(bufs, buf)
     STATS["all_gather_bytes"] += world * (8 + buf.numel() * 8)
     out = {}
     for b in bufs:
@@ -103,7 +144,8 @@ def broadcast_model(model, src=0):
         return model
     params = [p.data for p in model.parameters()]
     flat = torch.cat([p.reshape(-1).to(_dev(), torch.float32) for p in params])
-    dist.broadcast(flat, src=src)
+    with _timed("broadcast_s"):
+        dist.broadcast(flat, src=src)
     STATS["broadcast_calls"] += 1
     STATS["broadcast_bytes"] += flat.numel() * 4
     off = 0
@@ -120,14 +162,16 @@ def broadcast_bytes(payload, src):
     if world == 1:
         return payload
     n = torch.tensor([len(payload) if rank == src else 0], dtype=torch.int64, device=_dev())
-    dist.broadcast(n, src=src)
+    with _timed("broadcast_s"):
+        dist.broadcast(n, src=src)
     size = int(n.item())
     if rank == src:
         buf = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(_dev()) if size else torch.zeros(0, dtype=torch.uint8, device=_dev())
     else:
         buf = torch.zeros(size, dtype=torch.uint8, device=_dev())
     if size:
-        dist.broadcast(buf, src=src)
+        with _timed("broadcast_s"):
+            dist.broadcast(buf, src=src)
     STATS["broadcast_calls"] += 2 if size else 1
     STATS["broadcast_bytes"] += 8 + size
     return bytes(buf.cpu().numpy().tobytes())
@@ -179,7 +223,8 @@ def all_ok(ok, what=""):
     rank, world = rank_world()
     if world > 1:
         flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=_dev())
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        with _timed("all_reduce_s"):
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         STATS["all_reduce_calls"] += 1
         everyone = bool(int(flag.item()))
     else:
@@ -215,7 +260,8 @@ def sharded_grid_factory():
                     driver.set_random(it)
                     manager.gridsearch_exp_dir = node_dir(lr, it)
                     os.makedirs(manager.gridsearch_exp_dir, exist_ok=True)
-                    _, acc = manager.method.grid_train(args, manager, lr)
+                    with busy("grid"):
+                        _, acc = manager.method.grid_train(args, manager, lr)
                     mine[i] = acc
             except Exception as e:                        # reported collectively below
                 import traceback
@@ -273,7 +319,8 @@ def speculative_round(hf, args, manager, finetune_acc):
         os.makedirs(manager.heuristic_exp_dir, exist_ok=True)
         manager.method.hyperparams = twin.hyperparams
         try:
-            _, acc = manager.method.train(args, manager, twin.hyperparams)
+            with busy("decay"):
+                _, acc = manager.method.train(args, manager, twin.hyperparams)
             mine[k] = acc
         except Exception as e:
             import traceback

@@ -100,7 +100,11 @@ def conv3x3_wino_bwd_weight(x, dy, idx=None):
 
 
 def conv3x3_relu_pool_fwd(x, w, b):
-    """fused conv + bias + ReLU + 2x2 max-pool: returns (y_pool, idx_u8)."""
+    """fused conv + bias + ReLU + 2x2 max-pool: returns (y_pool, idx_u8).  idx codes are 0..4, NOT an index to gather with:
+    0..3 = window position r * 2 + c of the first maximum (ATen's order), 4 (CLHIP_POOL_DEAD, csrc/common.hpp) = the window's
+    maximum after ReLU is not positive — no gradient passes through it.  Only the fused-unpool consumers
+    (conv3x3_bwd_weight_unpool / conv3x3_bwd_data_unpool, which test `code == position`) take these codes;
+    maxpool_bwd (general k x k) takes the plain arg-max bytes of maxpool_fwd."""
     _chk(x, w, b)
     N, C, H, W = x.shape
     K = w.shape[0]

@@ -379,16 +379,16 @@ def test_engine_full_size_vs_oracle(name, N, hw):
     # ... and without forcing anything: the gradients as the executor delivers them against the fp64 oracle on the oracle's OWN
     # branch, in the l2 norm of each tensor (a flipped near-tie moves one row by ~1/sqrt(#pixels), so the element-wise bound
     # belongs to the forced comparison above; this one says the un-forced result is not merely right "up to branches"):
-    # l2 error <= 1e-2 of the tensor's norm, and no worse than 3x what the reference's own fp32 CPU arithmetic does
-    worst_l2 = 0.0
+    # l2 error <= 1e-2 of the tensor's norm (the reference's own fp32 CPU arithmetic is printed beside it: whichever of the two
+    # fp32 evaluations happens to flip a near-tie of a small batch carries that row's contribution, the other does not)
+    worst_l2 = worst_cpu = 0.0
     for i, (p, g32, g64) in enumerate(zip(m.parameters(), grads_ref, grads64)):
         nrm = max(float(g64.norm()), 1e-30)
         e_dev = float((p.grad.double().cpu() - g64).norm()) / nrm
-        e_cpu = float((g32.double() - g64).norm()) / nrm
-        worst_l2 = max(worst_l2, e_dev)
-        assert e_dev <= 1e-2 and e_dev <= max(1e-3, 3.0 * e_cpu), "grad %d un-forced: l2 %.3e (reference fp32: %.3e)" % (i, e_dev, e_cpu)
+        worst_l2, worst_cpu = max(worst_l2, e_dev), max(worst_cpu, float((g32.double() - g64).norm()) / nrm)
+        assert e_dev <= 1e-2, "grad %d un-forced: l2 error %.3e of its norm" % (i, e_dev)
     print("%s N=%d hw=%d: worst gradient element %.2e of scale on the forced branch; %d near-tie decisions differ from fp64; "
-          "un-forced l2 error <= %.2e" % (name, N, hw, worst, flips, worst_l2))
+          "un-forced l2 error <= %.2e (reference fp32 on CPU: %.2e)" % (name, N, hw, worst, flips, worst_l2, worst_cpu))
     del deep
     # eval-only pass leaves gradients untouched and reproduces the logits bit for bit
     before = eng.arena.grad.clone()
@@ -1471,21 +1471,17 @@ def test_engine_vgg_bn_variant_vs_oracle():
             assert_close(b.cpu(), rb, tol=1e-4, what=name + " (unchanged by eval)")
 
 
-@pytest.mark.parametrize("name", ["small_VGG9_cl_128_128_BN", "small_VGG9_cl_128_128_DROP", "small_VGG9_cl_128_128_DROP_BN",
-                                  "deep_VGG22_cl_512_512"])
-def test_model_name_training_step_matches_reference_g34(golden, name):
-    """One TRAINING-MODE step (BatchNorm batch statistics + running-stat update, the reference's own Dropout masks) of the
-    model the reference's factory built for this name (models/net.py:15-36, VGGSlim.py:27-76; G34): logits, loss, every
-    gradient and the BatchNorm buffers of the engine's step on the build's `parse_model_name` model against the reference's
-    tensors — 1e-3 of each tensor's scale (north_star), 2e-3 in the tensors a counted near-tie decision touches."""
+G34_NAMES = ["small_VGG9_cl_128_128_BN", "small_VGG9_cl_128_128_DROP", "small_VGG9_cl_128_128_DROP_BN", "deep_VGG22_cl_512_512"]
+
+
+def _g34_model(g, name):
+    """the build's model for `name` with the fixture's seeded parameters, its batch and the reference's Dropout masks"""
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
     import g20_common as GC
     from clsurvey_amd import models
-    from clsurvey_amd.net import NetEngine
-    g = golden("G34_model_names")
-    k = ["small_VGG9_cl_128_128_BN", "small_VGG9_cl_128_128_DROP", "small_VGG9_cl_128_128_DROP_BN", "deep_VGG22_cl_512_512"].index(name)
+    k = G34_NAMES.index(name)
     m = models.parse_model_name(name, (32, 32), 20)
     named = [(n, tuple(p.shape)) for n, p in m.named_parameters()]
     assert [n for n, _ in named] == [str(t) for t in g[name + "__param_names"]]
@@ -1496,37 +1492,55 @@ def test_model_name_training_step_matches_reference_g34(golden, name):
                 q = (1.0 + 2.0 * q) if n.endswith("weight") else q
             p.copy_(torch.from_numpy(q))
     x, y = (torch.from_numpy(a) for a in GC.batch(3450 + k, 6, 32, 20))
+    masks = {i: torch.from_numpy(g[name + "__dropmask%d" % i]) for i in range(sum(1 for f in g.files if f.startswith(name + "__dropmask")))}
+    positions = {n: GC.positions(int(np.prod(shape)), 3500 + 50 * k + j) for j, (n, shape) in enumerate(named)}
+    return m, x, y, masks, positions
+
+
+@pytest.mark.parametrize("name", G34_NAMES)
+def test_model_name_training_step_matches_reference_g34(golden, name):
+    """One TRAINING-MODE step (BatchNorm batch statistics + running-stat update, the reference's own Dropout masks) of the
+    model the reference's factory built for this name (models/net.py:15-36, VGGSlim.py:27-76; G34).  Three links:
+      * tests/test_oracle_golden.py (CPU): the torch-CPU oracle on the build's `parse_model_name` model reproduces the
+        reference's logits / loss / gradients / BatchNorm buffers of the fixture to 1e-5 — same module semantics;
+      * here: the engine's step against the fp64 oracle ON THE EXECUTOR'S BRANCH, every gradient element within 1e-4 of its
+        tensor's scale (north_star: 1e-3), differing decisions counted and near-ties (_forced_branch_grads);
+      * here: directly against the reference's fp32 tensors — 1e-3 per tensor, or 1.5x the reference's own distance from the
+        fp64 oracle where that is larger (BatchNorm over 6 x 2 x 2 elements and 22-layer nets amplify fp32 rounding)."""
+    from oracle import alexnet_ref
+    from clsurvey_amd.net import NetEngine
+    g = golden("G34_model_names")
+    m, x, y, masks, positions = _g34_model(g, name)
+    ref = copy.deepcopy(m).train()
+    ref64 = copy.deepcopy(m).double().train()
+    m64 = {i: mk.double() for i, mk in masks.items()} or None
+    l64, lo64, g64 = alexnet_ref.loss_and_grads(ref64, x.double(), y, m64)
     eng = NetEngine(m, 6, (3, 32, 32), dev())
     eng.auto_dropout = False
     drops = sorted(eng.drops)
-    assert len(drops) == sum(1 for f in g.files if f.startswith(name + "__dropmask"))
+    assert len(drops) == len(masks)
     for i, li in enumerate(drops):
-        eng.set_dropout(li, torch.from_numpy(g[name + "__dropmask%d" % i]).to(dev()))
+        eng.set_dropout(li, masks[i].to(dev()))
     m.train()
     loss, logits = eng.loss_step(x.to(dev()), y.to(dev()), "ce_mean", True, want_logits=True)
-    ref_logits = torch.from_numpy(g[name + "__logits"])
-    assert_close(logits.cpu(), ref_logits, tol=1e-3, what="logits")
-    assert abs(float(loss) - float(g[name + "__loss"][0])) <= 1e-3 * max(1.0, abs(float(g[name + "__loss"][0])))
-    gmax, worst = 0.0, 0.0
-    digests = []
-    for j, (n, _) in enumerate(named):
-        v, sums = g["%s__grad_%s__v" % (name, n)], g["%s__grad_%s__s" % (name, n)]
-        got = eng.arena.view("grad", dict(m.named_parameters())[n]).detach().cpu().numpy().reshape(-1)
-        assert got.size == int(sums[2])
-        digests.append((n, got[GC.positions(got.size, 3500 + 50 * k + j)], v))
-        gmax = max(gmax, float(np.abs(v).max()))
-    for n, got, v in digests:
-        # (a convolution bias in front of a BatchNorm has an exactly-zero true gradient: measured against 1e-4 of the net's largest entry)
-        e = float(np.abs(got - v).max()) / max(float(np.abs(v).max()), 1e-4 * gmax)
+    assert_fp32_parity(logits, torch.from_numpy(g[name + "__logits"]), lo64, "logits")
+    assert abs(float(loss) - float(l64)) <= max(1e-3, 1.5 * abs(float(g[name + "__loss"][0]) - float(l64))) * max(1.0, abs(float(l64)))
+    _forced_branch_grads(eng, m, ref, x, y, masks or None, "G34 " + name)
+    gmax = max(float(t.abs().max()) for t in g64)
+    worst = 0.0
+    for (n, p), t64 in zip(m.named_parameters(), g64):
+        pos = torch.from_numpy(positions[n])
+        got = eng.arena.view("grad", p).detach().cpu().reshape(-1)[pos]
+        # (a convolution bias in front of a BatchNorm has an exactly-zero true gradient: floor at 1e-4 of the net's largest entry)
+        e, _ = assert_fp32_parity(got, torch.from_numpy(g["%s__grad_%s__v" % (name, n)]), t64.reshape(-1)[pos], "grad " + n, floor=1e-4 * gmax)
         worst = max(worst, e)
-        assert e <= 2e-3, "%s grad %s: %.3e of its scale" % (name, n, e)
-    for n, b in m.named_buffers():
-        ref = g["%s__buf_%s" % (name, n)]
+    for (n, b), (_, b64) in zip(m.named_buffers(), ref64.named_buffers()):
+        want = g["%s__buf_%s" % (name, n)]
         if b.dtype == torch.float32:
-            assert_close(b.cpu(), torch.from_numpy(ref), tol=1e-4, what=n)
+            assert_fp32_parity(b, torch.from_numpy(want), b64, n, base=1e-4)
         else:
-            assert int(b) == int(ref), n
-    print("%s: training-mode step vs the reference's model: worst sampled gradient deviation %.2e of scale" % (name, worst))
+            assert int(b) == int(want), n
+    print("%s: training-mode step vs the reference's model: worst sampled gradient element %.2e of scale from the fp64 oracle" % (name, worst))
 
 
 def test_autograd_bridge_bn_drop_net_train_mode():

@@ -148,7 +148,14 @@ def test_hat_step_wide_vgg9_g20(golden, tag, hw, nb, seed):
         for j, (n, p) in enumerate(net.named_parameters()):
             key = "%s_s%d_grad_%s" % (tag, step, n)
             if key + "__v" in g.files:
-                worst = max(worst, _check(g, key, p.grad, seed + 199 + j, "step %d grad %s" % (step, n), flips=step > 0))
+                # north_star: 1e-3 — or 1.5x the reference's own distance from the fp64 oracle on this branch where that is larger
+                # (the first layer's weight gradient at 224 x 224 sums 200 000 cancelling terms per entry in fp32 on both sides)
+                tol = TOL
+                if g64.get(n) is not None and step == 0:
+                    ref_v = g[key + "__v"]
+                    v64 = g64[n].detach().cpu().numpy().reshape(-1)[C.positions(g64[n].numel(), seed + 199 + j)]
+                    tol = max(TOL, 1.5 * float(np.abs(ref_v - v64).max()) / max(float(np.abs(ref_v).max()), 1e-30))
+                worst = max(worst, _check(g, key, p.grad, seed + 199 + j, "step %d grad %s" % (step, n), tol=tol, flips=step > 0))
         opt.step(net, mask_back, t, s, 50, smax, 10000)
         HT.clamp_embeddings(net)
         if step == 0:          # (the oracle's optimizer restatement is the first-step form: momentum buffer = gradient)

@@ -632,3 +632,50 @@ def test_g21_hat_alexnet_oracle(golden):
         if "embs" in n:
             new = torch.clamp(new, -6, 6)
         check("train_theta_" + n, new, 5400 + j, 1e-5)
+
+
+def test_model_name_training_step_oracle_matches_reference_g34(golden):
+    """G34 (tests/golden/make_g34.py): the reference's factory (models/net.py:15-36, VGGSlim.py:27-76) built the `_BN`, `_DROP`,
+    `_DROP_BN` and deep_VGG22 models and ran one TRAINING-MODE step on them.  The torch-CPU oracle (oracle/alexnet_ref.py: a
+    walk over features / classifier with Dropout masks as data) on the BUILD's `parse_model_name` model of the same name, same
+    seeded parameters, batch and masks, reproduces the reference's logits, loss, every gradient and the BatchNorm buffers —
+    so module order, BatchNorm / Dropout placement and train-mode semantics of the build's models are the reference's."""
+    import copy
+    import sys
+    import numpy as np
+    import torch
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import g20_common as GC
+    from clsurvey_amd import models
+    from oracle import alexnet_ref
+    g = golden("G34_model_names")
+    names = ["small_VGG9_cl_128_128_BN", "small_VGG9_cl_128_128_DROP", "small_VGG9_cl_128_128_DROP_BN", "deep_VGG22_cl_512_512"]
+    for k, name in enumerate(names):
+        m = models.parse_model_name(name, (32, 32), 20)
+        named = [(n, tuple(p.shape)) for n, p in m.named_parameters()]
+        mods = dict(m.named_modules())
+        with torch.no_grad():
+            for (n, p), q in zip(m.named_parameters(), GC.fill_params(named, 3400 + k)):
+                if isinstance(mods[n.rsplit(".", 1)[0]], torch.nn.BatchNorm2d):
+                    q = (1.0 + 2.0 * q) if n.endswith("weight") else q
+                p.copy_(torch.from_numpy(q))
+        x, y = (torch.from_numpy(a) for a in GC.batch(3450 + k, 6, 32, 20))
+        masks = {i: torch.from_numpy(g[name + "__dropmask%d" % i]) for i in range(sum(1 for f in g.files if f.startswith(name + "__dropmask")))}
+        m.train()
+        loss, logits, grads = alexnet_ref.loss_and_grads(m, x, y, masks or None)
+        ref_logits = g[name + "__logits"]
+        assert float(np.abs(logits.numpy() - ref_logits).max()) <= 1e-5 * float(np.abs(ref_logits).max()), name
+        assert abs(float(loss) - float(g[name + "__loss"][0])) <= 1e-5 * abs(float(g[name + "__loss"][0]))
+        gmax = max(float(t.abs().max()) for t in grads)
+        for j, ((n, _), t) in enumerate(zip(named, grads)):
+            v, sums = g["%s__grad_%s__v" % (name, n)], g["%s__grad_%s__s" % (name, n)]
+            got = t.numpy().reshape(-1)
+            assert got.size == int(sums[2])
+            e = float(np.abs(got[GC.positions(got.size, 3500 + 50 * k + j)] - v).max()) / max(float(np.abs(v).max()), 1e-4 * gmax)
+            assert e <= 1e-5, (name, n, e)
+            assert abs(float(got.astype(np.float64).sum()) - float(sums[0])) <= 1e-5 * float(sums[1]) + 1e-12, (name, n)
+        for n, b in m.named_buffers():
+            ref = g["%s__buf_%s" % (name, n)]
+            if b.dtype == torch.float32:
+                assert float((b - torch.from_numpy(ref)).abs().max()) <= 1e-6 * max(1.0, float(np.abs(ref).max())), (name, n)

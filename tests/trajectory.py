@@ -179,6 +179,8 @@ def run_gpu_in_subprocess(prob, ref, lam, lr, env, every=20):
         torch.save({"prob": prob, "ref": [r["theta"] for r in ref], "lam": lam, "lr": lr, "every": every}, path)
         full = dict(os.environ)
         full.update(env)
+        repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        full["PYTHONPATH"] = repo + os.pathsep + full.get("PYTHONPATH", "")
         out = subprocess.run([sys.executable, os.path.abspath(__file__), path], env=full, capture_output=True, text=True, timeout=900)
         if out.returncode != 0:
             raise RuntimeError("child run failed:\n" + out.stderr[-3000:])
