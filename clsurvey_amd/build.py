@@ -81,7 +81,7 @@ def build_test_lib(force=False, verbose=True):
     return TEST_LIB
 
 
-def build_variant(name, src, defines, verbose=True):
+def build_variant(name, src, defines, verbose=True, extra_flags=()):
     """Experimental variant: recompile ONE source with extra -D flags and link libclhip_<name>.so.
     Selected at run time with CLHIP_LIB=<path> (tools/ only; the product always loads libclhip.so)."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -90,7 +90,7 @@ def build_variant(name, src, defines, verbose=True):
     procs = []
     for s in srcs:
         o = os.path.join(CSRC, s.replace(".hip", ".%s.o" % name))
-        cmd = [hipcc] + FLAGS + ["-D" + d for d in defines] + ["-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [hipcc] + FLAGS + list(extra_flags) + ["-D" + d for d in defines] + ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append(subprocess.Popen(cmd))

@@ -35,6 +35,9 @@
 
 namespace {
 
+#ifndef CLHIP_W16G_BURST
+#define CLHIP_W16G_BURST 0   // 1: no VALU between the MFMAs of a chunk (A/B experiment, see compute() in wino_conv16g_kernel)
+#endif
 #ifndef CLHIP_W16G_PF
 #define CLHIP_W16G_PF 2      // staging pipeline of wino_conv16g_kernel, see there
 #endif
@@ -1032,11 +1035,17 @@ __global__ __launch_bounds__(256, 2) void wino_conv16g_kernel(
             vv[4 * i + 1] = tlo[i].y + thi[i].x;
             vv[4 * i + 2] = thi[i].x - tlo[i].y;
         }
+#if CLHIP_W16G_BURST
+        __builtin_amdgcn_sched_barrier(0);      // A/B: all 16 transformed values in their own registers first, then 32 MFMAs back to back
+#endif
 #pragma unroll
         for (int f = 0; f < 16; ++f) {
             acc[0][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[f >> 2][f & 3], vv[f], acc[0][f], 0, 0, 0);
             acc[1][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[f >> 2][f & 3], vv[f], acc[1][f], 0, 0, 0);
         }
+#if CLHIP_W16G_BURST
+        __builtin_amdgcn_sched_barrier(0);
+#endif
     };
     // Staging pipeline.  The loads of a later chunk must be ISSUED before this chunk's MFMAs and WAITED FOR after them.
     // Left to itself the scheduler (it minimises register pressure, 180 of the 256 registers two waves per SIMD allow) sinks

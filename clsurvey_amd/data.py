@@ -160,4 +160,4 @@ def synthetic_task(n_train, n_val, n_test, n_classes, hw=64, seed=7, noise=1.0, 
     return out
 
 
-BLOBS_DEFAULT = {"g": 8, "amp": 4.0, "noise_lr": 1.2, "q": 0.9}
+BLOBS_DEFAULT = {"g": 8, "amp": 4.0, "noise_lr": 1.2, "q": 0.8}

