@@ -41,9 +41,11 @@ __global__ __launch_bounds__(GB) void axpy_kernel(float* __restrict__ y, const f
 //
 // M(M+1)/2 f64 accumulators per thread do not fit the register file beyond M = 6 (M = 16: 136 doubles = 272 registers; the
 // round-3 kernel spilled 29 .. 205 scratch instructions for M = 7 .. 16, and config 4 with 9 tasks in memory runs M = 10).
-// So the pairs are dealt out over S of the block's four WAVES (wave w holds the pairs p = w % S, w % S + S, ...; the choice is
-// uniform per wave, no divergence): the S waves of a set read the same 64 column groups (the second read of a line hits the
-// cache; HBM still sees ONE pass over G), each keeps at most 36 accumulators.
+// With the row indices of every pair as compile-time constants (GramPair) the accumulators of up to 11 rows (66 doubles) stay
+// in registers.  Beyond that the pairs are dealt out over S = 2 (16 rows: 4) of the block's WAVES (wave w holds the pairs p = w % S,
+// w % S + S, ...; uniform per wave, no divergence): the waves of a set read the same 64 column groups (the second read of
+// a line hits the cache; HBM still sees ONE pass over G, but the load path carries the lines twice: measured 3.9 TB/s at 11
+// rows with S = 2 against 5.3 at 5 rows with S = 1, which is why S = 1 is kept as far as the registers reach).
 __host__ __device__ constexpr int gram_pair_i(int M, int p) {
     int i = 0;
     while (p >= M - i) { p -= M - i; ++i; }
@@ -54,7 +56,7 @@ __host__ __device__ constexpr int gram_pair_j(int M, int p) {
     while (p >= M - i) { p -= M - i; ++i; }
     return i + p;
 }
-__host__ __device__ constexpr int gram_split(int M) { return M <= 8 ? 1 : M <= 11 ? 2 : 4; }
+__host__ __device__ constexpr int gram_split(int M) { return M <= 11 ? 1 : M <= 15 ? 2 : 4; }
 
 // pair K of wave group GRP: compile-time row indices (as template constants: a loop variable through a constexpr function
 // leaves the row array indexed at run time, i.e. in scratch)
