@@ -75,14 +75,20 @@ class OracleEWC:
             if count == 5:
                 lr *= 0.1
             t0 = time.perf_counter()
+            running_loss = 0.0
             for x, y in _batches(dsets["train"], args.batch_size, True):
-                _, _, grads, _ = vgg_ref.loss_and_grads(params, self.cfg, x, y, "ce_mean")
+                _, loss, grads, _ = vgg_ref.loss_and_grads(params, self.cfg, x, y, "ce_mean")
+                running_loss += float(loss)
                 stepped = [R.reg_sgd_step(t, g, o, iv, b, lam, lr, 0.9, args.weight_decay, first)
                            for t, g, o, iv, b in zip(params, grads, omega, init, bufs)]
                 params, bufs = [s[0] for s in stepped], [s[1] for s in stepped]
                 first = False
                 self.image_passes["train"] += x.shape[0]
             t1 = time.perf_counter()
+            epoch_loss = running_loss / len(dsets["train"])
+            if epoch_loss > 1e4 or epoch_loss != epoch_loss:          # train_EWC.py:204-205: a diverged run returns what it has
+                self.seconds["train"] += t1 - t0
+                return best_acc
             hits = 0
             with torch.no_grad():
                 for x, y in _batches(dsets["val"], args.batch_size, True):
