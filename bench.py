@@ -630,8 +630,11 @@ def pair_cpu_leg(root, threads, pin_from=None):
     pinned = None
     if pin_from is not None and hasattr(os, "sched_setaffinity"):
         try:                                    # its own cores: the other CPU leg runs beside this one
-            os.sched_setaffinity(0, range(pin_from, pin_from + threads))
-            pinned = [pin_from, pin_from + threads - 1]
+            allowed = sorted(os.sched_getaffinity(0))            # (a container may own a subset of the host's logical CPUs)
+            mine = [c for c in allowed if c >= pin_from][:threads]
+            if len(mine) == threads:
+                os.sched_setaffinity(0, mine)
+                pinned = [mine[0], mine[-1]]
         except OSError:
             pass
     with contextlib.redirect_stdout(io.StringIO()):

@@ -46,20 +46,33 @@ def worker(root, threads):
     from clsurvey_amd.framework import driver, shard
     from oracle import sweep_ref
     rank = int(os.environ["RANK"])
-    ncpu = os.cpu_count() or 1
-    if hasattr(os, "sched_setaffinity") and ncpu >= 2 * threads * int(os.environ["WORLD_SIZE"]):
-        os.sched_setaffinity(0, range(rank * threads, (rank + 1) * threads))      # physical cores first (the upper half are SMT siblings)
+    pinned = None
+    if hasattr(os, "sched_setaffinity"):
+        allowed = sorted(os.sched_getaffinity(0))           # (a container may own a subset of the host's logical CPUs)
+        if len(allowed) >= threads * int(os.environ["WORLD_SIZE"]):
+            mine = allowed[rank * threads:(rank + 1) * threads]
+            try:
+                os.sched_setaffinity(0, mine)
+                pinned = [mine[0], mine[-1]]
+            except OSError:
+                pass
     torch.set_num_threads(threads)
     shard.init_from_env("gloo")
     meth = sweep_ref.OracleEWC("small_VGG9")
-    with contextlib.redirect_stdout(io.StringIO()):
-        shard.barrier()
-        t0 = time.perf_counter()
-        out = driver.main(common(root, "cpu") + ["--shard", "--method_name", "EWC", "--max_task_count", "2"], method=meth)
-        shard.barrier()
-        dt = time.perf_counter() - t0
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            shard.barrier()
+            t0 = time.perf_counter()
+            out = driver.main(common(root, "cpu") + ["--shard", "--method_name", "EWC", "--max_task_count", "2"], method=meth)
+            shard.barrier()
+            dt = time.perf_counter() - t0
+    except BaseException:
+        import traceback
+        with open(os.path.join(root, "error_rank%d.txt" % rank), "w") as f:
+            f.write(traceback.format_exc())
+        raise
     hf = out["frameworks"][-1]
-    res = {"rank": rank, "seconds": dt, "image_passes": dict(meth.image_passes), "busy_s": dict(meth.seconds),
+    res = {"rank": rank, "seconds": dt, "pinned_to_logical_cpus": pinned, "image_passes": dict(meth.image_passes), "busy_s": dict(meth.seconds),
            "phase1": [[float(lr), float(a)] for lr, _, a in out["manager"].grid_trace],
            "phase2": [[float(h["lambda"]), float(a), float(th)] for h, a, th in hf.trace]}
     with open(os.path.join(root, "result_rank%d.json" % rank), "w") as f:
@@ -107,10 +120,17 @@ def main():
                                "--worker", croot, "--threads", str(a.threads)], env=env, capture_output=True, text=True)
         wall = time.perf_counter() - t0
         if proc.returncode != 0:
-            raise RuntimeError("CPU ranks failed:\n" + proc.stderr[-3000:])
+            errs = ""
+            for r in range(a.ranks):
+                f = os.path.join(croot, "error_rank%d.txt" % r)
+                if os.path.exists(f):
+                    errs += "--- rank %d\n%s\n" % (r, open(f).read()[-1500:])
+            raise RuntimeError("CPU ranks failed:\n" + (errs or proc.stderr[-3000:]))
         ranks = [json.load(open(os.path.join(croot, "result_rank%d.json" % r))) for r in range(a.ranks)]
         res.update({"cpu_task_s": max(r["seconds"] for r in ranks), "cpu_wall_with_process_start_s": wall,
                     "cpu_ranks": a.ranks, "cpu_threads_per_rank": a.threads, "host_logical_cores": os.cpu_count(),
+                    "cpus_this_container_may_use": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+                    "cpu_pinning": [r.get("pinned_to_logical_cpus") for r in ranks],
                     "cpu_image_passes_all_ranks": {k: sum(r["image_passes"][k] for r in ranks) for k in ("train", "eval")},
                     "cpu_phase1": ranks[0]["phase1"], "cpu_phase2": ranks[0]["phase2"],
                     "cpu_over_gpu": max(r["seconds"] for r in ranks) / gpu_s})
