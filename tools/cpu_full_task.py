@@ -113,7 +113,9 @@ def main():
         for r in range(a.ranks):
             for sub in ("data", "models", os.path.join("train", "synthetic_tiny_imagenet", "SI")):
                 shutil.copytree(os.path.join(groot, sub), os.path.join(croot, "rank%d" % r, sub))
-        env = dict(os.environ, OMP_NUM_THREADS=str(a.threads), MKL_NUM_THREADS=str(a.threads), PYTHONPATH=ROOT)
+        # (the CPU ranks must not see the GPU: shard.init_from_env would bind rank r to device r)
+        env = dict(os.environ, OMP_NUM_THREADS=str(a.threads), MKL_NUM_THREADS=str(a.threads), PYTHONPATH=ROOT,
+                   HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
         t0 = time.perf_counter()
         proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.ranks),
                                "--master-addr", "127.0.0.1", "--master-port", "29731", os.path.abspath(__file__),
