@@ -59,6 +59,17 @@ def worker(root, threads):
     torch.set_num_threads(threads)
     shard.init_from_env("gloo")
     meth = sweep_ref.OracleEWC("small_VGG9")
+    t_start = time.perf_counter()
+
+    def progress():                 # what this rank has done so far, every 15 s: a timed-out run still reports a lower bound
+        import threading
+        with open(os.path.join(root, "progress_rank%d.json" % rank), "w") as f:
+            json.dump({"rank": rank, "elapsed_s": time.perf_counter() - t_start, "image_passes": dict(meth.image_passes),
+                       "busy_s": dict(meth.seconds)}, f)
+        t = threading.Timer(15.0, progress)
+        t.daemon = True
+        t.start()
+    progress()
     try:
         with contextlib.redirect_stdout(io.StringIO()):
             shard.barrier()
@@ -85,6 +96,7 @@ def main():
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "cpu_full_task.json"))
     ap.add_argument("--worker", default=None)
+    ap.add_argument("--cpu-timeout", type=float, default=1500.0, help="seconds the CPU ranks may take before the run reports a lower bound")
     a = ap.parse_args()
     if a.worker:
         return worker(a.worker, a.threads)
@@ -105,7 +117,7 @@ def main():
         res = {"what": "task 2 of bench.py's EWC sweep (8000/2000/1000 blobs images, 5-LR grid, 70-epoch cap, batch 200, Fisher pass, "
                        "stability decay from lambda 400): build's driver on the GPU vs the same driver with the torch-CPU oracle's EWC "
                        "under `--shard` on %d gloo ranks x %d threads" % (a.ranks, a.threads),
-               "gpu_task_s": gpu_s,
+               "sizes": os.environ.get("CLHIP_CPUTASK_SIZES", "8000,2000,1000"), "gpu_task_s": gpu_s,
                "gpu_phase1": [[float(lr), float(acc)] for lr, _, acc in gout["manager"].grid_trace],
                "gpu_phase2": [[float(h["lambda"]), float(acc), float(th)] for h, acc, th in ghf.trace]}
         # every CPU rank works in <croot>/rank<r>: give each the task files and the first-task model
@@ -117,9 +129,30 @@ def main():
         env = dict(os.environ, OMP_NUM_THREADS=str(a.threads), MKL_NUM_THREADS=str(a.threads), PYTHONPATH=ROOT,
                    HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
         t0 = time.perf_counter()
-        proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.ranks),
-                               "--master-addr", "127.0.0.1", "--master-port", "29731", os.path.abspath(__file__),
-                               "--worker", croot, "--threads", str(a.threads)], env=env, capture_output=True, text=True)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.ranks),
+               "--master-addr", "127.0.0.1", "--master-port", "29731", os.path.abspath(__file__),
+               "--worker", croot, "--threads", str(a.threads)]
+        popen = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            out_s, err_s = popen.communicate(timeout=a.cpu_timeout)
+        except subprocess.TimeoutExpired:
+            import signal
+            os.killpg(popen.pid, signal.SIGKILL)         # the process group this script started (torchrun + its ranks), nothing else
+            popen.communicate()
+            prog = []
+            for r in range(a.ranks):
+                f = os.path.join(croot, "progress_rank%d.json" % r)
+                if os.path.exists(f):
+                    prog.append(json.load(open(f)))
+            res.update({"cpu_task_s": None, "cpu_timed_out_after_s": a.cpu_timeout, "cpu_progress_at_timeout": prog,
+                        "cpu_ranks": a.ranks, "cpu_threads_per_rank": a.threads,
+                        "cpu_over_gpu_at_least": a.cpu_timeout / gpu_s})
+            os.makedirs(os.path.dirname(a.out), exist_ok=True)
+            with open(a.out, "w") as f:
+                json.dump(res, f, indent=1)
+            print(json.dumps(res))
+            return
+        proc = subprocess.CompletedProcess(cmd, popen.returncode, out_s, err_s)
         wall = time.perf_counter() - t0
         if proc.returncode != 0:
             errs = ""
