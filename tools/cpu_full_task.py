@@ -114,9 +114,10 @@ def main():
             torch.cuda.synchronize()
             gpu_s = time.perf_counter() - t0
         ghf = gout["frameworks"][-1]
-        res = {"what": "task 2 of bench.py's EWC sweep (8000/2000/1000 blobs images, 5-LR grid, 70-epoch cap, batch 200, Fisher pass, "
-                       "stability decay from lambda 400): build's driver on the GPU vs the same driver with the torch-CPU oracle's EWC "
-                       "under `--shard` on %d gloo ranks x %d threads" % (a.ranks, a.threads),
+        res = {"what": "task 2 of bench.py's EWC sweep sequence at %s train/val/test 'blobs' images per task (5-LR grid, 70-epoch cap, batch "
+                       "200, Fisher pass, stability decay from lambda 400): build's driver on the GPU vs the same driver with the torch-CPU "
+                       "oracle's EWC under `--shard` on %d gloo ranks x %d threads"
+                       % (os.environ.get("CLHIP_CPUTASK_SIZES", "8000,2000,1000"), a.ranks, a.threads),
                "sizes": os.environ.get("CLHIP_CPUTASK_SIZES", "8000,2000,1000"), "gpu_task_s": gpu_s,
                "gpu_phase1": [[float(lr), float(acc)] for lr, _, acc in gout["manager"].grid_trace],
                "gpu_phase2": [[float(h["lambda"]), float(acc), float(th)] for h, acc, th in ghf.trace]}
