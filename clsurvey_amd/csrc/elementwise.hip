@@ -1,6 +1,5 @@
 // HBM-bound fused optimizer / importance-weight kernels (one pass over the parameter arena).
 // Reference arithmetic restated per kernel; algorithmic bytes per parameter in DESIGN.md.
-#include <cstdlib>
 #include "common.hpp"
 
 namespace {
@@ -53,53 +52,6 @@ struct RegSgd {
         reinterpret_cast<float4*>(theta)[i] = th;
     }
 };
-
-// RegSgd with more bytes in flight per thread (CLHIP_EW_MODE=1, the default: two 16-byte elements per thread and iteration, all
-// ten loads issued before the first use; =2: the same with non-temporal loads of the read-only streams and non-temporal
-// stores; =0: the generic driver above).  Same arithmetic per element as RegSgd::one — the three modes give the same bits
-// (tools/ew_mode_check.py).  Measured on a 57.8 M-parameter arena, second run of each: 5.39 / 5.62 / 5.58 TB/s.
-template <int MODE>
-__global__ __launch_bounds__(EW_BLOCK) void reg_sgd_unrolled_kernel(size_t n4, RegSgd f) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    auto ld = [&](const float* p, size_t i) -> floatx4 {
-        const floatx4* q = reinterpret_cast<const floatx4*>(p) + i;
-        if constexpr (MODE == 2) return __builtin_nontemporal_load(q);
-        return *q;
-    };
-    auto st = [&](float* p, size_t i, floatx4 v) {
-        floatx4* q = reinterpret_cast<floatx4*>(p) + i;
-        if constexpr (MODE == 2) __builtin_nontemporal_store(v, q);
-        else *q = v;
-    };
-    const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += 2 * stride) {
-        const size_t j = i + stride;
-        const bool two = j < n4;
-        const size_t jj = two ? j : i;
-        floatx4 th0 = reinterpret_cast<const floatx4*>(f.theta)[i], th1 = reinterpret_cast<const floatx4*>(f.theta)[jj];
-        floatx4 g0 = ld(f.grad, i), g1 = ld(f.grad, jj);
-        floatx4 om0 = f.omega ? ld(f.omega, i) : zero, om1 = f.omega ? ld(f.omega, jj) : zero;
-        floatx4 iv0 = f.omega ? ld(f.init, i) : zero, iv1 = f.omega ? ld(f.init, jj) : zero;
-        floatx4 b0 = f.first ? zero : reinterpret_cast<const floatx4*>(f.buf)[i], b1 = f.first ? zero : reinterpret_cast<const floatx4*>(f.buf)[jj];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float bb = b0[c];
-            th0[c] = f.one(th0[c], g0[c], om0[c], iv0[c], bb);
-            b0[c] = bb;
-            bb = b1[c];
-            th1[c] = f.one(th1[c], g1[c], om1[c], iv1[c], bb);
-            b1[c] = bb;
-        }
-        st(f.buf, i, b0);
-        st(f.theta, i, th0);
-        if (two) { st(f.buf, j, b1); st(f.theta, j, th1); }
-    }
-}
-
-static int ew_mode() {
-    static const int m = [] { const char* e = getenv("CLHIP_EW_MODE"); return e ? atoi(e) : 1; }();
-    return m;
-}
 
 struct FisherAcc {
     float* omega; const float* grad; float data_len;
@@ -310,14 +262,6 @@ int clhip_reg_sgd_step(float* theta, const float* grad, const float* omega, cons
     if (!theta || !grad || !buf || (omega && !init_val)) return CLHIP_EINVAL;
     RegSgd f{theta, grad, omega, init_val, buf, 2.f * reg_lambda, lr, momentum, wd, first};
     bool v = aligned16(theta) && aligned16(grad) && aligned16(buf) && (!omega || (aligned16(omega) && aligned16(init_val)));
-    if (v && ew_mode() > 0 && (n & 3) == 0 && n >= 4) {
-        const size_t n4 = n / 4;
-        const int grid = ew_grid((n4 + 1) / 2, EW_BLOCK);
-        if (ew_mode() == 2) hipLaunchKernelGGL(reg_sgd_unrolled_kernel<2>, dim3(grid), dim3(EW_BLOCK), 0, as_stream(stream), n4, f);
-        else hipLaunchKernelGGL(reg_sgd_unrolled_kernel<1>, dim3(grid), dim3(EW_BLOCK), 0, as_stream(stream), n4, f);
-        CLHIP_LAUNCH_CHECK();
-        return 0;
-    }
     return ew_launch(n, v, f, as_stream(stream));
 }
 
