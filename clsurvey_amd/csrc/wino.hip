@@ -35,6 +35,15 @@
 
 namespace {
 
+#ifndef CLHIP_W16G_ABL
+#define CLHIP_W16G_ABL 0     // TIMING-ONLY ablations of wino_conv16g_kernel's loop (wrong results; tools/gpu_r04_k.sh): bit 0 no input
+#endif                       // transform, 1 A operand read once, 2 no barrier, 3 no LDS stores, 4 no global loads, 5 no MFMAs
+#ifndef CLHIP_W16G_PRIO
+#define CLHIP_W16G_PRIO 2    // MFMA burst of a chunk fenced off and run at raised wave priority, see compute() in wino_conv16g_kernel
+#endif                       // (0: off — the A/B reference; 1: priority ramps up through the burst; 3: raised during staging instead)
+#ifndef CLHIP_WGPS_FENCE
+#define CLHIP_WGPS_FENCE 1   // wino_wgrad_ps_kernel: MFMAs of a step fenced off behind both dy transforms (0: the A/B reference)
+#endif
 #ifndef CLHIP_W16G_BURST
 #define CLHIP_W16G_BURST 0   // 1: no VALU between the MFMAs of a chunk (A/B experiment, see compute() in wino_conv16g_kernel)
 #endif
@@ -1004,6 +1013,14 @@ __global__ __launch_bounds__(256, 2) void wino_conv16g_kernel(
         for (int f = 0; f < 16; ++f) acc[k2][f] = floatx4v{0.f, 0.f, 0.f, 0.f};
 
     typedef float f2 __attribute__((ext_vector_type(2)));
+#if CLHIP_W16G_ABL & 2
+    floatx4 abl_a0[4], abl_a1[4];
+#pragma unroll
+    for (int fq = 0; fq < 4; ++fq) {
+        abl_a0[fq] = floatx4{0.5f + fq, 0.25f, -0.5f, 1.f} * (float)(lane + 1);
+        abl_a1[fq] = floatx4{0.75f, 0.5f + fq, 1.5f, -1.f} * (float)(lane + 2);
+    }
+#endif
     // one chunk from LDS buffer `bo`: operands, input transform, 32 MFMAs
     auto compute = [&](int bo) {
         const float* ab = lds + bo + a_off;
@@ -1017,8 +1034,12 @@ __global__ __launch_bounds__(256, 2) void wino_conv16g_kernel(
         floatx4 a0[4], a1[4];
 #pragma unroll
         for (int fq = 0; fq < 4; ++fq) {
+#if CLHIP_W16G_ABL & 2
+            a0[fq] = abl_a0[fq]; a1[fq] = abl_a1[fq];
+#else
             a0[fq] = *reinterpret_cast<const floatx4*>(ab + 4 * fq);
             a1[fq] = *reinterpret_cast<const floatx4*>(ab + 16 * WFP + 4 * fq);
+#endif
         }
         // V = B^T d B
         f2 tlo[4], thi[4];
@@ -1027,6 +1048,11 @@ __global__ __launch_bounds__(256, 2) void wino_conv16g_kernel(
         tlo[2] = dlo[2] - dlo[1]; thi[2] = dhi[2] - dhi[1];
         tlo[3] = dlo[1] - dlo[3]; thi[3] = dhi[1] - dhi[3];
         float vv[16];
+#if CLHIP_W16G_ABL & 1
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { vv[4 * i] = dlo[i].x; vv[4 * i + 1] = dlo[i].y; vv[4 * i + 2] = dhi[i].x; vv[4 * i + 3] = dhi[i].y; }
+        (void)tlo; (void)thi;
+#else
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const f2 o = tlo[i] - thi[i];
@@ -1035,18 +1061,73 @@ __global__ __launch_bounds__(256, 2) void wino_conv16g_kernel(
             vv[4 * i + 1] = tlo[i].y + thi[i].x;
             vv[4 * i + 2] = thi[i].x - tlo[i].y;
         }
+#endif
 #if CLHIP_W16G_BURST
         __builtin_amdgcn_sched_barrier(0);      // A/B: all 16 transformed values in their own registers first, then 32 MFMAs back to back
 #endif
+        // Round 4, measured per instance (profiles/r04_w16g_priority_variants.txt): fencing the 32 MFMAs of a chunk off from the
+        // operand reads / transform in front of them and running them at raised wave priority is 4 - 13 % FASTER on every instance
+        // that stages plain activations (forward, backward-data without a fused un-pool: wide_VGG9 359 -> 311, 188 -> 166 us) and
+        // 4 - 5 % SLOWER on the instances that rebuild the un-pooled gradient while staging (more VALU in front of the burst) —
+        // so it is on for the former only.  The three priority patterns tried (ramp, high in the burst, high while staging) time
+        // alike: what matters is the fence, the s_setprio pair costs nothing.
+        constexpr int PRIO = UNPOOL ? 0 : CLHIP_W16G_PRIO;
+        if constexpr (PRIO == 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(3);
+            __builtin_amdgcn_sched_barrier(0);
+        } else if constexpr (PRIO == 3) {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int f = 0; f < 16; ++f) {
+            if constexpr (PRIO == 1)
+            if ((f & 3) == 0) {                   // the further a wave is into its burst, the higher its claim on the matrix pipe
+                __builtin_amdgcn_sched_barrier(0);
+                if (f == 0) __builtin_amdgcn_s_setprio(0);
+                else if (f == 4) __builtin_amdgcn_s_setprio(1);
+                else if (f == 8) __builtin_amdgcn_s_setprio(2);
+                else __builtin_amdgcn_s_setprio(3);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#if CLHIP_W16G_ABL & 32
+            acc[0][f][0] += a0[f >> 2][f & 3] * vv[f];          // (one VALU op instead of the MFMA: keeps operands alive)
+            acc[1][f][0] += a1[f >> 2][f & 3] * vv[f];
+#else
             acc[0][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[f >> 2][f & 3], vv[f], acc[0][f], 0, 0, 0);
             acc[1][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[f >> 2][f & 3], vv[f], acc[1][f], 0, 0, 0);
+#endif
         }
 #if CLHIP_W16G_BURST
         __builtin_amdgcn_sched_barrier(0);
 #endif
+        if constexpr (PRIO == 1 || PRIO == 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+        } else if constexpr (PRIO == 3) {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(3);        // staging of the next chunk (LDS writes, global loads, operand reads) goes first
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
+#if CLHIP_W16G_ABL & 4
+#define W16G_SYNC() __builtin_amdgcn_wave_barrier()
+#else
+#define W16G_SYNC() __syncthreads()
+#endif
+#if CLHIP_W16G_ABL & 8
+#define W16G_STORE(bo, st) ((void)0)
+#else
+#define W16G_STORE(bo, st) store_chunk(bo, st)
+#endif
+#if CLHIP_W16G_ABL & 16
+#define W16G_LOAD(c, st) ((void)0)
+#else
+#define W16G_LOAD(c, st) load_chunk(c, st)
+#endif
     // Staging pipeline.  The loads of a later chunk must be ISSUED before this chunk's MFMAs and WAITED FOR after them.
     // Left to itself the scheduler (it minimises register pressure, 180 of the 256 registers two waves per SIMD allow) sinks
     // the loads below the MFMAs — issued right before the barrier, waited for right after it: every chunk then pays the whole
@@ -1063,16 +1144,16 @@ __global__ __launch_bounds__(256, 2) void wino_conv16g_kernel(
     load_chunk(2, sb);
     __syncthreads();
     for (int chunk = 0; chunk < n_chunks; chunk += 2) {               // n_chunks is even (Cin is a multiple of 8)
-        store_chunk(BUF, sa);                                          // chunk + 1 -> buffer 1 (read last in iteration chunk - 1)
-        load_chunk(chunk + 3, sa);
+        W16G_STORE(BUF, sa);                                           // chunk + 1 -> buffer 1 (read last in iteration chunk - 1)
+        W16G_LOAD(chunk + 3, sa);
         __builtin_amdgcn_sched_barrier(0);
         compute(0);
-        __syncthreads();
-        store_chunk(0, sb);                                            // chunk + 2 -> buffer 0
-        load_chunk(chunk + 4, sb);
+        W16G_SYNC();
+        W16G_STORE(0, sb);                                             // chunk + 2 -> buffer 0
+        W16G_LOAD(chunk + 4, sb);
         __builtin_amdgcn_sched_barrier(0);
         compute(BUF);
-        __syncthreads();
+        W16G_SYNC();
     }
 #else
     Stage sa;
@@ -1344,6 +1425,23 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_ps_kernel(
                 vv[4 * i + 1] = tlo[i].y + thi[i].x;
                 vv[4 * i + 2] = thi[i].x - tlo[i].y;
             }
+#if CLHIP_WGPS_FENCE
+            // round 4: both transformed dy tiles first, then the 32 MFMAs of the step fenced off at raised priority (-3 % on the
+            // un-pooling instances, neutral on the others: profiles/r04_w16g_priority_variants.txt)
+            float av0[16], av1[16];
+            dy_tf(cur + a_lane + doff, av0, bsum[0]);
+            dy_tf(cur + a_lane + 16 * G::LDP + doff, av1, bsum[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(3);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int f = 0; f < 16; ++f) acc[0][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[f], vv[f], acc[0][f], 0, 0, 0);
+#pragma unroll
+            for (int f = 0; f < 16; ++f) acc[1][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[f], vv[f], acc[1][f], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+#else
             float av[16];
             dy_tf(cur + a_lane + doff, av, bsum[0]);
 #pragma unroll
@@ -1351,6 +1449,7 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_ps_kernel(
             dy_tf(cur + a_lane + 16 * G::LDP + doff, av, bsum[1]);
 #pragma unroll
             for (int f = 0; f < 16; ++f) acc[1][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f], vv[f], acc[1][f], 0, 0, 0);
+#endif
         }
         __syncthreads();
     }
