@@ -41,6 +41,9 @@ namespace {
 #ifndef CLHIP_W16G_PRIO
 #define CLHIP_W16G_PRIO 2    // MFMA burst of a chunk fenced off and run at raised wave priority, see compute() in wino_conv16g_kernel
 #endif                       // (0: off — the A/B reference; 1: priority ramps up through the burst; 3: raised during staging instead)
+#ifndef CLHIP_W16G_PRIO_UNPOOL
+#define CLHIP_W16G_PRIO_UNPOOL 0   // the same switch for the instances that rebuild the un-pooled gradient while staging (measured slower with 2)
+#endif
 #ifndef CLHIP_WGPS_FENCE
 #define CLHIP_WGPS_FENCE 1   // wino_wgrad_ps_kernel: MFMAs of a step fenced off behind both dy transforms (0: the A/B reference)
 #endif
@@ -50,12 +53,44 @@ namespace {
 #ifndef CLHIP_W16G_PF
 #define CLHIP_W16G_PF 2      // staging pipeline of wino_conv16g_kernel, see there
 #endif
+#ifndef CLHIP_W16G_ADIRECT
+#define CLHIP_W16G_ADIRECT 1 // 1: wino_conv16g_kernel loads its A operands (transformed weights) from L2 straight into registers, from a
+#endif                       // second, lane-ordered image of U behind the LDS image; LDS then holds the halo planes only (see there).
+                             // 0: through LDS (the A/B reference; profiles/r04_w16g_adirect.txt: conv time of a pass -1.4 / -2.4 / -3.6 %
+                             // on small / base / wide_VGG9, the instances that un-pool while staging -7 .. -13 %)
 
 constexpr int WKT = 64;      // out channels per block
 constexpr int WCK = 8;       // in channels per chunk
 constexpr int WFP = 20;      // floats per (channel, out-channel) in the U tile: 16 frequencies + 4 pad — an 80-byte stride makes
                              // the 16-byte reads of 16 consecutive lanes land on 64 distinct LDS banks
 constexpr int W_FLOATS = WCK * WKT * WFP;         // 10240 floats = 40 KB: U tile of one chunk [c][k][f]
+// The lane-ordered image (CLHIP_W16G_ADIRECT): per (k-tile, 4-channel chunk) 16 pieces of 1 KB,
+//   [out-channel half wk][row tile r][frequency quad fq][lane = 16 * (channel of the quad) + (out channel & 15)][4 frequencies]
+// = what ONE buffer_load_dwordx4 of a wave of wino_conv16g_kernel wants as its A operands of 4 MFMAs: contiguous, whole lines.
+constexpr int WD_FLOATS = 4 * WKT * 16;           // 4096 floats = 16 KB per (k-tile, 4-channel chunk)
+#if CLHIP_W16G_ADIRECT
+constexpr int WU_FLOATS = W_FLOATS + 2 * WD_FLOATS;   // both images of an 8-channel chunk
+#else
+constexpr int WU_FLOATS = W_FLOATS;
+#endif
+
+// the four float4 of one (channel, out-channel) pair -> the LDS image (and the lane-ordered image behind it)
+__device__ __forceinline__ void wino_u_store(float* __restrict__ U, int kts, int n_chunks, int kt, int chunk, int c_l, int k_l,
+                                             const float4 (&u)[4]) {
+    float4* dst = reinterpret_cast<float4*>(U + (((size_t)(kt * n_chunks + chunk) * WCK + c_l) * WKT + k_l) * WFP);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) dst[a] = u[a];
+    dst[4] = make_float4(0.f, 0.f, 0.f, 0.f);
+#if CLHIP_W16G_ADIRECT
+    float* Ud = U + (size_t)kts * n_chunks * W_FLOATS;
+    const int chunk4 = 2 * chunk + (c_l >> 2), q = c_l & 3, wk = k_l >> 5, r = (k_l >> 4) & 1, ti = k_l & 15;
+    float4* dd = reinterpret_cast<float4*>(Ud + ((((size_t)(kt * 2 * n_chunks + chunk4) * 2 + wk) * 2 + r) * 4) * 256 + (q * 16 + ti) * 4);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) dd[a * 64] = u[a];
+#else
+    (void)kts;
+#endif
+}
 
 template <int TCB, int TRB, int NIMG>
 struct WGeoW {
@@ -95,11 +130,11 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
             t[2][s] = 0.5f * (g[0][s] - g[1][s] + g[2][s]);
             t[3][s] = g[2][s];
         }
-        float4* dst = reinterpret_cast<float4*>(U + (((size_t)(kt * n_chunks + chunk) * WCK + c_l) * WKT + k_l) * WFP);
+        float4 u[4];
 #pragma unroll
         for (int a = 0; a < 4; ++a)
-            dst[a] = make_float4(t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]), t[a][2]);
-        dst[4] = make_float4(0.f, 0.f, 0.f, 0.f);
+            u[a] = make_float4(t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]), t[a][2]);
+        wino_u_store(U, (Ko + WKT - 1) / WKT, n_chunks, kt, chunk, c_l, k_l, u);
     }
 }
 
@@ -130,11 +165,11 @@ __device__ __forceinline__ void wino_weight_one(const float* __restrict__ w, flo
         t[2][s] = 0.5f * (g[0][s] - g[1][s] + g[2][s]);
         t[3][s] = g[2][s];
     }
-    float4* dst = reinterpret_cast<float4*>(U + (((size_t)(kt * n_chunks + chunk) * WCK + c_l) * WKT + k_l) * WFP);
+    float4 u[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
-        dst[a] = make_float4(t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]), t[a][2]);
-    dst[4] = make_float4(0.f, 0.f, 0.f, 0.f);
+        u[a] = make_float4(t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]), t[a][2]);
+    wino_u_store(U, (Ko + WKT - 1) / WKT, n_chunks, kt, chunk, c_l, k_l, u);
 }
 
 __global__ __launch_bounds__(256) void wino_weight_multi_kernel(WtJobs J) {
@@ -923,7 +958,9 @@ __global__ __launch_bounds__(256, 2) void wino_conv16g_kernel(
     static_assert(NE * EROWS == 2 * TR && (NE == 1 || !UNPOOL || EROWS == 4), "whole entities");
     constexpr int PW = 2 * TC + 2, PRE = 2 * EROWS + 2, PLANE = NE * PRE * PW;
     constexpr int WQ_FLOATS = CQ * WKT * WFP;                         // 5120 floats: half of a U chunk (channels are its outer index)
-    constexpr int X_FLOATS = CQ * PLANE, BUF = WQ_FLOATS + X_FLOATS;
+    constexpr bool ADIRECT = CLHIP_W16G_ADIRECT != 0;                 // A operands from L2 straight into registers: LDS holds the halo planes only
+    constexpr int WOFF = ADIRECT ? 0 : WQ_FLOATS;
+    constexpr int X_FLOATS = CQ * PLANE, BUF = WOFF + X_FLOATS;
     __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
     __shared__ float bias_s[WKT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -943,9 +980,13 @@ __global__ __launch_bounds__(256, 2) void wino_conv16g_kernel(
     const __amdgpu_buffer_rsrc_t rs_x = clhip_rsrc(in_img, (size_t)(N - nb0) * Cin * plane_in * sizeof(float));
     const __amdgpu_buffer_rsrc_t rs_i = clhip_rsrc(UNPOOL ? pool_idx + (size_t)nb0 * Cin * plane_in : pool_idx,
                                                    UNPOOL ? (size_t)(N - nb0) * Cin * plane_in : 0);
-    const __amdgpu_buffer_rsrc_t rs_u = clhip_rsrc(U + (size_t)kt * n_chunks * WQ_FLOATS, (size_t)n_chunks * WQ_FLOATS * sizeof(float));
+    // LDS image of this k-tile's chunks, or (ADIRECT) its lane-ordered image behind the LDS images of the whole layer
+    const __amdgpu_buffer_rsrc_t rs_u = ADIRECT
+        ? clhip_rsrc(U + (size_t)((Cout + WKT - 1) / WKT) * (Cin / WCK) * W_FLOATS + (size_t)kt * n_chunks * WD_FLOATS,
+                     (size_t)n_chunks * WD_FLOATS * sizeof(float))
+        : clhip_rsrc(U + (size_t)kt * n_chunks * WQ_FLOATS, (size_t)n_chunks * WQ_FLOATS * sizeof(float));
 
-    constexpr int W_IT = WQ_FLOATS / 4 / 256;                         // 5
+    constexpr int W_IT = ADIRECT ? 1 : WQ_FLOATS / 4 / 256;           // 5 (ADIRECT: unused)
     constexpr int X_IT = (X_FLOATS + 255) / 256;
     struct Stage {                                                    // one chunk on its way from global memory to LDS
         float4 wv[W_IT];
@@ -975,8 +1016,10 @@ __global__ __launch_bounds__(256, 2) void wino_conv16g_kernel(
     }
     auto load_chunk = [&](int chunk, Stage& st) {
         const int cw = chunk < n_chunks ? chunk : n_chunks - 1;
+        if constexpr (!ADIRECT) {
 #pragma unroll
-        for (int u = 0; u < W_IT; ++u) st.wv[u] = clhip_buf_load4(rs_u, (tid + 256 * u) * 16, cw * WQ_FLOATS * 4);
+            for (int u = 0; u < W_IT; ++u) st.wv[u] = clhip_buf_load4(rs_u, (tid + 256 * u) * 16, cw * WQ_FLOATS * 4);
+        }
         const int xb = cw * CQ * plane_in;
 #pragma unroll
         for (int j = 0; j < X_IT; ++j) {
@@ -989,10 +1032,12 @@ __global__ __launch_bounds__(256, 2) void wino_conv16g_kernel(
         }
     };
     auto store_chunk = [&](int bo, const Stage& st) {
+        if constexpr (!ADIRECT) {
 #pragma unroll
-        for (int u = 0; u < W_IT; ++u)
-            *reinterpret_cast<floatx4*>(lds + bo + 4 * (tid + 256 * u)) = floatx4{st.wv[u].x, st.wv[u].y, st.wv[u].z, st.wv[u].w};
-        float* xs = lds + bo + WQ_FLOATS;
+            for (int u = 0; u < W_IT; ++u)
+                *reinterpret_cast<floatx4*>(lds + bo + 4 * (tid + 256 * u)) = floatx4{st.wv[u].x, st.wv[u].y, st.wv[u].z, st.wv[u].w};
+        }
+        float* xs = lds + bo + WOFF;
 #pragma unroll
         for (int j = 0; j < X_IT; ++j)
             if (256 * (j + 1) <= X_FLOATS || tid + 256 * j < X_FLOATS) {
@@ -1003,7 +1048,7 @@ __global__ __launch_bounds__(256, 2) void wino_conv16g_kernel(
 
     const int t_rowb = wp * TR + ti / TC, t_col = ti % TC;           // this lane's tile inside the block's TC x 2 TR tiles
     const int t_ent = t_rowb / EROWS, t_row = t_rowb % EROWS;        // its entity and its row inside the entity
-    const int d_off = WQ_FLOATS + q * PLANE + (t_ent * PRE + 2 * t_row) * PW + 2 * t_col;      // even: 8-byte aligned
+    const int d_off = WOFF + q * PLANE + (t_ent * PRE + 2 * t_row) * PW + 2 * t_col;           // even: 8-byte aligned
     const int a_off = (q * WKT + wk * 32 + ti) * WFP;
 
     floatx4v acc[2][16];
@@ -1021,8 +1066,23 @@ __global__ __launch_bounds__(256, 2) void wino_conv16g_kernel(
         abl_a1[fq] = floatx4{0.75f, 0.5f + fq, 1.5f, -1.f} * (float)(lane + 2);
     }
 #endif
+    // ADIRECT: the A operands of a chunk = 8 x 1 KB pieces of the lane-ordered image (this wave's out-channel half: 2 row tiles x 4
+    // frequency quads), each ONE coalesced buffer_load_dwordx4; issued a whole chunk ahead into the register set the previous
+    // burst has just released, so that L2 latency (~200-500 cycles) lies under the other set's chunk.
+    struct AReg { floatx4 a0[4], a1[4]; };
+    const int a_voff = wk * (2 * 4 * 256 * 4) + lane * 16;
+    auto load_a = [&](int chunk, AReg& A) {
+        const int ca = (chunk < n_chunks ? chunk : n_chunks - 1) * (WD_FLOATS * 4);
+#pragma unroll
+        for (int fq = 0; fq < 4; ++fq) {
+            const clhip_u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rs_u, a_voff + fq * 1024, ca, 0);
+            const clhip_u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rs_u, a_voff + 4096 + fq * 1024, ca, 0);
+            A.a0[fq] = floatx4{__uint_as_float(v0.x), __uint_as_float(v0.y), __uint_as_float(v0.z), __uint_as_float(v0.w)};
+            A.a1[fq] = floatx4{__uint_as_float(v1.x), __uint_as_float(v1.y), __uint_as_float(v1.z), __uint_as_float(v1.w)};
+        }
+    };
     // one chunk from LDS buffer `bo`: operands, input transform, 32 MFMAs
-    auto compute = [&](int bo) {
+    auto compute = [&](int bo, const AReg* areg) {
         const float* ab = lds + bo + a_off;
         const float* db = lds + bo + d_off;
         f2 dlo[4], dhi[4];
@@ -1037,8 +1097,12 @@ __global__ __launch_bounds__(256, 2) void wino_conv16g_kernel(
 #if CLHIP_W16G_ABL & 2
             a0[fq] = abl_a0[fq]; a1[fq] = abl_a1[fq];
 #else
-            a0[fq] = *reinterpret_cast<const floatx4*>(ab + 4 * fq);
-            a1[fq] = *reinterpret_cast<const floatx4*>(ab + 16 * WFP + 4 * fq);
+            if constexpr (ADIRECT) {
+                a0[fq] = areg->a0[fq]; a1[fq] = areg->a1[fq];
+            } else {
+                a0[fq] = *reinterpret_cast<const floatx4*>(ab + 4 * fq);
+                a1[fq] = *reinterpret_cast<const floatx4*>(ab + 16 * WFP + 4 * fq);
+            }
 #endif
         }
         // V = B^T d B
@@ -1071,7 +1135,7 @@ __global__ __launch_bounds__(256, 2) void wino_conv16g_kernel(
         // 4 - 5 % SLOWER on the instances that rebuild the un-pooled gradient while staging (more VALU in front of the burst) —
         // so it is on for the former only.  The three priority patterns tried (ramp, high in the burst, high while staging) time
         // alike: what matters is the fence, the s_setprio pair costs nothing.
-        constexpr int PRIO = UNPOOL ? 0 : CLHIP_W16G_PRIO;
+        constexpr int PRIO = UNPOOL ? CLHIP_W16G_PRIO_UNPOOL : CLHIP_W16G_PRIO;
         if constexpr (PRIO == 2) {
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(3);
@@ -1138,24 +1202,29 @@ __global__ __launch_bounds__(256, 2) void wino_conv16g_kernel(
     //                   2  two register sets: chunk + 3 issued at the top of chunk's iteration (two iterations in flight)
 #if CLHIP_W16G_PF == 2
     Stage sa, sb;
+    AReg ra, rb;                                                       // (ADIRECT) A operands of the even / odd chunks
     load_chunk(0, sa);
     store_chunk(0, sa);
     load_chunk(1, sa);
     load_chunk(2, sb);
+    if constexpr (ADIRECT) { load_a(0, ra); load_a(1, rb); }
     __syncthreads();
     for (int chunk = 0; chunk < n_chunks; chunk += 2) {               // n_chunks is even (Cin is a multiple of 8)
         W16G_STORE(BUF, sa);                                           // chunk + 1 -> buffer 1 (read last in iteration chunk - 1)
         W16G_LOAD(chunk + 3, sa);
         __builtin_amdgcn_sched_barrier(0);
-        compute(0);
+        compute(0, &ra);
+        if constexpr (ADIRECT) { load_a(chunk + 2, ra); __builtin_amdgcn_sched_barrier(0); }     // behind the burst that read `ra`
         W16G_SYNC();
         W16G_STORE(0, sb);                                             // chunk + 2 -> buffer 0
         W16G_LOAD(chunk + 4, sb);
         __builtin_amdgcn_sched_barrier(0);
-        compute(BUF);
+        compute(BUF, &rb);
+        if constexpr (ADIRECT) { load_a(chunk + 3, rb); __builtin_amdgcn_sched_barrier(0); }
         W16G_SYNC();
     }
 #else
+    static_assert(!ADIRECT, "CLHIP_W16G_ADIRECT needs the two-set pipeline (CLHIP_W16G_PF = 2)");
     Stage sa;
     load_chunk(0, sa);
     store_chunk(0, sa);
@@ -1169,7 +1238,7 @@ __global__ __launch_bounds__(256, 2) void wino_conv16g_kernel(
 #if CLHIP_W16G_PF == 1
         __builtin_amdgcn_sched_barrier(0);
 #endif
-        compute(bo);
+        compute(bo, nullptr);
         __syncthreads();
     }
 #endif
@@ -1249,7 +1318,10 @@ static bool wino16g_on() {
 }
 
 // units of the 32-tile kernel a layer has; below this the 8 x 8 variant takes 8 x 8 maps
-constexpr long long WINO16_BELOW_UNITS = 640;
+#ifndef CLHIP_WINO16_BELOW_UNITS
+#define CLHIP_WINO16_BELOW_UNITS 640
+#endif
+constexpr long long WINO16_BELOW_UNITS = CLHIP_WINO16_BELOW_UNITS;
 
 
 // ------------------------------------------------------------------------------------------------ weight gradient of small layers
@@ -1594,7 +1666,7 @@ bool clhip_internal_wino_ok(int Cin, int Cout, int H, int W) {
 }
 
 size_t clhip_internal_wino_ws(int Cin, int Cout) {
-    return (size_t)((Cout + WKT - 1) / WKT) * ((Cin + WCK - 1) / WCK) * W_FLOATS * sizeof(float);
+    return (size_t)((Cout + WKT - 1) / WKT) * ((Cin + WCK - 1) / WCK) * WU_FLOATS * sizeof(float);
 }
 
 // forward (mode 0) / backward-data (mode 1) through the Winograd path.  ws: clhip_internal_wino_ws(Cin, Cout) bytes.
