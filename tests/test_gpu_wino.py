@@ -124,3 +124,40 @@ def test_wino_weight_gradient(shape):
     dw_u_ref, db_u_ref = ops.conv3x3_bwd_weight(xd, ops.maxpool2_bwd(dyp, code))
     dw_u, db_u = ops.conv3x3_wino_bwd_weight(xd, dyp, idx=code)
     assert _rel(dw_u, dw_u_ref) <= 5e-5 and _rel(db_u, db_u_ref) <= 5e-5
+
+
+@pytest.mark.parametrize("C,K", [(24, 96), (64, 64), (128, 32)])
+def test_wino_weight_images_agree(C, K):
+    """The transformed weights U = G g G^T are kept twice: the LDS image [k-tile][8-channel chunk][channel][out channel]
+    [16 frequencies + 4 pad] and, behind it, the lane-ordered image wino_conv16g_kernel reads straight from L2 into its A-operand
+    registers: [k-tile][4-channel chunk][out-channel half][row tile][frequency quad][lane = 16 * channel + (out channel & 15)][4].
+    Both must hold the same bits, the LDS image must be G g G^T (Lavin & Gray's F(2x2, 3x3) weight transform), padding is zero."""
+    from clsurvey_amd import _lib, ops
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, C, 8, 8, generator=g).to(dev)
+    w = torch.randn(K, C, 3, 3, generator=g) * 0.1
+    wd, b = w.to(dev), torch.zeros(K, device=dev)
+    y = torch.empty(2, K, 8, 8, device=dev)
+    ws = torch.zeros(L.clhip_conv3x3_wino_ws(C, K), dtype=torch.uint8, device=dev)
+    ops.check(L.clhip_conv3x3_wino_fwd(ops._ptr(x), ops._ptr(wd), ops._ptr(b), ops._ptr(y), None, 2, C, K, 8, 8, 0, ops._ptr(ws),
+                                       ws.numel(), ops._stream()), "clhip_conv3x3_wino_fwd")
+    torch.cuda.synchronize()
+    U = ws.view(torch.float32).cpu().numpy()
+    kts, nch = (K + 63) // 64, (C + 7) // 8
+    n_lds = kts * nch * 8 * 64 * 20
+    lds = U[:n_lds].reshape(kts, nch, 8, 64, 20)
+    assert np.all(lds[..., 16:] == 0.0)
+    G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=np.float64)
+    want = np.zeros((kts * 64, nch * 8, 16))
+    want[:K, :C] = np.einsum("ar,kcrs,bs->kcab", G, w.double().numpy(), G).reshape(K, C, 16)
+    got = lds[..., :16].transpose(0, 3, 1, 2, 4).reshape(kts * 64, nch * 8, 16)          # [k][c][f]
+    assert np.abs(got - want).max() <= 1e-6 * max(1.0, np.abs(want).max())
+    if U.size < n_lds + kts * nch * 2 * 4096:
+        pytest.skip("library built with CLHIP_W16G_ADIRECT=0: no lane-ordered image")
+    direct = U[n_lds:n_lds + kts * nch * 2 * 4096].reshape(kts, 2 * nch, 2, 2, 4, 4, 16, 4)      # kt, chunk4, wk, r, fq, q, ti, j
+    # the same elements out of the LDS image: channel = 8 chunk8 + 4 half + q, out channel = 32 wk + 16 r + ti, frequency = 4 fq + j
+    e = lds[..., :16].reshape(kts, nch, 2, 4, 2, 2, 16, 4, 4)                                  # kt, chunk8, half, q, wk, r, ti, fq, j
+    e = e.transpose(0, 1, 2, 4, 5, 7, 3, 6, 8).reshape(kts, 2 * nch, 2, 2, 4, 4, 16, 4)
+    assert np.array_equal(direct.view(np.uint32), np.ascontiguousarray(e).view(np.uint32))
