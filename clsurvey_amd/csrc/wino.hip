@@ -1351,7 +1351,11 @@ struct WGeoP {
     static constexpr int LDS_FLOATS = 2 * BUF > XCH ? 2 * BUF : XCH;
 };
 
-template <int TCS, int TRS, bool UNPOOL>
+// VEC (maps of whole tiles in width: W % (2 TCS) == 0, 16-byte-aligned tensors): a stage is staged in 16-byte pieces — every halo-plane
+// row as its interior float4s (aligned in global memory; their LDS home starts one float behind the halo column, hence four 4-byte
+// LDS writes the compiler pairs into ds_write2_b32) plus the two halo columns as scalars, dy rows as float4s (two ds_write_b64) —
+// 6 + 2 vector loads and 10 + 4 LDS writes per thread and stage where the scalar form has 16 + 8 and 16 + 8.
+template <int TCS, int TRS, bool UNPOOL, bool VEC>
 __global__ __launch_bounds__(256, 2) void wino_wgrad_ps_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, const uint8_t* __restrict__ unpool_idx,
     int N, int C, int K, int H, int W, int tiles_w, int tiles_h, int total_stages, int splits, int c_tiles, size_t slab_stride) {
@@ -1389,6 +1393,26 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_ps_kernel(
     const int x_e0 = x_cl * plane_hw + x_row * W + x_col;
     const int x_dst0 = G::DY_FLOATS + x_cl * G::PLANEP + x_rem;
     bool dy_ok = false, x_ok = false;
+    // VEC units: x float4s — XU per plane, XCPT planes per pass; x halo scalars — HU per plane, HCPT planes per pass; dy float4s
+    constexpr int RSEG = G::DW / 4;
+    constexpr int XU = G::PR * RSEG, XCPT = 256 / XU, XV_IT = (G::CB + XCPT - 1) / XCPT;            // 24, 10, 4  |  20, 12, 3
+    constexpr int HU = G::PR * 2, HCPT = 256 / HU, XH_IT = (G::CB + HCPT - 1) / HCPT;               // 12, 21, 2  |  20, 12, 3
+    constexpr int DQV = G::DR * RSEG, DKSV = 256 / DQV, DYV_IT = G::KB / DKSV;                       // 16, 16, 2
+    static_assert(!VEC || (DQV * DKSV == 256 && DYV_IT * DKSV == G::KB), "dy float4 units fill the block exactly");
+    float4 xv[VEC ? XV_IT : 1], dyv[VEC && !UNPOOL ? DYV_IT : 1];
+    float xh[VEC ? XH_IT : 1];
+    const int v_cl = tid / XU, v_rem = tid - v_cl * XU, v_row = v_rem / RSEG, v_seg = v_rem - v_row * RSEG;
+    const bool v_thr = tid < XCPT * XU;
+    const int v_e0 = v_cl * plane_hw + v_row * W + 1 + 4 * v_seg;                   // relative to the halo origin (h0 - 1, w0 - 1)
+    const int v_dst0 = G::DY_FLOATS + v_cl * G::PLANEP + v_row * G::PW + 1 + 4 * v_seg;
+    const int h_cl = tid / HU, h_rem = tid - h_cl * HU, h_row = h_rem >> 1, h_col = (h_rem & 1) ? G::DW + 1 : 0;
+    const bool h_thr = tid < HCPT * HU;
+    const int h_e0 = h_cl * plane_hw + h_row * W + h_col;
+    const int h_dst0 = G::DY_FLOATS + h_cl * G::PLANEP + h_row * G::PW + h_col;
+    const int dv_kl = tid / DQV, dv_q = tid - dv_kl * DQV, dv_r = dv_q / RSEG, dv_seg = dv_q - dv_r * RSEG;
+    const int dv_e0 = dv_kl * plane_dy + dv_r * Wd + 4 * dv_seg;
+    const int dv_dst0 = dv_kl * G::LDP + dv_r * G::DW + 4 * dv_seg;                 // even: 8-byte aligned
+    bool xv_ok = false, xh_ok = false, dv_ok = false;
     __amdgpu_buffer_rsrc_t rs_dy = clhip_rsrc(dy, 0), rs_x = clhip_rsrc(x, 0), rs_di = clhip_rsrc(x, 0);
     auto begin_stage = [&](int st) {
         const bool live = st < st_end;
@@ -1407,19 +1431,50 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_ps_kernel(
         dy_ok = h0 + (UNPOOL ? 2 * d_r : d_r) < H && w0 + (UNPOOL ? 2 * d_c : d_c) < W;
         const int h = h0 - 1 + x_row, w = w0 - 1 + x_col;
         x_ok = x_thr && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+        if constexpr (VEC) {                      // whole tiles in width: the interior columns of a row are all inside the image
+            xv_ok = v_thr && (unsigned)(h0 - 1 + v_row) < (unsigned)H;
+            xh_ok = h_thr && (unsigned)(h0 - 1 + h_row) < (unsigned)H && (unsigned)(w0 - 1 + h_col) < (unsigned)W;
+            dv_ok = h0 + dv_r < H;
+        }
     };
     auto load_stage = [&]() {
+        if constexpr (VEC && !UNPOOL) {
 #pragma unroll
-        for (int u = 0; u < DY_IT; ++u) {
-            const int e = dy_e0 + u * DKS * plane_dy;
-            dyr[u] = clhip_buf_load(rs_dy, dy_ok ? e * 4 : CLHIP_OOB, 0);
-            if constexpr (UNPOOL) dyi[u] = clhip_buf_load_u8(rs_di, dy_ok ? e : CLHIP_OOB, 0);
+            for (int u = 0; u < DYV_IT; ++u) dyv[u] = clhip_buf_load4(rs_dy, dv_ok ? (dv_e0 + u * DKSV * plane_dy) * 4 : CLHIP_OOB, 0);
+        } else {
+#pragma unroll
+            for (int u = 0; u < DY_IT; ++u) {
+                const int e = dy_e0 + u * DKS * plane_dy;
+                dyr[u] = clhip_buf_load(rs_dy, dy_ok ? e * 4 : CLHIP_OOB, 0);
+                if constexpr (UNPOOL) dyi[u] = clhip_buf_load_u8(rs_di, dy_ok ? e : CLHIP_OOB, 0);
+            }
         }
+        if constexpr (VEC) {
 #pragma unroll
-        for (int j = 0; j < X_IT; ++j) xr[j] = clhip_buf_load(rs_x, x_ok ? (x_e0 + j * CPT * plane_hw) * 4 : CLHIP_OOB, 0);
+            for (int j = 0; j < XV_IT; ++j) {
+                const bool ok = xv_ok && ((j + 1) * XCPT <= G::CB || v_cl + j * XCPT < G::CB);
+                xv[j] = clhip_buf_load4(rs_x, ok ? (v_e0 + j * XCPT * plane_hw) * 4 : CLHIP_OOB, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < XH_IT; ++j) {
+                const bool ok = xh_ok && ((j + 1) * HCPT <= G::CB || h_cl + j * HCPT < G::CB);
+                xh[j] = clhip_buf_load(rs_x, ok ? (h_e0 + j * HCPT * plane_hw) * 4 : CLHIP_OOB, 0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < X_IT; ++j) xr[j] = clhip_buf_load(rs_x, x_ok ? (x_e0 + j * CPT * plane_hw) * 4 : CLHIP_OOB, 0);
+        }
     };
     typedef float f2 __attribute__((ext_vector_type(2)));
     auto store_stage = [&](int bo) {
+        if constexpr (VEC && !UNPOOL) {
+#pragma unroll
+            for (int u = 0; u < DYV_IT; ++u) {
+                float* d = lds + bo + dv_dst0 + u * DKSV * G::LDP;
+                *reinterpret_cast<f2*>(d) = f2{dyv[u].x, dyv[u].y};
+                *reinterpret_cast<f2*>(d + 2) = f2{dyv[u].z, dyv[u].w};
+            }
+        } else {
 #pragma unroll
         for (int u = 0; u < DY_IT; ++u) {
             const float v = dyr[u];
@@ -1432,7 +1487,22 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_ps_kernel(
                 lds[bo + dy_dst0 + u * DKS * G::LDP] = v;
             }
         }
-        if (x_thr) {
+        }
+        if constexpr (VEC) {
+            if (v_thr) {
+#pragma unroll
+                for (int j = 0; j < XV_IT; ++j)
+                    if ((j + 1) * XCPT <= G::CB || v_cl + j * XCPT < G::CB) {
+                        float* d = lds + bo + v_dst0 + j * XCPT * G::PLANEP;
+                        d[0] = xv[j].x; d[1] = xv[j].y; d[2] = xv[j].z; d[3] = xv[j].w;
+                    }
+            }
+            if (h_thr) {
+#pragma unroll
+                for (int j = 0; j < XH_IT; ++j)
+                    if ((j + 1) * HCPT <= G::CB || h_cl + j * HCPT < G::CB) lds[bo + h_dst0 + j * HCPT * G::PLANEP] = xh[j];
+            }
+        } else if (x_thr) {
 #pragma unroll
             for (int j = 0; j < X_IT; ++j) lds[bo + x_dst0 + j * CPT * G::PLANEP] = xr[j];
         }
@@ -1759,8 +1829,16 @@ int clhip_internal_wino_wgrad_partial(const float* x, const float* dy, const uin
         if (sp > total) sp = total;
         if (sp > cap) sp = cap;
         const unsigned gridp = (unsigned)(kc32 * sp);
-#define WGP(TCS_, TRS_, UNP_) hipLaunchKernelGGL((wino_wgrad_ps_kernel<TCS_, TRS_, UNP_>), dim3(gridp), dim3(256), 0, s, x, dy, part, \
-                                                 unpool_idx, N, C, K, H, W, tiles_w, tiles_h, (int)total, (int)sp, C / 32, slab)
+        // whole tiles in width and 16-byte-aligned tensors: stages staged in 16-byte pieces (VEC; CLHIP_WGPS_VEC=0: the scalar form)
+        static const bool vec_on = [] { const char* e = getenv("CLHIP_WGPS_VEC"); return !(e && e[0] == '0'); }();
+        const bool vec = vec_on && W % (2 * TCS) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
+#define WGP(TCS_, TRS_, UNP_)                                                                                                       \
+        do {                                                                                                                       \
+            if (vec) hipLaunchKernelGGL((wino_wgrad_ps_kernel<TCS_, TRS_, UNP_, true>), dim3(gridp), dim3(256), 0, s, x, dy, part,  \
+                                        unpool_idx, N, C, K, H, W, tiles_w, tiles_h, (int)total, (int)sp, C / 32, slab);            \
+            else hipLaunchKernelGGL((wino_wgrad_ps_kernel<TCS_, TRS_, UNP_, false>), dim3(gridp), dim3(256), 0, s, x, dy, part,     \
+                                    unpool_idx, N, C, K, H, W, tiles_w, tiles_h, (int)total, (int)sp, C / 32, slab);                \
+        } while (0)
         if (wide) { if (unpool_idx) WGP(8, 2, true); else WGP(8, 2, false); }
         else { if (unpool_idx) WGP(4, 4, true); else WGP(4, 4, false); }
 #undef WGP
