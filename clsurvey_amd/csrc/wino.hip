@@ -475,7 +475,10 @@ struct WGeoG {
     static constexpr int BUF = DY_FLOATS + X_FLOATS;
 };
 
-template <int TCS, int TRS, int NIS, bool UNPOOL>
+// VEC (one image per stage, maps of whole tiles in width, 16-byte-aligned tensors): the staging units are 16-byte pieces as in
+// wino_wgrad_ps_kernel below — interior float4s of the halo-plane rows + the two halo columns, dy rows as float4s: 15 - 16 units per
+// stage where the scalar form has 48 (27 - 28 against 48 when dy is the pooled gradient, which stays one element + code per unit).
+template <int TCS, int TRS, int NIS, bool UNPOOL, bool VEC>
 __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, const uint8_t* __restrict__ unpool_idx,
     int N, int C, int K, int H, int W, int tiles_w, int tiles_h, int total_stages, int splits, int c_tiles, size_t slab_stride) {
@@ -501,8 +504,30 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(
     constexpr int CPT = 256 / G::PLANE;                               // channels staged per pass
     static_assert(CPT >= 1 && WKT % CPT == 0, "whole passes over the 64 in-channels");
     constexpr int X_IT = WKT / CPT;
-    constexpr int NU = DY_IT + X_IT;
-    float dyr[DY_IT], xr[X_IT];
+    static_assert(!VEC || NIS == 1, "16-byte staging: one image per stage");
+    constexpr int RSEG = G::DW / 4;
+    constexpr int XU = G::PR * RSEG, XCPT = 256 / XU, XV_IT = (WKT + XCPT - 1) / XCPT;              // 24, 10, 7  |  20, 12, 6
+    constexpr int HU = G::PR * 2, HCPT = 256 / HU, XH_IT = (WKT + HCPT - 1) / HCPT;                 // 12, 21, 4  |  20, 12, 6
+    constexpr int DQV = G::DR * RSEG, DKSV = 256 / DQV, DYV_IT = WKT / DKSV;                         // 16, 16, 4
+    static_assert(!VEC || (DQV * DKSV == 256 && DYV_IT * DKSV == WKT), "dy float4 units fill the block exactly");
+    constexpr bool DYV = VEC && !UNPOOL;
+    constexpr int DYU = DYV ? DYV_IT : DY_IT;                         // dy units of a stage
+    constexpr int NU = VEC ? DYU + XV_IT + XH_IT : DY_IT + X_IT;
+    float dyr[DYV ? 1 : DY_IT], xr[VEC ? 1 : X_IT];
+    float4 dyv[DYV ? DYV_IT : 1], xv[VEC ? XV_IT : 1];
+    float xh[VEC ? XH_IT : 1];
+    const int v_cl = tid / XU, v_rem = tid - v_cl * XU, v_row = v_rem / RSEG, v_seg = v_rem - v_row * RSEG;
+    const bool v_thr = tid < XCPT * XU;
+    const int v_e0 = v_cl * plane_hw + v_row * W + 1 + 4 * v_seg;                   // relative to the halo origin (h0 - 1, w0 - 1)
+    const int v_dst0 = G::DY_FLOATS + v_cl * G::PLANEP + v_row * G::PW + 1 + 4 * v_seg;
+    const int h_cl = tid / HU, h_rem = tid - h_cl * HU, h_row = h_rem >> 1, h_col = (h_rem & 1) ? G::DW + 1 : 0;
+    const bool h_thr = tid < HCPT * HU;
+    const int h_e0 = h_cl * plane_hw + h_row * W + h_col;
+    const int h_dst0 = G::DY_FLOATS + h_cl * G::PLANEP + h_row * G::PW + h_col;
+    const int dv_kl = tid / DQV, dv_q = tid - dv_kl * DQV, dv_r = dv_q / RSEG, dv_seg = dv_q - dv_r * RSEG;
+    const int dv_e0 = dv_kl * plane_dy + dv_r * Wd + 4 * dv_seg;
+    const int dv_dst0 = dv_kl * G::LDP + dv_r * G::DW + 4 * dv_seg;                 // even: 8-byte aligned
+    bool xv_ok = false, xh_ok = false, dv_ok = false;
     unsigned dyi[UNPOOL ? DY_IT : 1];
     const int dq = tid & 63, dkl = tid >> 6;
     const int d_nb = dq / (G::DR * G::DW), d_r = (dq / G::DW) % G::DR, d_c = dq % G::DW;
@@ -535,8 +560,33 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(
         dy_ok = ld_n0 + d_nb < N && ld_h0 + d_r < H && ld_w0 + d_c < W;
         const int h = ld_h0 - 1 + x_row, w = ld_w0 - 1 + x_col;
         x_ok = x_thr && ld_n0 + x_nb < N && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+        if constexpr (VEC) {                      // whole tiles in width: the interior columns of a row are all inside the image
+            xv_ok = v_thr && ld_n0 < N && (unsigned)(ld_h0 - 1 + v_row) < (unsigned)H;
+            xh_ok = h_thr && ld_n0 < N && (unsigned)(ld_h0 - 1 + h_row) < (unsigned)H && (unsigned)(ld_w0 - 1 + h_col) < (unsigned)W;
+            dv_ok = ld_n0 < N && ld_h0 + dv_r < H;
+        }
     };
     auto load_unit = [&](int u) {
+        if constexpr (VEC) {
+            if (u < DYU) {
+                if constexpr (DYV) {
+                    dyv[u] = clhip_buf_load4(rs_dy, dv_ok ? (dv_e0 + u * DKSV * plane_dy) * 4 : CLHIP_OOB, 0);
+                } else {
+                    const int e = dy_e0 + u * 4 * plane_dy;
+                    dyr[u] = clhip_buf_load(rs_dy, dy_ok ? e * 4 : CLHIP_OOB, 0);
+                    dyi[u] = clhip_buf_load_u8(rs_di, dy_ok ? e : CLHIP_OOB, 0);
+                }
+            } else if (u < DYU + XV_IT) {
+                const int j = u - DYU;
+                const bool ok = xv_ok && ((j + 1) * XCPT <= WKT || v_cl + j * XCPT < WKT);
+                xv[j] = clhip_buf_load4(rs_x, ok ? (v_e0 + j * XCPT * plane_hw) * 4 : CLHIP_OOB, 0);
+            } else {
+                const int j = u - DYU - XV_IT;
+                const bool ok = xh_ok && ((j + 1) * HCPT <= WKT || h_cl + j * HCPT < WKT);
+                xh[j] = clhip_buf_load(rs_x, ok ? (h_e0 + j * HCPT * plane_hw) * 4 : CLHIP_OOB, 0);
+            }
+            return;
+        }
         if (u < DY_IT) {
             const int e = dy_e0 + u * 4 * plane_dy;
             dyr[u] = clhip_buf_load(rs_dy, dy_ok ? e * 4 : CLHIP_OOB, 0);
@@ -547,6 +597,28 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(
         }
     };
     auto store_unit = [&](int u, int bo) {
+        if constexpr (VEC) {
+            typedef float f2s __attribute__((ext_vector_type(2)));
+            if (u < DYU) {
+                if constexpr (DYV) {
+                    float* d = lds + bo + dv_dst0 + u * DKSV * G::LDP;
+                    *reinterpret_cast<f2s*>(d) = f2s{dyv[u].x, dyv[u].y};
+                    *reinterpret_cast<f2s*>(d + 2) = f2s{dyv[u].z, dyv[u].w};
+                } else {
+                    lds[bo + dy_dst0 + u * 4 * G::LDP] = ((int)dyi[u] == d_code) ? dyr[u] : 0.f;
+                }
+            } else if (u < DYU + XV_IT) {
+                const int j = u - DYU;
+                if (v_thr && ((j + 1) * XCPT <= WKT || v_cl + j * XCPT < WKT)) {
+                    float* d = lds + bo + v_dst0 + j * XCPT * G::PLANEP;
+                    d[0] = xv[j].x; d[1] = xv[j].y; d[2] = xv[j].z; d[3] = xv[j].w;
+                }
+            } else {
+                const int j = u - DYU - XV_IT;
+                if (h_thr && ((j + 1) * HCPT <= WKT || h_cl + j * HCPT < WKT)) lds[bo + h_dst0 + j * HCPT * G::PLANEP] = xh[j];
+            }
+            return;
+        }
         if (u < DY_IT) {
             float v = dyr[u];
             if constexpr (UNPOOL) v = ((int)dyi[u] == d_code) ? v : 0.f;
@@ -1847,8 +1919,16 @@ int clhip_internal_wino_wgrad_partial(const float* x, const float* dy, const uin
         return 0;
     }
     const unsigned grid = (unsigned)(kc_tiles * splits);
-#define WG(TCS_, TRS_, UNP_) hipLaunchKernelGGL((wino_wgrad_kernel<TCS_, TRS_, 1, UNP_>), dim3(grid), dim3(256), 0, s, x, dy, part,      \
-                                                unpool_idx, N, C, K, H, W, tiles_w, tiles_h, (int)total, (int)splits, C / WKT, slab)
+    // whole tiles in width and 16-byte-aligned tensors: stages staged in 16-byte pieces (VEC; CLHIP_WG_VEC=0: the scalar form)
+    static const bool vecg_on = [] { const char* e = getenv("CLHIP_WG_VEC"); return !(e && e[0] == '0'); }();
+    const bool vecg = vecg_on && W % (2 * TCS) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
+#define WG(TCS_, TRS_, UNP_)                                                                                                         \
+    do {                                                                                                                            \
+        if (vecg) hipLaunchKernelGGL((wino_wgrad_kernel<TCS_, TRS_, 1, UNP_, true>), dim3(grid), dim3(256), 0, s, x, dy, part,       \
+                                     unpool_idx, N, C, K, H, W, tiles_w, tiles_h, (int)total, (int)splits, C / WKT, slab);           \
+        else hipLaunchKernelGGL((wino_wgrad_kernel<TCS_, TRS_, 1, UNP_, false>), dim3(grid), dim3(256), 0, s, x, dy, part,           \
+                                unpool_idx, N, C, K, H, W, tiles_w, tiles_h, (int)total, (int)splits, C / WKT, slab);                \
+    } while (0)
     if (wide) { if (unpool_idx) WG(8, 2, true); else WG(8, 2, false); }
     else { if (unpool_idx) WG(4, 4, true); else WG(4, 4, false); }
 #undef WG
