@@ -41,6 +41,10 @@ namespace {
 #ifndef CLHIP_W16G_PRIO
 #define CLHIP_W16G_PRIO 2    // MFMA burst of a chunk fenced off and run at raised wave priority, see compute() in wino_conv16g_kernel
 #endif                       // (0: off — the A/B reference; 1: priority ramps up through the burst; 3: raised during staging instead)
+#ifndef CLHIP_W16_ADIRECT
+#define CLHIP_W16_ADIRECT 1  // wino_conv16_kernel (8 x 8 maps with few units): its A operands from the lane-ordered image too, except the
+#endif                       // instance that would spill (un-pooling, 32-channel waves).  0: through LDS (the A/B reference;
+                             // profiles/r04_w16_adirect.txt: 21.1 -> 19.8, 24.9 -> 20.9, 32.6 -> 30.4 us on small_VGG9's 8 x 8 launches)
 #ifndef CLHIP_W16G_PRIO_UNPOOL
 #define CLHIP_W16G_PRIO_UNPOOL 0   // the same switch for the instances that rebuild the un-pooled gradient while staging (measured slower with 2)
 #endif
@@ -784,13 +788,19 @@ typedef float floatx4v __attribute__((ext_vector_type(4)));
 // KT2 = 16-row MFMA tiles per wave: 2 -> block = 2 images x 64 out-channels (wave = image wp, channel half wk);
 //       1 -> block = 1 image x 64 out-channels (wave = channel quarter): twice the waves for layers with few out-channels
 template <int MODE, bool UNPOOL, int KT2>
-__global__ __launch_bounds__(256, 1) void wino_conv16_kernel(
+__global__ __launch_bounds__(256, (CLHIP_W16_ADIRECT && !(UNPOOL && KT2 == 2)) ? 2 : 1) void wino_conv16_kernel(
     const float* __restrict__ in, const float* __restrict__ U, const float* __restrict__ bias,
     const float* __restrict__ mask_src, float* __restrict__ out, uint8_t* __restrict__ pool_idx,
     int N, int Cin, int Cout, int relu) {
     constexpr int H = 8, W = 8, NIMG = KT2;
     constexpr int PW = 10, PR = 10, PLANE = NIMG * PR * PW;           // halo planes of the block's two images, per channel
-    constexpr int X_FLOATS = WCK * PLANE, BUF = W_FLOATS + X_FLOATS;
+    // CLHIP_W16_ADIRECT: A operands from the lane-ordered image of U straight into registers (as wino_conv16g_kernel); LDS = halo planes
+    // (two blocks per CU by registers then, which keeps the operands out of the AGPR shuffle a 512-register budget invites; the
+    // un-pooling instance with 32-channel waves needs 256 + registers that way and stays on the LDS path: measured 36.2 vs 37.4 us)
+    constexpr bool ADIRECT = CLHIP_W16_ADIRECT != 0 && !(UNPOOL && KT2 == 2);
+    static_assert(!ADIRECT || CLHIP_W16G_ADIRECT != 0, "the lane-ordered image of U is written only with CLHIP_W16G_ADIRECT");
+    constexpr int WOFF = ADIRECT ? 0 : W_FLOATS;
+    constexpr int X_FLOATS = WCK * PLANE, BUF = WOFF + X_FLOATS;
     __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
     __shared__ float bias_s[WKT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -809,13 +819,16 @@ __global__ __launch_bounds__(256, 1) void wino_conv16_kernel(
     const __amdgpu_buffer_rsrc_t rs_x = clhip_rsrc(in_blk, (size_t)(N - n0) * Cin * plane_in * sizeof(float));
     const __amdgpu_buffer_rsrc_t rs_i = clhip_rsrc(UNPOOL ? pool_idx + (size_t)n0 * Cin * plane_in : pool_idx,
                                                    UNPOOL ? (size_t)(N - n0) * Cin * plane_in : 0);
-    const __amdgpu_buffer_rsrc_t rs_u = clhip_rsrc(U + (size_t)kt * n_chunks * W_FLOATS, (size_t)n_chunks * W_FLOATS * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rs_u = ADIRECT
+        ? clhip_rsrc(U + (size_t)((Cout + WKT - 1) / WKT) * n_chunks * W_FLOATS + (size_t)kt * 2 * n_chunks * WD_FLOATS,
+                     (size_t)2 * n_chunks * WD_FLOATS * sizeof(float))
+        : clhip_rsrc(U + (size_t)kt * n_chunks * W_FLOATS, (size_t)n_chunks * W_FLOATS * sizeof(float));
 
     // ---- staging units (as above: one instruction each, weights = straight 16-byte copy, activations = one scalar per halo element)
-    constexpr int W_IT = W_FLOATS / 4 / 256;                         // 10
+    constexpr int W_IT = ADIRECT ? 0 : W_FLOATS / 4 / 256;           // 10
     constexpr int X_IT = (X_FLOATS + 255) / 256;                     // 7
     constexpr int NU = W_IT + X_IT;
-    float4 wv[W_IT];
+    float4 wv[W_IT ? W_IT : 1];
     float xr[X_IT];
     unsigned xi[UNPOOL ? X_IT : 1];
     int xoff[X_IT], xcode[UNPOOL ? X_IT : 1];
@@ -859,7 +872,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv16_kernel(
             *reinterpret_cast<floatx4*>(wd) = floatx4{wv[u].x, wv[u].y, wv[u].z, wv[u].w};
         } else {
             const int j = u - W_IT;
-            float* xs = lds + bo + W_FLOATS;
+            float* xs = lds + bo + WOFF;
             if (256 * (j + 1) <= X_FLOATS || tid + 256 * j < X_FLOATS) {
                 if constexpr (UNPOOL) xs[tid + 256 * j] = ((int)xi[j] == xcode[j]) ? xr[j] : 0.f;
                 else xs[tid + 256 * j] = xr[j];
@@ -869,7 +882,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv16_kernel(
 
     // this lane's tile: image wp of the block, tile (t_row, t_col) = (ti >> 2, ti & 3); channel q of a quad
     const int t_row = ti >> 2, t_col = ti & 3;
-    const int d_off = W_FLOATS + q * PLANE + (wp * PR + 2 * t_row) * PW + 2 * t_col;        // even: 8-byte aligned
+    const int d_off = WOFF + q * PLANE + (wp * PR + 2 * t_row) * PW + 2 * t_col;            // even: 8-byte aligned
     const int a_off = (q * WKT + wk * KW + ti) * WFP;                                      // + 16 * WFP: second row tile
 
     floatx4v acc[KT2][16];
@@ -883,8 +896,16 @@ __global__ __launch_bounds__(256, 1) void wino_conv16_kernel(
     floatx4 av[2][KT2][4];         // [pipeline slot][row tile][frequency quad]
     float vv[2][16];
     f2 dlo[4], dhi[4], tlo[4], thi[4];
-    auto rd_a = [&](const float* abase, int quad, int k2, int fq, int slot) {
-        av[slot][k2][fq] = *reinterpret_cast<const floatx4*>(abase + 4 * quad * WKT * WFP + k2 * 16 * WFP + 4 * fq);
+    // c4 = the 4-channel chunk the operands belong to (ADIRECT: piece (out-channel sixteen, frequency quad) of that chunk, 1 KB per wave)
+    auto rd_a = [&](const float* abase, int quad, int k2, int fq, int slot, int c4) {
+        if constexpr (ADIRECT) {
+            const int cc = c4 < 2 * n_chunks ? c4 : 2 * n_chunks - 1;
+            const clhip_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_u, (((wk * KW) >> 4) + k2) * 4096 + fq * 1024 + lane * 16,
+                                                                        cc * (WD_FLOATS * 4), 0);
+            av[slot][k2][fq] = floatx4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+        } else {
+            av[slot][k2][fq] = *reinterpret_cast<const floatx4*>(abase + 4 * quad * WKT * WFP + k2 * 16 * WFP + 4 * fq);
+        }
     };
     auto rd_d = [&](const float* dbase, int quad, int r) {
         dlo[r] = *reinterpret_cast<const f2*>(dbase + 4 * quad * PLANE + r * PW);
@@ -912,7 +933,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv16_kernel(
     for (int u = 0; u < NU; ++u) load_unit(u, 1);
     __syncthreads();
 #pragma unroll
-    for (int fq = 0; fq < 4; ++fq) { rd_a(lds + a_off, 0, 0, fq, 0); if (KT2 == 2) rd_a(lds + a_off, 0, KT2 - 1, fq, 0); }
+    for (int fq = 0; fq < 4; ++fq) { rd_a(lds + a_off, 0, 0, fq, 0, 0); if (KT2 == 2) rd_a(lds + a_off, 0, KT2 - 1, fq, 0, 0); }
 #pragma unroll
     for (int r = 0; r < 4; ++r) rd_d(lds + d_off, 0, r);
 #pragma unroll
@@ -937,8 +958,8 @@ __global__ __launch_bounds__(256, 1) void wino_conv16_kernel(
                 acc[0][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cs][0][f >> 2][f & 3], vv[cs][f], acc[0][f], 0, 0, 0);
                 if (KT2 == 2) acc[KT2 - 1][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cs][KT2 - 1][f >> 2][f & 3], vv[cs][f], acc[KT2 - 1][f], 0, 0, 0);
                 if (p == NQ - 1 && f == 0) __syncthreads();
-                if (f < 4) { rd_d(db, np, f); rd_a(ab, np, 0, f, ns); }
-                else if (f < 8) { if (KT2 == 2) rd_a(ab, np, KT2 - 1, f - 4, ns); }
+                if (f < 4) { rd_d(db, np, f); rd_a(ab, np, 0, f, ns, 2 * chunk + p + 1); }
+                else if (f < 8) { if (KT2 == 2) rd_a(ab, np, KT2 - 1, f - 4, ns, 2 * chunk + p + 1); }
                 else if (f < 12) row_tf(f - 8);
                 else col_tf(f - 12, ns);
                 if (p == 0) {
