@@ -150,9 +150,10 @@ def wino_wgrad_instance(N, C, K, H, W, unpool):
     kc = (K // 64) * (C // 64)
     splits = min(1 if kc >= 256 else 256 // kc, total)
     u = "true" if unpool else "false"
+    vec = "true" if W % (2 * tcs) == 0 else "false"       # stages staged in 16-byte pieces: maps of whole tiles in width (16-byte-aligned tensors)
     if total < 16 * splits:
-        return "wino_wgrad_ps_kernel<%d, %d, %s> (slabs + reduction)" % (tcs, trs, u)
-    return "wino_wgrad_kernel<%d, %d, 1, %s> (slabs + reduction)" % (tcs, trs, u)
+        return "wino_wgrad_ps_kernel<%d, %d, %s, %s> (slabs + reduction)" % (tcs, trs, u, vec)
+    return "wino_wgrad_kernel<%d, %d, 1, %s, %s> (slabs + reduction)" % (tcs, trs, u, vec)
 
 
 def time_kernels(eng, x, N, iters):

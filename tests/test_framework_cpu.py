@@ -284,11 +284,11 @@ def test_bench_names_the_winograd_instances_the_library_launches():
     assert bench.wino_conv_instance(8, 1, False, 200, 64).startswith("wino_conv16_kernel<1, false, 1>")       # <= 512 waves: 16-channel waves
     assert bench.wino_conv_instance(8, 0, False, 200, 512).startswith("wino_conv16g_kernel<4, 4, 4, 0, false>")
     # weight gradient: fewer than 16 sixteen-tile stages per 64x64-tile block -> the pixel-split kernel
-    assert bench.wino_wgrad_instance(200, 64, 64, 32, 32, True).startswith("wino_wgrad_ps_kernel<8, 2, true>")     # 3200 stages / 256 splits
-    assert bench.wino_wgrad_instance(200, 64, 64, 16, 16, False).startswith("wino_wgrad_ps_kernel<8, 2, false>")
-    assert bench.wino_wgrad_instance(200, 128, 128, 8, 8, True).startswith("wino_wgrad_ps_kernel<4, 4, true>")
-    assert bench.wino_wgrad_instance(200, 512, 512, 8, 8, False).startswith("wino_wgrad_kernel<4, 4, 1, false>")  # 200 stages / 4 splits
-    assert bench.wino_wgrad_instance(200, 256, 256, 16, 16, False).startswith("wino_wgrad_kernel<8, 2, 1, false>")
+    assert bench.wino_wgrad_instance(200, 64, 64, 32, 32, True).startswith("wino_wgrad_ps_kernel<8, 2, true, true>")     # 3200 stages / 256 splits
+    assert bench.wino_wgrad_instance(200, 64, 64, 16, 16, False).startswith("wino_wgrad_ps_kernel<8, 2, false, true>")
+    assert bench.wino_wgrad_instance(200, 128, 128, 8, 8, True).startswith("wino_wgrad_ps_kernel<4, 4, true, true>")
+    assert bench.wino_wgrad_instance(200, 512, 512, 8, 8, False).startswith("wino_wgrad_kernel<4, 4, 1, false, true>")  # 200 stages / 4 splits
+    assert bench.wino_wgrad_instance(200, 256, 256, 16, 16, False).startswith("wino_wgrad_kernel<8, 2, 1, false, true>")
 
 
 def test_hat_alexnet_net_structure():
