@@ -9,7 +9,9 @@ One "step" = one pass of the hot path over one batch of 200 synthetic 3x64x64 im
 i.e. 400 images through forward+backward per step.  Inputs (the whole 8000-image task) are
 resident in HBM before the timed region; batches are gathered on device.
 
-Prints ONE JSON line (rank 0).  Extra objects:
+Prints ONE JSON line (rank 0) as the LAST line of stdout, at most LINE_LIMIT bytes (compact_line): the contract's keys,
+`roofline`, `cpu_baseline` and a few scalars.  The full record (everything below) is written to
+gpurun_out/bench_details.json and to stderr as `bench-details: {...}`.  Objects of the full record:
   roofline      — dominant kernel (by time) vs the fp32-MFMA peak, timed with HIP events on
                   the launch stream inside this process
   cpu_baseline  — the CPU oracle (torch-CPU restatement of the reference path, kind "port")
@@ -650,7 +652,7 @@ def pair_cpu_leg(root, threads, pin_from=None):
     return res
 
 
-def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epochs=70):
+def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epochs=70, cpu_rates=None):
     """BASELINE.json's second metric ('full-sweep wall-clock'), two measurements.
 
     `gpu_s`: what framework/main.py runs for `small_VGG9_cl_128_128 --method_name EWC --test` with the reference's defaults
@@ -668,8 +670,9 @@ def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epoch
     initialisation.  `cpu_spread_points` = the largest accuracy difference between the two CPU legs (two summation orders of
     the same fp32 arithmetic); `max_accuracy_gap_points` = the largest between the GPU leg and the first CPU leg.
 
-    `cpu_s_extrapolated`: the GPU sweep's counted image passes priced at the two host rates (forward+backward+update, forward
-    only) the first CPU leg measured.  An extrapolation, and says so; `pair.cpu_s / pair.gpu_s` is measured like for like."""
+    `gpu_over_cpu_wall_clock` = `pair.cpu_s / pair.gpu_s`: measured like for like, the ratio to quote.
+    `cpu_s_extrapolated`: the GPU sweep's counted image passes priced at the two batch-200 host rates (forward+backward+update,
+    forward only) that cpu_baseline measured with the host otherwise idle (`cpu_rates`).  An extrapolation, and says so."""
     import contextlib
     import io
     import shutil
@@ -705,10 +708,12 @@ def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epoch
                 pin = leg_no * (ncpu // 4) if ncpu >= 4 * max(cpu_threads, other) else -1
                 for sub in ("data", "models", os.path.join("train", "synthetic_tiny_imagenet", "SI")):
                     shutil.copytree(os.path.join(proot, sub), os.path.join(croot, sub))
-                env = dict(os.environ, OMP_NUM_THREADS=str(t), MKL_NUM_THREADS=str(t))
+                env = dict(os.environ, OMP_NUM_THREADS=str(t), MKL_NUM_THREADS=str(t),
+                           HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")     # a CPU leg makes no device context
+                errf = open(os.path.join(root, "pair_cpu_t%d.stderr" % t), "w+")
                 legs.append((t, subprocess.Popen([sys.executable, os.path.abspath(__file__), "--pair-cpu-leg", croot, "--pair-threads", str(t), "--pair-pin", str(pin), "--sweep-blobs",
                                                   ",".join("%g" % SWEEP_DATA["blobs"][k] for k in ("g", "amp", "noise_lr", "q"))],
-                                                 stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True)))
+                                                 stdout=subprocess.PIPE, stderr=errf, env=env, text=True), errf))
             with contextlib.redirect_stdout(quiet), _PassCounter(PAIR["sizes"][0]) as pcounts:
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
@@ -767,12 +772,15 @@ def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epoch
         # ---- collect the CPU legs
         if pair is not None:
             cpu = []
-            for t, proc in legs:
+            for t, proc, errf in legs:
                 try:
-                    so, se = proc.communicate(timeout=900)
+                    so, _ = proc.communicate(timeout=900)
                 except subprocess.TimeoutExpired:
                     proc.kill()
-                    so, se = proc.communicate()
+                    so, _ = proc.communicate()
+                errf.seek(0)
+                se = errf.read()
+                errf.close()
                 line = [ln for ln in so.splitlines() if ln.startswith("{")]
                 if proc.returncode != 0 or not line:
                     raise RuntimeError("pair CPU leg (%d threads) failed:\n%s" % (t, se[-2000:]))
@@ -792,20 +800,28 @@ def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epoch
                 " / ".join(str(c["threads"]) for c in cpu), os.cpu_count() or 0)
             pair["gpu_over_cpu_wall_clock"] = pair["cpu_s"] / pair["gpu_s"]
             res["pair"] = pair
-            res["cpu_rates_images_per_s"] = cpu[0]["rates_images_per_s"]
-            if counts is not None:
-                rt = cpu[0]["rates_images_per_s"]
-                res["cpu_s_extrapolated"] = counts["train"] / rt["forward_backward_update"] + counts["eval"] / rt["forward_only"]
-                res["cpu_s_extrapolated_how"] = ("GPU sweep's image passes (%d forward+backward, %d forward-only) at the two host rates "
-                                                 "the pair's first CPU leg measured on this box; not run" % (counts["train"], counts["eval"]))
-                res["gpu_over_cpu_wall_clock"] = res["cpu_s_extrapolated"] / res["gpu_s"]
+            res["pair_cpu_rates_images_per_s"] = cpu[0]["rates_images_per_s"]
+            # the headline ratio is the MEASURED like-for-like one (same work on both sides)
+            res["gpu_over_cpu_wall_clock"] = pair["gpu_over_cpu_wall_clock"]
+            res["gpu_over_cpu_wall_clock_how"] = "pair: cpu_s / gpu_s of the same bounded task, both measured in this run"
+            if counts is not None and cpu_rates:
+                # The sweep runs at batch 200; the pair's legs run at batch 50, two of them side by side with the GPU sweep, so their
+                # rates under-state the host.  Price the sweep's passes at the batch-200 rates cpu_baseline measured ALONE on the
+                # host (best thread count of its probe) instead.
+                res["cpu_rates_images_per_s"] = dict(cpu_rates)
+                res["cpu_s_extrapolated"] = counts["train"] / cpu_rates["forward_backward_update"] + counts["eval"] / cpu_rates["forward_only"]
+                res["cpu_s_extrapolated_how"] = ("GPU sweep's image passes (%d forward+backward, %d forward-only) at the batch-200 host rates "
+                                                 "cpu_baseline measured with nothing else running on this box; an extrapolation, not run"
+                                                 % (counts["train"], counts["eval"]))
+                res["gpu_over_cpu_extrapolated"] = res["cpu_s_extrapolated"] / res["gpu_s"]
     except BaseException as e:
         if "gpu_error" not in res:
             raise
         res["error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
     finally:
-        for _, proc in legs:
+        for _, proc, errf in legs:
             proc.kill()
+            errf.close()
         shutil.rmtree(root, ignore_errors=True)
     return res
 
@@ -862,6 +878,97 @@ def sharded_sweep(dev_index, world, epochs=8, sizes=(2000, 500, 500), batch=50):
         shutil.rmtree(root, ignore_errors=True)
 
 
+LINE_LIMIT = 6000        # bytes: the driver keeps the last 8 KB of stdout and parses its LAST line
+
+
+def _round_floats(o, digits=6):
+    """Floats to `digits` significant digits (the line is a record, not an archive: full precision lives in the details file)."""
+    if isinstance(o, float):
+        return float("%.*g" % (digits, o)) if o == o and abs(o) != float("inf") else None
+    if isinstance(o, dict):
+        return {k: _round_floats(v, digits) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_round_floats(v, digits) for v in o]
+    return o
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def compact_line(out, details_path=None, limit=LINE_LIMIT):
+    """The ONE stdout line: the contract's keys + `roofline` + `cpu_baseline` + a few scalars of the other objects, at most
+    `limit` bytes.  Everything else (per-layer table, the other BASELINE configs, the sweep's body) goes to the details file
+    and to stderr.  Optional parts are dropped, longest first, if the line would still exceed the limit; the contract's keys
+    never are."""
+    c = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "dtype", "data"))
+    c["vs_baseline"] = out.get("vs_baseline")
+    c["config"] = _pick(out.get("config", {}), ("workload", "images_per_step", "batch", "parallelism", "algorithmic_gflop_per_step",
+                                                "step_algorithmic_tflops", "step_mfma_issued_frac", "gpu_over_cpu"))
+    if "roofline" in out:
+        r = out["roofline"]
+        c["roofline"] = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_gflop_per_launch",
+                                  "algorithmic_bytes_per_launch", "avg_launch_us", "avg_launch_how", "winograd", "peak_how",
+                                  "mfma_issued_frac", "mfma_busy_pmc"))
+        c["roofline"].setdefault("traffic", r.get("traffic"))
+    if "cpu_baseline" in out:
+        c["cpu_baseline"] = _pick(out["cpu_baseline"], ("value", "unit", "cores", "kind", "sample", "host_logical_cores", "host_cpu_model",
+                                                        "forward_only_images_per_s"))
+    optional = {}
+    if "sweep_s" in out:
+        optional["sweep_s"] = out["sweep_s"]
+    if isinstance(out.get("grid"), dict):
+        optional["grid"] = _pick(out["grid"], ("nodes", "iterations", "winner_rank", "winner_lr", "fill_factor", "collectives_in_timed_region"))
+    ss = out.get("sharded_sweep")
+    if isinstance(ss, dict):
+        optional["sharded_sweep"] = _pick(ss, ("error", "world", "seconds", "first_task_seconds", "methods", "fill_factor_grid", "fill_factor",
+                                               "useful_fraction", "phase2_trainings_task2", "accepted_lambda_task2"))
+        if "this_rank" in ss:
+            optional["sharded_sweep"]["busy_fraction_rank0"] = ss["this_rank"].get("busy_fraction")
+    cfgs = out.get("configs")
+    if isinstance(cfgs, dict):
+        optional["configs_ms_per_step"] = {k: v["ms_per_step"] for k, v in cfgs.items() if isinstance(v, dict) and "ms_per_step" in v}
+        cb = cfgs.get("conv_backward")
+        if isinstance(cb, dict):
+            optional["conv_backward_mfma_issued_frac"] = {k: v.get("all_backward_mfma_issued_frac") for k, v in cb.items() if isinstance(v, dict)}
+    if details_path:
+        optional["details"] = details_path
+    c.update(optional)
+    c = _round_floats(c)
+    line = json.dumps(c, separators=(",", ":"))
+    for k in sorted(optional, key=lambda k: -len(json.dumps(c.get(k)))):
+        if len(line) <= limit:
+            break
+        del c[k]
+        line = json.dumps(c, separators=(",", ":"))
+    if len(line) > limit:                      # last resort: the free-text fields
+        for path in (("roofline", "avg_launch_how"), ("roofline", "peak_how"), ("cpu_baseline", "host_cpu_model"), ("cpu_baseline", "sample")):
+            if len(line) <= limit:
+                break
+            if path[0] in c and path[1] in c[path[0]]:
+                c[path[0]][path[1]] = str(c[path[0]][path[1]])[:80]
+                line = json.dumps(c, separators=(",", ":"))
+    return line
+
+
+def emit(out):
+    """Details to gpurun_out/bench_details.json (when writable) and to stderr; the compact line LAST and ALONE on stdout."""
+    path = None
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, "bench_details.json")
+        with open(path, "w") as f:
+            json.dump(out, f)
+        path = os.path.relpath(path, ROOT)
+    except OSError:
+        path = None
+    sys.stderr.write("bench-details: " + json.dumps(out) + "\n")
+    sys.stderr.flush()
+    sys.stdout.flush()
+    print(compact_line(out, path), flush=True)
+
+
 def host_cpu():
     model = ""
     try:
@@ -915,9 +1022,17 @@ def cpu_baseline(batch, steps):
     for _ in range(steps):
         step(False)
     dt = time.perf_counter() - t0
+    # forward only (evaluation / validation passes of a sweep), same batch, same threads, nothing else on the host
+    with torch.no_grad():
+        vgg_ref.forward(params, SMALL, x)
+        t0 = time.perf_counter()
+        nf = max(2, steps // 2)
+        for _ in range(nf):
+            vgg_ref.forward(params, SMALL, x)
+        dtf = time.perf_counter() - t0
     cpu = host_cpu()
     return dict(value=2 * batch * steps / dt, unit="images/s", cores=cores, kind="port", host_logical_cores=cpu["logical_cores"],
-                host_cpu_model=cpu["model"],
+                host_cpu_model=cpu["model"], forward_only_images_per_s=batch * nf / dtf,
                 sample="%d steps (EWC train batch + Fisher batch, N=%d) of the torch-CPU oracle, %d threads (fastest of "
                        "16 / 32 / 64 on this host's %d logical cores), %.1f s" % (steps, batch, cores, cpu["logical_cores"], dt))
 
@@ -1124,16 +1239,21 @@ def main():
             out["config"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         if world == 1 and not args.no_sweep:
             try:
-                out["sweep"] = full_sweep(local_rank, cpu_threads=0 if args.no_cpu_baseline else out["cpu_baseline"]["cores"],
-                                          tasks=args.sweep_tasks, epochs=args.sweep_epochs)
+                cb = out.get("cpu_baseline")
+                out["sweep"] = full_sweep(local_rank, cpu_threads=0 if args.no_cpu_baseline else cb["cores"],
+                                          tasks=args.sweep_tasks, epochs=args.sweep_epochs,
+                                          cpu_rates=None if cb is None else {"forward_backward_update": cb["value"],
+                                                                             "forward_only": cb["forward_only_images_per_s"]})
             except BaseException as e:            # (incl. the SystemExit of a failed training) the headline line is printed regardless
                 import traceback
                 out["sweep"] = {"error": "%s: %s" % (type(e).__name__, e), "traceback_tail": traceback.format_exc()[-1500:]}
             out["sweep_s"] = {"gpu": out["sweep"].get("gpu_s"), "cpu_extrapolated": out["sweep"].get("cpu_s_extrapolated"),
+                              "gpu_over_cpu_measured_pair": out["sweep"].get("gpu_over_cpu_wall_clock"),
+                              "gpu_over_cpu_extrapolated": out["sweep"].get("gpu_over_cpu_extrapolated"),
                               "pair_gpu": out["sweep"].get("pair", {}).get("gpu_s"), "pair_cpu": out["sweep"].get("pair", {}).get("cpu_s"),
                               "pair_max_accuracy_gap_points": out["sweep"].get("pair", {}).get("max_accuracy_gap_points"),
                               "pair_cpu_spread_points": out["sweep"].get("pair", {}).get("cpu_spread_points")}
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist:
         dist.barrier()          # rank 0 was still timing kernels: tear the communicator down together
         dist.destroy_process_group()

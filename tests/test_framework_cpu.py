@@ -818,3 +818,37 @@ def test_model_names_match_reference_factory_g34():
                 assert abs(float(p.std()) - std) <= 0.1 * std and abs(float(p.mean())) <= 4 * std / p.numel() ** 0.5 + 1e-12, (name, pn)
         assert [type(mod).__name__ for mod in m.modules() if isinstance(mod, torch.nn.Dropout)] == ["Dropout"] * sum(
             1 for k in g.files if k.startswith(name + "__dropmask"))
+
+
+def test_bench_last_line_is_compact_and_parseable():
+    """The driver parses the LAST stdout line of bench.py and keeps 8 KB of tail: round 4's 23.7 KB line was lost.  The line
+    built from the largest full record on file (profiles/r04_final_bench.json) must stay under bench.LINE_LIMIT, parse, and
+    carry the contract's keys + roofline + cpu_baseline; a record ten times larger must still fit (optional parts dropped)."""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod3", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    with open(os.path.join(root, "profiles", "r04_final_bench.json")) as f:
+        full = json.load(f)
+    assert len(json.dumps(full)) > 20000
+    line = bench.compact_line(full, "gpurun_out/bench_details.json")
+    assert "\n" not in line and len(line) <= bench.LINE_LIMIT < 8192
+    rec = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in rec, k
+    assert rec["value"] == float("%.6g" % full["value"]) and rec["config"]["workload"] == full["config"]["workload"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us"):
+        assert k in rec["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in rec["cpu_baseline"], k
+    assert "per_layer" not in rec["roofline"] and "configs" not in rec and "sweep" not in rec
+    # a bloated record: optional objects go, the contract stays
+    full["grid"] = {"nodes": 8, "collectives_in_timed_region": ["x" * 3000] * 4, "fill_factor": 0.625}
+    full["roofline"]["avg_launch_how"] = "y" * 5000
+    line = bench.compact_line(full, None)
+    assert len(line) <= bench.LINE_LIMIT
+    rec = json.loads(line)
+    assert rec["value"] == float("%.6g" % full["value"]) and "roofline" in rec and "cpu_baseline" in rec
