@@ -763,27 +763,19 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_c3_unpool_kernel(
 //   dw[k][c][rs] = sum_s part[s][rs][k][c] ; db[k] = sum_s part[s][9KC + k]
 constexpr int RED_EL = 64, RED_J = 16, RED_V = 4;          // 64 elements x 16 split-lanes per block, 4 elements per thread
 constexpr int RED_THREADS = RED_EL / RED_V * RED_J;
-// CLHIP_WGRED_WIDE=1 (experiment, off: not yet measured): 256 elements x 4 split-lanes — a wave reads 1 KB of ONE slab per load
-// instruction instead of four 256-byte pieces of four slabs.  Another fixed association of the same sums: other bits, still
-// run-to-run deterministic; every reduction of a process uses the same shape.
-constexpr int REDW_EL = 256, REDW_J = 4;
-static_assert(REDW_EL / RED_V * REDW_J == RED_THREADS, "same block size");
-static bool red_wide() {
-    static const bool on = [] { const char* e = getenv("CLHIP_WGRED_WIDE"); return e && e[0] == '1'; }();
-    return on;
-}
-static int red_el() { return red_wide() ? REDW_EL : RED_EL; }
+// (Measured and removed in round 5: 256 elements x 4 split-lanes — 1 KB of ONE slab per wave and load instruction — ran 39.1 us
+// against 22.7 us for the slabs of a small_VGG9 pass, profiles/r05_wgred_wide.txt: fewer splits in flight per element.)
 
 // One block: elements [e0, e0 + 64) of the (9KC + K)-element slab.  Thread (j, v) sums splits [j q, (j + 1) q) of the 4
 // consecutive elements v (16-byte loads when the slab rows are 16-byte aligned), then lane j = 0 adds the 16 partial
 // sums in order: the order per element does not depend on the vector width.
-template <int RED_EL, int RED_J>
+template <int EL, int J>
 __device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db,
-                                                   int K, int C, int splits, size_t e0, double (*partial)[RED_EL]) {
+                                                   int K, int C, int splits, size_t e0, double (*partial)[EL]) {
     const size_t kc = (size_t)K * C, nw = 9 * kc, total = nw + K;
-    const int v = threadIdx.x % (RED_EL / RED_V), j = threadIdx.x / (RED_EL / RED_V);
+    const int v = threadIdx.x % (EL / RED_V), j = threadIdx.x / (EL / RED_V);
     const size_t e = e0 + (size_t)v * RED_V;
-    const int q = (splits + RED_J - 1) / RED_J;
+    const int q = (splits + J - 1) / J;
     const int s0 = j * q, s1 = min(splits, s0 + q);
     double s[RED_V] = {0.0, 0.0, 0.0, 0.0};
     if ((total & 3) == 0 && e + RED_V <= total) {
@@ -802,13 +794,13 @@ __device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ par
 #pragma unroll
     for (int t = 0; t < RED_V; ++t) partial[j][v * RED_V + t] = s[t];
     __syncthreads();
-    if (threadIdx.x < RED_EL) {
+    if (threadIdx.x < EL) {
         const int el = threadIdx.x;
         const size_t ee = e0 + el;
         if (ee < total) {
             double t = 0.0;
 #pragma unroll
-            for (int jj = 0; jj < RED_J; ++jj) t += partial[jj][el];
+            for (int jj = 0; jj < J; ++jj) t += partial[jj][el];
             if (ee < nw) {
                 const size_t rs = ee / kc, rem = ee - rs * kc;     // rem = k*C + c
                 dw[rem * 9 + rs] = (float)t;
@@ -947,9 +939,8 @@ static int bwd_weight_impl(const float* x, const float* dy, const uint8_t* unpoo
         *defer = clhip_wgrad_job{part, dw, db, K, C, p.splits};
         return 0;
     }
-    const unsigned bx = (unsigned)((p.slab + red_el() - 1) / red_el());
-    if (red_wide()) hipLaunchKernelGGL((wgrad_reduce_kernel<REDW_EL, REDW_J>), dim3(bx), dim3(RED_THREADS), 0, s, part, dw, db, K, C, p.splits);
-    else hipLaunchKernelGGL((wgrad_reduce_kernel<RED_EL, RED_J>), dim3(bx), dim3(RED_THREADS), 0, s, part, dw, db, K, C, p.splits);
+    const unsigned bx = (unsigned)((p.slab + RED_EL - 1) / RED_EL);
+    hipLaunchKernelGGL((wgrad_reduce_kernel<RED_EL, RED_J>), dim3(bx), dim3(RED_THREADS), 0, s, part, dw, db, K, C, p.splits);
     CLHIP_LAUNCH_CHECK();
     return 0;
 }
@@ -981,10 +972,8 @@ int clhip_conv3x3_bwd_weight_slabs(const float* x, const float* dy, const uint8_
 int clhip_conv3x3_bwd_weight_reduce(const void* ws, float* dw, float* db, int K, int C, int splits, void* stream) {
     if (!ws || !dw || K <= 0 || C <= 0 || splits <= 0) return CLHIP_EINVAL;
     const size_t slab = (size_t)9 * K * C + K;
-    const unsigned bx = (unsigned)((slab + red_el() - 1) / red_el());
-    if (red_wide()) hipLaunchKernelGGL((wgrad_reduce_kernel<REDW_EL, REDW_J>), dim3(bx), dim3(RED_THREADS), 0, as_stream(stream),
-                                       static_cast<const float*>(ws), dw, db, K, C, splits);
-    else hipLaunchKernelGGL((wgrad_reduce_kernel<RED_EL, RED_J>), dim3(bx), dim3(RED_THREADS), 0, as_stream(stream),
+    const unsigned bx = (unsigned)((slab + RED_EL - 1) / RED_EL);
+    hipLaunchKernelGGL((wgrad_reduce_kernel<RED_EL, RED_J>), dim3(bx), dim3(RED_THREADS), 0, as_stream(stream),
                             static_cast<const float*>(ws), dw, db, K, C, splits);
     CLHIP_LAUNCH_CHECK();
     return 0;
@@ -1009,11 +998,10 @@ int clhip_internal_wgrad_reduce_multi(const clhip_wgrad_job* jobs, int n, hipStr
     for (int i = 0; i < n; ++i) {
         r.job[i] = jobs[i];
         const size_t total = (size_t)9 * jobs[i].K * jobs[i].C + jobs[i].K;
-        r.first[i + 1] = r.first[i] + (unsigned)((total + red_el() - 1) / red_el());
+        r.first[i + 1] = r.first[i] + (unsigned)((total + RED_EL - 1) / RED_EL);
     }
     for (int i = n; i < CLHIP_WGRAD_JOBS_MAX; ++i) { r.job[i] = clhip_wgrad_job{nullptr, nullptr, nullptr, 0, 0, 0}; r.first[i + 1] = r.first[n]; }
-    if (red_wide()) hipLaunchKernelGGL((wgrad_reduce_multi_kernel<REDW_EL, REDW_J>), dim3(r.first[n]), dim3(RED_THREADS), 0, s, r);
-    else hipLaunchKernelGGL((wgrad_reduce_multi_kernel<RED_EL, RED_J>), dim3(r.first[n]), dim3(RED_THREADS), 0, s, r);
+    hipLaunchKernelGGL((wgrad_reduce_multi_kernel<RED_EL, RED_J>), dim3(r.first[n]), dim3(RED_THREADS), 0, s, r);
     CLHIP_LAUNCH_CHECK();
     return 0;
 }

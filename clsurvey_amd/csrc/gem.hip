@@ -76,16 +76,17 @@ __device__ __forceinline__ void gram_acc1(double* acc, const float* v, std::inte
     ((acc[K] += (double)v[GramPair<M, S, GRP, K>::i] * (double)v[GramPair<M, S, GRP, K>::j]), ...);
 }
 
+// Accumulation of wave group GRP's pairs over this block's columns; acc is padded to the same NA_MAX slots in every group
+// (slots past the group's own pair count stay 0) so that the reduction below is ONE piece of code for the whole block.
 template <int M, int S, int GRP, bool VEC>
-__device__ __forceinline__ void gram_partial_body(const float* __restrict__ G, size_t ld, const RowSel& sel, size_t n,
-                                                  double* __restrict__ partial, double* red) {
+__device__ __forceinline__ void gram_accumulate(const float* __restrict__ G, size_t ld, const RowSel& sel, size_t n,
+                                                double (&acc)[(M * (M + 1) / 2 + S - 1) / S]) {
     constexpr int NP = M * (M + 1) / 2;
     constexpr int NA = (NP - GRP + S - 1) / S;            // pairs GRP, GRP + S, ... of this wave
-    constexpr int NA_MAX = (NP + S - 1) / S;              // the same number of reduction rounds (barriers) in every wave
+    constexpr int NA_MAX = (NP + S - 1) / S;
     constexpr int COLS = GB / S;                          // column groups per block and sweep
-    double acc[NA];
 #pragma unroll
-    for (int k = 0; k < NA; ++k) acc[k] = 0.0;
+    for (int k = 0; k < NA_MAX; ++k) acc[k] = 0.0;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const size_t col0 = (size_t)blockIdx.x * COLS + (size_t)(wave / S) * 64 + lane, stride = (size_t)gridDim.x * COLS;
     const size_t n4 = VEC ? n / 4 : 0;
@@ -101,10 +102,35 @@ __device__ __forceinline__ void gram_partial_body(const float* __restrict__ G, s
         for (int i = 0; i < M; ++i) v[i] = G[(size_t)sel.idx[i] * ld + c];
         gram_acc1<M, S, GRP>(acc, v, std::make_integer_sequence<int, NA>{});
     }
-    // fixed tree: first over the wave sets (offsets that keep wave % S), then inside the wave; one pair slot per round
+}
+
+template <int M, bool VEC>
+__global__ __launch_bounds__(GB) void gram_partial_kernel(const float* __restrict__ G, size_t ld, RowSel sel, size_t n,
+                                                          double* __restrict__ partial) {
+    constexpr int S = gram_split(M);
+    constexpr int NP = M * (M + 1) / 2;
+    constexpr int NA_MAX = (NP + S - 1) / S;
+    __shared__ double red[GB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int grp = (tid >> 6) % S;                       // uniform per wave
+    double acc[NA_MAX];
+    // only the ACCUMULATION is specific to the wave group (compile-time pair indices); no barrier inside the branches
+    if constexpr (S == 1) {
+        gram_accumulate<M, 1, 0, VEC>(G, ld, sel, n, acc);
+    } else if constexpr (S == 2) {
+        if (grp) gram_accumulate<M, 2, 1, VEC>(G, ld, sel, n, acc);
+        else gram_accumulate<M, 2, 0, VEC>(G, ld, sel, n, acc);
+    } else {
+        if (grp == 0) gram_accumulate<M, 4, 0, VEC>(G, ld, sel, n, acc);
+        else if (grp == 1) gram_accumulate<M, 4, 1, VEC>(G, ld, sel, n, acc);
+        else if (grp == 2) gram_accumulate<M, 4, 2, VEC>(G, ld, sel, n, acc);
+        else gram_accumulate<M, 4, 3, VEC>(G, ld, sel, n, acc);
+    }
+    // common code, every wave at the same barriers: fixed tree, first over the wave sets (offsets that keep wave % S), then
+    // inside the wave; one pair slot per round (round k: pair grp + k * S of each wave group)
 #pragma unroll
     for (int k = 0; k < NA_MAX; ++k) {
-        red[tid] = (k < NA) ? acc[k < NA ? k : 0] : 0.0;
+        red[tid] = acc[k];
         __syncthreads();
         for (int o = GB / 2; o >= 64 * S; o >>= 1) {
             if (tid < o) red[tid] += red[tid + o];
@@ -114,27 +140,8 @@ __device__ __forceinline__ void gram_partial_body(const float* __restrict__ G, s
             if (tid < 64 * S && lane < o) red[tid] += red[tid + o];
             __syncthreads();
         }
-        if (tid < 64 * S && lane == 0 && GRP + k * S < NP) partial[(size_t)blockIdx.x * NP + GRP + k * S] = red[tid];
+        if (tid < 64 * S && lane == 0 && grp + k * S < NP) partial[(size_t)blockIdx.x * NP + grp + k * S] = red[tid];
         __syncthreads();
-    }
-}
-
-template <int M, bool VEC>
-__global__ __launch_bounds__(GB) void gram_partial_kernel(const float* __restrict__ G, size_t ld, RowSel sel, size_t n,
-                                                          double* __restrict__ partial) {
-    constexpr int S = gram_split(M);
-    __shared__ double red[GB];
-    const int grp = (threadIdx.x >> 6) % S;               // uniform per wave; every wave runs the same number of barriers
-    if constexpr (S == 1) {
-        gram_partial_body<M, 1, 0, VEC>(G, ld, sel, n, partial, red);
-    } else if constexpr (S == 2) {
-        if (grp) gram_partial_body<M, 2, 1, VEC>(G, ld, sel, n, partial, red);
-        else gram_partial_body<M, 2, 0, VEC>(G, ld, sel, n, partial, red);
-    } else {
-        if (grp == 0) gram_partial_body<M, 4, 0, VEC>(G, ld, sel, n, partial, red);
-        else if (grp == 1) gram_partial_body<M, 4, 1, VEC>(G, ld, sel, n, partial, red);
-        else if (grp == 2) gram_partial_body<M, 4, 2, VEC>(G, ld, sel, n, partial, red);
-        else gram_partial_body<M, 4, 3, VEC>(G, ld, sel, n, partial, red);
     }
 }
 

@@ -71,6 +71,10 @@ def build_parser():
     p.add_argument("--shard", action="store_true",
                    help="one process per GPU (torch.distributed.run): grid nodes, decay attempts and evaluations are "
                         "spread over the ranks; each rank writes under <results_root>/rank<r>")
+    p.add_argument("--methods", type=str, default=None,
+                   help="with --shard: comma-separated method names run SIDE BY SIDE on disjoint rank subsets of the node "
+                        "(e.g. MAS,SI on 8 GPUs = 4 + 4; each subset shards its method's grid / decay / evaluation as --shard "
+                        "does over the world).  With fewer ranks than methods they run one after the other over all ranks")
     p.add_argument("--no_speculation", action="store_true",
                    help="with --shard: phase 2 runs sequentially on rank 0 only; its model and state are broadcast")
     p.add_argument("--synthetic", type=str, default=None,
@@ -186,7 +190,7 @@ def lr_grid_single_task(args, manager, save_models_mode="keep_none", train_node=
             manager.gridsearch_exp_dir = node_dir(lr, it)
             os.makedirs(manager.gridsearch_exp_dir, exist_ok=True)
             from . import shard
-            with shard.busy("grid"):                             # (stage accounting only: shard.STATS, bench.py's N = 1 anchor)
+            with shard.busy("grid", device=getattr(args, "device", None)):      # (stage accounting only: shard.STATS)
                 _, acc = manager.method.grid_train(args, manager, lr)
             return acc
 
@@ -317,25 +321,25 @@ class HyperparameterFramework(object):
         mine = None
         if rank == 0:
             loaded = self.load_chkpt(manager)
-            mine = {"loaded": loaded, "state": copy.deepcopy(self._get_state()) if loaded else None,
+            if not loaded:
+                self.attempts = 0
+                self.hyperparams_backup = copy.deepcopy(self.hyperparams)
+            # rank 0's state travels in BOTH cases: every rank provably starts from identical hyper-parameters and backup
+            mine = {"loaded": loaded, "state": copy.deepcopy(self._get_state()),
                     "done": os.path.exists(manager.get_success_token_path(manager.heuristic_exp_dir))}
         dec = shard.broadcast_object(mine, 0)
-        if dec["loaded"]:
-            if rank != 0:
-                self._restore_state(dec["state"])
-        else:
-            self.attempts = 0
-            self.hyperparams_backup = copy.deepcopy(self.hyperparams)
+        if rank != 0:
+            self._restore_state(dec["state"])
         if dec["done"]:
             if rank != 0:
                 shutil.rmtree(manager.heuristic_exp_dir, ignore_errors=True)
             shard.broadcast_files(manager.heuristic_exp_dir, 0)
             manager.method.hyperparams = self.hyperparams
         elif rank != 0:
-            # a stale token of this rank's own (rank 0 says the task is NOT finished) must not survive into the retrain
-            token = manager.get_success_token_path(manager.heuristic_exp_dir)
-            if os.path.exists(token):
-                os.remove(token)
+            # rank 0 says the task is NOT finished: nothing of this rank's own earlier attempt (stale token, best_model.pth.tar,
+            # hyperparams.pth.tar of a run killed half-way) may survive into the retrain
+            shutil.rmtree(manager.heuristic_exp_dir, ignore_errors=True)
+            os.makedirs(manager.heuristic_exp_dir, exist_ok=True)
         return dec["done"]
 
     def _sequential_decay(self, args, manager, finetune_acc):
@@ -348,7 +352,7 @@ class HyperparameterFramework(object):
             try:
                 manager.method.hyperparams = self.hyperparams
                 from . import shard
-                with shard.busy("decay"):
+                with shard.busy("decay", device=getattr(args, "device", None)):
                     model, task_lr_acc = manager.method.train(args, manager, self.hyperparams)
             except Exception:
                 traceback.print_exc()
@@ -550,7 +554,7 @@ def eval_all_models_all_tasks(args, manager, ds_paths, model_paths):
             seq_acc, seq_forgetting = {dataset_index: []}, {dataset_index: []}
             for trained_model_idx in range(dataset_index, len(ds_paths)):
                 try:
-                    with shard.busy("eval"):
+                    with shard.busy("eval", device=getattr(args, "device", None)):
                         accuracy = evaluate(dataset_index, trained_model_idx)
                 except Exception:
                     print("ERROR in Testing model, trained until TASK ", str(trained_model_idx + 1))
@@ -575,7 +579,7 @@ def eval_all_models_all_tasks(args, manager, ds_paths, model_paths):
     table, err = {}, None
     try:
         mine = [(n, pq) for n, pq in enumerate(pairs) if n % world == rank]
-        with shard.busy("eval", len(mine)):
+        with shard.busy("eval", len(mine), device=getattr(args, "device", None)):
             table = {n: evaluate(*pq) for n, pq in mine}
     except Exception as e:
         traceback.print_exc()
@@ -619,14 +623,60 @@ def first_task_modelname(args):
     return "_".join(name)
 
 
+def main_methods(argv, names, dataset=None):
+    """`--shard --methods A,B[,...]` (BASELINE configs 3 / 5 are "MAS + SI" / "PackNet + HAT" on one 8-GPU node):
+    the world's ranks are split into one contiguous block per method (shard.split_ranks); each block runs main() for ITS method
+    with the block as its sharding world — own communicator, group-relative ranks, nothing exchanged between blocks.  Every
+    method's decisions equal those of a single-method run on a world of the block's size (tests/test_shard_gloo.py).  With
+    fewer ranks than methods the methods run one after the other, each over all ranks.  Returns {"method": name(s) this rank
+    ran, "blocks": {name: ranks}, "out": main()'s dict of this rank's (last) method, "outs": {name: dict}}."""
+    from . import shard
+    import sys as _sys
+    argv = list(_sys.argv[1:] if argv is None else argv)
+    clean, skip = [], False
+    for a in argv:                                  # drop --methods X / --method_name X: each inner run gets its own
+        if skip:
+            skip = False
+        elif a in ("--methods", "--method_name"):
+            skip = True
+        elif not (a.startswith("--methods=") or a.startswith("--method_name=")):
+            clean.append(a)
+    shard.init_from_env()
+    grank, gworld = shard.global_rank_world()
+    outs = {}
+    if gworld >= len(names) and gworld > 1:
+        gi, blocks = shard.enter_method_groups(len(names))
+        try:
+            outs[names[gi]] = main(clean + ["--method_name", names[gi]], dataset=dataset)
+        finally:
+            shard.leave_method_groups()
+        shard.world_barrier()
+        blocks = {n: b for n, b in zip(names, blocks)}
+        mine = names[gi]
+    else:
+        for n in names:
+            outs[n] = main(clean + ["--method_name", n], dataset=dataset)
+        blocks = {n: list(range(gworld)) for n in names}
+        mine = list(names)
+    return {"method": mine, "blocks": blocks, "out": outs[mine if isinstance(mine, str) else names[-1]], "outs": outs}
+
+
 def main(argv=None, method=None, dataset=None, train_node_factory=None):
     args = build_parser().parse_args(argv)
+    if args.methods:
+        names = [n for n in args.methods.split(",") if n]
+        if not args.shard:
+            raise SystemExit("--methods needs --shard")
+        if method is not None or train_node_factory is not None:
+            raise ValueError("--methods creates its own method objects")
+        return main_methods(argv, names, dataset=dataset)
     speculative = sequential_on_rank0 = False
     if args.shard:
         from . import shard
         rank, world = shard.init_from_env()
         if world > 1:
-            args.results_root = os.path.join(args.results_root, "rank%d" % rank)
+            # (the tree is named after the GLOBAL rank: under --methods two blocks both have a block rank 0)
+            args.results_root = os.path.join(args.results_root, "rank%d" % shard.global_rank_world()[0])
             train_node_factory = train_node_factory or shard.sharded_grid_factory()
             speculative = not args.no_speculation
             sequential_on_rank0 = args.no_speculation

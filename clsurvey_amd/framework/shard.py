@@ -34,15 +34,25 @@ import torch.distributed as dist
 STATS = {"broadcast_calls": 0, "broadcast_bytes": 0, "broadcast_s": 0.0, "all_gather_calls": 0, "all_gather_bytes": 0,
          "all_gather_s": 0.0, "all_reduce_calls": 0, "all_reduce_s": 0.0,
          # seconds THIS rank spent training / evaluating inside each sharded stage (what filled its GPU), and the units it ran
-         "grid_busy_s": 0.0, "grid_nodes": 0, "decay_busy_s": 0.0, "decay_attempts": 0, "eval_busy_s": 0.0, "eval_pairs": 0}
+         "grid_busy_s": 0.0, "grid_nodes": 0, "decay_busy_s": 0.0, "decay_attempts": 0, "eval_busy_s": 0.0, "eval_pairs": 0,
+         # phase-2 trainings of ALL the ranks this process shards with (the same numbers on each of them): what ran, and what
+         # the sequential rule would have run (attempts up to and including the accepted one) — the rest was speculation
+         "decay_trainings_group": 0, "decay_trainings_useful": 0}
+
+
+def _is_cuda(device):
+    return device is not None and str(device).startswith("cuda") and torch.cuda.is_available()
 
 
 class busy:
-    """with shard.busy("grid"): ...   adds the block's wall-clock to STATS["grid_busy_s"] and `units` to its unit counter."""
+    """with shard.busy("grid", device=args.device): ...   adds the block's wall-clock to STATS["grid_busy_s"] and `units` to
+    its unit counter.  The device queue is drained before the clock is read only when the RUN's device is a GPU: a CPU run
+    (the oracle legs of bench.py's pair, --device cpu) must not create or synchronise a device context beside a GPU run that
+    is being timed."""
     _unit = {"grid": "grid_nodes", "decay": "decay_attempts", "eval": "eval_pairs"}
 
-    def __init__(self, stage, units=1):
-        self.stage, self.units = stage, units
+    def __init__(self, stage, units=1, device=None):
+        self.stage, self.units, self.sync = stage, units, _is_cuda(device)
 
     def __enter__(self):
         import time
@@ -50,7 +60,7 @@ class busy:
 
     def __exit__(self, *exc):
         import time
-        if torch.cuda.is_available():
+        if self.sync:
             torch.cuda.synchronize()
         STATS[self.stage + "_busy_s"] += time.perf_counter() - self.t0
         STATS[self._unit[self.stage]] += self.units
@@ -73,10 +83,66 @@ class _timed:
         STATS[self.key] += time.perf_counter() - self.t0
 
 
-def rank_world():
+# The ranks this process shards WITH.  None: the whole world.  `--methods A,B` (driver.main) splits the world into one group of
+# disjoint ranks per method (BASELINE configs 3 and 5 are two methods on one 8-GPU node); inside a group every
+# function of this module behaves as if the group were the world: ranks are group-relative, collectives run on the group's
+# communicator (dist.new_group), `src` arguments are group ranks.
+_G = {"group": None, "ranks": None}
+
+
+def set_group(group, ranks):
+    _G["group"], _G["ranks"] = group, (list(ranks) if ranks is not None else None)
+
+
+def global_rank_world():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
+
+
+def rank_world():
+    """(rank, world) of the ranks this process shards with: the method's group under --methods, else the world."""
+    if dist.is_available() and dist.is_initialized():
+        if _G["ranks"] is not None:
+            return _G["ranks"].index(dist.get_rank()), len(_G["ranks"])
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def _src(r):
+    """group rank -> the global rank torch.distributed's `src` wants."""
+    return _G["ranks"][r] if _G["ranks"] is not None else r
+
+
+def split_ranks(n_groups, world):
+    """Contiguous, near-equal blocks of the world's ranks, one per group (the first world % n_groups groups get one more):
+    8 ranks, 2 methods -> [0..3], [4..7] (neighbouring GPUs share xGMI links either way: every pair is one hop)."""
+    if n_groups > world:
+        raise ValueError("%d methods need at least %d ranks, the world has %d" % (n_groups, n_groups, world))
+    out, lo = [], 0
+    for g in range(n_groups):
+        n = world // n_groups + (1 if g < world % n_groups else 0)
+        out.append(list(range(lo, lo + n)))
+        lo += n
+    return out
+
+
+def enter_method_groups(n_groups):
+    """Every rank of the world calls this with the same n_groups: creates ALL the groups' communicators (dist.new_group is
+    collective over the world, same order everywhere) and enters this rank's.  Returns (group index, ranks of every group)."""
+    rank, world = global_rank_world()
+    blocks = split_ranks(n_groups, world)
+    mine = None
+    for g, ranks in enumerate(blocks):
+        pg = dist.new_group(ranks=ranks)
+        if rank in ranks:
+            mine = (g, pg, ranks)
+    set_group(mine[1], mine[2])
+    return mine[0], blocks
+
+
+def leave_method_groups():
+    set_group(None, None)
 
 
 def init_from_env(backend=None):
@@ -119,7 +185,7 @@ def gather_scalars(values):
     n = torch.tensor([len(values)], dtype=torch.int64, device=_dev())
     counts = [torch.zeros_like(n) for _ in range(world)]
     with _timed("all_gather_s"):
-        dist.all_gather(counts, n)
+        dist.all_gather(counts, n, group=_G["group"])
     STATS["all_gather_calls"] += 2
     m = max(int(c.item()) for c in counts)
     buf = torch.full((max(m, 1), 2), -1.0, dtype=torch.float64, device=_dev())
@@ -127,7 +193,7 @@ def gather_scalars(values):
         buf[j, 0], buf[j, 1] = float(k), float(v)
     bufs = [torch.zeros_like(buf) for _ in range(world)]
     with _timed("all_gather_s"):
-        dist.all_gather(bufs, buf)
+        dist.all_gather(bufs, buf, group=_G["group"])
     STATS["all_gather_bytes"] += world * (8 + buf.numel() * 8)
     out = {}
     for b in bufs:
@@ -145,7 +211,7 @@ def broadcast_model(model, src=0):
     params = [p.data for p in model.parameters()]
     flat = torch.cat([p.reshape(-1).to(_dev(), torch.float32) for p in params])
     with _timed("broadcast_s"):
-        dist.broadcast(flat, src=src)
+        dist.broadcast(flat, src=_src(src), group=_G["group"])
     STATS["broadcast_calls"] += 1
     STATS["broadcast_bytes"] += flat.numel() * 4
     off = 0
@@ -163,7 +229,7 @@ def broadcast_bytes(payload, src):
         return payload
     n = torch.tensor([len(payload) if rank == src else 0], dtype=torch.int64, device=_dev())
     with _timed("broadcast_s"):
-        dist.broadcast(n, src=src)
+        dist.broadcast(n, src=_src(src), group=_G["group"])
     size = int(n.item())
     if rank == src:
         buf = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(_dev()) if size else torch.zeros(0, dtype=torch.uint8, device=_dev())
@@ -171,7 +237,7 @@ def broadcast_bytes(payload, src):
         buf = torch.zeros(size, dtype=torch.uint8, device=_dev())
     if size:
         with _timed("broadcast_s"):
-            dist.broadcast(buf, src=src)
+            dist.broadcast(buf, src=_src(src), group=_G["group"])
     STATS["broadcast_calls"] += 2 if size else 1
     STATS["broadcast_bytes"] += 8 + size
     return bytes(buf.cpu().numpy().tobytes())
@@ -213,6 +279,11 @@ def broadcast_object(obj, src=0):
 
 def barrier():
     if rank_world()[1] > 1:
+        dist.barrier(group=_G["group"])
+
+
+def world_barrier():
+    if global_rank_world()[1] > 1:
         dist.barrier()
 
 
@@ -224,7 +295,7 @@ def all_ok(ok, what=""):
     if world > 1:
         flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=_dev())
         with _timed("all_reduce_s"):
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=_G["group"])
         STATS["all_reduce_calls"] += 1
         everyone = bool(int(flag.item()))
     else:
@@ -260,7 +331,7 @@ def sharded_grid_factory():
                     driver.set_random(it)
                     manager.gridsearch_exp_dir = node_dir(lr, it)
                     os.makedirs(manager.gridsearch_exp_dir, exist_ok=True)
-                    with busy("grid"):
+                    with busy("grid", device=getattr(args, "device", None)):
                         _, acc = manager.method.grid_train(args, manager, lr)
                     mine[i] = acc
             except Exception as e:                        # reported collectively below
@@ -319,7 +390,7 @@ def speculative_round(hf, args, manager, finetune_acc):
         os.makedirs(manager.heuristic_exp_dir, exist_ok=True)
         manager.method.hyperparams = twin.hyperparams
         try:
-            with busy("decay"):
+            with busy("decay", device=getattr(args, "device", None)):
                 _, acc = manager.method.train(args, manager, twin.hyperparams)
             mine[k] = acc
         except Exception as e:
@@ -332,6 +403,8 @@ def speculative_round(hf, args, manager, finetune_acc):
     ok = sorted(kk for kk, a in accs.items() if a >= threshold)
     last = args.max_attempts_per_task - 1
     accepted = ok[0] if ok else (last if last in accs else None)      # the final attempt is kept whatever it scored
+    STATS["decay_trainings_group"] += len(accs)
+    STATS["decay_trainings_useful"] += sum(1 for kk in accs if accepted is None or kk <= accepted)
     if accepted is not None:
         src = accepted - hf.attempts
         if rank != src:

@@ -7,6 +7,7 @@ tasks of the same shape (10 tasks x 20 classes, 8000/2000/1000 images of 3x64x64
 data/tinyimgnet_dataprep.py:69-151) — class-conditional Gaussian prototypes + noise so accuracies
 and forgetting are non-trivial — as pickled {'train','val','test'} dicts, the same wire format the
 reference's framework passes between its layers."""
+import json
 import os
 from collections import OrderedDict
 
@@ -38,11 +39,30 @@ class SyntheticTaskSequence(object):
     def get_taskname(self, task_index):
         return str(task_index)
 
+    def spec(self, task_name):
+        """Everything the bytes of a task file depend on."""
+        return {"sizes": [int(v) for v in self.sizes], "classes": int(self.n_classes), "hw": int(self.hw),
+                "seed": int(self.seed) * 1000 + int(task_name), "noise": float(self.noise), "kind": str(self.kind),
+                "blobs": None if self.blobs is None else {k: float(v) for k, v in sorted(dict(self.blobs).items())}}
+
     def get_task_dataset_path(self, task_name=None, rnd_transform=False):
+        """Task files are cached under root/name/; a sidecar task_N.spec.json records what they were generated from.  A cached
+        file of ANOTHER spec (other kind / blobs / noise / sizes / seed under the same results root) is an error, not a hit:
+        the results tree beside it holds success tokens and models of that other data."""
         path = os.path.join(self.root, self.name, "task_%s.pth.tar" % task_name)
-        if not os.path.exists(path):
-            os.makedirs(os.path.dirname(path), exist_ok=True)
-            d = synthetic_task(self.sizes[0], self.sizes[1], self.sizes[2], self.n_classes, self.hw,
-                               seed=self.seed * 1000 + int(task_name), noise=self.noise, kind=self.kind, blobs=self.blobs)
-            torch.save(d, path)
+        side = os.path.join(self.root, self.name, "task_%s.spec.json" % task_name)
+        want = self.spec(task_name)
+        if os.path.exists(path) and os.path.exists(side):
+            with open(side) as f:
+                have = json.load(f)
+            if have != want:
+                raise RuntimeError("%s was generated from %s, this run asks for %s: use a fresh --results_root (its results tree "
+                                   "belongs to the other data)" % (path, have, want))
+            return path
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        d = synthetic_task(self.sizes[0], self.sizes[1], self.sizes[2], self.n_classes, self.hw,
+                           seed=want["seed"], noise=self.noise, kind=self.kind, blobs=self.blobs)
+        torch.save(d, path)
+        with open(side, "w") as f:                 # written last: a file without a sidecar is regenerated
+            json.dump(want, f)
         return path

@@ -179,6 +179,10 @@ def _worker(rank, world, port, tmp):
     if rank == 1:
         os.makedirs(hd6)
         torch.save({"stale": True}, os.path.join(hd6, "best_model.pth.tar"))
+        # ... and a stale checkpoint of a run killed half-way (other hyper-parameters, 5 attempts in): must not be resumed from
+        stale = driver.HyperparameterFramework(_DecayMethod())
+        stale.attempts, stale.hyperparams["a"], stale.hyperparams["b"] = 5, 0.125, 0.25
+        mg6.save_hyperparams(hd6, {"acc_threshold": 0.2, "val_acc": 0.1, "state": stale._get_state()})
         mg6.create_success_token(hd6)
     hf6 = driver.HyperparameterFramework(meth6)
     hf6.stabilityDecay(_args(), mg6, 1e-3, finetune_acc=0.25)
@@ -237,3 +241,73 @@ def _worker(rank, world, port, tmp):
 def test_grid_shard_world2(tmp_path):
     port = 29500 + os.getpid() % 2000
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+
+
+# ------------------------------------------------------------------------------------------------ method groups (--methods)
+class _GridMethodB(_GridMethod):
+    """A second method with another accuracy table: its block must reach ITS OWN decision."""
+    name = eval_name = "other"
+    TABLE = {1e-2: 0.2, 5e-3: 0.3, 1e-3: 0.4, 5e-4: 0.95, 1e-4: 0.6}
+
+    def grid_train(self, args, manager, lr):
+        self.trained.append(lr)
+        torch.save({"lr": lr, "rank": self.rank, "method": "other"}, os.path.join(manager.gridsearch_exp_dir, "best_model.pth.tar"))
+        return None, self.TABLE[lr]
+
+
+def _worker_groups(rank, world, port, tmp):
+    """World 4 split into two method blocks of two ranks (two methods side by side on one node)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from clsurvey_amd.framework import driver, shard
+    assert shard.init_from_env("gloo") == (rank, world)
+    assert shard.split_ranks(2, 8) == [[0, 1, 2, 3], [4, 5, 6, 7]] and shard.split_ranks(3, 8) == [[0, 1, 2], [3, 4, 5], [6, 7]]
+    gi, blocks = shard.enter_method_groups(2)
+    assert blocks == [[0, 1], [2, 3]] and gi == rank // 2
+    brank = rank % 2
+    assert shard.rank_world() == (brank, 2) and shard.global_rank_world() == (rank, 4)
+    # collectives stay inside the block; `src` is a block rank
+    got = shard.gather_scalars({brank: 10.0 * gi + brank})
+    assert got == {0: 10.0 * gi, 1: 10.0 * gi + 1}, got
+    assert shard.broadcast_object({"from": rank}, src=1) == {"from": blocks[gi][1]}
+    shard.all_ok(True)
+    # each block's sharded grid takes ITS method's decision, with the block's two ranks splitting the nodes
+    meth = (_GridMethod if gi == 0 else _GridMethodB)(rank)
+    mgr = driver.Manager(_DS(), meth, "prev", os.path.join(tmp, "rank%d" % rank, "grid"), None)
+    args = _args()
+    best_lr, best_acc = driver.lr_grid_single_task(args, mgr, "all", train_node=shard.sharded_grid_factory()(args, mgr))
+    # (the reference's rule, lr_grid_train.py: LRs in grid order, a later LR replaces the best only when strictly better)
+    assert (best_lr, best_acc) == ((5e-3, 0.9) if gi == 0 else (5e-4, 0.95))
+    assert meth.trained == ([1e-2, 1e-3, 1e-4] if brank == 0 else [5e-3, 5e-4]), meth.trained
+    won = torch.load(os.path.join(mgr.best_exp_grid_node_dirname, "best_model.pth.tar"), weights_only=False)
+    assert won["rank"] == blocks[gi][1] and won["lr"] == best_lr, won          # trained on the block's rank 1, present on both
+
+    # speculative phase 2 per block (different start values per block) == that block's sequential loop
+    def phase2(speculative, sub):
+        m2 = _DecayMethod()
+        if gi == 1:
+            m2.hyperparams = OrderedDict([("a", 16.0), ("b", 2.0)])
+        mg = driver.Manager(_DS(), m2, "prev", os.path.join(tmp, "rank%d" % rank, sub), None)
+        mg.speculative = speculative
+        hf = driver.HyperparameterFramework(m2)
+        hf.stabilityDecay(_args(), mg, 1e-3, finetune_acc=0.25)
+        return hf, m2, torch.load(os.path.join(mg.heuristic_exp_dir, "best_model.pth.tar"), weights_only=False)
+
+    before = dict(shard.STATS)
+    seq_hf, seq_m, seq_model = phase2(False, "seq")
+    spec_hf, spec_m, spec_model = phase2(True, "spec")
+    assert spec_hf.trace == seq_hf.trace and dict(spec_hf.hyperparams) == dict(seq_hf.hyperparams) and spec_model == seq_model
+    assert spec_hf.attempts == seq_hf.attempts
+    ran = shard.STATS["decay_trainings_group"] - before["decay_trainings_group"]
+    useful = shard.STATS["decay_trainings_useful"] - before["decay_trainings_useful"]
+    assert useful == len(seq_hf.trace) and useful <= ran <= useful + 1, (ran, useful)     # two in flight: at most one speculative extra
+    shard.barrier()
+    shard.leave_method_groups()
+    assert shard.rank_world() == (rank, world)
+    shard.world_barrier()
+    dist.destroy_process_group()
+
+
+def test_method_groups_world4(tmp_path):
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_worker_groups, args=(4, port, str(tmp_path)), nprocs=4, join=True)

@@ -50,3 +50,44 @@ def test_driver_shard_two_ranks(tmp_path):
     ndev = torch.cuda.device_count()
     port = 29500 + (os.getpid() * 7) % 2000
     mp.spawn(_worker, args=(2, port, str(tmp_path), ndev), nprocs=2, join=True)
+
+
+def _worker_methods(rank, world, port, tmp, ndev):
+    """`--shard --methods EWC,MAS` on 4 ranks: two blocks of two ranks, one method each."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank % ndev), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank % ndev)
+    from clsurvey_amd.framework import driver, shard
+    from clsurvey_amd.methods import method as M
+    assert shard.init_from_env("nccl" if ndev >= world else "gloo") == (rank, world)
+    common = ["small_VGG9_cl_128_128", "--lr_grid", "1e-2,3e-3,1e-3", "--num_epochs", "5", "--batch_size", "40",
+              "--saving_freq", "100", "--results_root", tmp, "--synthetic", "2,4,160,40,40,32", "--shard",
+              "--device", "cuda:%d" % (rank % ndev)]
+    driver.main(common + ["--method_name", "SI", "--runmode", "first_task_basemodel_dump"], method=M.parse("SI"))   # the whole world
+    res = driver.main(common + ["--methods", "EWC,MAS", "--test", "--drop_margin", "0.05"])
+    assert res["blocks"] == {"EWC": [0, 1], "MAS": [2, 3]} and res["method"] == ("EWC" if rank < 2 else "MAS")
+    assert shard.rank_world() == (rank, world)                       # back in the world
+    out = res["out"]
+    mgr = out["manager"]
+    assert mgr.method.name == res["method"] and "/%s/" % res["method"] in mgr.parent_exp_dir
+    assert mgr.previous_task_model_path.startswith(os.path.join(tmp, "rank%d" % rank))        # trees are per GLOBAL rank
+    model = torch.load(out["model_paths"][-1], weights_only=False)
+    digest = [float(p.detach().double().sum().cpu()) for p in model.parameters()]
+    omega = [float(model.reg_params[p]["omega"].double().sum().cpu()) for p in model.parameters() if p in model.reg_params]
+    mine = dict(method=res["method"], results=out["results"], grid=mgr.grid_trace, trace=out["frameworks"][-1].trace, digest=digest, omega=omega)
+    table = [None] * world
+    torch.distributed.all_gather_object(table, mine)
+    for a, b in ((0, 1), (2, 3)):                                    # the two ranks of a block end in the same state
+        for k in ("method", "results", "grid", "trace", "digest", "omega"):
+            assert table[a][k] == table[b][k], (a, b, k)
+    assert table[0]["omega"] != table[2]["omega"]                    # Fisher vs MAS importance: the blocks really ran different methods
+    assert table[0]["grid"] == table[2]["grid"]                      # ... whose phase 1 (plain finetuning from the same model) coincides
+    shard.world_barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_driver_methods_side_by_side(tmp_path):
+    ndev = torch.cuda.device_count()
+    port = 27500 + (os.getpid() * 11) % 2000
+    mp.spawn(_worker_methods, args=(4, port, str(tmp_path), ndev), nprocs=4, join=True)
