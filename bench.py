@@ -44,8 +44,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+WINO_ISSUE = 16.0 / 36.0        # F(2x2, 3x3): 16 multiplies per 2x2 output tile and channel pair where the direct form has 36
 PEAK_HBM_TBPS = 8.0            # MI355X_MICROARCH.md: HBM3E
 SMALL = [64, "M", 64, "M", 64, 64, "M", 128, 128, "M"]
+# what the path computes in: fp32 data end to end; the forward / backward-data convolutions of the >= 32-channel layers multiply
+# fp32 operands as three bf16 pieces each on the bf16 matrix cores (six products, fp32 accumulation — error of an fp32 chain,
+# tests/test_gpu_bs.py::test_bs_error_is_that_of_an_fp32_chain); every other kernel is f32 MFMA / f32 VALU, reductions in f64
+DTYPE = "f32 (bf16x6 split operands on the conv fwd/bwd-data matrix products, fp32 accumulate)"
 
 
 def conv_layers(cfg, hw):
@@ -143,6 +148,35 @@ def wino_conv_instance(W, mode, unpool, N=None, kout=None):
     return "wino_conv16g_kernel<%s, %d, %s> (+ wino_weight_kernel)" % ("8, 2, 4" if W >= 16 else "4, 4, 4", mode, "true" if unpool else "false")
 
 
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
+BS_ISSUE = 6.0                     # bf16-split direct convolution: six bf16 MFMA products per fp32 multiply (csrc/bsconv.hip)
+
+
+def bs_conv_instance(N, H, W, kout, mode, unpool):
+    """Instance name of the bf16-split forward (mode 0) / backward-data (mode 1) launch (csrc/bsconv.hip, bs_launch)."""
+    kts = (kout + 63) // 64
+
+    def big(rw, rh, ni):
+        return ((W + rw - 1) // rw) * ((H + rh - 1) // rh) * ((N + ni - 1) // ni) * kts >= 1024
+    if W > 16:
+        geo = "32, 8, 1, 4, 2, 2" if big(32, 8, 1) else "32, 4, 1, 2, 2, 1"
+    elif W > 8:
+        geo = "16, 16, 1, 4, 2, 2" if big(16, 16, 1) else "16, 8, 1, 2, 2, 1"
+    else:
+        geo = "8, 8, 4, 4, 2, 2" if big(8, 8, 4) else "8, 8, 2, 2, 2, 1"
+    return "bs_conv_kernel<BsGeo<%s>, %d, %s> (+ bs_weight_multi_kernel)" % (geo, mode, "true" if unpool else "false")
+
+
+def pipe_seconds(flops, path):
+    """Seconds the matrix pipe needs for a launch at its peak: direct f32 MFMA: flops / 157.3 T; Winograd F(2x2,3x3) on f32 MFMA:
+    16/36 of the multiplies; bf16-split: 6 bf16 products per multiply on the 2.5 PFLOP/s dense bf16 pipe."""
+    if path == "bs":
+        return flops * BS_ISSUE / (PEAK_BF16_MFMA_TFLOPS * 1e12)
+    if path == "wino":
+        return flops * WINO_ISSUE / (PEAK_F32_MFMA_TFLOPS * 1e12)
+    return flops / (PEAK_F32_MFMA_TFLOPS * 1e12)
+
+
 def wino_wgrad_instance(N, C, K, H, W, unpool):
     """Instance name of the Winograd weight-gradient launch (csrc/wino.hip, clhip_internal_wino_wgrad_partial): layers with fewer
     than 16 sixteen-tile stages per 64 x 64-tile block take the 32 x 32-tile pixel-split kernel."""
@@ -194,20 +228,26 @@ def time_kernels(eng, x, N, iters):
         # arg-max bytes carry the dead windows, csrc/common.hpp) — as the plan executor calls the kernels
         xmask = None if (li > 0 and eng.layers[li - 1][3]) else xin
         layer = "%dx%d@%d" % (C, K, H)
+        wt, bs = m.weight.data, m.bias.data
+        pf = "bs" if paths.get("bs_fwd") else ("wino" if paths["fwd"] else "direct")              # path of the forward launch
+        pd = "bs" if paths.get("bs_bwd_data") else ("wino" if paths["bwd_data"] else "direct")    # ... of backward-data
+        pw = "wino" if paths["bwd_weight"] else "direct"
+
+        def row(kernel, kind, sec, path, instance, alg_bytes):
+            rows.append(dict(kernel=kernel, layer=layer, li=li, kind=kind, flops=fl, sec=sec, path=path, winograd=path == "wino",
+                             pipe_sec=pipe_seconds(fl, path), instance=instance, alg_bytes=alg_bytes))
+        fwd_fn = {"bs": ops.conv3x3_bs_fwd, "wino": ops.conv3x3_wino_fwd}
         if pool:
-            yp, idx = ops.conv3x3_relu_pool_fwd(xin, m.weight.data, m.bias.data)
-            t_f = timed((lambda: ops.conv3x3_wino_fwd(xin, m.weight.data, m.bias.data, True, pool=True)) if paths["fwd"] else
-                        (lambda: ops.conv3x3_relu_pool_fwd(xin, m.weight.data, m.bias.data)))
-            rows.append(dict(kernel="conv3x3_relu_pool_fwd", layer=layer, li=li, kind="fwd", flops=fl, sec=t_f, winograd=paths["fwd"],
-                             instance=wino_conv_instance(W, 0, False, N, K) if paths["fwd"]
-                             else conv_instance(C, H, W, N, K, 0, True),
-                             alg_bytes=4.0 * N * H * W * (C + K / 4.0) + 1.0 * N * K * H * W / 4))
+            yp, idx = ops.conv3x3_relu_pool_fwd(xin, wt, bs)
+            t_f = timed((lambda: fwd_fn[pf](xin, wt, bs, True, pool=True)) if pf != "direct" else (lambda: ops.conv3x3_relu_pool_fwd(xin, wt, bs)))
+            row("conv3x3_relu_pool_fwd", "fwd", t_f, pf,
+                bs_conv_instance(N, H, W, K, 0, False) if pf == "bs" else wino_conv_instance(W, 0, False, N, K) if pf == "wino"
+                else conv_instance(C, H, W, N, K, 0, True), 4.0 * N * H * W * (C + K / 4.0) + 1.0 * N * K * H * W / 4)
         else:
-            t_f = timed((lambda: ops.conv3x3_wino_fwd(xin, m.weight.data, m.bias.data, True)) if paths["fwd"] else
-                        (lambda: ops.conv3x3_fwd(xin, m.weight.data, m.bias.data, True)))
-            rows.append(dict(kernel="conv3x3_fwd", layer=layer, li=li, kind="fwd", flops=fl, sec=t_f, winograd=paths["fwd"],
-                             instance=wino_conv_instance(W, 0, False, N, K) if paths["fwd"]
-                             else conv_instance(C, H, W, N, K, 0, False), alg_bytes=4.0 * N * H * W * (C + K)))
+            t_f = timed((lambda: fwd_fn[pf](xin, wt, bs, True)) if pf != "direct" else (lambda: ops.conv3x3_fwd(xin, wt, bs, True)))
+            row("conv3x3_fwd", "fwd", t_f, pf,
+                bs_conv_instance(N, H, W, K, 0, False) if pf == "bs" else wino_conv_instance(W, 0, False, N, K) if pf == "wino"
+                else conv_instance(C, H, W, N, K, 0, False), 4.0 * N * H * W * (C + K))
         if pool:
             dyp = torch.randn_like(yp)
         # the slab kernel alone, as the plan executor launches it (the slabs of all layers are reduced by ONE
@@ -215,36 +255,33 @@ def time_kernels(eng, x, N, iters):
         # both backward kernels take the POOLED gradient + arg-max bytes and rebuild the un-pooled tile while staging
         if C == 3 and pool:
             t_w = timed(lambda: ops.conv3x3_bwd_weight_slabs(xin, dyp, idx))
-            rows.append(dict(kernel="conv3x3_bwd_weight_unpool", layer=layer, li=li, kind="bwd_weight", flops=fl, sec=t_w, winograd=False,
-                             instance="conv3x3_wgrad_c3_unpool_kernel" if W % 32 == 0 else "conv3x3_wgrad_smallc_kernel",
-                             alg_bytes=4.0 * N * H * W * (C + K / 4.0)))
+            row("conv3x3_bwd_weight_unpool", "bwd_weight", t_w, "direct",
+                "conv3x3_wgrad_c3_unpool_kernel" if W % 32 == 0 else "conv3x3_wgrad_smallc_kernel", 4.0 * N * H * W * (C + K / 4.0))
         elif pool:
             # (the Winograd entry point times slabs + its own reduction launch; inside a pass the reduction is deferred)
-            t_w = timed((lambda: ops.conv3x3_wino_bwd_weight(xin, dyp, idx)) if paths["bwd_weight"] else
+            t_w = timed((lambda: ops.conv3x3_wino_bwd_weight(xin, dyp, idx)) if pw == "wino" else
                         (lambda: ops.conv3x3_bwd_weight_slabs(xin, dyp, idx)))
-            rows.append(dict(kernel="conv3x3_bwd_weight_unpool", layer=layer, li=li, kind="bwd_weight", flops=fl, sec=t_w, winograd=paths["bwd_weight"],
-                             instance=wino_wgrad_instance(N, C, K, H, W, True) if paths["bwd_weight"]
-                             else "conv3x3_wgrad_kernel<..., UNPOOL=true> (slabs; reduction deferred)",
-                             alg_bytes=4.0 * N * H * W * (C + K / 4.0) + 1.0 * N * K * H * W / 4))
+            row("conv3x3_bwd_weight_unpool", "bwd_weight", t_w, pw,
+                wino_wgrad_instance(N, C, K, H, W, True) if pw == "wino" else "conv3x3_wgrad_kernel<..., UNPOOL=true> (slabs; reduction deferred)",
+                4.0 * N * H * W * (C + K / 4.0) + 1.0 * N * K * H * W / 4)
         else:
-            t_w = timed((lambda: ops.conv3x3_wino_bwd_weight(xin, dy)) if paths["bwd_weight"] else
+            t_w = timed((lambda: ops.conv3x3_wino_bwd_weight(xin, dy)) if pw == "wino" else
                         (lambda: ops.conv3x3_bwd_weight_slabs(xin, dy)))
-            rows.append(dict(kernel="conv3x3_bwd_weight", layer=layer, li=li, kind="bwd_weight", flops=fl, sec=t_w, winograd=paths["bwd_weight"],
-                             instance=wino_wgrad_instance(N, C, K, H, W, False) if paths["bwd_weight"]
-                             else "conv3x3_wgrad_kernel (slabs; reduction deferred)", alg_bytes=4.0 * N * H * W * (C + K)))
+            row("conv3x3_bwd_weight", "bwd_weight", t_w, pw,
+                wino_wgrad_instance(N, C, K, H, W, False) if pw == "wino" else "conv3x3_wgrad_kernel (slabs; reduction deferred)",
+                4.0 * N * H * W * (C + K))
+        bwd_fn = {"bs": ops.conv3x3_bs_bwd_data, "wino": ops.conv3x3_wino_bwd_data}
         if C > 3 and pool:
-            t_d = timed((lambda: ops.conv3x3_wino_bwd_data(dyp, m.weight.data, xmask, idx)) if paths["bwd_data"] else
-                        (lambda: ops.conv3x3_bwd_data_unpool(dyp, idx, m.weight.data, xmask)))
-            rows.append(dict(kernel="conv3x3_bwd_data_unpool", layer=layer, li=li, kind="bwd_data", flops=fl, sec=t_d, winograd=paths["bwd_data"],
-                             instance=wino_conv_instance(W, 1, True, N, C) if paths["bwd_data"]
-                             else conv_instance(K, H, W, N, C, 1, False, True),
-                             alg_bytes=4.0 * N * H * W * ((2 if xmask is not None else 1) * C + K / 4.0) + 1.0 * N * K * H * W / 4))
+            t_d = timed((lambda: bwd_fn[pd](dyp, wt, xmask, idx)) if pd != "direct" else (lambda: ops.conv3x3_bwd_data_unpool(dyp, idx, wt, xmask)))
+            row("conv3x3_bwd_data_unpool", "bwd_data", t_d, pd,
+                bs_conv_instance(N, H, W, C, 1, True) if pd == "bs" else wino_conv_instance(W, 1, True, N, C) if pd == "wino"
+                else conv_instance(K, H, W, N, C, 1, False, True),
+                4.0 * N * H * W * ((2 if xmask is not None else 1) * C + K / 4.0) + 1.0 * N * K * H * W / 4)
         elif C > 3:
-            t_d = timed((lambda: ops.conv3x3_wino_bwd_data(dy, m.weight.data, xmask)) if paths["bwd_data"] else
-                        (lambda: ops.conv3x3_bwd_data(dy, m.weight.data, xmask)))
-            rows.append(dict(kernel="conv3x3_bwd_data", layer=layer, li=li, kind="bwd_data", flops=fl, sec=t_d, winograd=paths["bwd_data"],
-                             instance=wino_conv_instance(W, 1, False, N, C) if paths["bwd_data"]
-                             else conv_instance(K, H, W, N, C, 1, False), alg_bytes=4.0 * N * H * W * ((2 if xmask is not None else 1) * C + K)))
+            t_d = timed((lambda: bwd_fn[pd](dy, wt, xmask)) if pd != "direct" else (lambda: ops.conv3x3_bwd_data(dy, wt, xmask)))
+            row("conv3x3_bwd_data", "bwd_data", t_d, pd,
+                bs_conv_instance(N, H, W, C, 1, False) if pd == "bs" else wino_conv_instance(W, 1, False, N, C) if pd == "wino"
+                else conv_instance(K, H, W, N, C, 1, False), 4.0 * N * H * W * ((2 if xmask is not None else 1) * C + K))
         cur = ops.maxpool2_fwd(y)[0] if pool else y
     return rows
 
@@ -326,16 +363,14 @@ def mfma_busy_pmc(width, instance=None):
     return {"file": name, "kernels": rows}
 
 
-WINO_ISSUE = 16.0 / 36.0        # F(2x2, 3x3): 16 multiplies per 2x2 output tile and channel pair where the direct form has 36
-
 
 def step_flops_per_image(eng, hw):
-    """(algorithmic, issued) 2*MAC of one training / importance step per image — forward + backward-data (not on the first layer) +
-    weight gradient of every layer of the engine's plan — where `issued` counts a launch the plan runs through the Winograd
-    kernels (clhip_net_layer_paths) at 16/36 of its algorithmic FLOPs: what the matrix pipe really executes.  issued / time /
-    peak is a fraction of the hardware peak (<= 1 by construction); algorithmic / time / peak is the SURVEY 8(d) figure and may
-    exceed 1 on a net whose layers run Winograd."""
-    alg = iss = 0.0
+    """(algorithmic 2*MAC, matrix-pipe seconds at peak) of one training / importance step per image — forward + backward-data (not on
+    the first layer) + weight gradient of every layer of the engine's plan, each launch priced on the path the plan runs it through
+    (clhip_net_layer_paths, pipe_seconds).  pipe seconds / measured time is a fraction of the hardware's matrix peak (<= 1 by
+    construction); algorithmic / time / f32 peak is the SURVEY 8(d) figure and may exceed 1 on a net whose layers run Winograd or
+    on the bf16 pipe."""
+    alg = pipe = 0.0
     h = hw
     first = True
     for li, (kind, m, relu, pool) in enumerate(eng.layers):
@@ -344,10 +379,10 @@ def step_flops_per_image(eng, hw):
             h = (h + 2 * pd - ks) // st + 1
             f = 2.0 * ks * ks * m.in_channels * m.out_channels * h * h
             paths = eng.layer_paths(li)
-            for kind_, on in (("fwd", True), ("bwd_data", not first), ("bwd_weight", True)):
+            for kind_, bs_key, on in (("fwd", "bs_fwd", True), ("bwd_data", "bs_bwd_data", not first), ("bwd_weight", None, True)):
                 if on:
                     alg += f
-                    iss += f * (WINO_ISSUE if paths[kind_] else 1.0)
+                    pipe += pipe_seconds(f, "bs" if (bs_key and paths.get(bs_key)) else ("wino" if paths[kind_] else "direct"))
             first = False
             if pool:
                 pk, ps = pool if isinstance(pool, tuple) else (2, 2)
@@ -355,8 +390,8 @@ def step_flops_per_image(eng, hw):
         else:
             f = 2.0 * m.in_features * m.out_features
             alg += 3 * f
-            iss += 3 * f
-    return alg, iss
+            pipe += pipe_seconds(3 * f, "direct")
+    return alg, pipe
 
 
 def hbm_kernels(dev, n=57_823_240, iters=10):
@@ -428,18 +463,18 @@ def conv_backward_roofline(dev, N, iters=5):
         rows = [r for r in time_kernels(eng, x, N, iters) if "bwd" in r["kernel"]]
         dom = max(rows, key=lambda r: r["sec"])
 
-        def issue(r):
-            return WINO_ISSUE if r.get("winograd") else 1.0
+        # `mfma_issued_frac` of a launch = the time its matrix instructions need at the pipe's peak (pipe_seconds: f32 MFMA,
+        # Winograd at 16/36, bf16-split at 6 products on the bf16 pipe) / its measured time: a fraction of the hardware peak
         fl, sec = sum(r["flops"] for r in rows), sum(r["sec"] for r in rows)
-        fl_iss = sum(r["flops"] * issue(r) for r in rows)
         out[name] = {"dominant_backward_launch": "%s, layer %s [%s]" % (dom["kernel"], dom["layer"], dom["instance"]),
-                     "dominant_winograd": bool(dom.get("winograd")),
+                     "dominant_path": dom["path"],
                      "dominant_us": dom["sec"] * 1e6, "dominant_algorithmic_tflops": dom["flops"] / dom["sec"] / 1e12,
-                     "dominant_mfma_issued_frac": dom["flops"] * issue(dom) / dom["sec"] / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                     "dominant_mfma_issued_frac": dom["pipe_sec"] / dom["sec"],
                      "all_backward_launches_us": sec * 1e6, "all_backward_algorithmic_tflops": fl / sec / 1e12,
                      "all_backward_algorithmic_over_f32_mfma_peak": fl / sec / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                     "all_backward_mfma_issued_frac": fl_iss / sec / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                     "worst_backward_launch_mfma_issued_frac": min(r["flops"] * issue(r) / r["sec"] / 1e12 / PEAK_F32_MFMA_TFLOPS for r in rows),
+                     "all_backward_mfma_issued_frac": sum(r["pipe_sec"] for r in rows) / sec,
+                     "worst_backward_launch_mfma_issued_frac": min(r["pipe_sec"] / r["sec"] for r in rows),
+                     "paths": {p_: sum(1 for r in rows if r["path"] == p_) for p_ in ("direct", "wino", "bs")},
                      "mfma_busy_pmc": mfma_busy_pmc(name)}
         del eng
     return out
@@ -456,13 +491,12 @@ def extra_configs(dev, N, steps):
     g = torch.Generator(device=dev)
     g.manual_seed(11)
 
-    def entry(ms, images, flops, what, issued=None):
-        """flops: algorithmic; issued: what the matrix pipe executes (Winograd layers at 16/36, step_flops_per_image)."""
+    def entry(ms, images, flops, what, pipe_s=None):
+        """flops: algorithmic; pipe_s: seconds the step's matrix instructions need at the pipes' peaks (step_flops_per_image)."""
         e = {"what": what, "ms_per_step": ms, "images_per_s": images / ms * 1e3, "algorithmic_tflops": flops / ms / 1e9,
              "algorithmic_over_f32_mfma_peak": flops / ms / 1e9 / PEAK_F32_MFMA_TFLOPS}
-        if issued is not None:
-            e["mfma_issued_tflops"] = issued / ms / 1e9
-            e["mfma_issued_frac"] = issued / ms / 1e9 / PEAK_F32_MFMA_TFLOPS
+        if pipe_s is not None:
+            e["mfma_issued_frac"] = pipe_s / (ms * 1e-3)
         return e
 
     # ---- config 3: MAS importance pass + SI step, base_VGG9_cl_512_512, 3x64x64, batch N
@@ -908,7 +942,7 @@ def compact_line(out, details_path=None, limit=LINE_LIMIT):
     if "roofline" in out:
         r = out["roofline"]
         c["roofline"] = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_gflop_per_launch",
-                                  "algorithmic_bytes_per_launch", "avg_launch_us", "avg_launch_how", "winograd", "peak_how",
+                                  "algorithmic_bytes_per_launch", "avg_launch_us", "avg_launch_how", "path", "peak_how",
                                   "mfma_issued_frac", "mfma_busy_pmc"))
         c["roofline"].setdefault("traffic", r.get("traffic"))
     if "cpu_baseline" in out:
@@ -1162,13 +1196,13 @@ def main():
         eng.probe(None)
 
     fwd_fl, step_fl = algorithmic_flops_per_image(SMALL, (128, 128), 20, 64)
-    step_iss = step_flops_per_image(eng, 64)[1]          # the same step as the matrix pipe sees it (Winograd layers at 16/36)
+    step_iss = step_flops_per_image(eng, 64)[1]          # matrix-pipe seconds of the same step per image, at the pipes' peaks
     imgs = 2 * N * args.steps * world
     out = {
         "metric": "images/sec (train+importance pass), EWC small_VGG9 Tiny-ImageNet task batch",
         "value": imgs / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
         "config": {"workload": "EWC small_VGG9_cl_128_128, Tiny-ImageNet shapes (3x64x64, 20 classes), "
                                "batch 200: train step + Fisher step (BASELINE configs[1])",
                    "images_per_step": 2 * N, "batch": N,
@@ -1178,7 +1212,7 @@ def main():
                    "algorithmic_gflop_per_step": 2 * N * step_fl / 1e9,
                    "step_algorithmic_tflops": 2 * N * step_fl * args.steps / dt / 1e12,
                    "step_algorithmic_over_f32_mfma_peak": 2 * N * step_fl * args.steps / dt / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                   "step_mfma_issued_frac": 2 * N * step_iss * args.steps / dt / 1e12 / PEAK_F32_MFMA_TFLOPS},
+                   "step_mfma_issued_frac": 2 * N * step_iss * args.steps / dt},
     }
     if grid is not None:
         out["grid"] = grid
@@ -1197,16 +1231,19 @@ def main():
         in_situ = probed_n > 0
         dom_sec = probed_us * 1e-6 if in_situ else dom["sec"]
         ach = dom["flops"] / dom_sec / 1e12
-        # `achieved` prices the ALGORITHMIC flops of the convolution.  A Winograd F(2x2,3x3) launch issues 16 of the
-        # direct form's 36 multiplies, so its algorithmic rate is bounded by 36/16 of the fp32-MFMA peak, not by the peak itself:
-        # `peak` is that ceiling, and `frac` = achieved / peak is then a fraction of what the matrix pipe can do (<= 1; it equals
-        # mfma_issued_frac).  The ratio to the plain matrix peak is reported without "frac" in its name.
-        peak = PEAK_F32_MFMA_TFLOPS / WINO_ISSUE if dom.get("winograd") else PEAK_F32_MFMA_TFLOPS
+        # `achieved` prices the ALGORITHMIC flops of the convolution.  `peak` is the ceiling of that figure on the path the
+        # launch takes: the f32-MFMA peak for a direct f32 kernel; x 36/16 for Winograd F(2x2,3x3) (16 of the direct form's 36
+        # multiplies are issued); the dense bf16-MFMA peak / 6 for the bf16-split kernel (six bf16 products per fp32 multiply).
+        # `frac` = achieved / peak is then a fraction of what the matrix pipe can do (<= 1; it equals mfma_issued_frac).
+        peak = dom["flops"] / dom["pipe_sec"] / 1e12
+        peak_how = {"direct": "fp32-MFMA peak %.1f TFLOP/s (MI355X_MICROARCH.md)" % PEAK_F32_MFMA_TFLOPS,
+                    "wino": "fp32-MFMA peak %.1f TFLOP/s x 36/16 (F(2x2,3x3): 16 of the direct form's 36 multiplies are issued)" % PEAK_F32_MFMA_TFLOPS,
+                    "bs": "dense bf16-MFMA peak %.0f TFLOP/s / 6 (fp32 operands split into 3 bf16 pieces: 6 bf16 products per multiply, "
+                          "fp32 accumulation; error = an fp32 chain's, profiles/r05_bf16_split_dot.txt)" % PEAK_BF16_MFMA_TFLOPS}[dom["path"]]
         out["roofline"] = {"bound": "mfma", "kernel": "%s [%s, layer %s, N=%d]" % (dom["instance"], dom["kernel"], dom["layer"], N),
                            "achieved": ach, "peak": peak,
                            "unit": "TFLOP/s", "frac": ach / peak,
-                           "peak_how": ("fp32-MFMA peak %.1f TFLOP/s x 36/16 (F(2x2,3x3): 16 of the direct form's 36 multiplies are issued)"
-                                        % PEAK_F32_MFMA_TFLOPS) if dom.get("winograd") else "fp32-MFMA peak (MI355X_MICROARCH.md)",
+                           "peak_how": peak_how, "path": dom["path"],
                            "algorithmic_over_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
                            "traffic": measured_traffic(dom["kernel"], dom["layer"], N, dom["instance"]),
                            "algorithmic_gflop_per_launch": dom["flops"] / 1e9,
@@ -1215,20 +1252,15 @@ def main():
                            "avg_launch_how": ("HIP events around this launch inside the timed steps (clhip_net_probe_kind), last %d passes" % probed_n)
                                              if in_situ else "HIP events around %d back-to-back launches after the timed steps" % args.kernel_iters,
                            "back_to_back_us": dom["sec"] * 1e6,
-                           # Winograd F(2x2,3x3) launches issue 16 instead of 36 multiplies per 2x2 output tile and channel pair:
-                           # `achieved` prices the ALGORITHMIC flops of the convolution, this the flops the matrix
-                           # pipe really executes
-                           "winograd": bool(dom.get("winograd")),
-                           "mfma_issued_tflops": ach * (WINO_ISSUE if dom.get("winograd") else 1.0),
-                           "mfma_issued_frac": ach * (WINO_ISSUE if dom.get("winograd") else 1.0) / PEAK_F32_MFMA_TFLOPS,
+                           "winograd": dom["path"] == "wino",
+                           "mfma_issued_frac": dom["pipe_sec"] / dom_sec,
                            "mfma_busy_pmc": mfma_busy_pmc("small_VGG9", dom["instance"]),
                            "per_kernel": {k: {"tflops": v["flops"] / v["sec"] / 1e12, "us_per_step_pass": v["sec"] * 1e6}
                                           for k, v in agg.items()},
-                           "per_layer": [{"kernel": r["kernel"], "layer": r["layer"], "instance": r["instance"], "winograd": bool(r.get("winograd")),
+                           "per_layer": [{"kernel": r["kernel"], "layer": r["layer"], "instance": r["instance"], "path": r["path"],
                                           "us": r["sec"] * 1e6, "algorithmic_tflops": r["flops"] / r["sec"] / 1e12,
                                           "algorithmic_over_f32_mfma_peak": r["flops"] / r["sec"] / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                                          "mfma_issued_frac": r["flops"] * (WINO_ISSUE if r.get("winograd") else 1.0) / r["sec"] / 1e12
-                                                              / PEAK_F32_MFMA_TFLOPS} for r in rows]}
+                                          "mfma_issued_frac": r["pipe_sec"] / r["sec"]} for r in rows]}
         if world == 1 and not args.no_configs:
             del eng
             torch.cuda.empty_cache()

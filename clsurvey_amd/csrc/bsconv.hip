@@ -1,0 +1,473 @@
+// bsconv.hip — 3x3 convolution (stride 1, padding 1) forward / backward-data on the bf16 matrix cores with fp32 operands split into
+// three bf16 pieces each: the convolutions of VGGSlim.forward (models/VGGSlim.py:27-40) and their autograd backward w.r.t. the
+// input, same operators and fusions as wino.hip's entry points (bias + ReLU + optional 2x2 max-pool with arg-max codes on the
+// forward; gradient of the POOLED output + codes as input, (mask_src > 0) on the output of backward-data).
+//
+// Why.  On gfx950 the f32-input MFMA runs at the f32 VECTOR rate and, measured (tools/micro/bf16_split_dot.hip,
+// profiles/r05_bf16_split_dot.txt), it shares the vector lanes: ONE v_fma per MFMA in the same wave costs x1.48, a VALU-only
+// sibling wave adds its full time — the "MFMA time + everything else" sum that kept the Winograd kernels at 0.45 of the pipe.
+// v_mfma_f32_32x32x16_bf16 is 16x that rate and hides 4 VALU instructions per MFMA for free.  An fp32 value is EXACTLY
+// a0 + a1 + a2 with three bf16 pieces (8 + 8 + 8 significand bits, round-to-nearest residuals); every bf16 x bf16 product is exact
+// in fp32; the six products ai * bj with i + j <= 2 carry a * b to 2^-26 relative, the accumulation is fp32 inside the matrix core.
+// Measured against fp64 on 576 .. 4608-term dot products: max / rms error 1.1 - 2.2e-7 / 2.3 - 3.3e-8 of sum|a b| — the same as
+// the f32-input MFMA chain (1.2 - 2.1e-7 / 2.7 - 2.9e-8) and as a host fmaf chain.  Six bf16 MFMAs per 16-deep k-step = 2.67x the
+// f32 matrix rate on the DIRECT form (no Winograd transforms: their VALU work was the problem, and their conditioning is gone too).
+//
+// Data flow of one block (256 threads = 4 waves; BM = 128 or 256 output pixels x 64 output channels):
+//   * per 16-channel chunk the (RH + 2) x (RW + 2) halo tile of the input is loaded NCHW -> registers (dword buffer loads, lanes
+//     along x), split into 3 bf16 pieces and written to LDS as [piece][k half][halo row][pitch P] x 16 bytes (8 channels of one
+//     pixel, the A operand of one lane).  P = 8 mod 16 slots: the 16 lanes of every ds_read_b128 lane group hit 16 different
+//     4-bank groups for every tap (MI355X_MICROARCH.md, LDS table).  Double-buffered, one barrier per chunk; the staging of
+//     chunk c + 1 is issued inside the MFMA stream of chunk c.
+//   * weights: a lane-ordered image [n tile][chunk][tap][piece][lane] x 16 bytes (bs_weight_multi_kernel, once per pass) is read
+//     straight from L2 / L1 with one coalesced 1 KB buffer_load_dwordx4 per operand, one tap ahead.
+//   * an MFMA tile is 32 pixels x 32 channels; the 32 pixels are 8 pooling windows x 4 positions (m = 4 w + q) so that the four
+//     accumulator registers r = 4 g + q of a lane are one 2x2 window: ReLU + max-pool + arg-max code are lane-local.
+//   * per (tap, k-step) a wave issues 6 MFMAs per tile pair, small products first: a0 b2, a2 b0, a1 b1, a0 b1, a1 b0, a0 b0.
+//
+// Algorithmic FLOPs 2 * 9 * Cin * Cout * H * W * N; issued on the matrix pipe: 6x that, against the 2.5 PFLOP/s dense bf16 peak.
+#include "common.hpp"
+#include <cstdlib>
+
+namespace {
+
+typedef __bf16 bs_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bs_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float bs_f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int BS_BN = 64;            // output channels per block
+constexpr int BS_CK = 16;            // input channels per k-step (K of v_mfma_f32_32x32x16_bf16)
+
+// two floats -> two bf16 (round to nearest even), `lo` in bits 0..15: v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned bs_pk(float lo, float hi) {
+    bs_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bs_bf16x2));
+}
+// a = a0 + a1 + a2 exactly (up to 2^-26 |a|): pieces of (a, b) packed pairwise
+__device__ __forceinline__ void bs_split2(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+    p0 = bs_pk(a, b);
+    float ra = a - __uint_as_float(p0 << 16), rb = b - __uint_as_float(p0 & 0xffff0000u);
+    p1 = bs_pk(ra, rb);
+    ra -= __uint_as_float(p1 << 16);
+    rb -= __uint_as_float(p1 & 0xffff0000u);
+    p2 = bs_pk(ra, rb);
+}
+__device__ __forceinline__ void bs_split8(const float* v, clhip_u32x4& q0, clhip_u32x4& q1, clhip_u32x4& q2) {
+    unsigned a[4], b[4], c[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bs_split2(v[2 * i], v[2 * i + 1], a[i], b[i], c[i]);
+    q0 = clhip_u32x4{a[0], a[1], a[2], a[3]};
+    q1 = clhip_u32x4{b[0], b[1], b[2], b[3]};
+    q2 = clhip_u32x4{c[0], c[1], c[2], c[3]};
+}
+
+// ---------------------------------------------------------------------------------------------------- weight image
+// img[nt][chunk][tap][piece][lane] (16 bytes each): lane l of the B operand of n tile nt holds output channel ko = 32 nt + (l & 31)
+// and input channels ci = 16 chunk + 8 (l >> 5) + e, e = 0..7, of tap (r, s) — MODE 0: w[ko][ci][r][s]; MODE 1 (backward-data: the
+// kernel's input channels are the layer's output channels): w[ci][ko][2 - r][2 - s].  Ko / Ci: channel counts as the KERNEL sees them.
+constexpr int BS_WT_JOBS = 24;
+struct BsWtJobs { int n; int pad; clhip_wino_wt j[BS_WT_JOBS]; int first[BS_WT_JOBS + 1]; };
+
+__global__ __launch_bounds__(256) void bs_weight_multi_kernel(BsWtJobs J) {
+    int jb = 0;
+    for (int i = 1; i < J.n; ++i) jb = ((int)blockIdx.x >= J.first[i]) ? i : jb;
+    const clhip_wino_wt& q = J.j[jb];
+    const int n_chunks = (q.Ci + BS_CK - 1) / BS_CK, n_nt = (q.Ko + 31) / 32;
+    const int t = ((int)blockIdx.x - J.first[jb]) * 256 + threadIdx.x;
+    const int lane = t & 63;
+    int rest = t >> 6;
+    const int tap = rest % 9;
+    rest /= 9;
+    const int chunk = rest % n_chunks, nt = rest / n_chunks;
+    if (nt >= n_nt) return;
+    const int ko = nt * 32 + (lane & 31), ci0 = chunk * BS_CK + 8 * (lane >> 5);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ci = ci0 + e;
+        float x = 0.f;
+        if (ko < q.Ko && ci < q.Ci)
+            x = q.mode == 0 ? q.w[((size_t)ko * q.Ci + ci) * 9 + tap] : q.w[((size_t)ci * q.Ko + ko) * 9 + (8 - tap)];
+        v[e] = x;
+    }
+    clhip_u32x4 p0, p1, p2;
+    bs_split8(v, p0, p1, p2);
+    clhip_u32x4* img = reinterpret_cast<clhip_u32x4*>(q.U) + ((size_t)(nt * n_chunks + chunk) * 27 + tap * 3) * 64 + lane;
+    img[0] = p0;
+    img[64] = p1;
+    img[128] = p2;
+}
+
+// ---------------------------------------------------------------------------------------------------- the convolution
+// Geometry of a block: NI images x RH rows x RW columns of output pixels (= BM), all 64 output channels of one 64-channel group.
+//   RW = 32: one image, RH = 8 (BM 256) or 4 (BM 128);  RW = 16: RH = 16 / 8;  RW = 8: whole 8-row images, NI = 4 / 2, two images
+//   side by side per LDS row.  M tiles: 2 rows x 16 columns (RW >= 16) or 4 rows x 8 columns.
+template <int RW_, int RH_, int NI_, int WAVES_M_, int WM_, int WN_>
+struct BsGeo {
+    static constexpr int RW = RW_, RH = RH_, NI = NI_, WAVES_M = WAVES_M_, WAVES_N = 4 / WAVES_M_, WM = WM_, WN = WN_;
+    static constexpr int BM = RW * RH * NI;
+    static_assert(BM == 32 * WAVES_M * WM, "pixels per block = M tiles of the waves");
+    static_assert(32 * WAVES_N * WN == BS_BN, "64 output channels per block");
+    static constexpr int MTW = RW >= 16 ? 16 : 8, MTH = 32 / MTW;          // M tile: MTH rows x MTW columns
+    static_assert(RW % MTW == 0 && RH % MTH == 0, "whole M tiles");
+    static constexpr int MT_PER_ROW = RW / MTW, MT_PER_IMG = MT_PER_ROW * (RH / MTH);
+    static constexpr int IPR = RW == 8 ? 2 : 1;                            // images per LDS row
+    static_assert(NI % IPR == 0, "image pairs");
+    static constexpr int HW_ = RW + 2, HR = RH + 2;                        // halo tile of one image
+    static constexpr int P = (IPR * HW_ + 7) / 16 * 16 + 8;                // slots per LDS row, = 8 mod 16
+    static_assert(P >= IPR * HW_ && P % 16 == 8, "pitch");
+    static constexpr int ROWS = (NI / IPR) * HR;
+    static constexpr int PLANE_SLOTS = (ROWS - 1) * P + IPR * HW_;         // (the last row needs no padding)
+    static constexpr int PLANE_BYTES = PLANE_SLOTS * 16;
+    static constexpr int BUF_BYTES = 6 * PLANE_BYTES;                      // 3 pieces x 2 k halves
+    static constexpr int NHALO = NI * HR * HW_;
+    static constexpr int ITEMS = 2 * NHALO;                                // (halo pixel, k half): 8 channels each
+    static constexpr int ROUNDS = (ITEMS + 255) / 256;
+    static_assert(ROUNDS * 256 - ITEMS <= ITEMS, "the last round wraps at most once");
+};
+
+template <class G, int MODE, bool UNPOOL>
+__global__ __launch_bounds__(256, (2 * G::BUF_BYTES <= 80 * 1024) ? 2 : 1) void bs_conv_kernel(
+    const float* __restrict__ in, const clhip_u32x4* __restrict__ wimg, const float* __restrict__ bias,
+    const float* __restrict__ mask_src, float* __restrict__ out, uint8_t* __restrict__ pool_idx, int N, int Cin, int Cout, int H,
+    int W, int relu, int tiles_x, int tiles_y, int npb) {
+    constexpr int RW = G::RW, RH = G::RH, NI = G::NI, WM = G::WM, WN = G::WN, P = G::P, HR = G::HR, HW_ = G::HW_;
+    constexpr int ROUNDS = G::ROUNDS;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * G::BUF_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kts = (Cout + BS_BN - 1) / BS_BN;
+    // blocks of one pixel tile (all channel groups) follow each other on ONE XCD (block b runs on XCD b % 8): its input tile is read
+    // from HBM once per XCD L2
+    const int b = blockIdx.x;
+    const int kt = (b >> 3) % kts, pb = (b / (8 * kts)) * 8 + (b & 7);
+    if (pb >= npb) return;
+    const int tx = pb % tiles_x, ty = (pb / tiles_x) % tiles_y, grp = pb / (tiles_x * tiles_y);
+    const int n0 = grp * NI, y0 = ty * RH, x0 = tx * RW;
+    const int n_chunks = Cin / BS_CK;
+    const int IH = UNPOOL ? H >> 1 : H, IW = UNPOOL ? W >> 1 : W;          // the input tensor's own plane
+    const int plane_in = IH * IW;
+
+    const float* in_blk = in + (size_t)n0 * Cin * plane_in;
+    const __amdgpu_buffer_rsrc_t rs_x = clhip_rsrc(in_blk, (size_t)(N - n0) * Cin * plane_in * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rs_i = clhip_rsrc(UNPOOL ? pool_idx + (size_t)n0 * Cin * plane_in : pool_idx,
+                                                   UNPOOL ? (size_t)(N - n0) * Cin * plane_in : 0);
+    const int n_nt = (Cout + 31) / 32;
+    const __amdgpu_buffer_rsrc_t rs_w = clhip_rsrc(wimg, (size_t)n_nt * n_chunks * 27 * 1024);
+
+    // ---- staging items of this thread: (halo pixel, k half) -> element offset of channel 8 h of the chunk, LDS slot
+    int xoff[ROUNDS], lw[ROUNDS], pos[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        // (the last round wraps around: its spare threads stage the first items a second time — same data to the same slots —
+        // so that no load / LDS write of the loop sits under a branch)
+        const int it_ = r * 256 + tid, it = it_ < G::ITEMS ? it_ : it_ - G::ITEMS;
+        const int h = it >= G::NHALO ? 1 : 0, p = it - h * G::NHALO;
+        const int ni = p / (HR * HW_), rem = p - ni * (HR * HW_), hy = rem / HW_, hx = rem - hy * HW_;
+        const int gy = y0 + hy - 1, gx = x0 + hx - 1, n = n0 + ni;
+        const bool ok = n < N && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const int e = UNPOOL ? (gy >> 1) * IW + (gx >> 1) : gy * IW + gx;
+        xoff[r] = ok ? (ni * Cin + 8 * h) * plane_in + e : CLHIP_OOB;
+        pos[r] = ((gy & 1) << 1) | (gx & 1);
+        lw[r] = (h * G::PLANE_SLOTS + ((ni / G::IPR) * HR + hy) * P + (ni % G::IPR) * HW_ + hx) * 16;
+    }
+    float xr[ROUNDS][8];
+    unsigned xi[UNPOOL ? ROUNDS : 1][8];
+    auto load_chunk = [&](int c) {
+        const int cb = c * BS_CK * plane_in;
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int so = cb + e * plane_in;
+                xr[r][e] = clhip_buf_load(rs_x, xoff[r] != CLHIP_OOB ? xoff[r] * 4 : CLHIP_OOB, so * 4);
+                if constexpr (UNPOOL) xi[r][e] = clhip_buf_load_u8(rs_i, xoff[r], so);
+            }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if constexpr (UNPOOL) v[e] = xi[r][e] == (unsigned)pos[r] ? xr[r][e] : 0.f;     // max_pool2d backward (+ ReLU: dead code 4)
+                else v[e] = xr[r][e];
+            }
+            clhip_u32x4 q0, q1, q2;
+            bs_split8(v, q0, q1, q2);
+            unsigned char* d = lds + buf * G::BUF_BYTES + lw[r];
+            *reinterpret_cast<clhip_u32x4*>(d) = q0;
+            *reinterpret_cast<clhip_u32x4*>(d + 2 * G::PLANE_BYTES) = q1;
+            *reinterpret_cast<clhip_u32x4*>(d + 4 * G::PLANE_BYTES) = q2;
+        }
+    };
+
+    // ---- this wave's M tiles / N tiles
+    const int wm = wave % G::WAVES_M, wn = wave / G::WAVES_M;
+    const int m = lane & 31, kh = lane >> 5;
+    const int mw = m >> 2, mq = m & 3;
+    const int prow = 2 * (mw / (G::MTW / 2)) + (mq >> 1), pcol = 2 * (mw % (G::MTW / 2)) + (mq & 1);     // pixel of lane m inside its M tile
+    int abase[WM];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int mt = wm * WM + i;
+        const int ni = mt / G::MT_PER_IMG, rem = mt - ni * G::MT_PER_IMG, tr = rem / G::MT_PER_ROW, tc = rem - tr * G::MT_PER_ROW;
+        abase[i] = (kh * G::PLANE_SLOTS + ((ni / G::IPR) * HR + tr * G::MTH + prow) * P + (ni % G::IPR) * HW_ + tc * G::MTW + pcol) * 16;
+    }
+    const int nt0 = kt * (BS_BN / 32) + wn * WN;
+    int wvoff[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) wvoff[j] = (nt0 + j < n_nt) ? ((nt0 + j) * n_chunks * 27 * 64 + lane) * 16 : CLHIP_OOB;
+    auto load_b = [&](clhip_u32x4 (&bq)[WN][3], int c, int tap) {
+        const int so = (c * 27 + tap * 3) * 1024;
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) bq[j][s] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wvoff[j], so + s * 1024, 0);
+    };
+
+    floatx16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- prologue: chunk 0 in LDS, chunk 1 in flight, first weight operands in flight
+    clhip_u32x4 bcur[WN][3];
+    load_chunk(0);
+    load_b(bcur, 0, 0);
+    store_chunk(0);
+    load_chunk(n_chunks > 1 ? 1 : 0);
+    __syncthreads();
+
+    for (int c = 0; c < n_chunks; ++c) {
+        const unsigned char* lb = lds + (c & 1) * G::BUF_BYTES;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dr = tap / 3, ds = tap - dr * 3;
+            // next tap's weight operands (the first tap of the next chunk after the last one; past the end: any valid address)
+            clhip_u32x4 bnext[WN][3];
+            if (tap < 8) load_b(bnext, c, tap + 1);
+            else load_b(bnext, c + 1 < n_chunks ? c + 1 : c, 0);
+            clhip_u32x4 a[WM][3];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+                    a[i][s] = *reinterpret_cast<const clhip_u32x4*>(lb + abase[i] + (dr * P + ds) * 16 + s * 2 * G::PLANE_BYTES);
+            if (tap == 3) {
+                // staging of the next chunk inside this chunk's matrix stream, unconditionally (one basic block per chunk: the
+                // scheduler may place these VALU / LDS / load instructions between the MFMAs): after the last chunk the spare
+                // buffer takes a second copy of it, which nobody reads
+                store_chunk((c + 1) & 1);
+                load_chunk(c + 2 < n_chunks ? c + 2 : n_chunks - 1);
+            }
+            // six products per tile pair, small ones first; consecutive MFMAs go to different accumulators
+#define BS_TERM(PA, PB)                                                                                                           \
+            _Pragma("unroll") for (int i = 0; i < WM; ++i) _Pragma("unroll") for (int j = 0; j < WN; ++j)                         \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bs_bf16x8, a[i][PA]),                      \
+                                                                   __builtin_bit_cast(bs_bf16x8, bcur[j][PB]), acc[i][j], 0, 0, 0);
+            BS_TERM(0, 2) BS_TERM(2, 0) BS_TERM(1, 1) BS_TERM(0, 1) BS_TERM(1, 0) BS_TERM(0, 0)
+#undef BS_TERM
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int s = 0; s < 3; ++s) bcur[j][s] = bnext[j][s];
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: acc[i][j][4 g + q] = (pixel = window 2 g + kh of M tile i, position q; channel 32 (nt0 + j) + (lane & 31))
+    const bool pool = MODE == 0 && pool_idx != nullptr;
+    const bool odd = (H | W) & 1;
+    const size_t chw = (size_t)H * W;
+    const int OH = H >> 1, OW = W >> 1;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int k = (nt0 + j) * 32 + m;
+        const bool kok = k < Cout;
+        const float bv = (MODE == 0 && bias != nullptr && kok) ? bias[k] : 0.f;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            const int mt = wm * WM + i;
+            const int ni = mt / G::MT_PER_IMG, rem = mt - ni * G::MT_PER_IMG, tr = rem / G::MT_PER_ROW, tc = rem - tr * G::MT_PER_ROW;
+            const int n = n0 + ni;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int w8 = 2 * g + kh;                                               // window of the M tile
+                const int oh = y0 + tr * G::MTH + 2 * (w8 / (G::MTW / 2)), ow = x0 + tc * G::MTW + 2 * (w8 % (G::MTW / 2));
+                const bool ok = kok && n < N && oh < H && ow < W;
+                float y00 = acc[i][j][4 * g], y01 = acc[i][j][4 * g + 1], y10 = acc[i][j][4 * g + 2], y11 = acc[i][j][4 * g + 3];
+                if (MODE == 0) {
+                    y00 += bv; y01 += bv; y10 += bv; y11 += bv;
+                    if (relu) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
+                    if (pool) {
+                        float mx = y00; int am = 0;
+                        if (y01 > mx) { mx = y01; am = 1; }
+                        if (y10 > mx) { mx = y10; am = 2; }
+                        if (y11 > mx) { mx = y11; am = 3; }
+                        if (relu && !(mx > 0.f)) am = CLHIP_POOL_DEAD;       // ReLU folded into the code (common.hpp)
+                        if (ok) {
+                            const size_t o = ((size_t)n * Cout + k) * OH * OW + (size_t)(oh >> 1) * OW + (ow >> 1);
+                            out[o] = mx;
+                            pool_idx[o] = (uint8_t)am;
+                        }
+                        continue;
+                    }
+                }
+                if (!ok) continue;
+                const size_t o = ((size_t)n * Cout + k) * chw + (size_t)oh * W + ow;
+                if (odd) {
+                    const bool row1 = oh + 1 < H, col1 = ow + 1 < W;
+                    if (MODE == 1 && mask_src) {
+                        y00 = mask_src[o] > 0.f ? y00 : 0.f;
+                        if (col1) y01 = mask_src[o + 1] > 0.f ? y01 : 0.f;
+                        if (row1) y10 = mask_src[o + W] > 0.f ? y10 : 0.f;
+                        if (row1 && col1) y11 = mask_src[o + W + 1] > 0.f ? y11 : 0.f;
+                    }
+                    out[o] = y00;
+                    if (col1) out[o + 1] = y01;
+                    if (row1) out[o + W] = y10;
+                    if (row1 && col1) out[o + W + 1] = y11;
+                } else {
+                    if (MODE == 1 && mask_src) {
+                        const float2 m0 = *reinterpret_cast<const float2*>(mask_src + o), m1 = *reinterpret_cast<const float2*>(mask_src + o + W);
+                        y00 = m0.x > 0.f ? y00 : 0.f; y01 = m0.y > 0.f ? y01 : 0.f;
+                        y10 = m1.x > 0.f ? y10 : 0.f; y11 = m1.y > 0.f ? y11 : 0.f;
+                    }
+                    *reinterpret_cast<float2*>(out + o) = make_float2(y00, y01);
+                    *reinterpret_cast<float2*>(out + o + W) = make_float2(y10, y11);
+                }
+            }
+        }
+    }
+}
+
+// CLHIP_BS=0: the layers this path would take stay on the Winograd / direct f32 kernels (A/B measurements, the parity suite's
+// second leg).  CLHIP_BS_BM=128 / 256 forces the block size (default: by the number of blocks the launch would have).
+static int bs_env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e && e[0] ? atoi(e) : dflt;
+}
+static bool bs_on() {
+    static const bool on = bs_env_int("CLHIP_BS", 1) != 0;
+    return on;
+}
+
+template <class G, int MODE, bool UNPOOL>
+int bs_launch_geo(const float* in, const clhip_u32x4* wimg, const float* bias, const float* mask_src, float* out, uint8_t* pool_idx,
+                  int N, int Cin, int Cout, int H, int W, int relu, hipStream_t s) {
+    const int tiles_x = (W + G::RW - 1) / G::RW, tiles_y = (H + G::RH - 1) / G::RH, groups = (N + G::NI - 1) / G::NI;
+    const long long npb = (long long)tiles_x * tiles_y * groups;
+    const int kts = (Cout + BS_BN - 1) / BS_BN;
+    const long long blocks = (npb + 7) / 8 * 8 * kts;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return CLHIP_EINVAL;
+    hipLaunchKernelGGL((bs_conv_kernel<G, MODE, UNPOOL>), dim3((unsigned)blocks), dim3(256), 0, s, in, wimg, bias, mask_src, out,
+                       pool_idx, N, Cin, Cout, H, W, relu, tiles_x, tiles_y, (int)npb);
+    CLHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int MODE, bool UNPOOL>
+int bs_launch(const float* in, const clhip_u32x4* wimg, const float* bias, const float* mask_src, float* out, uint8_t* pool_idx,
+              int N, int Cin, int Cout, int H, int W, int relu, hipStream_t s) {
+    static const int force_bm = bs_env_int("CLHIP_BS_BM", 0);
+    const int kts = (Cout + BS_BN - 1) / BS_BN;
+    // 256-pixel blocks (64 x 64 wave tiles: half the operand fetches per MFMA) when they still give every CU >= 4 blocks
+    auto big = [&](int rw, int rh, int ni) {
+        if (force_bm) return force_bm == 256;
+        const long long nb = (long long)((W + rw - 1) / rw) * ((H + rh - 1) / rh) * ((N + ni - 1) / ni) * kts;
+        return nb >= 1024;
+    };
+#define BS_GO(...) return bs_launch_geo<BsGeo<__VA_ARGS__>, MODE, UNPOOL>(in, wimg, bias, mask_src, out, pool_idx, N, Cin, Cout, H, W, relu, s)
+    if (W > 16) {
+        if (big(32, 8, 1)) BS_GO(32, 8, 1, 4, 2, 2);
+        BS_GO(32, 4, 1, 2, 2, 1);
+    }
+    if (W > 8) {
+        if (big(16, 16, 1)) BS_GO(16, 16, 1, 4, 2, 2);
+        BS_GO(16, 8, 1, 2, 2, 1);
+    }
+    if (big(8, 8, 4)) BS_GO(8, 8, 4, 4, 2, 2);
+    BS_GO(8, 8, 2, 2, 2, 1);
+#undef BS_GO
+}
+
+}  // namespace
+
+// shapes this path takes: whole 32-channel k pairs on the input side, whole 64-channel groups on the output side; any H, W >= 4
+// (tiles past the edge stage zeros and store nothing); fused pooling / un-pooling only on even maps
+bool clhip_internal_bs_ok(int Cin, int Cout, int H, int W) {
+    return bs_on() && Cin >= 32 && Cin % 32 == 0 && Cout % 64 == 0 && H >= 4 && W >= 4;
+}
+
+size_t clhip_internal_bs_ws(int Cin, int Cout) {
+    return (size_t)((Cout + 31) / 32) * ((Cin + BS_CK - 1) / BS_CK) * 27 * 1024;
+}
+
+int clhip_internal_bs_weights(const clhip_wino_wt* jobs, int n, hipStream_t s) {
+    if (n <= 0) return 0;
+    if (!jobs) return CLHIP_EINVAL;
+    for (int base = 0; base < n; base += BS_WT_JOBS) {
+        BsWtJobs J;
+        J.n = n - base < BS_WT_JOBS ? n - base : BS_WT_JOBS;
+        J.pad = 0;
+        int blocks = 0;
+        for (int i = 0; i < J.n; ++i) {
+            const clhip_wino_wt& q = jobs[base + i];
+            if (!q.w || !q.U || q.Ko <= 0 || q.Ci <= 0) return CLHIP_EINVAL;
+            J.j[i] = q;
+            J.first[i] = blocks;
+            const int total = ((q.Ko + 31) / 32) * ((q.Ci + BS_CK - 1) / BS_CK) * 9 * 64;
+            blocks += (total + 255) / 256;
+        }
+        J.first[J.n] = blocks;
+        hipLaunchKernelGGL(bs_weight_multi_kernel, dim3(blocks), dim3(256), 0, s, J);
+        CLHIP_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// forward (mode 0) / backward-data (mode 1) on a weight image made by clhip_internal_bs_weights; arguments as
+// clhip_internal_wino_conv_u (backward-data: Cin = the layer's OUT channels, Cout = its IN channels)
+int clhip_internal_bs_conv_u(int mode, const float* in, const void* wimg, const float* bias, const float* mask_src, float* out,
+                             uint8_t* pool_idx, int unpool, int N, int Cin, int Cout, int H, int W, int relu, hipStream_t s) {
+    if (!in || !wimg || !out || N <= 0 || !clhip_internal_bs_ok(Cin, Cout, H, W)) return CLHIP_EINVAL;
+    if (((H | W) & 1) && (pool_idx || unpool)) return CLHIP_ENOTSUP;
+    const clhip_u32x4* img = static_cast<const clhip_u32x4*>(wimg);
+    if (mode == 0) return bs_launch<0, false>(in, img, bias, nullptr, out, pool_idx, N, Cin, Cout, H, W, relu, s);
+    if (unpool) return bs_launch<1, true>(in, img, nullptr, mask_src, out, pool_idx, N, Cin, Cout, H, W, 0, s);
+    return bs_launch<1, false>(in, img, nullptr, mask_src, out, nullptr, N, Cin, Cout, H, W, 0, s);
+}
+
+extern "C" {
+
+size_t clhip_conv3x3_bs_ws(int C, int K) {
+    const size_t a = clhip_internal_bs_ws(C, K), b = clhip_internal_bs_ws(K, C);
+    return a > b ? a : b;
+}
+
+int clhip_conv3x3_bs_fwd(const float* x, const float* w, const float* b, float* y, uint8_t* idx_u8_or_null, int N, int C, int K, int H,
+                         int W, int relu, void* ws, size_t ws_bytes, void* stream) {
+    if (N <= 0 || !clhip_internal_bs_ok(C, K, H, W)) return CLHIP_ENOTSUP;
+    if (!x || !w || !y || !ws || ws_bytes < clhip_internal_bs_ws(C, K)) return CLHIP_EINVAL;
+    const clhip_wino_wt job{w, static_cast<float*>(ws), K, C, 0, 0};
+    const int rc = clhip_internal_bs_weights(&job, 1, as_stream(stream));
+    if (rc) return rc;
+    return clhip_internal_bs_conv_u(0, x, ws, b, nullptr, y, idx_u8_or_null, 0, N, C, K, H, W, relu, as_stream(stream));
+}
+
+int clhip_conv3x3_bs_bwd_data(const float* dy, const uint8_t* idx_u8_or_null, const float* w, const float* relu_src, float* dx, int N,
+                              int C, int K, int H, int W, void* ws, size_t ws_bytes, void* stream) {
+    if (N <= 0 || !clhip_internal_bs_ok(K, C, H, W)) return CLHIP_ENOTSUP;
+    if (!dy || !w || !dx || !ws || ws_bytes < clhip_internal_bs_ws(K, C)) return CLHIP_EINVAL;
+    const clhip_wino_wt job{w, static_cast<float*>(ws), C, K, 1, 0};
+    const int rc = clhip_internal_bs_weights(&job, 1, as_stream(stream));
+    if (rc) return rc;
+    return clhip_internal_bs_conv_u(1, dy, ws, nullptr, relu_src, dx, const_cast<uint8_t*>(idx_u8_or_null), idx_u8_or_null != nullptr,
+                                    N, K, C, H, W, 0, as_stream(stream));
+}
+
+}  // extern "C"

@@ -39,6 +39,8 @@ struct LayerPlan {
     float* rmean; float* rvar; float bn_momentum, bn_eps;
     size_t wino_uf, wino_ud;     // byte offsets of this layer's transformed weights (forward / backward-data) in the plan's Winograd region
     int wino_f, wino_d, wino_w;  // forward / backward-data / weight gradient through Winograd F(2x2,3x3) (wino.hip) instead of the direct kernels
+    int bs_f, bs_d;              // ... forward / backward-data on the bf16 matrix cores with split fp32 operands (bsconv.hip): wino_f / wino_d
+                                 // are set as well (the layer takes the prepared-weights path) and wino_uf / wino_ud hold its weight IMAGE
     int wg3;                   // weight gradient on the 3x3 kernel (else the general gather-GEMM)
     size_t wg_off, wg_bytes;   // this layer's own weight-gradient slabs (3x3 layers; reduced for all layers at once)
     const float* extra_grad;   // added to the gradient w.r.t. this layer's input (side branches: clhip_net_set_input_grad)
@@ -219,7 +221,7 @@ int clhip_net_create(const clhip_layer_desc* descs, int n_layers, int max_batch,
             // Winograd path: 2.25x fewer matrix instructions, but a wave's work unit is 32 channels x 32 TILES (128
             // pixels) with 256 accumulator registers, one wave per SIMD: it needs enough units to fill most of the 1024 SIMDs
             // (measured at N = 200: 64->64 @16x16, 800 units, 1.26x the direct kernel; 128->128 @8x8, 400 units, 0.8x)
-            if (vgg && !L.bn && wino_enabled()) {
+            if (vgg && !L.bn) {
                 const long long tiles = (long long)max_batch * ((L.h + 1) / 2) * ((L.w + 1) / 2);
                 auto units = [&](int kout) { return ((tiles + 31) / 32) * ((kout + 31) / 32); };
                 // (8 x 8 maps: the 16x16x4-MFMA variant has 16-tile units, one image x 32 channels per wave)
@@ -227,11 +229,19 @@ int clhip_net_create(const clhip_layer_desc* descs, int n_layers, int max_batch,
                     if (units(kout) >= WINO_MIN_UNITS) return true;
                     return L.h == 8 && L.w == 8 && (long long)max_batch * ((kout + 31) / 32) >= WINO16_MIN_UNITS;
                 };
-                L.wino_f = clhip_internal_wino_ok(L.cin, L.cout, L.h, L.w) && enough(L.cout);
-                L.wino_d = i > 0 && clhip_internal_wino_ok(L.cout, L.cin, L.h, L.w) && enough(L.cin);
+                const bool wino = wino_enabled();
+                L.wino_f = wino && clhip_internal_wino_ok(L.cin, L.cout, L.h, L.w) && enough(L.cout);
+                L.wino_d = wino && i > 0 && clhip_internal_wino_ok(L.cout, L.cin, L.h, L.w) && enough(L.cin);
+                // bf16 matrix cores with split fp32 operands (bsconv.hip; CLHIP_BS=0 turns it off): every 3x3 layer of its shape domain;
+                // fused 2x2 pooling only exists on even maps there
+                const bool even = ((L.h | L.w) & 1) == 0;
+                L.bs_f = clhip_internal_bs_ok(L.cin, L.cout, L.h, L.w) && (even || !L.pool);
+                L.bs_d = i > 0 && clhip_internal_bs_ok(L.cout, L.cin, L.h, L.w) && (even || !L.pool);
+                if (L.bs_f) L.wino_f = 1;
+                if (L.bs_d) L.wino_d = 1;
                 // weight gradient: the reduction (tiles) splits over ~256 blocks per 64x64 (k, c) tile; each block needs a
                 // few 16-tile stages to amortise its 256-accumulator epilogue (measured: 12.5 stages per block 1.44x, 3.1 0.6x)
-                if (clhip_internal_wino_wgrad_ok(L.cin, L.cout, L.h, L.w)) {
+                if (wino && clhip_internal_wino_wgrad_ok(L.cin, L.cout, L.h, L.w)) {
                     const int kc = (L.cin / 64) * (L.cout / 64), splits = (256 + kc - 1) / kc;
                     const long long stages = (long long)max_batch * (((L.w + 1) / 2 + (L.w >= 16 ? 7 : 3)) / (L.w >= 16 ? 8 : 4)) *
                                              (((L.h + 1) / 2 + (L.w >= 16 ? 1 : 3)) / (L.w >= 16 ? 2 : 4));
@@ -248,8 +258,8 @@ int clhip_net_create(const clhip_layer_desc* descs, int n_layers, int max_batch,
                     }
                 }
                 // every Winograd layer keeps its own transformed weights: ONE transform launch per pass fills them all
-                if (L.wino_f) { L.wino_uf = wino_ws; wino_ws += align_up(clhip_internal_wino_ws(L.cin, L.cout), 256); }
-                if (L.wino_d) { L.wino_ud = wino_ws; wino_ws += align_up(clhip_internal_wino_ws(L.cout, L.cin), 256); }
+                if (L.wino_f) { L.wino_uf = wino_ws; wino_ws += align_up(L.bs_f ? clhip_internal_bs_ws(L.cin, L.cout) : clhip_internal_wino_ws(L.cin, L.cout), 256); }
+                if (L.wino_d) { L.wino_ud = wino_ws; wino_ws += align_up(L.bs_d ? clhip_internal_bs_ws(L.cout, L.cin) : clhip_internal_wino_ws(L.cout, L.cin), 256); }
             }
             if (L.out_elems > gmax) gmax = L.out_elems;
             if (L.in_elems > gmax) gmax = L.in_elems;
@@ -407,7 +417,9 @@ int clhip_net_layer_paths(void* handle, int layer) {
     // (bit 2: the Winograd weight gradient runs only inside the deferred-reduction scheme, net_backward_impl's `defer`; and even
     // then the kernel may hand single shapes back to the direct path — odd maps with a fused un-pool, > 2^31-byte offsets)
     const bool defer_capable = p->n_wg > 0 && !(p->overlap && p->overlap_mode == 1);
-    return (L.wino_f ? 1 : 0) | (L.wino_d ? 2 : 0) | ((L.wino_w && defer_capable) ? 4 : 0);
+    // bits 3 / 4: the forward / backward-data launch is the bf16-split kernel (bsconv.hip), not Winograd (bits 0 / 1 then say
+    // "prepared-weights path")
+    return (L.wino_f ? 1 : 0) | (L.wino_d ? 2 : 0) | ((L.wino_w && defer_capable) ? 4 : 0) | (L.bs_f ? 8 : 0) | (L.bs_d ? 16 : 0);
 }
 
 int clhip_net_set_input_grad(void* handle, int layer, const float* extra) {
@@ -494,18 +506,28 @@ static bool tail_usable(const NetPlan* p, const float* params, const void* ws, i
            (size_t)N * (p->n_classes | 1) <= 12288;        // the range in which the per-layer path uses softmax_ce_rows_lds_kernel
 }
 
-// transformed weights of every Winograd layer (forward set, backward-data set, or both) in one launch
+// the prepared-weights convolution of a layer: Winograd (wino.hip) or bf16-split (bsconv.hip), same arguments
+static int plan_conv_u(int bs, int mode, const float* in, const float* U, const float* bias, const float* mask_src, float* out,
+                       uint8_t* pool_idx, int unpool, int N, int Cin, int Cout, int H, int W, int relu, hipStream_t s) {
+    return bs ? clhip_internal_bs_conv_u(mode, in, U, bias, mask_src, out, pool_idx, unpool, N, Cin, Cout, H, W, relu, s)
+              : clhip_internal_wino_conv_u(mode, in, U, bias, mask_src, out, pool_idx, unpool, N, Cin, Cout, H, W, relu, s);
+}
+
+// transformed weights of every Winograd / bf16-split layer (forward set, backward-data set, or both) in one launch each
 static int wino_prepare(NetPlan* p, const float* params, char* base, bool fwd, bool bwd, hipStream_t s) {
-    std::vector<clhip_wino_wt> jobs;                     // (sized by the plan: a net of any depth gets every transform)
+    std::vector<clhip_wino_wt> jobs, bsjobs;             // (sized by the plan: a net of any depth gets every transform)
     jobs.reserve(2 * p->layers.size());
+    bsjobs.reserve(2 * p->layers.size());
     for (const LayerPlan& L : p->layers) {
         if (L.type != 0) continue;
         if (fwd && L.wino_f)
-            jobs.push_back(clhip_wino_wt{params + L.w_off, reinterpret_cast<float*>(base + p->off_wino + L.wino_uf), L.cout, L.cin, 0, 0});
+            (L.bs_f ? bsjobs : jobs).push_back(clhip_wino_wt{params + L.w_off, reinterpret_cast<float*>(base + p->off_wino + L.wino_uf), L.cout, L.cin, 0, 0});
         if (bwd && L.wino_d)
-            jobs.push_back(clhip_wino_wt{params + L.w_off, reinterpret_cast<float*>(base + p->off_wino + L.wino_ud), L.cin, L.cout, 1, 0});
+            (L.bs_d ? bsjobs : jobs).push_back(clhip_wino_wt{params + L.w_off, reinterpret_cast<float*>(base + p->off_wino + L.wino_ud), L.cin, L.cout, 1, 0});
     }
-    return clhip_internal_wino_weights(jobs.data(), (int)jobs.size(), s);
+    const int rc = clhip_internal_wino_weights(jobs.data(), (int)jobs.size(), s);
+    if (rc) return rc;
+    return clhip_internal_bs_weights(bsjobs.data(), (int)bsjobs.size(), s);      // (one launch each: Winograd U images, bf16-split images)
 }
 
 static int net_forward_impl(void* handle, const float* params, const float* x, int N, void* ws, float* logits_out,
@@ -549,7 +571,7 @@ static int net_forward_impl(void* handle, const float* params, const float* x, i
             float* zc = L.bn ? acts + L.z_off : y;
             const int crelu = L.bn ? 0 : L.relu;
             rc = (vgg && L.wino_f)
-                     ? clhip_internal_wino_conv_u(0, cur, reinterpret_cast<const float*>(base + p->off_wino + L.wino_uf), params + L.b_off,
+                     ? plan_conv_u(L.bs_f, 0, cur, reinterpret_cast<const float*>(base + p->off_wino + L.wino_uf), params + L.b_off,
                                                   nullptr, zc, nullptr, 0, N, L.cin, L.cout, L.h, L.w, crelu, as_stream(stream))
                  : vgg ? clhip_conv3x3_fwd(cur, params + L.w_off, params + L.b_off, zc, N, L.cin, L.cout, L.h, L.w, crelu, stream)
                      : clhip_conv2d_fwd(cur, params + L.w_off, params + L.b_off, zc, N, L.cin, L.h, L.w, L.cout, L.ks, L.ks, L.st,
@@ -573,7 +595,7 @@ static int net_forward_impl(void* handle, const float* params, const float* x, i
             if (L.pool && L.relu) {
                 // conv + bias + ReLU + max-pool in one kernel; the pre-pool tensor is never materialised
                 float* pl = acts + L.pool_off;
-                rc = L.wino_f ? clhip_internal_wino_conv_u(0, cur, reinterpret_cast<const float*>(base + p->off_wino + L.wino_uf),
+                rc = L.wino_f ? plan_conv_u(L.bs_f, 0, cur, reinterpret_cast<const float*>(base + p->off_wino + L.wino_uf),
                                                            params + L.b_off, nullptr, pl, idx + L.idx_off, 0, N, L.cin, L.cout, L.h, L.w, 1,
                                                            as_stream(stream))
                               : clhip_conv3x3_relu_pool_fwd(cur, params + L.w_off, params + L.b_off, pl, idx + L.idx_off, N, L.cin,
@@ -581,7 +603,7 @@ static int net_forward_impl(void* handle, const float* params, const float* x, i
                 if (rc) return rc;
                 cur = pl;
             } else {
-                rc = L.wino_f ? clhip_internal_wino_conv_u(0, cur, reinterpret_cast<const float*>(base + p->off_wino + L.wino_uf),
+                rc = L.wino_f ? plan_conv_u(L.bs_f, 0, cur, reinterpret_cast<const float*>(base + p->off_wino + L.wino_uf),
                                                            params + L.b_off, nullptr, y, nullptr, 0, N, L.cin, L.cout, L.h, L.w, L.relu,
                                                            as_stream(stream))
                               : clhip_conv3x3_fwd(cur, params + L.w_off, params + L.b_off, y, N, L.cin, L.cout, L.h, L.w, L.relu, stream);
@@ -805,7 +827,7 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
             if (wdone && i > 0 && !L.drop && !L.extra_grad) {
                 gout_d = take(); gout_d_buf = taken;
                 probe_begin(1);
-                rc = L.wino_d ? clhip_internal_wino_conv_u(1, gin, reinterpret_cast<const float*>(base + p->off_wino + L.wino_ud), nullptr,
+                rc = L.wino_d ? plan_conv_u(L.bs_d, 1, gin, reinterpret_cast<const float*>(base + p->off_wino + L.wino_ud), nullptr,
                                                            xmask, gout_d, idx + L.idx_off, 1, N, L.cout, L.cin, L.h, L.w, 0, as_stream(stream))
                               : clhip_conv3x3_bwd_data_unpool(gin, idx + L.idx_off, params + L.w_off, xmask, gout_d, N, L.cin, L.cout, L.h,
                                                               L.w, stream);
@@ -861,7 +883,7 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
             float* gout = take();
             probe_begin(1);
             rc = (vgg && L.wino_d)
-                     ? clhip_internal_wino_conv_u(1, gy, reinterpret_cast<const float*>(base + p->off_wino + L.wino_ud), nullptr, xmask, gout,
+                     ? plan_conv_u(L.bs_d, 1, gy, reinterpret_cast<const float*>(base + p->off_wino + L.wino_ud), nullptr, xmask, gout,
                                                   nullptr, 0, N, L.cout, L.cin, L.h, L.w, 0, as_stream(stream))
                  : vgg ? clhip_conv3x3_bwd_data(gy, params + L.w_off, xmask, gout, N, L.cin, L.cout, L.h, L.w, stream)
                      : clhip_conv2d_bwd_data(gy, params + L.w_off, xmask, gout, N, L.cin, L.h, L.w, L.cout, L.ks, L.ks, L.st, L.pd, stream);

@@ -85,6 +85,39 @@ def conv3x3_wino_bwd_data(dy, w, relu_src=None, idx=None):
     return dx
 
 
+def conv3x3_bs_fwd(x, w, b, relu=True, pool=False):
+    """clhip_conv3x3_bs_fwd: the forward operators above on the bf16 matrix cores with split fp32 operands (csrc/bsconv.hip).
+    Returns y, or (y_pool, idx_u8)."""
+    _chk(x, w, b)
+    N, C, H, W = x.shape
+    K = w.shape[0]
+    L = _lib.lib()
+    ws = torch.empty(L.clhip_conv3x3_bs_ws(C, K), dtype=torch.uint8, device=x.device)
+    if pool:
+        y = torch.empty((N, K, H // 2, W // 2), dtype=torch.float32, device=x.device)
+        idx = torch.empty((N, K, H // 2, W // 2), dtype=torch.uint8, device=x.device)
+    else:
+        y, idx = torch.empty((N, K, H, W), dtype=torch.float32, device=x.device), None
+    check(L.clhip_conv3x3_bs_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(y), _ptr(idx) if pool else None, N, C, K, H, W, int(relu),
+                                 _ptr(ws), ws.numel(), _stream()), "clhip_conv3x3_bs_fwd")
+    return (y, idx) if pool else y
+
+
+def conv3x3_bs_bwd_data(dy, w, relu_src=None, idx=None):
+    """clhip_conv3x3_bs_bwd_data: dx of the 3x3 convolution on the same path (idx: dy is the POOLED gradient + arg-max codes)."""
+    _chk(dy, w)
+    K, C = w.shape[0], w.shape[1]
+    N = dy.shape[0]
+    H, W = (dy.shape[2] * 2, dy.shape[3] * 2) if idx is not None else (dy.shape[2], dy.shape[3])
+    L = _lib.lib()
+    ws = torch.empty(L.clhip_conv3x3_bs_ws(C, K), dtype=torch.uint8, device=dy.device)
+    dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device)
+    check(L.clhip_conv3x3_bs_bwd_data(_ptr(dy), _ptr(idx) if idx is not None else None, _ptr(w),
+                                      _ptr(relu_src) if relu_src is not None else None, _ptr(dx), N, C, K, H, W, _ptr(ws),
+                                      ws.numel(), _stream()), "clhip_conv3x3_bs_bwd_data")
+    return dx
+
+
 def conv3x3_wino_bwd_weight(x, dy, idx=None):
     """clhip_conv3x3_wino_bwd_weight: (dw, db) of the 3x3 convolution (idx: dy is the POOLED gradient + arg-max codes)."""
     _chk(x, dy)

@@ -239,6 +239,19 @@ size_t clhip_conv3x3_wino_bwd_weight_ws(int N, int C, int K, int H, int W);
 int clhip_conv3x3_wino_bwd_weight(const float* x, const float* dy, const uint8_t* idx_u8_or_null, float* dw, float* db, int N, int C,
                                   int K, int H, int W, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------ 3x3 convolution on the bf16 matrix cores, split fp32 operands
+ * The same operators again (VGGSlim.py:27-40 and their autograd backward w.r.t. the input; arguments as the _wino_ entry points)
+ * in DIRECT form on v_mfma_f32_32x32x16_bf16: every fp32 operand is split exactly into three bf16 pieces, the six products
+ * a_i * b_j (i + j <= 2) of each 16-deep k-step are accumulated in fp32 inside the matrix core (csrc/bsconv.hip).  Measured error
+ * against fp64 = that of an fp32 fmaf chain (profiles/r05_bf16_split_dot.txt); results equal the other paths' up to fp32 rounding.
+ * Shapes: C % 32 == 0, K % 64 == 0 on the forward (K % 32, C % 64 on backward-data), H, W >= 4; fused pooling on even maps only;
+ * CLHIP_ENOTSUP otherwise.  ws: clhip_conv3x3_bs_ws(C, K) bytes (the weight image of this call).                            */
+size_t clhip_conv3x3_bs_ws(int C, int K);
+int clhip_conv3x3_bs_fwd(const float* x, const float* w, const float* b, float* y, uint8_t* idx_u8_or_null, int N, int C, int K,
+                         int H, int W, int relu, void* ws, size_t ws_bytes, void* stream);
+int clhip_conv3x3_bs_bwd_data(const float* dy, const uint8_t* idx_u8_or_null, const float* w, const float* relu_src, float* dx,
+                              int N, int C, int K, int H, int W, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------ HAT gates / back-masks / HAT_SGD
  * methods/HAT/networks/vgg_hat.py, approaches/hat.py, HAT_utils.py.  Gates multiply layer outputs in the
  * reference (vgg_hat.py:104-116); here they are folded into the NEXT layer's weights
@@ -337,7 +350,8 @@ int clhip_net_probe_read(void* handle, float* avg_us, int* count);
  * needs to judge gradients independently of ReLU / arg-max near-ties.  EINVAL for layers without a pool.   */
 int clhip_net_layer_pool_idx(void* handle, int layer, size_t* ws_byte_off, size_t* elems_per_sample);
 /* Which kernels the plan chose for a layer (measurement harnesses time the same ones): bit 0 forward, bit 1 backward-data, bit 2
- * weight gradient through the Winograd F(2x2,3x3) path (csrc/wino.hip) instead of the direct MFMA kernels; < 0 on error. */
+ * weight gradient through a prepared-weights path instead of the direct f32 MFMA kernels — Winograd F(2x2,3x3) (csrc/wino.hip)
+ * unless bit 3 (forward) / bit 4 (backward-data) says the launch is the bf16-split kernel (csrc/bsconv.hip); < 0 on error. */
 int clhip_net_layer_paths(void* handle, int layer);
 
 /* Side branches off a plan (EBLL's code layers on the flattened features, AlexNet_EBLL.py:110-117): the INPUT activation

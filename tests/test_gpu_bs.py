@@ -1,0 +1,187 @@
+"""3x3 convolution on the bf16 matrix cores with split fp32 operands (csrc/bsconv.hip) against torch CPU (the reference's arithmetic:
+nn.Conv2d + ReLU + MaxPool2d of models/VGGSlim.py:27-40 and their autograd backward w.r.t. the input), against the direct f32 MFMA
+kernels at the bench sizes, and against an fp64 convolution: the split path's error must stay at the level of an fp32 chain."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SHAPES = [  # N, C, K, H, W
+    (3, 64, 64, 32, 32), (5, 64, 64, 16, 16), (6, 64, 128, 8, 8), (9, 128, 128, 8, 8), (2, 32, 64, 8, 8),
+    (2, 32, 64, 12, 20), (3, 128, 256, 16, 16), (2, 64, 64, 64, 64), (7, 256, 256, 8, 8), (2, 32, 64, 28, 28),
+    (1, 64, 64, 4, 4), (3, 64, 64, 6, 10), (2, 64, 192, 56, 56),                      # maps smaller / other than the block regions
+    (200, 64, 64, 32, 32), (200, 64, 64, 16, 16), (200, 128, 128, 8, 8), (131, 128, 128, 8, 8), (200, 64, 128, 8, 8),
+    # odd maps (AlexNet's 13 x 13 layers, models/net.py:96-125): tiles past the edge, 4-byte stores, no fused pooling
+    (4, 32, 64, 13, 13), (3, 64, 64, 13, 13), (2, 32, 64, 9, 15), (5, 64, 64, 11, 13), (37, 192, 384, 13, 13),
+]
+
+
+def _rel(a, b):
+    return float((a.double().cpu() - b.double().cpu()).abs().max() / max(float(b.double().abs().max()), 1e-30))
+
+
+def _check_fused_pool(ops, xd, wd, bd, y_ref, N, K, H, W, big):
+    # fused ReLU + 2x2 max-pool: value within rounding; the arg-max code must name an element that attains the maximum
+    yp, idx = ops.conv3x3_bs_fwd(xd, wd, bd, relu=True, pool=True)
+    yc = y_ref.cuda() if not big else y_ref
+    win = yc.reshape(N, K, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(N, K, H // 2, W // 2, 4)
+    assert _rel(yp, win.max(4).values) <= 2e-5
+    assert torch.equal(idx == 4, yp == 0)           # code 4 = no positive maximum after ReLU (csrc/common.hpp)
+    live = idx.long().where(idx < 4, torch.zeros((), dtype=torch.long, device=idx.device))
+    picked = torch.gather(win, 4, live.unsqueeze(-1)).squeeze(-1)
+    assert float((picked - win.max(4).values).abs().max()) <= 2e-5 * float(yc.abs().max())
+    assert int(idx.max()) <= 4
+    ypn, idxn = ops.conv3x3_bs_fwd(xd, wd, bd, relu=False, pool=True)             # without ReLU the codes are plain arg-max bytes
+    assert int(idxn.max()) <= 3
+    # and the codes are the FIRST maximum in ATen's scan order, judged on the kernel's own un-pooled output (bitwise the same sums)
+    z = ops.conv3x3_bs_fwd(xd, wd, bd, relu=False)
+    zw = z.reshape(N, K, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(N, K, H // 2, W // 2, 4)
+    assert torch.equal(idxn.long(), zw.argmax(4)) or float((zw.max(4).values - torch.gather(zw, 4, idxn.long().unsqueeze(-1)).squeeze(-1)).abs().max()) == 0.0
+    assert torch.equal(ypn, zw.max(4).values)
+
+
+@pytest.mark.parametrize("bm", ["0", "128", "256"])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_bs_forward_and_backward_data(shape, bm):
+    """bm: block size forced through CLHIP_BS_BM (read once per process: the forced legs run in a subprocess)."""
+    if bm != "0":
+        if shape[0] >= 100 and shape != (200, 64, 64, 16, 16):
+            pytest.skip("forced block sizes: small shapes + one bench shape")
+        env = dict(os.environ, CLHIP_BS_BM=bm, CLHIP_BS_CHILD="1")
+        code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_bs as T; T._run(%r)"
+                % (ROOT, os.path.join(ROOT, "tests"), (shape,)))
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        return
+    _run((shape,))
+
+
+def _run(shapes):
+    from clsurvey_amd import ops
+    for shape in shapes:
+        N, C, K, H, W = shape
+        gen = np.random.RandomState(N * 7 + C + K + H)
+        x = torch.from_numpy(gen.standard_normal((N, C, H, W)).astype(np.float32))
+        w = torch.from_numpy((gen.standard_normal((K, C, 3, 3)) * (2.0 / (9 * C)) ** 0.5).astype(np.float32))
+        b = torch.from_numpy((gen.standard_normal((K,)) * 0.1).astype(np.float32))
+        xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+        big = N >= 100
+        # judge: torch CPU for the small shapes, the direct f32 MFMA kernels (themselves pinned against torch CPU) for the large ones
+        if big:
+            y_ref, z_ref = ops.conv3x3_fwd(xd, wd, bd, True), ops.conv3x3_fwd(xd, wd, bd, False)
+        else:
+            z_ref = F.conv2d(x, w, b, padding=1)
+            y_ref = F.relu(z_ref)
+        assert _rel(ops.conv3x3_bs_fwd(xd, wd, bd, relu=False), z_ref) <= 2e-5, shape
+        y = ops.conv3x3_bs_fwd(xd, wd, bd, relu=True)
+        assert _rel(y, y_ref) <= 2e-5, shape
+        odd = bool((H | W) & 1)
+        if not odd:
+            _check_fused_pool(ops, xd, wd, bd, y_ref, N, K, H, W, big)
+        if C % 64 or K % 32:
+            continue            # backward-data runs the same kernel with the channel roles swapped: its own shape domain
+        dy = torch.from_numpy(gen.standard_normal((N, K, H, W)).astype(np.float32))
+        msrc = torch.from_numpy(gen.standard_normal((N, C, H, W)).astype(np.float32))
+        dyd, md = dy.cuda(), msrc.cuda()
+        if big:
+            dx_ref = ops.conv3x3_bwd_data(dyd, wd)
+        else:
+            dx_ref = F.conv_transpose2d(dy, w, padding=1)
+        assert _rel(ops.conv3x3_bs_bwd_data(dyd, wd), dx_ref) <= 2e-5, shape
+        dxm = ops.conv3x3_bs_bwd_data(dyd, wd, relu_src=md)
+        assert _rel(dxm, dx_ref.cuda() * (md > 0)) <= 2e-5, shape
+        if odd:
+            continue            # no 2x2 pooling on odd maps
+        dyp = torch.from_numpy(gen.standard_normal((N, K, H // 2, W // 2)).astype(np.float32)).cuda()
+        code = torch.from_numpy(gen.randint(0, 5, size=(N, K, H // 2, W // 2)).astype(np.uint8)).cuda()
+        dy_full = ops.maxpool2_bwd(dyp, code)
+        ref_u = ops.conv3x3_bwd_data(dy_full, wd, md)
+        assert _rel(ops.conv3x3_bs_bwd_data(dyp, wd, relu_src=md, idx=code), ref_u) <= 2e-5, shape
+        # the un-pooling staging feeds the same sums as the plain one: bitwise equal to the kernel on the un-pooled gradient
+        assert torch.equal(ops.conv3x3_bs_bwd_data(dyp, wd, relu_src=md, idx=code), ops.conv3x3_bs_bwd_data(dy_full, wd, relu_src=md))
+
+
+def test_bs_refuses_shapes_outside_its_domain():
+    from clsurvey_amd import ops, _lib
+    with pytest.raises(_lib.ClhipError):           # 3 input channels: not whole 32-channel pairs
+        ops.conv3x3_bs_fwd(torch.zeros(1, 3, 8, 8, device="cuda"), torch.zeros(64, 3, 3, 3, device="cuda"), torch.zeros(64, device="cuda"))
+    with pytest.raises(_lib.ClhipError):           # 32 output channels: not a whole 64-channel group
+        ops.conv3x3_bs_fwd(torch.zeros(1, 32, 8, 8, device="cuda"), torch.zeros(32, 32, 3, 3, device="cuda"), torch.zeros(32, device="cuda"))
+    with pytest.raises(_lib.ClhipError):           # fused pooling on an odd map
+        ops.conv3x3_bs_fwd(torch.zeros(1, 32, 13, 13, device="cuda"), torch.zeros(64, 32, 3, 3, device="cuda"), torch.zeros(64, device="cuda"),
+                           pool=True)
+
+
+@pytest.mark.parametrize("C,K", [(64, 64), (128, 256), (512, 512)])
+def test_bs_error_is_that_of_an_fp32_chain(C, K):
+    """Against an fp64 convolution on the same fp32 inputs, in units of sum|x w| per output (what an fp32 rounding analysis bounds):
+    the split path's error must be at the level of the direct f32 MFMA kernel's and of the Winograd kernel's on the same data (the
+    claim `dtype: f32` rests on this), under 7 units of fp32's 2^-24 = 6e-8 in the maximum over ~10^5 outputs, under 1 unit rms."""
+    from clsurvey_amd import ops
+    N, H, W = 4, 16, 16
+    gen = np.random.RandomState(C + K)
+    x = torch.from_numpy(np.maximum(gen.standard_normal((N, C, H, W)), 0).astype(np.float32))          # a ReLU output
+    w = torch.from_numpy((gen.standard_normal((K, C, 3, 3)) * (2.0 / (9 * C)) ** 0.5).astype(np.float32))
+    b = torch.zeros(K)
+    ref = F.conv2d(x.double(), w.double(), None, padding=1)
+    scale = F.conv2d(x.double().abs(), w.double().abs(), None, padding=1).clamp_min(1e-30)
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+
+    def err(y):
+        e = (y.double().cpu() - ref).abs() / scale
+        return float(e.max()), float((e * e).mean().sqrt())
+    bs, direct, wino = err(ops.conv3x3_bs_fwd(xd, wd, bd, relu=False)), err(ops.conv3x3_fwd(xd, wd, bd, False)), err(ops.conv3x3_wino_fwd(xd, wd, bd, relu=False))
+    print("C=%d K=%d  error / sum|x w| (max, rms): bf16-split %.3e %.3e   direct f32 MFMA %.3e %.3e   Winograd f32 %.3e %.3e"
+          % ((C, K) + bs + direct + wino))
+    assert bs[0] <= 4e-7 and bs[1] <= 5e-8
+    assert bs[1] <= 1.25 * direct[1] and bs[0] <= 2.0 * direct[0]
+    assert bs[1] <= 1.25 * wino[1]
+    # backward-data likewise
+    dy = torch.from_numpy(gen.standard_normal((N, K, H, W)).astype(np.float32))
+    refd = F.conv_transpose2d(dy.double(), w.double(), padding=1)
+    scaled = F.conv_transpose2d(dy.double().abs(), w.double().abs(), padding=1).clamp_min(1e-30)
+    ed = ((ops.conv3x3_bs_bwd_data(dy.cuda(), wd).double().cpu() - refd).abs() / scaled)
+    assert float(ed.max()) <= 4e-7 and float((ed * ed).mean().sqrt()) <= 5e-8
+
+
+def test_bs_weight_image_is_an_exact_split():
+    """The weight image holds three bf16 pieces per weight, lane-ordered as the B operand of v_mfma_f32_32x32x16_bf16:
+    [n tile][16-channel chunk][tap][piece][lane = 32 * (k half) + (out channel & 31)][8 channels].  The pieces must sum to the
+    fp32 weight EXACTLY (in fp64), piece i must be the bf16 rounding of what pieces < i left, and backward-data's image holds
+    w[ci][ko] rotated by 180 degrees."""
+    from clsurvey_amd import _lib, ops
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    C, K = 64, 128
+    g = torch.Generator().manual_seed(3)
+    w = (torch.randn(K, C, 3, 3, generator=g) * 0.1).to(dev)
+    x = torch.randn(1, C, 8, 8, generator=g).to(dev)
+    for mode in (0, 1):
+        ws = torch.zeros(L.clhip_conv3x3_bs_ws(C, K), dtype=torch.uint8, device=dev)
+        if mode == 0:
+            y = torch.empty(1, K, 8, 8, device=dev)
+            assert L.clhip_conv3x3_bs_fwd(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), None, 1, C, K, 8, 8, 0, ws.data_ptr(), ws.numel(), None) == 0
+            Ko, Ci = K, C
+        else:
+            dy = torch.randn(1, K, 8, 8, device=dev)
+            dx = torch.empty(1, C, 8, 8, device=dev)
+            assert L.clhip_conv3x3_bs_bwd_data(dy.data_ptr(), None, w.data_ptr(), None, dx.data_ptr(), 1, C, K, 8, 8, ws.data_ptr(), ws.numel(), None) == 0
+            Ko, Ci = C, K
+        torch.cuda.synchronize()
+        n_nt, n_ch = Ko // 32, Ci // 16
+        img = ws[: n_nt * n_ch * 27 * 1024].view(torch.int16).view(n_nt, n_ch, 9, 3, 2, 32, 8).cpu()      # [nt][chunk][tap][piece][kh][ko & 31][e]
+        pieces = (img.to(torch.int32) << 16).view(torch.float32).double()                                   # bf16 bits -> value
+        # -> [piece][ko][ci][tap]
+        val = pieces.permute(3, 0, 5, 1, 4, 6, 2).reshape(3, Ko, Ci, 9)
+        wc = w.cpu().double()
+        want = wc.reshape(K, C, 9) if mode == 0 else wc.reshape(K, C, 9).flip(2).permute(1, 0, 2)
+        assert torch.equal(val.sum(0), want)
+        assert torch.equal(val[0].float(), want.float().to(torch.bfloat16).float())
+        assert torch.equal(val[1].float(), (want - val[0]).float().to(torch.bfloat16).float())
