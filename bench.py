@@ -154,17 +154,8 @@ BS_ISSUE = 6.0                     # bf16-split direct convolution: six bf16 MFM
 
 def bs_conv_instance(N, H, W, kout, mode, unpool):
     """Instance name of the bf16-split forward (mode 0) / backward-data (mode 1) launch (csrc/bsconv.hip, bs_launch)."""
-    kts = (kout + 63) // 64
-
-    def big(rw, rh, ni):
-        return ((W + rw - 1) // rw) * ((H + rh - 1) // rh) * ((N + ni - 1) // ni) * kts >= 1024
-    if W > 16:
-        geo = "32, 8, 1, 4, 2, 2" if big(32, 8, 1) else "32, 4, 1, 2, 2, 1"
-    elif W > 8:
-        geo = "16, 16, 1, 4, 2, 2" if big(16, 16, 1) else "16, 8, 1, 2, 2, 1"
-    else:
-        geo = "8, 8, 4, 4, 2, 2" if big(8, 8, 4) else "8, 8, 2, 2, 2, 1"
-    return "bs_conv_kernel<BsGeo<%s>, %d, %s> (+ bs_weight_multi_kernel)" % (geo, mode, "true" if unpool else "false")
+    geo = "32, 4, 1, 2, 2, 1" if W > 16 else ("16, 8, 1, 2, 2, 1" if W > 8 else "8, 8, 2, 2, 2, 1")
+    return "bs_conv_kernel<BsGeo<%s>, %d, %s, true> (+ bs_weight_multi_kernel)" % (geo, mode, "true" if unpool else "false")
 
 
 def pipe_seconds(flops, path):

@@ -13,14 +13,18 @@
 // the f32-input MFMA chain (1.2 - 2.1e-7 / 2.7 - 2.9e-8) and as a host fmaf chain.  Six bf16 MFMAs per 16-deep k-step = 2.67x the
 // f32 matrix rate on the DIRECT form (no Winograd transforms: their VALU work was the problem, and their conditioning is gone too).
 //
-// Data flow of one block (256 threads = 4 waves; BM = 128 or 256 output pixels x 64 output channels):
+// Data flow of one block (256 threads = 4 waves as 2 x 2; 128 output pixels x 64 output channels; two blocks per CU):
 //   * per 16-channel chunk the (RH + 2) x (RW + 2) halo tile of the input is loaded NCHW -> registers (dword buffer loads, lanes
-//     along x), split into 3 bf16 pieces and written to LDS as [piece][k half][halo row][pitch P] x 16 bytes (8 channels of one
-//     pixel, the A operand of one lane).  P = 8 mod 16 slots: the 16 lanes of every ds_read_b128 lane group hit 16 different
-//     4-bank groups for every tap (MI355X_MICROARCH.md, LDS table).  Double-buffered, one barrier per chunk; the staging of
-//     chunk c + 1 is issued inside the MFMA stream of chunk c.
-//   * weights: a lane-ordered image [n tile][chunk][tap][piece][lane] x 16 bytes (bs_weight_multi_kernel, once per pass) is read
-//     straight from L2 / L1 with one coalesced 1 KB buffer_load_dwordx4 per operand, one tap ahead.
+//     along x; one chunk ahead), split into 3 bf16 pieces and written to LDS as [piece][k half][halo row][pitch P] x 16 bytes
+//     (8 channels of one pixel, the A operand of one lane).  P = 8 mod 16 slots: the 16 lanes of every ds_read_b128 lane group
+//     hit 16 different 4-bank groups for every tap (MI355X_MICROARCH.md, LDS table).
+//   * weights: a lane-ordered image [n tile][chunk][tap][piece][lane] x 16 bytes (bs_weight_multi_kernel, once per pass); the
+//     block copies the chunk's two 27 KB slices into LDS (coalesced 16-byte loads, one chunk ahead in registers) and every wave
+//     reads its B operands from there.  (First build: every wave read them straight from L2 / L1 — 54 KB per wave and chunk, the
+//     vector-memory path of the CU at 60 % for the weights alone; measured 92 us on layer 2 against a 36 us matrix floor,
+//     profiles/r05_bs_v1_per_layer.txt.)
+//   * single-buffered: barrier, stage chunk c, barrier, 108 MFMAs per wave from LDS only — the co-resident block fills the
+//     matrix pipe while this one stages.
 //   * an MFMA tile is 32 pixels x 32 channels; the 32 pixels are 8 pooling windows x 4 positions (m = 4 w + q) so that the four
 //     accumulator registers r = 4 g + q of a lane are one 2x2 window: ReLU + max-pool + arg-max code are lane-local.
 //   * per (tap, k-step) a wave issues 6 MFMAs per tile pair, small products first: a0 b2, a2 b0, a1 b1, a0 b1, a1 b0, a0 b0.
@@ -99,9 +103,9 @@ __global__ __launch_bounds__(256) void bs_weight_multi_kernel(BsWtJobs J) {
 }
 
 // ---------------------------------------------------------------------------------------------------- the convolution
-// Geometry of a block: NI images x RH rows x RW columns of output pixels (= BM), all 64 output channels of one 64-channel group.
-//   RW = 32: one image, RH = 8 (BM 256) or 4 (BM 128);  RW = 16: RH = 16 / 8;  RW = 8: whole 8-row images, NI = 4 / 2, two images
-//   side by side per LDS row.  M tiles: 2 rows x 16 columns (RW >= 16) or 4 rows x 8 columns.
+// Geometry of a block: NI images x RH rows x RW columns of output pixels (= BM = 128), one 64-channel group of output channels.
+//   RW = 32: one image, RH = 4;  RW = 16: RH = 8;  RW = 8: two whole 8-row images side by side per LDS row.
+//   M tiles: 2 rows x 16 columns (RW >= 16) or 4 rows x 8 columns.  Waves: WAVES_M x WAVES_N, each WM x WN MFMA tiles.
 template <int RW_, int RH_, int NI_, int WAVES_M_, int WM_, int WN_>
 struct BsGeo {
     static constexpr int RW = RW_, RH = RH_, NI = NI_, WAVES_M = WAVES_M_, WAVES_N = 4 / WAVES_M_, WM = WM_, WN = WN_;
@@ -119,21 +123,31 @@ struct BsGeo {
     static constexpr int ROWS = (NI / IPR) * HR;
     static constexpr int PLANE_SLOTS = (ROWS - 1) * P + IPR * HW_;         // (the last row needs no padding)
     static constexpr int PLANE_BYTES = PLANE_SLOTS * 16;
-    static constexpr int BUF_BYTES = 6 * PLANE_BYTES;                      // 3 pieces x 2 k halves
+    static constexpr int A_BYTES = 6 * PLANE_BYTES;                        // 3 pieces x 2 k halves
     static constexpr int NHALO = NI * HR * HW_;
     static constexpr int ITEMS = 2 * NHALO;                                // (halo pixel, k half): 8 channels each
     static constexpr int ROUNDS = (ITEMS + 255) / 256;
     static_assert(ROUNDS * 256 - ITEMS <= ITEMS, "the last round wraps at most once");
+    // weight operands of one 16-channel chunk: [n tile (2)][tap][piece][lane] x 16 bytes — two contiguous 27 KB slices of the image
+    static constexpr int W_SLICE = 27 * 64;                                // 16-byte items per n tile
+    static constexpr int W_ITEMS = (BS_BN / 32) * W_SLICE;
+    static constexpr int W_BYTES = W_ITEMS * 16;
+    static constexpr int W_ROUNDS = (W_ITEMS + 255) / 256;
+    static_assert(W_ROUNDS * 256 - W_ITEMS <= W_ITEMS, "wrap once");
+    static constexpr int LDS_BYTES = A_BYTES + W_BYTES;
 };
 
-template <class G, int MODE, bool UNPOOL>
-__global__ __launch_bounds__(256, (2 * G::BUF_BYTES <= 80 * 1024) ? 2 : 1) void bs_conv_kernel(
+// SEP: the product of the leading pieces a0 b0 and the five small products are summed in accumulators of their own (added once, in
+// the epilogue): measured 3x less error than one accumulator, i.e. 3x less than an fp32 fmaf chain (profiles/r05_bf16_split_dot.txt)
+template <class G, int MODE, bool UNPOOL, bool SEP>
+__global__ __launch_bounds__(256, (2 * G::LDS_BYTES <= 160 * 1024) ? 2 : 1) void bs_conv_kernel(
     const float* __restrict__ in, const clhip_u32x4* __restrict__ wimg, const float* __restrict__ bias,
     const float* __restrict__ mask_src, float* __restrict__ out, uint8_t* __restrict__ pool_idx, int N, int Cin, int Cout, int H,
     int W, int relu, int tiles_x, int tiles_y, int npb) {
     constexpr int RW = G::RW, RH = G::RH, NI = G::NI, WM = G::WM, WN = G::WN, P = G::P, HR = G::HR, HW_ = G::HW_;
-    constexpr int ROUNDS = G::ROUNDS;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * G::BUF_BYTES];
+    constexpr int ROUNDS = G::ROUNDS, W_ROUNDS = G::W_ROUNDS;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[G::LDS_BYTES];
+    unsigned char* const lds_w = lds + G::A_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kts = (Cout + BS_BN - 1) / BS_BN;
@@ -171,8 +185,19 @@ __global__ __launch_bounds__(256, (2 * G::BUF_BYTES <= 80 * 1024) ? 2 : 1) void 
         pos[r] = ((gy & 1) << 1) | (gx & 1);
         lw[r] = (h * G::PLANE_SLOTS + ((ni / G::IPR) * HR + hy) * P + (ni % G::IPR) * HW_ + hx) * 16;
     }
+    // ... and of the weight slice: 16-byte item i of the block's two n tiles -> image offset (chunk 0), LDS offset
+    int woff[W_ROUNDS], wlds[W_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < W_ROUNDS; ++r) {
+        const int i_ = r * 256 + tid, i = i_ < G::W_ITEMS ? i_ : i_ - G::W_ITEMS;
+        const int ntl = i / G::W_SLICE, rem = i - ntl * G::W_SLICE;
+        const int nt = kt * (BS_BN / 32) + ntl;
+        woff[r] = nt < n_nt ? (nt * n_chunks * G::W_SLICE + rem) * 16 : CLHIP_OOB;
+        wlds[r] = i * 16;
+    }
     float xr[ROUNDS][8];
     unsigned xi[UNPOOL ? ROUNDS : 1][8];
+    clhip_u32x4 wr[W_ROUNDS];
     auto load_chunk = [&](int c) {
         const int cb = c * BS_CK * plane_in;
 #pragma unroll
@@ -183,8 +208,12 @@ __global__ __launch_bounds__(256, (2 * G::BUF_BYTES <= 80 * 1024) ? 2 : 1) void 
                 xr[r][e] = clhip_buf_load(rs_x, xoff[r] != CLHIP_OOB ? xoff[r] * 4 : CLHIP_OOB, so * 4);
                 if constexpr (UNPOOL) xi[r][e] = clhip_buf_load_u8(rs_i, xoff[r], so);
             }
+#pragma unroll
+        for (int r = 0; r < W_ROUNDS; ++r) wr[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff[r], c * G::W_SLICE * 16, 0);
     };
-    auto store_chunk = [&](int buf) {
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int r = 0; r < W_ROUNDS; ++r) *reinterpret_cast<clhip_u32x4*>(lds_w + wlds[r]) = wr[r];
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
             float v[8];
@@ -195,7 +224,7 @@ __global__ __launch_bounds__(256, (2 * G::BUF_BYTES <= 80 * 1024) ? 2 : 1) void 
             }
             clhip_u32x4 q0, q1, q2;
             bs_split8(v, q0, q1, q2);
-            unsigned char* d = lds + buf * G::BUF_BYTES + lw[r];
+            unsigned char* d = lds + lw[r];
             *reinterpret_cast<clhip_u32x4*>(d) = q0;
             *reinterpret_cast<clhip_u32x4*>(d + 2 * G::PLANE_BYTES) = q1;
             *reinterpret_cast<clhip_u32x4*>(d + 4 * G::PLANE_BYTES) = q2;
@@ -214,69 +243,62 @@ __global__ __launch_bounds__(256, (2 * G::BUF_BYTES <= 80 * 1024) ? 2 : 1) void 
         const int ni = mt / G::MT_PER_IMG, rem = mt - ni * G::MT_PER_IMG, tr = rem / G::MT_PER_ROW, tc = rem - tr * G::MT_PER_ROW;
         abase[i] = (kh * G::PLANE_SLOTS + ((ni / G::IPR) * HR + tr * G::MTH + prow) * P + (ni % G::IPR) * HW_ + tc * G::MTW + pcol) * 16;
     }
-    const int nt0 = kt * (BS_BN / 32) + wn * WN;
-    int wvoff[WN];
-#pragma unroll
-    for (int j = 0; j < WN; ++j) wvoff[j] = (nt0 + j < n_nt) ? ((nt0 + j) * n_chunks * 27 * 64 + lane) * 16 : CLHIP_OOB;
-    auto load_b = [&](clhip_u32x4 (&bq)[WN][3], int c, int tap) {
-        const int so = (c * 27 + tap * 3) * 1024;
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-#pragma unroll
-            for (int s = 0; s < 3; ++s) bq[j][s] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wvoff[j], so + s * 1024, 0);
-    };
+    const int nt0 = kt * (BS_BN / 32) + wn * WN;                                       // first n tile of this wave (global)
+    const unsigned char* const bbase = lds_w + (wn * WN * G::W_SLICE + lane) * 16;     // its operands in the staged slice
 
-    floatx16 acc[WM][WN];
+    floatx16 acc[WM][WN], accl[SEP ? WM : 1][SEP ? WN : 1];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < WN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                acc[i][j][r] = 0.f;
+                if constexpr (SEP) accl[i][j][r] = 0.f;
+            }
 
-    // ---- prologue: chunk 0 in LDS, chunk 1 in flight, first weight operands in flight
-    clhip_u32x4 bcur[WN][3];
     load_chunk(0);
-    load_b(bcur, 0, 0);
-    store_chunk(0);
-    load_chunk(n_chunks > 1 ? 1 : 0);
-    __syncthreads();
-
     for (int c = 0; c < n_chunks; ++c) {
-        const unsigned char* lb = lds + (c & 1) * G::BUF_BYTES;
+        // (registers hold chunk c) everybody has finished reading chunk c - 1: its LDS image is replaced, the loads of chunk c + 1
+        // go out and land during the matrix phase below; the sibling block of this CU computes while this one stages
+        if (c > 0) __syncthreads();
+        store_chunk();
+        load_chunk(c + 1 < n_chunks ? c + 1 : c);
+        __syncthreads();
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dr = tap / 3, ds = tap - dr * 3;
-            // next tap's weight operands (the first tap of the next chunk after the last one; past the end: any valid address)
-            clhip_u32x4 bnext[WN][3];
-            if (tap < 8) load_b(bnext, c, tap + 1);
-            else load_b(bnext, c + 1 < n_chunks ? c + 1 : c, 0);
-            clhip_u32x4 a[WM][3];
+            clhip_u32x4 a[WM][3], bq[WN][3];
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int s = 0; s < 3; ++s)
-                    a[i][s] = *reinterpret_cast<const clhip_u32x4*>(lb + abase[i] + (dr * P + ds) * 16 + s * 2 * G::PLANE_BYTES);
-            if (tap == 3) {
-                // staging of the next chunk inside this chunk's matrix stream, unconditionally (one basic block per chunk: the
-                // scheduler may place these VALU / LDS / load instructions between the MFMAs): after the last chunk the spare
-                // buffer takes a second copy of it, which nobody reads
-                store_chunk((c + 1) & 1);
-                load_chunk(c + 2 < n_chunks ? c + 2 : n_chunks - 1);
-            }
-            // six products per tile pair, small ones first; consecutive MFMAs go to different accumulators
-#define BS_TERM(PA, PB)                                                                                                           \
-            _Pragma("unroll") for (int i = 0; i < WM; ++i) _Pragma("unroll") for (int j = 0; j < WN; ++j)                         \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bs_bf16x8, a[i][PA]),                      \
-                                                                   __builtin_bit_cast(bs_bf16x8, bcur[j][PB]), acc[i][j], 0, 0, 0);
-            BS_TERM(0, 2) BS_TERM(2, 0) BS_TERM(1, 1) BS_TERM(0, 1) BS_TERM(1, 0) BS_TERM(0, 0)
-#undef BS_TERM
+                    a[i][s] = *reinterpret_cast<const clhip_u32x4*>(lds + abase[i] + (dr * P + ds) * 16 + s * 2 * G::PLANE_BYTES);
 #pragma unroll
             for (int j = 0; j < WN; ++j)
 #pragma unroll
-                for (int s = 0; s < 3; ++s) bcur[j][s] = bnext[j][s];
+                for (int s = 0; s < 3; ++s)
+                    bq[j][s] = *reinterpret_cast<const clhip_u32x4*>(bbase + ((j * 9 + tap) * 3 + s) * 1024);
+            // six products per tile pair, small ones first; consecutive MFMAs go to different accumulators
+#define BS_TERM(ACC, PA, PB)                                                                                                      \
+            _Pragma("unroll") for (int i = 0; i < WM; ++i) _Pragma("unroll") for (int j = 0; j < WN; ++j)                         \
+                ACC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bs_bf16x8, a[i][PA]),                      \
+                                                                   __builtin_bit_cast(bs_bf16x8, bq[j][PB]), ACC[i][j], 0, 0, 0);
+            if constexpr (SEP) {
+                BS_TERM(accl, 0, 2) BS_TERM(acc, 0, 0) BS_TERM(accl, 2, 0) BS_TERM(accl, 1, 1) BS_TERM(accl, 0, 1) BS_TERM(accl, 1, 0)
+            } else {
+                BS_TERM(acc, 0, 2) BS_TERM(acc, 2, 0) BS_TERM(acc, 1, 1) BS_TERM(acc, 0, 1) BS_TERM(acc, 1, 0) BS_TERM(acc, 0, 0)
+            }
+#undef BS_TERM
         }
-        __syncthreads();
+    }
+    if constexpr (SEP) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += accl[i][j][r];
     }
 
     // ---- epilogue: acc[i][j][4 g + q] = (pixel = window 2 g + kh of M tile i, position q; channel 32 (nt0 + j) + (lane & 31))
@@ -346,7 +368,7 @@ __global__ __launch_bounds__(256, (2 * G::BUF_BYTES <= 80 * 1024) ? 2 : 1) void 
 }
 
 // CLHIP_BS=0: the layers this path would take stay on the Winograd / direct f32 kernels (A/B measurements, the parity suite's
-// second leg).  CLHIP_BS_BM=128 / 256 forces the block size (default: by the number of blocks the launch would have).
+// second leg).  CLHIP_BS_SEP=0: one accumulator for all six products (error of an fp32 chain instead of a third of it).
 static int bs_env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return e && e[0] ? atoi(e) : dflt;
@@ -359,13 +381,18 @@ static bool bs_on() {
 template <class G, int MODE, bool UNPOOL>
 int bs_launch_geo(const float* in, const clhip_u32x4* wimg, const float* bias, const float* mask_src, float* out, uint8_t* pool_idx,
                   int N, int Cin, int Cout, int H, int W, int relu, hipStream_t s) {
+    static const bool sep = bs_env_int("CLHIP_BS_SEP", 1) != 0;
     const int tiles_x = (W + G::RW - 1) / G::RW, tiles_y = (H + G::RH - 1) / G::RH, groups = (N + G::NI - 1) / G::NI;
     const long long npb = (long long)tiles_x * tiles_y * groups;
     const int kts = (Cout + BS_BN - 1) / BS_BN;
     const long long blocks = (npb + 7) / 8 * 8 * kts;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return CLHIP_EINVAL;
-    hipLaunchKernelGGL((bs_conv_kernel<G, MODE, UNPOOL>), dim3((unsigned)blocks), dim3(256), 0, s, in, wimg, bias, mask_src, out,
-                       pool_idx, N, Cin, Cout, H, W, relu, tiles_x, tiles_y, (int)npb);
+    if (sep)
+        hipLaunchKernelGGL((bs_conv_kernel<G, MODE, UNPOOL, true>), dim3((unsigned)blocks), dim3(256), 0, s, in, wimg, bias, mask_src,
+                           out, pool_idx, N, Cin, Cout, H, W, relu, tiles_x, tiles_y, (int)npb);
+    else
+        hipLaunchKernelGGL((bs_conv_kernel<G, MODE, UNPOOL, false>), dim3((unsigned)blocks), dim3(256), 0, s, in, wimg, bias, mask_src,
+                           out, pool_idx, N, Cin, Cout, H, W, relu, tiles_x, tiles_y, (int)npb);
     CLHIP_LAUNCH_CHECK();
     return 0;
 }
@@ -373,24 +400,9 @@ int bs_launch_geo(const float* in, const clhip_u32x4* wimg, const float* bias, c
 template <int MODE, bool UNPOOL>
 int bs_launch(const float* in, const clhip_u32x4* wimg, const float* bias, const float* mask_src, float* out, uint8_t* pool_idx,
               int N, int Cin, int Cout, int H, int W, int relu, hipStream_t s) {
-    static const int force_bm = bs_env_int("CLHIP_BS_BM", 0);
-    const int kts = (Cout + BS_BN - 1) / BS_BN;
-    // 256-pixel blocks (64 x 64 wave tiles: half the operand fetches per MFMA) when they still give every CU >= 4 blocks
-    auto big = [&](int rw, int rh, int ni) {
-        if (force_bm) return force_bm == 256;
-        const long long nb = (long long)((W + rw - 1) / rw) * ((H + rh - 1) / rh) * ((N + ni - 1) / ni) * kts;
-        return nb >= 1024;
-    };
 #define BS_GO(...) return bs_launch_geo<BsGeo<__VA_ARGS__>, MODE, UNPOOL>(in, wimg, bias, mask_src, out, pool_idx, N, Cin, Cout, H, W, relu, s)
-    if (W > 16) {
-        if (big(32, 8, 1)) BS_GO(32, 8, 1, 4, 2, 2);
-        BS_GO(32, 4, 1, 2, 2, 1);
-    }
-    if (W > 8) {
-        if (big(16, 16, 1)) BS_GO(16, 16, 1, 4, 2, 2);
-        BS_GO(16, 8, 1, 2, 2, 1);
-    }
-    if (big(8, 8, 4)) BS_GO(8, 8, 4, 4, 2, 2);
+    if (W > 16) BS_GO(32, 4, 1, 2, 2, 1);
+    if (W > 8) BS_GO(16, 8, 1, 2, 2, 1);
     BS_GO(8, 8, 2, 2, 2, 1);
 #undef BS_GO
 }

@@ -47,20 +47,20 @@ def _check_fused_pool(ops, xd, wd, bd, y_ref, N, K, H, W, big):
     assert torch.equal(ypn, zw.max(4).values)
 
 
-@pytest.mark.parametrize("bm", ["0", "128", "256"])
 @pytest.mark.parametrize("shape", SHAPES)
-def test_bs_forward_and_backward_data(shape, bm):
-    """bm: block size forced through CLHIP_BS_BM (read once per process: the forced legs run in a subprocess)."""
-    if bm != "0":
-        if shape[0] >= 100 and shape != (200, 64, 64, 16, 16):
-            pytest.skip("forced block sizes: small shapes + one bench shape")
-        env = dict(os.environ, CLHIP_BS_BM=bm, CLHIP_BS_CHILD="1")
-        code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_bs as T; T._run(%r)"
-                % (ROOT, os.path.join(ROOT, "tests"), (shape,)))
-        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-        return
+def test_bs_forward_and_backward_data(shape):
     _run((shape,))
+
+
+def test_bs_single_accumulator_leg():
+    """CLHIP_BS_SEP=0 (all six products in one accumulator; read once per process, so this leg runs in a subprocess): the same
+    checks on the small shapes and one bench shape."""
+    shapes = tuple(sh for sh in SHAPES if sh[0] < 100) + ((200, 64, 64, 16, 16),)
+    env = dict(os.environ, CLHIP_BS_SEP="0")
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_bs as T; T._run(%r)"
+            % (ROOT, os.path.join(ROOT, "tests"), shapes))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
 
 
 def _run(shapes):
@@ -122,8 +122,8 @@ def test_bs_refuses_shapes_outside_its_domain():
 @pytest.mark.parametrize("C,K", [(64, 64), (128, 256), (512, 512)])
 def test_bs_error_is_that_of_an_fp32_chain(C, K):
     """Against an fp64 convolution on the same fp32 inputs, in units of sum|x w| per output (what an fp32 rounding analysis bounds):
-    the split path's error must be at the level of the direct f32 MFMA kernel's and of the Winograd kernel's on the same data (the
-    claim `dtype: f32` rests on this), under 7 units of fp32's 2^-24 = 6e-8 in the maximum over ~10^5 outputs, under 1 unit rms."""
+    the split path's error must not exceed the direct f32 MFMA kernel's nor the Winograd kernel's on the same data (the claim
+    `dtype: f32` rests on this), under 4 units of fp32's 2^-24 = 6e-8 in the maximum over ~10^5 outputs, under half a unit rms."""
     from clsurvey_amd import ops
     N, H, W = 4, 16, 16
     gen = np.random.RandomState(C + K)
@@ -140,15 +140,17 @@ def test_bs_error_is_that_of_an_fp32_chain(C, K):
     bs, direct, wino = err(ops.conv3x3_bs_fwd(xd, wd, bd, relu=False)), err(ops.conv3x3_fwd(xd, wd, bd, False)), err(ops.conv3x3_wino_fwd(xd, wd, bd, relu=False))
     print("C=%d K=%d  error / sum|x w| (max, rms): bf16-split %.3e %.3e   direct f32 MFMA %.3e %.3e   Winograd f32 %.3e %.3e"
           % ((C, K) + bs + direct + wino))
-    assert bs[0] <= 4e-7 and bs[1] <= 5e-8
-    assert bs[1] <= 1.25 * direct[1] and bs[0] <= 2.0 * direct[0]
-    assert bs[1] <= 1.25 * wino[1]
+    # (the leading product a0 b0 and the five small products are summed in accumulators of their own: measured a third of an fp32
+    # chain's error, profiles/r05_bf16_split_dot.txt)
+    assert bs[0] <= 2.5e-7 and bs[1] <= 2.5e-8
+    assert bs[1] <= direct[1] and bs[0] <= 1.25 * direct[0]
+    assert bs[1] <= wino[1]
     # backward-data likewise
     dy = torch.from_numpy(gen.standard_normal((N, K, H, W)).astype(np.float32))
     refd = F.conv_transpose2d(dy.double(), w.double(), padding=1)
     scaled = F.conv_transpose2d(dy.double().abs(), w.double().abs(), padding=1).clamp_min(1e-30)
     ed = ((ops.conv3x3_bs_bwd_data(dy.cuda(), wd).double().cpu() - refd).abs() / scaled)
-    assert float(ed.max()) <= 4e-7 and float((ed * ed).mean().sqrt()) <= 5e-8
+    assert float(ed.max()) <= 2.5e-7 and float((ed * ed).mean().sqrt()) <= 2.5e-8
 
 
 def test_bs_weight_image_is_an_exact_split():
