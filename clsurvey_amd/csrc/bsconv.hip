@@ -33,6 +33,12 @@
 #include "common.hpp"
 #include <cstdlib>
 
+// Timing-only ablations (tools/experiments; results wrong by design; the product is built with 0): 1 no MFMAs, 2 no LDS operand
+// reads, 4 no split / LDS writes, 8 no global loads, 16 no output stores, 32 no barriers, 64 per-lane (scattered) output stores
+#ifndef BS_ABL
+#define BS_ABL 0
+#endif
+
 namespace {
 
 typedef __bf16 bs_bf16x8 __attribute__((ext_vector_type(8)));
@@ -41,6 +47,14 @@ typedef float bs_f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int BS_BN = 64;            // output channels per block
 constexpr int BS_CK = 16;            // input channels per k-step (K of v_mfma_f32_32x32x16_bf16)
+
+// Workgroup barrier of the producer / consumer split: the two roles are whole waves and every wave executes the same NUMBER of these
+// (S_BARRIER counts arriving waves); LDS writes before it are visible after it (release / acquire fences at workgroup scope).
+__device__ __forceinline__ void bs_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 
 // two floats -> two bf16 (round to nearest even), `lo` in bits 0..15: v_cvt_pk_bf16_f32
 __device__ __forceinline__ unsigned bs_pk(float lo, float hi) {
@@ -135,21 +149,35 @@ struct BsGeo {
     static constexpr int W_ROUNDS = (W_ITEMS + 255) / 256;
     static_assert(W_ROUNDS * 256 - W_ITEMS <= W_ITEMS, "wrap once");
     static constexpr int LDS_BYTES = A_BYTES + W_BYTES;
+    // output region of one consumer wave (its WM M tiles): RGH rows x RGW columns of one image, 64 pixels
+    static constexpr bool SIDE_BY_SIDE = MT_PER_ROW >= WM;                 // the wave's M tiles sit next to each other (else: below)
+    static constexpr int RGW = SIDE_BY_SIDE ? WM * MTW : MTW, RGH = 32 * WM / RGW;
+    static_assert(MT_PER_IMG % WM == 0 && (SIDE_BY_SIDE ? MT_PER_ROW % WM == 0 : MT_PER_ROW == 1), "a wave's tiles form a rectangle");
+    static constexpr int TS = 32 * WM + 4;                                 // floats per channel in the transposition buffer (16-byte rows)
+    static_assert(4 * 32 * TS * 4 + 4 * 32 * 16 * WM <= 2 * LDS_BYTES, "transposition buffers fit the staging LDS");
 };
 
 // SEP: the product of the leading pieces a0 b0 and the five small products are summed in accumulators of their own (added once, in
 // the epilogue): measured 3x less error than one accumulator, i.e. 3x less than an fp32 fmaf chain (profiles/r05_bf16_split_dot.txt)
+//
+// 512 threads: waves 0-3 multiply (consumers, 2 x 2, each 64 pixels x 32 channels), waves 4-7 stage (producers) — one of each per SIMD,
+// so the split / LDS-write / load instructions of chunk c + 1 issue beside the MFMAs of chunk c by construction (bf16 MFMAs co-issue
+// with another wave's VALU, profiles/r05_bf16_split_dot.txt; two co-resident blocks that stage and multiply in turn ran in
+// lockstep and overlapped nothing: matrix 41 us + staging 40 us + stores 24 us = the 102 us measured, profiles/r05_bs_v2_ablations.txt).
+// LDS: activations and weights double-buffered (2 x 22.5 KB + 2 x 54 KB = 153 KB: one block per CU), ONE barrier per chunk.
 template <class G, int MODE, bool UNPOOL, bool SEP>
-__global__ __launch_bounds__(256, (2 * G::LDS_BYTES <= 160 * 1024) ? 2 : 1) void bs_conv_kernel(
+__global__ __launch_bounds__(512, 1) void bs_conv_kernel(
     const float* __restrict__ in, const clhip_u32x4* __restrict__ wimg, const float* __restrict__ bias,
     const float* __restrict__ mask_src, float* __restrict__ out, uint8_t* __restrict__ pool_idx, int N, int Cin, int Cout, int H,
     int W, int relu, int tiles_x, int tiles_y, int npb) {
     constexpr int RW = G::RW, RH = G::RH, NI = G::NI, WM = G::WM, WN = G::WN, P = G::P, HR = G::HR, HW_ = G::HW_;
     constexpr int ROUNDS = G::ROUNDS, W_ROUNDS = G::W_ROUNDS;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[G::LDS_BYTES];
-    unsigned char* const lds_w = lds + G::A_BYTES;
+    constexpr int BUF = G::LDS_BYTES;                                       // one (activations, weights) buffer
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool producer = wave >= 4;
+    const int tid = threadIdx.x & 255;                                      // index inside the role's four waves
     const int kts = (Cout + BS_BN - 1) / BS_BN;
     // blocks of one pixel tile (all channel groups) follow each other on ONE XCD (block b runs on XCD b % 8): its input tile is read
     // from HBM once per XCD L2
@@ -161,90 +189,13 @@ __global__ __launch_bounds__(256, (2 * G::LDS_BYTES <= 160 * 1024) ? 2 : 1) void
     const int n_chunks = Cin / BS_CK;
     const int IH = UNPOOL ? H >> 1 : H, IW = UNPOOL ? W >> 1 : W;          // the input tensor's own plane
     const int plane_in = IH * IW;
-
-    const float* in_blk = in + (size_t)n0 * Cin * plane_in;
-    const __amdgpu_buffer_rsrc_t rs_x = clhip_rsrc(in_blk, (size_t)(N - n0) * Cin * plane_in * sizeof(float));
-    const __amdgpu_buffer_rsrc_t rs_i = clhip_rsrc(UNPOOL ? pool_idx + (size_t)n0 * Cin * plane_in : pool_idx,
-                                                   UNPOOL ? (size_t)(N - n0) * Cin * plane_in : 0);
     const int n_nt = (Cout + 31) / 32;
-    const __amdgpu_buffer_rsrc_t rs_w = clhip_rsrc(wimg, (size_t)n_nt * n_chunks * 27 * 1024);
 
-    // ---- staging items of this thread: (halo pixel, k half) -> element offset of channel 8 h of the chunk, LDS slot
-    int xoff[ROUNDS], lw[ROUNDS], pos[ROUNDS];
-#pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
-        // (the last round wraps around: its spare threads stage the first items a second time — same data to the same slots —
-        // so that no load / LDS write of the loop sits under a branch)
-        const int it_ = r * 256 + tid, it = it_ < G::ITEMS ? it_ : it_ - G::ITEMS;
-        const int h = it >= G::NHALO ? 1 : 0, p = it - h * G::NHALO;
-        const int ni = p / (HR * HW_), rem = p - ni * (HR * HW_), hy = rem / HW_, hx = rem - hy * HW_;
-        const int gy = y0 + hy - 1, gx = x0 + hx - 1, n = n0 + ni;
-        const bool ok = n < N && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        const int e = UNPOOL ? (gy >> 1) * IW + (gx >> 1) : gy * IW + gx;
-        xoff[r] = ok ? (ni * Cin + 8 * h) * plane_in + e : CLHIP_OOB;
-        pos[r] = ((gy & 1) << 1) | (gx & 1);
-        lw[r] = (h * G::PLANE_SLOTS + ((ni / G::IPR) * HR + hy) * P + (ni % G::IPR) * HW_ + hx) * 16;
-    }
-    // ... and of the weight slice: 16-byte item i of the block's two n tiles -> image offset (chunk 0), LDS offset
-    int woff[W_ROUNDS], wlds[W_ROUNDS];
-#pragma unroll
-    for (int r = 0; r < W_ROUNDS; ++r) {
-        const int i_ = r * 256 + tid, i = i_ < G::W_ITEMS ? i_ : i_ - G::W_ITEMS;
-        const int ntl = i / G::W_SLICE, rem = i - ntl * G::W_SLICE;
-        const int nt = kt * (BS_BN / 32) + ntl;
-        woff[r] = nt < n_nt ? (nt * n_chunks * G::W_SLICE + rem) * 16 : CLHIP_OOB;
-        wlds[r] = i * 16;
-    }
-    float xr[ROUNDS][8];
-    unsigned xi[UNPOOL ? ROUNDS : 1][8];
-    clhip_u32x4 wr[W_ROUNDS];
-    auto load_chunk = [&](int c) {
-        const int cb = c * BS_CK * plane_in;
-#pragma unroll
-        for (int r = 0; r < ROUNDS; ++r)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int so = cb + e * plane_in;
-                xr[r][e] = clhip_buf_load(rs_x, xoff[r] != CLHIP_OOB ? xoff[r] * 4 : CLHIP_OOB, so * 4);
-                if constexpr (UNPOOL) xi[r][e] = clhip_buf_load_u8(rs_i, xoff[r], so);
-            }
-#pragma unroll
-        for (int r = 0; r < W_ROUNDS; ++r) wr[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff[r], c * G::W_SLICE * 16, 0);
-    };
-    auto store_chunk = [&]() {
-#pragma unroll
-        for (int r = 0; r < W_ROUNDS; ++r) *reinterpret_cast<clhip_u32x4*>(lds_w + wlds[r]) = wr[r];
-#pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) {
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                if constexpr (UNPOOL) v[e] = xi[r][e] == (unsigned)pos[r] ? xr[r][e] : 0.f;     // max_pool2d backward (+ ReLU: dead code 4)
-                else v[e] = xr[r][e];
-            }
-            clhip_u32x4 q0, q1, q2;
-            bs_split8(v, q0, q1, q2);
-            unsigned char* d = lds + lw[r];
-            *reinterpret_cast<clhip_u32x4*>(d) = q0;
-            *reinterpret_cast<clhip_u32x4*>(d + 2 * G::PLANE_BYTES) = q1;
-            *reinterpret_cast<clhip_u32x4*>(d + 4 * G::PLANE_BYTES) = q2;
-        }
-    };
-
-    // ---- this wave's M tiles / N tiles
-    const int wm = wave % G::WAVES_M, wn = wave / G::WAVES_M;
+    // ---- this (consumer) wave's M tiles / N tiles
+    const int cw = wave & 3;
+    const int wm = cw % G::WAVES_M, wn = cw / G::WAVES_M;
     const int m = lane & 31, kh = lane >> 5;
-    const int mw = m >> 2, mq = m & 3;
-    const int prow = 2 * (mw / (G::MTW / 2)) + (mq >> 1), pcol = 2 * (mw % (G::MTW / 2)) + (mq & 1);     // pixel of lane m inside its M tile
-    int abase[WM];
-#pragma unroll
-    for (int i = 0; i < WM; ++i) {
-        const int mt = wm * WM + i;
-        const int ni = mt / G::MT_PER_IMG, rem = mt - ni * G::MT_PER_IMG, tr = rem / G::MT_PER_ROW, tc = rem - tr * G::MT_PER_ROW;
-        abase[i] = (kh * G::PLANE_SLOTS + ((ni / G::IPR) * HR + tr * G::MTH + prow) * P + (ni % G::IPR) * HW_ + tc * G::MTW + pcol) * 16;
-    }
-    const int nt0 = kt * (BS_BN / 32) + wn * WN;                                       // first n tile of this wave (global)
-    const unsigned char* const bbase = lds_w + (wn * WN * G::W_SLICE + lane) * 16;     // its operands in the staged slice
+    const int nt0 = kt * (BS_BN / 32) + wn * WN;                            // first n tile of this wave (global)
 
     floatx16 acc[WM][WN], accl[SEP ? WM : 1][SEP ? WN : 1];
 #pragma unroll
@@ -257,14 +208,125 @@ __global__ __launch_bounds__(256, (2 * G::LDS_BYTES <= 160 * 1024) ? 2 : 1) void
                 if constexpr (SEP) accl[i][j][r] = 0.f;
             }
 
-    load_chunk(0);
+    if (producer) {
+        // =========================================================================================== producer waves
+        const float* in_blk = in + (size_t)n0 * Cin * plane_in;
+        const __amdgpu_buffer_rsrc_t rs_x = clhip_rsrc(in_blk, (size_t)(N - n0) * Cin * plane_in * sizeof(float));
+        const __amdgpu_buffer_rsrc_t rs_i = clhip_rsrc(UNPOOL ? pool_idx + (size_t)n0 * Cin * plane_in : pool_idx,
+                                                       UNPOOL ? (size_t)(N - n0) * Cin * plane_in : 0);
+        const __amdgpu_buffer_rsrc_t rs_w = clhip_rsrc(wimg, (size_t)n_nt * n_chunks * 27 * 1024);
+        // staging items of this thread: (halo pixel, k half) -> element offset of channel 8 h of the chunk, LDS slot
+        int xoff[ROUNDS], lw[ROUNDS], pos[ROUNDS];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            // (the last round wraps around: its spare threads stage the first items a second time — same data to the same slots —
+            // so that no load / LDS write of the loop sits under a branch)
+            const int it_ = r * 256 + tid, it = it_ < G::ITEMS ? it_ : it_ - G::ITEMS;
+            const int h = it >= G::NHALO ? 1 : 0, p = it - h * G::NHALO;
+            const int ni = p / (HR * HW_), rem = p - ni * (HR * HW_), hy = rem / HW_, hx = rem - hy * HW_;
+            const int gy = y0 + hy - 1, gx = x0 + hx - 1, n = n0 + ni;
+            const bool ok = n < N && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const int e = UNPOOL ? (gy >> 1) * IW + (gx >> 1) : gy * IW + gx;
+            xoff[r] = ok ? (ni * Cin + 8 * h) * plane_in + e : CLHIP_OOB;
+            pos[r] = ((gy & 1) << 1) | (gx & 1);
+            lw[r] = (h * G::PLANE_SLOTS + ((ni / G::IPR) * HR + hy) * P + (ni % G::IPR) * HW_ + hx) * 16;
+        }
+        // ... and of the weight slice: 16-byte item i of the block's two n tiles -> image offset (chunk 0), LDS offset
+        int woff[W_ROUNDS], wlds[W_ROUNDS];
+#pragma unroll
+        for (int r = 0; r < W_ROUNDS; ++r) {
+            const int i_ = r * 256 + tid, i = i_ < G::W_ITEMS ? i_ : i_ - G::W_ITEMS;
+            const int ntl = i / G::W_SLICE, rem = i - ntl * G::W_SLICE;
+            const int nt = kt * (BS_BN / 32) + ntl;
+            woff[r] = nt < n_nt ? (nt * n_chunks * G::W_SLICE + rem) * 16 : CLHIP_OOB;
+            wlds[r] = G::A_BYTES + i * 16;
+        }
+        float xr[ROUNDS][8];
+        unsigned xi[UNPOOL ? ROUNDS : 1][8];
+        clhip_u32x4 wr[W_ROUNDS];
+        auto load_chunk = [&](int c) {
+            if (BS_ABL & 8) return;
+            const int cb = c * BS_CK * plane_in;
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int so = cb + e * plane_in;
+                    xr[r][e] = clhip_buf_load(rs_x, xoff[r] != CLHIP_OOB ? xoff[r] * 4 : CLHIP_OOB, so * 4);
+                    if constexpr (UNPOOL) xi[r][e] = clhip_buf_load_u8(rs_i, xoff[r], so);
+                }
+#pragma unroll
+            for (int r = 0; r < W_ROUNDS; ++r) wr[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff[r], c * G::W_SLICE * 16, 0);
+        };
+        auto store_chunk = [&](int buf) {
+            if (BS_ABL & 4) return;
+            unsigned char* const lb = lds + buf * BUF;
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if constexpr (UNPOOL) v[e] = xi[r][e] == (unsigned)pos[r] ? xr[r][e] : 0.f;     // max_pool2d backward (+ ReLU: dead code 4)
+                    else v[e] = xr[r][e];
+                }
+                clhip_u32x4 q0, q1, q2;
+                bs_split8(v, q0, q1, q2);
+                unsigned char* d = lb + lw[r];
+                *reinterpret_cast<clhip_u32x4*>(d) = q0;
+                *reinterpret_cast<clhip_u32x4*>(d + 2 * G::PLANE_BYTES) = q1;
+                *reinterpret_cast<clhip_u32x4*>(d + 4 * G::PLANE_BYTES) = q2;
+            }
+#pragma unroll
+            for (int r = 0; r < W_ROUNDS; ++r) *reinterpret_cast<clhip_u32x4*>(lb + wlds[r]) = wr[r];
+        };
+        if (BS_ABL & 8) {
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { xr[r][e] = (float)(tid + e); if constexpr (UNPOOL) xi[r][e] = e & 3; }
+#pragma unroll
+            for (int r = 0; r < W_ROUNDS; ++r) wr[r] = clhip_u32x4{(unsigned)tid, 1u, 2u, 3u};
+        }
+        load_chunk(0);
+        store_chunk(0);
+        load_chunk(n_chunks > 1 ? 1 : 0);
+        if (!(BS_ABL & 32)) bs_barrier();                        // chunk 0 staged
+        for (int c = 0; c < n_chunks; ++c) {
+            // while the consumers multiply chunk c: chunk c + 1 into the other buffer (its readers finished before the last barrier),
+            // the loads of chunk c + 2 go out
+            if (c + 1 < n_chunks) {
+                store_chunk((c + 1) & 1);
+                load_chunk(c + 2 < n_chunks ? c + 2 : c + 1);
+            }
+            if (!(BS_ABL & 32)) bs_barrier();
+        }
+        return;
+    }
+
+    // =============================================================================================== consumer waves
+    const int mw = m >> 2, mq = m & 3;
+    const int prow = 2 * (mw / (G::MTW / 2)) + (mq >> 1), pcol = 2 * (mw % (G::MTW / 2)) + (mq & 1);     // pixel of lane m inside its M tile
+    int abase[WM];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int mt = wm * WM + i;
+        const int ni = mt / G::MT_PER_IMG, rem = mt - ni * G::MT_PER_IMG, tr = rem / G::MT_PER_ROW, tc = rem - tr * G::MT_PER_ROW;
+        abase[i] = (kh * G::PLANE_SLOTS + ((ni / G::IPR) * HR + tr * G::MTH + prow) * P + (ni % G::IPR) * HW_ + tc * G::MTW + pcol) * 16;
+    }
+    const int boff = G::A_BYTES + (wn * WN * G::W_SLICE + lane) * 16;       // this wave's B operands in a staged buffer
+    clhip_u32x4 a_fix[WM][3], b_fix[WN][3];
+    if (BS_ABL & 2) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+#pragma unroll
+            for (int i = 0; i < WM; ++i) a_fix[i][s] = clhip_u32x4{(unsigned)lane, 0x3f803f80u, (unsigned)s, (unsigned)i};
+#pragma unroll
+            for (int j = 0; j < WN; ++j) b_fix[j][s] = clhip_u32x4{0x3f803f80u, (unsigned)lane, (unsigned)s, (unsigned)j};
+        }
+    }
+    if (!(BS_ABL & 32)) bs_barrier();                            // chunk 0 staged
     for (int c = 0; c < n_chunks; ++c) {
-        // (registers hold chunk c) everybody has finished reading chunk c - 1: its LDS image is replaced, the loads of chunk c + 1
-        // go out and land during the matrix phase below; the sibling block of this CU computes while this one stages
-        if (c > 0) __syncthreads();
-        store_chunk();
-        load_chunk(c + 1 < n_chunks ? c + 1 : c);
-        __syncthreads();
+        const unsigned char* const lb = lds + (c & 1) * BUF;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dr = tap / 3, ds = tap - dr * 3;
@@ -273,17 +335,24 @@ __global__ __launch_bounds__(256, (2 * G::LDS_BYTES <= 160 * 1024) ? 2 : 1) void
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int s = 0; s < 3; ++s)
-                    a[i][s] = *reinterpret_cast<const clhip_u32x4*>(lds + abase[i] + (dr * P + ds) * 16 + s * 2 * G::PLANE_BYTES);
+                    a[i][s] = (BS_ABL & 2) ? a_fix[i][s]
+                                           : *reinterpret_cast<const clhip_u32x4*>(lb + abase[i] + (dr * P + ds) * 16 + s * 2 * G::PLANE_BYTES);
 #pragma unroll
             for (int j = 0; j < WN; ++j)
 #pragma unroll
                 for (int s = 0; s < 3; ++s)
-                    bq[j][s] = *reinterpret_cast<const clhip_u32x4*>(bbase + ((j * 9 + tap) * 3 + s) * 1024);
+                    bq[j][s] = (BS_ABL & 2) ? b_fix[j][s] : *reinterpret_cast<const clhip_u32x4*>(lb + boff + ((j * 9 + tap) * 3 + s) * 1024);
             // six products per tile pair, small ones first; consecutive MFMAs go to different accumulators
+#if BS_ABL & 1
+#define BS_TERM(ACC, PA, PB)                                                                                                      \
+            _Pragma("unroll") for (int i = 0; i < WM; ++i) _Pragma("unroll") for (int j = 0; j < WN; ++j)                         \
+                asm volatile("" : "+v"(ACC[i][j]) : "v"(a[i][PA]), "v"(bq[j][PB]));
+#else
 #define BS_TERM(ACC, PA, PB)                                                                                                      \
             _Pragma("unroll") for (int i = 0; i < WM; ++i) _Pragma("unroll") for (int j = 0; j < WN; ++j)                         \
                 ACC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bs_bf16x8, a[i][PA]),                      \
                                                                    __builtin_bit_cast(bs_bf16x8, bq[j][PB]), ACC[i][j], 0, 0, 0);
+#endif
             if constexpr (SEP) {
                 BS_TERM(accl, 0, 2) BS_TERM(acc, 0, 0) BS_TERM(accl, 2, 0) BS_TERM(accl, 1, 1) BS_TERM(accl, 0, 1) BS_TERM(accl, 1, 0)
             } else {
@@ -291,6 +360,7 @@ __global__ __launch_bounds__(256, (2 * G::LDS_BYTES <= 160 * 1024) ? 2 : 1) void
             }
 #undef BS_TERM
         }
+        if (!(BS_ABL & 32)) bs_barrier();
     }
     if constexpr (SEP) {
 #pragma unroll
@@ -306,6 +376,102 @@ __global__ __launch_bounds__(256, (2 * G::LDS_BYTES <= 160 * 1024) ? 2 : 1) void
     const bool odd = (H | W) & 1;
     const size_t chw = (size_t)H * W;
     const int OH = H >> 1, OW = W >> 1;
+    // the wave's region: RGH x RGW pixels of image n_w from (oh0, ow0)
+    const int mt0 = wm * WM;
+    const int ni_w = mt0 / G::MT_PER_IMG, rem_w = mt0 - ni_w * G::MT_PER_IMG, tr_w = rem_w / G::MT_PER_ROW, tc_w = rem_w - tr_w * G::MT_PER_ROW;
+    const int n_w = n0 + ni_w, oh0 = y0 + tr_w * G::MTH, ow0 = x0 + tc_w * G::MTW;
+    constexpr int RGW = G::RGW, RGH = G::RGH, TS = G::TS;
+    // Fast path (rows of whole float4s: W % 4 == 0, pooled rows likewise): the tile goes through LDS — every lane writes its channel's
+    // 2x2 windows, then reads rows back as float4s — so that a store instruction covers whole 32 .. 128-byte row pieces per channel
+    // instead of 64 scattered 8-byte pieces (the scattered form took 24 us of a 102 us launch on its own, 77 us with the mask reads of
+    // backward-data: profiles/r05_bs_v2_ablations.txt).  All staging buffers are free here (last barrier passed); each wave uses its own piece.
+    const bool fast = !odd && (W & 3) == 0 && (!pool || (OW & 3) == 0) && !(BS_ABL & 64);
+    if (fast) {
+        float* const T = reinterpret_cast<float*>(lds) + cw * (32 * TS);
+        uint8_t* const Cb = lds + 4 * 32 * TS * 4 + cw * (32 * 16 * WM);          // arg-max codes: [channel][pooled row][pooled column]
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int k = (nt0 + j) * 32 + m;
+            const float bv = (MODE == 0 && bias != nullptr && k < Cout) ? bias[k] : 0.f;
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+                const int di = G::SIDE_BY_SIDE ? 0 : i * G::MTH, dj = G::SIDE_BY_SIDE ? i * G::MTW : 0;     // M tile i inside the region
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int w8 = 2 * g + kh;
+                    const int rr = di + 2 * (w8 / (G::MTW / 2)), cc = dj + 2 * (w8 % (G::MTW / 2));
+                    float y00 = acc[i][j][4 * g], y01 = acc[i][j][4 * g + 1], y10 = acc[i][j][4 * g + 2], y11 = acc[i][j][4 * g + 3];
+                    if (MODE == 0) {
+                        y00 += bv; y01 += bv; y10 += bv; y11 += bv;
+                        if (relu) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
+                    }
+                    if (pool) {
+                        float mx = y00; int am = 0;
+                        if (y01 > mx) { mx = y01; am = 1; }
+                        if (y10 > mx) { mx = y10; am = 2; }
+                        if (y11 > mx) { mx = y11; am = 3; }
+                        if (relu && !(mx > 0.f)) am = CLHIP_POOL_DEAD;       // ReLU folded into the code (common.hpp)
+                        T[m * TS + (rr >> 1) * (RGW / 2) + (cc >> 1)] = mx;
+                        Cb[m * (16 * WM) + (rr >> 1) * (RGW / 2) + (cc >> 1)] = (uint8_t)am;
+                    } else {
+                        *reinterpret_cast<float2*>(T + m * TS + rr * RGW + cc) = make_float2(y00, y01);
+                        *reinterpret_cast<float2*>(T + m * TS + (rr + 1) * RGW + cc) = make_float2(y10, y11);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int kb = (nt0 + j) * 32;
+            if (pool) {
+                constexpr int PW = RGW / 2, PH = RGH / 2, F4 = PW * PH / 4;                 // pooled region, float4s per channel
+#pragma unroll
+                for (int t = 0; t < (32 * F4 + 63) / 64; ++t) {
+                    const int f = t * 64 + lane, oc = f / F4, r4 = f - oc * F4, pr = r4 / (PW / 4), c4 = r4 - pr * (PW / 4);
+                    const int k = kb + oc, ph = (oh0 >> 1) + pr, pw = (ow0 >> 1) + 4 * c4;
+                    if (f < 32 * F4 && k < Cout && n_w < N && ph < OH && pw < OW && !(BS_ABL & 16)) {
+                        const float4 v = *reinterpret_cast<const float4*>(T + oc * TS + pr * PW + 4 * c4);
+                        *reinterpret_cast<float4*>(out + ((size_t)n_w * Cout + k) * OH * OW + (size_t)ph * OW + pw) = v;
+                    }
+                }
+                // codes: one (channel, pooled row) per lane and step, PW bytes each
+#pragma unroll
+                for (int t = 0; t < (32 * PH + 63) / 64; ++t) {
+                    const int f = t * 64 + lane, oc = f / PH, pr = f - oc * PH;
+                    const int k = kb + oc, ph = (oh0 >> 1) + pr, pw = ow0 >> 1;
+                    if (f < 32 * PH && k < Cout && n_w < N && ph < OH && !(BS_ABL & 16)) {
+                        const uint8_t* src = Cb + oc * (16 * WM) + pr * PW;
+                        uint8_t* dst = pool_idx + ((size_t)n_w * Cout + k) * OH * OW + (size_t)ph * OW + pw;
+                        if (pw + PW <= OW) {
+                            if constexpr (PW == 16) *reinterpret_cast<clhip_u32x4*>(dst) = *reinterpret_cast<const clhip_u32x4*>(src);
+                            else if constexpr (PW == 8) *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(src);
+                            else *reinterpret_cast<unsigned*>(dst) = *reinterpret_cast<const unsigned*>(src);
+                        } else {
+                            for (int q = 0; q < PW && pw + q < OW; ++q) dst[q] = src[q];
+                        }
+                    }
+                }
+            } else {
+                constexpr int F4 = RGW * RGH / 4;                                           // float4s per channel (16 WM)
+#pragma unroll
+                for (int t = 0; t < 32 * F4 / 64; ++t) {
+                    const int f = t * 64 + lane, oc = f / F4, r4 = f - oc * F4, row = r4 / (RGW / 4), c4 = r4 - row * (RGW / 4);
+                    const int k = kb + oc, oh = oh0 + row, ow = ow0 + 4 * c4;
+                    if (k < Cout && n_w < N && oh < H && ow < W && !(BS_ABL & 16)) {
+                        float4 v = *reinterpret_cast<const float4*>(T + oc * TS + row * RGW + 4 * c4);
+                        const size_t o = ((size_t)n_w * Cout + k) * chw + (size_t)oh * W + ow;
+                        if (MODE == 1 && mask_src) {
+                            const float4 ms = *reinterpret_cast<const float4*>(mask_src + o);
+                            v.x = ms.x > 0.f ? v.x : 0.f; v.y = ms.y > 0.f ? v.y : 0.f; v.z = ms.z > 0.f ? v.z : 0.f; v.w = ms.w > 0.f ? v.w : 0.f;
+                        }
+                        *reinterpret_cast<float4*>(out + o) = v;
+                    }
+                }
+            }
+            if (j + 1 < WN) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+        }
+        return;
+    }
+    // general path (odd maps, rows that are not whole float4s): every lane stores its own 2x2 windows
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
         const int k = (nt0 + j) * 32 + m;
@@ -331,7 +497,7 @@ __global__ __launch_bounds__(256, (2 * G::LDS_BYTES <= 160 * 1024) ? 2 : 1) void
                         if (y10 > mx) { mx = y10; am = 2; }
                         if (y11 > mx) { mx = y11; am = 3; }
                         if (relu && !(mx > 0.f)) am = CLHIP_POOL_DEAD;       // ReLU folded into the code (common.hpp)
-                        if (ok) {
+                        if (ok && (!(BS_ABL & 16) || mx == 12345.678f)) {
                             const size_t o = ((size_t)n * Cout + k) * OH * OW + (size_t)(oh >> 1) * OW + (ow >> 1);
                             out[o] = mx;
                             pool_idx[o] = (uint8_t)am;
@@ -339,7 +505,7 @@ __global__ __launch_bounds__(256, (2 * G::LDS_BYTES <= 160 * 1024) ? 2 : 1) void
                         continue;
                     }
                 }
-                if (!ok) continue;
+                if (!ok || ((BS_ABL & 16) && y00 != 12345.678f)) continue;
                 const size_t o = ((size_t)n * Cout + k) * chw + (size_t)oh * W + ow;
                 if (odd) {
                     const bool row1 = oh + 1 < H, col1 = ow + 1 < W;
@@ -388,10 +554,10 @@ int bs_launch_geo(const float* in, const clhip_u32x4* wimg, const float* bias, c
     const long long blocks = (npb + 7) / 8 * 8 * kts;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return CLHIP_EINVAL;
     if (sep)
-        hipLaunchKernelGGL((bs_conv_kernel<G, MODE, UNPOOL, true>), dim3((unsigned)blocks), dim3(256), 0, s, in, wimg, bias, mask_src,
+        hipLaunchKernelGGL((bs_conv_kernel<G, MODE, UNPOOL, true>), dim3((unsigned)blocks), dim3(512), 0, s, in, wimg, bias, mask_src,
                            out, pool_idx, N, Cin, Cout, H, W, relu, tiles_x, tiles_y, (int)npb);
     else
-        hipLaunchKernelGGL((bs_conv_kernel<G, MODE, UNPOOL, false>), dim3((unsigned)blocks), dim3(256), 0, s, in, wimg, bias, mask_src,
+        hipLaunchKernelGGL((bs_conv_kernel<G, MODE, UNPOOL, false>), dim3((unsigned)blocks), dim3(512), 0, s, in, wimg, bias, mask_src,
                            out, pool_idx, N, Cin, Cout, H, W, relu, tiles_x, tiles_y, (int)npb);
     CLHIP_LAUNCH_CHECK();
     return 0;
