@@ -154,156 +154,137 @@ struct BsGeo {
     static constexpr int RGW = SIDE_BY_SIDE ? WM * MTW : MTW, RGH = 32 * WM / RGW;
     static_assert(MT_PER_IMG % WM == 0 && (SIDE_BY_SIDE ? MT_PER_ROW % WM == 0 : MT_PER_ROW == 1), "a wave's tiles form a rectangle");
     static constexpr int TS = 32 * WM + 4;                                 // floats per channel in the transposition buffer (16-byte rows)
-    static_assert(4 * 32 * TS * 4 + 4 * 32 * 16 * WM <= 2 * LDS_BYTES, "transposition buffers fit the staging LDS");
+    static_assert(4 * 32 * TS * 4 + 4 * 32 * 16 * WM <= LDS_BYTES, "transposition buffers fit the staging LDS");
 };
 
 // SEP: the product of the leading pieces a0 b0 and the five small products are summed in accumulators of their own (added once, in
 // the epilogue): measured 3x less error than one accumulator, i.e. 3x less than an fp32 fmaf chain (profiles/r05_bf16_split_dot.txt)
 //
-// 512 threads: waves 0-3 multiply (consumers, 2 x 2, each 64 pixels x 32 channels), waves 4-7 stage (producers) — one of each per SIMD,
-// so the split / LDS-write / load instructions of chunk c + 1 issue beside the MFMAs of chunk c by construction (bf16 MFMAs co-issue
-// with another wave's VALU, profiles/r05_bf16_split_dot.txt; two co-resident blocks that stage and multiply in turn ran in
-// lockstep and overlapped nothing: matrix 41 us + staging 40 us + stores 24 us = the 102 us measured, profiles/r05_bs_v2_ablations.txt).
-// LDS: activations and weights double-buffered (2 x 22.5 KB + 2 x 54 KB = 153 KB: one block per CU), ONE barrier per chunk.
+// PERSISTENT, one block of 4 waves per CU (one wave per SIMD, the whole LDS): a block walks its units u = blockIdx.x, + gridDim.x, ...
+// (unit = pixel tile x 64-channel group) and the (unit, chunk) stages form ONE software pipeline: while a wave multiplies stage s out of
+// buffer s & 1 it splits / writes stage s + 1 (registers -> buffer (s + 1) & 1) and issues the loads of stage s + 2, all inside its own
+// instruction stream — bf16 MFMAs hide ~4 other instructions each from the SAME wave but hardly any from a sibling wave
+// (profiles/r05_bf16_split_dot.txt: "same wave" vs "VALU sibling"), which is what two earlier forms of this kernel measured too:
+//   two co-resident blocks that stage and multiply in turn ran in lockstep (matrix 41 us + staging 40 us + stores 24 us = the 102 us
+//   measured on layer 2, profiles/r05_bs_v2_ablations.txt); producer / consumer waves sharing the SIMDs: 114 us, either role alone
+//   80 us (profiles/r05_bs_v3_ablations.txt); and every block launch cost ~2 us of dispatch + prologue with the LDS taken whole.
+// One barrier per stage; the tile's outputs go through the LDS buffer the last stage has just consumed (one more barrier per unit).
 template <class G, int MODE, bool UNPOOL, bool SEP>
-__global__ __launch_bounds__(512, 1) void bs_conv_kernel(
+__global__ __launch_bounds__(256, 1) void bs_conv_kernel(
     const float* __restrict__ in, const clhip_u32x4* __restrict__ wimg, const float* __restrict__ bias,
     const float* __restrict__ mask_src, float* __restrict__ out, uint8_t* __restrict__ pool_idx, int N, int Cin, int Cout, int H,
-    int W, int relu, int tiles_x, int tiles_y, int npb) {
+    int W, int relu, int tiles_x, int tiles_y, int n_units) {
     constexpr int RW = G::RW, RH = G::RH, NI = G::NI, WM = G::WM, WN = G::WN, P = G::P, HR = G::HR, HW_ = G::HW_;
     constexpr int ROUNDS = G::ROUNDS, W_ROUNDS = G::W_ROUNDS;
     constexpr int BUF = G::LDS_BYTES;                                       // one (activations, weights) buffer
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool producer = wave >= 4;
-    const int tid = threadIdx.x & 255;                                      // index inside the role's four waves
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kts = (Cout + BS_BN - 1) / BS_BN;
-    // blocks of one pixel tile (all channel groups) follow each other on ONE XCD (block b runs on XCD b % 8): its input tile is read
-    // from HBM once per XCD L2
-    const int b = blockIdx.x;
-    const int kt = (b >> 3) % kts, pb = (b / (8 * kts)) * 8 + (b & 7);
-    if (pb >= npb) return;
-    const int tx = pb % tiles_x, ty = (pb / tiles_x) % tiles_y, grp = pb / (tiles_x * tiles_y);
-    const int n0 = grp * NI, y0 = ty * RH, x0 = tx * RW;
     const int n_chunks = Cin / BS_CK;
     const int IH = UNPOOL ? H >> 1 : H, IW = UNPOOL ? W >> 1 : W;          // the input tensor's own plane
     const int plane_in = IH * IW;
     const int n_nt = (Cout + 31) / 32;
+    if ((int)blockIdx.x >= n_units) return;
+    const __amdgpu_buffer_rsrc_t rs_w = clhip_rsrc(wimg, (size_t)n_nt * n_chunks * 27 * 1024);
 
-    // ---- this (consumer) wave's M tiles / N tiles
-    const int cw = wave & 3;
-    const int wm = cw % G::WAVES_M, wn = cw / G::WAVES_M;
-    const int m = lane & 31, kh = lane >> 5;
-    const int nt0 = kt * (BS_BN / 32) + wn * WN;                            // first n tile of this wave (global)
+    // unit u -> (channel group kt, pixel tile): the channel groups of one pixel tile are consecutive units (concurrent blocks, and
+    // units 8 apart share an XCD: the input tile is read from HBM once per XCD L2)
+    struct Tile { int kt, n0, y0, x0; };
+    auto tile_of = [&](int u) {
+        Tile t;
+        t.kt = u % kts;
+        const int pb = u / kts;
+        t.x0 = (pb % tiles_x) * RW;
+        t.y0 = ((pb / tiles_x) % tiles_y) * RH;
+        t.n0 = (pb / (tiles_x * tiles_y)) * NI;
+        return t;
+    };
 
-    floatx16 acc[WM][WN], accl[SEP ? WM : 1][SEP ? WN : 1];
+    // ---- loader state: (halo pixel, k half) items of this thread -> element offset of channel 8 h of chunk 0, LDS slot; weight items
+    int lw[ROUNDS], hyx[ROUNDS];
 #pragma unroll
-    for (int i = 0; i < WM; ++i)
+    for (int r = 0; r < ROUNDS; ++r) {
+        // (the last round wraps around: its spare threads stage the first items a second time — same data to the same slots —
+        // so that no load / LDS write of the loop sits under a branch)
+        const int it_ = r * 256 + tid, it = it_ < G::ITEMS ? it_ : it_ - G::ITEMS;
+        const int h = it >= G::NHALO ? 1 : 0, p = it - h * G::NHALO;
+        const int ni = p / (HR * HW_), rem = p - ni * (HR * HW_), hy = rem / HW_, hx = rem - hy * HW_;
+        lw[r] = (h * G::PLANE_SLOTS + ((ni / G::IPR) * HR + hy) * P + (ni % G::IPR) * HW_ + hx) * 16;
+        hyx[r] = (h << 24) | (ni << 16) | (hy << 8) | hx;
+    }
+    int wrem[W_ROUNDS], wlds[W_ROUNDS];
 #pragma unroll
-        for (int j = 0; j < WN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                acc[i][j][r] = 0.f;
-                if constexpr (SEP) accl[i][j][r] = 0.f;
-            }
-
-    if (producer) {
-        // =========================================================================================== producer waves
-        const float* in_blk = in + (size_t)n0 * Cin * plane_in;
-        const __amdgpu_buffer_rsrc_t rs_x = clhip_rsrc(in_blk, (size_t)(N - n0) * Cin * plane_in * sizeof(float));
-        const __amdgpu_buffer_rsrc_t rs_i = clhip_rsrc(UNPOOL ? pool_idx + (size_t)n0 * Cin * plane_in : pool_idx,
-                                                       UNPOOL ? (size_t)(N - n0) * Cin * plane_in : 0);
-        const __amdgpu_buffer_rsrc_t rs_w = clhip_rsrc(wimg, (size_t)n_nt * n_chunks * 27 * 1024);
-        // staging items of this thread: (halo pixel, k half) -> element offset of channel 8 h of the chunk, LDS slot
-        int xoff[ROUNDS], lw[ROUNDS], pos[ROUNDS];
+    for (int r = 0; r < W_ROUNDS; ++r) {
+        const int i_ = r * 256 + tid, i = i_ < G::W_ITEMS ? i_ : i_ - G::W_ITEMS;
+        const int ntl = i / G::W_SLICE, rem = i - ntl * G::W_SLICE;
+        wrem[r] = (ntl * n_chunks * G::W_SLICE + rem) * 16;                 // offset inside the channel group's two image slices
+        wlds[r] = G::A_BYTES + i * 16;
+    }
+    int xoff[ROUNDS], pos[ROUNDS];
+    __amdgpu_buffer_rsrc_t rs_x = clhip_rsrc(in, 0), rs_i = clhip_rsrc(in, 0);
+    int w_kt = 0;                                                           // byte offset of the loader's channel group in the image
+    auto set_loader = [&](const Tile& t) {
+        const float* in_blk = in + (size_t)t.n0 * Cin * plane_in;
+        rs_x = clhip_rsrc(in_blk, (size_t)(N - t.n0) * Cin * plane_in * sizeof(float));
+        if constexpr (UNPOOL) rs_i = clhip_rsrc(pool_idx + (size_t)t.n0 * Cin * plane_in, (size_t)(N - t.n0) * Cin * plane_in);
+        w_kt = t.kt * (BS_BN / 32) * n_chunks * G::W_SLICE * 16;
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
-            // (the last round wraps around: its spare threads stage the first items a second time — same data to the same slots —
-            // so that no load / LDS write of the loop sits under a branch)
-            const int it_ = r * 256 + tid, it = it_ < G::ITEMS ? it_ : it_ - G::ITEMS;
-            const int h = it >= G::NHALO ? 1 : 0, p = it - h * G::NHALO;
-            const int ni = p / (HR * HW_), rem = p - ni * (HR * HW_), hy = rem / HW_, hx = rem - hy * HW_;
-            const int gy = y0 + hy - 1, gx = x0 + hx - 1, n = n0 + ni;
+            const int h = hyx[r] >> 24, ni = (hyx[r] >> 16) & 255, hy = (hyx[r] >> 8) & 255, hx = hyx[r] & 255;
+            const int gy = t.y0 + hy - 1, gx = t.x0 + hx - 1, n = t.n0 + ni;
             const bool ok = n < N && gy >= 0 && gy < H && gx >= 0 && gx < W;
             const int e = UNPOOL ? (gy >> 1) * IW + (gx >> 1) : gy * IW + gx;
             xoff[r] = ok ? (ni * Cin + 8 * h) * plane_in + e : CLHIP_OOB;
             pos[r] = ((gy & 1) << 1) | (gx & 1);
-            lw[r] = (h * G::PLANE_SLOTS + ((ni / G::IPR) * HR + hy) * P + (ni % G::IPR) * HW_ + hx) * 16;
         }
-        // ... and of the weight slice: 16-byte item i of the block's two n tiles -> image offset (chunk 0), LDS offset
-        int woff[W_ROUNDS], wlds[W_ROUNDS];
+    };
+    float xr[ROUNDS][8];
+    unsigned xi[UNPOOL ? ROUNDS : 1][8];
+    clhip_u32x4 wr[W_ROUNDS];
+    int st_pos[ROUNDS];                                                     // window positions of the items held in xr (their tile's)
+    auto load_chunk = [&](int c) {
+        if (BS_ABL & 8) return;
+        const int cb = c * BS_CK * plane_in;
 #pragma unroll
-        for (int r = 0; r < W_ROUNDS; ++r) {
-            const int i_ = r * 256 + tid, i = i_ < G::W_ITEMS ? i_ : i_ - G::W_ITEMS;
-            const int ntl = i / G::W_SLICE, rem = i - ntl * G::W_SLICE;
-            const int nt = kt * (BS_BN / 32) + ntl;
-            woff[r] = nt < n_nt ? (nt * n_chunks * G::W_SLICE + rem) * 16 : CLHIP_OOB;
-            wlds[r] = G::A_BYTES + i * 16;
-        }
-        float xr[ROUNDS][8];
-        unsigned xi[UNPOOL ? ROUNDS : 1][8];
-        clhip_u32x4 wr[W_ROUNDS];
-        auto load_chunk = [&](int c) {
-            if (BS_ABL & 8) return;
-            const int cb = c * BS_CK * plane_in;
+        for (int r = 0; r < ROUNDS; ++r) {
+            st_pos[r] = pos[r];
 #pragma unroll
-            for (int r = 0; r < ROUNDS; ++r)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int so = cb + e * plane_in;
-                    xr[r][e] = clhip_buf_load(rs_x, xoff[r] != CLHIP_OOB ? xoff[r] * 4 : CLHIP_OOB, so * 4);
-                    if constexpr (UNPOOL) xi[r][e] = clhip_buf_load_u8(rs_i, xoff[r], so);
-                }
-#pragma unroll
-            for (int r = 0; r < W_ROUNDS; ++r) wr[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff[r], c * G::W_SLICE * 16, 0);
-        };
-        auto store_chunk = [&](int buf) {
-            if (BS_ABL & 4) return;
-            unsigned char* const lb = lds + buf * BUF;
-#pragma unroll
-            for (int r = 0; r < ROUNDS; ++r) {
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    if constexpr (UNPOOL) v[e] = xi[r][e] == (unsigned)pos[r] ? xr[r][e] : 0.f;     // max_pool2d backward (+ ReLU: dead code 4)
-                    else v[e] = xr[r][e];
-                }
-                clhip_u32x4 q0, q1, q2;
-                bs_split8(v, q0, q1, q2);
-                unsigned char* d = lb + lw[r];
-                *reinterpret_cast<clhip_u32x4*>(d) = q0;
-                *reinterpret_cast<clhip_u32x4*>(d + 2 * G::PLANE_BYTES) = q1;
-                *reinterpret_cast<clhip_u32x4*>(d + 4 * G::PLANE_BYTES) = q2;
+            for (int e = 0; e < 8; ++e) {
+                const int so = cb + e * plane_in;
+                xr[r][e] = clhip_buf_load(rs_x, xoff[r] != CLHIP_OOB ? xoff[r] * 4 : CLHIP_OOB, so * 4);
+                if constexpr (UNPOOL) xi[r][e] = clhip_buf_load_u8(rs_i, xoff[r], so);
             }
-#pragma unroll
-            for (int r = 0; r < W_ROUNDS; ++r) *reinterpret_cast<clhip_u32x4*>(lb + wlds[r]) = wr[r];
-        };
-        if (BS_ABL & 8) {
-#pragma unroll
-            for (int r = 0; r < ROUNDS; ++r)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { xr[r][e] = (float)(tid + e); if constexpr (UNPOOL) xi[r][e] = e & 3; }
-#pragma unroll
-            for (int r = 0; r < W_ROUNDS; ++r) wr[r] = clhip_u32x4{(unsigned)tid, 1u, 2u, 3u};
         }
-        load_chunk(0);
-        store_chunk(0);
-        load_chunk(n_chunks > 1 ? 1 : 0);
-        if (!(BS_ABL & 32)) bs_barrier();                        // chunk 0 staged
-        for (int c = 0; c < n_chunks; ++c) {
-            // while the consumers multiply chunk c: chunk c + 1 into the other buffer (its readers finished before the last barrier),
-            // the loads of chunk c + 2 go out
-            if (c + 1 < n_chunks) {
-                store_chunk((c + 1) & 1);
-                load_chunk(c + 2 < n_chunks ? c + 2 : c + 1);
+#pragma unroll
+        for (int r = 0; r < W_ROUNDS; ++r) wr[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wrem[r], w_kt + c * G::W_SLICE * 16, 0);
+    };
+    auto store_chunk = [&](int buf) {
+        if (BS_ABL & 4) return;
+        unsigned char* const lb = lds + buf * BUF;
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if constexpr (UNPOOL) v[e] = xi[r][e] == (unsigned)st_pos[r] ? xr[r][e] : 0.f;     // max_pool2d backward (+ ReLU: dead code 4)
+                else v[e] = xr[r][e];
             }
-            if (!(BS_ABL & 32)) bs_barrier();
+            clhip_u32x4 q0, q1, q2;
+            bs_split8(v, q0, q1, q2);
+            unsigned char* d = lb + lw[r];
+            *reinterpret_cast<clhip_u32x4*>(d) = q0;
+            *reinterpret_cast<clhip_u32x4*>(d + 2 * G::PLANE_BYTES) = q1;
+            *reinterpret_cast<clhip_u32x4*>(d + 4 * G::PLANE_BYTES) = q2;
         }
-        return;
-    }
+#pragma unroll
+        for (int r = 0; r < W_ROUNDS; ++r) *reinterpret_cast<clhip_u32x4*>(lb + wlds[r]) = wr[r];
+    };
 
-    // =============================================================================================== consumer waves
+    // ---- this wave's M tiles / N tiles (the same in every unit)
+    const int wm = wave % G::WAVES_M, wn = wave / G::WAVES_M;
+    const int cw = wave;
+    const int m = lane & 31, kh = lane >> 5;
     const int mw = m >> 2, mq = m & 3;
     const int prow = 2 * (mw / (G::MTW / 2)) + (mq >> 1), pcol = 2 * (mw % (G::MTW / 2)) + (mq & 1);     // pixel of lane m inside its M tile
     int abase[WM];
@@ -324,52 +305,93 @@ __global__ __launch_bounds__(512, 1) void bs_conv_kernel(
             for (int j = 0; j < WN; ++j) b_fix[j][s] = clhip_u32x4{0x3f803f80u, (unsigned)lane, (unsigned)s, (unsigned)j};
         }
     }
-    if (!(BS_ABL & 32)) bs_barrier();                            // chunk 0 staged
-    for (int c = 0; c < n_chunks; ++c) {
-        const unsigned char* const lb = lds + (c & 1) * BUF;
+    if (BS_ABL & 8) {
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dr = tap / 3, ds = tap - dr * 3;
-            clhip_u32x4 a[WM][3], bq[WN][3];
+        for (int r = 0; r < ROUNDS; ++r)
 #pragma unroll
-            for (int i = 0; i < WM; ++i)
+            for (int e = 0; e < 8; ++e) { xr[r][e] = (float)(tid + e); if constexpr (UNPOOL) xi[r][e] = e & 3; }
 #pragma unroll
-                for (int s = 0; s < 3; ++s)
-                    a[i][s] = (BS_ABL & 2) ? a_fix[i][s]
-                                           : *reinterpret_cast<const clhip_u32x4*>(lb + abase[i] + (dr * P + ds) * 16 + s * 2 * G::PLANE_BYTES);
-#pragma unroll
-            for (int j = 0; j < WN; ++j)
-#pragma unroll
-                for (int s = 0; s < 3; ++s)
-                    bq[j][s] = (BS_ABL & 2) ? b_fix[j][s] : *reinterpret_cast<const clhip_u32x4*>(lb + boff + ((j * 9 + tap) * 3 + s) * 1024);
-            // six products per tile pair, small ones first; consecutive MFMAs go to different accumulators
-#if BS_ABL & 1
-#define BS_TERM(ACC, PA, PB)                                                                                                      \
-            _Pragma("unroll") for (int i = 0; i < WM; ++i) _Pragma("unroll") for (int j = 0; j < WN; ++j)                         \
-                asm volatile("" : "+v"(ACC[i][j]) : "v"(a[i][PA]), "v"(bq[j][PB]));
-#else
-#define BS_TERM(ACC, PA, PB)                                                                                                      \
-            _Pragma("unroll") for (int i = 0; i < WM; ++i) _Pragma("unroll") for (int j = 0; j < WN; ++j)                         \
-                ACC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bs_bf16x8, a[i][PA]),                      \
-                                                                   __builtin_bit_cast(bs_bf16x8, bq[j][PB]), ACC[i][j], 0, 0, 0);
-#endif
-            if constexpr (SEP) {
-                BS_TERM(accl, 0, 2) BS_TERM(acc, 0, 0) BS_TERM(accl, 2, 0) BS_TERM(accl, 1, 1) BS_TERM(accl, 0, 1) BS_TERM(accl, 1, 0)
-            } else {
-                BS_TERM(acc, 0, 2) BS_TERM(acc, 2, 0) BS_TERM(acc, 1, 1) BS_TERM(acc, 0, 1) BS_TERM(acc, 1, 0) BS_TERM(acc, 0, 0)
-            }
-#undef BS_TERM
-        }
-        if (!(BS_ABL & 32)) bs_barrier();
+        for (int r = 0; r < W_ROUNDS; ++r) wr[r] = clhip_u32x4{(unsigned)tid, 1u, 2u, 3u};
     }
-    if constexpr (SEP) {
+
+    // ---- the pipeline: loader position (lu, lc) runs two stages ahead of the multiplier
+    int lu = blockIdx.x, lc = 0;
+    auto advance = [&]() {                     // -> false when the loader has passed the last stage of this block
+        if (++lc == n_chunks) { lc = 0; lu += gridDim.x; if (lu < n_units) set_loader(tile_of(lu)); }
+        return lu < n_units;
+    };
+    set_loader(tile_of(lu));
+    load_chunk(0);
+    store_chunk(0);
+    if (advance()) load_chunk(lc);
+    if (!(BS_ABL & 32)) __syncthreads();
+    int s = 0;                                                              // stage counter: its operands are in buffer s & 1
+    for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const Tile T_ = tile_of(u);
+        const int kt = T_.kt, n0 = T_.n0, y0 = T_.y0, x0 = T_.x0;
+        const int nt0 = kt * (BS_BN / 32) + wn * WN;                        // first n tile of this wave (global)
+        floatx16 acc[WM][WN], accl[SEP ? WM : 1][SEP ? WN : 1];
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
             for (int j = 0; j < WN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] += accl[i][j][r];
-    }
+                for (int r = 0; r < 16; ++r) {
+                    acc[i][j][r] = 0.f;
+                    if constexpr (SEP) accl[i][j][r] = 0.f;
+                }
+        for (int c = 0; c < n_chunks; ++c, ++s) {
+            const unsigned char* const lb = lds + (s & 1) * BUF;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dr = tap / 3, ds = tap - dr * 3;
+                clhip_u32x4 a[WM][3], bq[WN][3];
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        a[i][q] = (BS_ABL & 2) ? a_fix[i][q]
+                                               : *reinterpret_cast<const clhip_u32x4*>(lb + abase[i] + (dr * P + ds) * 16 + q * 2 * G::PLANE_BYTES);
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        bq[j][q] = (BS_ABL & 2) ? b_fix[j][q] : *reinterpret_cast<const clhip_u32x4*>(lb + boff + ((j * 9 + tap) * 3 + q) * 1024);
+                // the next stage (already in registers: loaded while the previous stage was multiplied) is split and written into the
+                // other buffer from here on, between the MFMAs below; its readers passed the last barrier.  Past the block's last stage
+                // this writes stale registers into a buffer nobody reads.
+                if (tap == 5) store_chunk((s + 1) & 1);
+                // six products per tile pair, small ones first; consecutive MFMAs go to different accumulators
+#if BS_ABL & 1
+#define BS_TERM(ACC, PA, PB)                                                                                                      \
+                _Pragma("unroll") for (int i = 0; i < WM; ++i) _Pragma("unroll") for (int j = 0; j < WN; ++j)                     \
+                    asm volatile("" : "+v"(ACC[i][j]) : "v"(a[i][PA]), "v"(bq[j][PB]));
+#else
+#define BS_TERM(ACC, PA, PB)                                                                                                      \
+                _Pragma("unroll") for (int i = 0; i < WM; ++i) _Pragma("unroll") for (int j = 0; j < WN; ++j)                     \
+                    ACC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bs_bf16x8, a[i][PA]),                  \
+                                                                       __builtin_bit_cast(bs_bf16x8, bq[j][PB]), ACC[i][j], 0, 0, 0);
+#endif
+                if constexpr (SEP) {
+                    BS_TERM(accl, 0, 2) BS_TERM(acc, 0, 0) BS_TERM(accl, 2, 0) BS_TERM(accl, 1, 1) BS_TERM(accl, 0, 1) BS_TERM(accl, 1, 0)
+                } else {
+                    BS_TERM(acc, 0, 2) BS_TERM(acc, 2, 0) BS_TERM(acc, 1, 1) BS_TERM(acc, 0, 1) BS_TERM(acc, 1, 0) BS_TERM(acc, 0, 0)
+                }
+#undef BS_TERM
+            }
+            // the loads of the stage after next go out now (they have until tap 5 of the next stage to land)
+            if (lu < n_units && advance()) load_chunk(lc);
+            if (!(BS_ABL & 32)) __syncthreads();
+        }
+        if constexpr (SEP) {
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += accl[i][j][r];
+        }
+        unsigned char* const lds_free = lds + ((s - 1) & 1) * BUF;          // the buffer the last stage has just consumed
 
     // ---- epilogue: acc[i][j][4 g + q] = (pixel = window 2 g + kh of M tile i, position q; channel 32 (nt0 + j) + (lane & 31))
     const bool pool = MODE == 0 && pool_idx != nullptr;
@@ -387,8 +409,8 @@ __global__ __launch_bounds__(512, 1) void bs_conv_kernel(
     // backward-data: profiles/r05_bs_v2_ablations.txt).  All staging buffers are free here (last barrier passed); each wave uses its own piece.
     const bool fast = !odd && (W & 3) == 0 && (!pool || (OW & 3) == 0) && !(BS_ABL & 64);
     if (fast) {
-        float* const T = reinterpret_cast<float*>(lds) + cw * (32 * TS);
-        uint8_t* const Cb = lds + 4 * 32 * TS * 4 + cw * (32 * 16 * WM);          // arg-max codes: [channel][pooled row][pooled column]
+        float* const T = reinterpret_cast<float*>(lds_free) + cw * (32 * TS);
+        uint8_t* const Cb = lds_free + 4 * 32 * TS * 4 + cw * (32 * 16 * WM);          // arg-max codes: [channel][pooled row][pooled column]
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
             const int k = (nt0 + j) * 32 + m;
@@ -469,8 +491,7 @@ __global__ __launch_bounds__(512, 1) void bs_conv_kernel(
             }
             if (j + 1 < WN) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
         }
-        return;
-    }
+    } else {
     // general path (odd maps, rows that are not whole float4s): every lane stores its own 2x2 windows
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
@@ -531,6 +552,11 @@ __global__ __launch_bounds__(512, 1) void bs_conv_kernel(
             }
         }
     }
+    }
+        // the transposition pieces live in a staging buffer: nobody may start writing the stage after next into it before every wave
+        // has read its piece back
+        if (u + (int)gridDim.x < n_units && !(BS_ABL & 32)) __syncthreads();
+    }
 }
 
 // CLHIP_BS=0: the layers this path would take stay on the Winograd / direct f32 kernels (A/B measurements, the parity suite's
@@ -551,14 +577,20 @@ int bs_launch_geo(const float* in, const clhip_u32x4* wimg, const float* bias, c
     const int tiles_x = (W + G::RW - 1) / G::RW, tiles_y = (H + G::RH - 1) / G::RH, groups = (N + G::NI - 1) / G::NI;
     const long long npb = (long long)tiles_x * tiles_y * groups;
     const int kts = (Cout + BS_BN - 1) / BS_BN;
-    const long long blocks = (npb + 7) / 8 * 8 * kts;
-    if (blocks <= 0 || blocks > 0x7fffffffLL) return CLHIP_EINVAL;
+    const long long units = npb * kts;
+    if (units <= 0 || units > 0x7fffffffLL) return CLHIP_EINVAL;
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    const long long blocks = units < cus ? units : cus;                   // one persistent block per CU (it takes the whole LDS)
     if (sep)
-        hipLaunchKernelGGL((bs_conv_kernel<G, MODE, UNPOOL, true>), dim3((unsigned)blocks), dim3(512), 0, s, in, wimg, bias, mask_src,
-                           out, pool_idx, N, Cin, Cout, H, W, relu, tiles_x, tiles_y, (int)npb);
+        hipLaunchKernelGGL((bs_conv_kernel<G, MODE, UNPOOL, true>), dim3((unsigned)blocks), dim3(256), 0, s, in, wimg, bias, mask_src,
+                           out, pool_idx, N, Cin, Cout, H, W, relu, tiles_x, tiles_y, (int)units);
     else
-        hipLaunchKernelGGL((bs_conv_kernel<G, MODE, UNPOOL, false>), dim3((unsigned)blocks), dim3(512), 0, s, in, wimg, bias, mask_src,
-                           out, pool_idx, N, Cin, Cout, H, W, relu, tiles_x, tiles_y, (int)npb);
+        hipLaunchKernelGGL((bs_conv_kernel<G, MODE, UNPOOL, false>), dim3((unsigned)blocks), dim3(256), 0, s, in, wimg, bias, mask_src,
+                           out, pool_idx, N, Cin, Cout, H, W, relu, tiles_x, tiles_y, (int)units);
     CLHIP_LAUNCH_CHECK();
     return 0;
 }
