@@ -117,9 +117,10 @@ __global__ __launch_bounds__(256) void bs_weight_multi_kernel(BsWtJobs J) {
 }
 
 // ---------------------------------------------------------------------------------------------------- the convolution
-// Geometry of a block: NI images x RH rows x RW columns of output pixels (= BM = 128), one 64-channel group of output channels.
-//   RW = 32: one image, RH = 4;  RW = 16: RH = 8;  RW = 8: two whole 8-row images side by side per LDS row.
-//   M tiles: 2 rows x 16 columns (RW >= 16) or 4 rows x 8 columns.  Waves: WAVES_M x WAVES_N, each WM x WN MFMA tiles.
+// Geometry of a block (256 threads = 4 waves as WAVES_M x WAVES_N, each WM x WN MFMA tiles): NI images x RH rows x RW columns of
+// output pixels (= BM) x one 64-channel group of output channels.
+//   RW = 32: one image, RH = BM / 32;  RW = 16: RH = BM / 16;  RW = 8: whole 8-row images, two side by side per LDS row.
+//   M tiles: 2 rows x 16 columns (RW >= 16) or 4 rows x 8 columns.
 template <int RW_, int RH_, int NI_, int WAVES_M_, int WM_, int WN_>
 struct BsGeo {
     static constexpr int RW = RW_, RH = RH_, NI = NI_, WAVES_M = WAVES_M_, WAVES_N = 4 / WAVES_M_, WM = WM_, WN = WN_;
@@ -137,72 +138,63 @@ struct BsGeo {
     static constexpr int ROWS = (NI / IPR) * HR;
     static constexpr int PLANE_SLOTS = (ROWS - 1) * P + IPR * HW_;         // (the last row needs no padding)
     static constexpr int PLANE_BYTES = PLANE_SLOTS * 16;
-    static constexpr int A_BYTES = 6 * PLANE_BYTES;                        // 3 pieces x 2 k halves
+    static constexpr int BUF_BYTES = 6 * PLANE_BYTES;                      // 3 pieces x 2 k halves
     static constexpr int NHALO = NI * HR * HW_;
     static constexpr int ITEMS = 2 * NHALO;                                // (halo pixel, k half): 8 channels each
     static constexpr int ROUNDS = (ITEMS + 255) / 256;
     static_assert(ROUNDS * 256 - ITEMS <= ITEMS, "the last round wraps at most once");
-    // weight operands of one 16-channel chunk: [n tile (2)][tap][piece][lane] x 16 bytes — two contiguous 27 KB slices of the image
-    static constexpr int W_SLICE = 27 * 64;                                // 16-byte items per n tile
-    static constexpr int W_ITEMS = (BS_BN / 32) * W_SLICE;
-    static constexpr int W_BYTES = W_ITEMS * 16;
-    static constexpr int W_ROUNDS = (W_ITEMS + 255) / 256;
-    static_assert(W_ROUNDS * 256 - W_ITEMS <= W_ITEMS, "wrap once");
-    static constexpr int LDS_BYTES = A_BYTES + W_BYTES;
-    // output region of one consumer wave (its WM M tiles): RGH rows x RGW columns of one image, 64 pixels
-    static constexpr bool SIDE_BY_SIDE = MT_PER_ROW >= WM;                 // the wave's M tiles sit next to each other (else: below)
-    static constexpr int RGW = SIDE_BY_SIDE ? WM * MTW : MTW, RGH = 32 * WM / RGW;
-    static_assert(MT_PER_IMG % WM == 0 && (SIDE_BY_SIDE ? MT_PER_ROW % WM == 0 : MT_PER_ROW == 1), "a wave's tiles form a rectangle");
+    // output region of one wave (its WM M tiles): RGH rows x RGW columns of one image, TPR tiles per region row
+    static constexpr int TPR = WM < MT_PER_ROW ? WM : MT_PER_ROW;
+    static_assert(WM % TPR == 0 && MT_PER_ROW % TPR == 0 && MT_PER_IMG % WM == 0, "a wave's tiles form a rectangle inside one image");
+    static constexpr int RGW = TPR * MTW, RGH = 32 * WM / RGW;
     static constexpr int TS = 32 * WM + 4;                                 // floats per channel in the transposition buffer (16-byte rows)
-    static_assert(4 * 32 * TS * 4 + 4 * 32 * 16 * WM <= LDS_BYTES, "transposition buffers fit the staging LDS");
+    static_assert(4 * 32 * TS * 4 <= 2 * BUF_BYTES, "transposition buffers fit the staging LDS");
 };
 
 // SEP: the product of the leading pieces a0 b0 and the five small products are summed in accumulators of their own (added once, in
-// the epilogue): measured 3x less error than one accumulator, i.e. 3x less than an fp32 fmaf chain (profiles/r05_bf16_split_dot.txt)
+// the epilogue): measured 3x less error than one accumulator, i.e. 3x less than an fp32 fmaf chain (profiles/r05_bf16_split_dot.txt).
 //
-// PERSISTENT, one block of 4 waves per CU (one wave per SIMD, the whole LDS): a block walks its units u = blockIdx.x, + gridDim.x, ...
-// (unit = pixel tile x 64-channel group) and the (unit, chunk) stages form ONE software pipeline: while a wave multiplies stage s out of
-// buffer s & 1 it splits / writes stage s + 1 (registers -> buffer (s + 1) & 1) and issues the loads of stage s + 2, all inside its own
-// instruction stream — bf16 MFMAs hide ~4 other instructions each from the SAME wave but hardly any from a sibling wave
-// (profiles/r05_bf16_split_dot.txt: "same wave" vs "VALU sibling"), which is what two earlier forms of this kernel measured too:
-//   two co-resident blocks that stage and multiply in turn ran in lockstep (matrix 41 us + staging 40 us + stores 24 us = the 102 us
-//   measured on layer 2, profiles/r05_bs_v2_ablations.txt); producer / consumer waves sharing the SIMDs: 114 us, either role alone
-//   80 us (profiles/r05_bs_v3_ablations.txt); and every block launch cost ~2 us of dispatch + prologue with the LDS taken whole.
-// One barrier per stage; the tile's outputs go through the LDS buffer the last stage has just consumed (one more barrier per unit).
+// What was measured on the way here (layer 2 of the bench net, 64 -> 64 @ 32 x 32, N = 200; matrix floor 36 us at 2.5 PF, ~43 us at the
+// clock the pipe sustains; Winograd f32 kernel 95 - 100 us in the same sessions):
+//   v1  activations double-buffered in LDS and staged INSIDE the wave's MFMA stream, weight operands straight from L2 (one 1 KB
+//       coalesced load per operand): 92 us with 64 x 32 wave tiles, 102 us with 64 x 64 (profiles/r05_bs_v1_per_layer.txt);
+//   v2  weights through LDS once per block, single-buffered, two blocks per CU taking turns: 98 us — the two blocks run in lockstep,
+//       matrix 43 + staging 47 + stores add up (profiles/r05_bs_v2_ablations.txt; matrix + LDS reads alone: 51 us);
+//   v3  producer / consumer waves, everything double-buffered, one block per CU: 114 us, either role alone 80 us;
+//   v4  persistent one-wave-per-SIMD blocks, one in-wave pipeline over (tile, chunk) stages: 121 us, matrix + reads 76, staging + reads 76.
+// In every form the non-matrix work ADDS to the matrix time; what differs is how much of it there is per MFMA.  This form keeps v1's
+// structure (no weight bytes through VALU / LDS-write at all) and halves its load on the vector-memory path with 128 x 32 wave tiles.
 template <class G, int MODE, bool UNPOOL, bool SEP>
-__global__ __launch_bounds__(256, 1) void bs_conv_kernel(
+__global__ __launch_bounds__(256, (2 * G::BUF_BYTES <= 80 * 1024) ? 2 : 1) void bs_conv_kernel(
     const float* __restrict__ in, const clhip_u32x4* __restrict__ wimg, const float* __restrict__ bias,
     const float* __restrict__ mask_src, float* __restrict__ out, uint8_t* __restrict__ pool_idx, int N, int Cin, int Cout, int H,
-    int W, int relu, int tiles_x, int tiles_y, int n_units) {
+    int W, int relu, int tiles_x, int tiles_y, int npb) {
     constexpr int RW = G::RW, RH = G::RH, NI = G::NI, WM = G::WM, WN = G::WN, P = G::P, HR = G::HR, HW_ = G::HW_;
-    constexpr int ROUNDS = G::ROUNDS, W_ROUNDS = G::W_ROUNDS;
-    constexpr int BUF = G::LDS_BYTES;                                       // one (activations, weights) buffer
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
+    constexpr int ROUNDS = G::ROUNDS;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * G::BUF_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kts = (Cout + BS_BN - 1) / BS_BN;
+    // blocks of one pixel tile (all channel groups) follow each other on ONE XCD (block b runs on XCD b % 8): its input tile is read
+    // from HBM once per XCD L2
+    const int b = blockIdx.x;
+    const int kt = (b >> 3) % kts, pb = (b / (8 * kts)) * 8 + (b & 7);
+    if (pb >= npb) return;
+    const int tx = pb % tiles_x, ty = (pb / tiles_x) % tiles_y, grp = pb / (tiles_x * tiles_y);
+    const int n0 = grp * NI, y0 = ty * RH, x0 = tx * RW;
     const int n_chunks = Cin / BS_CK;
     const int IH = UNPOOL ? H >> 1 : H, IW = UNPOOL ? W >> 1 : W;          // the input tensor's own plane
     const int plane_in = IH * IW;
+
+    const float* in_blk = in + (size_t)n0 * Cin * plane_in;
+    const __amdgpu_buffer_rsrc_t rs_x = clhip_rsrc(in_blk, (size_t)(N - n0) * Cin * plane_in * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rs_i = clhip_rsrc(UNPOOL ? pool_idx + (size_t)n0 * Cin * plane_in : pool_idx,
+                                                   UNPOOL ? (size_t)(N - n0) * Cin * plane_in : 0);
     const int n_nt = (Cout + 31) / 32;
-    if ((int)blockIdx.x >= n_units) return;
     const __amdgpu_buffer_rsrc_t rs_w = clhip_rsrc(wimg, (size_t)n_nt * n_chunks * 27 * 1024);
 
-    // unit u -> (channel group kt, pixel tile): the channel groups of one pixel tile are consecutive units (concurrent blocks, and
-    // units 8 apart share an XCD: the input tile is read from HBM once per XCD L2)
-    struct Tile { int kt, n0, y0, x0; };
-    auto tile_of = [&](int u) {
-        Tile t;
-        t.kt = u % kts;
-        const int pb = u / kts;
-        t.x0 = (pb % tiles_x) * RW;
-        t.y0 = ((pb / tiles_x) % tiles_y) * RH;
-        t.n0 = (pb / (tiles_x * tiles_y)) * NI;
-        return t;
-    };
-
-    // ---- loader state: (halo pixel, k half) items of this thread -> element offset of channel 8 h of chunk 0, LDS slot; weight items
-    int lw[ROUNDS], hyx[ROUNDS];
+    // ---- staging items of this thread: (halo pixel, k half) -> element offset of channel 8 h of the chunk, LDS slot
+    int xoff[ROUNDS], lw[ROUNDS], pos[ROUNDS];
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
         // (the last round wraps around: its spare threads stage the first items a second time — same data to the same slots —
@@ -210,80 +202,48 @@ __global__ __launch_bounds__(256, 1) void bs_conv_kernel(
         const int it_ = r * 256 + tid, it = it_ < G::ITEMS ? it_ : it_ - G::ITEMS;
         const int h = it >= G::NHALO ? 1 : 0, p = it - h * G::NHALO;
         const int ni = p / (HR * HW_), rem = p - ni * (HR * HW_), hy = rem / HW_, hx = rem - hy * HW_;
+        const int gy = y0 + hy - 1, gx = x0 + hx - 1, n = n0 + ni;
+        const bool ok = n < N && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const int e = UNPOOL ? (gy >> 1) * IW + (gx >> 1) : gy * IW + gx;
+        xoff[r] = ok ? (ni * Cin + 8 * h) * plane_in + e : CLHIP_OOB;
+        pos[r] = ((gy & 1) << 1) | (gx & 1);
         lw[r] = (h * G::PLANE_SLOTS + ((ni / G::IPR) * HR + hy) * P + (ni % G::IPR) * HW_ + hx) * 16;
-        hyx[r] = (h << 24) | (ni << 16) | (hy << 8) | hx;
     }
-    int wrem[W_ROUNDS], wlds[W_ROUNDS];
-#pragma unroll
-    for (int r = 0; r < W_ROUNDS; ++r) {
-        const int i_ = r * 256 + tid, i = i_ < G::W_ITEMS ? i_ : i_ - G::W_ITEMS;
-        const int ntl = i / G::W_SLICE, rem = i - ntl * G::W_SLICE;
-        wrem[r] = (ntl * n_chunks * G::W_SLICE + rem) * 16;                 // offset inside the channel group's two image slices
-        wlds[r] = G::A_BYTES + i * 16;
-    }
-    int xoff[ROUNDS], pos[ROUNDS];
-    __amdgpu_buffer_rsrc_t rs_x = clhip_rsrc(in, 0), rs_i = clhip_rsrc(in, 0);
-    int w_kt = 0;                                                           // byte offset of the loader's channel group in the image
-    auto set_loader = [&](const Tile& t) {
-        const float* in_blk = in + (size_t)t.n0 * Cin * plane_in;
-        rs_x = clhip_rsrc(in_blk, (size_t)(N - t.n0) * Cin * plane_in * sizeof(float));
-        if constexpr (UNPOOL) rs_i = clhip_rsrc(pool_idx + (size_t)t.n0 * Cin * plane_in, (size_t)(N - t.n0) * Cin * plane_in);
-        w_kt = t.kt * (BS_BN / 32) * n_chunks * G::W_SLICE * 16;
-#pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) {
-            const int h = hyx[r] >> 24, ni = (hyx[r] >> 16) & 255, hy = (hyx[r] >> 8) & 255, hx = hyx[r] & 255;
-            const int gy = t.y0 + hy - 1, gx = t.x0 + hx - 1, n = t.n0 + ni;
-            const bool ok = n < N && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            const int e = UNPOOL ? (gy >> 1) * IW + (gx >> 1) : gy * IW + gx;
-            xoff[r] = ok ? (ni * Cin + 8 * h) * plane_in + e : CLHIP_OOB;
-            pos[r] = ((gy & 1) << 1) | (gx & 1);
-        }
-    };
     float xr[ROUNDS][8];
     unsigned xi[UNPOOL ? ROUNDS : 1][8];
-    clhip_u32x4 wr[W_ROUNDS];
-    int st_pos[ROUNDS];                                                     // window positions of the items held in xr (their tile's)
     auto load_chunk = [&](int c) {
         if (BS_ABL & 8) return;
         const int cb = c * BS_CK * plane_in;
 #pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) {
-            st_pos[r] = pos[r];
+        for (int r = 0; r < ROUNDS; ++r)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int so = cb + e * plane_in;
                 xr[r][e] = clhip_buf_load(rs_x, xoff[r] != CLHIP_OOB ? xoff[r] * 4 : CLHIP_OOB, so * 4);
                 if constexpr (UNPOOL) xi[r][e] = clhip_buf_load_u8(rs_i, xoff[r], so);
             }
-        }
-#pragma unroll
-        for (int r = 0; r < W_ROUNDS; ++r) wr[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wrem[r], w_kt + c * G::W_SLICE * 16, 0);
     };
     auto store_chunk = [&](int buf) {
         if (BS_ABL & 4) return;
-        unsigned char* const lb = lds + buf * BUF;
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                if constexpr (UNPOOL) v[e] = xi[r][e] == (unsigned)st_pos[r] ? xr[r][e] : 0.f;     // max_pool2d backward (+ ReLU: dead code 4)
+                if constexpr (UNPOOL) v[e] = xi[r][e] == (unsigned)pos[r] ? xr[r][e] : 0.f;     // max_pool2d backward (+ ReLU: dead code 4)
                 else v[e] = xr[r][e];
             }
             clhip_u32x4 q0, q1, q2;
             bs_split8(v, q0, q1, q2);
-            unsigned char* d = lb + lw[r];
+            unsigned char* d = lds + buf * G::BUF_BYTES + lw[r];
             *reinterpret_cast<clhip_u32x4*>(d) = q0;
             *reinterpret_cast<clhip_u32x4*>(d + 2 * G::PLANE_BYTES) = q1;
             *reinterpret_cast<clhip_u32x4*>(d + 4 * G::PLANE_BYTES) = q2;
         }
-#pragma unroll
-        for (int r = 0; r < W_ROUNDS; ++r) *reinterpret_cast<clhip_u32x4*>(lb + wlds[r]) = wr[r];
     };
 
-    // ---- this wave's M tiles / N tiles (the same in every unit)
+    // ---- this wave's M tiles / N tiles
     const int wm = wave % G::WAVES_M, wn = wave / G::WAVES_M;
-    const int cw = wave;
     const int m = lane & 31, kh = lane >> 5;
     const int mw = m >> 2, mq = m & 3;
     const int prow = 2 * (mw / (G::MTW / 2)) + (mq >> 1), pcol = 2 * (mw % (G::MTW / 2)) + (mq & 1);     // pixel of lane m inside its M tile
@@ -294,104 +254,95 @@ __global__ __launch_bounds__(256, 1) void bs_conv_kernel(
         const int ni = mt / G::MT_PER_IMG, rem = mt - ni * G::MT_PER_IMG, tr = rem / G::MT_PER_ROW, tc = rem - tr * G::MT_PER_ROW;
         abase[i] = (kh * G::PLANE_SLOTS + ((ni / G::IPR) * HR + tr * G::MTH + prow) * P + (ni % G::IPR) * HW_ + tc * G::MTW + pcol) * 16;
     }
-    const int boff = G::A_BYTES + (wn * WN * G::W_SLICE + lane) * 16;       // this wave's B operands in a staged buffer
-    clhip_u32x4 a_fix[WM][3], b_fix[WN][3];
-    if (BS_ABL & 2) {
+    const int nt0 = kt * (BS_BN / 32) + wn * WN;
+    int wvoff[WN];
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
+    for (int j = 0; j < WN; ++j) wvoff[j] = (nt0 + j < n_nt) ? ((nt0 + j) * n_chunks * 27 * 64 + lane) * 16 : CLHIP_OOB;
+    auto load_b = [&](clhip_u32x4 (&bq)[WN][3], int c, int tap) {
+        if (BS_ABL & 2) return;
+        const int so = (c * 27 + tap * 3) * 1024;
 #pragma unroll
-            for (int i = 0; i < WM; ++i) a_fix[i][s] = clhip_u32x4{(unsigned)lane, 0x3f803f80u, (unsigned)s, (unsigned)i};
+        for (int j = 0; j < WN; ++j)
 #pragma unroll
-            for (int j = 0; j < WN; ++j) b_fix[j][s] = clhip_u32x4{0x3f803f80u, (unsigned)lane, (unsigned)s, (unsigned)j};
+            for (int s = 0; s < 3; ++s) bq[j][s] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wvoff[j], so + s * 1024, 0);
+    };
+
+    floatx16 acc[WM][WN], accl[SEP ? WM : 1][SEP ? WN : 1];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[i][j][r] = 0.f;
+                if constexpr (SEP) accl[i][j][r] = 0.f;
+            }
+
+    // ---- prologue: chunk 0 in LDS, chunk 1 in flight, first weight operands in flight
+    clhip_u32x4 bcur[WN][3];
+    load_chunk(0);
+    load_b(bcur, 0, 0);
+    store_chunk(0);
+    load_chunk(n_chunks > 1 ? 1 : 0);
+    if (!(BS_ABL & 32)) __syncthreads();
+
+    for (int c = 0; c < n_chunks; ++c) {
+        const unsigned char* lb = lds + (c & 1) * G::BUF_BYTES;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dr = tap / 3, ds = tap - dr * 3;
+            // next tap's weight operands (the first tap of the next chunk after the last one; past the end: any valid address)
+            clhip_u32x4 bnext[WN][3];
+            if (tap < 8) load_b(bnext, c, tap + 1);
+            else load_b(bnext, c + 1 < n_chunks ? c + 1 : c, 0);
+            clhip_u32x4 a[WM][3];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+                    a[i][s] = *reinterpret_cast<const clhip_u32x4*>(lb + abase[i] + (dr * P + ds) * 16 + s * 2 * G::PLANE_BYTES);
+            if (tap == 3) {
+                // staging of the next chunk inside this chunk's matrix stream, unconditionally (one basic block per chunk: the
+                // scheduler may place these VALU / LDS / load instructions between the MFMAs): after the last chunk the spare
+                // buffer takes a second copy of it, which nobody reads
+                store_chunk((c + 1) & 1);
+                load_chunk(c + 2 < n_chunks ? c + 2 : n_chunks - 1);
+            }
+            // six products per tile pair, small ones first; consecutive MFMAs go to different accumulators
+#if BS_ABL & 1
+#define BS_TERM(ACC, PA, PB)                                                                                                      \
+            _Pragma("unroll") for (int i = 0; i < WM; ++i) _Pragma("unroll") for (int j = 0; j < WN; ++j)                         \
+                asm volatile("" : "+v"(ACC[i][j]) : "v"(a[i][PA]), "v"(bcur[j][PB]));
+#else
+#define BS_TERM(ACC, PA, PB)                                                                                                      \
+            _Pragma("unroll") for (int i = 0; i < WM; ++i) _Pragma("unroll") for (int j = 0; j < WN; ++j)                         \
+                ACC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bs_bf16x8, a[i][PA]),                      \
+                                                                   __builtin_bit_cast(bs_bf16x8, bcur[j][PB]), ACC[i][j], 0, 0, 0);
+#endif
+            if constexpr (SEP) {
+                BS_TERM(accl, 0, 2) BS_TERM(acc, 0, 0) BS_TERM(accl, 2, 0) BS_TERM(accl, 1, 1) BS_TERM(accl, 0, 1) BS_TERM(accl, 1, 0)
+            } else {
+                BS_TERM(acc, 0, 2) BS_TERM(acc, 2, 0) BS_TERM(acc, 1, 1) BS_TERM(acc, 0, 1) BS_TERM(acc, 1, 0) BS_TERM(acc, 0, 0)
+            }
+#undef BS_TERM
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int s = 0; s < 3; ++s) bcur[j][s] = bnext[j][s];
         }
-    }
-    if (BS_ABL & 8) {
-#pragma unroll
-        for (int r = 0; r < ROUNDS; ++r)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { xr[r][e] = (float)(tid + e); if constexpr (UNPOOL) xi[r][e] = e & 3; }
-#pragma unroll
-        for (int r = 0; r < W_ROUNDS; ++r) wr[r] = clhip_u32x4{(unsigned)tid, 1u, 2u, 3u};
+        if (!(BS_ABL & 32)) __syncthreads();
     }
 
-    // ---- the pipeline: loader position (lu, lc) runs two stages ahead of the multiplier
-    int lu = blockIdx.x, lc = 0;
-    auto advance = [&]() {                     // -> false when the loader has passed the last stage of this block
-        if (++lc == n_chunks) { lc = 0; lu += gridDim.x; if (lu < n_units) set_loader(tile_of(lu)); }
-        return lu < n_units;
-    };
-    set_loader(tile_of(lu));
-    load_chunk(0);
-    store_chunk(0);
-    if (advance()) load_chunk(lc);
-    if (!(BS_ABL & 32)) __syncthreads();
-    int s = 0;                                                              // stage counter: its operands are in buffer s & 1
-    for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
-        const Tile T_ = tile_of(u);
-        const int kt = T_.kt, n0 = T_.n0, y0 = T_.y0, x0 = T_.x0;
-        const int nt0 = kt * (BS_BN / 32) + wn * WN;                        // first n tile of this wave (global)
-        floatx16 acc[WM][WN], accl[SEP ? WM : 1][SEP ? WN : 1];
+    if constexpr (SEP) {
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
             for (int j = 0; j < WN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    acc[i][j][r] = 0.f;
-                    if constexpr (SEP) accl[i][j][r] = 0.f;
-                }
-        for (int c = 0; c < n_chunks; ++c, ++s) {
-            const unsigned char* const lb = lds + (s & 1) * BUF;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int dr = tap / 3, ds = tap - dr * 3;
-                clhip_u32x4 a[WM][3], bq[WN][3];
-#pragma unroll
-                for (int i = 0; i < WM; ++i)
-#pragma unroll
-                    for (int q = 0; q < 3; ++q)
-                        a[i][q] = (BS_ABL & 2) ? a_fix[i][q]
-                                               : *reinterpret_cast<const clhip_u32x4*>(lb + abase[i] + (dr * P + ds) * 16 + q * 2 * G::PLANE_BYTES);
-#pragma unroll
-                for (int j = 0; j < WN; ++j)
-#pragma unroll
-                    for (int q = 0; q < 3; ++q)
-                        bq[j][q] = (BS_ABL & 2) ? b_fix[j][q] : *reinterpret_cast<const clhip_u32x4*>(lb + boff + ((j * 9 + tap) * 3 + q) * 1024);
-                // the next stage (already in registers: loaded while the previous stage was multiplied) is split and written into the
-                // other buffer from here on, between the MFMAs below; its readers passed the last barrier.  Past the block's last stage
-                // this writes stale registers into a buffer nobody reads.
-                if (tap == 5) store_chunk((s + 1) & 1);
-                // six products per tile pair, small ones first; consecutive MFMAs go to different accumulators
-#if BS_ABL & 1
-#define BS_TERM(ACC, PA, PB)                                                                                                      \
-                _Pragma("unroll") for (int i = 0; i < WM; ++i) _Pragma("unroll") for (int j = 0; j < WN; ++j)                     \
-                    asm volatile("" : "+v"(ACC[i][j]) : "v"(a[i][PA]), "v"(bq[j][PB]));
-#else
-#define BS_TERM(ACC, PA, PB)                                                                                                      \
-                _Pragma("unroll") for (int i = 0; i < WM; ++i) _Pragma("unroll") for (int j = 0; j < WN; ++j)                     \
-                    ACC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bs_bf16x8, a[i][PA]),                  \
-                                                                       __builtin_bit_cast(bs_bf16x8, bq[j][PB]), ACC[i][j], 0, 0, 0);
-#endif
-                if constexpr (SEP) {
-                    BS_TERM(accl, 0, 2) BS_TERM(acc, 0, 0) BS_TERM(accl, 2, 0) BS_TERM(accl, 1, 1) BS_TERM(accl, 0, 1) BS_TERM(accl, 1, 0)
-                } else {
-                    BS_TERM(acc, 0, 2) BS_TERM(acc, 2, 0) BS_TERM(acc, 1, 1) BS_TERM(acc, 0, 1) BS_TERM(acc, 1, 0) BS_TERM(acc, 0, 0)
-                }
-#undef BS_TERM
-            }
-            // the loads of the stage after next go out now (they have until tap 5 of the next stage to land)
-            if (lu < n_units && advance()) load_chunk(lc);
-            if (!(BS_ABL & 32)) __syncthreads();
-        }
-        if constexpr (SEP) {
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int j = 0; j < WN; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] += accl[i][j][r];
-        }
-        unsigned char* const lds_free = lds + ((s - 1) & 1) * BUF;          // the buffer the last stage has just consumed
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += accl[i][j][r];
+    }
+    const int cw = wave;
+    unsigned char* const lds_free = lds;                 // (the last barrier has passed: both staging buffers are free)
 
     // ---- epilogue: acc[i][j][4 g + q] = (pixel = window 2 g + kh of M tile i, position q; channel 32 (nt0 + j) + (lane & 31))
     const bool pool = MODE == 0 && pool_idx != nullptr;
@@ -410,14 +361,15 @@ __global__ __launch_bounds__(256, 1) void bs_conv_kernel(
     const bool fast = !odd && (W & 3) == 0 && (!pool || (OW & 3) == 0) && !(BS_ABL & 64);
     if (fast) {
         float* const T = reinterpret_cast<float*>(lds_free) + cw * (32 * TS);
-        uint8_t* const Cb = lds_free + 4 * 32 * TS * 4 + cw * (32 * 16 * WM);          // arg-max codes: [channel][pooled row][pooled column]
+        // arg-max codes [pooled row][pooled column] of a channel: behind its 8 WM pooled values, inside its own row of T
+        uint8_t* const Cb = reinterpret_cast<uint8_t*>(T + 16 * WM);
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
             const int k = (nt0 + j) * 32 + m;
             const float bv = (MODE == 0 && bias != nullptr && k < Cout) ? bias[k] : 0.f;
 #pragma unroll
             for (int i = 0; i < WM; ++i) {
-                const int di = G::SIDE_BY_SIDE ? 0 : i * G::MTH, dj = G::SIDE_BY_SIDE ? i * G::MTW : 0;     // M tile i inside the region
+                const int di = (i / G::TPR) * G::MTH, dj = (i % G::TPR) * G::MTW;                            // M tile i inside the region
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int w8 = 2 * g + kh;
@@ -434,7 +386,7 @@ __global__ __launch_bounds__(256, 1) void bs_conv_kernel(
                         if (y11 > mx) { mx = y11; am = 3; }
                         if (relu && !(mx > 0.f)) am = CLHIP_POOL_DEAD;       // ReLU folded into the code (common.hpp)
                         T[m * TS + (rr >> 1) * (RGW / 2) + (cc >> 1)] = mx;
-                        Cb[m * (16 * WM) + (rr >> 1) * (RGW / 2) + (cc >> 1)] = (uint8_t)am;
+                        Cb[m * (TS * 4) + (rr >> 1) * (RGW / 2) + (cc >> 1)] = (uint8_t)am;
                     } else {
                         *reinterpret_cast<float2*>(T + m * TS + rr * RGW + cc) = make_float2(y00, y01);
                         *reinterpret_cast<float2*>(T + m * TS + (rr + 1) * RGW + cc) = make_float2(y10, y11);
@@ -461,7 +413,7 @@ __global__ __launch_bounds__(256, 1) void bs_conv_kernel(
                     const int f = t * 64 + lane, oc = f / PH, pr = f - oc * PH;
                     const int k = kb + oc, ph = (oh0 >> 1) + pr, pw = ow0 >> 1;
                     if (f < 32 * PH && k < Cout && n_w < N && ph < OH && !(BS_ABL & 16)) {
-                        const uint8_t* src = Cb + oc * (16 * WM) + pr * PW;
+                        const uint8_t* src = Cb + oc * (TS * 4) + pr * PW;
                         uint8_t* dst = pool_idx + ((size_t)n_w * Cout + k) * OH * OW + (size_t)ph * OW + pw;
                         if (pw + PW <= OW) {
                             if constexpr (PW == 16) *reinterpret_cast<clhip_u32x4*>(dst) = *reinterpret_cast<const clhip_u32x4*>(src);
@@ -553,10 +505,6 @@ __global__ __launch_bounds__(256, 1) void bs_conv_kernel(
         }
     }
     }
-        // the transposition pieces live in a staging buffer: nobody may start writing the stage after next into it before every wave
-        // has read its piece back
-        if (u + (int)gridDim.x < n_units && !(BS_ABL & 32)) __syncthreads();
-    }
 }
 
 // CLHIP_BS=0: the layers this path would take stay on the Winograd / direct f32 kernels (A/B measurements, the parity suite's
@@ -573,24 +521,26 @@ static bool bs_on() {
 template <class G, int MODE, bool UNPOOL>
 int bs_launch_geo(const float* in, const clhip_u32x4* wimg, const float* bias, const float* mask_src, float* out, uint8_t* pool_idx,
                   int N, int Cin, int Cout, int H, int W, int relu, hipStream_t s) {
-    static const bool sep = bs_env_int("CLHIP_BS_SEP", 1) != 0;
+    // (separate accumulators only where they fit the 256 registers of a wave at two blocks per CU: wave tiles of two MFMA tiles)
+    static const bool sep_on = bs_env_int("CLHIP_BS_SEP", 1) != 0;
+    const bool sep = sep_on && G::WM * G::WN <= 2;
     const int tiles_x = (W + G::RW - 1) / G::RW, tiles_y = (H + G::RH - 1) / G::RH, groups = (N + G::NI - 1) / G::NI;
     const long long npb = (long long)tiles_x * tiles_y * groups;
     const int kts = (Cout + BS_BN - 1) / BS_BN;
-    const long long units = npb * kts;
-    if (units <= 0 || units > 0x7fffffffLL) return CLHIP_EINVAL;
-    static const int cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        return n;
-    }();
-    const long long blocks = units < cus ? units : cus;                   // one persistent block per CU (it takes the whole LDS)
-    if (sep)
-        hipLaunchKernelGGL((bs_conv_kernel<G, MODE, UNPOOL, true>), dim3((unsigned)blocks), dim3(256), 0, s, in, wimg, bias, mask_src,
-                           out, pool_idx, N, Cin, Cout, H, W, relu, tiles_x, tiles_y, (int)units);
-    else
+    const long long blocks = (npb + 7) / 8 * 8 * kts;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return CLHIP_EINVAL;
+    if constexpr (G::WM * G::WN <= 2) {
+        if (sep) {
+            hipLaunchKernelGGL((bs_conv_kernel<G, MODE, UNPOOL, true>), dim3((unsigned)blocks), dim3(256), 0, s, in, wimg, bias, mask_src,
+                               out, pool_idx, N, Cin, Cout, H, W, relu, tiles_x, tiles_y, (int)npb);
+            CLHIP_LAUNCH_CHECK();
+            return 0;
+        }
+    }
+    {
         hipLaunchKernelGGL((bs_conv_kernel<G, MODE, UNPOOL, false>), dim3((unsigned)blocks), dim3(256), 0, s, in, wimg, bias, mask_src,
-                           out, pool_idx, N, Cin, Cout, H, W, relu, tiles_x, tiles_y, (int)units);
+                           out, pool_idx, N, Cin, Cout, H, W, relu, tiles_x, tiles_y, (int)npb);
+    }
     CLHIP_LAUNCH_CHECK();
     return 0;
 }
@@ -598,10 +548,26 @@ int bs_launch_geo(const float* in, const clhip_u32x4* wimg, const float* bias, c
 template <int MODE, bool UNPOOL>
 int bs_launch(const float* in, const clhip_u32x4* wimg, const float* bias, const float* mask_src, float* out, uint8_t* pool_idx,
               int N, int Cin, int Cout, int H, int W, int relu, hipStream_t s) {
+    // CLHIP_BS_CFG (measurements): 0 = 128-pixel blocks of 64 x 32 wave tiles; 1 = 256-pixel blocks of 128 x 32 wave tiles (half the
+    // weight-operand bytes per MFMA); 2 = 256-pixel blocks of 64 x 64 wave tiles
+    static const int cfg = bs_env_int("CLHIP_BS_CFG", 1);
+    const int kts = (Cout + BS_BN - 1) / BS_BN;
+    auto enough = [&](int rw, int rh, int ni) {            // 256-pixel blocks only where they still give every CU two blocks
+        return (long long)((W + rw - 1) / rw) * ((H + rh - 1) / rh) * ((N + ni - 1) / ni) * kts >= 512;
+    };
 #define BS_GO(...) return bs_launch_geo<BsGeo<__VA_ARGS__>, MODE, UNPOOL>(in, wimg, bias, mask_src, out, pool_idx, N, Cin, Cout, H, W, relu, s)
-    if (W > 16) BS_GO(32, 4, 1, 2, 2, 1);
-    if (W > 8) BS_GO(16, 8, 1, 2, 2, 1);
-    BS_GO(8, 8, 2, 2, 2, 1);
+    if (W > 16) {
+        if (cfg == 1 && enough(32, 8, 1)) BS_GO(32, 8, 1, 2, 4, 1);
+        if (cfg == 2 && enough(32, 8, 1)) BS_GO(32, 8, 1, 4, 2, 2);
+        BS_GO(32, 4, 1, 2, 2, 1);
+    }
+    if (W > 8) {
+        if (cfg == 1 && enough(16, 16, 1)) BS_GO(16, 16, 1, 2, 4, 1);
+        if (cfg == 2 && enough(16, 16, 1)) BS_GO(16, 16, 1, 4, 2, 2);
+        BS_GO(16, 8, 1, 2, 2, 1);
+    }
+    if (cfg == 2 && enough(8, 8, 4)) BS_GO(8, 8, 4, 4, 2, 2);
+    BS_GO(8, 8, 2, 2, 2, 1);                               // (four M tiles of a wave would span two 8 x 8 images)
 #undef BS_GO
 }
 
