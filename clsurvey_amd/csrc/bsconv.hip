@@ -507,17 +507,11 @@ __global__ __launch_bounds__(256, (2 * G::BUF_BYTES <= 80 * 1024) ? 2 : 1) void 
     }
 }
 
-// CLHIP_BS=0: the layers this path would take stay on the Winograd / direct f32 kernels (A/B measurements, the parity suite's
-// second leg).  CLHIP_BS_SEP=0: one accumulator for all six products (error of an fp32 chain instead of a third of it).
+// CLHIP_BS_SEP=0: one accumulator for all six products (error of an fp32 chain instead of a third of it).
 static int bs_env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return e && e[0] ? atoi(e) : dflt;
 }
-static bool bs_on() {
-    static const bool on = bs_env_int("CLHIP_BS", 1) != 0;
-    return on;
-}
-
 template <class G, int MODE, bool UNPOOL>
 int bs_launch_geo(const float* in, const clhip_u32x4* wimg, const float* bias, const float* mask_src, float* out, uint8_t* pool_idx,
                   int N, int Cin, int Cout, int H, int W, int relu, hipStream_t s) {
@@ -548,26 +542,13 @@ int bs_launch_geo(const float* in, const clhip_u32x4* wimg, const float* bias, c
 template <int MODE, bool UNPOOL>
 int bs_launch(const float* in, const clhip_u32x4* wimg, const float* bias, const float* mask_src, float* out, uint8_t* pool_idx,
               int N, int Cin, int Cout, int H, int W, int relu, hipStream_t s) {
-    // CLHIP_BS_CFG (measurements): 0 = 128-pixel blocks of 64 x 32 wave tiles; 1 = 256-pixel blocks of 128 x 32 wave tiles (half the
-    // weight-operand bytes per MFMA); 2 = 256-pixel blocks of 64 x 64 wave tiles
-    static const int cfg = bs_env_int("CLHIP_BS_CFG", 1);
-    const int kts = (Cout + BS_BN - 1) / BS_BN;
-    auto enough = [&](int rw, int rh, int ni) {            // 256-pixel blocks only where they still give every CU two blocks
-        return (long long)((W + rw - 1) / rw) * ((H + rh - 1) / rh) * ((N + ni - 1) / ni) * kts >= 512;
-    };
+    // 128-pixel blocks of 64 x 32 wave tiles everywhere.  Measured and dropped (profiles/r05_bs_v5_per_layer_cfg*.txt, layer 2 forward /
+    // backward-data at N = 200): 256-pixel blocks of 128 x 32 wave tiles (half the weight-operand bytes per MFMA, no room for the
+    // separate accumulators) 92 / 90 us, of 64 x 64 wave tiles 95 / 96 us, against 83 / 92 us for this shape.
 #define BS_GO(...) return bs_launch_geo<BsGeo<__VA_ARGS__>, MODE, UNPOOL>(in, wimg, bias, mask_src, out, pool_idx, N, Cin, Cout, H, W, relu, s)
-    if (W > 16) {
-        if (cfg == 1 && enough(32, 8, 1)) BS_GO(32, 8, 1, 2, 4, 1);
-        if (cfg == 2 && enough(32, 8, 1)) BS_GO(32, 8, 1, 4, 2, 2);
-        BS_GO(32, 4, 1, 2, 2, 1);
-    }
-    if (W > 8) {
-        if (cfg == 1 && enough(16, 16, 1)) BS_GO(16, 16, 1, 2, 4, 1);
-        if (cfg == 2 && enough(16, 16, 1)) BS_GO(16, 16, 1, 4, 2, 2);
-        BS_GO(16, 8, 1, 2, 2, 1);
-    }
-    if (cfg == 2 && enough(8, 8, 4)) BS_GO(8, 8, 4, 4, 2, 2);
-    BS_GO(8, 8, 2, 2, 2, 1);                               // (four M tiles of a wave would span two 8 x 8 images)
+    if (W > 16) BS_GO(32, 4, 1, 2, 2, 1);
+    if (W > 8) BS_GO(16, 8, 1, 2, 2, 1);
+    BS_GO(8, 8, 2, 2, 2, 1);
 #undef BS_GO
 }
 
@@ -576,7 +557,18 @@ int bs_launch(const float* in, const clhip_u32x4* wimg, const float* bias, const
 // shapes this path takes: whole 32-channel k pairs on the input side, whole 64-channel groups on the output side; any H, W >= 4
 // (tiles past the edge stage zeros and store nothing); fused pooling / un-pooling only on even maps
 bool clhip_internal_bs_ok(int Cin, int Cout, int H, int W) {
-    return bs_on() && Cin >= 32 && Cin % 32 == 0 && Cout % 64 == 0 && H >= 4 && W >= 4;
+    return Cin >= 32 && Cin % 32 == 0 && Cout % 64 == 0 && H >= 4 && W >= 4;
+}
+
+// ... and where the plan executor prefers it to the Winograd f32 kernels (CLHIP_BS=0: nowhere; CLHIP_BS=2: wherever it can run).
+// Every block re-reads the weight operands of its 64 output channels (221 KB per 64 input channels) for its 128 pixels, so the path
+// pays where a launch has many pixels per weight: measured at N = 200 (profiles/r05_bs_v5_per_layer_cfg0.txt, us, Winograd / this):
+// 64 -> 64 @32x32 forward 100 / 83, backward-data 102 / 92; 64 -> 128 @32x32 158 / 144, 163 / 156; at 16 x 16 within 1 - 2 us either
+// way; at 8 x 8 and from 256 channels on backward-data is 5 - 20 % slower.
+bool clhip_internal_bs_preferred(int Cin, int Cout, int H, int W) {
+    static const int mode = bs_env_int("CLHIP_BS", 1);
+    if (mode == 0 || !clhip_internal_bs_ok(Cin, Cout, H, W)) return false;
+    return mode == 2 || ((long long)H * W >= 1024 && Cin <= 128 && Cout <= 128);
 }
 
 size_t clhip_internal_bs_ws(int Cin, int Cout) {

@@ -232,11 +232,12 @@ int clhip_net_create(const clhip_layer_desc* descs, int n_layers, int max_batch,
                 const bool wino = wino_enabled();
                 L.wino_f = wino && clhip_internal_wino_ok(L.cin, L.cout, L.h, L.w) && enough(L.cout);
                 L.wino_d = wino && i > 0 && clhip_internal_wino_ok(L.cout, L.cin, L.h, L.w) && enough(L.cin);
-                // bf16 matrix cores with split fp32 operands (bsconv.hip; CLHIP_BS=0 turns it off): every 3x3 layer of its shape domain;
-                // fused 2x2 pooling only exists on even maps there
+                // bf16 matrix cores with split fp32 operands (bsconv.hip) where that path is the faster one (large maps: see
+                // clhip_internal_bs_preferred; CLHIP_BS=0 turns it off, =2 takes it wherever it can run); fused 2x2 pooling only exists
+                // on even maps there
                 const bool even = ((L.h | L.w) & 1) == 0;
-                L.bs_f = clhip_internal_bs_ok(L.cin, L.cout, L.h, L.w) && (even || !L.pool);
-                L.bs_d = i > 0 && clhip_internal_bs_ok(L.cout, L.cin, L.h, L.w) && (even || !L.pool);
+                L.bs_f = clhip_internal_bs_preferred(L.cin, L.cout, L.h, L.w) && (even || !L.pool);
+                L.bs_d = i > 0 && clhip_internal_bs_preferred(L.cout, L.cin, L.h, L.w) && (even || !L.pool);
                 if (L.bs_f) L.wino_f = 1;
                 if (L.bs_d) L.wino_d = 1;
                 // weight gradient: the reduction (tiles) splits over ~256 blocks per 64x64 (k, c) tile; each block needs a

@@ -187,3 +187,16 @@ def test_bs_weight_image_is_an_exact_split():
         assert torch.equal(val.sum(0), want)
         assert torch.equal(val[0].float(), want.float().to(torch.bfloat16).float())
         assert torch.equal(val[1].float(), (want - val[0]).float().to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize("mode", ["0", "2"])
+def test_engine_parity_with_bs_off_and_everywhere(mode):
+    """CLHIP_BS (read once per process by the plan builder): 0 = no layer takes the bf16-split kernels, 2 = every layer that can
+    (default 1: the large maps only).  The engine's own parity tests — golden G1 and the full-size small_VGG9 step against the
+    oracle — must hold on both sides of the switch."""
+    env = dict(os.environ, CLHIP_BS=mode)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q",
+                        "-p", "no:cacheprovider", "-k", "golden_g1 or (full_size_vs_oracle and small) or fused_conv_relu_pool"],
+                       env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout

@@ -1,7 +1,8 @@
 """End-to-end agreement where agreement is possible (north_star: "per-task accuracies, forgetting ... match the reference CPU
 path"): the EWC task recipe (main_EWC.py:14-76, train_EWC.py:23-86,164-197) on runners that share start model, importance
-weights, fresh head and every batch — the HIP path (default kernels: Winograd F(2x2,3x3) on the 3x3 layers; and with
-CLHIP_WINO=0: direct MFMA kernels), the fp32 CPU oracle at two thread counts, the fp64 oracle.
+weights, fresh head and every batch — the HIP path (default kernels: bf16-split convolutions on the large maps, Winograd F(2x2,3x3)
+on the other 3x3 layers; with CLHIP_BS=2 / 0: the bf16-split kernels wherever they can run / nowhere; with CLHIP_WINO=0
+CLHIP_BS=0: direct f32 MFMA kernels), the fp32 CPU oracle at two thread counts, the fp64 oracle.
 
 Penalised training amplifies rounding (tests/trajectory.py): measured on this recipe, the fp32 CPU runs themselves end 3e-3
 (relative l2) away from the fp64 run after 240 steps having been 1e-7 .. 2e-5 away after 20 — and which of the two it is
@@ -42,7 +43,10 @@ def test_trajectory_separation_vs_fp64():
         runs["cpu_fp32_t%d" % t] = T.run_oracle(prob, torch.float32, t, LAM, LR)
     runs["cpu_fp32_displaced_1e-6"] = T.run_oracle(prob, torch.float32, threads[-1], LAM, LR, perturb=1e-6)
     runs["gpu"] = T.run_gpu(prob, LAM, LR)
-    runs["gpu_direct_kernels"] = T.run_gpu_in_subprocess(prob, runs["fp64"], LAM, LR, {"CLHIP_WINO": "0"})
+    runs["gpu_direct_kernels"] = T.run_gpu_in_subprocess(prob, runs["fp64"], LAM, LR, {"CLHIP_WINO": "0", "CLHIP_BS": "0"})
+    # the bf16-split convolutions (csrc/bsconv.hip) on every layer they can run / on none (default: on the large maps only)
+    runs["gpu_bs_everywhere"] = T.run_gpu_in_subprocess(prob, runs["fp64"], LAM, LR, {"CLHIP_BS": "2"})
+    runs["gpu_bs_nowhere"] = T.run_gpu_in_subprocess(prob, runs["fp64"], LAM, LR, {"CLHIP_BS": "0"})
     text, seps = T.table(runs)
     print(text)
     cpu = [n for n in runs if n.startswith("cpu_")]
