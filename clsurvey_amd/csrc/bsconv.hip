@@ -151,8 +151,9 @@ struct BsGeo {
     static_assert(4 * 32 * TS * 4 <= 2 * BUF_BYTES, "transposition buffers fit the staging LDS");
 };
 
-// SEP: the product of the leading pieces a0 b0 and the five small products are summed in accumulators of their own (added once, in
-// the epilogue): measured 3x less error than one accumulator, i.e. 3x less than an fp32 fmaf chain (profiles/r05_bf16_split_dot.txt).
+// The product of the leading pieces a0 b0 and the five small products are summed in accumulators of their own (added once, in the
+// epilogue): measured 3x less error than one accumulator, i.e. 3x less than an fp32 fmaf chain (profiles/r05_bf16_split_dot.txt), at
+// the same speed (profiles/r05_bs_v2_per_layer.txt and the single-accumulator run of the same session).
 //
 // What was measured on the way here (layer 2 of the bench net, 64 -> 64 @ 32 x 32, N = 200; matrix floor 36 us at 2.5 PF, ~43 us at the
 // clock the pipe sustains; Winograd f32 kernel 95 - 100 us in the same sessions):
@@ -164,7 +165,7 @@ struct BsGeo {
 //   v4  persistent one-wave-per-SIMD blocks, one in-wave pipeline over (tile, chunk) stages: 121 us, matrix + reads 76, staging + reads 76.
 // In every form the non-matrix work ADDS to the matrix time; what differs is how much of it there is per MFMA.  This form keeps v1's
 // structure (no weight bytes through VALU / LDS-write at all) and halves its load on the vector-memory path with 128 x 32 wave tiles.
-template <class G, int MODE, bool UNPOOL, bool SEP>
+template <class G, int MODE, bool UNPOOL>
 __global__ __launch_bounds__(256, (2 * G::BUF_BYTES <= 80 * 1024) ? 2 : 1) void bs_conv_kernel(
     const float* __restrict__ in, const clhip_u32x4* __restrict__ wimg, const float* __restrict__ bias,
     const float* __restrict__ mask_src, float* __restrict__ out, uint8_t* __restrict__ pool_idx, int N, int Cin, int Cout, int H,
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(256, (2 * G::BUF_BYTES <= 80 * 1024) ? 2 : 1) void 
             for (int s = 0; s < 3; ++s) bq[j][s] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wvoff[j], so + s * 1024, 0);
     };
 
-    floatx16 acc[WM][WN], accl[SEP ? WM : 1][SEP ? WN : 1];
+    floatx16 acc[WM][WN], accl[WM][WN];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(256, (2 * G::BUF_BYTES <= 80 * 1024) ? 2 : 1) void 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 acc[i][j][r] = 0.f;
-                if constexpr (SEP) accl[i][j][r] = 0.f;
+                accl[i][j][r] = 0.f;
             }
 
     // ---- prologue: chunk 0 in LDS, chunk 1 in flight, first weight operands in flight
@@ -319,11 +320,7 @@ __global__ __launch_bounds__(256, (2 * G::BUF_BYTES <= 80 * 1024) ? 2 : 1) void 
                 ACC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bs_bf16x8, a[i][PA]),                      \
                                                                    __builtin_bit_cast(bs_bf16x8, bcur[j][PB]), ACC[i][j], 0, 0, 0);
 #endif
-            if constexpr (SEP) {
-                BS_TERM(accl, 0, 2) BS_TERM(acc, 0, 0) BS_TERM(accl, 2, 0) BS_TERM(accl, 1, 1) BS_TERM(accl, 0, 1) BS_TERM(accl, 1, 0)
-            } else {
-                BS_TERM(acc, 0, 2) BS_TERM(acc, 2, 0) BS_TERM(acc, 1, 1) BS_TERM(acc, 0, 1) BS_TERM(acc, 1, 0) BS_TERM(acc, 0, 0)
-            }
+            BS_TERM(accl, 0, 2) BS_TERM(acc, 0, 0) BS_TERM(accl, 2, 0) BS_TERM(accl, 1, 1) BS_TERM(accl, 0, 1) BS_TERM(accl, 1, 0)
 #undef BS_TERM
 #pragma unroll
             for (int j = 0; j < WN; ++j)
@@ -333,14 +330,12 @@ __global__ __launch_bounds__(256, (2 * G::BUF_BYTES <= 80 * 1024) ? 2 : 1) void 
         if (!(BS_ABL & 32)) __syncthreads();
     }
 
-    if constexpr (SEP) {
 #pragma unroll
-        for (int i = 0; i < WM; ++i)
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
-            for (int j = 0; j < WN; ++j)
+        for (int j = 0; j < WN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] += accl[i][j][r];
-    }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += accl[i][j][r];
     const int cw = wave;
     unsigned char* const lds_free = lds;                 // (the last barrier has passed: both staging buffers are free)
 
@@ -507,34 +502,21 @@ __global__ __launch_bounds__(256, (2 * G::BUF_BYTES <= 80 * 1024) ? 2 : 1) void 
     }
 }
 
-// CLHIP_BS_SEP=0: one accumulator for all six products (error of an fp32 chain instead of a third of it).
 static int bs_env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return e && e[0] ? atoi(e) : dflt;
 }
+
 template <class G, int MODE, bool UNPOOL>
 int bs_launch_geo(const float* in, const clhip_u32x4* wimg, const float* bias, const float* mask_src, float* out, uint8_t* pool_idx,
                   int N, int Cin, int Cout, int H, int W, int relu, hipStream_t s) {
-    // (separate accumulators only where they fit the 256 registers of a wave at two blocks per CU: wave tiles of two MFMA tiles)
-    static const bool sep_on = bs_env_int("CLHIP_BS_SEP", 1) != 0;
-    const bool sep = sep_on && G::WM * G::WN <= 2;
     const int tiles_x = (W + G::RW - 1) / G::RW, tiles_y = (H + G::RH - 1) / G::RH, groups = (N + G::NI - 1) / G::NI;
     const long long npb = (long long)tiles_x * tiles_y * groups;
     const int kts = (Cout + BS_BN - 1) / BS_BN;
     const long long blocks = (npb + 7) / 8 * 8 * kts;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return CLHIP_EINVAL;
-    if constexpr (G::WM * G::WN <= 2) {
-        if (sep) {
-            hipLaunchKernelGGL((bs_conv_kernel<G, MODE, UNPOOL, true>), dim3((unsigned)blocks), dim3(256), 0, s, in, wimg, bias, mask_src,
-                               out, pool_idx, N, Cin, Cout, H, W, relu, tiles_x, tiles_y, (int)npb);
-            CLHIP_LAUNCH_CHECK();
-            return 0;
-        }
-    }
-    {
-        hipLaunchKernelGGL((bs_conv_kernel<G, MODE, UNPOOL, false>), dim3((unsigned)blocks), dim3(256), 0, s, in, wimg, bias, mask_src,
-                           out, pool_idx, N, Cin, Cout, H, W, relu, tiles_x, tiles_y, (int)npb);
-    }
+    hipLaunchKernelGGL((bs_conv_kernel<G, MODE, UNPOOL>), dim3((unsigned)blocks), dim3(256), 0, s, in, wimg, bias, mask_src, out,
+                       pool_idx, N, Cin, Cout, H, W, relu, tiles_x, tiles_y, (int)npb);
     CLHIP_LAUNCH_CHECK();
     return 0;
 }
@@ -544,7 +526,7 @@ int bs_launch(const float* in, const clhip_u32x4* wimg, const float* bias, const
               int N, int Cin, int Cout, int H, int W, int relu, hipStream_t s) {
     // 128-pixel blocks of 64 x 32 wave tiles everywhere.  Measured and dropped (profiles/r05_bs_v5_per_layer_cfg*.txt, layer 2 forward /
     // backward-data at N = 200): 256-pixel blocks of 128 x 32 wave tiles (half the weight-operand bytes per MFMA, no room for the
-    // separate accumulators) 92 / 90 us, of 64 x 64 wave tiles 95 / 96 us, against 83 / 92 us for this shape.
+    // separate accumulators at two blocks per CU) 92 / 90 us, of 64 x 64 wave tiles 95 / 96 us, against 83 / 92 us for this shape.
 #define BS_GO(...) return bs_launch_geo<BsGeo<__VA_ARGS__>, MODE, UNPOOL>(in, wimg, bias, mask_src, out, pool_idx, N, Cin, Cout, H, W, relu, s)
     if (W > 16) BS_GO(32, 4, 1, 2, 2, 1);
     if (W > 8) BS_GO(16, 8, 1, 2, 2, 1);

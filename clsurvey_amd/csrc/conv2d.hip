@@ -409,11 +409,8 @@ int wgrad_splits(int M, int Nn, long Kd) {
     return (int)s;
 }
 
-// CLHIP_CONVKK=0 keeps every layer on the gather-GEMM (A/B measurements)
-bool halo_kernel() {
-    static const bool on = [] { const char* e = getenv("CLHIP_CONVKK"); return !(e && e[0] == '0'); }();
-    return on;
-}
+// (the LDS-halo kernel of convkk.hip wherever its shape domain allows; the gather-GEMM serves the rest)
+bool halo_kernel() { return true; }
 
 }  // namespace
 

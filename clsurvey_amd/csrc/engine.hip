@@ -53,10 +53,7 @@ struct LayerPlan {
 constexpr long long WINO_MIN_UNITS = 640;
 constexpr long long WINO16_MIN_UNITS = 384;      // waves of the 8 x 8 variant (wino.hip, wino_conv16_kernel)
 // CLHIP_WINO=0 keeps every layer on the direct kernels (A/B measurements, triage)
-static bool wino_small_wgrad() {
-    static const bool on = [] { const char* e = getenv("CLHIP_WINO_WGRAD_SMALL"); return !(e && e[0] == '0'); }();
-    return on;
-}
+static bool wino_small_wgrad() { return true; }      // (layers with few stages per block: wino_wgrad_ps_kernel, wino.hip)
 
 static bool wino_enabled() {
     const char* e = std::getenv("CLHIP_WINO");
@@ -247,7 +244,7 @@ int clhip_net_create(const clhip_layer_desc* descs, int n_layers, int max_batch,
                     const long long stages = (long long)max_batch * (((L.w + 1) / 2 + (L.w >= 16 ? 7 : 3)) / (L.w >= 16 ? 8 : 4)) *
                                              (((L.h + 1) / 2 + (L.w >= 16 ? 1 : 3)) / (L.w >= 16 ? 2 : 4));
                     // (fewer stages per block: wino_wgrad_ps_kernel — 32 x 32 tiles, a quarter of the splits — inside the same entry point;
-                    // CLHIP_WINO_WGRAD_SMALL=0 keeps those layers on the direct pixel-split kernel)
+                    // measured faster than the direct pixel-split kernel on those layers in round 3)
                     L.wino_w = stages >= 8LL * splits || wino_small_wgrad();
                     if (L.wino_w) {                   // its slabs live in this layer's weight-gradient region
                         const size_t ww = clhip_internal_wino_wgrad_ws(max_batch, L.cin, L.cout, L.h, L.w);

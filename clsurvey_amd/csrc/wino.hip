@@ -24,7 +24,7 @@
 // Kernels of this file, in the order they were built (all share the U layout and the weight-transform launch):
 //   wino_weight_kernel / wino_weight_multi_kernel   U = G g G^T (one layer / every Winograd layer of a pass in one launch)
 //   wino_conv_kernel        forward / backward-data, 32-tile waves on 32x32x2 MFMAs, slot-pinned pipeline — the A/B reference
-//                           behind CLHIP_WINO16G=0 since the 16-tile kernel below is faster on every shape
+//                           kept for the shapes the 16-tile kernel below does not take (odd maps wider than 8 tiles, maps narrower than 16 other than 8 x 8)
 //   wino_wgrad_kernel       weight gradient, 64 x 64 (k, c) tiles, 256 accumulators, slot-pinned — layers with >= 8 stages per block
 //   wino_conv16_kernel      forward / backward-data of 8 x 8 maps with few units: one image per wave on 16x16x4 MFMAs
 //   wino_conv16g_kernel     forward / backward-data, 16-tile waves on 16x16x4 MFMAs, two blocks per CU — the DEFAULT path
@@ -1403,12 +1403,9 @@ __global__ __launch_bounds__(256, 2) void wino_conv16g_kernel(
     }
 }
 
-// CLHIP_WINO16G=0 keeps even maps >= 16 wide on the 32-tile kernel (A/B measurements; N = 200: 64->64 @32x32 forward 126 -> 109 us,
+// (measured against the 32-tile kernel on even maps >= 16 wide in round 3: N = 200: 64->64 @32x32 forward 126 -> 109 us,
 // backward-data 136 -> 110; 256->256 @16x16 357 -> 317 = 190 TFLOP/s algorithmic)
-static bool wino16g_on() {
-    static const bool on = [] { const char* e = getenv("CLHIP_WINO16G"); return !(e && e[0] == '0'); }();
-    return on;
-}
+static bool wino16g_on() { return true; }
 
 // units of the 32-tile kernel a layer has; below this the 8 x 8 variant takes 8 x 8 maps
 #ifndef CLHIP_WINO16_BELOW_UNITS
@@ -1747,11 +1744,7 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_ps_kernel(
     }
 }
 
-// CLHIP_WGRAD_PS=0 keeps small layers off the pixel-split Winograd weight gradient (A/B measurements)
-static bool wgrad_ps_on() {
-    static const bool on = [] { const char* e = getenv("CLHIP_WGRAD_PS"); return !(e && e[0] == '0'); }();
-    return on;
-}
+static bool wgrad_ps_on() { return true; }       // (small layers: the pixel-split Winograd weight gradient, wino_wgrad_ps_kernel)
 
 template <int MODE, bool UNPOOL>
 int launch_wino(const float* in, const float* U, const float* bias, const float* mask_src, float* out, uint8_t* pool_idx,
@@ -1798,21 +1791,9 @@ int launch_wino(const float* in, const float* U, const float* bias, const float*
         hipLaunchKernelGGL((wino_conv_kernel<TCB_, TRB_, NIMG_, MODE, UNPOOL>), dim3((unsigned)blocks), dim3(256), 0, s, in, U, \
                            bias, mask_src, out, pool_idx, N, Cin, Cout, H, W, relu, tiles_w, tiles_h, (int)npb);              \
     } while (0)
-    if constexpr (!UNPOOL) {
-        if (((H | W) & 1) && W <= 16) {
-            // odd maps up to 16 wide (AlexNet's 13 x 13): 8 consecutive tile rows of the (image, tile row) list per block
-            const int trt = (H + 1) / 2;
-            const long long npb = ((long long)N * trt + 7) / 8, blocks = npb * kts;
-            if (blocks <= 0 || blocks > 0x7fffffffLL) return CLHIP_EINVAL;
-            hipLaunchKernelGGL((wino_conv_kernel<8, 1, 8, MODE, false, true>), dim3((unsigned)blocks), dim3(256), 0, s, in, U, bias,
-                               mask_src, out, nullptr, N, Cin, Cout, H, W, relu, 1, trt, (int)npb);
-            CLHIP_LAUNCH_CHECK();
-            return 0;
-        }
-    }
-    if (W >= 32) WINO_GEO(16, 4, 1);
-    else if (W >= 16) WINO_GEO(8, 8, 1);
-    else WINO_GEO(4, 4, 4);
+    // what is left for the 32-tile kernel: even maps narrower than 16 other than 8 x 8 (the 16-tile kernel above took every other shape
+    // of clhip_internal_wino_ok: even maps >= 16 wide, 8 x 8 maps, odd maps up to 16 wide)
+    WINO_GEO(4, 4, 4);
 #undef WINO_GEO
     CLHIP_LAUNCH_CHECK();
     return 0;
@@ -1922,9 +1903,8 @@ int clhip_internal_wino_wgrad_partial(const float* x, const float* dy, const uin
         if (sp > total) sp = total;
         if (sp > cap) sp = cap;
         const unsigned gridp = (unsigned)(kc32 * sp);
-        // whole tiles in width and 16-byte-aligned tensors: stages staged in 16-byte pieces (VEC; CLHIP_WGPS_VEC=0: the scalar form)
-        static const bool vec_on = [] { const char* e = getenv("CLHIP_WGPS_VEC"); return !(e && e[0] == '0'); }();
-        const bool vec = vec_on && W % (2 * TCS) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
+        // whole tiles in width and 16-byte-aligned tensors: stages staged in 16-byte pieces (VEC; other shapes: the scalar form)
+        const bool vec = W % (2 * TCS) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
 #define WGP(TCS_, TRS_, UNP_)                                                                                                       \
         do {                                                                                                                       \
             if (vec) hipLaunchKernelGGL((wino_wgrad_ps_kernel<TCS_, TRS_, UNP_, true>), dim3(gridp), dim3(256), 0, s, x, dy, part,  \
@@ -1940,9 +1920,8 @@ int clhip_internal_wino_wgrad_partial(const float* x, const float* dy, const uin
         return 0;
     }
     const unsigned grid = (unsigned)(kc_tiles * splits);
-    // whole tiles in width and 16-byte-aligned tensors: stages staged in 16-byte pieces (VEC; CLHIP_WG_VEC=0: the scalar form)
-    static const bool vecg_on = [] { const char* e = getenv("CLHIP_WG_VEC"); return !(e && e[0] == '0'); }();
-    const bool vecg = vecg_on && W % (2 * TCS) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
+    // whole tiles in width and 16-byte-aligned tensors: stages staged in 16-byte pieces (VEC; other shapes: the scalar form)
+    const bool vecg = W % (2 * TCS) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
 #define WG(TCS_, TRS_, UNP_)                                                                                                         \
     do {                                                                                                                            \
         if (vecg) hipLaunchKernelGGL((wino_wgrad_kernel<TCS_, TRS_, 1, UNP_, true>), dim3(grid), dim3(256), 0, s, x, dy, part,       \

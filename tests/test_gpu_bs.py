@@ -52,17 +52,6 @@ def test_bs_forward_and_backward_data(shape):
     _run((shape,))
 
 
-def test_bs_single_accumulator_leg():
-    """CLHIP_BS_SEP=0 (all six products in one accumulator; read once per process, so this leg runs in a subprocess): the same
-    checks on the small shapes and one bench shape."""
-    shapes = tuple(sh for sh in SHAPES if sh[0] < 100) + ((200, 64, 64, 16, 16),)
-    env = dict(os.environ, CLHIP_BS_SEP="0")
-    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_bs as T; T._run(%r)"
-            % (ROOT, os.path.join(ROOT, "tests"), shapes))
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-
-
 def _run(shapes):
     from clsurvey_amd import ops
     for shape in shapes:
@@ -197,6 +186,19 @@ def test_engine_parity_with_bs_off_and_everywhere(mode):
     env = dict(os.environ, CLHIP_BS=mode)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q",
                         "-p", "no:cacheprovider", "-k", "golden_g1 or (full_size_vs_oracle and small) or fused_conv_relu_pool"],
+                       env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_engine_parity_with_weight_gradients_on_a_side_stream(mode):
+    """CLHIP_WGRAD_OVERLAP (read at plan creation): 1 = the weight-gradient launches of every conv layer on a side stream, 2 = of
+    the small-map layers only (default 0: one stream; measured slower).  Same kernels, same order per stream: the engine's
+    parity tests must hold, and the weight gradients stay bitwise deterministic."""
+    env = dict(os.environ, CLHIP_WGRAD_OVERLAP=mode)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q",
+                        "-p", "no:cacheprovider", "-k", "golden_g1 or (full_size_vs_oracle and small) or deterministic"],
                        env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout

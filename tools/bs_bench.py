@@ -1,6 +1,6 @@
 """Per-layer timing of the bf16-split conv kernels (csrc/bsconv.hip) next to the Winograd f32 kernels on the 3x3 layers of the three
 VGG9 widths at N = 200 (HIP events, 20 launches, best of 3): forward (+ fused ReLU / pool where the net has it), backward-data plain
-and from the pooled gradient.  CLHIP_BS_SEP=0: one accumulator (one process per setting)."""
+and from the pooled gradient."""
 import os
 import sys
 
@@ -34,7 +34,7 @@ def timed(fn, iters=20):
 def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     dev = torch.device("cuda:0")
-    print("N = %d, CLHIP_BS_SEP = %s   (us: wino / bs; floor = bf16 pipe at 2.5 PF x 1/6)" % (N, os.environ.get("CLHIP_BS_SEP", "1")))
+    print("N = %d   (us: wino / bs; floor = bf16 pipe at 2.5 PF x 1/6)" % N)
     tot = {"wino": 0.0, "bs": 0.0}
     for C, K, H, pool in LAYERS:
         x = torch.randn(N, C, H, H, device=dev).relu_()
