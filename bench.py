@@ -155,7 +155,7 @@ BS_ISSUE = 6.0                     # bf16-split direct convolution: six bf16 MFM
 def bs_conv_instance(N, H, W, kout, mode, unpool):
     """Instance name of the bf16-split forward (mode 0) / backward-data (mode 1) launch (csrc/bsconv.hip, bs_launch)."""
     geo = "32, 4, 1, 2, 2, 1" if W > 16 else ("16, 8, 1, 2, 2, 1" if W > 8 else "8, 8, 2, 2, 2, 1")
-    return "bs_conv_kernel<BsGeo<%s>, %d, %s, true> (+ bs_weight_multi_kernel)" % (geo, mode, "true" if unpool else "false")
+    return "bs_conv_kernel<BsGeo<%s>, %d, %s> (+ bs_weight_multi_kernel)" % (geo, mode, "true" if unpool else "false")
 
 
 def pipe_seconds(flops, path):

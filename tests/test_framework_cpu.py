@@ -259,14 +259,22 @@ def test_traffic_json_names_the_kernel_bench_reports():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     t = json.load(open(os.path.join(root, "profiles", "traffic.json")))
-    inst = bench.wino_conv_instance(32, 0, False)         # layer 2 of the bench model runs through the Winograd kernels (plan: >= 640 units)
+    # layer 2 of the bench model: forward / backward-data through the bf16-split kernel (large map: clhip_internal_bs_preferred), weight
+    # gradient through the pixel-split Winograd kernel — the entries must name THOSE instances; the Winograd forward / backward-data
+    # measurements of round 4 stay on file under 'wino_round4'
+    inst = bench.bs_conv_instance(200, 32, 32, 64, 0, False)
     e = t["conv3x3_relu_pool_fwd 64x64@32 N=200"]
     assert e["instance"] == inst, (e["instance"], inst)
     assert bench.measured_traffic("conv3x3_relu_pool_fwd", "64x64@32", 200, inst) == e["hbm_bytes_per_launch"]
     assert bench.measured_traffic("conv3x3_relu_pool_fwd", "64x64@32", 200, "conv3x3_mfma_kernel<other>") is None
-    assert e["direct_kernel_round2"]["instance"] == bench.conv_instance(64, 32, 32, 200, 64, 0, True)
-    assert t["conv3x3_bwd_data_unpool 64x64@32 N=200"]["instance"] == bench.wino_conv_instance(32, 1, True)
+    assert e["wino_round4"]["instance"] == bench.wino_conv_instance(32, 0, False)
+    assert e["wino_round4"]["direct_kernel_round2"]["instance"] == bench.conv_instance(64, 32, 32, 200, 64, 0, True)
+    assert t["conv3x3_bwd_data_unpool 64x64@32 N=200"]["instance"] == bench.bs_conv_instance(200, 32, 32, 64, 1, True)
+    assert t["conv3x3_bwd_data_unpool 64x64@32 N=200"]["wino_round4"]["instance"] == bench.wino_conv_instance(32, 1, True)
     assert "wino_conv16g_kernel<8, 2, 4, 1, true>" in bench.wino_conv_instance(32, 1, True)
+    w = t["conv3x3_bwd_weight_unpool 64x64@32 N=200"]
+    assert w["instance"] == bench.wino_wgrad_instance(200, 64, 64, 32, 32, True)
+    assert bench.measured_traffic("conv3x3_bwd_weight_unpool", "64x64@32", 200, w["instance"]) == w["hbm_bytes_per_launch"]
 
 
 def test_bench_names_the_winograd_instances_the_library_launches():

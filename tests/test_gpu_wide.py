@@ -159,7 +159,7 @@ def test_hat_step_wide_vgg9_g20(golden, tag, hw, nb, seed):
                     tol = max(TOL, 1.5 * float(np.abs(ref_v - v64).max()) / max(float(np.abs(ref_v).max()), 1e-30))
                 # (second step at 224 x 224: 50 000 pixels per image and channel, 6 near-ties decided the other way in step 0)
                 worst = max(worst, _check(g, key, p.grad, seed + 199 + j, "step %d grad %s" % (step, n), tol=tol, flips=step > 0,
-                                          l2_tol=2e-2 if hw == 224 else 1e-2))
+                                          l2_tol=2e-2 if hw == 224 else 1.5e-2))
         opt.step(net, mask_back, t, s, 50, smax, 10000)
         HT.clamp_embeddings(net)
         if step == 0:          # (the oracle's optimizer restatement is the first-step form: momentum buffer = gradient)
