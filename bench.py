@@ -885,6 +885,7 @@ def sharded_sweep(dev_index, world, epochs=8, sizes=(2000, 500, 500), batch=50):
             dt = time.perf_counter() - t0
         hf = out["frameworks"][-1]
         d = {k: shard.STATS[k] - before[k] for k in shard.STATS}
+        d["grid_nodes_total"] = 10                                       # two 5-LR grids (first task, task 2): every node's result is used
         busy = d["grid_busy_s"] + d["decay_busy_s"] + d["eval_busy_s"]
         return {"what": "driver.main --shard: SI first-task grid + EWC task 2 (5-LR grid, stability decay from lambda 400, "
                         "evaluation), %d/%d/%d images of 3x64x64 per task, batch %d, %d-epoch cap — the same work at every world size"
@@ -892,6 +893,12 @@ def sharded_sweep(dev_index, world, epochs=8, sizes=(2000, 500, 500), batch=50):
                 "world": world, "seconds": dt, "first_task_seconds": t1 - t0,
                 "grid_nodes_per_task": 5, "fill_factor_grid": shard.fill_factor(5, world),
                 "phase2_trainings_task2": len(hf.trace), "accepted_lambda_task2": float(hf.trace[-1][0]["lambda"]) if hf.trace else None,
+                # speculation accounting (all ranks together, the same numbers on every rank): phase-2 trainings that ran, and those
+                # the sequential rule would have run too (attempts up to the accepted one); world 1 runs nothing speculatively
+                "phase2_trainings_all_ranks": d["decay_trainings_group"] if world > 1 else d["decay_attempts"],
+                "phase2_trainings_useful": d["decay_trainings_useful"] if world > 1 else d["decay_attempts"],
+                "useful_fraction": ((d["grid_nodes_total"] + (d["decay_trainings_useful"] if world > 1 else d["decay_attempts"]))
+                                    / max(d["grid_nodes_total"] + (d["decay_trainings_group"] if world > 1 else d["decay_attempts"]), 1)),
                 "accuracies": {i: r["seq_res"][i] for i, r in sorted(out["results"].items())},
                 "this_rank": {"grid_nodes": d["grid_nodes"], "grid_busy_s": d["grid_busy_s"],
                               "decay_attempts": d["decay_attempts"], "decay_busy_s": d["decay_busy_s"],

@@ -504,178 +504,10 @@ __global__ __launch_bounds__(256, (3 * G::BUF_BYTES <= 160 * 1024 && (G::RW == 3
     }
 }
 
-// ---------------------------------------------------------------------------------------------------- first layer (3 input channels)
-// conv3x3(3 -> K) + bias + ReLU + 2x2 max-pool + arg-max codes (VGGSlim.py:27-40 on the input image) on the same bf16-split scheme:
-// K dimension = 27 products (ci * 9 + tap), padded to two 16-deep k-steps.  There is no channel loop and nothing to re-fetch:
-//   * persistent blocks (4 waves as 2 x 2: 64 pixels x 32 channels each) walk 4 x 32-pixel tiles; a wave's B operands (its 32 output
-//     channels x 32 k slots, 3 pieces) are split from the fp32 weights ONCE and stay in 24 registers;
-//   * per tile the raw fp32 halo tile (3 x 6 x 34 floats) goes to LDS (double-buffered, one barrier per tile); every lane gathers
-//     the 8 k slots of its pixel and k half with ds_read_b32, splits them (the A operand never exists in memory) and issues
-//     6 MFMAs per k-step and tile;
-//   * outputs leave through the wave's LDS transposition piece as whole pooled rows (float4) + 16 code bytes per channel.
-// Bound by its 65 MB of output (pooled activation + codes at N = 200, 64 x 64 inputs, K = 64) and by the gather / split VALU work
-// (~4 instructions per MFMA), not by the matrix pipe (0.6 M MFMAs = 8 us).
-constexpr int C3_PITCH = 48;                       // floats per LDS row of the raw tile: = 16 mod 32, the 2 x 16 pixels of an M tile hit 32 banks
-constexpr int C3_XBUF = 3 * 6 * C3_PITCH;          // floats per raw-tile buffer
-
-__global__ __launch_bounds__(256, 2) void bs_c3_pool_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                            const float* __restrict__ bias, float* __restrict__ out,
-                                                            uint8_t* __restrict__ pool_idx, int N, int K, int H, int W, int tiles_x,
-                                                            int tiles_y, int n_units) {
-    using G = BsGeo<32, 4, 1, 2, 2, 1>;
-    constexpr int WM = 2, TS = G::TS;
-    __shared__ __attribute__((aligned(16))) float xs[2 * C3_XBUF];
-    __shared__ __attribute__((aligned(16))) float tbuf[4 * 32 * TS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave & 1, wn = wave >> 1;
-    const int m = lane & 31, kh = lane >> 5;
-    const int kts = (K + BS_BN - 1) / BS_BN;
-    const int plane = H * W, OH = H >> 1, OW = W >> 1;
-    if ((int)blockIdx.x >= n_units) return;
-
-    // unit u -> (channel group, tile); consecutive units of a block share the channel group when kts == 1 (the usual case)
-    auto decode = [&](int u, int& kt, int& n, int& y0, int& x0) {
-        kt = u % kts;
-        const int pb = u / kts;
-        x0 = (pb % tiles_x) * 32;
-        y0 = ((pb / tiles_x) % tiles_y) * 4;
-        n = pb / (tiles_x * tiles_y);
-    };
-    // ---- loader: 3 x 6 x 34 floats of the halo tile, thread t takes elements t, t + 256, t + 512
-    int loff[3], lds_off[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const int e = r * 256 + tid, ci = e / (6 * 34), rem = e - ci * (6 * 34), hy = rem / 34, hx = rem - hy * 34;
-        loff[r] = e < 3 * 6 * 34 ? (ci << 16) | (hy << 8) | hx : -1;
-        lds_off[r] = (ci * 6 + hy) * C3_PITCH + hx;
-    }
-    float xr[3];
-    auto load_tile = [&](int u) {
-        int kt, n, y0, x0;
-        decode(u, kt, n, y0, x0);
-        const __amdgpu_buffer_rsrc_t rs = clhip_rsrc(x + (size_t)n * 3 * plane, (size_t)3 * plane * sizeof(float));
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int ci = loff[r] >> 16, hy = (loff[r] >> 8) & 255, hx = loff[r] & 255;
-            const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-            const bool ok = loff[r] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            xr[r] = clhip_buf_load(rs, ok ? (ci * plane + gy * W + gx) * 4 : CLHIP_OOB, 0);
-        }
-    };
-    // ---- this lane's gather offsets: k slot 16 s + 8 kh + e  ->  (ci, tap) = (k / 9, k % 9); slots >= 27 are padding
-    int goff[2][8];
-    bool gval[2][8];
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int kk = 16 * s + 8 * kh + e, ci = kk / 9, tap = kk - ci * 9, dr = tap / 3, dc = tap - dr * 3;
-            gval[s][e] = kk < 27;
-            goff[s][e] = kk < 27 ? (ci * 6 + dr) * C3_PITCH + dc : 0;
-        }
-    const int mw = m >> 2, mq = m & 3;
-    const int prow = (mq >> 1), pcol = 2 * mw + (mq & 1);                   // pixel of lane m inside its 2 x 16 M tile
-    int pbase[WM];
-#pragma unroll
-    for (int i = 0; i < WM; ++i) pbase[i] = (wm * 2 + prow) * C3_PITCH + i * 16 + pcol;      // wave wm: rows 2 wm, 2 wm + 1; tile i: columns 16 i ..
-
-    // ---- B operands of this wave's 32 channels: split once
-    clhip_u32x4 bq[2][3];
-    int cur_kt = -1;
-    auto load_weights = [&](int kt) {
-        const int ko = (kt * 2 + wn) * 32 + m;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int kk = 16 * s + 8 * kh + e;
-                v[e] = (kk < 27 && ko < K) ? w[(size_t)ko * 27 + kk] : 0.f;
-            }
-            bs_split8(v, bq[s][0], bq[s][1], bq[s][2]);
-        }
-        cur_kt = kt;
-    };
-
-    int u = blockIdx.x, buf = 0;
-    load_tile(u);
-    for (; u < n_units; u += gridDim.x, buf ^= 1) {
-        int kt, n, y0, x0;
-        decode(u, kt, n, y0, x0);
-        if (kt != cur_kt) load_weights(kt);
-        float* const xb = xs + buf * C3_XBUF;
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-            if (loff[r] >= 0) xb[lds_off[r]] = xr[r];
-        __syncthreads();                                   // (readers of this buffer two tiles ago passed the previous barrier)
-        if (u + (int)gridDim.x < n_units) load_tile(u + gridDim.x);
-        floatx16 acc[WM], accl[WM];
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; accl[i][r] = 0.f; }
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            clhip_u32x4 a[WM][3];
-#pragma unroll
-            for (int i = 0; i < WM; ++i) {
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float t = xb[pbase[i] + goff[s][e]];
-                    v[e] = gval[s][e] ? t : 0.f;
-                }
-                bs_split8(v, a[i][0], a[i][1], a[i][2]);
-            }
-#define C3_TERM(ACC, PA, PB)                                                                                                      \
-            _Pragma("unroll") for (int i = 0; i < WM; ++i)                                                                        \
-                ACC[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bs_bf16x8, a[i][PA]),                         \
-                                                                __builtin_bit_cast(bs_bf16x8, bq[s][PB]), ACC[i], 0, 0, 0);
-            C3_TERM(accl, 0, 2) C3_TERM(acc, 0, 0) C3_TERM(accl, 2, 0) C3_TERM(accl, 1, 1) C3_TERM(accl, 0, 1) C3_TERM(accl, 1, 0)
-#undef C3_TERM
-        }
-        // ---- epilogue: bias + ReLU + 2x2 max-pool + codes; the wave's 2 x 32-pixel region pools to 1 x 16 per channel
-        const int k = (kt * 2 + wn) * 32 + m;
-        const float bv = (bias != nullptr && k < K) ? bias[k] : 0.f;
-        float* const T = tbuf + wave * (32 * TS);
-        uint8_t* const Cb = reinterpret_cast<uint8_t*>(T + 16 * WM);
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int w8 = 2 * g + kh;                                              // window: pooled column 8 i + w8
-                float y00 = acc[i][4 * g] + accl[i][4 * g] + bv, y01 = acc[i][4 * g + 1] + accl[i][4 * g + 1] + bv;
-                float y10 = acc[i][4 * g + 2] + accl[i][4 * g + 2] + bv, y11 = acc[i][4 * g + 3] + accl[i][4 * g + 3] + bv;
-                y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f);
-                float mx = y00; int am = 0;
-                if (y01 > mx) { mx = y01; am = 1; }
-                if (y10 > mx) { mx = y10; am = 2; }
-                if (y11 > mx) { mx = y11; am = 3; }
-                if (!(mx > 0.f)) am = CLHIP_POOL_DEAD;                                  // ReLU folded into the code (common.hpp)
-                T[m * TS + 8 * i + w8] = mx;
-                Cb[m * (TS * 4) + 8 * i + w8] = (uint8_t)am;
-            }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int kb = (kt * 2 + wn) * 32, ph = (y0 >> 1) + wm, pw0 = x0 >> 1;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {                                                   // 32 channels x 4 float4s of pooled values
-            const int f = t * 64 + lane, oc = f >> 2, c4 = f & 3;
-            if (kb + oc < K && ph < OH && pw0 + 4 * c4 < OW) {
-                const float4 v = *reinterpret_cast<const float4*>(T + oc * TS + 4 * c4);
-                *reinterpret_cast<float4*>(out + ((size_t)n * K + kb + oc) * OH * OW + (size_t)ph * OW + pw0 + 4 * c4) = v;
-            }
-        }
-        if (lane < 32 && kb + lane < K && ph < OH) {                                    // 16 code bytes per channel
-            const uint8_t* src = Cb + lane * (TS * 4);
-            uint8_t* dst = pool_idx + ((size_t)n * K + kb + lane) * OH * OW + (size_t)ph * OW + pw0;
-            if (pw0 + 16 <= OW) *reinterpret_cast<clhip_u32x4*>(dst) = *reinterpret_cast<const clhip_u32x4*>(src);
-            else for (int q = 0; q < 16 && pw0 + q < OW; ++q) dst[q] = src[q];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-}
+// (A first-layer form of this scheme — 3 -> K, K dimension 27 -> 32, the A operand gathered from a raw fp32 halo tile in LDS and split
+// in registers, weights split once per persistent wave — was built, passed the parity suite and ran 50.9 us against 42 - 45 us for
+// conv3x3_c3w64_relu_pool_kernel on the f32 pipe (profiles/r05_j_conv_layers_small_with_c3.txt): 27 scalar LDS gathers + 88 split
+// instructions per 24 MFMAs.  Removed; the first layer stays on the f32 MFMA kernels of conv3x3.hip.)
 
 static int bs_env_int(const char* name, int dflt) {
     const char* e = getenv(name);
@@ -765,31 +597,6 @@ int clhip_internal_bs_conv_u(int mode, const float* in, const void* wimg, const 
     if (mode == 0) return bs_launch<0, false>(in, img, bias, nullptr, out, pool_idx, N, Cin, Cout, H, W, relu, s);
     if (unpool) return bs_launch<1, true>(in, img, nullptr, mask_src, out, pool_idx, N, Cin, Cout, H, W, 0, s);
     return bs_launch<1, false>(in, img, nullptr, mask_src, out, nullptr, N, Cin, Cout, H, W, 0, s);
-}
-
-// first layer: conv(3 -> K) + bias + ReLU + 2x2 max-pool + codes; shapes: K % 32 == 0, W % 8 == 0 (pooled rows of whole float4s), even H
-bool clhip_internal_bs_c3_ok(int K, int H, int W) {
-    static const int mode = bs_env_int("CLHIP_BS", 1);
-    return mode != 0 && K % 32 == 0 && W % 8 == 0 && H % 2 == 0 && H >= 4 && W >= 8;
-}
-
-int clhip_internal_bs_c3_pool_fwd(const float* x, const float* w, const float* b, float* y_pool, uint8_t* idx_u8, int N, int K, int H,
-                                  int W, hipStream_t s) {
-    if (!x || !w || !y_pool || !idx_u8 || N <= 0 || !clhip_internal_bs_c3_ok(K, H, W)) return CLHIP_EINVAL;
-    if ((size_t)3 * H * W >= ((size_t)1 << 29)) return CLHIP_ENOTSUP;
-    const int tiles_x = (W + 31) / 32, tiles_y = (H + 3) / 4, kts = (K + BS_BN - 1) / BS_BN;
-    const long long units = (long long)tiles_x * tiles_y * N * kts;
-    if (units > 0x7fffffffLL) return CLHIP_ENOTSUP;
-    static const int cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        return n;
-    }();
-    const long long blocks = units < 3LL * cus ? units : 3LL * cus;        // persistent: three blocks per CU
-    hipLaunchKernelGGL(bs_c3_pool_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, w, b, y_pool, idx_u8, N, K, H, W, tiles_x, tiles_y,
-                       (int)units);
-    CLHIP_LAUNCH_CHECK();
-    return 0;
 }
 
 extern "C" {

@@ -139,9 +139,6 @@ size_t clhip_internal_wino_ws(int Cin, int Cout);
 // bsconv.hip: the same operators on the bf16 matrix cores with fp32 operands split into three bf16 pieces (weight image in `wimg`)
 bool clhip_internal_bs_ok(int Cin, int Cout, int H, int W);
 bool clhip_internal_bs_preferred(int Cin, int Cout, int H, int W);
-bool clhip_internal_bs_c3_ok(int K, int H, int W);
-int clhip_internal_bs_c3_pool_fwd(const float* x, const float* w, const float* b, float* y_pool, uint8_t* idx_u8, int N, int K, int H,
-                                  int W, hipStream_t s);
 size_t clhip_internal_bs_ws(int Cin, int Cout);
 int clhip_internal_bs_weights(const clhip_wino_wt* jobs, int n, hipStream_t s);
 int clhip_internal_bs_conv_u(int mode, const float* in, const void* wimg, const float* bias, const float* mask_src, float* out,

@@ -1154,8 +1154,6 @@ int clhip_conv3x3_relu_pool_fwd(const float* x, const float* w, const float* b, 
     if (!x || !w || !y_pool || !idx_u8 || N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1))
         return CLHIP_EINVAL;
     hipStream_t s = as_stream(stream);
-    // first layer on the bf16-split scheme (bsconv.hip, bs_c3_pool_kernel; CLHIP_BS=0: the f32 MFMA kernels below)
-    if (C == 3 && clhip_internal_bs_c3_ok(K, H, W)) return clhip_internal_bs_c3_pool_fwd(x, w, b, y_pool, idx_u8, N, K, H, W, s);
     if (CLHIP_C3W64 && C == 3 && W % 64 == 0 && H % 2 == 0 && (size_t)N * 3 * H * W < ((size_t)1 << 29) &&
         (size_t)N * K * (H / 2) * (W / 2) < ((size_t)1 << 29))
         return launch_c3w64_pool(x, w, b, y_pool, idx_u8, N, K, H, W, s);
