@@ -55,6 +55,9 @@ SIGNATURES = {
     "clhip_conv3x3_wino_ws": (_z, [_i, _i]),
     "clhip_conv3x3_wino_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "clhip_conv3x3_wino_bwd_data": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "clhip_conv5x5_bs_ws": (_z, [_i, _i]),
+    "clhip_conv5x5_bs_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "clhip_conv5x5_bs_bwd_data": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
     "clhip_conv3x3_bs_ws": (_z, [_i, _i]),
     "clhip_conv3x3_bs_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "clhip_conv3x3_bs_bwd_data": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),

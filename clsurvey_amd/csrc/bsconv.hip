@@ -82,7 +82,8 @@ __device__ __forceinline__ void bs_split8(const float* v, clhip_u32x4& q0, clhip
 // ---------------------------------------------------------------------------------------------------- weight image
 // img[nt][chunk][tap][piece][lane] (16 bytes each): lane l of the B operand of n tile nt holds output channel ko = 32 nt + (l & 31)
 // and input channels ci = 16 chunk + 8 (l >> 5) + e, e = 0..7, of tap (r, s) — MODE 0: w[ko][ci][r][s]; MODE 1 (backward-data: the
-// kernel's input channels are the layer's output channels): w[ci][ko][2 - r][2 - s].  Ko / Ci: channel counts as the KERNEL sees them.
+// kernel's input channels are the layer's output channels): w[ci][ko][ks - 1 - r][ks - 1 - s].  Ko / Ci: channel counts as the KERNEL
+// sees them; ks x ks taps (3 x 3, or 5 x 5: AlexNet's second convolution, models/net.py:96-125).
 constexpr int BS_WT_JOBS = 24;
 struct BsWtJobs { int n; int pad; clhip_wino_wt j[BS_WT_JOBS]; int first[BS_WT_JOBS + 1]; };
 
@@ -91,11 +92,12 @@ __global__ __launch_bounds__(256) void bs_weight_multi_kernel(BsWtJobs J) {
     for (int i = 1; i < J.n; ++i) jb = ((int)blockIdx.x >= J.first[i]) ? i : jb;
     const clhip_wino_wt& q = J.j[jb];
     const int n_chunks = (q.Ci + BS_CK - 1) / BS_CK, n_nt = (q.Ko + 31) / 32;
+    const int ks = q.pad > 0 ? q.pad : 3, T = ks * ks;         // (clhip_wino_wt::pad carries the kernel size here: 0 = 3)
     const int t = ((int)blockIdx.x - J.first[jb]) * 256 + threadIdx.x;
     const int lane = t & 63;
     int rest = t >> 6;
-    const int tap = rest % 9;
-    rest /= 9;
+    const int tap = rest % T;
+    rest /= T;
     const int chunk = rest % n_chunks, nt = rest / n_chunks;
     if (nt >= n_nt) return;
     const int ko = nt * 32 + (lane & 31), ci0 = chunk * BS_CK + 8 * (lane >> 5);
@@ -105,12 +107,12 @@ __global__ __launch_bounds__(256) void bs_weight_multi_kernel(BsWtJobs J) {
         const int ci = ci0 + e;
         float x = 0.f;
         if (ko < q.Ko && ci < q.Ci)
-            x = q.mode == 0 ? q.w[((size_t)ko * q.Ci + ci) * 9 + tap] : q.w[((size_t)ci * q.Ko + ko) * 9 + (8 - tap)];
+            x = q.mode == 0 ? q.w[((size_t)ko * q.Ci + ci) * T + tap] : q.w[((size_t)ci * q.Ko + ko) * T + (T - 1 - tap)];
         v[e] = x;
     }
     clhip_u32x4 p0, p1, p2;
     bs_split8(v, p0, p1, p2);
-    clhip_u32x4* img = reinterpret_cast<clhip_u32x4*>(q.U) + ((size_t)(nt * n_chunks + chunk) * 27 + tap * 3) * 64 + lane;
+    clhip_u32x4* img = reinterpret_cast<clhip_u32x4*>(q.U) + ((size_t)(nt * n_chunks + chunk) * 3 * T + tap * 3) * 64 + lane;
     img[0] = p0;
     img[64] = p1;
     img[128] = p2;
@@ -121,9 +123,10 @@ __global__ __launch_bounds__(256) void bs_weight_multi_kernel(BsWtJobs J) {
 // output pixels (= BM) x one 64-channel group of output channels.
 //   RW = 32: one image, RH = BM / 32;  RW = 16: RH = BM / 16;  RW = 8: whole 8-row images, two side by side per LDS row.
 //   M tiles: 2 rows x 16 columns (RW >= 16) or 4 rows x 8 columns.
-template <int RW_, int RH_, int NI_, int WAVES_M_, int WM_, int WN_>
+template <int RW_, int RH_, int NI_, int WAVES_M_, int WM_, int WN_, int KS_ = 3>
 struct BsGeo {
     static constexpr int RW = RW_, RH = RH_, NI = NI_, WAVES_M = WAVES_M_, WAVES_N = 4 / WAVES_M_, WM = WM_, WN = WN_;
+    static constexpr int KS = KS_, HP = KS_ / 2, TAPS = KS_ * KS_;         // kernel size (3 or 5, stride 1, padding KS / 2)
     static constexpr int BM = RW * RH * NI;
     static_assert(BM == 32 * WAVES_M * WM, "pixels per block = M tiles of the waves");
     static_assert(32 * WAVES_N * WN == BS_BN, "64 output channels per block");
@@ -132,7 +135,7 @@ struct BsGeo {
     static constexpr int MT_PER_ROW = RW / MTW, MT_PER_IMG = MT_PER_ROW * (RH / MTH);
     static constexpr int IPR = RW == 8 ? 2 : 1;                            // images per LDS row
     static_assert(NI % IPR == 0, "image pairs");
-    static constexpr int HW_ = RW + 2, HR = RH + 2;                        // halo tile of one image
+    static constexpr int HW_ = RW + 2 * HP, HR = RH + 2 * HP;              // halo tile of one image
     static constexpr int P = (IPR * HW_ + 7) / 16 * 16 + 8;                // slots per LDS row, = 8 mod 16
     static_assert(P >= IPR * HW_ && P % 16 == 8, "pitch");
     static constexpr int ROWS = (NI / IPR) * HR;
@@ -168,7 +171,7 @@ struct BsGeo {
 template <class G, int MODE, bool UNPOOL>
 // (three blocks per CU — 45 KB of LDS each — where the registers allow: every forward / plain backward-data instance at <= 162, the
 // un-pooling instance of the 32-wide geometry at 168 without spills; its narrower geometries would spill 11 - 12 registers)
-__global__ __launch_bounds__(256, (3 * G::BUF_BYTES <= 160 * 1024 && (G::RW == 32 || !UNPOOL)) ? 3 : 2) void bs_conv_kernel(
+__global__ __launch_bounds__(256, (3 * 2 * G::BUF_BYTES <= 160 * 1024 && (G::RW == 32 || !UNPOOL)) ? 3 : 2) void bs_conv_kernel(
     const float* __restrict__ in, const clhip_u32x4* __restrict__ wimg, const float* __restrict__ bias,
     const float* __restrict__ mask_src, float* __restrict__ out, uint8_t* __restrict__ pool_idx, int N, int Cin, int Cout, int H,
     int W, int relu, int tiles_x, int tiles_y, int npb) {
@@ -194,7 +197,8 @@ __global__ __launch_bounds__(256, (3 * G::BUF_BYTES <= 160 * 1024 && (G::RW == 3
     const __amdgpu_buffer_rsrc_t rs_i = clhip_rsrc(UNPOOL ? pool_idx + (size_t)n0 * Cin * plane_in : pool_idx,
                                                    UNPOOL ? (size_t)(N - n0) * Cin * plane_in : 0);
     const int n_nt = (Cout + 31) / 32;
-    const __amdgpu_buffer_rsrc_t rs_w = clhip_rsrc(wimg, (size_t)n_nt * n_chunks * 27 * 1024);
+    constexpr int TAPS = G::TAPS, KS = G::KS;
+    const __amdgpu_buffer_rsrc_t rs_w = clhip_rsrc(wimg, (size_t)n_nt * n_chunks * 3 * TAPS * 1024);
 
     // ---- staging items of this thread: (halo pixel, k half) -> element offset of channel 8 h of the chunk, LDS slot
     int xoff[ROUNDS], lw[ROUNDS], pos[ROUNDS];
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(256, (3 * G::BUF_BYTES <= 160 * 1024 && (G::RW == 3
         const int it_ = r * 256 + tid, it = it_ < G::ITEMS ? it_ : it_ - G::ITEMS;
         const int h = it >= G::NHALO ? 1 : 0, p = it - h * G::NHALO;
         const int ni = p / (HR * HW_), rem = p - ni * (HR * HW_), hy = rem / HW_, hx = rem - hy * HW_;
-        const int gy = y0 + hy - 1, gx = x0 + hx - 1, n = n0 + ni;
+        const int gy = y0 + hy - G::HP, gx = x0 + hx - G::HP, n = n0 + ni;
         const bool ok = n < N && gy >= 0 && gy < H && gx >= 0 && gx < W;
         const int e = UNPOOL ? (gy >> 1) * IW + (gx >> 1) : gy * IW + gx;
         xoff[r] = ok ? (ni * Cin + 8 * h) * plane_in + e : CLHIP_OOB;
@@ -260,10 +264,10 @@ __global__ __launch_bounds__(256, (3 * G::BUF_BYTES <= 160 * 1024 && (G::RW == 3
     const int nt0 = kt * (BS_BN / 32) + wn * WN;
     int wvoff[WN];
 #pragma unroll
-    for (int j = 0; j < WN; ++j) wvoff[j] = (nt0 + j < n_nt) ? ((nt0 + j) * n_chunks * 27 * 64 + lane) * 16 : CLHIP_OOB;
+    for (int j = 0; j < WN; ++j) wvoff[j] = (nt0 + j < n_nt) ? ((nt0 + j) * n_chunks * 3 * TAPS * 64 + lane) * 16 : CLHIP_OOB;
     auto load_b = [&](clhip_u32x4 (&bq)[WN][3], int c, int tap) {
         if (BS_ABL & 2) return;
-        const int so = (c * 27 + tap * 3) * 1024;
+        const int so = (c * 3 * TAPS + tap * 3) * 1024;
 #pragma unroll
         for (int j = 0; j < WN; ++j)
 #pragma unroll
@@ -292,11 +296,11 @@ __global__ __launch_bounds__(256, (3 * G::BUF_BYTES <= 160 * 1024 && (G::RW == 3
     for (int c = 0; c < n_chunks; ++c) {
         const unsigned char* lb = lds + (c & 1) * G::BUF_BYTES;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dr = tap / 3, ds = tap - dr * 3;
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int dr = tap / KS, ds = tap - dr * KS;
             // next tap's weight operands (the first tap of the next chunk after the last one; past the end: any valid address)
             clhip_u32x4 bnext[WN][3];
-            if (tap < 8) load_b(bnext, c, tap + 1);
+            if (tap < TAPS - 1) load_b(bnext, c, tap + 1);
             else load_b(bnext, c + 1 < n_chunks ? c + 1 : c, 0);
             clhip_u32x4 a[WM][3];
 #pragma unroll
@@ -304,7 +308,7 @@ __global__ __launch_bounds__(256, (3 * G::BUF_BYTES <= 160 * 1024 && (G::RW == 3
 #pragma unroll
                 for (int s = 0; s < 3; ++s)
                     a[i][s] = *reinterpret_cast<const clhip_u32x4*>(lb + abase[i] + (dr * P + ds) * 16 + s * 2 * G::PLANE_BYTES);
-            if (tap == 3) {
+            if (tap == TAPS / 3) {
                 // staging of the next chunk inside this chunk's matrix stream, unconditionally (one basic block per chunk: the
                 // scheduler may place these VALU / LDS / load instructions between the MFMAs): after the last chunk the spare
                 // buffer takes a second copy of it, which nobody reads
@@ -541,6 +545,14 @@ int bs_launch(const float* in, const clhip_u32x4* wimg, const float* bias, const
 #undef BS_GO
 }
 
+// 5 x 5 taps (stride 1, padding 2; no fused pooling: AlexNet pools 3 x 3 / 2)
+template <int MODE>
+int bs_launch5(const float* in, const clhip_u32x4* wimg, const float* bias, const float* mask_src, float* out, int N, int Cin, int Cout,
+               int H, int W, int relu, hipStream_t s) {
+    if (W > 16) return bs_launch_geo<BsGeo<32, 4, 1, 2, 2, 1, 5>, MODE, false>(in, wimg, bias, mask_src, out, nullptr, N, Cin, Cout, H, W, relu, s);
+    return bs_launch_geo<BsGeo<16, 8, 1, 2, 2, 1, 5>, MODE, false>(in, wimg, bias, mask_src, out, nullptr, N, Cin, Cout, H, W, relu, s);
+}
+
 }  // namespace
 
 // shapes this path takes: whole 32-channel k pairs on the input side, whole 64-channel groups on the output side; any H, W >= 4
@@ -554,14 +566,26 @@ bool clhip_internal_bs_ok(int Cin, int Cout, int H, int W) {
 // pays where a launch has many pixels per weight: measured at N = 200 (profiles/r05_bs_v5_per_layer_cfg0.txt, us, Winograd / this):
 // 64 -> 64 @32x32 forward 100 / 83, backward-data 102 / 92; 64 -> 128 @32x32 158 / 144, 163 / 156; at 16 x 16 within 1 - 2 us either
 // way; at 8 x 8 and from 256 channels on backward-data is 5 - 20 % slower.
+// At 224 x 224 inputs (N = 50, profiles/r05_k_bs_shapes.txt): 256 -> 512 and 512 -> 512 @28x28 513 / 441 and 985 / 856 forward, 554 / 475
+// and 1007 / 899 backward-data; @56x56 within 2 %; 64 -> 128 @112x112 476 / 487 (3.5 tiles of 32 columns per row).
 bool clhip_internal_bs_preferred(int Cin, int Cout, int H, int W) {
     static const int mode = bs_env_int("CLHIP_BS", 1);
     if (mode == 0 || !clhip_internal_bs_ok(Cin, Cout, H, W)) return false;
-    return mode == 2 || ((long long)H * W >= 1024 && Cin <= 128 && Cout <= 128);
+    if (mode == 2) return true;
+    const long long px = (long long)H * W;
+    return (px >= 1024 && px <= 4096 && Cin <= 128 && Cout <= 128) || (px >= 512 && px < 1024 && Cin >= 256 && Cout >= 256);
+}
+// 5 x 5 layers (AlexNet's second convolution: 64 -> 192 on 27 x 27): against the f32 LDS-halo kernel of convkk.hip
+bool clhip_internal_bs5_preferred(int Cin, int Cout, int H, int W) {
+    static const int mode = bs_env_int("CLHIP_BS", 1);
+    return mode != 0 && clhip_internal_bs_ok(Cin, Cout, H, W) && W > 8;
 }
 
 size_t clhip_internal_bs_ws(int Cin, int Cout) {
     return (size_t)((Cout + 31) / 32) * ((Cin + BS_CK - 1) / BS_CK) * 27 * 1024;
+}
+size_t clhip_internal_bs5_ws(int Cin, int Cout) {
+    return (size_t)((Cout + 31) / 32) * ((Cin + BS_CK - 1) / BS_CK) * 75 * 1024;
 }
 
 int clhip_internal_bs_weights(const clhip_wino_wt* jobs, int n, hipStream_t s) {
@@ -577,7 +601,8 @@ int clhip_internal_bs_weights(const clhip_wino_wt* jobs, int n, hipStream_t s) {
             if (!q.w || !q.U || q.Ko <= 0 || q.Ci <= 0) return CLHIP_EINVAL;
             J.j[i] = q;
             J.first[i] = blocks;
-            const int total = ((q.Ko + 31) / 32) * ((q.Ci + BS_CK - 1) / BS_CK) * 9 * 64;
+            const int ks = q.pad > 0 ? q.pad : 3;
+            const int total = ((q.Ko + 31) / 32) * ((q.Ci + BS_CK - 1) / BS_CK) * ks * ks * 64;
             blocks += (total + 255) / 256;
         }
         J.first[J.n] = blocks;
@@ -599,7 +624,41 @@ int clhip_internal_bs_conv_u(int mode, const float* in, const void* wimg, const 
     return bs_launch<1, false>(in, img, nullptr, mask_src, out, nullptr, N, Cin, Cout, H, W, 0, s);
 }
 
+// the same for 5 x 5 taps (image made by clhip_internal_bs_weights from a job with pad = 5)
+int clhip_internal_bs5_conv_u(int mode, const float* in, const void* wimg, const float* bias, const float* mask_src, float* out, int N,
+                              int Cin, int Cout, int H, int W, int relu, hipStream_t s) {
+    if (!in || !wimg || !out || N <= 0 || !clhip_internal_bs_ok(Cin, Cout, H, W) || W <= 8) return CLHIP_EINVAL;
+    const clhip_u32x4* img = static_cast<const clhip_u32x4*>(wimg);
+    if (mode == 0) return bs_launch5<0>(in, img, bias, nullptr, out, N, Cin, Cout, H, W, relu, s);
+    return bs_launch5<1>(in, img, nullptr, mask_src, out, N, Cin, Cout, H, W, 0, s);
+}
+
 extern "C" {
+
+size_t clhip_conv5x5_bs_ws(int C, int K) {
+    const size_t a = clhip_internal_bs5_ws(C, K), b = clhip_internal_bs5_ws(K, C);
+    return a > b ? a : b;
+}
+
+int clhip_conv5x5_bs_fwd(const float* x, const float* w, const float* b, float* y, int N, int C, int K, int H, int W, int relu, void* ws,
+                         size_t ws_bytes, void* stream) {
+    if (N <= 0 || !clhip_internal_bs_ok(C, K, H, W) || W <= 8) return CLHIP_ENOTSUP;
+    if (!x || !w || !y || !ws || ws_bytes < clhip_internal_bs5_ws(C, K)) return CLHIP_EINVAL;
+    const clhip_wino_wt job{w, static_cast<float*>(ws), K, C, 0, 5};
+    const int rc = clhip_internal_bs_weights(&job, 1, as_stream(stream));
+    if (rc) return rc;
+    return clhip_internal_bs5_conv_u(0, x, ws, b, nullptr, y, N, C, K, H, W, relu, as_stream(stream));
+}
+
+int clhip_conv5x5_bs_bwd_data(const float* dy, const float* w, const float* relu_src, float* dx, int N, int C, int K, int H, int W,
+                              void* ws, size_t ws_bytes, void* stream) {
+    if (N <= 0 || !clhip_internal_bs_ok(K, C, H, W) || W <= 8) return CLHIP_ENOTSUP;
+    if (!dy || !w || !dx || !ws || ws_bytes < clhip_internal_bs5_ws(K, C)) return CLHIP_EINVAL;
+    const clhip_wino_wt job{w, static_cast<float*>(ws), C, K, 1, 5};
+    const int rc = clhip_internal_bs_weights(&job, 1, as_stream(stream));
+    if (rc) return rc;
+    return clhip_internal_bs5_conv_u(1, dy, ws, nullptr, relu_src, dx, N, K, C, H, W, 0, as_stream(stream));
+}
 
 size_t clhip_conv3x3_bs_ws(int C, int K) {
     const size_t a = clhip_internal_bs_ws(C, K), b = clhip_internal_bs_ws(K, C);

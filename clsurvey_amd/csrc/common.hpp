@@ -139,6 +139,10 @@ size_t clhip_internal_wino_ws(int Cin, int Cout);
 // bsconv.hip: the same operators on the bf16 matrix cores with fp32 operands split into three bf16 pieces (weight image in `wimg`)
 bool clhip_internal_bs_ok(int Cin, int Cout, int H, int W);
 bool clhip_internal_bs_preferred(int Cin, int Cout, int H, int W);
+bool clhip_internal_bs5_preferred(int Cin, int Cout, int H, int W);
+size_t clhip_internal_bs5_ws(int Cin, int Cout);
+int clhip_internal_bs5_conv_u(int mode, const float* in, const void* wimg, const float* bias, const float* mask_src, float* out, int N,
+                              int Cin, int Cout, int H, int W, int relu, hipStream_t s);
 size_t clhip_internal_bs_ws(int Cin, int Cout);
 int clhip_internal_bs_weights(const clhip_wino_wt* jobs, int n, hipStream_t s);
 int clhip_internal_bs_conv_u(int mode, const float* in, const void* wimg, const float* bias, const float* mask_src, float* out,

@@ -39,6 +39,7 @@ struct LayerPlan {
     float* rmean; float* rvar; float bn_momentum, bn_eps;
     size_t wino_uf, wino_ud;     // byte offsets of this layer's transformed weights (forward / backward-data) in the plan's Winograd region
     int wino_f, wino_d, wino_w;  // forward / backward-data / weight gradient through Winograd F(2x2,3x3) (wino.hip) instead of the direct kernels
+    int bs5_f, bs5_d;            // 5 x 5 layers: forward / backward-data on the bf16-split kernel (image offsets in wino_uf / wino_ud)
     int bs_f, bs_d;              // ... forward / backward-data on the bf16 matrix cores with split fp32 operands (bsconv.hip): wino_f / wino_d
                                  // are set as well (the layer takes the prepared-weights path) and wino_uf / wino_ud hold its weight IMAGE
     int wg3;                   // weight gradient on the 3x3 kernel (else the general gather-GEMM)
@@ -259,6 +260,14 @@ int clhip_net_create(const clhip_layer_desc* descs, int n_layers, int max_batch,
                 if (L.wino_f) { L.wino_uf = wino_ws; wino_ws += align_up(L.bs_f ? clhip_internal_bs_ws(L.cin, L.cout) : clhip_internal_wino_ws(L.cin, L.cout), 256); }
                 if (L.wino_d) { L.wino_ud = wino_ws; wino_ws += align_up(L.bs_d ? clhip_internal_bs_ws(L.cout, L.cin) : clhip_internal_wino_ws(L.cout, L.cin), 256); }
             }
+            // 5 x 5 / stride 1 / padding 2 layers (AlexNet's second convolution) on the bf16-split kernel: bs5_f / bs5_d, images in the
+            // same region
+            if (!vgg && !L.bn && L.ks == 5 && L.st == 1 && L.pd == 2) {
+                L.bs5_f = clhip_internal_bs5_preferred(L.cin, L.cout, L.h, L.w);
+                L.bs5_d = i > 0 && clhip_internal_bs5_preferred(L.cout, L.cin, L.h, L.w);
+                if (L.bs5_f) { L.wino_uf = wino_ws; wino_ws += align_up(clhip_internal_bs5_ws(L.cin, L.cout), 256); }
+                if (L.bs5_d) { L.wino_ud = wino_ws; wino_ws += align_up(clhip_internal_bs5_ws(L.cout, L.cin), 256); }
+            }
             if (L.out_elems > gmax) gmax = L.out_elems;
             if (L.in_elems > gmax) gmax = L.in_elems;
             h = oh; w = ow;
@@ -417,7 +426,8 @@ int clhip_net_layer_paths(void* handle, int layer) {
     const bool defer_capable = p->n_wg > 0 && !(p->overlap && p->overlap_mode == 1);
     // bits 3 / 4: the forward / backward-data launch is the bf16-split kernel (bsconv.hip), not Winograd (bits 0 / 1 then say
     // "prepared-weights path")
-    return (L.wino_f ? 1 : 0) | (L.wino_d ? 2 : 0) | ((L.wino_w && defer_capable) ? 4 : 0) | (L.bs_f ? 8 : 0) | (L.bs_d ? 16 : 0);
+    return (L.wino_f ? 1 : 0) | (L.wino_d ? 2 : 0) | ((L.wino_w && defer_capable) ? 4 : 0) | ((L.bs_f || L.bs5_f) ? 8 : 0) |
+           ((L.bs_d || L.bs5_d) ? 16 : 0);
 }
 
 int clhip_net_set_input_grad(void* handle, int layer, const float* extra) {
@@ -522,6 +532,10 @@ static int wino_prepare(NetPlan* p, const float* params, char* base, bool fwd, b
             (L.bs_f ? bsjobs : jobs).push_back(clhip_wino_wt{params + L.w_off, reinterpret_cast<float*>(base + p->off_wino + L.wino_uf), L.cout, L.cin, 0, 0});
         if (bwd && L.wino_d)
             (L.bs_d ? bsjobs : jobs).push_back(clhip_wino_wt{params + L.w_off, reinterpret_cast<float*>(base + p->off_wino + L.wino_ud), L.cin, L.cout, 1, 0});
+        if (fwd && L.bs5_f)
+            bsjobs.push_back(clhip_wino_wt{params + L.w_off, reinterpret_cast<float*>(base + p->off_wino + L.wino_uf), L.cout, L.cin, 0, 5});
+        if (bwd && L.bs5_d)
+            bsjobs.push_back(clhip_wino_wt{params + L.w_off, reinterpret_cast<float*>(base + p->off_wino + L.wino_ud), L.cin, L.cout, 1, 5});
     }
     const int rc = clhip_internal_wino_weights(jobs.data(), (int)jobs.size(), s);
     if (rc) return rc;
@@ -572,6 +586,8 @@ static int net_forward_impl(void* handle, const float* params, const float* x, i
                      ? plan_conv_u(L.bs_f, 0, cur, reinterpret_cast<const float*>(base + p->off_wino + L.wino_uf), params + L.b_off,
                                                   nullptr, zc, nullptr, 0, N, L.cin, L.cout, L.h, L.w, crelu, as_stream(stream))
                  : vgg ? clhip_conv3x3_fwd(cur, params + L.w_off, params + L.b_off, zc, N, L.cin, L.cout, L.h, L.w, crelu, stream)
+                 : L.bs5_f ? clhip_internal_bs5_conv_u(0, cur, base + p->off_wino + L.wino_uf, params + L.b_off, nullptr, zc, N, L.cin, L.cout,
+                                                       L.h, L.w, crelu, as_stream(stream))
                      : clhip_conv2d_fwd(cur, params + L.w_off, params + L.b_off, zc, N, L.cin, L.h, L.w, L.cout, L.ks, L.ks, L.st,
                                         L.pd, crelu, stream);
             if (rc) return rc;
@@ -884,6 +900,8 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
                      ? plan_conv_u(L.bs_d, 1, gy, reinterpret_cast<const float*>(base + p->off_wino + L.wino_ud), nullptr, xmask, gout,
                                                   nullptr, 0, N, L.cout, L.cin, L.h, L.w, 0, as_stream(stream))
                  : vgg ? clhip_conv3x3_bwd_data(gy, params + L.w_off, xmask, gout, N, L.cin, L.cout, L.h, L.w, stream)
+                 : L.bs5_d ? clhip_internal_bs5_conv_u(1, gy, base + p->off_wino + L.wino_ud, nullptr, xmask, gout, N, L.cout, L.cin, L.h, L.w,
+                                                       0, as_stream(stream))
                      : clhip_conv2d_bwd_data(gy, params + L.w_off, xmask, gout, N, L.cin, L.h, L.w, L.cout, L.ks, L.ks, L.st, L.pd, stream);
             if (rc) return rc;
             probe_end(1);

@@ -118,6 +118,33 @@ def conv3x3_bs_bwd_data(dy, w, relu_src=None, idx=None):
     return dx
 
 
+def conv5x5_bs_fwd(x, w, b, relu=True):
+    """clhip_conv5x5_bs_fwd: 5 x 5 / stride 1 / padding 2 convolution (+ bias, ReLU) on the bf16-split kernel (csrc/bsconv.hip)."""
+    _chk(x, w, b)
+    N, C, H, W = x.shape
+    K = w.shape[0]
+    assert w.shape == (K, C, 5, 5)
+    L = _lib.lib()
+    ws = torch.empty(L.clhip_conv5x5_bs_ws(C, K), dtype=torch.uint8, device=x.device)
+    y = torch.empty((N, K, H, W), dtype=torch.float32, device=x.device)
+    check(L.clhip_conv5x5_bs_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(y), N, C, K, H, W, int(relu), _ptr(ws), ws.numel(), _stream()),
+          "clhip_conv5x5_bs_fwd")
+    return y
+
+
+def conv5x5_bs_bwd_data(dy, w, relu_src=None):
+    """clhip_conv5x5_bs_bwd_data: dx of that convolution (x (relu_src > 0) when given)."""
+    _chk(dy, w)
+    K, C = w.shape[0], w.shape[1]
+    N, _, H, W = dy.shape
+    L = _lib.lib()
+    ws = torch.empty(L.clhip_conv5x5_bs_ws(C, K), dtype=torch.uint8, device=dy.device)
+    dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device)
+    check(L.clhip_conv5x5_bs_bwd_data(_ptr(dy), _ptr(w), _ptr(relu_src) if relu_src is not None else None, _ptr(dx), N, C, K, H, W,
+                                      _ptr(ws), ws.numel(), _stream()), "clhip_conv5x5_bs_bwd_data")
+    return dx
+
+
 def conv3x3_wino_bwd_weight(x, dy, idx=None):
     """clhip_conv3x3_wino_bwd_weight: (dw, db) of the 3x3 convolution (idx: dy is the POOLED gradient + arg-max codes)."""
     _chk(x, dy)

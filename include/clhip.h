@@ -251,6 +251,14 @@ int clhip_conv3x3_bs_fwd(const float* x, const float* w, const float* b, float* 
                          int H, int W, int relu, void* ws, size_t ws_bytes, void* stream);
 int clhip_conv3x3_bs_bwd_data(const float* dy, const uint8_t* idx_u8_or_null, const float* w, const float* relu_src, float* dx,
                               int N, int C, int K, int H, int W, void* ws, size_t ws_bytes, void* stream);
+/* The same kernel with 5 x 5 taps (stride 1, padding 2): torchvision AlexNet's features[3], nn.Conv2d(64, 192, 5, padding=2) + ReLU
+ * (models/net.py:96-125) and its autograd w.r.t. the input (dx *= (relu_src > 0) when relu_src != NULL).  w: [K][C][5][5].
+ * C % 32 == 0, K % 64 == 0 on the forward (roles swapped on backward-data), W > 8.  ws: clhip_conv5x5_bs_ws(C, K) bytes.      */
+size_t clhip_conv5x5_bs_ws(int C, int K);
+int clhip_conv5x5_bs_fwd(const float* x, const float* w, const float* b, float* y, int N, int C, int K, int H, int W, int relu,
+                         void* ws, size_t ws_bytes, void* stream);
+int clhip_conv5x5_bs_bwd_data(const float* dy, const float* w, const float* relu_src, float* dx, int N, int C, int K, int H, int W,
+                              void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ HAT gates / back-masks / HAT_SGD
  * methods/HAT/networks/vgg_hat.py, approaches/hat.py, HAT_utils.py.  Gates multiply layer outputs in the

@@ -202,3 +202,28 @@ def test_engine_parity_with_weight_gradients_on_a_side_stream(mode):
                        env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 192, 27, 27), (3, 32, 64, 12, 20), (2, 64, 64, 16, 16), (1, 192, 64, 27, 27), (128, 64, 192, 27, 27)])
+def test_bs_5x5_forward_and_backward_data(shape):
+    """The same kernel with 5 x 5 taps (torchvision AlexNet's features[3], models/net.py:96-125: Conv2d(64, 192, 5, padding=2) + ReLU)
+    against torch CPU, at AlexNet's own size against the f32 LDS-halo kernel behind clhip_conv2d_fwd / _bwd_data."""
+    from clsurvey_amd import ops
+    N, C, K, H, W = shape
+    gen = np.random.RandomState(N * 5 + C + K + H)
+    x = torch.from_numpy(gen.standard_normal((N, C, H, W)).astype(np.float32))
+    w = torch.from_numpy((gen.standard_normal((K, C, 5, 5)) * (2.0 / (25 * C)) ** 0.5).astype(np.float32))
+    b = torch.from_numpy((gen.standard_normal((K,)) * 0.1).astype(np.float32))
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+    big = N >= 100
+    z_ref = ops.conv2d_fwd(xd, wd, bd, 1, 2, False) if big else F.conv2d(x, w, b, padding=2)
+    assert _rel(ops.conv5x5_bs_fwd(xd, wd, bd, relu=False), z_ref) <= 2e-5
+    assert _rel(ops.conv5x5_bs_fwd(xd, wd, bd, relu=True), z_ref.clamp_min(0)) <= 2e-5
+    if C % 64 or K % 32:
+        return
+    dy = torch.from_numpy(gen.standard_normal((N, K, H, W)).astype(np.float32))
+    msrc = torch.from_numpy(gen.standard_normal((N, C, H, W)).astype(np.float32))
+    dyd, md = dy.cuda(), msrc.cuda()
+    dx_ref = ops.conv2d_bwd_data(dyd, wd, (N, C, H, W), 1, 2) if big else F.conv_transpose2d(dy, w, padding=2)
+    assert _rel(ops.conv5x5_bs_bwd_data(dyd, wd), dx_ref) <= 2e-5
+    assert _rel(ops.conv5x5_bs_bwd_data(dyd, wd, relu_src=md), dx_ref.cuda() * (md > 0)) <= 2e-5
