@@ -166,11 +166,13 @@ def test_hat_step_wide_vgg9_g20(golden, tag, hw, nb, seed):
             from oracle import hat_ref
             _hat_update_on_branch(net, P64, g64, hat_ref.init_masks(P64, t, smax)[1], t, s, smax, lr, mom, wd, "HAT wide_VGG9")
         for j, (n, p) in enumerate(net.named_parameters()):
-            # (after the second step at 224 x 224 the parameters carry lr x the gradient entries of the near-ties that fell the
-            # other way — 6 of 200 000 decisions per channel plane in step 0: judged in the Euclidean norm, 2e-3 of the tensor's)
-            late224 = hw == 224 and step > 0
+            # (after the second step the parameters carry lr x the gradient entries of the near-ties that fell the other way — at
+            # 224 x 224 6 of 200 000 decisions per channel plane in step 0, at 64 x 64 1 - 2 per step, and WHICH ones depends on the
+            # rounding of the kernel path: judged in the Euclidean norm, 2e-3 of the tensor's, every entry 3e-2 of the largest; the
+            # forced-branch check above holds every gradient element of both steps to 1e-4)
+            late = step > 0
             worst = max(worst, _check(g, "%s_s%d_theta_%s" % (tag, step, n), p.data, seed + 299 + j, "step %d theta %s" % (step, n),
-                                      flips=late224, l2_tol=2e-3))
+                                      flips=late, l2_tol=2e-3))
     print("HAT wide_VGG9 at %d x %d: worst sampled relative deviation %.2e" % (hw, hw, worst))
 
 
