@@ -792,6 +792,10 @@ def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epoch
             res["gpu_first_accuracies"] = [r[i]["seq_res"][i][0] for i in sorted(r)]           # task i right after training it
             res["gpu_avg_accuracy"] = float(np.mean(res["gpu_final_accuracies"]))
             res["gpu_avg_forgetting"] = float(np.mean([r[i]["seq_forgetting"][i][-1] for i in sorted(r) if r[i]["seq_forgetting"][i]] or [0.0]))
+            res["outcome_note"] = ("penalised SGD runs near its stability limit on these tasks (an attempt with val_acc 0.0 diverged): which "
+                                   "attempts diverge, hence accepted lambdas, accuracies and forgetting, depend on fp32 rounding — the same "
+                                   "sweep on three fp32-grade kernel paths gave 77.3 / 4.0, 55.9 / 27.3 and 79.0 / 2.0 (avg accuracy / "
+                                   "forgetting; profiles/r05_m_sweep_three_paths.txt); agreement with the CPU path is judged by `pair`")
             res["chance_accuracy"] = 100.0 / 20
             res["best_possible_accuracy"] = 100.0 * (SWEEP_DATA["blobs"]["q"] + (1 - SWEEP_DATA["blobs"]["q"]) / 20)
         # ---- collect the CPU legs
