@@ -1899,7 +1899,11 @@ int clhip_internal_wino_wgrad_partial(const float* x, const float* dy, const uin
     if (wgrad_ps_on() && total < 16 * splits) {          // (measured: layer 2 of the bench model, 12.5 stages per block, 99 -> 92 us; 50 stages: slower)
         // fewer than 16 stages per 64 x 64 tile block: 32 x 32 tiles, a quarter of the splits, two blocks per CU (wino_wgrad_ps_kernel)
         const int kc32 = (K / 32) * (C / 32);
-        long long sp = kc32 >= 512 ? 1 : 512 / kc32;
+        // blocks of the launch = (k, c) tiles x pixel splits: two per CU; one per CU on 8 x 8 maps with few (k, c) tiles, where a block
+        // of the 512-block launch saw 3 - 6 stages (measured at N = 200, profiles/r05_o_wgps_blocks.txt: 64 -> 128 @8x8 30.5 -> 26.6 us,
+        // 128 -> 128 @8x8 40.7 -> 39.3; every other layer of small_VGG9 is fastest at 512: 256 / 384 / 768 / 1024 blocks cost 1 - 28 %)
+        const int target = ((long long)H * W <= 64 && kc32 <= 16) ? 256 : 512;
+        long long sp = kc32 >= target ? 1 : target / kc32;
         if (sp > total) sp = total;
         if (sp > cap) sp = cap;
         const unsigned gridp = (unsigned)(kc32 * sp);
