@@ -10,31 +10,34 @@
 // a0 + a1 + a2 with three bf16 pieces (8 + 8 + 8 significand bits, round-to-nearest residuals); every bf16 x bf16 product is exact
 // in fp32; the six products ai * bj with i + j <= 2 carry a * b to 2^-26 relative, the accumulation is fp32 inside the matrix core.
 // Measured against fp64 on 576 .. 4608-term dot products: max / rms error 1.1 - 2.2e-7 / 2.3 - 3.3e-8 of sum|a b| — the same as
-// the f32-input MFMA chain (1.2 - 2.1e-7 / 2.7 - 2.9e-8) and as a host fmaf chain.  Six bf16 MFMAs per 16-deep k-step = 2.67x the
+// the f32-input MFMA chain (1.2 - 2.1e-7 / 2.7 - 2.9e-8) and as a host fmaf chain; 4 - 8e-8 / 1e-8 with a0 b0 in its own accumulator.  Six bf16 MFMAs per 16-deep k-step = 2.67x the
 // f32 matrix rate on the DIRECT form (no Winograd transforms: their VALU work was the problem, and their conditioning is gone too).
 //
-// Data flow of one block (256 threads = 4 waves as 2 x 2; 128 output pixels x 64 output channels; two blocks per CU):
+// Data flow of one block (256 threads = 4 waves as 2 x 2, each 64 pixels x 32 channels; 128 output pixels x 64 output channels;
+// three blocks per CU):
 //   * per 16-channel chunk the (RH + 2) x (RW + 2) halo tile of the input is loaded NCHW -> registers (dword buffer loads, lanes
 //     along x; one chunk ahead), split into 3 bf16 pieces and written to LDS as [piece][k half][halo row][pitch P] x 16 bytes
 //     (8 channels of one pixel, the A operand of one lane).  P = 8 mod 16 slots: the 16 lanes of every ds_read_b128 lane group
-//     hit 16 different 4-bank groups for every tap (MI355X_MICROARCH.md, LDS table).
-//   * weights: a lane-ordered image [n tile][chunk][tap][piece][lane] x 16 bytes (bs_weight_multi_kernel, once per pass); the
-//     block copies the chunk's two 27 KB slices into LDS (coalesced 16-byte loads, one chunk ahead in registers) and every wave
-//     reads its B operands from there.  (First build: every wave read them straight from L2 / L1 — 54 KB per wave and chunk, the
-//     vector-memory path of the CU at 60 % for the weights alone; measured 92 us on layer 2 against a 36 us matrix floor,
-//     profiles/r05_bs_v1_per_layer.txt.)
-//   * single-buffered: barrier, stage chunk c, barrier, 108 MFMAs per wave from LDS only — the co-resident block fills the
-//     matrix pipe while this one stages.
+//     hit 16 different 4-bank groups for every tap (MI355X_MICROARCH.md, LDS table; measured 1.7 % conflict cycles).
+//     Double-buffered, one barrier per chunk; the split / LDS writes of chunk c + 1 and the loads of chunk c + 2 are issued INSIDE
+//     the wave's MFMA stream of chunk c (one basic block per chunk).
+//   * weights: a lane-ordered image [n tile][chunk][tap][piece][lane] x 16 bytes (bs_weight_multi_kernel, once per pass) is read
+//     straight from L2 / L1 with one coalesced 1 KB buffer_load_dwordx4 per operand, one tap ahead.  (Copying the chunk's slices to
+//     LDS once per block instead — three different block structures, see the notes in front of the kernel — was slower every time.)
 //   * an MFMA tile is 32 pixels x 32 channels; the 32 pixels are 8 pooling windows x 4 positions (m = 4 w + q) so that the four
 //     accumulator registers r = 4 g + q of a lane are one 2x2 window: ReLU + max-pool + arg-max code are lane-local.
-//   * per (tap, k-step) a wave issues 6 MFMAs per tile pair, small products first: a0 b2, a2 b0, a1 b1, a0 b1, a1 b0, a0 b0.
+//   * per (tap, k-step) a wave issues 6 MFMAs per tile: a0 b2, a0 b0, a2 b0, a1 b1, a0 b1, a1 b0 — a0 b0 into an accumulator of
+//     its own (added in the epilogue): a third of the error of one accumulator.
+//   * outputs leave through an LDS transposition (the staging buffers are free by then) as whole rows: float4 stores of 32 .. 128
+//     contiguous bytes per channel instead of 64 scattered 8-byte pieces per store instruction.
+//   * the same kernel with 25 taps (KS = 5, halo 2) is AlexNet's second convolution.
 //
 // Algorithmic FLOPs 2 * 9 * Cin * Cout * H * W * N; issued on the matrix pipe: 6x that, against the 2.5 PFLOP/s dense bf16 peak.
 #include "common.hpp"
 #include <cstdlib>
 
-// Timing-only ablations (tools/experiments; results wrong by design; the product is built with 0): 1 no MFMAs, 2 no LDS operand
-// reads, 4 no split / LDS writes, 8 no global loads, 16 no output stores, 32 no barriers, 64 per-lane (scattered) output stores
+// Timing-only ablations (tools/experiments; results wrong by design; the product is built with 0): 1 no MFMAs, 2 no weight-operand
+// loads, 4 no split / LDS writes, 8 no activation loads, 16 no output stores, 32 no barriers, 64 per-lane (scattered) output stores
 #ifndef BS_ABL
 #define BS_ABL 0
 #endif
@@ -47,14 +50,6 @@ typedef float bs_f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int BS_BN = 64;            // output channels per block
 constexpr int BS_CK = 16;            // input channels per k-step (K of v_mfma_f32_32x32x16_bf16)
-
-// Workgroup barrier of the producer / consumer split: the two roles are whole waves and every wave executes the same NUMBER of these
-// (S_BARRIER counts arriving waves); LDS writes before it are visible after it (release / acquire fences at workgroup scope).
-__device__ __forceinline__ void bs_barrier() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
 
 // two floats -> two bf16 (round to nearest even), `lo` in bits 0..15: v_cvt_pk_bf16_f32
 __device__ __forceinline__ unsigned bs_pk(float lo, float hi) {
