@@ -63,6 +63,8 @@ SIGNATURES = {
     "clhip_conv3x3_bs_bwd_data": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
     "clhip_conv3x3_wino_bwd_weight_ws": (_z, [_i, _i, _i, _i, _i]),
     "clhip_conv3x3_wino_bwd_weight": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "clhip_conv3x3_wino_bwd_ws": (_z, [_i, _i, _i, _i, _i]),
+    "clhip_conv3x3_wino_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
     "clhip_maxpool2_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "clhip_maxpool2_bwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "clhip_fc_ws": (_z, [_i, _i, _i]),

@@ -151,6 +151,10 @@ bool clhip_internal_wino_wgrad_ok(int C, int K, int H, int W);
 size_t clhip_internal_wino_wgrad_ws(int N, int C, int K, int H, int W);
 int clhip_internal_wino_wgrad_partial(const float* x, const float* dy, const uint8_t* unpool_idx, float* dw, float* db, int N, int C,
                                       int K, int H, int W, void* ws, size_t ws_bytes, hipStream_t s, clhip_wgrad_job* job);
+// backward-data + weight-gradient slabs of one 3x3 layer as ONE grid (wino.hip, wino_pair_kernel); CLHIP_ENOTSUP: two launches
+int clhip_internal_wino_pair(const float* dy, const uint8_t* unpool_idx, const float* U, const float* mask_src, float* dx,
+                             const float* x, float* dw, float* db, int N, int C, int K, int H, int W, void* ws, size_t ws_bytes,
+                             hipStream_t s, clhip_wgrad_job* job);
 int clhip_internal_wino_conv(int mode, const float* in, const float* w, const float* bias, const float* mask_src, float* out,
                              uint8_t* pool_idx, int unpool, int N, int Cin, int Cout, int H, int W, int relu, void* ws,
                              size_t ws_bytes, hipStream_t s);

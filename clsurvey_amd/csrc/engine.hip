@@ -703,6 +703,12 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
     hipEvent_t last_side = nullptr;
     int taken = -1;
     const bool defer = p->n_wg > 0 && !ov;
+    // layers whose backward-data and weight gradient can go out as one grid: plain 3x3 layers on the Winograd kernels with deferred
+    // slabs, a backward-data to compute and nothing to apply to it afterwards (clhip_internal_wino_pair decides on the shape)
+    auto pair_ok = [&](const LayerPlan& Lp, int layer) {
+        return defer && layer > 0 && Lp.type == 0 && Lp.ks == 3 && Lp.st == 1 && Lp.pd == 1 && !Lp.bn && Lp.wino_w && Lp.wino_d &&
+               !Lp.bs_d && Lp.wg_bytes && !Lp.drop && !Lp.extra_grad && !side_ok(layer);
+    };
     clhip_wgrad_job jobs[CLHIP_WGRAD_JOBS_MAX];
     int n_jobs = 0;
     // next ping-pong buffer as an OUTPUT of a main-stream launch
@@ -821,6 +827,17 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
             // the POOLED gradient + the arg-max codes while staging it, when their kernels support the shape (first
             // layer: the small-C kernel; others: the 16-byte staging paths).  The 4x larger un-pooled tensor and the
             // clhip_maxpool2_bwd launch disappear.
+            if (pair_ok(L, i)) {
+                // backward-data and the weight-gradient slabs of this layer as ONE grid (wino.hip, wino_pair_kernel)
+                gout_d = take(); gout_d_buf = taken;
+                probe_begin(p->probe_kind);
+                rc = clhip_internal_wino_pair(gin, idx + L.idx_off, reinterpret_cast<const float*>(base + p->off_wino + L.wino_ud), xmask,
+                                              gout_d, xin, grads + L.w_off, grads + L.b_off, N, L.cin, L.cout, L.h, L.w,
+                                              base + p->off_wg + L.wg_off, L.wg_bytes, main_s, &jobs[n_jobs]);
+                if (rc == 0) { wdone = ddone = true; ++n_jobs; probe_end(p->probe_kind); }
+                else if (rc != CLHIP_ENOTSUP) return rc;
+            }
+            if (!wdone) {
             probe_begin(2);
             rc = on_side(i, gin_buf, [&](void* st) {
                 if (defer && L.wino_w) {
@@ -838,8 +855,9 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
             });
             if (rc == 0) { wdone = true; if (defer) ++n_jobs; probe_end(2); }
             else if (rc != CLHIP_ENOTSUP) return rc;
-            if (wdone && i > 0 && !L.drop && !L.extra_grad) {
-                gout_d = take(); gout_d_buf = taken;
+            }
+            if (wdone && !ddone && i > 0 && !L.drop && !L.extra_grad) {
+                if (!gout_d) { gout_d = take(); gout_d_buf = taken; }
                 probe_begin(1);
                 rc = L.wino_d ? plan_conv_u(L.bs_d, 1, gin, reinterpret_cast<const float*>(base + p->off_wino + L.wino_ud), nullptr,
                                                            xmask, gout_d, idx + L.idx_off, 1, N, L.cout, L.cin, L.h, L.w, 0, as_stream(stream))
@@ -856,6 +874,7 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
                         : clhip_maxpool_bwd(gin, idx + L.idx_off, gout, N * L.cout, L.oh, L.ow, L.pk, L.ps, stream);
             if (rc) return rc;
             gy = gout; gy_buf = taken;
+            gout_d = nullptr;
         }
         if (L.bn) {
             // dy (w.r.t. the ReLU output) -> dz (w.r.t. the convolution output), in place; dgamma, dbeta
@@ -865,6 +884,15 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
             rc = clhip_bn_bwd(gy, acts + L.act_off, acts + L.z_off, params + L.bn_w_off, st, st + L.cout, dzb, grads + L.bn_w_off,
                               grads + L.bn_b_off, N, L.cout, L.oh * L.ow, p->training, L.relu, scratch, p->scratch_bytes, stream);
             if (rc) return rc;
+        }
+        if (!wdone && !L.pool && !gout_d && pair_ok(L, i)) {
+            gout_d = take(); gout_d_buf = taken;
+            probe_begin(p->probe_kind);
+            rc = clhip_internal_wino_pair(gy, nullptr, reinterpret_cast<const float*>(base + p->off_wino + L.wino_ud), xmask, gout_d, xin,
+                                          grads + L.w_off, grads + L.b_off, N, L.cin, L.cout, L.h, L.w, base + p->off_wg + L.wg_off,
+                                          L.wg_bytes, main_s, &jobs[n_jobs]);
+            if (rc == 0) { wdone = ddone = true; ++n_jobs; probe_end(p->probe_kind); }
+            else if (rc != CLHIP_ENOTSUP) return rc;
         }
         if (!wdone) {
             bool job = false;                 // this layer left slabs for the deferred reduction
@@ -894,7 +922,8 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
         if (i > 0 && ddone) {
             gin = gout_d; gin_buf = gout_d_buf;
         } else if (i > 0) {
-            float* gout = take();
+            float* gout = gout_d;             // (taken for a merged launch that declined the shape)
+            if (gout) taken = gout_d_buf; else gout = take();
             probe_begin(1);
             rc = (vgg && L.wino_d)
                      ? plan_conv_u(L.bs_d, 1, gy, reinterpret_cast<const float*>(base + p->off_wino + L.wino_ud), nullptr, xmask, gout,

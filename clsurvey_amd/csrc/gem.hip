@@ -78,8 +78,8 @@ __device__ __forceinline__ void gram_acc1(double* acc, const float* v, std::inte
 
 // Accumulation of wave group GRP's pairs over this block's columns; acc is padded to the same NA_MAX slots in every group
 // (slots past the group's own pair count stay 0) so that the reduction below is ONE piece of code for the whole block.
-template <int M, int S, int GRP, bool VEC>
-__device__ __forceinline__ void gram_accumulate(const float* __restrict__ G, size_t ld, const RowSel& sel, size_t n,
+template <int M, int S, int GRP>
+__device__ __forceinline__ void gram_accumulate(const float* __restrict__ G, size_t ld, const RowSel& sel, size_t n, bool vec,
                                                 double (&acc)[(M * (M + 1) / 2 + S - 1) / S]) {
     constexpr int NP = M * (M + 1) / 2;
     constexpr int NA = (NP - GRP + S - 1) / S;            // pairs GRP, GRP + S, ... of this wave
@@ -89,7 +89,7 @@ __device__ __forceinline__ void gram_accumulate(const float* __restrict__ G, siz
     for (int k = 0; k < NA_MAX; ++k) acc[k] = 0.0;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const size_t col0 = (size_t)blockIdx.x * COLS + (size_t)(wave / S) * 64 + lane, stride = (size_t)gridDim.x * COLS;
-    const size_t n4 = VEC ? n / 4 : 0;
+    const size_t n4 = vec ? n / 4 : 0;      // (a run-time flag: the 16-byte loop and the scalar loop are both in every instance anyway)
     for (size_t c4 = col0; c4 < n4; c4 += stride) {
         float4 v[M];
 #pragma unroll
@@ -104,8 +104,8 @@ __device__ __forceinline__ void gram_accumulate(const float* __restrict__ G, siz
     }
 }
 
-template <int M, bool VEC>
-__global__ __launch_bounds__(GB) void gram_partial_kernel(const float* __restrict__ G, size_t ld, RowSel sel, size_t n,
+template <int M>
+__global__ __launch_bounds__(GB) void gram_partial_kernel(const float* __restrict__ G, size_t ld, RowSel sel, size_t n, int vec,
                                                           double* __restrict__ partial) {
     constexpr int S = gram_split(M);
     constexpr int NP = M * (M + 1) / 2;
@@ -116,15 +116,15 @@ __global__ __launch_bounds__(GB) void gram_partial_kernel(const float* __restric
     double acc[NA_MAX];
     // only the ACCUMULATION is specific to the wave group (compile-time pair indices); no barrier inside the branches
     if constexpr (S == 1) {
-        gram_accumulate<M, 1, 0, VEC>(G, ld, sel, n, acc);
+        gram_accumulate<M, 1, 0>(G, ld, sel, n, vec != 0, acc);
     } else if constexpr (S == 2) {
-        if (grp) gram_accumulate<M, 2, 1, VEC>(G, ld, sel, n, acc);
-        else gram_accumulate<M, 2, 0, VEC>(G, ld, sel, n, acc);
+        if (grp) gram_accumulate<M, 2, 1>(G, ld, sel, n, vec != 0, acc);
+        else gram_accumulate<M, 2, 0>(G, ld, sel, n, vec != 0, acc);
     } else {
-        if (grp == 0) gram_accumulate<M, 4, 0, VEC>(G, ld, sel, n, acc);
-        else if (grp == 1) gram_accumulate<M, 4, 1, VEC>(G, ld, sel, n, acc);
-        else if (grp == 2) gram_accumulate<M, 4, 2, VEC>(G, ld, sel, n, acc);
-        else gram_accumulate<M, 4, 3, VEC>(G, ld, sel, n, acc);
+        if (grp == 0) gram_accumulate<M, 4, 0>(G, ld, sel, n, vec != 0, acc);
+        else if (grp == 1) gram_accumulate<M, 4, 1>(G, ld, sel, n, vec != 0, acc);
+        else if (grp == 2) gram_accumulate<M, 4, 2>(G, ld, sel, n, vec != 0, acc);
+        else gram_accumulate<M, 4, 3>(G, ld, sel, n, vec != 0, acc);
     }
     // common code, every wave at the same barriers: fixed tree, first over the wave sets (offsets that keep wave % S), then
     // inside the wave; one pair slot per round (round k: pair grp + k * S of each wave group)
@@ -369,8 +369,7 @@ __global__ __launch_bounds__(GB) void project_dev_kernel(const float* __restrict
 
 template <int M>
 int gram_launch(const float* G, size_t ld, const RowSel& sel, size_t n, double* partial, int blocks, bool vec, hipStream_t s) {
-    if (vec) hipLaunchKernelGGL((gram_partial_kernel<M, true>), dim3(blocks), dim3(GB), 0, s, G, ld, sel, n, partial);
-    else hipLaunchKernelGGL((gram_partial_kernel<M, false>), dim3(blocks), dim3(GB), 0, s, G, ld, sel, n, partial);
+    hipLaunchKernelGGL((gram_partial_kernel<M>), dim3(blocks), dim3(GB), 0, s, G, ld, sel, n, vec ? 1 : 0, partial);
     return 0;
 }
 

@@ -1040,8 +1040,17 @@ __global__ __launch_bounds__(256, (CLHIP_W16_ADIRECT && !(UNPOOL && KT2 == 2)) ?
 //   EROWS = TR = 4    two entities = two whole 8 x 8 images                                   (<4, 4, 4>)
 //   EROWS = 1         four consecutive tile rows of the (image, tile row) list, odd maps 9..16 wide (AlexNet's 13 x 13: <8, 2, 1>;
 //                     49 of 56 tile slots busy; half-outside tiles read 0 and store nothing, 4-byte stores)
+// LDS floats of a block: the two chunk buffers, then the 64 bias values.  The kernel body is a device function over (LDS base, block
+// index) so that the SAME code is both the launch of its own (wino_conv16g_kernel) and one half of a merged grid (wino_pair_kernel,
+// below): the __global__ wrappers own the LDS array.
+template <int TC, int TR, int EROWS>
+__host__ __device__ constexpr int wino16g_lds_floats() {
+    return 2 * ((CLHIP_W16G_ADIRECT != 0 ? 0 : 4 * WKT * WFP) + 4 * (2 * TR / EROWS) * (2 * EROWS + 2) * (2 * TC + 2)) + WKT;
+}
+
 template <int TC, int TR, int EROWS, int MODE, bool UNPOOL>
-__global__ __launch_bounds__(256, 2) void wino_conv16g_kernel(
+__device__ __forceinline__ void wino_conv16g_body(
+    float* __restrict__ lds, const int bid,
     const float* __restrict__ in, const float* __restrict__ U, const float* __restrict__ bias,
     const float* __restrict__ mask_src, float* __restrict__ out, uint8_t* __restrict__ pool_idx,
     int N, int Cin, int Cout, int H, int W, int relu, int tiles_w, int tiles_h, int n_pix_blocks) {
@@ -1054,12 +1063,12 @@ __global__ __launch_bounds__(256, 2) void wino_conv16g_kernel(
     constexpr bool ADIRECT = CLHIP_W16G_ADIRECT != 0;                 // A operands from L2 straight into registers: LDS holds the halo planes only
     constexpr int WOFF = ADIRECT ? 0 : WQ_FLOATS;
     constexpr int X_FLOATS = CQ * PLANE, BUF = WOFF + X_FLOATS;
-    __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
-    __shared__ float bias_s[WKT];
+    static_assert(wino16g_lds_floats<TC, TR, EROWS>() == 2 * BUF + WKT, "LDS size of the wrappers");
+    float* const bias_s = lds + 2 * BUF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wk = wave & 1, wp = wave >> 1;
     const int ti = lane & 15, q = lane >> 4;
-    const int kt = blockIdx.x / n_pix_blocks, pb = blockIdx.x - kt * n_pix_blocks;
+    const int kt = bid / n_pix_blocks, pb = bid - kt * n_pix_blocks;
     // tiles_h = row groups (entities) per image; entity v = (image v / tiles_h, group v % tiles_h); offsets relative to image nb0
     const int bw = pb % tiles_w, v0 = (pb / tiles_w) * NE;
     const int nb0 = v0 / tiles_h, w0 = bw * 2 * TC;
@@ -1403,6 +1412,16 @@ __global__ __launch_bounds__(256, 2) void wino_conv16g_kernel(
     }
 }
 
+template <int TC, int TR, int EROWS, int MODE, bool UNPOOL>
+__global__ __launch_bounds__(256, 2) void wino_conv16g_kernel(
+    const float* __restrict__ in, const float* __restrict__ U, const float* __restrict__ bias,
+    const float* __restrict__ mask_src, float* __restrict__ out, uint8_t* __restrict__ pool_idx,
+    int N, int Cin, int Cout, int H, int W, int relu, int tiles_w, int tiles_h, int n_pix_blocks) {
+    __shared__ __attribute__((aligned(16))) float lds[wino16g_lds_floats<TC, TR, EROWS>()];
+    wino_conv16g_body<TC, TR, EROWS, MODE, UNPOOL>(lds, (int)blockIdx.x, in, U, bias, mask_src, out, pool_idx, N, Cin, Cout, H, W, relu,
+                                                   tiles_w, tiles_h, n_pix_blocks);
+}
+
 // (measured against the 32-tile kernel on even maps >= 16 wide in round 3: N = 200: 64->64 @32x32 forward 126 -> 109 us,
 // backward-data 136 -> 110; 256->256 @16x16 357 -> 317 = 190 TFLOP/s algorithmic)
 static bool wino16g_on() { return true; }
@@ -1446,15 +1465,15 @@ struct WGeoP {
 // LDS writes the compiler pairs into ds_write2_b32) plus the two halo columns as scalars, dy rows as float4s (two ds_write_b64) —
 // 6 + 2 vector loads and 10 + 4 LDS writes per thread and stage where the scalar form has 16 + 8 and 16 + 8.
 template <int TCS, int TRS, bool UNPOOL, bool VEC>
-__global__ __launch_bounds__(256, 2) void wino_wgrad_ps_kernel(
+__device__ __forceinline__ void wino_wgrad_ps_body(
+    float* __restrict__ lds, const int bid,
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, const uint8_t* __restrict__ unpool_idx,
     int N, int C, int K, int H, int W, int tiles_w, int tiles_h, int total_stages, int splits, int c_tiles, size_t slab_stride) {
     using G = WGeoP<TCS, TRS>;
-    __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wc = wave & 1, wp = wave >> 1;
     const int li = lane & 15, q = lane >> 4;
-    const int split = blockIdx.x % splits, tile = blockIdx.x / splits;
+    const int split = bid % splits, tile = bid / splits;
     const int ct = tile % c_tiles, kt = tile / c_tiles;
     const int k0 = kt * G::KB, c0 = ct * G::CB;
     const int per = total_stages / splits, extra = total_stages % splits;
@@ -1744,7 +1763,59 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_ps_kernel(
     }
 }
 
+template <int TCS, int TRS, bool UNPOOL, bool VEC>
+__global__ __launch_bounds__(256, 2) void wino_wgrad_ps_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, const uint8_t* __restrict__ unpool_idx,
+    int N, int C, int K, int H, int W, int tiles_w, int tiles_h, int total_stages, int splits, int c_tiles, size_t slab_stride) {
+    __shared__ __attribute__((aligned(16))) float lds[WGeoP<TCS, TRS>::LDS_FLOATS];
+    wino_wgrad_ps_body<TCS, TRS, UNPOOL, VEC>(lds, (int)blockIdx.x, x, dy, part, unpool_idx, N, C, K, H, W, tiles_w, tiles_h,
+                                              total_stages, splits, c_tiles, slab_stride);
+}
+
 static bool wgrad_ps_on() { return true; }       // (small layers: the pixel-split Winograd weight gradient, wino_wgrad_ps_kernel)
+
+// ------------------------------------------------------------------------------------------------ backward of a small layer as ONE grid
+// The deep layers of the VGG9s (16 x 16 and 8 x 8 maps at N = 200) give every launch of their backward pass 200 - 512 blocks: ONE
+// round of blocks on 256 CUs x 2, all of them in the same phase at the same time — every block loads its first operands together,
+// runs its MFMAs together, stores together — and the matrix pipe idles through the memory phases (0.17 - 0.35 of the pipe issued,
+// DESIGN 6).  Backward-data and the weight gradient of a layer read the same dy and do not depend on each other.  Issued on two
+// streams WITHOUT events between them the two launches of a layer take 20 - 35 % less than one after the other
+// (profiles/r05_s_coresident_pair.txt: blocks of different phase share the CUs); with the events a plan needs the gain is gone
+// (CLHIP_WGRAD_OVERLAP=2, round 4: slower).  Here the two launches are one grid: block b is a block of wino_conv16g_kernel
+// (MODE 1) or a block of wino_wgrad_ps_kernel, the same device code as the two kernels of their own (their bodies are device
+// functions over an LDS base and a block index), results bit-identical to the two launches.
+// Order of the blocks: groups of 8 consecutive blocks (one per XCD) alternate between the two kinds, and the phase of the
+// alternation flips every 32 groups, so that the two blocks a CU receives first differ in kind whichever way the dispatcher
+// fills the CUs of an XCD (CU-major or slot-major); once the shorter list is used up the rest of the longer one follows.
+template <int TC, int TR, int EROWS, bool UNPOOL, int TCS, int TRS>
+__global__ __launch_bounds__(256, 2) void wino_pair_kernel(
+    // backward-data half (arguments of wino_conv16g_kernel<TC, TR, EROWS, 1, UNPOOL>)
+    const float* __restrict__ d_in, const float* __restrict__ d_U, const float* __restrict__ d_mask, float* __restrict__ d_out,
+    uint8_t* __restrict__ d_idx, int N, int d_Cin, int d_Cout, int H, int W, int d_tiles_w, int d_tiles_h, int d_npb,
+    // weight-gradient half (arguments of wino_wgrad_ps_kernel<TCS, TRS, UNPOOL, true>)
+    const float* __restrict__ w_x, float* __restrict__ w_part, int w_tiles_w, int w_tiles_h, int w_total, int w_splits, int w_ctiles,
+    size_t w_slab, int nb_d, int nb_w) {
+    constexpr int LD = wino16g_lds_floats<TC, TR, EROWS>(), LW = WGeoP<TCS, TRS>::LDS_FLOATS;
+    __shared__ __attribute__((aligned(16))) float lds[LD > LW ? LD : LW];
+    const int b = (int)blockIdx.x;
+    const int m8 = (nb_d < nb_w ? nb_d : nb_w) & ~7;       // blocks of each kind inside the alternating part
+    int kind, idx;                                          // kind 0: backward-data block idx, 1: weight-gradient block idx
+    if (b < 2 * m8) {
+        const int g = b >> 3;
+        kind = (g + (g >> 5)) & 1;
+        idx = (g >> 1) * 8 + (b & 7);
+    } else {
+        const int r = b - 2 * m8;
+        kind = r < nb_d - m8 ? 0 : 1;
+        idx = m8 + (kind ? r - (nb_d - m8) : r);
+    }
+    if (kind == 0)
+        wino_conv16g_body<TC, TR, EROWS, 1, UNPOOL>(lds, idx, d_in, d_U, nullptr, d_mask, d_out, d_idx, N, d_Cin, d_Cout, H, W, 0,
+                                                    d_tiles_w, d_tiles_h, d_npb);
+    else
+        wino_wgrad_ps_body<TCS, TRS, UNPOOL, true>(lds, idx, w_x, d_in, w_part, d_idx, N, d_Cout, d_Cin, H, W, w_tiles_w, w_tiles_h,
+                                                   w_total, w_splits, w_ctiles, w_slab);
+}
 
 template <int MODE, bool UNPOOL>
 int launch_wino(const float* in, const float* U, const float* bias, const float* mask_src, float* out, uint8_t* pool_idx,
@@ -1875,40 +1946,70 @@ size_t clhip_internal_wino_wgrad_ws(int N, int C, int K, int H, int W) {
     return ((size_t)9 * K * C + K) * (size_t)((256 + kc_tiles - 1) / kc_tiles) * sizeof(float);
 }
 
-int clhip_internal_wino_wgrad_partial(const float* x, const float* dy, const uint8_t* unpool_idx, float* dw, float* db, int N, int C,
-                                      int K, int H, int W, void* ws, size_t ws_bytes, hipStream_t s, clhip_wgrad_job* job) {
-    if (!x || !dy || !dw || !ws || !job || N <= 0) return CLHIP_EINVAL;
+// Launch geometry of the weight gradient of one layer.  ps: the pixel-split kernel (wino_wgrad_ps_kernel) takes it, with `splits`
+// pixel splits of its kc32 32 x 32 (k, c) tiles; else wino_wgrad_kernel with `splits` splits of its kc_tiles 64 x 64 tiles.
+struct WgradGeo {
+    bool wide, ps, vec;
+    int tiles_w, tiles_h, kc_tiles, kc32;
+    long long total, splits;
+    size_t slab;
+};
+
+// CLHIP_ENOTSUP: not a shape of the Winograd weight gradient; CLHIP_ENOSPC: the workspace does not hold one slab
+static int wino_wgrad_geo(const float* x, const float* dy, const uint8_t* unpool_idx, int N, int C, int K, int H, int W,
+                          size_t ws_bytes, WgradGeo* g) {
     if (!clhip_internal_wino_wgrad_ok(C, K, H, W)) return CLHIP_ENOTSUP;
     if ((size_t)N * K * H * W >= ((size_t)1 << 29) || (size_t)N * C * H * W >= ((size_t)1 << 29)) return CLHIP_ENOTSUP;   // 32-bit byte offsets
-    const bool wide = W >= 16;
-    const int TCS = wide ? 8 : 4, TRS = wide ? 2 : 4;
+    g->wide = W >= 16;
+    const int TCS = g->wide ? 8 : 4, TRS = g->wide ? 2 : 4;
     if (((H | W) & 1) && unpool_idx) return CLHIP_ENOTSUP;
-    const int tiles_w = ((W + 1) / 2 + TCS - 1) / TCS, tiles_h = ((H + 1) / 2 + TRS - 1) / TRS;
-    const long long total = (long long)tiles_w * tiles_h * N;
-    if (total > 0x7fffffffLL) return CLHIP_ENOTSUP;
-    const int kc_tiles = (K / WKT) * (C / WKT);
-    const size_t slab = (size_t)9 * K * C + K;
+    g->tiles_w = ((W + 1) / 2 + TCS - 1) / TCS;
+    g->tiles_h = ((H + 1) / 2 + TRS - 1) / TRS;
+    g->total = (long long)g->tiles_w * g->tiles_h * N;
+    if (g->total > 0x7fffffffLL) return CLHIP_ENOTSUP;
+    g->kc_tiles = (K / WKT) * (C / WKT);
+    g->slab = (size_t)9 * K * C + K;
     // one block per CU: the largest split count that keeps the grid within 256 blocks (18 (k, c) tiles x 15 splits = 270 blocks
     // ran as two rounds on AlexNet's 192 -> 384 layer: 405 us against 215 us with 14 splits)
-    long long splits = kc_tiles >= 256 ? 1 : 256 / kc_tiles;
-    if (splits > total) splits = total;
-    const long long cap = (long long)(ws_bytes / (slab * sizeof(float)));
+    long long splits = g->kc_tiles >= 256 ? 1 : 256 / g->kc_tiles;
+    if (splits > g->total) splits = g->total;
+    const long long cap = (long long)(ws_bytes / (g->slab * sizeof(float)));
     if (cap < 1) return CLHIP_ENOSPC;
     if (splits > cap) splits = cap;
-    float* part = static_cast<float*>(ws);
-    if (wgrad_ps_on() && total < 16 * splits) {          // (measured: layer 2 of the bench model, 12.5 stages per block, 99 -> 92 us; 50 stages: slower)
+    g->splits = splits;
+    // whole tiles in width and 16-byte-aligned tensors: stages staged in 16-byte pieces (VEC; other shapes: the scalar form)
+    g->vec = W % (2 * TCS) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
+    g->kc32 = (K / 32) * (C / 32);
+    g->ps = wgrad_ps_on() && g->total < 16 * splits;      // (measured: layer 2 of the bench model, 12.5 stages per block, 99 -> 92 us; 50 stages: slower)
+    if (g->ps) {
         // fewer than 16 stages per 64 x 64 tile block: 32 x 32 tiles, a quarter of the splits, two blocks per CU (wino_wgrad_ps_kernel)
-        const int kc32 = (K / 32) * (C / 32);
         // blocks of the launch = (k, c) tiles x pixel splits: two per CU; one per CU on 8 x 8 maps with few (k, c) tiles, where a block
         // of the 512-block launch saw 3 - 6 stages (measured at N = 200, profiles/r05_o_wgps_blocks.txt: 64 -> 128 @8x8 30.5 -> 26.6 us,
         // 128 -> 128 @8x8 40.7 -> 39.3; every other layer of small_VGG9 is fastest at 512: 256 / 384 / 768 / 1024 blocks cost 1 - 28 %)
-        const int target = ((long long)H * W <= 64 && kc32 <= 16) ? 256 : 512;
-        long long sp = kc32 >= target ? 1 : target / kc32;
-        if (sp > total) sp = total;
+        const int target = ((long long)H * W <= 64 && g->kc32 <= 16) ? 256 : 512;
+        long long sp = g->kc32 >= target ? 1 : target / g->kc32;
+        if (sp > g->total) sp = g->total;
         if (sp > cap) sp = cap;
-        const unsigned gridp = (unsigned)(kc32 * sp);
-        // whole tiles in width and 16-byte-aligned tensors: stages staged in 16-byte pieces (VEC; other shapes: the scalar form)
-        const bool vec = W % (2 * TCS) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
+        g->splits = sp;
+    }
+    return 0;
+}
+
+int clhip_internal_wino_wgrad_partial(const float* x, const float* dy, const uint8_t* unpool_idx, float* dw, float* db, int N, int C,
+                                      int K, int H, int W, void* ws, size_t ws_bytes, hipStream_t s, clhip_wgrad_job* job) {
+    if (!x || !dy || !dw || !ws || !job || N <= 0) return CLHIP_EINVAL;
+    WgradGeo g;
+    const int rc = wino_wgrad_geo(x, dy, unpool_idx, N, C, K, H, W, ws_bytes, &g);
+    if (rc) return rc;
+    const bool wide = g.wide;
+    const int tiles_w = g.tiles_w, tiles_h = g.tiles_h, kc_tiles = g.kc_tiles;
+    const long long total = g.total, splits = g.splits;
+    const size_t slab = g.slab;
+    float* part = static_cast<float*>(ws);
+    if (g.ps) {
+        const long long sp = g.splits;
+        const unsigned gridp = (unsigned)(g.kc32 * sp);
+        const bool vec = g.vec;
 #define WGP(TCS_, TRS_, UNP_)                                                                                                       \
         do {                                                                                                                       \
             if (vec) hipLaunchKernelGGL((wino_wgrad_ps_kernel<TCS_, TRS_, UNP_, true>), dim3(gridp), dim3(256), 0, s, x, dy, part,  \
@@ -1924,8 +2025,7 @@ int clhip_internal_wino_wgrad_partial(const float* x, const float* dy, const uin
         return 0;
     }
     const unsigned grid = (unsigned)(kc_tiles * splits);
-    // whole tiles in width and 16-byte-aligned tensors: stages staged in 16-byte pieces (VEC; other shapes: the scalar form)
-    const bool vecg = W % (2 * TCS) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
+    const bool vecg = g.vec;
 #define WG(TCS_, TRS_, UNP_)                                                                                                         \
     do {                                                                                                                            \
         if (vecg) hipLaunchKernelGGL((wino_wgrad_kernel<TCS_, TRS_, 1, UNP_, true>), dim3(grid), dim3(256), 0, s, x, dy, part,       \
@@ -1938,6 +2038,48 @@ int clhip_internal_wino_wgrad_partial(const float* x, const float* dy, const uin
 #undef WG
     CLHIP_LAUNCH_CHECK();
     *job = clhip_wgrad_job{part, dw, db, K, C, (int)splits};
+    return 0;
+}
+
+// Backward of one 3x3 layer as ONE grid (wino_pair_kernel): dx = backward-data of dy on weights already transformed into U (mode 1
+// of clhip_internal_wino_weights), and the weight-gradient slabs of (x, dy) into ws, exactly as clhip_internal_wino_conv_u(1, ...)
+// followed by clhip_internal_wino_wgrad_partial would leave them (same device code, same block -> work mapping inside each half).
+// C / K: the layer's in / out channels; unpool_idx: dy is the POOLED gradient + arg-max codes.  CLHIP_ENOTSUP: not a layer this
+// grid takes (the caller issues the two launches): it takes even maps >= 16 wide and 8 x 8 maps whose weight gradient runs on the
+// pixel-split kernel with 16-byte staging, at most CLHIP_PAIR_MAX_PIXELS pixels per map — the launches that fill one round of
+// blocks or less; on larger maps the two launches fill the chip on their own (64 -> 64 @32x32: 190.8 us one after the other,
+// 190.6 us co-resident, profiles/r05_s_coresident_pair.txt).
+#ifndef CLHIP_PAIR_MAX_PIXELS
+#define CLHIP_PAIR_MAX_PIXELS 256
+#endif
+int clhip_internal_wino_pair(const float* dy, const uint8_t* unpool_idx, const float* U, const float* mask_src, float* dx,
+                             const float* x, float* dw, float* db, int N, int C, int K, int H, int W, void* ws, size_t ws_bytes,
+                             hipStream_t s, clhip_wgrad_job* job) {
+    if (!dy || !U || !dx || !x || !dw || !ws || !job || N <= 0) return CLHIP_EINVAL;
+    if (((H | W) & 1) || (long long)H * W > CLHIP_PAIR_MAX_PIXELS || !clhip_internal_wino_ok(K, C, H, W)) return CLHIP_ENOTSUP;
+    const bool wide = W >= 16, m88 = H == 8 && W == 8;
+    if (!wide && !m88) return CLHIP_ENOTSUP;
+    WgradGeo g;
+    const int rc = wino_wgrad_geo(x, dy, unpool_idx, N, C, K, H, W, ws_bytes, &g);
+    if (rc) return rc == CLHIP_ENOSPC ? CLHIP_ENOTSUP : rc;
+    if (!g.ps || !g.vec || g.wide != wide) return CLHIP_ENOTSUP;
+    // backward-data half: geometry of launch_wino's 16-tile launch (kernel Cin = K, Cout = C)
+    const int TC = wide ? 8 : 4, TR = wide ? 2 : 4, ER = 4, NE = 2 * TR / ER;
+    const int d_tiles_w = (W / 2 + TC - 1) / TC, d_groups = (H / 2 + ER - 1) / ER;
+    const long long npb = (((long long)N * d_groups + NE - 1) / NE) * d_tiles_w, nb_d = npb * ((C + WKT - 1) / WKT);
+    const long long nb_w = (long long)g.kc32 * g.splits;
+    if (nb_d <= 0 || nb_w <= 0 || nb_d + nb_w > 0x7fffffffLL) return CLHIP_ENOTSUP;
+    float* part = static_cast<float*>(ws);
+    uint8_t* idx = const_cast<uint8_t*>(unpool_idx);
+#define PAIR(TC_, TR_, UNP_)                                                                                                        \
+    hipLaunchKernelGGL((wino_pair_kernel<TC_, TR_, 4, UNP_, TC_, TR_>), dim3((unsigned)(nb_d + nb_w)), dim3(256), 0, s, dy, U, mask_src, \
+                       dx, idx, N, K, C, H, W, d_tiles_w, d_groups, (int)npb, x, part, g.tiles_w, g.tiles_h, (int)g.total,          \
+                       (int)g.splits, C / 32, g.slab, (int)nb_d, (int)nb_w)
+    if (wide) { if (unpool_idx) PAIR(8, 2, true); else PAIR(8, 2, false); }
+    else { if (unpool_idx) PAIR(4, 4, true); else PAIR(4, 4, false); }
+#undef PAIR
+    CLHIP_LAUNCH_CHECK();
+    *job = clhip_wgrad_job{part, dw, db, K, C, (int)g.splits};
     return 0;
 }
 
@@ -1973,6 +2115,37 @@ int clhip_conv3x3_wino_bwd_weight(const float* x, const float* dy, const uint8_t
     int rc = clhip_internal_wino_wgrad_partial(x, dy, idx_u8_or_null, dw, db, N, C, K, H, W, ws, ws_bytes, as_stream(stream), &job);
     if (rc) return rc;
     return clhip_conv3x3_bwd_weight_reduce(ws, dw, db, K, C, job.splits, stream);
+}
+
+// workspace of clhip_conv3x3_wino_bwd: the transformed weights (16-byte multiple), then the weight-gradient slabs
+static size_t wino_bwd_u_bytes(int C, int K) { return (clhip_internal_wino_ws(K, C) + 255) & ~(size_t)255; }
+
+size_t clhip_conv3x3_wino_bwd_ws(int N, int C, int K, int H, int W) {
+    const size_t slabs = clhip_internal_wino_wgrad_ws(N, C, K, H, W);
+    return slabs ? wino_bwd_u_bytes(C, K) + slabs : 0;
+}
+
+int clhip_conv3x3_wino_bwd(const float* x, const float* dy, const uint8_t* idx_u8_or_null, const float* w, const float* relu_src,
+                           float* dx, float* dw, float* db, int N, int C, int K, int H, int W, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !dy || !w || !dx || !dw || !ws || N <= 0) return CLHIP_EINVAL;
+    if (((H | W) & 1) || !clhip_internal_wino_ok(K, C, H, W) || !clhip_internal_wino_wgrad_ok(C, K, H, W)) return CLHIP_ENOTSUP;
+    const size_t ub = wino_bwd_u_bytes(C, K);
+    if (ws_bytes < clhip_conv3x3_wino_bwd_ws(N, C, K, H, W)) return CLHIP_EINVAL;
+    hipStream_t s = as_stream(stream);
+    float* U = static_cast<float*>(ws);
+    const int n_chunks = (K + WCK - 1) / WCK;
+    const int total = ((C + WKT - 1) / WKT) * n_chunks * WCK * WKT;
+    clhip_wgrad_job job;
+    // (shape check first: nothing is launched for a layer the merged grid does not take)
+    WgradGeo g;
+    if (wino_wgrad_geo(x, dy, idx_u8_or_null, N, C, K, H, W, ws_bytes - ub, &g) || !g.ps || !g.vec) return CLHIP_ENOTSUP;
+    if ((long long)H * W > CLHIP_PAIR_MAX_PIXELS || !(W >= 16 || (H == 8 && W == 8))) return CLHIP_ENOTSUP;
+    hipLaunchKernelGGL(wino_weight_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w, U, C, K, 1, n_chunks);
+    CLHIP_LAUNCH_CHECK();
+    int rc = clhip_internal_wino_pair(dy, idx_u8_or_null, U, relu_src, dx, x, dw, db, N, C, K, H, W, static_cast<char*>(ws) + ub,
+                                      ws_bytes - ub, s, &job);
+    if (rc) return rc;
+    return clhip_conv3x3_bwd_weight_reduce(static_cast<char*>(ws) + ub, dw, db, K, C, job.splits, stream);
 }
 
 }  // extern "C"

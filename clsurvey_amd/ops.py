@@ -159,6 +159,26 @@ def conv3x3_wino_bwd_weight(x, dy, idx=None):
     return dw, db
 
 
+def conv3x3_wino_bwd(x, dy, w, relu_src=None, idx=None):
+    """clhip_conv3x3_wino_bwd: (dx, dw, db) of one 3x3 layer as ONE grid (backward-data and weight-gradient blocks interleaved).
+    Returns None for a layer the merged grid does not take (CLHIP_ENOTSUP: nothing was launched)."""
+    _chk(x, dy, w)
+    N, C, H, W = x.shape
+    K = dy.shape[1]
+    L = _lib.lib()
+    ws = torch.empty(max(L.clhip_conv3x3_wino_bwd_ws(N, C, K, H, W), 16), dtype=torch.uint8, device=x.device)
+    dx = torch.empty((N, C, H, W), dtype=torch.float32, device=x.device)
+    dw = torch.empty((K, C, 3, 3), dtype=torch.float32, device=x.device)
+    db = torch.empty((K,), dtype=torch.float32, device=x.device)
+    rc = L.clhip_conv3x3_wino_bwd(_ptr(x), _ptr(dy), _ptr(idx) if idx is not None else None, _ptr(w),
+                                  _ptr(relu_src) if relu_src is not None else None, _ptr(dx), _ptr(dw), _ptr(db), N, C, K, H, W,
+                                  _ptr(ws), ws.numel(), _stream())
+    if rc == -3:                      # CLHIP_ENOTSUP
+        return None
+    check(rc, "clhip_conv3x3_wino_bwd")
+    return dx, dw, db
+
+
 def conv3x3_relu_pool_fwd(x, w, b):
     """fused conv + bias + ReLU + 2x2 max-pool: returns (y_pool, idx_u8).  idx codes are 0..4, NOT an index to gather with:
     0..3 = window position r * 2 + c of the first maximum (ATen's order), 4 (CLHIP_POOL_DEAD, csrc/common.hpp) = the window's

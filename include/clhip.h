@@ -238,6 +238,15 @@ int clhip_conv3x3_wino_bwd_data(const float* dy, const uint8_t* idx_u8_or_null, 
 size_t clhip_conv3x3_wino_bwd_weight_ws(int N, int C, int K, int H, int W);
 int clhip_conv3x3_wino_bwd_weight(const float* x, const float* dy, const uint8_t* idx_u8_or_null, float* dw, float* db, int N, int C,
                                   int K, int H, int W, void* ws, size_t ws_bytes, void* stream);
+/* The whole backward of one such layer — dx (clhip_conv3x3_wino_bwd_data) and dW, db (clhip_conv3x3_wino_bwd_weight) — as ONE
+ * grid: the blocks of the two launches interleaved so that blocks in their memory phases share the CUs with blocks in their matrix
+ * phases (the autograd backward of one conv of VGGSlim.py:27-40; results bit-identical to the two entry points above).  Taken for the
+ * layers whose launches fill one round of blocks or less: even maps of at most 256 pixels, 16 or more wide or 8 x 8, weight gradient
+ * on the pixel-split kernel, 16-byte-aligned tensors; CLHIP_ENOTSUP otherwise (nothing launched: call the two entry points).
+ * ws: clhip_conv3x3_wino_bwd_ws(N, C, K, H, W) bytes.                                                                             */
+size_t clhip_conv3x3_wino_bwd_ws(int N, int C, int K, int H, int W);
+int clhip_conv3x3_wino_bwd(const float* x, const float* dy, const uint8_t* idx_u8_or_null, const float* w, const float* relu_src,
+                           float* dx, float* dw, float* db, int N, int C, int K, int H, int W, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ 3x3 convolution on the bf16 matrix cores, split fp32 operands
  * The same operators again (VGGSlim.py:27-40 and their autograd backward w.r.t. the input; arguments as the _wino_ entry points)
