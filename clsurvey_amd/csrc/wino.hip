@@ -787,8 +787,16 @@ typedef float floatx4v __attribute__((ext_vector_type(4)));
 
 // KT2 = 16-row MFMA tiles per wave: 2 -> block = 2 images x 64 out-channels (wave = image wp, channel half wk);
 //       1 -> block = 1 image x 64 out-channels (wave = channel quarter): twice the waves for layers with few out-channels
+// (LDS floats of a block: the two chunk buffers + the 64 bias values; body = device function over (LDS base, block index), as
+// wino_conv16g_body below: the kernel of its own and one half of wino_pair_kernel are the same code)
+template <bool UNPOOL, int KT2>
+__host__ __device__ constexpr int wino16_lds_floats() {
+    return 2 * ((CLHIP_W16_ADIRECT != 0 && !(UNPOOL && KT2 == 2) ? 0 : W_FLOATS) + WCK * KT2 * 100) + WKT;
+}
+
 template <int MODE, bool UNPOOL, int KT2>
-__global__ __launch_bounds__(256, (CLHIP_W16_ADIRECT && !(UNPOOL && KT2 == 2)) ? 2 : 1) void wino_conv16_kernel(
+__device__ __forceinline__ void wino_conv16_body(
+    float* __restrict__ lds, const int bid,
     const float* __restrict__ in, const float* __restrict__ U, const float* __restrict__ bias,
     const float* __restrict__ mask_src, float* __restrict__ out, uint8_t* __restrict__ pool_idx,
     int N, int Cin, int Cout, int relu) {
@@ -801,14 +809,14 @@ __global__ __launch_bounds__(256, (CLHIP_W16_ADIRECT && !(UNPOOL && KT2 == 2)) ?
     static_assert(!ADIRECT || CLHIP_W16G_ADIRECT != 0, "the lane-ordered image of U is written only with CLHIP_W16G_ADIRECT");
     constexpr int WOFF = ADIRECT ? 0 : W_FLOATS;
     constexpr int X_FLOATS = WCK * PLANE, BUF = WOFF + X_FLOATS;
-    __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
-    __shared__ float bias_s[WKT];
+    static_assert(wino16_lds_floats<UNPOOL, KT2>() == 2 * BUF + WKT, "LDS size of the wrappers");
+    float* const bias_s = lds + 2 * BUF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wk = KT2 == 2 ? wave & 1 : wave, wp = KT2 == 2 ? wave >> 1 : 0;      // wk: 32- (KT2 = 2) or 16-channel slice of the block's 64
     constexpr int KW = 16 * KT2;                                                     // out channels per wave
     const int ti = lane & 15, q = lane >> 4;
     const int n_grp = (N + NIMG - 1) / NIMG;
-    const int kt = blockIdx.x / n_grp, ng = blockIdx.x - kt * n_grp;
+    const int kt = bid / n_grp, ng = bid - kt * n_grp;
     const int n0 = ng * NIMG, ko0 = kt * WKT;
     const int n_chunks = (Cin + WCK - 1) / WCK;
     if (MODE == 0 && tid < WKT) bias_s[tid] = (bias && ko0 + tid < Cout) ? bias[ko0 + tid] : 0.f;
@@ -1023,6 +1031,15 @@ __global__ __launch_bounds__(256, (CLHIP_W16_ADIRECT && !(UNPOOL && KT2 == 2)) ?
             *reinterpret_cast<float2*>(out + o + W) = make_float2(y10, y11);
         }
     }
+}
+
+template <int MODE, bool UNPOOL, int KT2>
+__global__ __launch_bounds__(256, (CLHIP_W16_ADIRECT && !(UNPOOL && KT2 == 2)) ? 2 : 1) void wino_conv16_kernel(
+    const float* __restrict__ in, const float* __restrict__ U, const float* __restrict__ bias,
+    const float* __restrict__ mask_src, float* __restrict__ out, uint8_t* __restrict__ pool_idx,
+    int N, int Cin, int Cout, int relu) {
+    __shared__ __attribute__((aligned(16))) float lds[wino16_lds_floats<UNPOOL, KT2>()];
+    wino_conv16_body<MODE, UNPOOL, KT2>(lds, (int)blockIdx.x, in, U, bias, mask_src, out, pool_idx, N, Cin, Cout, relu);
 }
 
 
@@ -1784,35 +1801,32 @@ static bool wgrad_ps_on() { return true; }       // (small layers: the pixel-spl
 // (CLHIP_WGRAD_OVERLAP=2, round 4: slower).  Here the two launches are one grid: block b is a block of wino_conv16g_kernel
 // (MODE 1) or a block of wino_wgrad_ps_kernel, the same device code as the two kernels of their own (their bodies are device
 // functions over an LDS base and a block index), results bit-identical to the two launches.
-// Order of the blocks: groups of 8 consecutive blocks (one per XCD) alternate between the two kinds, and the phase of the
-// alternation flips every 32 groups, so that the two blocks a CU receives first differ in kind whichever way the dispatcher
-// fills the CUs of an XCD (CU-major or slot-major); once the shorter list is used up the rest of the longer one follows.
-template <int TC, int TR, int EROWS, bool UNPOOL, int TCS, int TRS>
+// Order of the blocks: the weight-gradient list first, then the backward-data list.  Measured on the four deep layers of small_VGG9
+// (N = 200, rocprofv3, profiles/r05_v_pair_orders.txt; the two launches of their own: 65.0 / 61.0 / 71.2 / 41.7 us): this order 58.6 /
+// 53.4 / 55.2 / 30.4 us, backward-data first 60.7 / 56.2 / 53.7 / 30.7, the two kinds alternating in groups of 8 blocks (one per
+// XCD) 61.8 / 58.2 / 55.5 / 30.7.
+// DK: the backward-data half is a block of wino_conv16g_kernel<TC, TR, EROWS, 1, UNPOOL> (0) or, on 8 x 8 maps of layers with few
+// in-channels, of wino_conv16_kernel<1, UNPOOL, 1> (1: one image x 64 channels per block, as launch_wino chooses on its own)
+template <int DK, int TC, int TR, int EROWS, bool UNPOOL, int TCS, int TRS>
 __global__ __launch_bounds__(256, 2) void wino_pair_kernel(
     // backward-data half (arguments of wino_conv16g_kernel<TC, TR, EROWS, 1, UNPOOL>)
     const float* __restrict__ d_in, const float* __restrict__ d_U, const float* __restrict__ d_mask, float* __restrict__ d_out,
     uint8_t* __restrict__ d_idx, int N, int d_Cin, int d_Cout, int H, int W, int d_tiles_w, int d_tiles_h, int d_npb,
     // weight-gradient half (arguments of wino_wgrad_ps_kernel<TCS, TRS, UNPOOL, true>)
     const float* __restrict__ w_x, float* __restrict__ w_part, int w_tiles_w, int w_tiles_h, int w_total, int w_splits, int w_ctiles,
-    size_t w_slab, int nb_d, int nb_w) {
-    constexpr int LD = wino16g_lds_floats<TC, TR, EROWS>(), LW = WGeoP<TCS, TRS>::LDS_FLOATS;
+    size_t w_slab, int nb_w) {
+    constexpr int LD = DK ? wino16_lds_floats<UNPOOL, 1>() : wino16g_lds_floats<TC, TR, EROWS>(), LW = WGeoP<TCS, TRS>::LDS_FLOATS;
     __shared__ __attribute__((aligned(16))) float lds[LD > LW ? LD : LW];
     const int b = (int)blockIdx.x;
-    const int m8 = (nb_d < nb_w ? nb_d : nb_w) & ~7;       // blocks of each kind inside the alternating part
-    int kind, idx;                                          // kind 0: backward-data block idx, 1: weight-gradient block idx
-    if (b < 2 * m8) {
-        const int g = b >> 3;
-        kind = (g + (g >> 5)) & 1;
-        idx = (g >> 1) * 8 + (b & 7);
-    } else {
-        const int r = b - 2 * m8;
-        kind = r < nb_d - m8 ? 0 : 1;
-        idx = m8 + (kind ? r - (nb_d - m8) : r);
-    }
-    if (kind == 0)
-        wino_conv16g_body<TC, TR, EROWS, 1, UNPOOL>(lds, idx, d_in, d_U, nullptr, d_mask, d_out, d_idx, N, d_Cin, d_Cout, H, W, 0,
-                                                    d_tiles_w, d_tiles_h, d_npb);
-    else
+    // weight-gradient blocks first (the longer ones), then the backward-data blocks
+    const int kind = b < nb_w ? 1 : 0, idx = kind ? b : b - nb_w;
+    if (kind == 0) {
+        if constexpr (DK)
+            wino_conv16_body<1, UNPOOL, 1>(lds, idx, d_in, d_U, nullptr, d_mask, d_out, d_idx, N, d_Cin, d_Cout, 0);
+        else
+            wino_conv16g_body<TC, TR, EROWS, 1, UNPOOL>(lds, idx, d_in, d_U, nullptr, d_mask, d_out, d_idx, N, d_Cin, d_Cout, H, W, 0,
+                                                        d_tiles_w, d_tiles_h, d_npb);
+    } else
         wino_wgrad_ps_body<TCS, TRS, UNPOOL, true>(lds, idx, w_x, d_in, w_part, d_idx, N, d_Cout, d_Cin, H, W, w_tiles_w, w_tiles_h,
                                                    w_total, w_splits, w_ctiles, w_slab);
 }
@@ -2066,17 +2080,20 @@ int clhip_internal_wino_pair(const float* dy, const uint8_t* unpool_idx, const f
     // backward-data half: geometry of launch_wino's 16-tile launch (kernel Cin = K, Cout = C)
     const int TC = wide ? 8 : 4, TR = wide ? 2 : 4, ER = 4, NE = 2 * TR / ER;
     const int d_tiles_w = (W / 2 + TC - 1) / TC, d_groups = (H / 2 + ER - 1) / ER;
-    const long long npb = (((long long)N * d_groups + NE - 1) / NE) * d_tiles_w, nb_d = npb * ((C + WKT - 1) / WKT);
+    // 8 x 8 maps of layers with few in-channels: one-image blocks of 16-channel waves (launch_wino's `narrow` launch of wino_conv16_kernel)
+    const bool narrow = m88 && ((long long)N * 16 + 31) / 32 * ((C + 31) / 32) < WINO16_BELOW_UNITS && (long long)N * ((C + 31) / 32) <= 512;
+    const long long npb = narrow ? N : (((long long)N * d_groups + NE - 1) / NE) * d_tiles_w, nb_d = npb * ((C + WKT - 1) / WKT);
     const long long nb_w = (long long)g.kc32 * g.splits;
     if (nb_d <= 0 || nb_w <= 0 || nb_d + nb_w > 0x7fffffffLL) return CLHIP_ENOTSUP;
     float* part = static_cast<float*>(ws);
     uint8_t* idx = const_cast<uint8_t*>(unpool_idx);
-#define PAIR(TC_, TR_, UNP_)                                                                                                        \
-    hipLaunchKernelGGL((wino_pair_kernel<TC_, TR_, 4, UNP_, TC_, TR_>), dim3((unsigned)(nb_d + nb_w)), dim3(256), 0, s, dy, U, mask_src, \
-                       dx, idx, N, K, C, H, W, d_tiles_w, d_groups, (int)npb, x, part, g.tiles_w, g.tiles_h, (int)g.total,          \
-                       (int)g.splits, C / 32, g.slab, (int)nb_d, (int)nb_w)
-    if (wide) { if (unpool_idx) PAIR(8, 2, true); else PAIR(8, 2, false); }
-    else { if (unpool_idx) PAIR(4, 4, true); else PAIR(4, 4, false); }
+#define PAIR(DK_, TC_, TR_, UNP_)                                                                                                   \
+    hipLaunchKernelGGL((wino_pair_kernel<DK_, TC_, TR_, 4, UNP_, TC_, TR_>), dim3((unsigned)(nb_d + nb_w)), dim3(256), 0, s, dy, U,  \
+                       mask_src, dx, idx, N, K, C, H, W, d_tiles_w, d_groups, (int)npb, x, part, g.tiles_w, g.tiles_h, (int)g.total, \
+                       (int)g.splits, C / 32, g.slab, (int)nb_w)
+    if (wide) { if (unpool_idx) PAIR(0, 8, 2, true); else PAIR(0, 8, 2, false); }
+    else if (narrow) { if (unpool_idx) PAIR(1, 4, 4, true); else PAIR(1, 4, 4, false); }
+    else { if (unpool_idx) PAIR(0, 4, 4, true); else PAIR(0, 4, 4, false); }
 #undef PAIR
     CLHIP_LAUNCH_CHECK();
     *job = clhip_wgrad_job{part, dw, db, K, C, (int)g.splits};
