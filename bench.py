@@ -273,6 +273,16 @@ def time_kernels(eng, x, N, iters):
             row("conv3x3_bwd_data", "bwd_data", t_d, pd,
                 bs_conv_instance(N, H, W, C, 1, False) if pd == "bs" else wino_conv_instance(W, 1, False, N, C) if pd == "wino"
                 else conv_instance(K, H, W, N, C, 1, False), 4.0 * N * H * W * ((2 if xmask is not None else 1) * C + K))
+        # layers whose two backward launches the plan executor issues as ONE grid (csrc/wino.hip, wino_pair_kernel): the rows above are
+        # the launches of their own; the merged operator (with its own weight transform and slab reduction, which a pass shares
+        # between the layers) is timed beside them
+        if C > 3 and pd == "wino" and pw == "wino":
+            args = (xin, dyp, wt, xmask, idx) if pool else (xin, dy, wt, xmask, None)
+            if ops.conv3x3_wino_bwd(*args) is not None:
+                t_m = timed(lambda: ops.conv3x3_wino_bwd(*args))
+                for r in rows[-2:]:
+                    r["one_grid"] = True
+                    r["one_grid_us_both_launches"] = t_m * 1e6
         cur = ops.maxpool2_fwd(y)[0] if pool else y
     return rows
 
@@ -1262,7 +1272,10 @@ def main():
                            "per_layer": [{"kernel": r["kernel"], "layer": r["layer"], "instance": r["instance"], "path": r["path"],
                                           "us": r["sec"] * 1e6, "algorithmic_tflops": r["flops"] / r["sec"] / 1e12,
                                           "algorithmic_over_f32_mfma_peak": r["flops"] / r["sec"] / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                                          "mfma_issued_frac": r["pipe_sec"] / r["sec"]} for r in rows]}
+                                          "mfma_issued_frac": r["pipe_sec"] / r["sec"],
+                                          **({"one_grid_with_the_layers_other_backward_launch": True,
+                                              "one_grid_us_both_launches_with_transform_and_reduction": r["one_grid_us_both_launches"]}
+                                             if r.get("one_grid") else {})} for r in rows]}
         if world == 1 and not args.no_configs:
             del eng
             torch.cuda.empty_cache()
