@@ -2000,6 +2000,8 @@ static int wino_wgrad_geo(const float* x, const float* dy, const uint8_t* unpool
         // blocks of the launch = (k, c) tiles x pixel splits: two per CU; one per CU on 8 x 8 maps with few (k, c) tiles, where a block
         // of the 512-block launch saw 3 - 6 stages (measured at N = 200, profiles/r05_o_wgps_blocks.txt: 64 -> 128 @8x8 30.5 -> 26.6 us,
         // 128 -> 128 @8x8 40.7 -> 39.3; every other layer of small_VGG9 is fastest at 512: 256 / 384 / 768 / 1024 blocks cost 1 - 28 %)
+        // (inside the merged grids of the 16 x 16 layers, 400 backward-data blocks beside them: 256 / 384 / 400 / 512 / 624 / 800 weight-gradient
+        // blocks give a bench step of 1.500 - 1.72 / 1.517 / 1.516 / 1.507 / 1.509 / 1.546 ms, profiles/r05_x_pair_wgrad_blocks.txt)
         const int target = ((long long)H * W <= 64 && g->kc32 <= 16) ? 256 : 512;
         long long sp = g->kc32 >= target ? 1 : target / g->kc32;
         if (sp > g->total) sp = g->total;
