@@ -838,23 +838,23 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
                 else if (rc != CLHIP_ENOTSUP) return rc;
             }
             if (!wdone) {
-            probe_begin(2);
-            rc = on_side(i, gin_buf, [&](void* st) {
-                if (defer && L.wino_w) {
-                    const int r = clhip_internal_wino_wgrad_partial(xin, gin, idx + L.idx_off, grads + L.w_off, grads + L.b_off, N, L.cin,
-                                                                    L.cout, L.h, L.w, base + p->off_wg + L.wg_off, L.wg_bytes,
-                                                                    as_stream(st), &jobs[n_jobs]);
-                    if (r != CLHIP_ENOTSUP && r != CLHIP_ENOSPC) return r;
-                }
-                if (defer)
-                    return clhip_internal_conv3x3_wgrad_partial(xin, gin, idx + L.idx_off, grads + L.w_off, grads + L.b_off, N, L.cin,
-                                                                L.cout, L.h, L.w, base + p->off_wg + L.wg_off, L.wg_bytes, st,
-                                                                &jobs[n_jobs]);
-                return clhip_conv3x3_bwd_weight_unpool(xin, gin, idx + L.idx_off, grads + L.w_off, grads + L.b_off, N, L.cin, L.cout,
-                                                       L.h, L.w, scratch, p->scratch_bytes, st);
-            });
-            if (rc == 0) { wdone = true; if (defer) ++n_jobs; probe_end(2); }
-            else if (rc != CLHIP_ENOTSUP) return rc;
+                probe_begin(2);
+                rc = on_side(i, gin_buf, [&](void* st) {
+                    if (defer && L.wino_w) {
+                        const int r = clhip_internal_wino_wgrad_partial(xin, gin, idx + L.idx_off, grads + L.w_off, grads + L.b_off, N, L.cin,
+                                                                        L.cout, L.h, L.w, base + p->off_wg + L.wg_off, L.wg_bytes,
+                                                                        as_stream(st), &jobs[n_jobs]);
+                        if (r != CLHIP_ENOTSUP && r != CLHIP_ENOSPC) return r;
+                    }
+                    if (defer)
+                        return clhip_internal_conv3x3_wgrad_partial(xin, gin, idx + L.idx_off, grads + L.w_off, grads + L.b_off, N, L.cin,
+                                                                    L.cout, L.h, L.w, base + p->off_wg + L.wg_off, L.wg_bytes, st,
+                                                                    &jobs[n_jobs]);
+                    return clhip_conv3x3_bwd_weight_unpool(xin, gin, idx + L.idx_off, grads + L.w_off, grads + L.b_off, N, L.cin, L.cout,
+                                                           L.h, L.w, scratch, p->scratch_bytes, st);
+                });
+                if (rc == 0) { wdone = true; if (defer) ++n_jobs; probe_end(2); }
+                else if (rc != CLHIP_ENOTSUP) return rc;
             }
             if (wdone && !ddone && i > 0 && !L.drop && !L.extra_grad) {
                 if (!gout_d) { gout_d = take(); gout_d_buf = taken; }
