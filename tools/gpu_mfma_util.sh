@@ -23,7 +23,7 @@ for r in rows:
 print("kernel,dispatches,avg_us,mfma_busy_over_32x_sq_busy,valu_active_over_wave_cycles")
 for k in sorted(agg, key=lambda k: -dur[k]):
     a = agg[k]; n = len(disp[k])
-    if a.get("SQ_BUSY_CYCLES", 0) <= 0 or not re.search("conv|wgrad|gemm|fc_chain", k):
+    if a.get("SQ_BUSY_CYCLES", 0) <= 0 or not re.search("conv|wgrad|gemm|fc_chain|pair", k):
         continue
     # SQ_BUSY_CYCLES is summed over the 32 shader engines, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs
     util = a["SQ_VALU_MFMA_BUSY_CYCLES"] / (32.0 * a["SQ_BUSY_CYCLES"])
