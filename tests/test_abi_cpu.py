@@ -34,6 +34,11 @@ def test_argument_errors_do_not_need_a_device():
     assert lib.clhip_maxpool2_fwd(None, None, None, 1, 7, 8, None) == -1
     assert lib.clhip_conv3x3_bwd_weight_ws(200, 64, 64, 32, 32) > 0
     assert lib.clhip_fc_ws(200, 2048, 128) > 0
+    # the one-grid backward of a small 3x3 layer: workspace = transformed weights + weight-gradient slabs; 0 for channel counts the
+    # Winograd weight gradient does not take; argument errors before any launch
+    assert lib.clhip_conv3x3_wino_bwd_ws(200, 64, 64, 16, 16) > lib.clhip_conv3x3_wino_bwd_weight_ws(200, 64, 64, 16, 16) > 0
+    assert lib.clhip_conv3x3_wino_bwd_ws(200, 48, 64, 16, 16) == 0
+    assert lib.clhip_conv3x3_wino_bwd(None, None, None, None, None, None, None, None, 8, 64, 64, 16, 16, None, 0, None) == -1
 
 
 def test_ops_refuse_cpu_tensors():
