@@ -105,6 +105,8 @@ def parse():
     ap.add_argument("--pair-threads", type=int, default=16)
     ap.add_argument("--pair-pin", type=int, default=-1, help="internal: first logical CPU of this leg's affinity set (-1: not pinned)")
     ap.add_argument("--sweep-blobs", type=str, default=None, help="tuning: g,amp,noise_lr,q of the sweep's synthetic tasks")
+    ap.add_argument("--forced-leg", type=str, default=None, help="internal: run the teacher-forced trainings of this plan file (JSON) on the "
+                                                                 "kernel path CLHIP_BS selects")
     return ap.parse_args()
 
 
@@ -687,7 +689,178 @@ def pair_cpu_leg(root, threads, pin_from=None):
     return res
 
 
-def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epochs=70, cpu_rates=None):
+def sweep_stability(out):
+    """Per task of a finished EWC sweep: the learning rate phase 1 picked, A_ft, and the step size of penalised SGD along its
+    stiffest coordinate, 2 * lambda * max(Omega) * lr, for every phase-2 attempt (train_EWC.py:60-75: the penalty's gradient is
+    2 * lambda * Omega * (theta - theta*); plain SGD on that coordinate alone is stable below 2, with momentum 0.9 below 3.8).
+    Omega = the importance the task's training was penalised with (sum over the earlier tasks, main_EWC.py:205-232), read from the
+    task's own model file."""
+    rows = []
+    for t, (hf, path) in enumerate(zip(out["frameworks"], out["model_paths"])):
+        if hf is None or not hf.trace:
+            continue
+        m = torch.load(path, map_location="cpu", weights_only=False)
+        om = [v["omega"] for v in getattr(m, "reg_params", {}).values() if isinstance(v, dict) and "omega" in v]
+        omax = float(max(float(o.max()) for o in om)) if om else 0.0
+        lr, a_ft = getattr(hf, "phase1", (None, None))
+        rows.append({"task": t + 1, "lr": lr, "A_ft": float(a_ft) if a_ft is not None else None,
+                     "omega_max": omax, "omega_max_per_tensor": [float("%.3g" % float(o.max())) for o in om], "omega_sum": float(sum(float(o.double().sum()) for o in om)) if om else 0.0,
+                     "attempts": [{"lambda": float(h["lambda"]), "val_acc": float(a), "threshold": float(th),
+                                   "two_lambda_omega_lr": 2.0 * float(h["lambda"]) * omax * float(lr) if lr is not None else None}
+                                  for h, a, th in hf.trace]})
+    return rows
+
+
+STABILITY_LIMIT = 2.0 * (1.0 + 0.9)      # heavy-ball SGD (momentum 0.9) on a quadratic of curvature h is stable iff lr * h < 2 (1 + 0.9)
+NEAR_LIMIT = 3.0                        # a training above this is within 25 % of the limit: not a well-conditioned comparison leg
+
+
+def sweep_conditioning(rows):
+    """How a finished sweep's stability-decay decisions sit against the heavy-ball limit of the stiffest penalised coordinate
+    (x = 2 lambda max(Omega) lr; STABILITY_LIMIT = 3.8).  Measured on 40 sweeps of round 6 (profiles/r06_sweep_stability.md):
+    every attempt with x < 3.8 met the threshold and every rejected attempt had x > 3.8 (`rejected_all_above_limit`); above the
+    limit a training diverges when the stiff coordinate is excited, which depends on rounding — `min_margin` = the smallest
+    |ln(x / 3.8)| over the attempts says how close the nearest decision came."""
+    import math
+    att = [a for row in rows for a in row["attempts"] if a["two_lambda_omega_lr"] is not None]
+    if not att:
+        return None
+    rej = [a for a in att if a["val_acc"] < a["threshold"]]
+    return {"attempts": len(att), "rejected": len(rej), "rejected_diverged": sum(1 for a in rej if a["val_acc"] < 0.1),
+            "rejected_all_above_limit": all(a["two_lambda_omega_lr"] > STABILITY_LIMIT for a in rej),
+            "accepted_above_limit": sum(1 for a in att if a["val_acc"] >= a["threshold"] and a["two_lambda_omega_lr"] > STABILITY_LIMIT),
+            "below_limit_rejected": sum(1 for a in rej if a["two_lambda_omega_lr"] <= STABILITY_LIMIT),
+            "max_x_accepted": max(a["two_lambda_omega_lr"] for a in att if a["val_acc"] >= a["threshold"]) if len(rej) < len(att) else None,
+            "min_margin": min(abs(math.log(max(a["two_lambda_omega_lr"], 1e-12) / STABILITY_LIMIT)) for a in att),
+            "limit": STABILITY_LIMIT}
+
+
+def forced_leg(plan_path, device):
+    """One kernel path's leg of the teacher-forced sweep comparison (its own process: CLHIP_BS is read once per process).  For every
+    task of the plan: the EWC training of that task exactly as the free-running sweep's accepted attempt ran it — SAME start model
+    (the free run's model of the previous task), learning rate and lambda, Fisher pass over the previous task included — from a
+    fixed seed; then the new task's test accuracy, the previous task's test accuracy under the new trunk (one-step forgetting),
+    and the sum / max of the importance weights the training was penalised with (the previous model's Omega + this path's Fisher)."""
+    import contextlib
+    import io
+    import shutil
+    import tempfile
+    from clsurvey_amd.framework import driver, inference
+    from clsurvey_amd.methods import ewc, method as M
+    from clsurvey_amd.methods import train_common as tc
+    with open(plan_path) as f:
+        plan = json.load(f)
+    meth = M.parse("EWC")
+    scratch = tempfile.mkdtemp(prefix="clhip_forced_")
+    legs = []
+    quiet = io.StringIO()
+    try:
+        for job in plan["jobs"]:
+            exp_dir = os.path.join(scratch, "task_%d" % job["task"])
+            driver.set_random(7)
+            with contextlib.redirect_stdout(quiet):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                _, val = ewc.fine_tune_EWC_acuumelation(dataset_path=job["dataset"], previous_task_model_path=job["previous_model"],
+                                                        exp_dir=exp_dir, data_dir=None, reg_sets=[job["previous_dataset"]],
+                                                        reg_lambda=job["lambda"], num_epochs=plan["epochs"], lr=job["lr"],
+                                                        batch_size=plan["batch"], device=device)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                best = os.path.join(exp_dir, "best_model.pth.tar")
+                row = {"task": job["task"], "seconds": dt, "val_acc": float(val), "lr": job["lr"], "lambda": job["lambda"]}
+                if os.path.exists(best):
+                    model = tc.load_model(best)
+                    last = str(len(model.classifier._modules) - 1)
+                    om = [v["omega"] for v in model.reg_params.values() if isinstance(v, dict) and "omega" in v]
+                    row["omega_sum"] = float(sum(float(o.double().sum()) for o in om))
+                    row["omega_max"] = float(max(float(o.max()) for o in om))
+                    row["test_acc"] = inference.test_model(meth, model, job["dataset"], 0, inference.get_prev_heads(best, last, device),
+                                                           batch_size=plan["batch"], device=device)
+                    row["previous_task_test_acc"] = inference.test_model(
+                        meth, tc.load_model(best), job["previous_dataset"], 0, inference.get_prev_heads(job["previous_model"], last, device),
+                        batch_size=plan["batch"], device=device)
+                else:
+                    row["diverged"] = True                    # train_EWC.py:204-205: the training stopped on a NaN / 1e4 loss
+            legs.append(row)
+            shutil.rmtree(exp_dir, ignore_errors=True)
+    finally:
+        shutil.rmtree(scratch, ignore_errors=True)
+    return {"clhip_bs": os.environ.get("CLHIP_BS", "1"), "tasks": legs}
+
+
+def forced_paths(out, stability, groot, epochs, batch=200, paths=("0", "1", "2")):
+    """The three fp32-grade kernel paths (CLHIP_BS = 0: Winograd f32 on every 3x3 layer; 1: the default; 2: bf16-split wherever it
+    runs) compared TASK BY TASK on the sweep that just ran: each path repeats every task's accepted training from the free run's
+    own previous model, learning rate and lambda (`forced_leg`), in its own process, the three side by side on this GPU.  A free-
+    running sweep cannot be compared this way: which stability-decay attempts diverge is decided by rounding (sweep_conditioning),
+    on any fp32 implementation.  Reports per task the largest accuracy difference between the paths (new task, previous task under
+    the new trunk), the validation accuracies, and the relative spread of Sum(Omega); legs whose training sits within 25 % of the
+    stability limit (x > NEAR_LIMIT) are listed and left out of the `well_conditioned` maxima."""
+    import subprocess
+    jobs = []
+    for row in stability:
+        t = row["task"]
+        if t < 2 or row["lr"] is None:
+            continue
+        acc = row["attempts"][-1]
+        jobs.append({"task": t, "dataset": out["ds_paths"][t - 1], "previous_dataset": out["ds_paths"][t - 2],
+                     "previous_model": out["model_paths"][t - 2], "lr": float(row["lr"]), "lambda": float(acc["lambda"]),
+                     "x": acc["two_lambda_omega_lr"]})
+    plan_path = os.path.join(groot, "forced_plan.json")
+    with open(plan_path, "w") as f:
+        json.dump({"jobs": jobs, "epochs": epochs, "batch": batch}, f)
+    t0 = time.perf_counter()
+    procs = []
+    for p in paths:
+        env = dict(os.environ, CLHIP_BS=p)
+        errf = open(os.path.join(groot, "forced_%s.stderr" % p), "w+")
+        procs.append((p, subprocess.Popen([sys.executable, os.path.abspath(__file__), "--forced-leg", plan_path], stdout=subprocess.PIPE,
+                                          stderr=errf, env=env, text=True), errf))
+    legs = {}
+    for p, proc, errf in procs:
+        so, _ = proc.communicate(timeout=1200)
+        errf.seek(0)
+        se = errf.read()
+        errf.close()
+        line = [ln for ln in so.splitlines() if ln.startswith("{")]
+        if proc.returncode != 0 or not line:
+            raise RuntimeError("forced leg CLHIP_BS=%s failed:\n%s" % (p, se[-1500:]))
+        legs[p] = json.loads(line[-1])["tasks"]
+    res = {"what": "every task's accepted EWC training repeated on CLHIP_BS=%s from the free run's previous model, lr and lambda "
+                   "(teacher-forced; fixed seed), three processes side by side" % "/".join(paths),
+           "seconds": time.perf_counter() - t0, "per_task": [], "near_limit_tasks": []}
+    worst = {"test_acc": 0.0, "previous_task_test_acc": 0.0, "val_acc_points": 0.0, "omega_sum_rel": 0.0}
+    for i, job in enumerate(jobs):
+        rows = [legs[p][i] for p in paths]
+        entry = {"task": job["task"], "lr": job["lr"], "lambda": job["lambda"], "x": job["x"],
+                 "diverged": [p for p, r in zip(paths, rows) if r.get("diverged")]}
+        gaps = {}
+        for key, scale in (("test_acc", 1.0), ("previous_task_test_acc", 1.0), ("val_acc", 100.0)):
+            vals = [r[key] * scale for r in rows if key in r]
+            entry[key] = [round(v, 3) for v in vals]
+            gaps[key] = (max(vals) - min(vals)) if len(vals) == len(rows) else float("inf")
+        oms = [r["omega_sum"] for r in rows if "omega_sum" in r]
+        entry["omega_sum"] = oms
+        gaps["omega_sum_rel"] = (max(oms) - min(oms)) / max(max(oms), 1e-30) if len(oms) == len(rows) else float("inf")
+        entry["gap_points"] = {"test_acc": gaps["test_acc"], "previous_task_test_acc": gaps["previous_task_test_acc"], "val_acc": gaps["val_acc"]}
+        entry["omega_sum_rel_spread"] = gaps["omega_sum_rel"]
+        res["per_task"].append(entry)
+        if job["x"] is not None and job["x"] > NEAR_LIMIT:
+            res["near_limit_tasks"].append(job["task"])
+            continue
+        worst["test_acc"] = max(worst["test_acc"], gaps["test_acc"])
+        worst["previous_task_test_acc"] = max(worst["previous_task_test_acc"], gaps["previous_task_test_acc"])
+        worst["val_acc_points"] = max(worst["val_acc_points"], gaps["val_acc"])
+        worst["omega_sum_rel"] = max(worst["omega_sum_rel"], gaps["omega_sum_rel"])
+    res["max_gap_all_tasks_points"] = max([max(e["gap_points"]["test_acc"], e["gap_points"]["previous_task_test_acc"]) for e in res["per_task"]] or [0.0])
+    res["well_conditioned"] = {"tasks": [j["task"] for j in jobs if not (j["x"] is not None and j["x"] > NEAR_LIMIT)],
+                               "max_gap_points_new_task": worst["test_acc"], "max_gap_points_previous_task": worst["previous_task_test_acc"],
+                               "max_gap_points_validation": worst["val_acc_points"], "max_omega_sum_rel_spread": worst["omega_sum_rel"]}
+    return res
+
+
+def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epochs=70, cpu_rates=None, lr_grid=None, forced=True):
     """BASELINE.json's second metric ('full-sweep wall-clock'), two measurements.
 
     `gpu_s`: what framework/main.py runs for `small_VGG9_cl_128_128 --method_name EWC --test` with the reference's defaults
@@ -766,12 +939,14 @@ def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epoch
         if tasks > 0:
             ds = SyntheticTaskSequence(os.path.join(groot, "data"), task_count=tasks, classes_per_task=20, sizes=tuple(sizes), hw=64,
                                        name="synthetic_tiny_imagenet", noise=SWEEP_DATA["noise"], kind=SWEEP_DATA["kind"],
-                                       blobs=SWEEP_DATA["blobs"])
+                                       blobs=SWEEP_DATA["blobs"], seed=SWEEP_DATA.get("seed", 7))
             t0 = time.perf_counter()
             for i in range(1, tasks + 1):
                 ds.get_task_dataset_path(str(i))
             res["task_files_s (not counted)"] = time.perf_counter() - t0
             common = [model, "--num_epochs", str(epochs), "--results_root", groot, "--device", dev]
+            if lr_grid:     # (the first task keeps the whole grid: the first-task model's name is made of --lr_grid, net.py:39-53)
+                common += ["--lr_grid", lr_grid, "--boot_lr_grid", "1e-2,5e-3,1e-3,5e-4,1e-4"]
             with contextlib.redirect_stdout(quiet), _PassCounter(sizes[0]) as counts:
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
@@ -798,14 +973,18 @@ def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epoch
             om = [v["omega"] for v in getattr(last, "reg_params", {}).values() if isinstance(v, dict) and "omega" in v]
             res["gpu_omega_of_last_model"] = {"max": float(max(float(o.max()) for o in om)), "sum": float(sum(float(o.double().sum()) for o in om))} if om else None
             res["gpu_accepted_lambda_per_task"] = [float(hf.trace[-1][0]["lambda"]) for hf in out["frameworks"] if hf is not None and hf.trace]
+            res["gpu_stability"] = sweep_stability(out)
+            res["gpu_last_grid"] = [[float(lr), float(a)] for lr, _, a in out["manager"].grid_trace]
             res["gpu_final_accuracies"] = [r[i]["seq_res"][i][-1] for i in sorted(r)]          # task i under the LAST model
             res["gpu_first_accuracies"] = [r[i]["seq_res"][i][0] for i in sorted(r)]           # task i right after training it
             res["gpu_avg_accuracy"] = float(np.mean(res["gpu_final_accuracies"]))
             res["gpu_avg_forgetting"] = float(np.mean([r[i]["seq_forgetting"][i][-1] for i in sorted(r) if r[i]["seq_forgetting"][i]] or [0.0]))
-            res["outcome_note"] = ("penalised SGD runs near its stability limit on these tasks (an attempt with val_acc 0.0 diverged): which "
-                                   "attempts diverge, hence accepted lambdas, accuracies and forgetting, depend on fp32 rounding — the same "
-                                   "sweep on three fp32-grade kernel paths gave 77.3 / 4.0, 55.9 / 27.3 and 79.0 / 2.0 (avg accuracy / "
-                                   "forgetting; profiles/r05_m_sweep_three_paths.txt); agreement with the CPU path is judged by `pair`")
+            res["conditioning"] = sweep_conditioning(res["gpu_stability"])
+            if forced:
+                try:
+                    res["forced_paths"] = forced_paths(out, res["gpu_stability"], groot, epochs)
+                except BaseException as e:     # noqa: BLE001
+                    res["forced_paths"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:400])}
             res["chance_accuracy"] = 100.0 / 20
             res["best_possible_accuracy"] = 100.0 * (SWEEP_DATA["blobs"]["q"] + (1 - SWEEP_DATA["blobs"]["q"]) / 20)
         # ---- collect the CPU legs
@@ -955,7 +1134,8 @@ def compact_line(out, details_path=None, limit=LINE_LIMIT):
         r = out["roofline"]
         c["roofline"] = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_gflop_per_launch",
                                   "algorithmic_bytes_per_launch", "avg_launch_us", "avg_launch_how", "path", "peak_how",
-                                  "mfma_issued_frac", "mfma_busy_pmc"))
+                                  "mfma_issued_frac", "mfma_busy_pmc", "share_of_conv_launch_time", "launches_per_pass", "longest_launch",
+                                  "by_share"))
         c["roofline"].setdefault("traffic", r.get("traffic"))
     if "cpu_baseline" in out:
         c["cpu_baseline"] = _pick(out["cpu_baseline"], ("value", "unit", "cores", "kind", "sample", "host_logical_cores", "host_cpu_model",
@@ -1117,6 +1297,9 @@ def main():
             dist.broadcast(h, src=src)
             t.copy_(h)
 
+    if args.forced_leg:
+        print(json.dumps(forced_leg(args.forced_leg, "cuda:%d" % local_rank)), flush=True)
+        return
     if args.sweep_only:
         print(json.dumps(full_sweep(local_rank, cpu_threads=0 if args.no_cpu_baseline else 16, tasks=args.sweep_tasks,
                                     epochs=args.sweep_epochs)), flush=True)
@@ -1165,7 +1348,14 @@ def main():
     rows, dom = None, None
     if rank == 0:
         rows = time_kernels(eng, data_x[:N].contiguous(), N, args.kernel_iters)
-        dom = max(rows, key=lambda r: r["sec"])
+        # dominant = the kernel INSTANCE with the largest share of a pass (sum over its launches), not the longest single
+        # launch; its longest launch is the one probed in situ
+        by_inst = {}
+        for r in rows:
+            by_inst.setdefault(r["instance"], []).append(r)
+        dom_rows = max(by_inst.values(), key=lambda rs: sum(r["sec"] for r in rs))
+        dom = max(dom_rows, key=lambda r: r["sec"])
+        longest = max(rows, key=lambda r: r["sec"])
         eng.probe(dom["li"], dom["kind"])
     torch.cuda.synchronize()
     if dist:
@@ -1267,6 +1457,16 @@ def main():
                            "winograd": dom["path"] == "wino",
                            "mfma_issued_frac": dom["pipe_sec"] / dom_sec,
                            "mfma_busy_pmc": mfma_busy_pmc("small_VGG9", dom["instance"]),
+                           "chosen_by": "largest share of the conv launches of a pass, summed over the launches of one kernel instance",
+                           "share_of_conv_launch_time": sum(r["sec"] for r in dom_rows) / sum(r["sec"] for r in rows),
+                           "launches_per_pass": len(dom_rows),
+                           "longest_launch": {"kernel": "%s [%s, layer %s]" % (longest["instance"], longest["kernel"], longest["layer"]),
+                                              "us": longest["sec"] * 1e6, "frac": longest["pipe_sec"] / longest["sec"],
+                                              "share": longest["sec"] / sum(r["sec"] for r in rows)},
+                           "by_share": [{"kernel": inst, "launches": len(rs), "share": sum(r["sec"] for r in rs) / sum(r["sec"] for r in rows),
+                                         "frac": sum(r["pipe_sec"] for r in rs) / sum(r["sec"] for r in rs),
+                                         "busy_pmc": (mfma_busy_pmc("small_VGG9", inst) or {}).get("busy")}
+                                        for inst, rs in sorted(by_inst.items(), key=lambda kv: -sum(r["sec"] for r in kv[1]))[:3]],
                            "per_kernel": {k: {"tflops": v["flops"] / v["sec"] / 1e12, "us_per_step_pass": v["sec"] * 1e6}
                                           for k, v in agg.items()},
                            "per_layer": [{"kernel": r["kernel"], "layer": r["layer"], "instance": r["instance"], "path": r["path"],
@@ -1300,6 +1500,14 @@ def main():
                               "pair_gpu": out["sweep"].get("pair", {}).get("gpu_s"), "pair_cpu": out["sweep"].get("pair", {}).get("cpu_s"),
                               "pair_max_accuracy_gap_points": out["sweep"].get("pair", {}).get("max_accuracy_gap_points"),
                               "pair_cpu_spread_points": out["sweep"].get("pair", {}).get("cpu_spread_points")}
+            fp, cond = out["sweep"].get("forced_paths") or {}, out["sweep"].get("conditioning") or {}
+            out["sweep_s"]["avg_accuracy"] = out["sweep"].get("gpu_avg_accuracy")
+            out["sweep_s"]["avg_forgetting"] = out["sweep"].get("gpu_avg_forgetting")
+            # the three kernel paths task by task (teacher-forced on the sweep that just ran), and where the free run's stability-
+            # decay decisions sit against the heavy-ball limit (sweep_conditioning)
+            out["sweep_s"]["kernel_paths_max_gap_points"] = fp.get("max_gap_all_tasks_points", fp.get("error"))
+            out["sweep_s"]["kernel_paths_max_omega_sum_rel_spread"] = max([e["omega_sum_rel_spread"] for e in fp.get("per_task", [])] or [None]) if "per_task" in fp else None
+            out["sweep_s"]["decisions"] = _pick(cond, ("attempts", "rejected", "below_limit_rejected", "rejected_all_above_limit", "accepted_above_limit", "min_margin")) if cond else None
         emit(out)
     if dist:
         dist.barrier()          # rank 0 was still timing kernels: tear the communicator down together

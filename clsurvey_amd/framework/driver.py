@@ -280,6 +280,7 @@ class HyperparameterFramework(object):
 
     def stabilityDecay(self, args, manager, finetune_lr, finetune_acc):
         args.lr = finetune_lr
+        self.phase1 = (finetune_lr, finetune_acc)                 # (observable only: what phase 2 started from)
         manager.heuristic_exp_dir = os.path.join(manager.parent_exp_dir, "task_" + str(args.task_counter),
                                                  "TASK_TRAINING")
         if hasattr(manager.method, "train_init"):
@@ -688,7 +689,7 @@ def main(argv=None, method=None, dataset=None, train_node_factory=None):
         blobs = dict(zip(("g", "amp", "noise_lr", "q"), (float(v) for v in fields[8:12]))) or None
         dataset = SyntheticTaskSequence(os.path.join(args.results_root, "data"), task_count=n_tasks, classes_per_task=n_cls,
                                         sizes=(n_tr, n_va, n_te), hw=hw, noise=float(fields[6]) if len(fields) > 6 else 1.0,
-                                        kind=kind, blobs=blobs)
+                                        kind=kind, blobs=blobs, seed=int(fields[12]) if len(fields) > 12 else 7)
     set_random(7)                                                 # utils.init -> set_random()
     if method is None:
         method = methods.parse(args.method_name)
