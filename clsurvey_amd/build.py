@@ -13,7 +13,7 @@ SOURCES = ["elementwise.hip", "loss.hip", "pool.hip", "conv3x3.hip", "wino.hip",
 # -pragma-unroll-threshold: the software-pipelined conv loops are fully unrolled by `#pragma unroll` (one piece of
 # staging work per MFMA slot, all register-array indices constant); at the default threshold hipcc silently stops
 # unrolling the largest instance and its operand registers land in scratch / LDS.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
          "-mllvm", "-pragma-unroll-threshold=100000"]
 
 

@@ -830,11 +830,11 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
             if (pair_ok(L, i)) {
                 // backward-data and the weight-gradient slabs of this layer as ONE grid (wino.hip, wino_pair_kernel)
                 gout_d = take(); gout_d_buf = taken;
-                probe_begin(p->probe_kind);
+                if (p->probe_kind) probe_begin(p->probe_kind);   // (kinds 1 and 2 both time the merged launch; a forward probe does not)
                 rc = clhip_internal_wino_pair(gin, idx + L.idx_off, reinterpret_cast<const float*>(base + p->off_wino + L.wino_ud), xmask,
                                               gout_d, xin, grads + L.w_off, grads + L.b_off, N, L.cin, L.cout, L.h, L.w,
                                               base + p->off_wg + L.wg_off, L.wg_bytes, main_s, &jobs[n_jobs]);
-                if (rc == 0) { wdone = ddone = true; ++n_jobs; probe_end(p->probe_kind); }
+                if (rc == 0) { wdone = ddone = true; ++n_jobs; if (p->probe_kind) probe_end(p->probe_kind); }
                 else if (rc != CLHIP_ENOTSUP) return rc;
             }
             if (!wdone) {
@@ -887,11 +887,11 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
         }
         if (!wdone && !L.pool && !gout_d && pair_ok(L, i)) {
             gout_d = take(); gout_d_buf = taken;
-            probe_begin(p->probe_kind);
+            if (p->probe_kind) probe_begin(p->probe_kind);   // (kinds 1 and 2 both time the merged launch; a forward probe does not)
             rc = clhip_internal_wino_pair(gy, nullptr, reinterpret_cast<const float*>(base + p->off_wino + L.wino_ud), xmask, gout_d, xin,
                                           grads + L.w_off, grads + L.b_off, N, L.cin, L.cout, L.h, L.w, base + p->off_wg + L.wg_off,
                                           L.wg_bytes, main_s, &jobs[n_jobs]);
-            if (rc == 0) { wdone = ddone = true; ++n_jobs; probe_end(p->probe_kind); }
+            if (rc == 0) { wdone = ddone = true; ++n_jobs; if (p->probe_kind) probe_end(p->probe_kind); }
             else if (rc != CLHIP_ENOTSUP) return rc;
         }
         if (!wdone) {

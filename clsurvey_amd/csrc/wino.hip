@@ -49,6 +49,10 @@ namespace {
 #define CLHIP_W16G_PRIO_UNPOOL 0   // the same switch for the instances that rebuild the un-pooled gradient while staging (measured slower with 2)
 #endif
 #ifndef CLHIP_WGPS_FENCE
+#ifndef CLHIP_WGPS_PITCH
+#define CLHIP_WGPS_PITCH 0   // wino_wgrad_ps_kernel: 1 = LDS row pitches of 4 mod 64 floats (no bank conflict on the operand reads).  Measured
+#endif                       // in round 6 (profiles/r06_j_wgps_pitch_ab.txt): 99.8 / 37.5 / 39.2 us against 97.7 / 36.7 / 38.7 with the old pitches —
+                             // the conflicts (0.38 of the LDS cycles) are not what the kernel waits for; not adopted.
 #define CLHIP_WGPS_FENCE 1   // wino_wgrad_ps_kernel: MFMAs of a step fenced off behind both dy transforms (0: the A/B reference)
 #endif
 #ifndef CLHIP_W16G_BURST
@@ -1466,11 +1470,22 @@ struct WGeoP {
     static constexpr int KB = 32, CB = 32;                 // (k, c) tile of a block
     static constexpr int DW = 2 * TCS, DR = 2 * TRS;
     static constexpr int DPIX = DR * DW;                   // 64 pixels
-    static constexpr int LDP = DPIX + 2;
     static constexpr int PW = DW + 2, PR = DR + 2;
     static constexpr int PLANE = PR * PW;
+#if CLHIP_WGPS_PITCH
+    // The operand reads of a step are ds_read_b64 whose 32 lanes of a group are 16 channels (lane stride = the row pitch) x 2
+    // neighbouring tiles (2 floats apart); ds_read_b64 banks are (float index) mod 64, so the group is conflict-free when the pitch
+    // is 4 mod 64 floats: slot (8 bytes) = 2 * channel + tile, all 32 distinct.  (Round 5's pitches, 66 and PLANE | 2, were odd in
+    // 8-byte units — conflict-free over the channels alone, two-way between (channel, tile + 1) and (channel + k, tile): 0.38 of
+    // the kernel's LDS cycles were bank conflicts, profiles/r05_i_pmc_summary.txt.)
+    static constexpr int LDP = (DPIX + 63 - 4) / 64 * 64 + 4;          // 68
+    static constexpr int PLANEP = (PLANE + 63 - 4) / 64 * 64 + 4;      // 132
+    static_assert(LDP >= DPIX && PLANEP >= PLANE && LDP % 64 == 4 && PLANEP % 64 == 4, "row pitches of 4 mod 64 floats");
+#else
+    static constexpr int LDP = DPIX + 2;
     static constexpr int PLANEP = (PLANE % 4 == 2) ? PLANE : PLANE + 2;
     static_assert((LDP / 2) % 2 == 1 && (PLANEP / 2) % 2 == 1, "lane strides must be odd in 8-byte units");
+#endif
     static constexpr int DY_FLOATS = KB * LDP, X_FLOATS = CB * PLANEP;
     static constexpr int BUF = DY_FLOATS + X_FLOATS;
     static constexpr int XCH = 4 * 65 * 64;                // exchange area: per wave 64 accumulators + 1 bias sum, 64 lanes

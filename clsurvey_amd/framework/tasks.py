@@ -60,9 +60,20 @@ class SyntheticTaskSequence(object):
                                    "belongs to the other data)" % (path, have, want))
             return path
         os.makedirs(os.path.dirname(path), exist_ok=True)
+        if os.path.exists(path) and not os.path.exists(side):
+            # data without its spec (a cache older than the sidecars, or a writer that died between the two files): regenerating is
+            # only safe while no results tree (the driver keeps <results_root>/train and /test beside <results_root>/data) was
+            # built from the old bytes
+            if any(os.path.isdir(os.path.join(os.path.dirname(self.root), d)) for d in ("train", "test")):
+                raise RuntimeError("%s has no %s beside it but a results tree exists under %s: cannot tell what data those results "
+                                   "were made from — use a fresh --results_root" % (path, os.path.basename(side), os.path.dirname(self.root)))
         d = synthetic_task(self.sizes[0], self.sizes[1], self.sizes[2], self.n_classes, self.hw,
                            seed=want["seed"], noise=self.noise, kind=self.kind, blobs=self.blobs)
-        torch.save(d, path)
-        with open(side, "w") as f:                 # written last: a file without a sidecar is regenerated
+        tmp = "%s.tmp.%d" % (path, os.getpid())    # (torch.save is not atomic: a killed writer must not leave a truncated task file)
+        torch.save(d, tmp)
+        os.replace(tmp, path)
+        tmp = "%s.tmp.%d" % (side, os.getpid())
+        with open(tmp, "w") as f:
             json.dump(want, f)
+        os.replace(tmp, side)                      # written last: a data file without a sidecar is never a hit
         return path

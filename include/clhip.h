@@ -23,6 +23,13 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: the prototypes of this header are its whole dynamic symbol table (the
+ * cross-translation-unit helpers of csrc/common.hpp stay inside the .so). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#define CLHIP_VISIBILITY_PUSHED 1
+#endif
+
 #define CLHIP_EINVAL (-1)   /* bad shape / null pointer */
 #define CLHIP_ENOSPC (-2)   /* workspace too small */
 #define CLHIP_ENOTSUP (-3)  /* shape not supported by this build */
@@ -424,6 +431,11 @@ int clhip_gem_project(const float* G, size_t ld, const int* row_idx_host, const 
 int clhip_gem_qp(const double* gram_f64, int m, double margin, double eps, double* v_out_f64, int* info_i32, void* stream);
 int clhip_gem_project_dev(const float* G, size_t ld, const int* row_idx_host, const double* v_dev_f64, const int* info_dev,
                           int m, const float* g, float* out, size_t n, void* stream);
+
+#ifdef CLHIP_VISIBILITY_PUSHED
+#pragma GCC visibility pop
+#undef CLHIP_VISIBILITY_PUSHED
+#endif
 
 #ifdef __cplusplus
 }

@@ -4,6 +4,7 @@
 // Built into tests/libclhip_dbg.so (clsurvey_amd/build.py: build_test_lib); NOT part of libclhip.so.
 #include "../../clsurvey_amd/csrc/common.hpp"
 
+#pragma GCC visibility push(default)        // (built with -fvisibility=hidden like the product library: these four are exported)
 extern "C" {
 int clhip_dbg_conv3x3_fwd(const float* x, const float* w, const float* b, float* y, int N, int C, int K, int H, int W, int relu,
                           void* stream);
@@ -15,6 +16,7 @@ int clhip_dbg_conv3x3_bwd_weight(const float* x, const float* dy, float* dw, flo
 // the documented fragment map
 int clhip_dbg_mfma_probe(float* out_2048, void* stream);
 }
+#pragma GCC visibility pop
 
 namespace {
 

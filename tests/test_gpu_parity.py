@@ -341,7 +341,8 @@ def test_autograd_path_matches_engine_and_golden(golden):
 
 
 @pytest.mark.parametrize("name,N,hw", [("small_VGG9", 200, 64), ("base_VGG9", 32, 64), ("wide_VGG9", 8, 64), ("deep_VGG22", 6, 64),
-                                       ("wide_VGG9", 2, 224)])     # 224: the iNaturalist input size of BASELINE configs[4]
+                                       ("wide_VGG9", 2, 224),      # 224: the iNaturalist input size of BASELINE configs[4]
+                                       ("base_VGG9", 200, 64)])    # the batch configs_ms_per_step times MAS / SI at (dispatch depends on N)
 def test_engine_full_size_vs_oracle(name, N, hw):
     cfg = vgg_ref.CFGS[name]
     fc = (128, 128) if name == "small_VGG9" else (512, 512)

@@ -1,9 +1,15 @@
 """Winograd F(2x2, 3x3) convolution kernels (csrc/wino.hip) against torch CPU (the reference's arithmetic: nn.Conv2d + ReLU +
 MaxPool2d of models/VGGSlim.py:27-40 and their autograd backward) and against the direct MFMA kernels."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import torch_ref  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -12,6 +18,9 @@ SHAPES = [  # N, C, K, H, W
     (2, 24, 96, 12, 20), (3, 128, 256, 16, 16), (2, 64, 64, 64, 64), (7, 256, 256, 8, 8), (2, 32, 64, 28, 28),
     (200, 64, 64, 32, 32), (200, 64, 64, 16, 16), (200, 128, 128, 8, 8),
     (131, 128, 128, 8, 8), (200, 64, 128, 8, 8),        # 8 x 8 maps with few units: the 16x16x4-MFMA variant, both wave shapes, odd image count
+    # every 3x3 layer shape base_VGG9 / wide_VGG9 run at the bench batch (BASELINE configs 3 and 5; dispatch depends on N)
+    (200, 64, 128, 16, 16), (200, 128, 128, 16, 16), (200, 128, 256, 8, 8), (200, 256, 256, 8, 8),
+    (200, 64, 128, 32, 32), (200, 128, 256, 16, 16), (200, 256, 256, 16, 16), (200, 256, 512, 8, 8), (200, 512, 512, 8, 8),
     # odd maps (AlexNet's 13 x 13 layers, models/net.py:96-125): row-packed geometry, half-outside last tile row / column
     (4, 32, 64, 13, 13), (3, 64, 32, 13, 13), (2, 16, 32, 9, 15), (5, 64, 64, 11, 13), (3, 32, 32, 13, 16), (37, 192, 384, 13, 13),
 ]
@@ -47,12 +56,11 @@ def test_wino_forward_and_backward_data(shape):
     b = torch.from_numpy((gen.standard_normal((K,)) * 0.1).astype(np.float32))
     xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
     big = N >= 100
-    # judge: torch CPU for the small shapes, the direct MFMA kernels (themselves pinned against torch CPU) for the large ones
+    # judge: torch CPU at every batch size (tests/torch_ref.py)
+    z_ref = F.conv2d(x, w, b, padding=1)
+    y_ref = F.relu(z_ref)
     if big:
-        y_ref, z_ref = ops.conv3x3_fwd(xd, wd, bd, True), ops.conv3x3_fwd(xd, wd, bd, False)
-    else:
-        z_ref = F.conv2d(x, w, b, padding=1)
-        y_ref = F.relu(z_ref)
+        y_ref = y_ref.cuda()
     assert _rel(ops.conv3x3_wino_fwd(xd, wd, bd, relu=False), z_ref) <= 2e-5
     y = ops.conv3x3_wino_fwd(xd, wd, bd, relu=True)
     assert _rel(y, y_ref) <= 2e-5
@@ -65,10 +73,7 @@ def test_wino_forward_and_backward_data(shape):
     dy = torch.from_numpy(gen.standard_normal((N, K, H, W)).astype(np.float32))
     msrc = torch.from_numpy(gen.standard_normal((N, C, H, W)).astype(np.float32))
     dyd, md = dy.cuda(), msrc.cuda()
-    if big:
-        dx_ref = ops.conv3x3_bwd_data(dyd, wd)
-    else:
-        dx_ref = F.conv_transpose2d(dy, w, padding=1)
+    dx_ref = F.conv_transpose2d(dy, w, padding=1)
     assert _rel(ops.conv3x3_wino_bwd_data(dyd, wd), dx_ref) <= 2e-5
     dxm = ops.conv3x3_wino_bwd_data(dyd, wd, relu_src=md)
     assert _rel(dxm, dx_ref.cuda() * (md > 0)) <= 2e-5
@@ -76,8 +81,8 @@ def test_wino_forward_and_backward_data(shape):
         return              # no 2x2 pooling on odd maps
     dyp = torch.from_numpy(gen.standard_normal((N, K, H // 2, W // 2)).astype(np.float32)).cuda()
     code = torch.from_numpy(gen.randint(0, 5, size=(N, K, H // 2, W // 2)).astype(np.uint8)).cuda()
-    dy_full = ops.maxpool2_bwd(dyp, code)
-    ref_u = ops.conv3x3_bwd_data(dy_full, wd, md)
+    dy_full = torch_ref.unpool(dyp, code)
+    ref_u = F.conv_transpose2d(dy_full, w, padding=1) * (msrc > 0)
     assert _rel(ops.conv3x3_wino_bwd_data(dyp, wd, relu_src=md, idx=code), ref_u) <= 2e-5
 
 
@@ -93,12 +98,14 @@ def test_wino_refuses_shapes_outside_its_domain():
 
 WG_SHAPES = [(3, 64, 64, 32, 32), (5, 64, 64, 16, 16), (6, 64, 128, 8, 8), (4, 128, 64, 8, 8), (2, 64, 64, 12, 20), (2, 64, 128, 28, 28),
              (3, 128, 256, 16, 16), (200, 64, 64, 32, 32), (200, 64, 64, 16, 16), (200, 128, 128, 8, 8),
+             (200, 64, 128, 16, 16), (200, 128, 128, 16, 16), (200, 128, 256, 8, 8), (200, 256, 256, 8, 8),      # base_VGG9 at the bench batch
+             (200, 64, 128, 32, 32), (200, 128, 256, 16, 16), (200, 256, 256, 16, 16), (200, 256, 512, 8, 8), (200, 512, 512, 8, 8),   # wide_VGG9
              (6, 64, 64, 13, 13), (3, 128, 64, 9, 11), (4, 64, 128, 15, 16), (40, 192, 384, 13, 13)]
 
 
 @pytest.mark.parametrize("shape", WG_SHAPES)
 def test_wino_weight_gradient(shape):
-    """dW, db through G^T[(A dY A^T).*(B^T d B)]G against torch CPU autograd (small shapes) / the direct MFMA kernel (large),
+    """dW, db through G^T[(A dY A^T).*(B^T d B)]G against torch CPU autograd (every shape, the bench batch included),
     plain and from the POOLED gradient + arg-max codes; repeated calls are bitwise equal (fixed-order slab reduction)."""
     from clsurvey_amd import ops
     N, C, K, H, W = shape
@@ -106,13 +113,7 @@ def test_wino_weight_gradient(shape):
     x = torch.from_numpy(gen.standard_normal((N, C, H, W)).astype(np.float32))
     dy = torch.from_numpy(gen.standard_normal((N, K, H, W)).astype(np.float32))
     xd, dyd = x.cuda(), dy.cuda()
-    if N >= 100:
-        dw_ref, db_ref = ops.conv3x3_bwd_weight(xd, dyd)
-    else:
-        w = torch.zeros(K, C, 3, 3, requires_grad=True)
-        b = torch.zeros(K, requires_grad=True)
-        F.conv2d(x, w, b, padding=1).backward(dy)
-        dw_ref, db_ref = w.grad, b.grad
+    dw_ref, db_ref = torch_ref.bwd_weight(x, dy)             # torch CPU autograd at every batch size
     dw, db = ops.conv3x3_wino_bwd_weight(xd, dyd)
     assert _rel(dw, dw_ref) <= 5e-5 and _rel(db, db_ref) <= 5e-5, (_rel(dw, dw_ref), _rel(db, db_ref))
     dw2, db2 = ops.conv3x3_wino_bwd_weight(xd, dyd)
@@ -121,7 +122,7 @@ def test_wino_weight_gradient(shape):
         return              # no 2x2 pooling on odd maps
     dyp = torch.from_numpy(gen.standard_normal((N, K, H // 2, W // 2)).astype(np.float32)).cuda()
     code = torch.from_numpy(gen.randint(0, 5, size=(N, K, H // 2, W // 2)).astype(np.uint8)).cuda()
-    dw_u_ref, db_u_ref = ops.conv3x3_bwd_weight(xd, ops.maxpool2_bwd(dyp, code))
+    dw_u_ref, db_u_ref = torch_ref.bwd_weight(x, torch_ref.unpool(dyp, code))
     dw_u, db_u = ops.conv3x3_wino_bwd_weight(xd, dyp, idx=code)
     assert _rel(dw_u, dw_u_ref) <= 5e-5 and _rel(db_u, db_u_ref) <= 5e-5
 
