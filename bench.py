@@ -1139,12 +1139,13 @@ def compact_line(out, details_path=None, limit=LINE_LIMIT):
         c["roofline"].setdefault("traffic", r.get("traffic"))
     if "cpu_baseline" in out:
         c["cpu_baseline"] = _pick(out["cpu_baseline"], ("value", "unit", "cores", "kind", "sample", "host_logical_cores", "host_cpu_model",
-                                                        "forward_only_images_per_s"))
+                                                        "forward_only_images_per_s", "thread_probe_images_per_s"))
     optional = {}
     if "sweep_s" in out:
         optional["sweep_s"] = out["sweep_s"]
     if isinstance(out.get("grid"), dict):
-        optional["grid"] = _pick(out["grid"], ("nodes", "iterations", "winner_rank", "winner_lr", "fill_factor", "collectives_in_timed_region"))
+        optional["grid"] = _pick(out["grid"], ("nodes", "iterations", "winner_rank", "winner_lr", "fill_factor", "collectives_in_timed_region",
+                                                     "per_rank_ms_per_step", "collective_seconds_max_over_ranks", "backend", "visible_devices"))
     ss = out.get("sharded_sweep")
     if isinstance(ss, dict):
         optional["sharded_sweep"] = _pick(ss, ("error", "world", "seconds", "first_task_seconds", "methods", "fill_factor_grid", "fill_factor",
@@ -1234,14 +1235,18 @@ def cpu_baseline(batch, steps):
         fisher = [R.fisher_accum(f, gi, 8000) for f, gi in zip(fisher, g)]
 
     best = None
-    for cand in sorted({min(ncpu, c) for c in (16, 32, 64)}):
+    probe = {}
+    for cand in sorted({min(ncpu, c) for c in (16, 32, 64, 128, 256)}):
         torch.set_num_threads(cand)
         step(best is None)           # warm-up at this thread count (first call creates the buffers)
         t0 = time.perf_counter()
         step(False)
         t = time.perf_counter() - t0
+        probe[cand] = t
         if best is None or t < best[1]:
             best = (cand, t)
+        if t > 4.0 * best[1]:        # (far past the knee: larger counts only get slower, and the probe must stay short)
+            break
     cores = best[0]
     torch.set_num_threads(cores)
     t0 = time.perf_counter()
@@ -1259,8 +1264,11 @@ def cpu_baseline(batch, steps):
     cpu = host_cpu()
     return dict(value=2 * batch * steps / dt, unit="images/s", cores=cores, kind="port", host_logical_cores=cpu["logical_cores"],
                 host_cpu_model=cpu["model"], forward_only_images_per_s=batch * nf / dtf,
-                sample="%d steps (EWC train batch + Fisher batch, N=%d) of the torch-CPU oracle, %d threads (fastest of "
-                       "16 / 32 / 64 on this host's %d logical cores), %.1f s" % (steps, batch, cores, cpu["logical_cores"], dt))
+                thread_probe_images_per_s={str(k): 2 * batch / v for k, v in sorted(probe.items())},
+                sample="%d steps (EWC train batch + Fisher batch, N=%d) of the torch-CPU oracle, %d threads (fastest of %s "
+                       "on this host's %d logical cores: %s images/s in a one-step probe; one process, as the reference runs), %.1f s"
+                       % (steps, batch, cores, " / ".join(str(k) for k in sorted(probe)), cpu["logical_cores"],
+                          " / ".join("%.0f" % (2 * batch / probe[k]) for k in sorted(probe)), dt))
 
 
 def main():
@@ -1363,8 +1371,21 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     grid = None
+    coll_ev = []          # (name, start event, end event) on the current stream around each collective of the timed region
+
+    def timed_collective(name, fn):
+        if backend == "nccl":
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+            coll_ev.append((name, a, b))
+        else:
+            t = time.perf_counter()
+            fn()
+            coll_ev.append((name, time.perf_counter() - t, None))
     if dist:
-        bcast(A.theta, 0)                              # every node starts from the previous task's model (one RCCL broadcast)
+        timed_collective("broadcast_start_arena", lambda: bcast(A.theta, 0))   # every node starts from the previous task's model
         stats.zero_()
     for i in range(args.steps):
         step(i)
@@ -1374,15 +1395,16 @@ def main():
         if backend != "nccl":
             mine = mine.cpu()
         table = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(table, mine)
+        timed_collective("all_gather_node_metrics", lambda: dist.all_gather(table, mine))
         winner = int(max(table, key=lambda t: (float(t[0]), -float(t[1])))[1])
-        bcast(A.theta, winner)
+        timed_collective("broadcast_winner_arena", lambda: bcast(A.theta, winner))
         grid = {"nodes": world, "lr_grid": LR_GRID, "iterations": -(-world // len(LR_GRID)), "winner_rank": winner,
                 "winner_lr": LR_GRID[winner % len(LR_GRID)],
                 "collectives_in_timed_region": ["broadcast(start arena %.1f MB)" % (A.numel * 4 / 1e6),
                                                 "all_gather(node metrics)", "broadcast(winner arena)"],
                 "fill_factor": shard_fill(len(LR_GRID), world)}
     torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0            # this rank's own time (before it waits for the others)
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -1391,6 +1413,18 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # per-rank record (outside the timed region): every rank's own ms per step and the seconds its collectives took on its stream,
+        # so that a weak-scaling value that is not N x the single-GPU one can be read from the line (slow rank vs. slow collective)
+        mine_s = [dt_local] + [(a.elapsed_time(b) * 1e-3 if b is not None else float(a)) for _, a, b in coll_ev]
+        tt = torch.tensor(mine_s, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        allr = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(allr, tt)
+        per_rank = [[float(v) for v in r.cpu()] for r in allr]
+        grid["per_rank_ms_per_step"] = [r[0] / args.steps * 1e3 for r in per_rank]
+        grid["collective_seconds_max_over_ranks"] = {name: max(r[1 + j] for r in per_rank) for j, (name, _, _) in enumerate(coll_ev)}
+        grid["collective_seconds_rank0"] = {name: per_rank[0][1 + j] for j, (name, _, _) in enumerate(coll_ev)}
+        grid["backend"] = "rccl" if backend == "nccl" else backend
+        grid["visible_devices"] = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES"))
     if not torch.isfinite(A.theta).all():
         raise SystemExit("non-finite parameters after the timed run")
     probed_us, probed_n = eng.probe_read() if dom is not None else (0.0, 0)

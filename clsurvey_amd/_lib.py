@@ -85,6 +85,9 @@ SIGNATURES = {
     "clhip_conv2d_fwd": (_i, [_p, _p, _p, _p] + [_i] * 10 + [_p]),
     "clhip_conv2d_bwd_data": (_i, [_p, _p, _p, _p] + [_i] * 9 + [_p]),
     "clhip_conv2d_bwd_weight": (_i, [_p, _p, _p, _p] + [_i] * 9 + [_p, _z, _p]),
+    "clhip_conv2d_s2d_ws": (_z, [_i] * 8),
+    "clhip_conv2d_s2d_fwd": (_i, [_p, _p, _p, _p] + [_i] * 9 + [_p, _z, _p]),
+    "clhip_conv2d_s2d_bwd_weight": (_i, [_p, _p, _p, _p] + [_i] * 8 + [_p, _z, _p]),
     "clhip_imm_merge": (_i, [_p, _p, _p, _i, _z, _p, _p]),
     "clhip_lwf_loss": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _i, _p, _p, _p, _p]),
     "clhip_packnet_finetune_mask": (_i, [_p, _z, _i, _p]),

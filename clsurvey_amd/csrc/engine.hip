@@ -42,6 +42,8 @@ struct LayerPlan {
     int bs5_f, bs5_d;            // 5 x 5 layers: forward / backward-data on the bf16-split kernel (image offsets in wino_uf / wino_ud)
     int bs_f, bs_d;              // ... forward / backward-data on the bf16 matrix cores with split fp32 operands (bsconv.hip): wino_f / wino_d
                                  // are set as well (the layer takes the prepared-weights path) and wino_uf / wino_ud hold its weight IMAGE
+    int s2d;                   // strided first layer through space-to-depth + the dense 3x3 kernels (s2dconv.hip); frames at s2d_off
+    size_t s2d_off, s2d_bytes;
     int wg3;                   // weight gradient on the 3x3 kernel (else the general gather-GEMM)
     size_t wg_off, wg_bytes;   // this layer's own weight-gradient slabs (3x3 layers; reduced for all layers at once)
     const float* extra_grad;   // added to the gradient w.r.t. this layer's input (side branches: clhip_net_set_input_grad)
@@ -76,6 +78,8 @@ struct NetPlan {
     size_t scratch_bytes;    // wgrad / fc split-K scratch
     size_t wino_bytes;       // transformed weights of the layer in flight (Winograd path)
     size_t off_wino;
+    size_t off_s2d;          // frames of the space-to-depth first layer (its own region: the phase planes of the forward pass feed the
+    int s2d_fresh_n;         // weight gradient of the same pass; s2d_fresh_n = the batch they were made for, 0 = stale)
     size_t total_bytes;
     // derived offsets (bytes) inside ws
     size_t off_acts, off_idx, off_g0, off_g1, off_scratch, off_dlogits, off_loss, off_fcdz, off_wg;
@@ -168,7 +172,7 @@ int clhip_net_create(const clhip_layer_desc* descs, int n_layers, int max_batch,
     p->in_elems = (size_t)in_c * in_h * in_w;
     int c = in_c, h = in_h, w = in_w;
     size_t feat = p->in_elems;
-    size_t acts = 0, idxb = 0, gmax = 0, scratch = 0, wg_total = 0, wino_ws = 0;
+    size_t acts = 0, idxb = 0, gmax = 0, scratch = 0, wg_total = 0, wino_ws = 0, s2d_total = 0;
     int n_wg = 0;
     bool seen_fc = false;
     for (int i = 0; i < n_layers; ++i) {
@@ -268,6 +272,15 @@ int clhip_net_create(const clhip_layer_desc* descs, int n_layers, int max_batch,
                 if (L.bs5_f) { L.wino_uf = wino_ws; wino_ws += align_up(clhip_internal_bs5_ws(L.cin, L.cout), 256); }
                 if (L.bs5_d) { L.wino_ud = wino_ws; wino_ws += align_up(clhip_internal_bs5_ws(L.cout, L.cin), 256); }
             }
+            // AlexNet's 11 x 11 / stride-4 first layer as a dense 3x3 convolution over the 48 phase planes of the padded input
+            // (s2dconv.hip), CLHIP_S2D=1.  Off by default: measured at N = 128 (profiles/r06_l_alexnet_s2d.txt) the dense kernels take
+            // 159 (forward) and 192 us (weight gradient) but building the frames and cropping the output costs 64 + 62 + 45 us more —
+            // 285 / 237 us against the gather-GEMM's 257 / 217; the step 4.72 against 4.69 ms.  First layer only: no backward-data.
+            if (!vgg && !L.bn && i == 0 && !descs[i].has_drop) {
+                const char* e = std::getenv("CLHIP_S2D");
+                const size_t sb = !(e && e[0] == '1') ? 0 : clhip_conv2d_s2d_ws(max_batch, L.cin, L.h, L.w, L.cout, L.ks, L.st, L.pd);
+                if (sb) { L.s2d = 1; L.s2d_off = s2d_total; L.s2d_bytes = align_up(sb, 256); s2d_total += L.s2d_bytes; }
+            }
             if (L.out_elems > gmax) gmax = L.out_elems;
             if (L.in_elems > gmax) gmax = L.in_elems;
             h = oh; w = ow;
@@ -328,6 +341,8 @@ int clhip_net_create(const clhip_layer_desc* descs, int n_layers, int max_batch,
     p->off_wg = off;
     p->n_wg = (n_wg >= 2 && n_wg <= CLHIP_WGRAD_JOBS_MAX) ? n_wg : 0;
     if (p->n_wg) off += align_up(wg_total, 256);
+    p->off_s2d = off; off += s2d_total;
+    p->s2d_fresh_n = 0;
     p->total_bytes = off;
     p->training = 1;
     p->overlap = false;
@@ -588,9 +603,12 @@ static int net_forward_impl(void* handle, const float* params, const float* x, i
                  : vgg ? clhip_conv3x3_fwd(cur, params + L.w_off, params + L.b_off, zc, N, L.cin, L.cout, L.h, L.w, crelu, stream)
                  : L.bs5_f ? clhip_internal_bs5_conv_u(0, cur, base + p->off_wino + L.wino_uf, params + L.b_off, nullptr, zc, N, L.cin, L.cout,
                                                        L.h, L.w, crelu, as_stream(stream))
+                 : L.s2d ? clhip_conv2d_s2d_fwd(cur, params + L.w_off, params + L.b_off, zc, N, L.cin, L.h, L.w, L.cout, L.ks, L.st, L.pd,
+                                                crelu, base + p->off_s2d + L.s2d_off, L.s2d_bytes, stream)
                      : clhip_conv2d_fwd(cur, params + L.w_off, params + L.b_off, zc, N, L.cin, L.h, L.w, L.cout, L.ks, L.ks, L.st,
                                         L.pd, crelu, stream);
             if (rc) return rc;
+            if (L.s2d) p->s2d_fresh_n = N;
             if (L.bn) {
                 float* st = acts + L.stat_off;
                 rc = clhip_bn_fwd(zc, params + L.bn_w_off, params + L.bn_b_off, L.rmean, L.rvar, y, st, st + L.cout, N, L.cout,
@@ -909,6 +927,12 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
                     job = true;
                     return clhip_internal_conv3x3_wgrad_partial(xin, gy, nullptr, grads + L.w_off, grads + L.b_off, N, L.cin, L.cout, L.h,
                                                                 L.w, base + p->off_wg + L.wg_off, L.wg_bytes, st, &jobs[n_jobs]);
+                }
+                if (L.s2d) {                  // (the phase planes of this pass's forward are still in the layer's frames)
+                    const bool fresh = p->s2d_fresh_n == N;
+                    p->s2d_fresh_n = 0;
+                    return clhip_conv2d_s2d_bwd_weight(fresh ? nullptr : xin, gy, grads + L.w_off, grads + L.b_off, N, L.cin, L.h, L.w, L.cout,
+                                                       L.ks, L.st, L.pd, base + p->off_s2d + L.s2d_off, L.s2d_bytes, st);
                 }
                 return L.wg3 ? clhip_conv3x3_bwd_weight(xin, gy, grads + L.w_off, grads + L.b_off, N, L.cin, L.cout, L.h, L.w, scratch,
                                                       p->scratch_bytes, st)

@@ -307,6 +307,45 @@ def conv2d_bwd_weight(x, dy, ksize, stride=1, pad=0, need_bias=True):
     return dw, db
 
 
+def conv2d_s2d_fwd(x, w, b, stride, pad, relu=False, ws=None):
+    """Strided convolution through space-to-depth + the dense 3x3 kernels (csrc/s2dconv.hip); returns (y, ws) — hand `ws` to
+    conv2d_s2d_bwd_weight(None, ...) to reuse the phase planes.  None when the shape is not taken."""
+    _chk(x, w, b)
+    N, C, H, W = x.shape
+    K, _, R, S = w.shape
+    L = _lib.lib()
+    nbytes = L.clhip_conv2d_s2d_ws(N, C, H, W, K, R, int(stride), int(pad)) if R == S else 0
+    if not nbytes:
+        return None
+    if ws is None:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    OH, OW = _out_hw(H, W, R, S, stride, pad)
+    y = torch.empty((N, K, OH, OW), dtype=torch.float32, device=x.device)
+    check(L.clhip_conv2d_s2d_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(y), N, C, H, W, K, R, int(stride), int(pad), int(relu), _ptr(ws),
+                                 ws.numel(), _stream()), "clhip_conv2d_s2d_fwd")
+    return y, ws
+
+
+def conv2d_s2d_bwd_weight(x, dy, x_shape, ksize, stride, pad, ws=None):
+    """(dW, db) of the same layer; x None = the phase planes of conv2d_s2d_fwd are still in `ws`."""
+    _chk(dy, x)
+    N, C, H, W = x_shape
+    K = dy.shape[1]
+    R = int(ksize)
+    L = _lib.lib()
+    nbytes = L.clhip_conv2d_s2d_ws(N, C, H, W, K, R, int(stride), int(pad))
+    if not nbytes:
+        return None
+    if ws is None:
+        assert x is not None
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
+    dw = torch.empty((K, C, R, R), dtype=torch.float32, device=dy.device)
+    db = torch.empty((K,), dtype=torch.float32, device=dy.device)
+    check(L.clhip_conv2d_s2d_bwd_weight(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), N, C, H, W, K, R, int(stride), int(pad), _ptr(ws),
+                                        ws.numel(), _stream()), "clhip_conv2d_s2d_bwd_weight")
+    return dw, db
+
+
 # ------------------------------------------------------------------ batch norm
 def bn_fwd(z, gamma, beta, running_mean, running_var, training, momentum, eps, relu):
     """nn.BatchNorm2d (+ReLU): returns (y, save_mean, save_invstd); training mode moves the running statistics in place."""

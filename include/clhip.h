@@ -133,6 +133,18 @@ int clhip_conv2d_bwd_data(const float* dy, const float* w, const float* relu_src
 int clhip_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* db, int N, int C, int H, int W, int K, int R,
                             int S, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
 
+/* The same strided convolution by space-to-depth (csrc/s2dconv.hip): stride s in {2, 4}, 2 s < R <= 3 s, C s^2 <= 64, K % 64 == 0 —
+ * AlexNet's Conv2d(3, 64, 11, 4, 2), models/net.py:96-125 — becomes a dense 3x3 convolution over the C s^2 phase planes of the
+ * padded input and runs on clhip_conv3x3_bs_fwd / clhip_conv3x3_wino_bwd_weight over frames kept in `ws`
+ * (clhip_conv2d_s2d_ws bytes; 0 = shape not taken, the entry points then return CLHIP_ENOTSUP).  Same results as
+ * clhip_conv2d_fwd / clhip_conv2d_bwd_weight up to fp32 summation order.  bwd_weight with x == NULL reuses the phase planes the
+ * forward call left in the same ws (same batch); there is no backward-data (the layer reads the images). */
+size_t clhip_conv2d_s2d_ws(int N, int C, int H, int W, int K, int R, int stride, int pad);
+int clhip_conv2d_s2d_fwd(const float* x, const float* w, const float* b, float* y, int N, int C, int H, int W, int K, int R, int stride,
+                         int pad, int relu, void* ws, size_t ws_bytes, void* stream);
+int clhip_conv2d_s2d_bwd_weight(const float* x_or_null, const float* dy, float* dw, float* db, int N, int C, int H, int W, int K, int R,
+                                int stride, int pad, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------ fully connected (MFMA fp32)
  * nn.Linear — models/VGGSlim.py:68-74.  x[M][I], w[O][I], b[O], y[M][O].                   */
 /* ws: optional split-K scratch (>= clhip_fc_ws(M,I,O) bytes); NULL => no K split (slower, same result
