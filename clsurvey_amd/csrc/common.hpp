@@ -147,6 +147,11 @@ size_t clhip_internal_bs_ws(int Cin, int Cout);
 int clhip_internal_bs_weights(const clhip_wino_wt* jobs, int n, hipStream_t s);
 int clhip_internal_bs_conv_u(int mode, const float* in, const void* wimg, const float* bias, const float* mask_src, float* out,
                              uint8_t* pool_idx, int unpool, int N, int Cin, int Cout, int H, int W, int relu, hipStream_t s);
+// bswgrad.hip: 3x3 weight gradient on the bf16 matrix cores (split fp32 operands, no LDS); slabs in conv3x3_wgrad.hip's format
+bool clhip_internal_bs_wgrad_ok(int C, int K, int H, int W);
+size_t clhip_internal_bs_wgrad_ws(int N, int C, int K, int H, int W);
+int clhip_internal_bs_wgrad_partial(const float* x, const float* dy, const uint8_t* unpool_idx, float* dw, float* db, int N, int C, int K,
+                                    int H, int W, void* ws, size_t ws_bytes, hipStream_t s, clhip_wgrad_job* job);
 bool clhip_internal_wino_wgrad_ok(int C, int K, int H, int W);
 size_t clhip_internal_wino_wgrad_ws(int N, int C, int K, int H, int W);
 int clhip_internal_wino_wgrad_partial(const float* x, const float* dy, const uint8_t* unpool_idx, float* dw, float* db, int N, int C,

@@ -26,7 +26,7 @@ def unpool(dyp, code):
 def bwd_weight(x, dy, ksize=3):
     """(dW, db) of a stride-1 'same' convolution by autograd on the CPU."""
     K, C = dy.shape[1], x.shape[1]
-    w = torch.zeros(K, C, ksize, ksize, requires_grad=True)
-    b = torch.zeros(K, requires_grad=True)
+    w = torch.zeros(K, C, ksize, ksize, dtype=x.dtype, requires_grad=True)
+    b = torch.zeros(K, dtype=x.dtype, requires_grad=True)
     F.conv2d(x.cpu(), w, b, padding=ksize // 2).backward(dy.cpu())
     return w.grad, b.grad
