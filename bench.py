@@ -224,7 +224,7 @@ def time_kernels(eng, x, N, iters):
         wt, bs = m.weight.data, m.bias.data
         pf = "bs" if paths.get("bs_fwd") else ("wino" if paths["fwd"] else "direct")              # path of the forward launch
         pd = "bs" if paths.get("bs_bwd_data") else ("wino" if paths["bwd_data"] else "direct")    # ... of backward-data
-        pw = "wino" if paths["bwd_weight"] else "direct"
+        pw = "bs" if paths.get("bs_bwd_weight") else ("wino" if paths["bwd_weight"] else "direct")
 
         def row(kernel, kind, sec, path, instance, alg_bytes):
             rows.append(dict(kernel=kernel, layer=layer, li=li, kind=kind, flops=fl, sec=sec, path=path, winograd=path == "wino",
@@ -252,15 +252,19 @@ def time_kernels(eng, x, N, iters):
                 "conv3x3_wgrad_c3_unpool_kernel" if W % 32 == 0 else "conv3x3_wgrad_smallc_kernel", 4.0 * N * H * W * (C + K / 4.0))
         elif pool:
             # (the Winograd entry point times slabs + its own reduction launch; inside a pass the reduction is deferred)
-            t_w = timed((lambda: ops.conv3x3_wino_bwd_weight(xin, dyp, idx)) if pw == "wino" else
+            t_w = timed((lambda: ops.conv3x3_bs_bwd_weight(xin, dyp, idx)) if pw == "bs" else
+                        (lambda: ops.conv3x3_wino_bwd_weight(xin, dyp, idx)) if pw == "wino" else
                         (lambda: ops.conv3x3_bwd_weight_slabs(xin, dyp, idx)))
             row("conv3x3_bwd_weight_unpool", "bwd_weight", t_w, pw,
+                "bs_wgrad_kernel<true> (slabs + reduction)" if pw == "bs" else
                 wino_wgrad_instance(N, C, K, H, W, True) if pw == "wino" else "conv3x3_wgrad_kernel<..., UNPOOL=true> (slabs; reduction deferred)",
                 4.0 * N * H * W * (C + K / 4.0) + 1.0 * N * K * H * W / 4)
         else:
-            t_w = timed((lambda: ops.conv3x3_wino_bwd_weight(xin, dy)) if pw == "wino" else
+            t_w = timed((lambda: ops.conv3x3_bs_bwd_weight(xin, dy)) if pw == "bs" else
+                        (lambda: ops.conv3x3_wino_bwd_weight(xin, dy)) if pw == "wino" else
                         (lambda: ops.conv3x3_bwd_weight_slabs(xin, dy)))
             row("conv3x3_bwd_weight", "bwd_weight", t_w, pw,
+                "bs_wgrad_kernel<false> (slabs + reduction)" if pw == "bs" else
                 wino_wgrad_instance(N, C, K, H, W, False) if pw == "wino" else "conv3x3_wgrad_kernel (slabs; reduction deferred)",
                 4.0 * N * H * W * (C + K))
         bwd_fn = {"bs": ops.conv3x3_bs_bwd_data, "wino": ops.conv3x3_wino_bwd_data}
@@ -382,7 +386,7 @@ def step_flops_per_image(eng, hw):
             h = (h + 2 * pd - ks) // st + 1
             f = 2.0 * ks * ks * m.in_channels * m.out_channels * h * h
             paths = eng.layer_paths(li)
-            for kind_, bs_key, on in (("fwd", "bs_fwd", True), ("bwd_data", "bs_bwd_data", not first), ("bwd_weight", None, True)):
+            for kind_, bs_key, on in (("fwd", "bs_fwd", True), ("bwd_data", "bs_bwd_data", not first), ("bwd_weight", "bs_bwd_weight", True)):
                 if on:
                     alg += f
                     pipe += pipe_seconds(f, "bs" if (bs_key and paths.get(bs_key)) else ("wino" if paths[kind_] else "direct"))

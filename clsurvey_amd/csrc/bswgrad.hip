@@ -22,6 +22,7 @@
 // UNPOOL: dy is the POOLED gradient + 2x2 arg-max codes (common.hpp: 0..3 position, 4 dead) — the un-pooled row is rebuilt in
 // registers from 4 pooled values + 4 codes per lane.
 #include "common.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -294,6 +295,22 @@ static int bs_wgrad_splits(int N, int C, int K, int H, int W) {
     if (s < 1) s = 1;
     if (s > rows) s = rows;
     return (int)s;
+}
+
+// ... and where the plan executor prefers it to the Winograd f32 weight gradient (CLHIP_BS_WGRAD=0: nowhere, =2: wherever it runs).
+// Measured at N = 200 (profiles/r06_p_bswgrad_build3.txt; us, Winograd / this, plain dy | pooled dy + codes):
+//   64 -> 64 @32x32  93.0 / 90.5 | 93.6 / 84.6      64 -> 128 @32x32  154.3 / 145.0 | 163.8 / 138.2     64 -> 64 @16x16  35.0 / 36.8 | 38.3 / 36.0
+//   64 -> 128 @16x16  51.0 / 51.2 | 55.4 / 49.2     128 -> 128 @16x16  84.7 / 82.2 | 90.8 / 77.4
+//   128 -> 256 @16x16  149.0 / 143.6 | 163.8 / 132.1     256 -> 256 @16x16  277.6 / 264.4 | 305.5 / 240.9
+// so: maps of 1024 pixels and more, and 16 x 16 maps from 128 x 128 channels on or behind a pool.  (Layers whose backward runs as one
+// merged grid — wino_pair_kernel — keep it: the executor asks for this path only where the weight gradient is a launch of its own.)
+bool clhip_internal_bs_wgrad_preferred(int C, int K, int H, int W, int pooled) {
+    static const int mode = [] { const char* e = std::getenv("CLHIP_BS_WGRAD"); return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1; }();
+    if (mode == 0 || !clhip_internal_bs_wgrad_ok(C, K, H, W)) return false;
+    if (mode == 2) return true;
+    const long long px = (long long)H * W;
+    if (px >= 1024) return true;
+    return (long long)C * K >= 128LL * 128 || (pooled && C * K >= 64 * 128);
 }
 
 size_t clhip_internal_bs_wgrad_ws(int N, int C, int K, int H, int W) {

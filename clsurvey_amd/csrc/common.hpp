@@ -149,6 +149,7 @@ int clhip_internal_bs_conv_u(int mode, const float* in, const void* wimg, const 
                              uint8_t* pool_idx, int unpool, int N, int Cin, int Cout, int H, int W, int relu, hipStream_t s);
 // bswgrad.hip: 3x3 weight gradient on the bf16 matrix cores (split fp32 operands, no LDS); slabs in conv3x3_wgrad.hip's format
 bool clhip_internal_bs_wgrad_ok(int C, int K, int H, int W);
+bool clhip_internal_bs_wgrad_preferred(int C, int K, int H, int W, int pooled);
 size_t clhip_internal_bs_wgrad_ws(int N, int C, int K, int H, int W);
 int clhip_internal_bs_wgrad_partial(const float* x, const float* dy, const uint8_t* unpool_idx, float* dw, float* db, int N, int C, int K,
                                     int H, int W, void* ws, size_t ws_bytes, hipStream_t s, clhip_wgrad_job* job);
@@ -160,6 +161,7 @@ int clhip_internal_wino_wgrad_partial(const float* x, const float* dy, const uin
 int clhip_internal_wino_pair(const float* dy, const uint8_t* unpool_idx, const float* U, const float* mask_src, float* dx,
                              const float* x, float* dw, float* db, int N, int C, int K, int H, int W, void* ws, size_t ws_bytes,
                              hipStream_t s, clhip_wgrad_job* job);
+bool clhip_internal_wino_pair_shape(int N, int C, int K, int H, int W, int pooled);
 int clhip_internal_wino_conv(int mode, const float* in, const float* w, const float* bias, const float* mask_src, float* out,
                              uint8_t* pool_idx, int unpool, int N, int Cin, int Cout, int H, int W, int relu, void* ws,
                              size_t ws_bytes, hipStream_t s);

@@ -42,6 +42,7 @@ struct LayerPlan {
     int bs5_f, bs5_d;            // 5 x 5 layers: forward / backward-data on the bf16-split kernel (image offsets in wino_uf / wino_ud)
     int bs_f, bs_d;              // ... forward / backward-data on the bf16 matrix cores with split fp32 operands (bsconv.hip): wino_f / wino_d
                                  // are set as well (the layer takes the prepared-weights path) and wino_uf / wino_ud hold its weight IMAGE
+    int bs_w;                  // weight gradient on the bf16-split kernel (bswgrad.hip) instead of the Winograd / direct f32 kernels
     int s2d;                   // strided first layer through space-to-depth + the dense 3x3 kernels (s2dconv.hip); frames at s2d_off
     size_t s2d_off, s2d_bytes;
     int wg3;                   // weight gradient on the 3x3 kernel (else the general gather-GEMM)
@@ -260,6 +261,20 @@ int clhip_net_create(const clhip_layer_desc* descs, int n_layers, int max_batch,
                         }
                     }
                 }
+                // ... or on the bf16 matrix cores with split fp32 operands (bswgrad.hip) where that is the faster launch and the layer's
+                // backward is not one merged grid: its slabs live in the same region
+                {
+                    const bool pooled22 = L.pool && L.pk == 2 && L.ps == 2;
+                    const bool merged = i > 0 && L.wino_w && L.wino_d && !L.bs_d && L.wg_bytes &&
+                                        clhip_internal_wino_pair_shape(max_batch, L.cin, L.cout, L.h, L.w, pooled22 ? 1 : 0);
+                    if (!merged && clhip_internal_bs_wgrad_preferred(L.cin, L.cout, L.h, L.w, pooled22 ? 1 : 0)) {
+                        const size_t bw = clhip_internal_bs_wgrad_ws(max_batch, L.cin, L.cout, L.h, L.w);
+                        if (bw && L.wg3) {
+                            L.bs_w = 1;
+                            if (bw > L.wg_bytes) { wg_total += align_up(bw, 256) - L.wg_bytes; L.wg_bytes = align_up(bw, 256); }
+                        }
+                    }
+                }
                 // every Winograd layer keeps its own transformed weights: ONE transform launch per pass fills them all
                 if (L.wino_f) { L.wino_uf = wino_ws; wino_ws += align_up(L.bs_f ? clhip_internal_bs_ws(L.cin, L.cout) : clhip_internal_wino_ws(L.cin, L.cout), 256); }
                 if (L.wino_d) { L.wino_ud = wino_ws; wino_ws += align_up(L.bs_d ? clhip_internal_bs_ws(L.cout, L.cin) : clhip_internal_wino_ws(L.cout, L.cin), 256); }
@@ -441,8 +456,9 @@ int clhip_net_layer_paths(void* handle, int layer) {
     const bool defer_capable = p->n_wg > 0 && !(p->overlap && p->overlap_mode == 1);
     // bits 3 / 4: the forward / backward-data launch is the bf16-split kernel (bsconv.hip), not Winograd (bits 0 / 1 then say
     // "prepared-weights path")
+    // bit 5: the weight gradient is the bf16-split kernel (bswgrad.hip)
     return (L.wino_f ? 1 : 0) | (L.wino_d ? 2 : 0) | ((L.wino_w && defer_capable) ? 4 : 0) | ((L.bs_f || L.bs5_f) ? 8 : 0) |
-           ((L.bs_d || L.bs5_d) ? 16 : 0);
+           ((L.bs_d || L.bs5_d) ? 16 : 0) | ((L.bs_w && defer_capable) ? 32 : 0);
 }
 
 int clhip_net_set_input_grad(void* handle, int layer, const float* extra) {
@@ -725,7 +741,7 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
     // slabs, a backward-data to compute and nothing to apply to it afterwards (clhip_internal_wino_pair decides on the shape)
     auto pair_ok = [&](const LayerPlan& Lp, int layer) {
         return defer && layer > 0 && Lp.type == 0 && Lp.ks == 3 && Lp.st == 1 && Lp.pd == 1 && !Lp.bn && Lp.wino_w && Lp.wino_d &&
-               !Lp.bs_d && Lp.wg_bytes && !Lp.drop && !Lp.extra_grad && !side_ok(layer);
+               !Lp.bs_d && !Lp.bs_w && Lp.wg_bytes && !Lp.drop && !Lp.extra_grad && !side_ok(layer);
     };
     clhip_wgrad_job jobs[CLHIP_WGRAD_JOBS_MAX];
     int n_jobs = 0;
@@ -858,6 +874,12 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
             if (!wdone) {
                 probe_begin(2);
                 rc = on_side(i, gin_buf, [&](void* st) {
+                    if (defer && L.bs_w) {
+                        const int r = clhip_internal_bs_wgrad_partial(xin, gin, idx + L.idx_off, grads + L.w_off, grads + L.b_off, N, L.cin,
+                                                                      L.cout, L.h, L.w, base + p->off_wg + L.wg_off, L.wg_bytes, as_stream(st),
+                                                                      &jobs[n_jobs]);
+                        if (r != CLHIP_ENOTSUP && r != CLHIP_ENOSPC) return r;
+                    }
                     if (defer && L.wino_w) {
                         const int r = clhip_internal_wino_wgrad_partial(xin, gin, idx + L.idx_off, grads + L.w_off, grads + L.b_off, N, L.cin,
                                                                         L.cout, L.h, L.w, base + p->off_wg + L.wg_off, L.wg_bytes,
@@ -916,6 +938,12 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
             bool job = false;                 // this layer left slabs for the deferred reduction
             probe_begin(2);
             rc = on_side(i, gy_buf, [&](void* st) {
+                if (defer && L.bs_w && L.wg_bytes) {
+                    const int r = clhip_internal_bs_wgrad_partial(xin, gy, nullptr, grads + L.w_off, grads + L.b_off, N, L.cin, L.cout, L.h, L.w,
+                                                                  base + p->off_wg + L.wg_off, L.wg_bytes, as_stream(st), &jobs[n_jobs]);
+                    if (r == 0) job = true;
+                    if (r != CLHIP_ENOTSUP && r != CLHIP_ENOSPC) return r;
+                }
                 if (defer && L.wino_w && L.wg_bytes) {
                     const int r = clhip_internal_wino_wgrad_partial(xin, gy, nullptr, grads + L.w_off, grads + L.b_off, N, L.cin, L.cout,
                                                                     L.h, L.w, base + p->off_wg + L.wg_off, L.wg_bytes, as_stream(st),

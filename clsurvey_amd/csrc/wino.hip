@@ -2117,6 +2117,18 @@ int clhip_internal_wino_pair(const float* dy, const uint8_t* unpool_idx, const f
     return 0;
 }
 
+// plan-time form of the shape test above (16-byte-aligned tensors, enough workspace): does the backward of this layer run as one grid?
+bool clhip_internal_wino_pair_shape(int N, int C, int K, int H, int W, int pooled) {
+    if (N <= 0 || ((H | W) & 1) || (long long)H * W > CLHIP_PAIR_MAX_PIXELS || !clhip_internal_wino_ok(K, C, H, W)) return false;
+    const bool wide = W >= 16, m88 = H == 8 && W == 8;
+    if (!wide && !m88) return false;
+    WgradGeo g;
+    alignas(16) static const float a16[4] = {0.f, 0.f, 0.f, 0.f};
+    static const uint8_t one = 0;
+    if (wino_wgrad_geo(a16, a16, pooled ? &one : nullptr, N, C, K, H, W, (size_t)1 << 40, &g)) return false;
+    return g.ps && g.vec && g.wide == wide;
+}
+
 extern "C" {
 
 size_t clhip_conv3x3_wino_ws(int C, int K) {

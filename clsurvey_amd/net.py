@@ -279,12 +279,12 @@ class NetEngine:
     def layer_paths(self, layer):
         """{'fwd', 'bwd_data', 'bwd_weight'} -> True where the plan runs the layer's kernel through a prepared-weights path
         (Winograd, csrc/wino.hip) instead of the direct f32 kernels; 'bs_fwd' / 'bs_bwd_data' -> True where that launch is the
-        bf16-split kernel (csrc/bsconv.hip) instead of Winograd."""
+        bf16-split kernel (csrc/bsconv.hip) instead of Winograd; 'bs_bwd_weight' -> the weight gradient is csrc/bswgrad.hip."""
         bits = _lib.lib().clhip_net_layer_paths(self._h, int(layer))
         if bits < 0:
             raise RuntimeError("clhip_net_layer_paths(%d)" % layer)
         return {"fwd": bool(bits & 1), "bwd_data": bool(bits & 2), "bwd_weight": bool(bits & 4),
-                "bs_fwd": bool(bits & 8), "bs_bwd_data": bool(bits & 16)}
+                "bs_fwd": bool(bits & 8), "bs_bwd_data": bool(bits & 16), "bs_bwd_weight": bool(bits & 32)}
 
     def set_input_grad(self, layer, extra):
         """extra [N][in_elems] (or None) is added to the gradient w.r.t. layer_input(layer) in the following backward

@@ -395,7 +395,8 @@ int clhip_net_probe_read(void* handle, float* avg_us, int* count);
 int clhip_net_layer_pool_idx(void* handle, int layer, size_t* ws_byte_off, size_t* elems_per_sample);
 /* Which kernels the plan chose for a layer (measurement harnesses time the same ones): bit 0 forward, bit 1 backward-data, bit 2
  * weight gradient through a prepared-weights path instead of the direct f32 MFMA kernels — Winograd F(2x2,3x3) (csrc/wino.hip)
- * unless bit 3 (forward) / bit 4 (backward-data) says the launch is the bf16-split kernel (csrc/bsconv.hip); < 0 on error. */
+ * unless bit 3 (forward) / bit 4 (backward-data) says the launch is the bf16-split kernel (csrc/bsconv.hip); bit 5: the weight
+ * gradient is the bf16-split kernel (csrc/bswgrad.hip); < 0 on error. */
 int clhip_net_layer_paths(void* handle, int layer);
 
 /* Side branches off a plan (EBLL's code layers on the flattened features, AlexNet_EBLL.py:110-117): the INPUT activation

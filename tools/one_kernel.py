@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Run ONE conv entry point a few times (for rocprofv3 --pmc passes).
 usage: python tools/one_kernel.py {c3pool|fwdpool|fwd|dgrad|dgrad_unpool|wgrad|wino_fwdpool|wino_fwd|wino_dgrad|wino_dgrad_unpool|wino_dgrad_unpool_mask|
-wino_wgrad|wino_wgrad_unpool|bs_fwdpool|bs_fwd|bs_dgrad|bs_dgrad_unpool} N C K HW [iters]"""
+wino_wgrad|wino_wgrad_unpool|bs_wgrad|bs_wgrad_unpool|bs_fwdpool|bs_fwd|bs_dgrad|bs_dgrad_unpool} N C K HW [iters]"""
 import os
 import sys
 
@@ -27,6 +27,7 @@ fn = {"dgrad_unpool": lambda: ops.conv3x3_bwd_data_unpool(dyp, idx, w, x), "c3po
       "wino_dgrad_unpool_mask": lambda: ops.conv3x3_wino_bwd_data(dyp, w, x, idx),
       "bs_fwdpool": lambda: ops.conv3x3_bs_fwd(x, w, b, True, pool=True), "bs_fwd": lambda: ops.conv3x3_bs_fwd(x, w, b, True),
       "bs_dgrad": lambda: ops.conv3x3_bs_bwd_data(dy, w, x), "bs_dgrad_unpool": lambda: ops.conv3x3_bs_bwd_data(dyp, w, None, idx),
+      "bs_wgrad": lambda: ops.conv3x3_bs_bwd_weight(x, dy), "bs_wgrad_unpool": lambda: ops.conv3x3_bs_bwd_weight(x, dyp, idx),
       "wino_wgrad": lambda: ops.conv3x3_wino_bwd_weight(x, dy), "wino_wgrad_unpool": lambda: ops.conv3x3_wino_bwd_weight(x, dyp, idx)}[kind]
 for _ in range(iters):
     fn()
