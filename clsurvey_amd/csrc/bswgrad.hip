@@ -298,7 +298,7 @@ static int bs_wgrad_splits(int N, int C, int K, int H, int W) {
 }
 
 // ... and where the plan executor prefers it to the Winograd f32 weight gradient (CLHIP_BS_WGRAD=0: nowhere, =2: wherever it runs).
-// Measured at N = 200 (profiles/r06_p_bswgrad_build3.txt; us, Winograd / this, plain dy | pooled dy + codes):
+// Measured at N = 200 (profiles/r06_p_bswgrad_builds.txt; us, Winograd / this, plain dy | pooled dy + codes):
 //   64 -> 64 @32x32  93.0 / 90.5 | 93.6 / 84.6      64 -> 128 @32x32  154.3 / 145.0 | 163.8 / 138.2     64 -> 64 @16x16  35.0 / 36.8 | 38.3 / 36.0
 //   64 -> 128 @16x16  51.0 / 51.2 | 55.4 / 49.2     128 -> 128 @16x16  84.7 / 82.2 | 90.8 / 77.4
 //   128 -> 256 @16x16  149.0 / 143.6 | 163.8 / 132.1     256 -> 256 @16x16  277.6 / 264.4 | 305.5 / 240.9

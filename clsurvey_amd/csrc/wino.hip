@@ -2074,7 +2074,10 @@ int clhip_internal_wino_wgrad_partial(const float* x, const float* dy, const uin
 
 // Backward of one 3x3 layer as ONE grid (wino_pair_kernel): dx = backward-data of dy on weights already transformed into U (mode 1
 // of clhip_internal_wino_weights), and the weight-gradient slabs of (x, dy) into ws, exactly as clhip_internal_wino_conv_u(1, ...)
-// followed by clhip_internal_wino_wgrad_partial would leave them (same device code, same block -> work mapping inside each half).
+// followed by clhip_internal_wino_wgrad_partial would leave them (same device code, same block -> work mapping inside each half;
+// one exception: on 8 x 8 maps with N * ceil(C / 32) > 512 and fewer than WINO16_BELOW_UNITS units launch_wino runs
+// wino_conv16_kernel<1, UNPOOL, 2> where this grid runs wino_conv16g_body<4, 4, 4> — the same sums in another order; the layers
+// of the VGG9 plans at the bench batch are bit-identical, tests/test_gpu_pair.py).
 // C / K: the layer's in / out channels; unpool_idx: dy is the POOLED gradient + arg-max codes.  CLHIP_ENOTSUP: not a layer this
 // grid takes (the caller issues the two launches): it takes even maps >= 16 wide and 8 x 8 maps whose weight gradient runs on the
 // pixel-split kernel with 16-byte staging, at most CLHIP_PAIR_MAX_PIXELS pixels per map — the launches that fill one round of

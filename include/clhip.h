@@ -267,7 +267,10 @@ int clhip_conv3x3_wino_bwd_weight(const float* x, const float* dy, const uint8_t
                                   int K, int H, int W, void* ws, size_t ws_bytes, void* stream);
 /* The whole backward of one such layer — dx (clhip_conv3x3_wino_bwd_data) and dW, db (clhip_conv3x3_wino_bwd_weight) — as ONE
  * grid: the blocks of the two launches interleaved so that blocks in their memory phases share the CUs with blocks in their matrix
- * phases (the autograd backward of one conv of VGGSlim.py:27-40; results bit-identical to the two entry points above).  Taken for the
+ * phases (the autograd backward of one conv of VGGSlim.py:27-40; results bit-identical to the two entry points above wherever they
+ * run the same kernels — every layer the VGG9 plans merge, asserted per shape in tests/test_gpu_pair.py; on 8 x 8 maps with
+ * N * ceil(C / 32) > 512 and few units the stand-alone backward-data launch is the two-wave-shape instance of wino_conv16_kernel and the
+ * agreement is up to fp32 summation order).  Taken for the
  * layers whose launches fill one round of blocks or less: even maps of at most 256 pixels, 16 or more wide or 8 x 8, weight gradient
  * on the pixel-split kernel, 16-byte-aligned tensors; CLHIP_ENOTSUP otherwise (nothing launched: call the two entry points).
  * ws: clhip_conv3x3_wino_bwd_ws(N, C, K, H, W) bytes.                                                                             */
@@ -280,6 +283,9 @@ int clhip_conv3x3_wino_bwd(const float* x, const float* dy, const uint8_t* idx_u
  * in DIRECT form on v_mfma_f32_32x32x16_bf16: every fp32 operand is split exactly into three bf16 pieces, the six products
  * a_i * b_j (i + j <= 2) of each 16-deep k-step are accumulated in fp32 inside the matrix core (csrc/bsconv.hip).  Measured error
  * against fp64 = that of an fp32 fmaf chain (profiles/r05_bf16_split_dot.txt); results equal the other paths' up to fp32 rounding.
+ * Non-finite inputs: an operand that is +-Inf, or so large that its leading bf16 piece rounds to Inf (|v| > 3.39e38), splits into
+ * Inf + NaN residuals, so such an output is NaN where the f32 kernels give +-Inf; either way the loss is non-finite and the trainers
+ * stop the attempt (train_EWC.py:204-205).
  * Shapes: C % 32 == 0, K % 64 == 0 on the forward (K % 32, C % 64 on backward-data), H, W >= 4; fused pooling on even maps only;
  * CLHIP_ENOTSUP otherwise.  ws: clhip_conv3x3_bs_ws(C, K) bytes (the weight image of this call).                            */
 size_t clhip_conv3x3_bs_ws(int C, int K);
