@@ -156,7 +156,7 @@ BS_ISSUE = 6.0                     # bf16-split direct convolution: six bf16 MFM
 
 def bs_conv_instance(N, H, W, kout, mode, unpool):
     """Instance name of the bf16-split forward (mode 0) / backward-data (mode 1) launch (csrc/bsconv.hip, bs_launch)."""
-    geo = "32, 4, 1, 2, 2, 1" if W > 16 else ("16, 8, 1, 2, 2, 1" if W > 8 else "8, 8, 2, 2, 2, 1")
+    geo = "32, 4, 1, 2, 2, 1, 3" if W > 16 else ("16, 8, 1, 2, 2, 1, 3" if W > 8 else "8, 8, 2, 2, 2, 1, 3")
     return "bs_conv_kernel<BsGeo<%s>, %d, %s> (+ bs_weight_multi_kernel)" % (geo, mode, "true" if unpool else "false")
 
 
@@ -369,6 +369,17 @@ def mfma_busy_pmc(width, instance=None):
         return None
     return {"file": name, "kernels": rows}
 
+
+
+def _weighted_busy(rows):
+    """MFMA-pipe busy (PMC, from the newest profiles/rNN_mfma_util_small.csv) of a group of launches, weighted by their time."""
+    num = den = 0.0
+    for r in rows:
+        b = (mfma_busy_pmc("small_VGG9", r["instance"]) or {}).get("busy")
+        if b is not None:
+            num += b * r["sec"]
+            den += r["sec"]
+    return num / den if den > 0 else None
 
 
 def step_flops_per_image(eng, hw):
@@ -1362,9 +1373,15 @@ def main():
         rows = time_kernels(eng, data_x[:N].contiguous(), N, args.kernel_iters)
         # dominant = the kernel INSTANCE with the largest share of a pass (sum over its launches), not the longest single
         # launch; its longest launch is the one probed in situ
+        # (the forward and the backward-data launch of a layer are two template instances of ONE kernel — rocprofv3's stats list them under
+        # one name: grouped by that name, mode / un-pool arguments dropped)
+        import re
+
+        def family(inst):
+            return re.sub(r">, [01], (true|false)> ", ">, mode, unpool> ", inst) if inst.startswith("bs_conv_kernel") else inst
         by_inst = {}
         for r in rows:
-            by_inst.setdefault(r["instance"], []).append(r)
+            by_inst.setdefault(family(r["instance"]), []).append(r)
         dom_rows = max(by_inst.values(), key=lambda rs: sum(r["sec"] for r in rs))
         dom = max(dom_rows, key=lambda r: r["sec"])
         longest = max(rows, key=lambda r: r["sec"])
@@ -1503,7 +1520,7 @@ def main():
                                               "share": longest["sec"] / sum(r["sec"] for r in rows)},
                            "by_share": [{"kernel": inst, "launches": len(rs), "share": sum(r["sec"] for r in rs) / sum(r["sec"] for r in rows),
                                          "frac": sum(r["pipe_sec"] for r in rs) / sum(r["sec"] for r in rs),
-                                         "busy_pmc": (mfma_busy_pmc("small_VGG9", inst) or {}).get("busy")}
+                                         "busy_pmc": _weighted_busy(rs)}
                                         for inst, rs in sorted(by_inst.items(), key=lambda kv: -sum(r["sec"] for r in kv[1]))[:3]],
                            "per_kernel": {k: {"tflops": v["flops"] / v["sec"] / 1e12, "us_per_step_pass": v["sec"] * 1e6}
                                           for k, v in agg.items()},
