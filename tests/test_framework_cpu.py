@@ -259,9 +259,8 @@ def test_traffic_json_names_the_kernel_bench_reports():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     t = json.load(open(os.path.join(root, "profiles", "traffic.json")))
-    # layer 2 of the bench model: forward / backward-data through the bf16-split kernel (large map: clhip_internal_bs_preferred), weight
-    # gradient through the pixel-split Winograd kernel — the entries must name THOSE instances; the Winograd forward / backward-data
-    # measurements of round 4 stay on file under 'wino_round4'
+    # layer 2 of the bench model: forward / backward-data through the bf16-split kernel (large map: clhip_internal_bs_preferred) —
+    # the entries must name THOSE instances; the Winograd forward / backward-data measurements of round 4 stay on file under 'wino_round4'
     inst = bench.bs_conv_instance(200, 32, 32, 64, 0, False)
     e = t["conv3x3_relu_pool_fwd 64x64@32 N=200"]
     assert e["instance"] == inst, (e["instance"], inst)
@@ -272,8 +271,10 @@ def test_traffic_json_names_the_kernel_bench_reports():
     assert t["conv3x3_bwd_data_unpool 64x64@32 N=200"]["instance"] == bench.bs_conv_instance(200, 32, 32, 64, 1, True)
     assert t["conv3x3_bwd_data_unpool 64x64@32 N=200"]["wino_round4"]["instance"] == bench.wino_conv_instance(32, 1, True)
     assert "wino_conv16g_kernel<8, 2, 4, 1, true>" in bench.wino_conv_instance(32, 1, True)
+    # round 6: the layer-2 weight gradient is the bf16-split kernel (csrc/bswgrad.hip); the Winograd kernel's values stay under 'wino_round5'
     w = t["conv3x3_bwd_weight_unpool 64x64@32 N=200"]
-    assert w["instance"] == bench.wino_wgrad_instance(200, 64, 64, 32, 32, True)
+    assert w["instance"] == "bs_wgrad_kernel<true> (slabs + reduction)"
+    assert w["wino_round5"]["instance"] == bench.wino_wgrad_instance(200, 64, 64, 32, 32, True)
     assert bench.measured_traffic("conv3x3_bwd_weight_unpool", "64x64@32", 200, w["instance"]) == w["hbm_bytes_per_launch"]
 
 
