@@ -163,22 +163,20 @@ struct BsGeo {
 //   v4  persistent one-wave-per-SIMD blocks, one in-wave pipeline over (tile, chunk) stages: 121 us, matrix + reads 76, staging + reads 76.
 // In every form the non-matrix work ADDS to the matrix time; what differs is how much of it there is per MFMA.  This form keeps v1's
 // structure (no weight bytes through VALU / LDS-write at all) and halves its load on the vector-memory path with 128 x 32 wave tiles.
+// The work of block b of a launch (a device function: bs_conv_kernel runs it for the whole grid, bs_conv_mixed_kernel for two geometries
+// in one grid); lds: 2 * G::BUF_BYTES bytes of the block's LDS.
 template <class G, int MODE, bool UNPOOL>
-// (three blocks per CU — 45 KB of LDS each — where the registers allow: every forward / plain backward-data instance at <= 162, the
-// un-pooling instance of the 32-wide geometry at 168 without spills; its narrower geometries would spill 11 - 12 registers)
-__global__ __launch_bounds__(256, (3 * 2 * G::BUF_BYTES <= 160 * 1024 && (G::RW == 32 || !UNPOOL)) ? 3 : 2) void bs_conv_kernel(
-    const float* __restrict__ in, const clhip_u32x4* __restrict__ wimg, const float* __restrict__ bias,
-    const float* __restrict__ mask_src, float* __restrict__ out, uint8_t* __restrict__ pool_idx, int N, int Cin, int Cout, int H,
-    int W, int relu, int tiles_x, int tiles_y, int npb) {
+__device__ __forceinline__ void bs_conv_body(
+    unsigned char* __restrict__ lds, const int b, const float* __restrict__ in, const clhip_u32x4* __restrict__ wimg,
+    const float* __restrict__ bias, const float* __restrict__ mask_src, float* __restrict__ out, uint8_t* __restrict__ pool_idx, int N,
+    int Cin, int Cout, int H, int W, int relu, int tiles_x, int tiles_y, int npb) {
     constexpr int RW = G::RW, RH = G::RH, NI = G::NI, WM = G::WM, WN = G::WN, P = G::P, HR = G::HR, HW_ = G::HW_;
     constexpr int ROUNDS = G::ROUNDS;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * G::BUF_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kts = (Cout + BS_BN - 1) / BS_BN;
     // blocks of one pixel tile (all channel groups) follow each other on ONE XCD (block b runs on XCD b % 8): its input tile is read
     // from HBM once per XCD L2
-    const int b = blockIdx.x;
     const int kt = (b >> 3) % kts, pb = (b / (8 * kts)) * 8 + (b & 7);
     if (pb >= npb) return;
     const int tx = pb % tiles_x, ty = (pb / tiles_x) % tiles_y, grp = pb / (tiles_x * tiles_y);
@@ -503,6 +501,54 @@ __global__ __launch_bounds__(256, (3 * 2 * G::BUF_BYTES <= 160 * 1024 && (G::RW 
     }
 }
 
+// (three blocks per CU — 45 KB of LDS each — where the registers allow: every forward / plain backward-data instance at <= 162, the
+// un-pooling instance of the 32-wide geometry at 168 without spills; its narrower geometries would spill 11 - 12 registers)
+template <class G, bool UNPOOL>
+constexpr int bs_blocks_per_cu() {
+    // (the 25-tap instances of the narrow geometries would spill 56 - 64 bytes at three blocks per CU)
+    return (3 * 2 * G::BUF_BYTES <= 160 * 1024 && (G::RW == 32 || (!UNPOOL && G::KS == 3))) ? 3 : 2;
+}
+
+template <class G, int MODE, bool UNPOOL>
+__global__ __launch_bounds__(256, (bs_blocks_per_cu<G, UNPOOL>())) void bs_conv_kernel(
+    const float* __restrict__ in, const clhip_u32x4* __restrict__ wimg, const float* __restrict__ bias,
+    const float* __restrict__ mask_src, float* __restrict__ out, uint8_t* __restrict__ pool_idx, int N, int Cin, int Cout, int H,
+    int W, int relu, int tiles_x, int tiles_y, int npb) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * G::BUF_BYTES];
+    bs_conv_body<G, MODE, UNPOOL>(lds, (int)blockIdx.x, in, wimg, bias, mask_src, out, pool_idx, N, Cin, Cout, H, W, relu, tiles_x, tiles_y, npb);
+}
+
+// Two geometries in ONE grid.  1 600 equal blocks on 3 x 256 slots leave the last 64 of them a round of their own: measured on layer 2 of
+// the bench model (64 -> 64 @32x32; tools/experiments/r06_m.sh), N = 192 (two whole rounds) 75.0 us, N = 200 83.2 — the last 8 images cost
+// 8.2 us instead of 3.1.  So the images that fill whole rounds of the launch go out as GA tiles, the rest as the smaller GB tiles
+// (twice as many blocks of half the length behind them): blocks [0, blocks_a) run GA on images [0, NA), the others GB on [NA, N).
+// An output pixel's sum does not depend on the tile it falls in (same chunk / tap / product order): results are bitwise those of
+// the one-geometry launch (tests/test_gpu_bs.py::test_two_geometry_launch_is_bitwise).
+template <class GA, class GB, int MODE, bool UNPOOL>
+__global__ __launch_bounds__(256, (bs_blocks_per_cu<GA, UNPOOL>() < bs_blocks_per_cu<GB, UNPOOL>() ? bs_blocks_per_cu<GA, UNPOOL>()
+                                                                                                  : bs_blocks_per_cu<GB, UNPOOL>()))
+void bs_conv_mixed_kernel(const float* __restrict__ in, const clhip_u32x4* __restrict__ wimg, const float* __restrict__ bias,
+                          const float* __restrict__ mask_src, float* __restrict__ out, uint8_t* __restrict__ pool_idx, int N, int Cin,
+                          int Cout, int H, int W, int relu, int blocks_a, int NA, int tiles_xa, int tiles_ya, int npb_a, int tiles_xb,
+                          int tiles_yb, int npb_b) {
+    constexpr int LB = 2 * (GA::BUF_BYTES > GB::BUF_BYTES ? GA::BUF_BYTES : GB::BUF_BYTES);
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LB];
+    const int b = (int)blockIdx.x;
+    if (b < blocks_a) {
+        bs_conv_body<GA, MODE, UNPOOL>(lds, b, in, wimg, bias, mask_src, out, pool_idx, NA, Cin, Cout, H, W, relu, tiles_xa, tiles_ya, npb_a);
+    } else {
+        // the tensors of images NA .. N - 1: the input ([Cin] planes of H x W, or of the pooled size when un-pooling, with its arg-max
+        // bytes), the output ([Cout] planes; pooled + arg-max bytes when the forward pools), the ReLU mask source of backward-data
+        const size_t in_img = (size_t)Cin * (UNPOOL ? (size_t)(H >> 1) * (W >> 1) : (size_t)H * W);
+        const bool pool = MODE == 0 && pool_idx != nullptr;
+        const size_t out_img = (size_t)Cout * (pool ? (size_t)(H >> 1) * (W >> 1) : (size_t)H * W);
+        uint8_t* idx_b = pool_idx ? pool_idx + (size_t)NA * (UNPOOL ? in_img : out_img) : nullptr;
+        bs_conv_body<GB, MODE, UNPOOL>(lds, b - blocks_a, in + (size_t)NA * in_img, wimg, bias,
+                                       mask_src ? mask_src + (size_t)NA * Cout * H * W : nullptr, out + (size_t)NA * out_img, idx_b, N - NA,
+                                       Cin, Cout, H, W, relu, tiles_xb, tiles_yb, npb_b);
+    }
+}
+
 // (A first-layer form of this scheme — 3 -> K, K dimension 27 -> 32, the A operand gathered from a raw fp32 halo tile in LDS and split
 // in registers, weights split once per persistent wave — was built, passed the parity suite and ran 50.9 us against 42 - 45 us for
 // conv3x3_c3w64_relu_pool_kernel on the f32 pipe (profiles/r05_j_conv_layers_small_with_c3.txt): 27 scalar LDS gathers + 88 split
@@ -527,9 +573,43 @@ int bs_launch_geo(const float* in, const clhip_u32x4* wimg, const float* bias, c
     return 0;
 }
 
+// GA = 128-pixel tiles of the 32-wide geometry, GB = its 64-pixel tiles; taken when the launch has whole rounds of GA blocks plus a
+// remainder of at most half a round (CLHIP_BS_MIXED=0: never)
+template <int MODE, bool UNPOOL>
+int bs_launch_mixed32(const float* in, const clhip_u32x4* wimg, const float* bias, const float* mask_src, float* out, uint8_t* pool_idx,
+                      int N, int Cin, int Cout, int H, int W, int relu, hipStream_t s, bool* taken) {
+    using GA = BsGeo<32, 4, 1, 2, 2, 1>;
+    using GB = BsGeo<32, 2, 1, 2, 1, 1>;
+    *taken = false;
+    static const int on = bs_env_int("CLHIP_BS_MIXED", 1);
+    if (!on) return 0;
+    const int kts = (Cout + BS_BN - 1) / BS_BN;
+    const long long per_img_a = (long long)((W + GA::RW - 1) / GA::RW) * ((H + GA::RH - 1) / GA::RH);
+    const long long slots = 256LL * bs_blocks_per_cu<GA, UNPOOL>();
+    const long long total = per_img_a * N * kts, rounds = total / slots, rem = total - rounds * slots;
+    if (rounds < 1 || rem == 0 || 2 * rem > slots) return 0;
+    const long long na = rounds * slots / (per_img_a * kts);            // images that fill the whole rounds
+    if (na < 1 || na >= N || na % 8) return 0;                             // (whole groups of 8 pixel tiles: the XCD order of the blocks)
+    const int NA = (int)na;
+    const int txa = (W + GA::RW - 1) / GA::RW, tya = (H + GA::RH - 1) / GA::RH, txb = (W + GB::RW - 1) / GB::RW, tyb = (H + GB::RH - 1) / GB::RH;
+    const long long npb_a = (long long)txa * tya * NA, npb_b = (long long)txb * tyb * (N - NA);
+    const long long blocks_a = (npb_a + 7) / 8 * 8 * kts, blocks_b = (npb_b + 7) / 8 * 8 * kts;
+    if (blocks_a + blocks_b > 0x7fffffffLL) return 0;
+    hipLaunchKernelGGL((bs_conv_mixed_kernel<GA, GB, MODE, UNPOOL>), dim3((unsigned)(blocks_a + blocks_b)), dim3(256), 0, s, in, wimg, bias,
+                       mask_src, out, pool_idx, N, Cin, Cout, H, W, relu, (int)blocks_a, NA, txa, tya, (int)npb_a, txb, tyb, (int)npb_b);
+    CLHIP_LAUNCH_CHECK();
+    *taken = true;
+    return 0;
+}
+
 template <int MODE, bool UNPOOL>
 int bs_launch(const float* in, const clhip_u32x4* wimg, const float* bias, const float* mask_src, float* out, uint8_t* pool_idx,
               int N, int Cin, int Cout, int H, int W, int relu, hipStream_t s) {
+    if (W > 16 && !((H | W) & 1)) {
+        bool taken = false;
+        const int rc = bs_launch_mixed32<MODE, UNPOOL>(in, wimg, bias, mask_src, out, pool_idx, N, Cin, Cout, H, W, relu, s, &taken);
+        if (rc || taken) return rc;
+    }
     // 128-pixel blocks of 64 x 32 wave tiles everywhere.  Measured and dropped (profiles/r05_bs_v5_per_layer_cfg*.txt, layer 2 forward /
     // backward-data at N = 200): 256-pixel blocks of 128 x 32 wave tiles (half the weight-operand bytes per MFMA, no room for the
     // separate accumulators at two blocks per CU) 92 / 90 us, of 64 x 64 wave tiles 95 / 96 us, against 83 / 92 us for this shape.

@@ -99,6 +99,36 @@ def _run(shapes):
         assert torch.equal(ops.conv3x3_bs_bwd_data(dyp, wd, relu_src=md, idx=code), ops.conv3x3_bs_bwd_data(dy_full, wd, relu_src=md))
 
 
+@pytest.mark.parametrize("N,C,K,HW", [(200, 64, 64, 32), (100, 64, 64, 32), (200, 64, 128, 32), (50, 256, 512, 28)])
+def test_two_geometry_launch_is_bitwise(N, C, K, HW):
+    """Launches with whole rounds of 128-pixel blocks plus a short remainder put the last images out as 64-pixel tiles in the same grid
+    (bs_conv_mixed_kernel).  An output does not depend on the tile it falls in: every image equals, bit for bit, the same entry point
+    run on a batch that takes the one-geometry launch (the first 8 images; the last 8; a middle chunk)."""
+    from clsurvey_amd import ops
+    g = torch.Generator(device="cuda")
+    g.manual_seed(N + C + K)
+    x = torch.randn((N, C, HW, HW), generator=g, device="cuda").relu_()
+    w = torch.randn((K, C, 3, 3), generator=g, device="cuda") * (2.0 / (9 * C)) ** 0.5
+    b = torch.randn((K,), generator=g, device="cuda") * 0.1
+    dy = torch.randn((N, K, HW, HW), generator=g, device="cuda")
+    dyp = torch.randn((N, K, HW // 2, HW // 2), generator=g, device="cuda")
+    code = torch.randint(0, 5, (N, K, HW // 2, HW // 2), generator=g, device="cuda", dtype=torch.uint8)
+    chunks = [(0, 8), (N - 8, N), (N // 2 - 4, N // 2 + 4)]
+    yp, idx = ops.conv3x3_bs_fwd(x, w, b, relu=True, pool=True)
+    y = ops.conv3x3_bs_fwd(x, w, b, relu=True)
+    if C % 64 == 0 and K % 32 == 0:
+        dx = ops.conv3x3_bs_bwd_data(dy, w, relu_src=x)
+        dxu = ops.conv3x3_bs_bwd_data(dyp, w, relu_src=None, idx=code)
+    for a, e in chunks:
+        xs = x[a:e].contiguous()
+        yps, idxs = ops.conv3x3_bs_fwd(xs, w, b, relu=True, pool=True)
+        assert torch.equal(yp[a:e], yps) and torch.equal(idx[a:e], idxs), (a, e)
+        assert torch.equal(y[a:e], ops.conv3x3_bs_fwd(xs, w, b, relu=True)), (a, e)
+        if C % 64 == 0 and K % 32 == 0:
+            assert torch.equal(dx[a:e], ops.conv3x3_bs_bwd_data(dy[a:e].contiguous(), w, relu_src=xs)), (a, e)
+            assert torch.equal(dxu[a:e], ops.conv3x3_bs_bwd_data(dyp[a:e].contiguous(), w, relu_src=None, idx=code[a:e].contiguous())), (a, e)
+
+
 def test_bs_refuses_shapes_outside_its_domain():
     from clsurvey_amd import ops, _lib
     with pytest.raises(_lib.ClhipError):           # 3 input channels: not whole 32-channel pairs
