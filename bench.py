@@ -157,7 +157,19 @@ BS_ISSUE = 6.0                     # bf16-split direct convolution: six bf16 MFM
 def bs_conv_instance(N, H, W, kout, mode, unpool):
     """Instance name of the bf16-split forward (mode 0) / backward-data (mode 1) launch (csrc/bsconv.hip, bs_launch)."""
     geo = "32, 4, 1, 2, 2, 1, 3" if W > 16 else ("16, 8, 1, 2, 2, 1, 3" if W > 8 else "8, 8, 2, 2, 2, 1, 3")
-    return "bs_conv_kernel<BsGeo<%s>, %d, %s> (+ bs_weight_multi_kernel)" % (geo, mode, "true" if unpool else "false")
+    u = "true" if unpool else "false"
+    if W > 16 and not ((H | W) & 1) and os.environ.get("CLHIP_BS_MIXED", "1") != "0":
+        # whole rounds of 128-pixel blocks + a remainder of at most half a round: the last images go out as 64-pixel tiles in the same
+        # grid (bs_launch_mixed32)
+        kts = (kout + 63) // 64
+        per_img = ((W + 31) // 32) * ((H + 3) // 4)
+        slots = 256 * 3
+        total = per_img * N * kts
+        rounds, rem = divmod(total, slots)
+        na = rounds * slots // (per_img * kts)
+        if rounds >= 1 and 0 < rem and 2 * rem <= slots and 1 <= na < N and na % 8 == 0:
+            return "bs_conv_mixed_kernel<BsGeo<%s>, BsGeo<32, 2, 1, 2, 1, 1, 3>, %d, %s> (+ bs_weight_multi_kernel)" % (geo, mode, u)
+    return "bs_conv_kernel<BsGeo<%s>, %d, %s> (+ bs_weight_multi_kernel)" % (geo, mode, u)
 
 
 def pipe_seconds(flops, path):
@@ -1378,7 +1390,7 @@ def main():
         import re
 
         def family(inst):
-            return re.sub(r">, [01], (true|false)> ", ">, mode, unpool> ", inst) if inst.startswith("bs_conv_kernel") else inst
+            return re.sub(r">, [01], (true|false)> ", ">, mode, unpool> ", inst) if inst.startswith("bs_conv_") else inst
         by_inst = {}
         for r in rows:
             by_inst.setdefault(family(r["instance"]), []).append(r)
