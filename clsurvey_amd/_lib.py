@@ -87,6 +87,8 @@ SIGNATURES = {
     "clhip_conv2d_bwd_weight": (_i, [_p, _p, _p, _p] + [_i] * 9 + [_p, _z, _p]),
     "clhip_conv3x3_bs_bwd_weight_ws": (_z, [_i] * 5),
     "clhip_conv3x3_bs_bwd_weight": (_i, [_p] * 5 + [_i] * 5 + [_p, _z, _p]),
+    "clhip_conv5x5_bs_bwd_weight_ws": (_z, [_i] * 5),
+    "clhip_conv5x5_bs_bwd_weight": (_i, [_p] * 4 + [_i] * 5 + [_p, _z, _p]),
     "clhip_conv2d_s2d_ws": (_z, [_i] * 8),
     "clhip_conv2d_s2d_fwd": (_i, [_p, _p, _p, _p] + [_i] * 9 + [_p, _z, _p]),
     "clhip_conv2d_s2d_bwd_weight": (_i, [_p, _p, _p, _p] + [_i] * 8 + [_p, _z, _p]),

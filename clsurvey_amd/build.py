@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libclhip.so")
-SOURCES = ["elementwise.hip", "loss.hip", "pool.hip", "conv3x3.hip", "wino.hip", "bsconv.hip", "bswgrad.hip", "conv3x3_wgrad.hip", "conv2d.hip", "convkk.hip", "s2dconv.hip", "bn.hip", "gemm.hip", "fc_chain.hip",
+SOURCES = ["elementwise.hip", "loss.hip", "pool.hip", "conv3x3.hip", "wino.hip", "bsconv.hip", "bswgrad.hip", "bswgrad5.hip", "conv3x3_wgrad.hip", "conv2d.hip", "convkk.hip", "s2dconv.hip", "bn.hip", "gemm.hip", "fc_chain.hip",
            "packnet.hip", "hat.hip", "gem.hip", "engine.hip"]
 # -pragma-unroll-threshold: the software-pipelined conv loops are fully unrolled by `#pragma unroll` (one piece of
 # staging work per MFMA slot, all register-array indices constant); at the default threshold hipcc silently stops

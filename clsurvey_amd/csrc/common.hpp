@@ -119,7 +119,7 @@ int clhip_internal_fc_fwd_partial(const float* x, const float* w, int M, int I, 
 
 // conv3x3_wgrad.hip: deferred slab reduction (see clhip_internal_conv3x3_wgrad_partial)
 #define CLHIP_WGRAD_JOBS_MAX 32
-struct clhip_wgrad_job { const float* part; float* dw; float* db; int K, C, splits; };
+struct clhip_wgrad_job { const float* part; float* dw; float* db; int K, C, splits; int taps; };     // taps: 0 = 9 (3x3); 25 = 5x5 (bswgrad5.hip)
 int clhip_internal_conv3x3_wgrad_partial(const float* x, const float* dy, const uint8_t* unpool_idx, float* dw, float* db, int N,
                                          int C, int K, int H, int W, void* ws, size_t ws_bytes, void* stream, clhip_wgrad_job* job);
 int clhip_internal_wgrad_reduce_multi(const clhip_wgrad_job* jobs, int n, hipStream_t s);
@@ -147,6 +147,11 @@ size_t clhip_internal_bs_ws(int Cin, int Cout);
 int clhip_internal_bs_weights(const clhip_wino_wt* jobs, int n, hipStream_t s);
 int clhip_internal_bs_conv_u(int mode, const float* in, const void* wimg, const float* bias, const float* mask_src, float* out,
                              uint8_t* pool_idx, int unpool, int N, int Cin, int Cout, int H, int W, int relu, hipStream_t s);
+// bswgrad5.hip: 5x5 / padding-2 weight gradient on the bf16 matrix cores (AlexNet's second convolution): slabs + reduction
+bool clhip_internal_bs5_wgrad_ok(int N, int C, int K, int H, int W);
+size_t clhip_internal_bs5_wgrad_ws(int N, int C, int K, int H, int W);
+int clhip_internal_bs5_wgrad(const float* x, const float* dy, float* dw, float* db, int N, int C, int K, int H, int W, void* ws,
+                             size_t ws_bytes, hipStream_t s);
 // bswgrad.hip: 3x3 weight gradient on the bf16 matrix cores (split fp32 operands, no LDS); slabs in conv3x3_wgrad.hip's format
 bool clhip_internal_bs_wgrad_ok(int C, int K, int H, int W);
 bool clhip_internal_bs_wgrad_preferred(int C, int K, int H, int W, int pooled);

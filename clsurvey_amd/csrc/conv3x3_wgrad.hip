@@ -771,8 +771,8 @@ constexpr int RED_THREADS = RED_EL / RED_V * RED_J;
 // sums in order: the order per element does not depend on the vector width.
 template <int EL, int J>
 __device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db,
-                                                   int K, int C, int splits, size_t e0, double (*partial)[EL]) {
-    const size_t kc = (size_t)K * C, nw = 9 * kc, total = nw + K;
+                                                   int K, int C, int splits, size_t e0, double (*partial)[EL], int T = 9) {
+    const size_t kc = (size_t)K * C, nw = (size_t)T * kc, total = nw + K;      // T taps per (k, c): 9, or 25 for the 5x5 slabs of bswgrad5.hip
     const int v = threadIdx.x % (EL / RED_V), j = threadIdx.x / (EL / RED_V);
     const size_t e = e0 + (size_t)v * RED_V;
     const int q = (splits + J - 1) / J;
@@ -803,7 +803,7 @@ __device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ par
             for (int jj = 0; jj < J; ++jj) t += partial[jj][el];
             if (ee < nw) {
                 const size_t rs = ee / kc, rem = ee - rs * kc;     // rem = k*C + c
-                dw[rem * 9 + rs] = (float)t;
+                dw[rem * T + rs] = (float)t;
             } else if (db) {
                 db[ee - nw] = (float)t;
             }
@@ -832,7 +832,7 @@ __global__ __launch_bounds__(RED_THREADS) void wgrad_reduce_multi_kernel(RedJobs
     int ji = 0;
     while (ji + 1 < jobs.n && blockIdx.x >= jobs.first[ji + 1]) ++ji;
     const clhip_wgrad_job J = jobs.job[ji];
-    wgrad_reduce_block<EL, JL>(J.part, J.dw, J.db, J.K, J.C, J.splits, (size_t)(blockIdx.x - jobs.first[ji]) * EL, partial);
+    wgrad_reduce_block<EL, JL>(J.part, J.dw, J.db, J.K, J.C, J.splits, (size_t)(blockIdx.x - jobs.first[ji]) * EL, partial, J.taps ? J.taps : 9);
 }
 
 struct WPlan {
@@ -997,10 +997,10 @@ int clhip_internal_wgrad_reduce_multi(const clhip_wgrad_job* jobs, int n, hipStr
     r.first[0] = 0;
     for (int i = 0; i < n; ++i) {
         r.job[i] = jobs[i];
-        const size_t total = (size_t)9 * jobs[i].K * jobs[i].C + jobs[i].K;
+        const size_t total = (size_t)(jobs[i].taps ? jobs[i].taps : 9) * jobs[i].K * jobs[i].C + jobs[i].K;
         r.first[i + 1] = r.first[i] + (unsigned)((total + RED_EL - 1) / RED_EL);
     }
-    for (int i = n; i < CLHIP_WGRAD_JOBS_MAX; ++i) { r.job[i] = clhip_wgrad_job{nullptr, nullptr, nullptr, 0, 0, 0}; r.first[i + 1] = r.first[n]; }
+    for (int i = n; i < CLHIP_WGRAD_JOBS_MAX; ++i) { r.job[i] = clhip_wgrad_job{nullptr, nullptr, nullptr, 0, 0, 0, 0}; r.first[i + 1] = r.first[n]; }
     hipLaunchKernelGGL((wgrad_reduce_multi_kernel<RED_EL, RED_J>), dim3(r.first[n]), dim3(RED_THREADS), 0, s, r);
     CLHIP_LAUNCH_CHECK();
     return 0;

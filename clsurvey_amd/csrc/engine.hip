@@ -40,6 +40,7 @@ struct LayerPlan {
     size_t wino_uf, wino_ud;     // byte offsets of this layer's transformed weights (forward / backward-data) in the plan's Winograd region
     int wino_f, wino_d, wino_w;  // forward / backward-data / weight gradient through Winograd F(2x2,3x3) (wino.hip) instead of the direct kernels
     int bs5_f, bs5_d;            // 5 x 5 layers: forward / backward-data on the bf16-split kernel (image offsets in wino_uf / wino_ud)
+    int bs5_w;                   // ... and their weight gradient (bswgrad5.hip; slabs in the plan's scratch)
     int bs_f, bs_d;              // ... forward / backward-data on the bf16 matrix cores with split fp32 operands (bsconv.hip): wino_f / wino_d
                                  // are set as well (the layer takes the prepared-weights path) and wino_uf / wino_ud hold its weight IMAGE
     int bs_w;                  // weight gradient on the bf16-split kernel (bswgrad.hip) instead of the Winograd / direct f32 kernels
@@ -284,6 +285,12 @@ int clhip_net_create(const clhip_layer_desc* descs, int n_layers, int max_batch,
             if (!vgg && !L.bn && L.ks == 5 && L.st == 1 && L.pd == 2) {
                 L.bs5_f = clhip_internal_bs5_preferred(L.cin, L.cout, L.h, L.w);
                 L.bs5_d = i > 0 && clhip_internal_bs5_preferred(L.cout, L.cin, L.h, L.w);
+                // weight gradient: 372 us against the gather-GEMM's 589 at N = 128 (profiles/r06_x_bswgrad5.txt); CLHIP_BS_WGRAD=0: off
+                {
+                    const char* e = std::getenv("CLHIP_BS_WGRAD");
+                    const size_t w5 = (e && e[0] == '0') ? 0 : clhip_internal_bs5_wgrad_ws(max_batch, L.cin, L.cout, L.h, L.w);
+                    if (w5) { L.bs5_w = 1; if (w5 > scratch) scratch = w5; }
+                }
                 if (L.bs5_f) { L.wino_uf = wino_ws; wino_ws += align_up(clhip_internal_bs5_ws(L.cin, L.cout), 256); }
                 if (L.bs5_d) { L.wino_ud = wino_ws; wino_ws += align_up(clhip_internal_bs5_ws(L.cout, L.cin), 256); }
             }
@@ -955,6 +962,11 @@ static int net_backward_impl(void* handle, const float* params, float* grads, co
                     job = true;
                     return clhip_internal_conv3x3_wgrad_partial(xin, gy, nullptr, grads + L.w_off, grads + L.b_off, N, L.cin, L.cout, L.h,
                                                                 L.w, base + p->off_wg + L.wg_off, L.wg_bytes, st, &jobs[n_jobs]);
+                }
+                if (L.bs5_w) {
+                    const int r = clhip_internal_bs5_wgrad(xin, gy, grads + L.w_off, grads + L.b_off, N, L.cin, L.cout, L.h, L.w, scratch,
+                                                           p->scratch_bytes, as_stream(st));
+                    if (r != CLHIP_ENOTSUP && r != CLHIP_ENOSPC) return r;
                 }
                 if (L.s2d) {                  // (the phase planes of this pass's forward are still in the layer's frames)
                     const bool fresh = p->s2d_fresh_n == N;

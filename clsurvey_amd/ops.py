@@ -173,6 +173,20 @@ def conv3x3_bs_bwd_weight(x, dy, idx=None):
     return dw, db
 
 
+def conv5x5_bs_bwd_weight(x, dy):
+    """clhip_conv5x5_bs_bwd_weight: (dw, db) of the 5x5 / padding-2 convolution on the bf16 matrix cores with split fp32 operands."""
+    _chk(x, dy)
+    N, C, H, W = x.shape
+    K = dy.shape[1]
+    L = _lib.lib()
+    ws = torch.empty(max(L.clhip_conv5x5_bs_bwd_weight_ws(N, C, K, H, W), 16), dtype=torch.uint8, device=x.device)
+    dw = torch.empty((K, C, 5, 5), dtype=torch.float32, device=x.device)
+    db = torch.empty((K,), dtype=torch.float32, device=x.device)
+    check(L.clhip_conv5x5_bs_bwd_weight(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), N, C, K, H, W, _ptr(ws), ws.numel(), _stream()),
+          "clhip_conv5x5_bs_bwd_weight")
+    return dw, db
+
+
 def conv3x3_wino_bwd(x, dy, w, relu_src=None, idx=None):
     """clhip_conv3x3_wino_bwd: (dx, dw, db) of one 3x3 layer as ONE grid (backward-data and weight-gradient blocks interleaved).
     Returns None for a layer the merged grid does not take (CLHIP_ENOTSUP: nothing was launched)."""

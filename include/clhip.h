@@ -141,6 +141,14 @@ size_t clhip_conv3x3_bs_bwd_weight_ws(int N, int C, int K, int H, int W);
 int clhip_conv3x3_bs_bwd_weight(const float* x, const float* dy, const uint8_t* idx_u8_or_null, float* dw, float* db, int N, int C, int K,
                                 int H, int W, void* ws, size_t ws_bytes, void* stream);
 
+/* Weight / bias gradient of the 5x5 / padding-2 convolution (AlexNet's Conv2d(64, 192, 5, padding=2), models/net.py:96-125) on the bf16
+ * matrix cores with exact 3-piece fp32 splits of both operands (csrc/bswgrad5.hip): the operator of clhip_conv2d_bwd_weight(R = S = 5,
+ * stride 1, pad 2), for C % 32 == 0, K % 32 == 0, W >= 16, tensors < 2 GB (CLHIP_ENOTSUP otherwise).  ws:
+ * clhip_conv5x5_bs_bwd_weight_ws(N, C, K, H, W) bytes of slabs, reduced in a fixed order (bitwise deterministic). */
+size_t clhip_conv5x5_bs_bwd_weight_ws(int N, int C, int K, int H, int W);
+int clhip_conv5x5_bs_bwd_weight(const float* x, const float* dy, float* dw, float* db, int N, int C, int K, int H, int W, void* ws,
+                                size_t ws_bytes, void* stream);
+
 /* The same strided convolution by space-to-depth (csrc/s2dconv.hip): stride s in {2, 4}, 2 s < R <= 3 s, C s^2 <= 64, K % 64 == 0 —
  * AlexNet's Conv2d(3, 64, 11, 4, 2), models/net.py:96-125 — becomes a dense 3x3 convolution over the C s^2 phase planes of the
  * padded input and runs on clhip_conv3x3_bs_fwd / clhip_conv3x3_wino_bwd_weight over frames kept in `ws`

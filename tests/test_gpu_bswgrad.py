@@ -84,3 +84,35 @@ def test_bs_weight_gradient_error_is_that_of_an_fp32_chain(C, K, N, HW):
     # (sums of 16 k - 33 k products with random signs: all three sit far below one fp32 ulp of the sum of magnitudes)
     assert bs[0] <= 2.5e-7 and bs[1] <= 5e-8
     assert bs[1] <= 2.0 * max(wino[1], direct[1]) and bs[0] <= 2.0 * max(wino[0], direct[0])
+
+
+SHAPES5 = [  # N, C, K, H, W — 5x5 / padding-2 weight gradient (csrc/bswgrad5.hip); AlexNet's second convolution first
+    (128, 64, 192, 27, 27), (3, 32, 64, 16, 16), (2, 64, 32, 9, 20), (5, 32, 32, 27, 27), (2, 32, 64, 5, 48), (1, 32, 32, 1, 16), (7, 64, 64, 31, 17),
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES5)
+def test_bs_weight_gradient_5x5(shape):
+    """dW, db of nn.Conv2d(C, K, 5, padding=2) (models/net.py:96-125) against torch CPU autograd and against the gather-GEMM entry point
+    of the same operator; bitwise deterministic."""
+    from clsurvey_amd import ops
+    N, C, K, H, W = shape
+    gen = np.random.RandomState(N * 13 + C + K + W)
+    x = torch.from_numpy(gen.standard_normal((N, C, H, W)).astype(np.float32))
+    dy = torch.from_numpy(gen.standard_normal((N, K, H, W)).astype(np.float32))
+    xd, dyd = x.cuda(), dy.cuda()
+    dw_ref, db_ref = torch_ref.bwd_weight(x, dy, ksize=5)
+    dw, db = ops.conv5x5_bs_bwd_weight(xd, dyd)
+    assert _rel(dw, dw_ref) <= 5e-5 and _rel(db, db_ref) <= 5e-5, (_rel(dw, dw_ref), _rel(db, db_ref))
+    dw2, db2 = ops.conv5x5_bs_bwd_weight(xd, dyd)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    dwg, dbg = ops.conv2d_bwd_weight(xd, dyd, (5, 5), 1, 2)
+    assert _rel(dwg, dw) <= 5e-5 and _rel(dbg, db) <= 5e-5
+
+
+def test_bs_weight_gradient_5x5_refuses_shapes_outside_its_domain():
+    from clsurvey_amd import _lib
+    L = _lib.lib()
+    assert L.clhip_conv5x5_bs_bwd_weight_ws(8, 64, 192, 27, 27) > 0
+    for C, K, H, W in ((3, 64, 27, 27), (48, 64, 27, 27), (64, 80, 27, 27), (64, 64, 8, 8)):
+        assert L.clhip_conv5x5_bs_bwd_weight_ws(8, C, K, H, W) == 0
