@@ -338,10 +338,16 @@ int clhip_internal_bs_wgrad_partial(const float* x, const float* dy, const uint8
 
 extern "C" {
 
-size_t clhip_conv3x3_bs_bwd_weight_ws(int N, int C, int K, int H, int W) { return clhip_internal_bs_wgrad_ws(N, C, K, H, W); }
+// (maps the 16-pixel-aligned kernel does not take — odd widths, 13 x 13 — go to the tap-split kernel of bswgrad5.hip; plain dy only)
+size_t clhip_conv3x3_bs_bwd_weight_ws(int N, int C, int K, int H, int W) {
+    const size_t a = clhip_internal_bs_wgrad_ws(N, C, K, H, W);
+    return a ? a : clhip_internal_bs3k_wgrad_ws(N, C, K, H, W);
+}
 
 int clhip_conv3x3_bs_bwd_weight(const float* x, const float* dy, const uint8_t* idx_u8_or_null, float* dw, float* db, int N, int C, int K,
                                 int H, int W, void* ws, size_t ws_bytes, void* stream) {
+    if (!idx_u8_or_null && N > 0 && !clhip_internal_bs_wgrad_ok(C, K, H, W))
+        return clhip_internal_bs3k_wgrad(x, dy, dw, db, N, C, K, H, W, ws, ws_bytes, as_stream(stream));
     clhip_wgrad_job job;
     const int rc = clhip_internal_bs_wgrad_partial(x, dy, idx_u8_or_null, dw, db, N, C, K, H, W, ws, ws_bytes, as_stream(stream), &job);
     if (rc) return rc;

@@ -152,6 +152,9 @@ bool clhip_internal_bs5_wgrad_ok(int N, int C, int K, int H, int W);
 size_t clhip_internal_bs5_wgrad_ws(int N, int C, int K, int H, int W);
 int clhip_internal_bs5_wgrad(const float* x, const float* dy, float* dw, float* db, int N, int C, int K, int H, int W, void* ws,
                              size_t ws_bytes, hipStream_t s);
+size_t clhip_internal_bs3k_wgrad_ws(int N, int C, int K, int H, int W);         // the 3x3 layer on bswgrad5.hip's kernel (any map width >= 8)
+int clhip_internal_bs3k_wgrad(const float* x, const float* dy, float* dw, float* db, int N, int C, int K, int H, int W, void* ws,
+                              size_t ws_bytes, hipStream_t s);
 // bswgrad.hip: 3x3 weight gradient on the bf16 matrix cores (split fp32 operands, no LDS); slabs in conv3x3_wgrad.hip's format
 bool clhip_internal_bs_wgrad_ok(int C, int K, int H, int W);
 bool clhip_internal_bs_wgrad_preferred(int C, int K, int H, int W, int pooled);

@@ -135,7 +135,8 @@ int clhip_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* d
 
 /* Weight / bias gradient of the 3x3 layer on the bf16 matrix cores with exact 3-piece fp32 splits of BOTH operands (csrc/bswgrad.hip):
  * the operator of clhip_conv3x3_wino_bwd_weight (same arguments; idx_u8 != NULL: dy is the pooled gradient [N][K][H/2][W/2] + the
- * forward pass's arg-max codes), for C % 64 == 0, K % 64 == 0, W % 16 == 0 (CLHIP_ENOTSUP otherwise).  ws:
+ * forward pass's arg-max codes), for C % 64 == 0, K % 64 == 0, W % 16 == 0; other maps from 8 pixels wide (13 x 13!) with C % 32 == 0,
+ * K % 32 == 0 and a plain dy run on the tap-split kernel of csrc/bswgrad5.hip (CLHIP_ENOTSUP otherwise).  ws:
  * clhip_conv3x3_bs_bwd_weight_ws(N, C, K, H, W) bytes of slabs, reduced in a fixed order (bitwise deterministic). */
 size_t clhip_conv3x3_bs_bwd_weight_ws(int N, int C, int K, int H, int W);
 int clhip_conv3x3_bs_bwd_weight(const float* x, const float* dy, const uint8_t* idx_u8_or_null, float* dw, float* db, int N, int C, int K,

@@ -19,6 +19,8 @@ SHAPES = [  # N, C, K, H, W
     (3, 128, 256, 16, 16), (13, 64, 64, 30, 48), (2, 256, 64, 17, 16),
     (200, 64, 64, 32, 32), (200, 64, 64, 16, 16), (131, 64, 64, 32, 32),
     (200, 64, 128, 16, 16), (200, 128, 128, 16, 16), (200, 64, 128, 32, 32), (200, 128, 256, 16, 16), (200, 256, 256, 16, 16),
+    # maps that are not whole 16-pixel strips (AlexNet's 13 x 13 layers, models/net.py:96-125): the tap-split kernel of bswgrad5.hip
+    (37, 192, 384, 13, 13), (4, 32, 64, 13, 13), (3, 64, 32, 9, 15), (5, 64, 64, 11, 13), (2, 32, 32, 8, 8), (3, 32, 96, 12, 20), (128, 256, 256, 13, 13),
 ]
 
 
@@ -39,8 +41,8 @@ def test_bs_weight_gradient(shape):
     assert _rel(dw, dw_ref) <= 5e-5 and _rel(db, db_ref) <= 5e-5, (_rel(dw, dw_ref), _rel(db, db_ref))
     dw2, db2 = ops.conv3x3_bs_bwd_weight(xd, dyd)
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
-    if (H | W) & 1:
-        return
+    if ((H | W) & 1) or W % 16 or C % 64 or K % 64:
+        return              # (pooled gradients: the 16-pixel-aligned kernel only)
     dyp = torch.from_numpy(gen.standard_normal((N, K, H // 2, W // 2)).astype(np.float32)).cuda()
     code = torch.from_numpy(gen.randint(0, 5, size=(N, K, H // 2, W // 2)).astype(np.uint8)).cuda()
     dw_u_ref, db_u_ref = torch_ref.bwd_weight(x, torch_ref.unpool(dyp, code))
@@ -55,10 +57,10 @@ def test_bs_weight_gradient_refuses_shapes_outside_its_domain():
     from clsurvey_amd import _lib
     L = _lib.lib()
     assert L.clhip_conv3x3_bs_bwd_weight_ws(8, 64, 64, 32, 32) > 0
-    for C, K, H, W in ((3, 64, 64, 64), (32, 64, 16, 16), (64, 96, 16, 16), (64, 64, 8, 8), (64, 64, 13, 13)):
+    for C, K, H, W in ((3, 64, 64, 64), (48, 64, 16, 16), (64, 80, 16, 16), (64, 64, 4, 4)):
         assert L.clhip_conv3x3_bs_bwd_weight_ws(8, C, K, H, W) == 0
-    x = torch.zeros(2, 64, 8, 8, device="cuda")
-    assert L.clhip_conv3x3_bs_bwd_weight(x.data_ptr(), x.data_ptr(), None, x.data_ptr(), x.data_ptr(), 2, 64, 64, 8, 8, x.data_ptr(), 1 << 20,
+    x = torch.zeros(2, 64, 4, 4, device="cuda")
+    assert L.clhip_conv3x3_bs_bwd_weight(x.data_ptr(), x.data_ptr(), None, x.data_ptr(), x.data_ptr(), 2, 64, 64, 4, 4, x.data_ptr(), 1 << 20,
                                          None) == -3
 
 
@@ -114,5 +116,5 @@ def test_bs_weight_gradient_5x5_refuses_shapes_outside_its_domain():
     from clsurvey_amd import _lib
     L = _lib.lib()
     assert L.clhip_conv5x5_bs_bwd_weight_ws(8, 64, 192, 27, 27) > 0
-    for C, K, H, W in ((3, 64, 27, 27), (48, 64, 27, 27), (64, 80, 27, 27), (64, 64, 8, 8)):
+    for C, K, H, W in ((3, 64, 27, 27), (48, 64, 27, 27), (64, 80, 27, 27), (64, 64, 4, 4)):
         assert L.clhip_conv5x5_bs_bwd_weight_ws(8, C, K, H, W) == 0

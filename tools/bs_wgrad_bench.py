@@ -18,7 +18,8 @@ for i in range(0, len(a), 4):
     dyp = torch.randn(N, K, HW // 2, HW // 2, device=dev)
     idx = torch.randint(0, 5, (N, K, HW // 2, HW // 2), device=dev, dtype=torch.uint8)
     fl = 2.0 * 9 * C * K * HW * HW * N
-    t = [timed(lambda: ops.conv3x3_bs_bwd_weight(x, dy)), timed(lambda: ops.conv3x3_bs_bwd_weight(x, dyp, idx)),
-         timed(lambda: ops.conv3x3_wino_bwd_weight(x, dy)), timed(lambda: ops.conv3x3_wino_bwd_weight(x, dyp, idx))]
+    pooled = HW % 16 == 0 and C % 64 == 0 and K % 64 == 0
+    t = [timed(lambda: ops.conv3x3_bs_bwd_weight(x, dy)), timed(lambda: ops.conv3x3_bs_bwd_weight(x, dyp, idx)) if pooled else float("nan"),
+         timed(lambda: ops.conv3x3_wino_bwd_weight(x, dy)), timed(lambda: ops.conv3x3_wino_bwd_weight(x, dyp, idx)) if pooled else float("nan")]
     print("%dx%d@%d N=%d  bf16-split %6.1f (pooled dy %6.1f) us = %5.1f TF   Winograd %6.1f (pooled dy %6.1f) us = %5.1f TF"
           % (C, K, HW, N, t[0], t[1], fl / t[0] / 1e6, t[2], t[3], fl / t[2] / 1e6), flush=True)
