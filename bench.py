@@ -104,6 +104,8 @@ def parse():
     ap.add_argument("--pair-cpu-leg", type=str, default=None, help="internal: run one CPU leg of the sweep pair under this root")
     ap.add_argument("--pair-threads", type=int, default=16)
     ap.add_argument("--pair-pin", type=int, default=-1, help="internal: first logical CPU of this leg's affinity set (-1: not pinned)")
+    ap.add_argument("--chain-cpu-leg", type=str, default=None, help="internal: run one task of this chain plan (JSON) on the torch-CPU oracle")
+    ap.add_argument("--chain-job", type=int, default=0)
     ap.add_argument("--sweep-blobs", type=str, default=None, help="tuning: g,amp,noise_lr,q of the sweep's synthetic tasks")
     ap.add_argument("--forced-leg", type=str, default=None, help="internal: run the teacher-forced trainings of this plan file (JSON) on the "
                                                                  "kernel path CLHIP_BS selects")
@@ -802,6 +804,10 @@ def forced_leg(plan_path, device):
                     om = [v["omega"] for v in model.reg_params.values() if isinstance(v, dict) and "omega" in v]
                     row["omega_sum"] = float(sum(float(o.double().sum()) for o in om))
                     row["omega_max"] = float(max(float(o.max()) for o in om))
+                    # (the parameters the NEXT training is penalised on: everything but the head; reg_params also keeps the entries
+                    # of the heads of earlier tasks, main_EWC.py:160-232)
+                    trunk = list(model.parameters())[:-2]
+                    row["omega_sum_trunk"] = float(sum(float(model.reg_params[p]["omega"].double().sum()) for p in trunk if p in model.reg_params))
                     row["test_acc"] = inference.test_model(meth, model, job["dataset"], 0, inference.get_prev_heads(best, last, device),
                                                            batch_size=plan["batch"], device=device)
                     row["previous_task_test_acc"] = inference.test_model(
@@ -887,7 +893,189 @@ def forced_paths(out, stability, groot, epochs, batch=200, paths=("0", "1", "2")
     return res
 
 
-def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epochs=70, cpu_rates=None, lr_grid=None, forced=True):
+# ------------------------------------------------------------------------------------------------ CPU path vs HIP path, task by task
+# A bounded task sequence (PAIR's sizes and schedule, CHAIN["tasks"] tasks) run freely through the driver on the GPU — the reference's
+# loop with its LR grid, Fisher pass and stability decay from lambda 400 — and then EVERY task's EWC training repeated on both sides
+# from the free run's own model of the task before (teacher-forced, as forced_paths does between kernel paths): the HIP path in this
+# process, the torch-CPU oracle (oracle/sweep_ref.py) in one host process per task, all of them side by side while the GPU runs its
+# 10-task sweep.  lambda of a task's comparison job = the lambda the free run accepted, halved further (the reference's own decay
+# schedule, framework_train.py:168-216) until x = 2 lambda max(Omega) lr <= NEAR_LIMIT: above it penalised SGD sits at its stability
+# limit and two fp32 implementations may differ by whether the stiff coordinate gets excited (sweep_conditioning).
+CHAIN = {"tasks": 4}
+
+
+def _chain_args(device, root):
+    b = SWEEP_DATA["blobs"]
+    spec = "%d,20,%d,%d,%d,64,%g,%s,%g,%g,%g,%g" % ((CHAIN["tasks"],) + tuple(PAIR["sizes"]) + (SWEEP_DATA["noise"], SWEEP_DATA["kind"], b["g"], b["amp"], b["noise_lr"], b["q"]))
+    return ["small_VGG9_cl_128_128", "--num_epochs", str(PAIR["epochs"]), "--batch_size", str(PAIR["batch"]), "--saving_freq", "1000",
+            "--synthetic", spec, "--device", device, "--lr_grid", PAIR["lr"], "--results_root", root]
+
+
+def chain_cpu_leg(plan_path, index, threads, pin_from=None):
+    """One task of the chain on the torch-CPU oracle (its own process: `bench.py --chain-cpu-leg PLAN --chain-job I`): Fisher pass over
+    the previous task, omega accumulated onto the previous model's (read from the HIP run's model file: the artefact is the
+    reference's own, a pickled nn.Module with reg_params), penalised SGD with the count-based LR drop, best-validation model kept —
+    then the new task's test accuracy and the previous task's under the new trunk, as forced_leg reports them for the HIP path."""
+    import shutil
+    import tempfile
+    import types
+    from clsurvey_amd.framework import driver
+    from oracle import sweep_ref
+    torch.set_num_threads(threads)
+    if pin_from is not None and hasattr(os, "sched_setaffinity"):
+        try:
+            mine = [c for c in sorted(os.sched_getaffinity(0)) if c >= pin_from][:threads]
+            if len(mine) == threads:
+                os.sched_setaffinity(0, mine)
+        except OSError:
+            pass
+    with open(plan_path) as f:
+        plan = json.load(f)
+    job = plan["jobs"][index]
+    meth = sweep_ref.OracleEWC("small_VGG9")
+    scratch = tempfile.mkdtemp(prefix="clhip_chain_cpu_")
+    try:
+        args = types.SimpleNamespace(num_epochs=plan["epochs"], batch_size=plan["batch"], lr=job["lr"], weight_decay=0.0)
+        manager = types.SimpleNamespace(current_task_dataset_path=job["dataset"], reg_sets=[job["previous_dataset"]],
+                                        previous_task_model_path=job["previous_model"], heuristic_exp_dir=scratch)
+        driver.set_random(7)
+        t0 = time.perf_counter()
+        _, val = meth.train(args, manager, {"lambda": job["lambda"]})
+        dt = time.perf_counter() - t0
+        row = {"task": job["task"], "seconds": dt, "val_acc": float(val), "lr": job["lr"], "lambda": job["lambda"], "threads": torch.get_num_threads()}
+        best = os.path.join(scratch, "best_model.pth.tar")
+        if os.path.exists(best):
+            model = torch.load(best, map_location="cpu", weights_only=False)
+            row["omega_sum_trunk"] = float(sum(float(o.double().sum()) for o in model.oracle_omega[:-2]))
+            row["omega_max"] = float(max(float(o.max()) for o in model.oracle_omega[:-2]))
+
+            def acc(dset, head):
+                return meth.inference_eval(types.SimpleNamespace(dset_path=dset, test_set="test", eval_model_path=best, head_paths=head,
+                                                                 batch_size=plan["batch"]), None)
+            row["test_acc"] = acc(job["dataset"], best)
+            row["previous_task_test_acc"] = acc(job["previous_dataset"], job["previous_model"])
+        else:
+            row["diverged"] = True
+    finally:
+        shutil.rmtree(scratch, ignore_errors=True)
+    return row
+
+
+def chain_start(root, dev, cpu_threads, pin_from=None, pin_room=0):
+    """GPU: free run of the chain's sequence, then the jobs; starts one CPU process per job and returns the state chain_collect reads.
+    The CPU legs share the logical CPUs [pin_from, pin_from + pin_room) in equal parts when given (full_sweep: the free cores of the
+    socket the pair's second leg runs on, so that the pair's timed first leg keeps its socket to itself), else run unpinned."""
+    import contextlib
+    import io
+    import subprocess
+    from clsurvey_amd.framework import driver
+    from clsurvey_amd.methods import method as M
+    croot = os.path.join(root, "chain_gpu")
+    quiet = io.StringIO()
+    with contextlib.redirect_stdout(quiet):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        driver.main(_chain_args(dev, croot) + ["--method_name", "SI", "--runmode", "first_task_basemodel_dump"], method=M.parse("SI"))
+        out = driver.main(_chain_args(dev, croot) + ["--method_name", "EWC", "--test"], method=M.parse("EWC"))
+        torch.cuda.synchronize()
+        free_s = time.perf_counter() - t0
+    stab = sweep_stability(out)
+    jobs = []
+    for row in stab:
+        t = row["task"]
+        if t < 2 or row["lr"] is None:
+            continue
+        lam_acc = float(row["attempts"][-1]["lambda"])
+        per_lambda = 2.0 * row["omega_max"] * float(row["lr"])
+        lam, halvings = lam_acc, 0
+        while lam * per_lambda > NEAR_LIMIT and halvings < 12:
+            lam *= 0.5
+            halvings += 1
+        jobs.append({"task": t, "dataset": out["ds_paths"][t - 1], "previous_dataset": out["ds_paths"][t - 2],
+                     "previous_model": out["model_paths"][t - 2], "lr": float(row["lr"]), "lambda": lam,
+                     "lambda_accepted_by_free_run": lam_acc, "halvings_below_accepted": halvings,
+                     "x": lam * per_lambda, "x_of_accepted": lam_acc * per_lambda,
+                     "free_run_attempts": [[a["lambda"], a["val_acc"]] for a in row["attempts"]]})
+    plan_path = os.path.join(root, "chain_plan.json")
+    with open(plan_path, "w") as f:
+        json.dump({"jobs": jobs, "epochs": PAIR["epochs"], "batch": PAIR["batch"]}, f)
+    procs = []
+    share = pin_room // max(len(jobs), 1) if pin_from is not None else 0
+    if share >= 4:
+        cpu_threads = min(cpu_threads, share)
+    for j, job in enumerate(jobs):
+        pin = pin_from + j * share if share >= 4 else -1
+        env = dict(os.environ, OMP_NUM_THREADS=str(cpu_threads), MKL_NUM_THREADS=str(cpu_threads),
+                   HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+        errf = open(os.path.join(root, "chain_cpu_%d.stderr" % j), "w+")
+        procs.append((subprocess.Popen([sys.executable, os.path.abspath(__file__), "--chain-cpu-leg", plan_path, "--chain-job", str(j),
+                                        "--pair-threads", str(cpu_threads), "--pair-pin", str(pin)],
+                                       stdout=subprocess.PIPE, stderr=errf, env=env, text=True), errf))
+    r = out["results"]
+    free = {"seconds": free_s, "accepted_lambda_per_task": [float(row["attempts"][-1]["lambda"]) for row in stab if row["attempts"]],
+            "final_accuracies": [r[i]["seq_res"][i][-1] for i in sorted(r)], "first_accuracies": [r[i]["seq_res"][i][0] for i in sorted(r)],
+            "conditioning": sweep_conditioning(stab)}
+    # the HIP path's own legs of the same jobs (this process, default kernel path)
+    t0 = time.perf_counter()
+    gpu_rows = forced_leg(plan_path, dev)["tasks"]
+    return {"jobs": jobs, "procs": procs, "gpu_rows": gpu_rows, "gpu_forced_s": time.perf_counter() - t0, "free": free,
+            "cpu_threads_per_leg": cpu_threads, "cpu_pinned_from": pin_from if share >= 4 else None}
+
+
+def chain_collect(state):
+    import subprocess
+    cpu_rows = []
+    for proc, errf in state["procs"]:
+        try:
+            so, _ = proc.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            proc.kill()
+            so, _ = proc.communicate()
+        errf.seek(0)
+        se = errf.read()
+        errf.close()
+        line = [ln for ln in so.splitlines() if ln.startswith("{")]
+        if proc.returncode != 0 or not line:
+            raise RuntimeError("chain CPU leg failed:\n%s" % se[-2000:])
+        cpu_rows.append(json.loads(line[-1]))
+    state["procs"] = []
+    res = {"what": "%d-task sequence (%d/%d/%d images per task, batch %d, %d-epoch cap, LR grid {%s}) run freely on the GPU through the driver "
+                   "(stability decay from lambda 400); then every task's EWC training — Fisher pass, omega accumulation, penalised SGD — "
+                   "repeated from the free run's model of the task before on the HIP path and on the torch-CPU oracle (one host process "
+                   "per task), same task files, start model, seed, batches, head initialisation; lambda = the accepted one, halved "
+                   "until x = 2 lambda max(Omega) lr <= %g" % ((CHAIN["tasks"],) + tuple(PAIR["sizes"]) + (PAIR["batch"], PAIR["epochs"], PAIR["lr"], NEAR_LIMIT)),
+           "free_run": state["free"], "gpu_forced_seconds": state["gpu_forced_s"], "cpu_threads_per_leg": state["cpu_threads_per_leg"],
+           "cpu_legs_pinned_from_logical_cpu": state["cpu_pinned_from"], "per_task": []}
+    worst = {"test_acc": 0.0, "previous_task_test_acc": 0.0, "val_acc": 0.0, "omega": 0.0}
+    for job, g, c in zip(state["jobs"], state["gpu_rows"], cpu_rows):
+        e = {k: job[k] for k in ("task", "lr", "lambda", "lambda_accepted_by_free_run", "halvings_below_accepted", "x", "x_of_accepted")}
+        e["diverged"] = [n for n, r in (("gpu", g), ("cpu", c)) if r.get("diverged")]
+        e["gpu_s"], e["cpu_s"] = g["seconds"], c["seconds"]
+        gaps = {}
+        for key, scale in (("test_acc", 1.0), ("previous_task_test_acc", 1.0), ("val_acc", 100.0)):
+            if key in g and key in c:
+                e[key] = {"gpu": round(g[key] * scale, 3), "cpu": round(c[key] * scale, 3)}
+                gaps[key] = abs(g[key] - c[key]) * scale
+            else:
+                gaps[key] = float("inf")
+        e["gap_points"] = gaps
+        if "omega_sum_trunk" in g and "omega_sum_trunk" in c:
+            e["omega_sum_trunk"] = {"gpu": g["omega_sum_trunk"], "cpu": c["omega_sum_trunk"]}
+            e["omega_sum_trunk_rel_gap"] = abs(g["omega_sum_trunk"] - c["omega_sum_trunk"]) / max(abs(c["omega_sum_trunk"]), 1e-30)
+        else:
+            e["omega_sum_trunk_rel_gap"] = float("inf")
+        for k in ("test_acc", "previous_task_test_acc", "val_acc"):
+            worst[k] = max(worst[k], gaps[k])
+        worst["omega"] = max(worst["omega"], e["omega_sum_trunk_rel_gap"])
+        res["per_task"].append(e)
+    res["tasks_compared"] = len(res["per_task"])
+    res["max_gap_points"] = {"new_task": worst["test_acc"], "previous_task": worst["previous_task_test_acc"], "validation": worst["val_acc"]}
+    res["max_omega_sum_rel_gap"] = worst["omega"]
+    res["cpu_over_gpu_seconds"] = (sum(e["cpu_s"] for e in res["per_task"]) / max(sum(e["gpu_s"] for e in res["per_task"]), 1e-9)) if res["per_task"] else None
+    return res
+
+
+def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epochs=70, cpu_rates=None, lr_grid=None, forced=True, chain=True):
     """BASELINE.json's second metric ('full-sweep wall-clock'), two measurements.
 
     `gpu_s`: what framework/main.py runs for `small_VGG9_cl_128_128 --method_name EWC --test` with the reference's defaults
@@ -926,6 +1114,7 @@ def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epoch
            "data": {"kind": SWEEP_DATA["kind"], "noise": SWEEP_DATA["noise"], **SWEEP_DATA["blobs"]}}
     quiet = io.StringIO()
     legs = []
+    chain_state = None
     try:
         pair = None
         if cpu_threads:
@@ -960,6 +1149,15 @@ def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epoch
                             "evaluated; same task files, start model, batches and head initialisation on every leg"
                             % (tuple(PAIR["sizes"]) + (PAIR["lr"], PAIR["epochs"], PAIR["batch"], PAIR["lam"])),
                     "gpu": _pair_summary(gout, dt, pcounts)}
+            if chain:
+                try:
+                    # (the pair's legs hold [0, cpu_threads) and [ncpu / 4, ncpu / 4 + other): the chain's legs take what is left of the
+                    # second quarter — on a two-socket host the second socket)
+                    room = ncpu // 2 - (ncpu // 4 + other)
+                    pinned = ncpu >= 4 * max(cpu_threads, other) and room >= 4 * (CHAIN["tasks"] - 1)
+                    chain_state = chain_start(root, dev, cpu_threads, ncpu // 4 + other if pinned else None, room if pinned else 0)
+                except BaseException as e:     # noqa: BLE001  (the pair and the sweep are reported regardless)
+                    res["chain"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:400])}
         # ---- the full sweep on the GPU (tasks == 0: only the pair, for checks of the pair itself)
         counts = None
         groot = os.path.join(root, "gpu")
@@ -1015,6 +1213,11 @@ def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epoch
             res["chance_accuracy"] = 100.0 / 20
             res["best_possible_accuracy"] = 100.0 * (SWEEP_DATA["blobs"]["q"] + (1 - SWEEP_DATA["blobs"]["q"]) / 20)
         # ---- collect the CPU legs
+        if chain_state is not None:
+            try:
+                res["chain"] = chain_collect(chain_state)
+            except BaseException as e:     # noqa: BLE001
+                res["chain"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:400])}
         if pair is not None:
             cpu = []
             for t, proc, errf in legs:
@@ -1065,6 +1268,9 @@ def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epoch
         res["error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
     finally:
         for _, proc, errf in legs:
+            proc.kill()
+            errf.close()
+        for proc, errf in (chain_state or {}).get("procs", []):
             proc.kill()
             errf.close()
         shutil.rmtree(root, ignore_errors=True)
@@ -1304,6 +1510,9 @@ def main():
         SWEEP_DATA["blobs"] = dict(zip(("g", "amp", "noise_lr", "q"), (float(v) for v in args.sweep_blobs.split(","))))
     if args.pair_cpu_leg:                      # a CPU leg of the sweep pair, in its own process (no GPU work)
         print(json.dumps(pair_cpu_leg(args.pair_cpu_leg, args.pair_threads, args.pair_pin if args.pair_pin >= 0 else None)), flush=True)
+        return
+    if args.chain_cpu_leg:
+        print(json.dumps(chain_cpu_leg(args.chain_cpu_leg, args.chain_job, args.pair_threads, args.pair_pin if args.pair_pin >= 0 else None)), flush=True)
         return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -1568,6 +1777,11 @@ def main():
                               "pair_max_accuracy_gap_points": out["sweep"].get("pair", {}).get("max_accuracy_gap_points"),
                               "pair_cpu_spread_points": out["sweep"].get("pair", {}).get("cpu_spread_points")}
             fp, cond = out["sweep"].get("forced_paths") or {}, out["sweep"].get("conditioning") or {}
+            ch = out["sweep"].get("chain") or {}
+            out["sweep_s"]["cpu_vs_hip_chain"] = ({"tasks": ch.get("tasks_compared"), "max_gap_points": ch.get("max_gap_points"),
+                                                   "max_omega_sum_rel_gap": ch.get("max_omega_sum_rel_gap"),
+                                                   "cpu_over_gpu_seconds": ch.get("cpu_over_gpu_seconds")}
+                                                  if "per_task" in ch else ch.get("error"))
             out["sweep_s"]["avg_accuracy"] = out["sweep"].get("gpu_avg_accuracy")
             out["sweep_s"]["avg_forgetting"] = out["sweep"].get("gpu_avg_forgetting")
             # the three kernel paths task by task (teacher-forced on the sweep that just ran), and where the free run's stability-

@@ -112,6 +112,7 @@ __device__ __forceinline__ void fc_chain_wgrad_block(const FcChain& c, const FcT
 // multiple of 32 as gemm_mfma_kernel with one split, epilogues apply bias / ReLU / mask in the same order, the
 // per-row loss code is the text of softmax_ce_rows_lds_kernel (loss.hip), and the loss / hit totals are formed by the
 // last workgroup to finish in that kernel's order (64-row butterflies, then 16 sequential adds).
+constexpr int FC_TAIL_ROWS_DEFAULT = 32;
 constexpr int TL = 129;            // LDS row stride in floats: odd, so walks along rows and along columns are conflict-free
 constexpr int ZL = 33;
 struct FcTail {
@@ -149,6 +150,10 @@ __device__ __forceinline__ floatx16 tail_mm(int K, FA a_at, FB b_at) {
     return acc;
 }
 
+// RB = rows (samples) a workgroup owns: 32, 16 or 8.  The products always run on 32-row MFMA tiles (rows past RB are zero and
+// are never stored), so a row's values do not depend on RB; fewer rows per workgroup = more workgroups on this latency-bound
+// launch and all split-K slabs of a row block in flight at once (RB / 8 float4 per thread and slab).
+template <int RB>
 __global__ __launch_bounds__(256) void fc_tail_kernel(FcTail t, const float* __restrict__ params, const float* __restrict__ h1,
                                                       float* __restrict__ acts, int N, const int64_t* __restrict__ labels,
                                                       int reduction, int col_off, int C, float* __restrict__ dlogits,
@@ -169,14 +174,17 @@ __global__ __launch_bounds__(256) void fc_tail_kernel(FcTail t, const float* __r
     __shared__ int w_corr[16];
     __shared__ unsigned s_ticket;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kk = lane >> 5;
-    const int m0 = blockIdx.x * 32;
+    static_assert(RB == 32 || RB == 16 || RB == 8, "rows per workgroup");
+    constexpr int JN = RB / 8;           // float4 of the h1 row block per thread (RB rows x 32 float4 / 256 threads at d1 = 128)
+    constexpr int UN = 32 / JN;          // slabs per trip of the slab sum: 32 loads in flight per thread
+    const int m0 = blockIdx.x * RB;
     const int K1 = (t.d1 + 31) & ~31, K2 = (t.d2 + 31) & ~31;       // padded widths of h1 / h2
 
     // ---- stage W2 [d2][d1], the h1 row block and W3 [d3][d2]: all loads in flight before the first LDS write;
     //      everything outside the real extents reads as zero (buffer range check), which is the GEMM kernel's padding
     const __amdgpu_buffer_rsrc_t r_w2 = clhip_rsrc(params + t.w2, (size_t)t.d2 * t.d1 * 4);
     const __amdgpu_buffer_rsrc_t r_w3 = clhip_rsrc(params + t.w3, (size_t)t.d3 * t.d2 * 4);
-    const int rows_here = min(32, N - m0);
+    const int rows_here = min(RB, N - m0);
     const __amdgpu_buffer_rsrc_t r_h1 = clhip_rsrc(h1 + (size_t)m0 * t.d1, (size_t)rows_here * t.d1 * 4);
     float4 q2[16], q1[4], q3[4];
     const int c1 = K1 >> 2, c2 = K2 >> 2;           // float4 columns
@@ -210,17 +218,33 @@ __global__ __launch_bounds__(256) void fc_tail_kernel(FcTail t, const float* __r
             off[j] = (r < rows_here && i < t.d1 && e < 32 * c1) ? (r * t.d1 + i) * 4 : CLHIP_OOB;
             q1[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        for (int s0 = 0; s0 < live; s0 += 8) {
-            float4 pv[8][4];
+        // (rows >= RB of the block: items j >= JN at d1 = 128, out of range by `off`; narrower layers keep the general loop)
+        if (K1 == 128) {
+            for (int s0 = 0; s0 < live; s0 += UN) {
+                float4 pv[UN][JN];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+                for (int u = 0; u < UN; ++u)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    pv[u][j] = clhip_buf_load4(r_p, (s0 + u < live && off[j] != CLHIP_OOB) ? off[j] + (int)((size_t)(s0 + u) * slab * 4) : CLHIP_OOB, 0);
+                    for (int j = 0; j < JN; ++j)
+                        pv[u][j] = clhip_buf_load4(r_p, (s0 + u < live && off[j] != CLHIP_OOB) ? off[j] + (int)((size_t)(s0 + u) * slab * 4) : CLHIP_OOB, 0);
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+                for (int u = 0; u < UN; ++u)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { q1[j].x += pv[u][j].x; q1[j].y += pv[u][j].y; q1[j].z += pv[u][j].z; q1[j].w += pv[u][j].w; }
+                    for (int j = 0; j < JN; ++j) { q1[j].x += pv[u][j].x; q1[j].y += pv[u][j].y; q1[j].z += pv[u][j].z; q1[j].w += pv[u][j].w; }
+            }
+        } else {
+            for (int s0 = 0; s0 < live; s0 += 8) {
+                float4 pv[8][4];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        pv[u][j] = clhip_buf_load4(r_p, (s0 + u < live && off[j] != CLHIP_OOB) ? off[j] + (int)((size_t)(s0 + u) * slab * 4) : CLHIP_OOB, 0);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { q1[j].x += pv[u][j].x; q1[j].y += pv[u][j].y; q1[j].z += pv[u][j].z; q1[j].w += pv[u][j].w; }
+            }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -270,7 +294,7 @@ __global__ __launch_bounds__(256) void fc_tail_kernel(FcTail t, const float* __r
             if (t.relu2) v = fmaxf(v, 0.f);
             if (n >= t.d2) v = 0.f;
             h2s[row * TL + n] = v;
-            if (m < N && n < t.d2) acts[t.a2 + (size_t)m * t.d2 + n] = v;
+            if (row < rows_here && n < t.d2) acts[t.a2 + (size_t)m * t.d2 + n] = v;
         }
     }
 #if defined(CLHIP_TAIL_STOP) && CLHIP_TAIL_STOP == 2
@@ -289,7 +313,7 @@ __global__ __launch_bounds__(256) void fc_tail_kernel(FcTail t, const float* __r
             if (t.relu3) v = fmaxf(v, 0.f);
             if (li >= t.d3) v = 0.f;
             zs[row * ZL + li] = v;
-            if (m < N && li < t.d3) acts[t.a3 + (size_t)m * t.d3 + li] = v;
+            if (row < rows_here && li < t.d3) acts[t.a3 + (size_t)m * t.d3 + li] = v;
         }
     }
 #if defined(CLHIP_TAIL_STOP) && CLHIP_TAIL_STOP == 3
@@ -303,10 +327,9 @@ __global__ __launch_bounds__(256) void fc_tail_kernel(FcTail t, const float* __r
     // (spread over the workgroup: the exponentials of a row are evaluated by different lanes, every sum still runs over
     //  the classes in ascending order in one lane, so each value is the one the row-per-thread text produces)
     if (tid < 32) {
-        const int m = m0 + tid;
         float mx = -INFINITY;
         int am = 0;
-        if (m < N) {
+        if (tid < rows_here) {
             const float* z = zs + tid * ZL + col_off;
             for (int c = 0; c < C; ++c) {
                 float v = z[c];
@@ -323,7 +346,7 @@ __global__ __launch_bounds__(256) void fc_tail_kernel(FcTail t, const float* __r
     __syncthreads();
     if (tid < 32) {
         const int m = m0 + tid;
-        if (m < N) {
+        if (tid < rows_here) {
             const float* z = zs + tid * ZL + col_off;
             const int y = (int)labels[m];
             const float mx = r_mx[tid];
@@ -340,14 +363,14 @@ __global__ __launch_bounds__(256) void fc_tail_kernel(FcTail t, const float* __r
     for (int e = tid; e < 32 * 32; e += 256) {
         const int row = e >> 5, c = e & 31, cc = c - col_off;
         float v = 0.f;
-        if (m0 + row < N && c < ld && cc >= 0 && cc < C)
+        if (row < rows_here && c < ld && cc >= 0 && cc < C)
             v = (expf(zs[row * ZL + c] - r_mx[row] - r_lse[row]) - (cc == r_y[row] ? 1.f : 0.f)) * scale;
         zs[row * ZL + c] = v;
     }
     __syncthreads();
     for (int e = tid; e < 32 * ld; e += 256) {
         const int row = e / ld, c = e - row * ld;
-        if (m0 + row < N) dlogits[(size_t)(m0 + row) * ld + c] = zs[row * ZL + c];
+        if (row < rows_here) dlogits[(size_t)(m0 + row) * ld + c] = zs[row * ZL + c];
     }
 #if defined(CLHIP_TAIL_STOP) && CLHIP_TAIL_STOP == 4
     return;
@@ -362,7 +385,7 @@ __global__ __launch_bounds__(256) void fc_tail_kernel(FcTail t, const float* __r
                 float v = h2s[row * TL + n] > 0.f ? acc[r] : 0.f;
                 if (n >= t.d2) v = 0.f;
                 dz2s[row * TL + n] = v;
-                if (m < N && n < t.d2) fcdz[t.dz2 + (size_t)m * t.d2 + n] = v;
+                if (row < rows_here && n < t.d2) fcdz[t.dz2 + (size_t)m * t.d2 + n] = v;
             }
         }
         __syncthreads();
@@ -373,7 +396,7 @@ __global__ __launch_bounds__(256) void fc_tail_kernel(FcTail t, const float* __r
             for (int r = 0; r < 16; ++r) {
                 const int row = mfma32_row(r, lane), m = m0 + row;
                 const float v = h1s[row * TL + n] > 0.f ? acc[r] : 0.f;
-                if (m < N && n < t.d1) fcdz[t.dz1 + (size_t)m * t.d1 + n] = v;
+                if (row < rows_here && n < t.d1) fcdz[t.dz1 + (size_t)m * t.d1 + n] = v;
             }
         }
     }
@@ -495,9 +518,17 @@ int clhip_internal_fc_tail(const clhip_fc_chain* d, const float* params, float* 
     if (live <= 0) h1_slabs = nullptr;
     float* row_loss = static_cast<float*>(row_scratch);
     int* row_ok = reinterpret_cast<int*>(row_loss + N);
-    hipLaunchKernelGGL(fc_tail_kernel, dim3((N + 31) / 32), dim3(256), 0, s, t, params, acts + d->act_off[0], acts, N, labels,
-                       reduction, col_off, ncols, dlogits, fcdz, loss_out, stats, row_loss, row_ok, counter, do_loss, do_bwd,
-                       h1_slabs, live);
+    // rows per workgroup (CLHIP_FC_TAIL_ROWS = 32 | 16 | 8; results do not depend on it, tests/test_gpu_fc_tail.py)
+    static const int rows_env = [] { const char* e = getenv("CLHIP_FC_TAIL_ROWS"); return e && e[0] ? atoi(e) : 0; }();
+    const int rb = rows_env == 32 || rows_env == 16 || rows_env == 8 ? rows_env : FC_TAIL_ROWS_DEFAULT;
+#define FC_TAIL_GO(RB)                                                                                                              \
+    hipLaunchKernelGGL(fc_tail_kernel<RB>, dim3((N + RB - 1) / RB), dim3(256), 0, s, t, params, acts + d->act_off[0], acts, N, labels, \
+                       reduction, col_off, ncols, dlogits, fcdz, loss_out, stats, row_loss, row_ok, counter, do_loss, do_bwd,       \
+                       h1_slabs, live)
+    if (rb == 8) FC_TAIL_GO(8);
+    else if (rb == 16) FC_TAIL_GO(16);
+    else FC_TAIL_GO(32);
+#undef FC_TAIL_GO
     CLHIP_LAUNCH_CHECK();
     return 0;
 }

@@ -30,6 +30,21 @@ def _store(model, params):
     return model
 
 
+def _omega_of_reg_params(model):
+    """Omega of a model file written by the reference's own EWC code (or by the build's HIP path, which writes the same
+    artefact): `model.reg_params[param]["omega"]` per parameter (EWC/main_EWC.py:160-232), in model.parameters() order; None
+    for a parameter without an entry (the fresh head of the last training).  Lets a training of this oracle start from such a
+    file — bench.py's teacher-forced chain hands every task's CPU leg the GPU run's model of the task before."""
+    rp = getattr(model, "reg_params", None)
+    if not rp:
+        return None
+    out = []
+    for p in model.parameters():
+        e = rp.get(p)
+        out.append(e["omega"].detach().cpu().clone() if isinstance(e, dict) and "omega" in e else None)
+    return out if any(o is not None for o in out) else None
+
+
 def _order(n, shuffle):
     """Sample order of one pass of torch.utils.data.DataLoader(dataset, batch_size, shuffle) — what the reference's loops
     iterate (Finetune/main_SGD.py, EWC/main_EWC.py:138-157): every iterator first draws its worker base seed from the global
@@ -129,6 +144,8 @@ class OracleEWC:
         self.image_passes["train"] += len(prev)
         self.seconds["train"] += time.perf_counter() - t0
         older = getattr(model, "oracle_omega", None)                   # omega accumulated over the earlier tasks
+        if older is None:
+            older = _omega_of_reg_params(model)
         omega = [f if o is None else o + f for f, o in zip(fisher, older or [None] * len(fisher))]
         init = [t.clone() for t in theta]
         params = self._fresh_head(model, theta, len(dsets["train"].classes))

@@ -41,3 +41,37 @@ def test_three_kernel_paths_agree_task_by_task_on_a_sweep():
         assert e["gap_points"]["test_acc"] <= 1.0, e
         assert e["gap_points"]["previous_task_test_acc"] <= 1.0, e
         assert e["gap_points"]["val_acc"] <= 1.0, e
+
+
+@pytest.mark.timeout(900)
+def test_cpu_oracle_and_hip_path_agree_task_by_task_on_a_chain(monkeypatch):
+    """bench.chain_start / chain_collect on a 3-task sequence at the bench's own chain size (2000 / 500 / 500 images, batch 50, 6-epoch
+    cap: the trainings saturate at the accuracy the data sets; at 1000 images and 4 epochs the two sides are compared in the middle of
+    the rise of the learning curve and one rounding difference moves the previous task's accuracy by 6 points — measured, round 6): run
+    freely on the GPU, then tasks 2 and 3 repeated from the free run's own previous model on the HIP path and on the torch-CPU oracle
+    (one host process per task), at a lambda of the reference's decay schedule that sits clear of the stability limit.  Asserted per
+    task: new-task / previous-task test accuracy and validation accuracy within 1 point (5 of 500 images), Sum(Omega) over the trunk
+    within 1e-3 relative, nothing diverged."""
+    assert torch.cuda.is_available()
+    import shutil
+    import tempfile
+    import bench
+    monkeypatch.setitem(bench.CHAIN, "tasks", 3)
+    root = tempfile.mkdtemp(prefix="clhip_chain_test_")
+    state = None
+    try:
+        state = bench.chain_start(root, "cuda:0", min(16, max(2, (os.cpu_count() or 4) // 4)))
+        res = bench.chain_collect(state)
+    finally:
+        for proc, errf in (state or {}).get("procs", []):
+            proc.kill()
+            errf.close()
+        shutil.rmtree(root, ignore_errors=True)
+    assert res["tasks_compared"] == 2, res
+    for e in res["per_task"]:
+        assert not e["diverged"], e
+        assert e["x"] <= bench.NEAR_LIMIT, e
+        assert e["omega_sum_trunk_rel_gap"] <= 1e-3, e
+        assert e["gap_points"]["test_acc"] <= 1.0, e
+        assert e["gap_points"]["previous_task_test_acc"] <= 1.0, e
+        assert e["gap_points"]["val_acc"] <= 1.0, e
