@@ -945,10 +945,10 @@ __global__ __launch_bounds__(512) void conv3x3_c3w64_relu_pool_kernel(
     float* __restrict__ out, uint8_t* __restrict__ pool_idx, int N, int Cout, int H, int W,
     int tiles_w, int row_pairs, int ntiles) {
     __shared__ float halo_s[8 * 2 * W6_HALO];
-    __shared__ float bias_s[KT];
+    __shared__ float ones_s[W6_TWP + 5];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kk = lane >> 5;
     const int ko0 = blockIdx.y * KT;
-    if (tid < KT) bias_s[tid] = (bias && ko0 + tid < Cout) ? bias[ko0 + tid] : 0.f;
+    if (tid < W6_TWP + 5) ones_s[tid] = 1.f;
 
     // K order and pairing: as in conv3x3_c3_relu_pool_kernel (the two taps of a pair differ by a fixed LDS offset)
     float a[2][14];
@@ -966,6 +966,11 @@ __global__ __launch_bounds__(512) void conv3x3_c3w64_relu_pool_kernel(
         for (int half = 0; half < 2; ++half) {
             const int ch = ko0 + 32 * half + li;
             a[half][j] = (real && ch < Cout) ? wt[(size_t)ch * 27 + c * 9 + r * 3 + s2] : 0.f;
+            // The 28th slot of K (second half of the last k-pair, zero so far) carries the BIAS: its B operand reads 1.0 (ones_s), so the
+            // bias arrives inside the last MFMA of the chain instead of through 64 v_add_f32 per unit in the epilogue (VALU issue adds to
+            // the f32-MFMA time of the SIMD's other wave; round 6, second session).  The sum differs from "(sum over 27 taps) + bias" by
+            // the rounding of one addition.
+            if (j == 13 && kk == 1) a[half][j] = (bias && ch < Cout) ? bias[ch] : 0.f;
         }
     }
     const int b_row = 2 * li + kk * W6_TWP, b_col = 2 * li + kk, b_pln = 2 * li + kk * W6_PLANE;
@@ -973,7 +978,7 @@ __global__ __launch_bounds__(512) void conv3x3_c3w64_relu_pool_kernel(
         if (j < 9) return b_row + (j / 3) * W6_PLANE + (j % 3);
         if (j < 12) return b_col + (j - 9) * W6_PLANE + 2 * W6_TWP;
         if (j == 12) return b_pln + 2 * W6_TWP + 2;
-        return 2 * li + 2 * W6_PLANE + 2 * W6_TWP + 2;              // kk = 1 reads the same finite value; its A is 0
+        return 2 * li + 2 * W6_PLANE + 2 * W6_TWP + 2;              // (kk = 1: the bias slot, reads ones_s instead)
     };
 
     // units of this wave
@@ -1022,7 +1027,7 @@ __global__ __launch_bounds__(512) void conv3x3_c3w64_relu_pool_kernel(
     const int chw = OH * OW;
     const __amdgpu_buffer_rsrc_t r_o = clhip_rsrc(out, (size_t)N * Cout * chw * 4);
     const __amdgpu_buffer_rsrc_t r_i = clhip_rsrc(pool_idx, (size_t)N * Cout * chw);
-    __syncthreads();                                // bias_s
+    __syncthreads();                                // ones_s
     if (u0 >= u1) return;
     int t_cur = u0 >> 1;
     const int t_last = (u1 - 1) >> 1;
@@ -1049,7 +1054,8 @@ __global__ __launch_bounds__(512) void conv3x3_c3w64_relu_pool_kernel(
 #pragma unroll
             for (int row = 0; row < 2; ++row)
 #pragma unroll
-                for (int par = 0; par < 2; ++par) b[row][par][j] = xs[b_addr(j) + row * W6_TWP + par];
+                for (int par = 0; par < 2; ++par)
+                    b[row][par][j] = (j == 13 && kk == 1) ? ones_s[row * W6_TWP + par] : xs[b_addr(j) + row * W6_TWP + par];
         __builtin_amdgcn_sched_barrier(0);          // all LDS reads in flight before the first MFMA
         {   // first k-pair: C operand is the constant 0 (no 64 v_mov to clear the accumulators)
             const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1072,18 +1078,25 @@ __global__ __launch_bounds__(512) void conv3x3_c3w64_relu_pool_kernel(
         const int cbase = ko0 + 32 * half;
         const int obase = ((n * Cout + cbase) * OH + (h >> 1)) * OW + (w0 >> 1);      // scalar part of the output offset
         const int ovoff = (4 * kk * chw + li);                                        // lane part (elements)
-        const float* bias_k = bias_s + 32 * half + 4 * kk;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int c0 = (r & 3) + 8 * (r >> 2);
-            const float bv = bias_k[c0];
-            const float tl = fmaxf(acc[0][0][r] + bv, 0.f), tr = fmaxf(acc[0][1][r] + bv, 0.f);
-            const float bl = fmaxf(acc[1][0][r] + bv, 0.f), br = fmaxf(acc[1][1][r] + bv, 0.f);
-            float m = tl; int am = 0;
-            if (tr > m) { m = tr; am = 1; }
-            if (bl > m) { m = bl; am = 2; }
-            if (br > m) { m = br; am = 3; }
-            if (!(m > 0.f)) am = CLHIP_POOL_DEAD;
+            // (the bias is already in the accumulators: see a[][13])
+            // max(relu(.)) = relu(max(.)), and while the maximum is positive the first window position that holds it is the same before
+            // and after the ReLU (smaller positions are <= it either way); a non-positive maximum is a dead window: same values and
+            // codes as the scan over the four ReLU outputs, 15 instead of 21 VALU instructions per pooled value (they add to the
+            // f32-MFMA time of the SIMD's other wave)
+            const float tl = acc[0][0][r], tr = acc[0][1][r], bl = acc[1][0][r], br = acc[1][1][r];
+            // (v_max3 / v_max by name: fmaxf() on an MFMA result first canonicalises it with a v_max_f32 x, x of its own)
+            float mx, m;
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(tl), "v"(tr), "v"(bl));
+            asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(mx), "v"(br));
+            int am = 3;
+            am = bl == mx ? 2 : am;
+            am = tr == mx ? 1 : am;
+            am = tl == mx ? 0 : am;
+            if (!(mx > 0.f)) am = CLHIP_POOL_DEAD;
+            asm("v_max_f32 %0, 0, %1" : "=v"(m) : "v"(mx));
             const bool cok = FULL || cbase + c0 + 4 * kk < Cout;
             clhip_buf_store(m, r_o, cok ? ovoff * 4 : CLHIP_OOB, (obase + c0 * chw) * 4);
             clhip_buf_store_u8((uint8_t)am, r_i, cok ? ovoff : CLHIP_OOB, obase + c0 * chw);

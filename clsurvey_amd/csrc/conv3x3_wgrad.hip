@@ -627,6 +627,24 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_smallc_kernel(
 #ifndef CLHIP_U3
 #define CLHIP_U3 1
 #endif
+// 1: the bias gradient (sum of the un-pooled gradient over the pixels) rides on the matrix pipe — column C * 9 of the B operand, one of
+// the 32 - 27 spare ones, reads 1.0, so accumulator column C * 9 IS the sum of the A operands: no v_cvt_f64_f32 + v_add_f64 per MFMA
+// in the stage loop (32 of its ~80 VALU instructions per 16 MFMAs).  The block's partial sum is then an fp32 MFMA chain (a few hundred
+// terms) instead of an f64 sum; the slabs are still added in f64 (wgrad_reduce_block).  0: f64 sums as conv3x3_wgrad_smallc_kernel.
+#ifndef CLHIP_U3_BSUM_MFMA
+#define CLHIP_U3_BSUM_MFMA 0
+#endif
+// 1: the pooled gradient and its arg-max codes reach the lanes through a wave-private LDS image instead of straight from memory.  A
+// lane of the A operand is a CHANNEL: loading "the 16 windows of my channel" puts every lane of a load instruction on a cache line of
+// its own (channel planes are 4 KB apart) — 5 instructions x 64 lines per stage and wave, ~400 tag look-ups of the CU's vector cache
+// per 1024 matrix cycles, 16 waves per CU: the cache's address pipe, not the matrix pipe, set the pace (removing 75 % of the loop's
+// VALU instructions moved the launch by 4 %).  Here four lanes share a channel's 64-byte run (16 channels per instruction: 2 x 16 lines
+// for the gradient, 32 half-lines for the codes), write it to LDS rows of 80 bytes, and lane (channel, half) reads its row back with
+// five conflict-free ds_read_b128.  Same values into the same MFMAs: the slabs hold the same bits.
+#ifndef CLHIP_U3_LDSDY
+#define CLHIP_U3_LDSDY 1
+#endif
+constexpr int U3_DYROW = 20, U3_DY = 32 * U3_DYROW;          // dwords: 16 windows + 16 code bytes per channel row (80 bytes), 32 rows
 constexpr int U3_TWP = 35, U3_PLANE = 3 * U3_TWP, U3_HALO = 3 * U3_PLANE + 5;      // 320 floats per wave and buffer
 
 __global__ __launch_bounds__(256) void conv3x3_wgrad_c3_unpool_kernel(
@@ -635,6 +653,14 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_c3_unpool_kernel(
     const uint8_t* __restrict__ pool_idx) {
     __shared__ float halo[4 * 2 * U3_HALO];
     __shared__ float red[2 * 16 * 64 + 64];
+#if CLHIP_U3_LDSDY
+    __shared__ __attribute__((aligned(16))) float dyl[4 * 2 * U3_DY];
+#endif
+#if CLHIP_U3_BSUM_MFMA
+    __shared__ float ones_s[64];
+    ones_s[threadIdx.x & 63] = 1.f;          // (every wave writes the same values; read after the first stage's wave-private LDS traffic)
+    __syncthreads();
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wk = wave & 1, wh = wave >> 1;
     const int li = lane & 31, kk = lane >> 5;
@@ -661,19 +687,42 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_c3_unpool_kernel(
     const int k = k0 + wk * 32 + li;
     const bool kok = k < K;
     const unsigned want = 2 * wh + kk;
-    const __amdgpu_buffer_rsrc_t r_dy = clhip_rsrc(dyp, (size_t)N * K * OH * OW * 4);
-    const __amdgpu_buffer_rsrc_t r_ix = clhip_rsrc(pool_idx, (size_t)N * K * OH * OW);
-    const __amdgpu_buffer_rsrc_t r_x = clhip_rsrc(x, (size_t)N * C * H * W * 4);
+    // Addresses of a stage = a per-lane constant (vector offset, computed once) + a wave-uniform part (scalar offset, SALU): no vector
+    // multiplies and no per-element coordinate compares in the stage loop (they were ~65 of its ~190 VALU instructions per 16 MFMAs,
+    // and VALU issue adds to the f32-MFMA time on this chip: round 6, second session).
+    const int chw_p = OH * OW;
+    const __amdgpu_buffer_rsrc_t r_dy = clhip_rsrc(dyp, (size_t)N * K * chw_p * 4);
+    const __amdgpu_buffer_rsrc_t r_ix = clhip_rsrc(pool_idx, (size_t)N * K * chw_p);
+#if CLHIP_U3_LDSDY
+    // loads: lane = (channel cA = lane / 4 [+ 16], quarter q of its 64-byte run); codes: lane = (channel lane / 2, half of its 16 bytes)
+    float* dy_w = dyl + wave * (2 * U3_DY);
+    const int cA = lane >> 2, q4 = lane & 3, c2 = lane >> 1, h2 = lane & 1;
+    const int kA = k0 + wk * 32 + cA, kB = kA + 16, k2 = k0 + wk * 32 + c2;
+    const int dyA_voff = kA < K ? (kA * chw_p + 4 * q4) * 4 : CLHIP_OOB, dyB_voff = kB < K ? (kB * chw_p + 4 * q4) * 4 : CLHIP_OOB;
+    const int ix8_voff = k2 < K ? k2 * chw_p + 8 * h2 : CLHIP_OOB;
+    const int dstA = cA * U3_DYROW + 4 * q4, dstB = dstA + 16 * U3_DYROW, dst8 = c2 * U3_DYROW + 16 + 2 * h2;
+#else
+    const int dy_voff = kok ? k * chw_p * 4 : CLHIP_OOB, ix_voff = kok ? k * chw_p : CLHIP_OOB;
+#endif
+    // x: the descriptor starts (W + 1) elements BEFORE the tensor so that the scalar part (image, row h - 1, column w0 - 1) is never
+    // negative; elements outside the image are masked by lane (vector offset CLHIP_OOB reads 0), nothing in front of x is touched
+    const __amdgpu_buffer_rsrc_t r_x = clhip_rsrc(x - (W + 1), ((size_t)N * C * H * W + (size_t)(W + 1)) * 4);
     // halo element e = lane + 64 j of [3 channels][3 rows][34 columns]
-    int xe_c[5], xe_r[5], xe_w[5], xe_dst[5];
+    int xe_voff[5], xe_dst[5];
+    unsigned edge_bits = 0;         // nibble j: element j sits in halo row 0 / row 2 / column 0 / column 33
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
         const int e = lane + 64 * j;
         const int c = e / 102, rem = e - c * 102, row = rem / 34, col = rem - row * 34;
-        xe_c[j] = (e < 306 && c < C) ? c : -1; xe_r[j] = row; xe_w[j] = col;
+        xe_voff[j] = (e < 306 && c < C) ? ((c * H + row) * W + col) * 4 : CLHIP_OOB;
+        edge_bits |= ((row == 0 ? 1u : 0u) | (row == 2 ? 2u : 0u) | (col == 0 ? 4u : 0u) | (col == 33 ? 8u : 0u)) << (4 * j);
         xe_dst[j] = e < 306 ? c * U3_PLANE + row * U3_TWP + col : 3 * U3_PLANE + (lane & 3);       // spare words behind the planes
     }
+#if CLHIP_U3_LDSDY
+    struct Stage { float4 gA, gB; float2 code8; float xr[5]; };
+#else
     struct Stage { float4 g[4]; clhip_u32x4 code; float xr[5]; };
+#endif
 
     int cur_n, cur_th, cur_tw;
     {
@@ -683,56 +732,93 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_c3_unpool_kernel(
         cur_th = t0 % tiles_h;
         cur_n = t0 / tiles_h;
     }
-    auto load_stage = [&](Stage& S) {
+    // (live == false: a stage past this block's range — every vector offset out of range, the loads return zeros and touch nothing)
+    auto load_stage = [&](Stage& S, bool live) {
         const int n = cur_n, h0 = cur_th * 2, w0 = cur_tw * 32;
         if (++cur_tw == tiles_w) { cur_tw = 0; if (++cur_th == tiles_h) { cur_th = 0; ++cur_n; } }
-        const int o = ((n * K + k) * OH + (h0 >> 1)) * OW + (w0 >> 1);         // 16 pooled windows of this lane's channel
+        const int o = __builtin_amdgcn_readfirstlane(live ? (n * K * OH + (h0 >> 1)) * OW + (w0 >> 1) : 0);      // 16 pooled windows of every channel
+#if CLHIP_U3_LDSDY
+        S.gA = clhip_buf_load4(r_dy, live ? dyA_voff : CLHIP_OOB, o * 4);
+        S.gB = clhip_buf_load4(r_dy, live ? dyB_voff : CLHIP_OOB, o * 4);
+        S.code8 = clhip_buf_load2(r_ix, live ? ix8_voff : CLHIP_OOB, o);
+#else
+        const int dv = live ? dy_voff : CLHIP_OOB, iv = live ? ix_voff : CLHIP_OOB;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) S.g[j] = clhip_buf_load4(r_dy, kok ? (o + 4 * j) * 4 : CLHIP_OOB, 0);
-        S.code = __builtin_amdgcn_raw_buffer_load_b128(r_ix, kok ? o : CLHIP_OOB, 0, 0);
+        for (int j = 0; j < 4; ++j) S.g[j] = clhip_buf_load4(r_dy, dv, (o + 4 * j) * 4);
+        S.code = __builtin_amdgcn_raw_buffer_load_b128(r_ix, iv, o, 0);
+#endif
         const int hrow = h0 + wh;
+        // halo row 0 is image row hrow - 1, row 2 is hrow + 1; column 0 is w0 - 1, column 33 is w0 + 32
+        const unsigned edges = (hrow == 0 ? 1u : 0u) | (hrow + 1 >= H ? 2u : 0u) | (w0 == 0 ? 4u : 0u) | (w0 + 32 >= W ? 8u : 0u);
+        const unsigned bad = live ? edge_bits & (unsigned)__builtin_amdgcn_readfirstlane((int)(edges * 0x11111u)) : 0xfffffu;
+        const int xo = __builtin_amdgcn_readfirstlane(live ? ((n * C * H + hrow) * W + w0) * 4 : 0);       // (+ (W + 1) - (W + 1): see r_x)
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const int ih = hrow - 1 + xe_r[j], iw = w0 - 1 + xe_w[j];
-            const bool ok = (xe_c[j] >= 0) & ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W);      // & : no exec-mask branch
-            S.xr[j] = clhip_buf_load(r_x, ok ? (((n * C + xe_c[j]) * H + ih) * W + iw) * 4 : CLHIP_OOB, 0);
-        }
+        for (int j = 0; j < 5; ++j)
+            S.xr[j] = clhip_buf_load(r_x, (bad & (0xfu << (4 * j))) ? CLHIP_OOB : xe_voff[j], xo);
     };
     auto store_x = [&](const Stage& S, int buf) {
         float* d = xs_w + buf * U3_HALO;
 #pragma unroll
         for (int j = 0; j < 5; ++j) d[xe_dst[j]] = S.xr[j];
+#if CLHIP_U3_LDSDY
+        float* dd = dy_w + buf * U3_DY;
+        *reinterpret_cast<float4*>(dd + dstA) = S.gA;
+        *reinterpret_cast<float4*>(dd + dstB) = S.gB;
+        *reinterpret_cast<float2*>(dd + dst8) = S.code8;
+#endif
     };
     auto compute = [&](const Stage& S, int buf) {
+#if CLHIP_U3_LDSDY
+        // this lane's channel row: 16 windows + 16 codes (LDS operations of one wave execute in order: the row is complete)
+        const float* row = dy_w + buf * U3_DY + li * U3_DYROW;
+        float4 Sg[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Sg[j] = *reinterpret_cast<const float4*>(row + 4 * j);
+        const clhip_u32x4 Scode = *reinterpret_cast<const clhip_u32x4*>(row + 16);
+#else
+        const float4* Sg = S.g;
+        const clhip_u32x4 Scode = S.code;
+#endif
+#if CLHIP_U3_BSUM_MFMA
+        const float* bp = li == ncol ? ones_s + kk : xs_w + buf * U3_HALO + col_off + kk;
+#else
         const float* bp = xs_w + buf * U3_HALO + col_off + kk;
+#endif
+        // (the accumulator lives in AGPRs across the whole stage loop: without the pin the loop-carried copy sat in VGPRs and every
+        //  trip paid 16 v_accvgpr_write + 16 v_accvgpr_read)
+        asm volatile("" : "+a"(acc));
 #pragma unroll
         for (int wp = 0; wp < 16; ++wp) {
-            const float g = wp & 2 ? (wp & 1 ? S.g[wp >> 2].w : S.g[wp >> 2].z) : (wp & 1 ? S.g[wp >> 2].y : S.g[wp >> 2].x);
-            const unsigned word = S.code[wp >> 2];
+            const float g = wp & 2 ? (wp & 1 ? Sg[wp >> 2].w : Sg[wp >> 2].z) : (wp & 1 ? Sg[wp >> 2].y : Sg[wp >> 2].x);
+            const unsigned word = Scode[wp >> 2];
             const unsigned code = (word >> (8 * (wp & 3))) & 0xffu;
             const float a = code == want ? g : 0.f;
+#if !CLHIP_U3_BSUM_MFMA
             bsum += (double)a;
+#endif
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[2 * wp], acc, 0, 0, 0);
         }
+        asm volatile("" : "+a"(acc));
     };
 
-    if (st_begin < st_end) {
+    // Stage pairs in ONE basic block (loads, LDS writes and both stages' MFMAs unconditional; the load behind the block's last stage is
+    // dead: see load_stage), the odd last stage behind the loop: with branches inside the loop the loop-carried accumulator was copied
+    // AGPR -> VGPR -> AGPR on every trip (16 + 16 VALU instructions per two stages).
+    const int n_st = st_end - st_begin;
+    if (n_st > 0) {
         Stage SA, SB;
-        load_stage(SA);
+        load_stage(SA, true);
         store_x(SA, 0);
-        int st = st_begin;
-        while (true) {
-            if (st + 1 < st_end) load_stage(SB);
+        const int pairs = n_st >> 1;
+        for (int i = 0; i < pairs; ++i) {
+            load_stage(SB, true);                    // stage 2 i + 1 < n_st
             compute(SA, 0);
-            if (st + 1 >= st_end) break;
             store_x(SB, 1);
-            ++st;
-            if (st + 1 < st_end) load_stage(SA);
+            load_stage(SA, 2 * i + 2 < n_st);
             compute(SB, 1);
-            if (st + 1 >= st_end) break;
             store_x(SA, 0);
-            ++st;
         }
+        if (n_st & 1) compute(SA, 0);
     }
     // combine the two row halves through LDS, fixed order: half 0 + half 1 (as conv3x3_wgrad_smallc_kernel)
     bsum += __shfl_xor(bsum, 32, 64);
@@ -752,7 +838,17 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_c3_unpool_kernel(
                 if (kr < K) slab[((size_t)rs * K + kr) * C + cc] = acc[r] + red[(wk * 16 + r) * 64 + lane];
             }
         }
+#if CLHIP_U3_BSUM_MFMA
+        if (li == ncol) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kr = k0 + wk * 32 + mfma32_row(r, lane);
+                if (kr < K) slab[(size_t)9 * K * C + kr] = acc[r] + red[(wk * 16 + r) * 64 + lane];
+            }
+        }
+#else
         if (kk == 0 && kok) slab[(size_t)9 * K * C + k] = (float)(bsum + (double)red[2048 + wk * 32 + li]);
+#endif
     }
 }
 

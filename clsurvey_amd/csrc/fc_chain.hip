@@ -112,7 +112,7 @@ __device__ __forceinline__ void fc_chain_wgrad_block(const FcChain& c, const FcT
 // multiple of 32 as gemm_mfma_kernel with one split, epilogues apply bias / ReLU / mask in the same order, the
 // per-row loss code is the text of softmax_ce_rows_lds_kernel (loss.hip), and the loss / hit totals are formed by the
 // last workgroup to finish in that kernel's order (64-row butterflies, then 16 sequential adds).
-constexpr int FC_TAIL_ROWS_DEFAULT = 32;
+constexpr int FC_TAIL_ROWS_DEFAULT = 16;      // measured at N = 200 (rocprofv3, 40 launches): 32 rows 29.7 us, 16 rows 26.8, 8 rows 26.7
 constexpr int TL = 129;            // LDS row stride in floats: odd, so walks along rows and along columns are conflict-free
 constexpr int ZL = 33;
 struct FcTail {
