@@ -622,8 +622,9 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_smallc_kernel(
 // (channel, kk) holds the pooled gradient g and arg-max code of window wp of ITS channel (16 windows of a stage = four
 // 16-byte loads + one 16-byte load of codes per lane) and supplies  a = (code == 2 wh + kk) ? g : 0.  The x halo of the
 // wave's image row (3 channels x 3 rows x 34 columns) is wave-private in LDS, double buffered: no block barrier in the
-// stage loop, the four waves drift apart.  Stage order, pixel-pair order, the f64 bias sums and the final addition of the
-// two row halves are those of conv3x3_wgrad_smallc_kernel<32, 2> => every slab holds the same bits.
+// stage loop, the four waves drift apart.  Stage order, pixel-pair order and the final addition of the two row halves are those of
+// conv3x3_wgrad_smallc_kernel<32, 2> => the weight-gradient part of every slab holds the same bits (the bias sums: see
+// CLHIP_U3_BSUM_MFMA below).
 #ifndef CLHIP_U3
 #define CLHIP_U3 1
 #endif
@@ -631,8 +632,10 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_smallc_kernel(
 // the 32 - 27 spare ones, reads 1.0, so accumulator column C * 9 IS the sum of the A operands: no v_cvt_f64_f32 + v_add_f64 per MFMA
 // in the stage loop (32 of its ~80 VALU instructions per 16 MFMAs).  The block's partial sum is then an fp32 MFMA chain (a few hundred
 // terms) instead of an f64 sum; the slabs are still added in f64 (wgrad_reduce_block).  0: f64 sums as conv3x3_wgrad_smallc_kernel.
+// Measured on the LDS-staged build (N = 200, tools/experiments/r06_b6.sh): 45.0 -> 43.3 us; the bias gradient of a 200-image batch
+// differs from the f64 sum by 1.9e-4 at |db| = 1e3 (2e-7 relative; the f64 form: 8e-5), tools/experiments/u3_dump.py.
 #ifndef CLHIP_U3_BSUM_MFMA
-#define CLHIP_U3_BSUM_MFMA 0
+#define CLHIP_U3_BSUM_MFMA 1
 #endif
 // 1: the pooled gradient and its arg-max codes reach the lanes through a wave-private LDS image instead of straight from memory.  A
 // lane of the A operand is a CHANNEL: loading "the 16 windows of my channel" puts every lane of a load instruction on a cache line of
@@ -685,7 +688,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_c3_unpool_kernel(
     float* xs_w = halo + wave * (2 * U3_HALO);
     const int OH = H >> 1, OW = W >> 1;
     const int k = k0 + wk * 32 + li;
-    const bool kok = k < K;
+    [[maybe_unused]] const bool kok = k < K;
     const unsigned want = 2 * wh + kk;
     // Addresses of a stage = a per-lane constant (vector offset, computed once) + a wave-uniform part (scalar offset, SALU): no vector
     // multiplies and no per-element coordinate compares in the stage loop (they were ~65 of its ~190 VALU instructions per 16 MFMAs,
@@ -961,6 +964,10 @@ WPlan make_plan(int N, int C, int K, int H, int W) {
     int tiles = p.k_tiles * p.c_tiles;
     // MFMA-bound general kernel: ~1 block per CU. HBM-bound first-layer kernel: several per CU.
     int target = smallc ? 1024 : 256;       // (512 PS blocks, two per CU, measured slower: 44 vs 39 us at 8x8)
+    if (smallc) {                           // tuning switch (tools/experiments): blocks of the first-layer launch
+        static const int t_env = [] { const char* e = getenv("CLHIP_WG_SMALLC_BLOCKS"); return e && e[0] ? atoi(e) : 0; }();
+        if (t_env > 0) target = t_env;
+    }
     int splits = (target + tiles - 1) / tiles;
     if (splits > p.total_stages) splits = p.total_stages;
     p.slab = (size_t)9 * K * C + K;
