@@ -939,6 +939,17 @@ constexpr int W6_TWP = 67;                          // odd row stride: the two t
 constexpr int W6_PLANE = 4 * W6_TWP;                // 4 halo rows per channel
 constexpr int W6_HALO = 3 * W6_PLANE;               // 804 floats per wave and buffer
 
+// Timing-only ablations (tools/experiments; results wrong by design; the product is built with 0): 1 no stores, 2 no pooling
+// arithmetic, 4 no LDS reads of the B operands, 8 no MFMAs
+#ifndef C3W64_ABL
+#define C3W64_ABL 0
+#endif
+#if C3W64_ABL & 8
+__device__ __forceinline__ floatx16 c3w64_fake_mfma(float a, float b, floatx16 c) { c[0] += a * b; return c; }
+#define C3W64_MFMA(a, b, c, x, y, z) c3w64_fake_mfma(a, b, c)
+#else
+#define C3W64_MFMA(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z)
+#endif
 template <bool FULL>       // FULL: every block owns 64 real output channels (no per-store channel predicate)
 __global__ __launch_bounds__(512) void conv3x3_c3w64_relu_pool_kernel(
     const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
@@ -1037,12 +1048,6 @@ __global__ __launch_bounds__(512) void conv3x3_c3w64_relu_pool_kernel(
     if (t_cur < t_last) load_tile(t_cur + 1);
     for (int u = u0; u < u1; ++u) {
         const int t = u >> 1, half = u & 1;
-        if (t != t_cur) {                           // next row pair: its halo was loaded while the previous one computed
-            buf ^= 1;
-            store_tile(buf);
-            t_cur = t;
-            if (t_cur < t_last) load_tile(t_cur + 1);
-        }
         float ac[14];
 #pragma unroll
         for (int j = 0; j < 14; ++j) ac[j] = half ? a[1][j] : a[0][j];
@@ -1055,21 +1060,37 @@ __global__ __launch_bounds__(512) void conv3x3_c3w64_relu_pool_kernel(
             for (int row = 0; row < 2; ++row)
 #pragma unroll
                 for (int par = 0; par < 2; ++par)
+#if C3W64_ABL & 4          // timing only: no LDS reads of the B operands
+                    b[row][par][j] = __int_as_float(0x3f800000 + j + row + par + lane);
+#else
                     b[row][par][j] = (j == 13 && kk == 1) ? ones_s[row * W6_TWP + par] : xs[b_addr(j) + row * W6_TWP + par];
+#endif
         __builtin_amdgcn_sched_barrier(0);          // all LDS reads in flight before the first MFMA
         {   // first k-pair: C operand is the constant 0 (no 64 v_mov to clear the accumulators)
             const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[0], b[0][0][0], zero, 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[0], b[0][1][0], zero, 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[0], b[1][0][0], zero, 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[0], b[1][1][0], zero, 0, 0, 0);
+            acc[0][0] = C3W64_MFMA(ac[0], b[0][0][0], zero, 0, 0, 0);
+            acc[0][1] = C3W64_MFMA(ac[0], b[0][1][0], zero, 0, 0, 0);
+            acc[1][0] = C3W64_MFMA(ac[0], b[1][0][0], zero, 0, 0, 0);
+            acc[1][1] = C3W64_MFMA(ac[0], b[1][1][0], zero, 0, 0, 0);
         }
 #pragma unroll
         for (int j = 1; j < 14; ++j) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[j], b[0][0][j], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[j], b[0][1][j], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[j], b[1][0][j], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[j], b[1][1][j], acc[1][1], 0, 0, 0);
+            acc[0][0] = C3W64_MFMA(ac[j], b[0][0][j], acc[0][0], 0, 0, 0);
+            acc[0][1] = C3W64_MFMA(ac[j], b[0][1][j], acc[0][1], 0, 0, 0);
+            acc[1][0] = C3W64_MFMA(ac[j], b[1][0][j], acc[1][0], 0, 0, 0);
+            acc[1][1] = C3W64_MFMA(ac[j], b[1][1][j], acc[1][1], 0, 0, 0);
+        }
+        // The next row pair's halo (loaded while this one computed) goes to the other LDS buffer HERE, between the MFMAs and the
+        // output stores, and the loads of the row pair after it are issued here too.  Vector-memory operations of a wave complete in
+        // order and loads and stores share one counter: with the staging at the top of the next unit the s_waitcnt vmcnt(0) in front of
+        // it also waited for the 32 stores the wave had issued a moment before — a full store round trip per unit with nothing else
+        // to do (round 6, second session: ablations in profiles/r06b_c3w64_ablations.txt).  Here the youngest stores in front of the
+        // loads are a whole MFMA phase old.
+        const bool last_of_tile = u + 1 < u1 && ((u + 1) >> 1) != t;
+        if (last_of_tile) {
+            store_tile(buf ^ 1);
+            t_cur = t + 1;
+            if (t_cur < t_last) load_tile(t_cur + 1);
         }
         // epilogue: window = {(h, w), (h, w+1), (h+1, w), (h+1, w+1)}, first maximum in that scan order wins (ATen
         // max_pool2d); lanes 0-31 store the pooled run of channel c, lanes 32-63 that of channel c + 4
@@ -1086,6 +1107,13 @@ __global__ __launch_bounds__(512) void conv3x3_c3w64_relu_pool_kernel(
             // and after the ReLU (smaller positions are <= it either way); a non-positive maximum is a dead window: same values and
             // codes as the scan over the four ReLU outputs, 15 instead of 21 VALU instructions per pooled value (they add to the
             // f32-MFMA time of the SIMD's other wave)
+#if C3W64_ABL & 2          // timing only: no pooling arithmetic
+            const float m2 = acc[0][0][r] + acc[0][1][r] + acc[1][0][r] + acc[1][1][r];
+            const bool cok2 = FULL || cbase + c0 + 4 * kk < Cout;
+            clhip_buf_store(m2, r_o, cok2 ? ovoff * 4 : CLHIP_OOB, (obase + c0 * chw) * 4);
+            clhip_buf_store_u8((uint8_t)r, r_i, cok2 ? ovoff : CLHIP_OOB, obase + c0 * chw);
+            continue;
+#endif
             const float tl = acc[0][0][r], tr = acc[0][1][r], bl = acc[1][0][r], br = acc[1][1][r];
             // (v_max3 / v_max by name: fmaxf() on an MFMA result first canonicalises it with a v_max_f32 x, x of its own)
             float mx, m;
@@ -1098,9 +1126,16 @@ __global__ __launch_bounds__(512) void conv3x3_c3w64_relu_pool_kernel(
             if (!(mx > 0.f)) am = CLHIP_POOL_DEAD;
             asm("v_max_f32 %0, 0, %1" : "=v"(m) : "v"(mx));
             const bool cok = FULL || cbase + c0 + 4 * kk < Cout;
+#if C3W64_ABL & 1          // timing only: no stores (one lane keeps the values alive)
+            if (m == 12345.678f) {
+#endif
             clhip_buf_store(m, r_o, cok ? ovoff * 4 : CLHIP_OOB, (obase + c0 * chw) * 4);
             clhip_buf_store_u8((uint8_t)am, r_i, cok ? ovoff : CLHIP_OOB, obase + c0 * chw);
+#if C3W64_ABL & 1
+            }
+#endif
         }
+        if (last_of_tile) buf ^= 1;
     }
 }
 
