@@ -1244,8 +1244,11 @@ def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epoch
             pair["cpu_spread_points"] = gap(cpu[0], cpu[1]) if len(cpu) > 1 else None
             pair["agree"] = pair["max_accuracy_gap_points"] <= max(3.0, pair["cpu_spread_points"] or 0.0)
             pair["gpu_s"], pair["cpu_s"] = pair["gpu"]["seconds"], cpu[0]["seconds"]
-            pair["cpu_concurrency"] = "the two CPU legs (%s threads) ran side by side while the GPU ran its sweep (%d logical cores)" % (
-                " / ".join(str(c["threads"]) for c in cpu), os.cpu_count() or 0)
+            pair["cpu_concurrency"] = "the two CPU legs (%s threads) ran side by side%s while the GPU ran its sweep (%d logical cores)" % (
+                " / ".join(str(c["threads"]) for c in cpu),
+                (", next to the chain's %d CPU legs (%s threads each, logical CPUs from %s)" % (
+                    res["chain"].get("tasks_compared", 0), res["chain"].get("cpu_threads_per_leg"), res["chain"].get("cpu_legs_pinned_from_logical_cpu"))
+                 if isinstance(res.get("chain"), dict) and "per_task" in res["chain"] else ""), os.cpu_count() or 0)
             pair["gpu_over_cpu_wall_clock"] = pair["cpu_s"] / pair["gpu_s"]
             res["pair"] = pair
             res["pair_cpu_rates_images_per_s"] = cpu[0]["rates_images_per_s"]

@@ -61,7 +61,11 @@ def test_chain_cpu_leg_accumulates_onto_the_model_files_omega(tmp_path):
     ppath = str(tmp_path / "plan.json")
     with open(ppath, "w") as f:
         json.dump(plan, f)
-    row = bench.chain_cpu_leg(ppath, 0, 2)
+    threads = torch.get_num_threads()
+    try:
+        row = bench.chain_cpu_leg(ppath, 0, 2)           # (a leg is a process of its own in the bench: it sets its thread count)
+    finally:
+        torch.set_num_threads(threads)
     assert not row.get("diverged"), row
     for k in ("val_acc", "test_acc", "previous_task_test_acc", "omega_sum_trunk", "omega_max", "seconds"):
         assert k in row, row
