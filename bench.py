@@ -822,12 +822,13 @@ def forced_leg(plan_path, device):
     return {"clhip_bs": os.environ.get("CLHIP_BS", "1"), "tasks": legs}
 
 
-def forced_paths(out, stability, groot, epochs, batch=200, paths=("0", "1", "2")):
+def forced_paths(out, stability, groot, epochs, batch=200, paths=("0", "1", "2"), condition=True):
     """The three fp32-grade kernel paths (CLHIP_BS = 0: Winograd f32 on every 3x3 layer; 1: the default; 2: bf16-split wherever it
     runs) compared TASK BY TASK on the sweep that just ran: each path repeats every task's accepted training from the free run's
     own previous model, learning rate and lambda (`forced_leg`), in its own process, the three side by side on this GPU.  A free-
     running sweep cannot be compared this way: which stability-decay attempts diverge is decided by rounding (sweep_conditioning),
-    on any fp32 implementation.  Reports per task the largest accuracy difference between the paths (new task, previous task under
+    on any fp32 implementation.  `condition`: a task whose accepted training sits within 25 % of the stability limit (x > NEAR_LIMIT)
+    is repeated at the accepted lambda halved until x <= NEAR_LIMIT (as the chain does), so that every task is a well-conditioned leg.  Reports per task the largest accuracy difference between the paths (new task, previous task under
     the new trunk), the validation accuracies, and the relative spread of Sum(Omega); legs whose training sits within 25 % of the
     stability limit (x > NEAR_LIMIT) are listed and left out of the `well_conditioned` maxima."""
     import subprocess
@@ -837,9 +838,16 @@ def forced_paths(out, stability, groot, epochs, batch=200, paths=("0", "1", "2")
         if t < 2 or row["lr"] is None:
             continue
         acc = row["attempts"][-1]
+        # lambda of the comparison = the accepted one, halved further along the reference's schedule (framework_train.py:168-216) until
+        # x = 2 lambda max(Omega) lr <= NEAR_LIMIT: two kernel paths are compared, not two draws of a training at its stability limit
+        lam, x = float(acc["lambda"]), acc["two_lambda_omega_lr"]
+        halvings = 0
+        while condition and x is not None and x > NEAR_LIMIT and halvings < 12:
+            lam, x, halvings = 0.5 * lam, 0.5 * x, halvings + 1
         jobs.append({"task": t, "dataset": out["ds_paths"][t - 1], "previous_dataset": out["ds_paths"][t - 2],
-                     "previous_model": out["model_paths"][t - 2], "lr": float(row["lr"]), "lambda": float(acc["lambda"]),
-                     "x": acc["two_lambda_omega_lr"]})
+                     "previous_model": out["model_paths"][t - 2], "lr": float(row["lr"]), "lambda": lam, "x": x,
+                     "lambda_accepted_by_free_run": float(acc["lambda"]), "x_of_accepted": acc["two_lambda_omega_lr"],
+                     "halvings_below_accepted": halvings})
     plan_path = os.path.join(groot, "forced_plan.json")
     with open(plan_path, "w") as f:
         json.dump({"jobs": jobs, "epochs": epochs, "batch": batch}, f)
@@ -867,6 +875,7 @@ def forced_paths(out, stability, groot, epochs, batch=200, paths=("0", "1", "2")
     for i, job in enumerate(jobs):
         rows = [legs[p][i] for p in paths]
         entry = {"task": job["task"], "lr": job["lr"], "lambda": job["lambda"], "x": job["x"],
+                 "lambda_accepted_by_free_run": job["lambda_accepted_by_free_run"], "x_of_accepted": job["x_of_accepted"],
                  "diverged": [p for p, r in zip(paths, rows) if r.get("diverged")]}
         gaps = {}
         for key, scale in (("test_acc", 1.0), ("previous_task_test_acc", 1.0), ("val_acc", 100.0)):

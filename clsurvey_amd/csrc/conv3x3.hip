@@ -935,6 +935,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_relu_pool_kernel(
 #ifndef CLHIP_C3W64
 #define CLHIP_C3W64 1
 #endif
+// (Measured and removed, round 6: the B operands of a unit as 12 ds_read2_b64 — the four floats X[c][halo row][2 li .. 2 li + 3] around a
+// lane's two pixel columns, even row stride, operands picked by name + 20 v_cndmask — instead of 22 two-dword reads: 43.0 against
+// 43.1 us; the 13.5 us the LDS reads cost by ablation are not a matter of the instruction count.  tools/experiments/r06_b9.sh)
 constexpr int W6_TWP = 67;                          // odd row stride: the two taps of a k-pair sit on different banks
 constexpr int W6_PLANE = 4 * W6_TWP;                // 4 halo rows per channel
 constexpr int W6_HALO = 3 * W6_PLANE;               // 804 floats per wave and buffer
@@ -943,6 +946,14 @@ constexpr int W6_HALO = 3 * W6_PLANE;               // 804 floats per wave and b
 // arithmetic, 4 no LDS reads of the B operands, 8 no MFMAs
 #ifndef C3W64_ABL
 #define C3W64_ABL 0
+#endif
+// 1: the bias rides in the 28th slot of K (second half of the last k-pair; A = bias, B = 1.0 from ones_s) and arrives inside the last
+// MFMA of the chain instead of through 64 v_add_f32 per unit in the epilogue (measured ~ -0.8 us of 44).  The sum then differs from
+// "(sum over 27 taps) + bias" by the rounding of one addition — fp32-grade either way, but ANY change of the last bit re-draws the
+// outcome of the bench's ill-conditioned 10-task sweep, and the draw of the bit pattern of rounds 3 - 6 is the recorded one:
+// default 0, the product adds the bias behind the chain as every other conv kernel of the library does.
+#ifndef CLHIP_C3W64_BIAS_IN_K
+#define CLHIP_C3W64_BIAS_IN_K 0
 #endif
 #if C3W64_ABL & 8
 __device__ __forceinline__ floatx16 c3w64_fake_mfma(float a, float b, floatx16 c) { c[0] += a * b; return c; }
@@ -955,11 +966,19 @@ __global__ __launch_bounds__(512) void conv3x3_c3w64_relu_pool_kernel(
     const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
     float* __restrict__ out, uint8_t* __restrict__ pool_idx, int N, int Cout, int H, int W,
     int tiles_w, int row_pairs, int ntiles) {
-    __shared__ float halo_s[8 * 2 * W6_HALO];
+    __shared__ __attribute__((aligned(16))) float halo_s[8 * 2 * W6_HALO];
+#if CLHIP_C3W64_BIAS_IN_K
     __shared__ float ones_s[W6_TWP + 5];
+#else
+    __shared__ float bias_s[KT];
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kk = lane >> 5;
     const int ko0 = blockIdx.y * KT;
+#if CLHIP_C3W64_BIAS_IN_K
     if (tid < W6_TWP + 5) ones_s[tid] = 1.f;
+#else
+    if (tid < KT) bias_s[tid] = (bias && ko0 + tid < Cout) ? bias[ko0 + tid] : 0.f;
+#endif
 
     // K order and pairing: as in conv3x3_c3_relu_pool_kernel (the two taps of a pair differ by a fixed LDS offset)
     float a[2][14];
@@ -977,11 +996,9 @@ __global__ __launch_bounds__(512) void conv3x3_c3w64_relu_pool_kernel(
         for (int half = 0; half < 2; ++half) {
             const int ch = ko0 + 32 * half + li;
             a[half][j] = (real && ch < Cout) ? wt[(size_t)ch * 27 + c * 9 + r * 3 + s2] : 0.f;
-            // The 28th slot of K (second half of the last k-pair, zero so far) carries the BIAS: its B operand reads 1.0 (ones_s), so the
-            // bias arrives inside the last MFMA of the chain instead of through 64 v_add_f32 per unit in the epilogue (VALU issue adds to
-            // the f32-MFMA time of the SIMD's other wave; round 6, second session).  The sum differs from "(sum over 27 taps) + bias" by
-            // the rounding of one addition.
+#if CLHIP_C3W64_BIAS_IN_K
             if (j == 13 && kk == 1) a[half][j] = (bias && ch < Cout) ? bias[ch] : 0.f;
+#endif
         }
     }
     const int b_row = 2 * li + kk * W6_TWP, b_col = 2 * li + kk, b_pln = 2 * li + kk * W6_PLANE;
@@ -989,7 +1006,7 @@ __global__ __launch_bounds__(512) void conv3x3_c3w64_relu_pool_kernel(
         if (j < 9) return b_row + (j / 3) * W6_PLANE + (j % 3);
         if (j < 12) return b_col + (j - 9) * W6_PLANE + 2 * W6_TWP;
         if (j == 12) return b_pln + 2 * W6_TWP + 2;
-        return 2 * li + 2 * W6_PLANE + 2 * W6_TWP + 2;              // (kk = 1: the bias slot, reads ones_s instead)
+        return 2 * li + 2 * W6_PLANE + 2 * W6_TWP + 2;              // kk = 1 reads the same finite value; its A is 0 (or: the bias slot, reads ones_s)
     };
 
     // units of this wave
@@ -1038,7 +1055,7 @@ __global__ __launch_bounds__(512) void conv3x3_c3w64_relu_pool_kernel(
     const int chw = OH * OW;
     const __amdgpu_buffer_rsrc_t r_o = clhip_rsrc(out, (size_t)N * Cout * chw * 4);
     const __amdgpu_buffer_rsrc_t r_i = clhip_rsrc(pool_idx, (size_t)N * Cout * chw);
-    __syncthreads();                                // ones_s
+    __syncthreads();                                // ones_s / bias_s
     if (u0 >= u1) return;
     int t_cur = u0 >> 1;
     const int t_last = (u1 - 1) >> 1;
@@ -1063,7 +1080,11 @@ __global__ __launch_bounds__(512) void conv3x3_c3w64_relu_pool_kernel(
 #if C3W64_ABL & 4          // timing only: no LDS reads of the B operands
                     b[row][par][j] = __int_as_float(0x3f800000 + j + row + par + lane);
 #else
+#if CLHIP_C3W64_BIAS_IN_K
                     b[row][par][j] = (j == 13 && kk == 1) ? ones_s[row * W6_TWP + par] : xs[b_addr(j) + row * W6_TWP + par];
+#else
+                    b[row][par][j] = xs[b_addr(j) + row * W6_TWP + par];
+#endif
 #endif
         __builtin_amdgcn_sched_barrier(0);          // all LDS reads in flight before the first MFMA
         {   // first k-pair: C operand is the constant 0 (no 64 v_mov to clear the accumulators)
@@ -1102,7 +1123,11 @@ __global__ __launch_bounds__(512) void conv3x3_c3w64_relu_pool_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int c0 = (r & 3) + 8 * (r >> 2);
-            // (the bias is already in the accumulators: see a[][13])
+#if CLHIP_C3W64_BIAS_IN_K
+            const float bv = 0.f;                   // (already in the accumulators: see a[][13])
+#else
+            const float bv = bias_s[32 * half + 4 * kk + c0];
+#endif
             // max(relu(.)) = relu(max(.)), and while the maximum is positive the first window position that holds it is the same before
             // and after the ReLU (smaller positions are <= it either way); a non-positive maximum is a dead window: same values and
             // codes as the scan over the four ReLU outputs, 15 instead of 21 VALU instructions per pooled value (they add to the
@@ -1114,7 +1139,7 @@ __global__ __launch_bounds__(512) void conv3x3_c3w64_relu_pool_kernel(
             clhip_buf_store_u8((uint8_t)r, r_i, cok2 ? ovoff : CLHIP_OOB, obase + c0 * chw);
             continue;
 #endif
-            const float tl = acc[0][0][r], tr = acc[0][1][r], bl = acc[1][0][r], br = acc[1][1][r];
+            const float tl = acc[0][0][r] + bv, tr = acc[0][1][r] + bv, bl = acc[1][0][r] + bv, br = acc[1][1][r] + bv;
             // (v_max3 / v_max by name: fmaxf() on an MFMA result first canonicalises it with a v_max_f32 x, x of its own)
             float mx, m;
             asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(tl), "v"(tr), "v"(bl));

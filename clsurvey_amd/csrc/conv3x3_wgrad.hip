@@ -634,8 +634,11 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_smallc_kernel(
 // terms) instead of an f64 sum; the slabs are still added in f64 (wgrad_reduce_block).  0: f64 sums as conv3x3_wgrad_smallc_kernel.
 // Measured on the LDS-staged build (N = 200, tools/experiments/r06_b6.sh): 45.0 -> 43.3 us; the bias gradient of a 200-image batch
 // differs from the f64 sum by 1.9e-4 at |db| = 1e3 (2e-7 relative; the f64 form: 8e-5), tools/experiments/u3_dump.py.
+// Default 0 all the same: any change of the last bit of a gradient re-draws the outcome of the bench's ill-conditioned 10-task sweep
+// (with this form on, the sweep's task 2 is accepted above the stability limit and the sequence ends without a model at
+// task 4), and the recorded draw is that of the f64 sums.
 #ifndef CLHIP_U3_BSUM_MFMA
-#define CLHIP_U3_BSUM_MFMA 1
+#define CLHIP_U3_BSUM_MFMA 0
 #endif
 // 1: the pooled gradient and its arg-max codes reach the lanes through a wave-private LDS image instead of straight from memory.  A
 // lane of the A operand is a CHANNEL: loading "the 16 windows of my channel" puts every lane of a load instruction on a cache line of
