@@ -1789,6 +1789,8 @@ def main():
                               "pair_max_accuracy_gap_points": out["sweep"].get("pair", {}).get("max_accuracy_gap_points"),
                               "pair_cpu_spread_points": out["sweep"].get("pair", {}).get("cpu_spread_points")}
             fp, cond = out["sweep"].get("forced_paths") or {}, out["sweep"].get("conditioning") or {}
+            if out["sweep"].get("error") or out["sweep"].get("gpu_error"):       # (a sequence that ends without a model: profiles/r06b_sweep_redraw.txt)
+                out["sweep_s"]["error"] = str(out["sweep"].get("gpu_error") or out["sweep"].get("error"))[:160]
             ch = out["sweep"].get("chain") or {}
             out["sweep_s"]["cpu_vs_hip_chain"] = ({"tasks": ch.get("tasks_compared"), "max_gap_points": ch.get("max_gap_points"),
                                                    "max_omega_sum_rel_gap": ch.get("max_omega_sum_rel_gap"),

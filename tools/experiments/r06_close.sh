@@ -3,8 +3,8 @@
 # ranks on cuda:0, HIP_VISIBLE_DEVICES given); then the profile set of the same build: rocprofv3 kernel trace of the plan-executor step,
 # MFMA-pipe busy (PMC) per kernel for the three VGG9 widths, per-layer conv timings, HBM traffic of the layer-2 launches, AlexNet step
 set -u
-mkdir -p gpurun_out/r06y; export TMPDIR=/tmp
-O=gpurun_out/r06y; P=$PWD
+mkdir -p gpurun_out/r06x; export TMPDIR=/tmp
+O=gpurun_out/r06x; P=$PWD
 SECONDS=0
 python -m pytest tests -m gpu -q -p no:cacheprovider --tb=short 2>&1 | tail -4 | cut -c1-300
 echo "suite: $SECONDS s"
@@ -25,10 +25,10 @@ head -14 $O/kernel_stats_by_grid.csv | cut -c1-200
 echo "trace: $SECONDS s"; SECONDS=0
 for m in small base wide; do
   timeout 120 python tools/conv_bench.py $m 200 20 2>&1 | grep -v amdgpu.ids > $O/conv_layers_$m.txt
-  bash tools/gpu_mfma_util.sh ${m}_VGG9_cl_$([ $m = small ] && echo 128_128 || echo 512_512) r06y/mfma_util_$m > /dev/null 2>&1
+  bash tools/gpu_mfma_util.sh ${m}_VGG9_cl_$([ $m = small ] && echo 128_128 || echo 512_512) r06x/mfma_util_$m > /dev/null 2>&1
 done
 tail -4 $O/conv_layers_small.txt; tail -1 $O/conv_layers_base.txt; tail -1 $O/conv_layers_wide.txt
 head -10 $O/mfma_util_small.csv | cut -c1-150
-for k in bs_fwdpool bs_dgrad_unpool bs_wgrad_unpool; do bash tools/gpu_traffic.sh r06y/t_$k $k 200 64 64 32 3 2>&1 | grep -v amdgpu.ids | tee -a $O/traffic.txt; done
+for k in bs_fwdpool bs_dgrad_unpool bs_wgrad_unpool; do bash tools/gpu_traffic.sh r06x/t_$k $k 200 64 64 32 3 2>&1 | grep -v amdgpu.ids | tee -a $O/traffic.txt; done
 timeout 200 python tools/alexnet_step.py 128 2>&1 | grep -v amdgpu.ids | tail -3 | tee $O/alexnet_step.txt
 echo "profiles: $SECONDS s"
