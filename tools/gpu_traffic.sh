@@ -16,7 +16,7 @@ agg = collections.defaultdict(list)
 for r in rows:
     agg[r["Kernel_Name"][:70]].append(float(r["Counter_Value"]))
 for k, v in agg.items():
-    if "conv3x3" in k or "wino" in k:
+    if "conv3x3" in k or "wino" in k or "bs_" in k or "wgrad_reduce" in k:
         print(sys.argv[2], k, "dispatches", len(v), "per-dispatch", sorted(v)[len(v) // 2])
 PY
 done
