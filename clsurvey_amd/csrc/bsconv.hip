@@ -354,6 +354,10 @@ __device__ __forceinline__ void bs_conv_body(
     // backward-data: profiles/r05_bs_v2_ablations.txt).  All staging buffers are free here (last barrier passed); each wave uses its own piece.
     const bool fast = !odd && (W & 3) == 0 && (!pool || (OW & 3) == 0) && !(BS_ABL & 64);
     if (fast) {
+        // (output stores: buffer instructions with the output cache policy of common.hpp, descriptors at the wave's image)
+        const size_t img_elems = (size_t)Cout * (pool ? (size_t)OH * OW : chw);
+        const __amdgpu_buffer_rsrc_t rs_out = clhip_out_rsrc(out + (size_t)n_w * img_elems);
+        const __amdgpu_buffer_rsrc_t rs_code = clhip_out_rsrc(pool ? pool_idx + (size_t)n_w * img_elems : nullptr);
         float* const T = reinterpret_cast<float*>(lds_free) + cw * (32 * TS);
         // arg-max codes [pooled row][pooled column] of a channel: behind its 8 WM pooled values, inside its own row of T
         uint8_t* const Cb = reinterpret_cast<uint8_t*>(T + 16 * WM);
@@ -398,7 +402,7 @@ __device__ __forceinline__ void bs_conv_body(
                     const int k = kb + oc, ph = (oh0 >> 1) + pr, pw = (ow0 >> 1) + 4 * c4;
                     if (f < 32 * F4 && k < Cout && n_w < N && ph < OH && pw < OW && !(BS_ABL & 16)) {
                         const float4 v = *reinterpret_cast<const float4*>(T + oc * TS + pr * PW + 4 * c4);
-                        *reinterpret_cast<float4*>(out + ((size_t)n_w * Cout + k) * OH * OW + (size_t)ph * OW + pw) = v;
+                        clhip_buf_store4(v, rs_out, ((k * OH + ph) * OW + pw) * 4, 0);
                     }
                 }
                 // codes: one (channel, pooled row) per lane and step, PW bytes each
@@ -410,9 +414,11 @@ __device__ __forceinline__ void bs_conv_body(
                         const uint8_t* src = Cb + oc * (TS * 4) + pr * PW;
                         uint8_t* dst = pool_idx + ((size_t)n_w * Cout + k) * OH * OW + (size_t)ph * OW + pw;
                         if (pw + PW <= OW) {
-                            if constexpr (PW == 16) *reinterpret_cast<clhip_u32x4*>(dst) = *reinterpret_cast<const clhip_u32x4*>(src);
-                            else if constexpr (PW == 8) *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(src);
-                            else *reinterpret_cast<unsigned*>(dst) = *reinterpret_cast<const unsigned*>(src);
+                            const int co = (k * OH + ph) * OW + pw;
+                            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                            if constexpr (PW == 16) __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const clhip_u32x4*>(src), rs_code, co, 0, CLHIP_ST_AUX);
+                            else if constexpr (PW == 8) __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(src), rs_code, co, 0, CLHIP_ST_AUX);
+                            else __builtin_amdgcn_raw_buffer_store_b32(*reinterpret_cast<const unsigned*>(src), rs_code, co, 0, CLHIP_ST_AUX);
                         } else {
                             for (int q = 0; q < PW && pw + q < OW; ++q) dst[q] = src[q];
                         }
@@ -431,7 +437,7 @@ __device__ __forceinline__ void bs_conv_body(
                             const float4 ms = *reinterpret_cast<const float4*>(mask_src + o);
                             v.x = ms.x > 0.f ? v.x : 0.f; v.y = ms.y > 0.f ? v.y : 0.f; v.z = ms.z > 0.f ? v.z : 0.f; v.w = ms.w > 0.f ? v.w : 0.f;
                         }
-                        *reinterpret_cast<float4*>(out + o) = v;
+                        clhip_buf_store4(v, rs_out, ((k * H + oh) * W + ow) * 4, 0);
                     }
                 }
             }

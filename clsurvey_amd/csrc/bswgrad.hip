@@ -266,13 +266,14 @@ __global__ __launch_bounds__(256, 1) void bs_wgrad_kernel(const float* __restric
 
     // ---- slab: acc[t][i] = dW[t][k0 + row(i, lane)][c0 + col]
     float* slab = part + (size_t)split * slab_stride;
+    const __amdgpu_buffer_rsrc_t rs_slab = clhip_out_rsrc(slab);          // (output cache policy: common.hpp)
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) slab[((size_t)t * K + k0 + mfma32_row(i, lane)) * C + c0 + col] = acc[t][i];
+        for (int i = 0; i < 16; ++i) clhip_buf_store(acc[t][i], rs_slab, (((t * K + k0 + mfma32_row(i, lane)) * C + c0 + col)) * 4, 0);
     if (ct == 0 && (wave >> 1) == 0) {          // bias sums: the two pixel halves of out-channel k0 + col
         bsum += __shfl_xor(bsum, 32, 64);
-        if (half == 0) slab[(size_t)9 * K * C + k0 + col] = bsum;
+        if (half == 0) clhip_buf_store(bsum, rs_slab, (9 * K * C + k0 + col) * 4, 0);
     }
 }
 

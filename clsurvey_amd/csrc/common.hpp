@@ -64,11 +64,33 @@ __device__ __forceinline__ unsigned clhip_buf_load_u16(__amdgpu_buffer_rsrc_t r,
 __device__ __forceinline__ unsigned clhip_buf_load_u8(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     return (unsigned)__builtin_amdgcn_raw_buffer_load_b8(r, voff, soff, 0);
 }
+// Cache policy of the stores that carry a kernel's OUTPUT (activations, gradients, weight-gradient slabs) to the next kernel:
+// sc1 = write-through at agent scope.  The XCD L2s are not coherent with each other, so a kernel ends by writing back whatever its
+// stores left dirty in them; measured (tools/micro/store_policy.hip, profiles/r06c_store_policy.txt) a kernel that writes >= 16 MB
+// ends 2 - 2.5 us earlier when its stores went through as they were issued (8 MB: ~1 us; `nt` alone: nothing).  Same bytes, same
+// values.  CLHIP_ST_AUX=0 builds the default policy (aux bits of the buffer instructions: 1 = sc0, 2 = nt, 16 = sc1).
+#ifndef CLHIP_ST_AUX
+#define CLHIP_ST_AUX 16
+#endif
 __device__ __forceinline__ void clhip_buf_store(float v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, CLHIP_ST_AUX);
 }
 __device__ __forceinline__ void clhip_buf_store_u8(uint8_t v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    __builtin_amdgcn_raw_buffer_store_b8(v, r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b8(v, r, voff, soff, CLHIP_ST_AUX);
+}
+__device__ __forceinline__ void clhip_buf_store4(float4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    const clhip_u32x4 q = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(q, r, voff, soff, CLHIP_ST_AUX);
+}
+__device__ __forceinline__ void clhip_buf_store2(float2 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 q = {__float_as_uint(v.x), __float_as_uint(v.y)};
+    __builtin_amdgcn_raw_buffer_store_b64(q, r, voff, soff, CLHIP_ST_AUX);
+}
+// Output stores through a plain pointer with that policy: `base` must be wave-uniform (it becomes the buffer descriptor), `off` is
+// the lane's ELEMENT offset from it (< 2^29 elements)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t clhip_out_rsrc(void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
 }
 __device__ __forceinline__ size_t out_img_of(int C, int hw) { return (size_t)C * hw; }
 
