@@ -399,6 +399,14 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(
     const bool odd = (H | W) & 1;                                   // uniform; the last tile row / column may be half outside
     const bool row1 = oh + 1 < H, col1 = ow + 1 < W;
     const bool pool = MODE == 0 && pool_idx != nullptr;
+    // output stores with the output cache policy (common.hpp) while 32-bit byte offsets reach the whole tensor, plain stores beyond
+    const bool st32 = (size_t)N * Cout * (pool ? (size_t)(H >> 1) * (W >> 1) : (size_t)H * W) * sizeof(float) <= 0x7fffffffull;
+    const __amdgpu_buffer_rsrc_t rs_out = clhip_out_rsrc(out), rs_code = clhip_out_rsrc(pool_idx);
+    auto st1 = [&](size_t o, float v) { if (st32) clhip_buf_store(v, rs_out, (int)o * 4, 0); else out[o] = v; };
+    auto st2 = [&](size_t o, float a, float b) {
+        if (st32) clhip_buf_store2(make_float2(a, b), rs_out, (int)o * 4, 0); else *reinterpret_cast<float2*>(out + o) = make_float2(a, b);
+    };
+    auto stc = [&](size_t o, int a) { if (st32) clhip_buf_store_u8((uint8_t)a, rs_code, (int)o, 0); else pool_idx[o] = (uint8_t)a; };
     const size_t chw = (size_t)H * W;
     const int OH = H >> 1, OW = W >> 1;
 #pragma unroll
@@ -425,8 +433,8 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(
                 if (relu && !(m > 0.f)) a = CLHIP_POOL_DEAD;   // ReLU folded into the code (see common.hpp)
                 if (ok) {
                     const size_t o = ((size_t)n * Cout + k) * OH * OW + (size_t)(oh >> 1) * OW + (ow >> 1);
-                    out[o] = m;
-                    pool_idx[o] = (uint8_t)a;
+                    st1(o, m);
+                    stc(o, a);
                 }
                 continue;
             }
@@ -439,10 +447,10 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(
                 if (row1) y10 = mask_src[o + W] > 0.f ? y10 : 0.f;
                 if (row1 && col1) y11 = mask_src[o + W + 1] > 0.f ? y11 : 0.f;
             }
-            out[o] = y00;
-            if (col1) out[o + 1] = y01;
-            if (row1) out[o + W] = y10;
-            if (row1 && col1) out[o + W + 1] = y11;
+            st1(o, y00);
+            if (col1) st1(o + 1, y01);
+            if (row1) st1(o + W, y10);
+            if (row1 && col1) st1(o + W + 1, y11);
         } else if (ok) {
             const size_t o = ((size_t)n * Cout + k) * chw + (size_t)oh * W + ow;
             if (MODE == 1 && mask_src) {
@@ -450,8 +458,8 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(
                 y00 = m0.x > 0.f ? y00 : 0.f; y01 = m0.y > 0.f ? y01 : 0.f;
                 y10 = m1.x > 0.f ? y10 : 0.f; y11 = m1.y > 0.f ? y11 : 0.f;
             }
-            *reinterpret_cast<float2*>(out + o) = make_float2(y00, y01);
-            *reinterpret_cast<float2*>(out + o + W) = make_float2(y10, y11);
+            st2(o, y00, y01);
+            st2(o + W, y10, y11);
         }
     }
 }
@@ -741,6 +749,7 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(
     // ------------------------------------------------------------------ output transform  dW = G^T M' G  per accumulator register
     // register r of lane l = (k = k0 + wk*32 + row(r, l), c = c0 + wc*32 + li); M'_f carries the sign (-1)^{[i == 3] + [j == 3]}
     float* slab = part + (size_t)split * slab_stride;
+    const __amdgpu_buffer_rsrc_t rs_slab = clhip_out_rsrc(slab);          // (output cache policy: common.hpp)
     const int cidx = c0 + wc * 32 + li;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -762,16 +771,16 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 const float s12 = 0.5f * (t[a][1] + t[a][2]);
-                slab[((size_t)(3 * a + 0) * K + k) * C + cidx] = t[a][0] + s12;
-                slab[((size_t)(3 * a + 1) * K + k) * C + cidx] = 0.5f * (t[a][1] - t[a][2]);
-                slab[((size_t)(3 * a + 2) * K + k) * C + cidx] = s12 + t[a][3];
+                clhip_buf_store(t[a][0] + s12, rs_slab, (int)(((3 * a + 0) * K + k) * C + cidx) * 4, 0);
+                clhip_buf_store(0.5f * (t[a][1] - t[a][2]), rs_slab, (int)(((3 * a + 1) * K + k) * C + cidx) * 4, 0);
+                clhip_buf_store(s12 + t[a][3], rs_slab, (int)(((3 * a + 2) * K + k) * C + cidx) * 4, 0);
             }
         }
     }
     if (ct == 0 && wc == 0) {
         bsum += __shfl_xor(bsum, 32, 64);
         const int k = k0 + wk * 32 + li;
-        if (kk == 0 && k < K) slab[(size_t)9 * K * C + k] = bsum;
+        if (kk == 0 && k < K) clhip_buf_store(bsum, rs_slab, (int)(9 * K * C + k) * 4, 0);
     }
 }
 
@@ -990,6 +999,14 @@ __device__ __forceinline__ void wino_conv16_body(
     const int n = n0 + wp, oh = 2 * t_row, ow = 2 * t_col;
     const bool tile_ok = n < N;
     const bool pool = MODE == 0 && pool_idx != nullptr;
+    // output stores with the output cache policy (common.hpp) while 32-bit byte offsets reach the whole tensor, plain stores beyond
+    const bool st32 = (size_t)N * Cout * (pool ? (size_t)(H >> 1) * (W >> 1) : (size_t)H * W) * sizeof(float) <= 0x7fffffffull;
+    const __amdgpu_buffer_rsrc_t rs_out = clhip_out_rsrc(out), rs_code = clhip_out_rsrc(pool_idx);
+    auto st1 = [&](size_t o, float v) { if (st32) clhip_buf_store(v, rs_out, (int)o * 4, 0); else out[o] = v; };
+    auto st2 = [&](size_t o, float a, float b) {
+        if (st32) clhip_buf_store2(make_float2(a, b), rs_out, (int)o * 4, 0); else *reinterpret_cast<float2*>(out + o) = make_float2(a, b);
+    };
+    auto stc = [&](size_t o, int a) { if (st32) clhip_buf_store_u8((uint8_t)a, rs_code, (int)o, 0); else pool_idx[o] = (uint8_t)a; };
     constexpr int chw = H * W, OH = H >> 1, OW = W >> 1;
 #pragma unroll
     for (int k2 = 0; k2 < KT2; ++k2)
@@ -1018,8 +1035,8 @@ __device__ __forceinline__ void wino_conv16_body(
                 if (relu && !(m > 0.f)) a = CLHIP_POOL_DEAD;
                 if (ok) {
                     const size_t o = ((size_t)n * Cout + k) * OH * OW + (size_t)(oh >> 1) * OW + (ow >> 1);
-                    out[o] = m;
-                    pool_idx[o] = (uint8_t)a;
+                    st1(o, m);
+                    stc(o, a);
                 }
                 continue;
             }
@@ -1031,8 +1048,8 @@ __device__ __forceinline__ void wino_conv16_body(
                 y00 = m0.x > 0.f ? y00 : 0.f; y01 = m0.y > 0.f ? y01 : 0.f;
                 y10 = m1.x > 0.f ? y10 : 0.f; y11 = m1.y > 0.f ? y11 : 0.f;
             }
-            *reinterpret_cast<float2*>(out + o) = make_float2(y00, y01);
-            *reinterpret_cast<float2*>(out + o + W) = make_float2(y10, y11);
+            st2(o, y00, y01);
+            st2(o + W, y10, y11);
         }
     }
 }
@@ -1373,6 +1390,14 @@ __device__ __forceinline__ void wino_conv16g_body(
     const bool odd = (H | W) & 1;                                   // uniform; the last tile row / column may be half outside
     const bool row1 = oh + 1 < H, col1 = ow + 1 < W;
     const bool pool = MODE == 0 && pool_idx != nullptr;
+    // output stores with the output cache policy (common.hpp) while 32-bit byte offsets reach the whole tensor, plain stores beyond
+    const bool st32 = (size_t)N * Cout * (pool ? (size_t)(H >> 1) * (W >> 1) : (size_t)H * W) * sizeof(float) <= 0x7fffffffull;
+    const __amdgpu_buffer_rsrc_t rs_out = clhip_out_rsrc(out), rs_code = clhip_out_rsrc(pool_idx);
+    auto st1 = [&](size_t o, float v) { if (st32) clhip_buf_store(v, rs_out, (int)o * 4, 0); else out[o] = v; };
+    auto st2 = [&](size_t o, float a, float b) {
+        if (st32) clhip_buf_store2(make_float2(a, b), rs_out, (int)o * 4, 0); else *reinterpret_cast<float2*>(out + o) = make_float2(a, b);
+    };
+    auto stc = [&](size_t o, int a) { if (st32) clhip_buf_store_u8((uint8_t)a, rs_code, (int)o, 0); else pool_idx[o] = (uint8_t)a; };
     const size_t chw = (size_t)H * W;
     const int OH = H >> 1, OW = W >> 1;
 #pragma unroll
@@ -1402,8 +1427,8 @@ __device__ __forceinline__ void wino_conv16g_body(
                 if (relu && !(m > 0.f)) a = CLHIP_POOL_DEAD;
                 if (ok) {
                     const size_t o = ((size_t)n * Cout + k) * OH * OW + (size_t)(oh >> 1) * OW + (ow >> 1);
-                    out[o] = m;
-                    pool_idx[o] = (uint8_t)a;
+                    st1(o, m);
+                    stc(o, a);
                 }
                 continue;
             }
@@ -1416,10 +1441,10 @@ __device__ __forceinline__ void wino_conv16g_body(
                 if (row1) y10 = mask_src[o + W] > 0.f ? y10 : 0.f;
                 if (row1 && col1) y11 = mask_src[o + W + 1] > 0.f ? y11 : 0.f;
             }
-            out[o] = y00;
-            if (col1) out[o + 1] = y01;
-            if (row1) out[o + W] = y10;
-            if (row1 && col1) out[o + W + 1] = y11;
+            st1(o, y00);
+            if (col1) st1(o + 1, y01);
+            if (row1) st1(o + W, y10);
+            if (row1 && col1) st1(o + W + 1, y11);
         } else if (ok) {
             const size_t o = ((size_t)n * Cout + k) * chw + (size_t)oh * W + ow;
             if (MODE == 1 && mask_src) {
@@ -1427,8 +1452,8 @@ __device__ __forceinline__ void wino_conv16g_body(
                 y00 = m0.x > 0.f ? y00 : 0.f; y01 = m0.y > 0.f ? y01 : 0.f;
                 y10 = m1.x > 0.f ? y10 : 0.f; y11 = m1.y > 0.f ? y11 : 0.f;
             }
-            *reinterpret_cast<float2*>(out + o) = make_float2(y00, y01);
-            *reinterpret_cast<float2*>(out + o + W) = make_float2(y10, y11);
+            st2(o, y00, y01);
+            st2(o + W, y10, y11);
         }
     }
 }
@@ -1760,6 +1785,7 @@ __device__ __forceinline__ void wino_wgrad_ps_body(
 
     // ---- output transform dW = G^T M' G: register r of fin[f] of lane (li, q) = (k = k0 + 16 wp + 4 q + r, c = c0 + 16 wc + li)
     float* slab = part + (size_t)split * slab_stride;
+    const __amdgpu_buffer_rsrc_t rs_slab = clhip_out_rsrc(slab);          // (output cache policy: common.hpp)
     const int cidx = c0 + wc * 16 + li;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -1781,9 +1807,9 @@ __device__ __forceinline__ void wino_wgrad_ps_body(
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 const float s12 = 0.5f * (t[a][1] + t[a][2]);
-                slab[((size_t)(3 * a + 0) * K + k) * C + cidx] = t[a][0] + s12;
-                slab[((size_t)(3 * a + 1) * K + k) * C + cidx] = 0.5f * (t[a][1] - t[a][2]);
-                slab[((size_t)(3 * a + 2) * K + k) * C + cidx] = s12 + t[a][3];
+                clhip_buf_store(t[a][0] + s12, rs_slab, (int)(((3 * a + 0) * K + k) * C + cidx) * 4, 0);
+                clhip_buf_store(0.5f * (t[a][1] - t[a][2]), rs_slab, (int)(((3 * a + 1) * K + k) * C + cidx) * 4, 0);
+                clhip_buf_store(s12 + t[a][3], rs_slab, (int)(((3 * a + 2) * K + k) * C + cidx) * 4, 0);
             }
         }
     }
@@ -1791,7 +1817,7 @@ __device__ __forceinline__ void wino_wgrad_ps_body(
         bfin += __shfl_xor(bfin, 16, 64);
         bfin += __shfl_xor(bfin, 32, 64);
         const int k = k0 + wp * 16 + li;
-        if (q == 0 && k < K) slab[(size_t)9 * K * C + k] = bfin;
+        if (q == 0 && k < K) clhip_buf_store(bfin, rs_slab, (int)(9 * K * C + k) * 4, 0);
     }
 }
 
