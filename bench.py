@@ -906,8 +906,8 @@ def forced_paths(out, stability, groot, epochs, batch=200, paths=("0", "1", "2")
 # A bounded task sequence (PAIR's sizes and schedule, CHAIN["tasks"] tasks) run freely through the driver on the GPU — the reference's
 # loop with its LR grid, Fisher pass and stability decay from lambda 400 — and then EVERY task's EWC training repeated on both sides
 # from the free run's own model of the task before (teacher-forced, as forced_paths does between kernel paths): the HIP path in this
-# process, the torch-CPU oracle (oracle/sweep_ref.py) in one host process per task, all of them side by side while the GPU runs its
-# 10-task sweep.  lambda of a task's comparison job = the lambda the free run accepted, halved further (the reference's own decay
+# process, the torch-CPU oracle (oracle/sweep_ref.py) in one host process per task, all of them side by side (the GPU's 10-task sweep
+# has run before them, on an idle host).  lambda of a task's comparison job = the lambda the free run accepted, halved further (the reference's own decay
 # schedule, framework_train.py:168-216) until x = 2 lambda max(Omega) lr <= NEAR_LIMIT: above it penalised SGD sits at its stability
 # limit and two fp32 implementations may differ by whether the stiff coordinate gets excited (sweep_conditioning).
 CHAIN = {"tasks": 4}
@@ -1098,7 +1098,8 @@ def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epoch
     GPU trained (outside every timed region), one learning rate, a PAIR["epochs"]-epoch cap, Fisher pass, one stability-decay
     attempt at the reference's lambda, evaluation of both models: the build's driver + HIP path on the GPU; the same driver +
     the CPU oracle's EWC (oracle/sweep_ref.py) on the host cores, TWICE — at the thread count that won cpu_baseline's probe and at
-    half / double of it, in two processes that run while the GPU does its sweep.  Same task files, start model, batches, head
+    half / double of it, in two processes that start AFTER the GPU's sweep (which is timed with nothing else on the host) and run
+    beside the GPU's remaining legs (the pair's, the chain's, the kernel-path comparison).  Same task files, start model, batches, head
     initialisation.  `cpu_spread_points` = the largest accuracy difference between the two CPU legs (two summation orders of
     the same fp32 arithmetic); `max_accuracy_gap_points` = the largest between the GPU leg and the first CPU leg.
 
@@ -1126,48 +1127,10 @@ def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epoch
     chain_state = None
     try:
         pair = None
-        if cpu_threads:
-            # ---- the pair: first-task model on the GPU (untimed), CPU legs started in the background, GPU leg timed
-            proot = os.path.join(root, "pair_gpu")
-            with contextlib.redirect_stdout(quiet):
-                driver.main(_pair_args(dev) + ["--results_root", proot, "--method_name", "SI", "--runmode", "first_task_basemodel_dump"],
-                            method=M.parse("SI"))
-            other = cpu_threads // 2 if cpu_threads >= 32 else min(2 * cpu_threads, os.cpu_count() or cpu_threads)
-            ncpu = os.cpu_count() or 1
-            for leg_no, t in enumerate([cpu_threads] + ([other] if other != cpu_threads else [])):
-                croot = os.path.join(root, "pair_cpu_t%d" % t)
-                # (logical CPUs [0, n/4) and [n/4, n/2): distinct physical cores, on a two-socket host distinct sockets; the
-                # upper half are the SMT siblings.  Not pinned on small hosts.)
-                pin = leg_no * (ncpu // 4) if ncpu >= 4 * max(cpu_threads, other) else -1
-                for sub in ("data", "models", os.path.join("train", "synthetic_tiny_imagenet", "SI")):
-                    shutil.copytree(os.path.join(proot, sub), os.path.join(croot, sub))
-                env = dict(os.environ, OMP_NUM_THREADS=str(t), MKL_NUM_THREADS=str(t),
-                           HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")     # a CPU leg makes no device context
-                errf = open(os.path.join(root, "pair_cpu_t%d.stderr" % t), "w+")
-                legs.append((t, subprocess.Popen([sys.executable, os.path.abspath(__file__), "--pair-cpu-leg", croot, "--pair-threads", str(t), "--pair-pin", str(pin), "--sweep-blobs",
-                                                  ",".join("%g" % SWEEP_DATA["blobs"][k] for k in ("g", "amp", "noise_lr", "q"))],
-                                                 stdout=subprocess.PIPE, stderr=errf, env=env, text=True), errf))
-            with contextlib.redirect_stdout(quiet), _PassCounter(PAIR["sizes"][0]) as pcounts:
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                gout = driver.main(_pair_args(dev) + _pair_fixed() + ["--results_root", proot], method=M.parse("EWC"))
-                torch.cuda.synchronize()
-                dt = time.perf_counter() - t0
-            pair = {"what": "task 2 of a 2-task sequence (%d/%d/%d images of 3x64x64, 20 classes), from the same first-task model: LR "
-                            "grid {%s}, %d-epoch cap, batch %d, Fisher pass, one stability-decay attempt at lambda = %g, both models "
-                            "evaluated; same task files, start model, batches and head initialisation on every leg"
-                            % (tuple(PAIR["sizes"]) + (PAIR["lr"], PAIR["epochs"], PAIR["batch"], PAIR["lam"])),
-                    "gpu": _pair_summary(gout, dt, pcounts)}
-            if chain:
-                try:
-                    # (the pair's legs hold [0, cpu_threads) and [ncpu / 4, ncpu / 4 + other): the chain's legs take what is left of the
-                    # second quarter — on a two-socket host the second socket)
-                    room = ncpu // 2 - (ncpu // 4 + other)
-                    pinned = ncpu >= 4 * max(cpu_threads, other) and room >= 4 * (CHAIN["tasks"] - 1)
-                    chain_state = chain_start(root, dev, cpu_threads, ncpu // 4 + other if pinned else None, room if pinned else 0)
-                except BaseException as e:     # noqa: BLE001  (the pair and the sweep are reported regardless)
-                    res["chain"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:400])}
-        # ---- the full sweep on the GPU (tasks == 0: only the pair, for checks of the pair itself)
+        # ---- the full sweep on the GPU (tasks == 0: only the pair, for checks of the pair itself).  FIRST, with nothing else on the host:
+        # beside the five torch-CPU processes of the pair / chain legs (~100 busy threads) the same sweep takes 2.7x longer — the
+        # host side of the launch path slows down, not the GPU (profiles/r06c_sweep_alone_vs_in_bench.txt: 32.6 s alone, 88 - 99 s
+        # beside them, pinning this process to free cores changes nothing) — and BASELINE's 'full-sweep wall-clock' is the GPU path's.
         counts = None
         groot = os.path.join(root, "gpu")
         if tasks > 0:
@@ -1214,6 +1177,49 @@ def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epoch
             res["gpu_avg_accuracy"] = float(np.mean(res["gpu_final_accuracies"]))
             res["gpu_avg_forgetting"] = float(np.mean([r[i]["seq_forgetting"][i][-1] for i in sorted(r) if r[i]["seq_forgetting"][i]] or [0.0]))
             res["conditioning"] = sweep_conditioning(res["gpu_stability"])
+        if cpu_threads:
+            # ---- the pair: first-task model on the GPU (untimed), CPU legs started in the background, GPU leg timed
+            proot = os.path.join(root, "pair_gpu")
+            with contextlib.redirect_stdout(quiet):
+                driver.main(_pair_args(dev) + ["--results_root", proot, "--method_name", "SI", "--runmode", "first_task_basemodel_dump"],
+                            method=M.parse("SI"))
+            other = cpu_threads // 2 if cpu_threads >= 32 else min(2 * cpu_threads, os.cpu_count() or cpu_threads)
+            ncpu = os.cpu_count() or 1
+            for leg_no, t in enumerate([cpu_threads] + ([other] if other != cpu_threads else [])):
+                croot = os.path.join(root, "pair_cpu_t%d" % t)
+                # (logical CPUs [0, n/4) and [n/4, n/2): distinct physical cores, on a two-socket host distinct sockets; the
+                # upper half are the SMT siblings.  Not pinned on small hosts.)
+                pin = leg_no * (ncpu // 4) if ncpu >= 4 * max(cpu_threads, other) else -1
+                for sub in ("data", "models", os.path.join("train", "synthetic_tiny_imagenet", "SI")):
+                    shutil.copytree(os.path.join(proot, sub), os.path.join(croot, sub))
+                env = dict(os.environ, OMP_NUM_THREADS=str(t), MKL_NUM_THREADS=str(t),
+                           HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")     # a CPU leg makes no device context
+                errf = open(os.path.join(root, "pair_cpu_t%d.stderr" % t), "w+")
+                legs.append((t, subprocess.Popen([sys.executable, os.path.abspath(__file__), "--pair-cpu-leg", croot, "--pair-threads", str(t), "--pair-pin", str(pin), "--sweep-blobs",
+                                                  ",".join("%g" % SWEEP_DATA["blobs"][k] for k in ("g", "amp", "noise_lr", "q"))],
+                                                 stdout=subprocess.PIPE, stderr=errf, env=env, text=True), errf))
+            with contextlib.redirect_stdout(quiet), _PassCounter(PAIR["sizes"][0]) as pcounts:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                gout = driver.main(_pair_args(dev) + _pair_fixed() + ["--results_root", proot], method=M.parse("EWC"))
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            pair = {"what": "task 2 of a 2-task sequence (%d/%d/%d images of 3x64x64, 20 classes), from the same first-task model: LR "
+                            "grid {%s}, %d-epoch cap, batch %d, Fisher pass, one stability-decay attempt at lambda = %g, both models "
+                            "evaluated; same task files, start model, batches and head initialisation on every leg"
+                            % (tuple(PAIR["sizes"]) + (PAIR["lr"], PAIR["epochs"], PAIR["batch"], PAIR["lam"])),
+                    "gpu": _pair_summary(gout, dt, pcounts)}
+            if chain:
+                try:
+                    # (the pair's legs hold [0, cpu_threads) and [ncpu / 4, ncpu / 4 + other): the chain's legs take what is left of the
+                    # second quarter — on a two-socket host the second socket)
+                    room = ncpu // 2 - (ncpu // 4 + other)
+                    pinned = ncpu >= 4 * max(cpu_threads, other) and room >= 4 * (CHAIN["tasks"] - 1)
+                    chain_state = chain_start(root, dev, cpu_threads, ncpu // 4 + other if pinned else None, room if pinned else 0)
+                except BaseException as e:     # noqa: BLE001  (the pair and the sweep are reported regardless)
+                    res["chain"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:400])}
+        # ---- (the full sweep ran first, above) its kernel-path comparison runs beside the CPU legs
+        if tasks > 0:
             if forced:
                 try:
                     res["forced_paths"] = forced_paths(out, res["gpu_stability"], groot, epochs)
@@ -1253,7 +1259,7 @@ def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epoch
             pair["cpu_spread_points"] = gap(cpu[0], cpu[1]) if len(cpu) > 1 else None
             pair["agree"] = pair["max_accuracy_gap_points"] <= max(3.0, pair["cpu_spread_points"] or 0.0)
             pair["gpu_s"], pair["cpu_s"] = pair["gpu"]["seconds"], cpu[0]["seconds"]
-            pair["cpu_concurrency"] = "the two CPU legs (%s threads) ran side by side%s while the GPU ran its sweep (%d logical cores)" % (
+            pair["cpu_concurrency"] = "the two CPU legs (%s threads) ran side by side%s, after the GPU sweep, beside the GPU's pair / chain / kernel-path legs (%d logical cores)" % (
                 " / ".join(str(c["threads"]) for c in cpu),
                 (", next to the chain's %d CPU legs (%s threads each, logical CPUs from %s)" % (
                     res["chain"].get("tasks_compared", 0), res["chain"].get("cpu_threads_per_leg"), res["chain"].get("cpu_legs_pinned_from_logical_cpu"))
@@ -1265,7 +1271,7 @@ def full_sweep(dev_index, cpu_threads, tasks=10, sizes=(8000, 2000, 1000), epoch
             res["gpu_over_cpu_wall_clock"] = pair["gpu_over_cpu_wall_clock"]
             res["gpu_over_cpu_wall_clock_how"] = "pair: cpu_s / gpu_s of the same bounded task, both measured in this run"
             if counts is not None and cpu_rates:
-                # The sweep runs at batch 200; the pair's legs run at batch 50, two of them side by side with the GPU sweep, so their
+                # The sweep runs at batch 200; the pair's legs run at batch 50, two of them side by side with the chain's legs, so their
                 # rates under-state the host.  Price the sweep's passes at the batch-200 rates cpu_baseline measured ALONE on the
                 # host (best thread count of its probe) instead.
                 res["cpu_rates_images_per_s"] = dict(cpu_rates)
@@ -1490,7 +1496,9 @@ def cpu_baseline(batch, steps):
         probe[cand] = t
         if best is None or t < best[1]:
             best = (cand, t)
-        if t > 4.0 * best[1]:        # (far past the knee: larger counts only get slower, and the probe must stay short)
+        # (past the knee larger counts only get slower, and the probe must stay short: at 256 threads one warm-up + one timed step took
+        # 90 s — 9 images/s, profiles/r06b_final_bench_line.json — behind 182 images/s at 128 and 506 at 32)
+        if t > 2.0 * best[1]:
             break
     cores = best[0]
     torch.set_num_threads(cores)
