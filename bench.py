@@ -1396,7 +1396,7 @@ def compact_line(out, details_path=None, limit=LINE_LIMIT):
         optional["sweep_s"] = out["sweep_s"]
     if isinstance(out.get("grid"), dict):
         optional["grid"] = _pick(out["grid"], ("nodes", "iterations", "winner_rank", "winner_lr", "fill_factor", "collectives_in_timed_region",
-                                                     "per_rank_ms_per_step", "collective_seconds_max_over_ranks", "backend", "visible_devices"))
+                                                     "per_rank_ms_per_step", "collective_seconds_max_over_ranks", "host_marks_s_rank0", "backend", "visible_devices"))
     ss = out.get("sharded_sweep")
     if isinstance(ss, dict):
         optional["sharded_sweep"] = _pick(ss, ("error", "world", "seconds", "first_task_seconds", "methods", "fill_factor_grid", "fill_factor",
@@ -1544,7 +1544,16 @@ def main():
     dev = torch.device("cuda", local_rank)
     dist = None
     backend = os.environ.get("CLHIP_BENCH_BACKEND", "nccl")
-    if world > 1:
+    # CLHIP_BENCH_FORCE_DIST=1: the N > 1 code path with a communicator of ONE rank (dry run of the RCCL calls on a 1-GPU box: every
+    # collective of this file and of framework/shard.py is issued over the real backend; tools/experiments/r06c_rccl1.sh)
+    force_dist = world == 1 and os.environ.get("CLHIP_BENCH_FORCE_DIST") == "1"
+    multi = world > 1 or force_dist
+    if force_dist:
+        os.environ["CLHIP_SHARD_FORCE_COLLECTIVES"] = "1"
+        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -1629,6 +1638,22 @@ def main():
         eng.probe(dom["li"], dom["kind"])
     torch.cuda.synchronize()
     if dist:
+        # the collectives of the timed region once, untimed, on buffers of the same shapes: the first broadcast / all_gather of a
+        # process pays the backend's one-off set-up (streams, events, kernel load: 8 - 28 ms measured on a one-rank RCCL communicator,
+        # profiles/r06c_rccl_one_rank.txt) — as much as the 20 steps they bracket
+        # ... and so does the first launch of every torch kernel the exchange uses (the float64 division / stack / scalar upload that build
+        # the metric row: 18 - 52 ms on an idle GPU the first time, tools/experiments/r06c_rccl4.sh) — so the exchange's own statements run here
+        wb = torch.empty_like(A.theta)
+        bcast(wb, 0)
+        wm = torch.stack([stats[1] / max(float(args.steps * N), 1.0), torch.tensor(float(rank), dtype=torch.float64, device=dev)])
+        if backend != "nccl":
+            wm = wm.cpu()
+        wt = [torch.zeros_like(wm) for _ in range(world)]
+        dist.all_gather(wt, wm)
+        int(max(wt, key=lambda t: (float(t[0]), -float(t[1])))[1])
+        bcast(wb, world - 1)
+        del wb, wm, wt
+        torch.cuda.synchronize()
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -1646,20 +1671,28 @@ def main():
             t = time.perf_counter()
             fn()
             coll_ev.append((name, time.perf_counter() - t, None))
+    marks = []            # (what has been ENQUEUED / finished on the host, seconds since t0): where a rank's time goes when N > 1
     if dist:
         timed_collective("broadcast_start_arena", lambda: bcast(A.theta, 0))   # every node starts from the previous task's model
         stats.zero_()
+        marks.append(("start_broadcast_enqueued", time.perf_counter() - t0))
     for i in range(args.steps):
         step(i)
+    marks.append(("steps_enqueued", time.perf_counter() - t0))
     if dist:
         # metrics of the N nodes to every rank, the winner's parameter arena back to every rank
         mine = torch.stack([stats[1] / max(float(args.steps * N), 1.0), torch.tensor(float(rank), dtype=torch.float64, device=dev)])
+        marks.append(("metrics_tensor_built", time.perf_counter() - t0))
         if backend != "nccl":
             mine = mine.cpu()
         table = [torch.zeros_like(mine) for _ in range(world)]
+        marks.append(("table_allocated", time.perf_counter() - t0))
         timed_collective("all_gather_node_metrics", lambda: dist.all_gather(table, mine))
+        marks.append(("all_gather_enqueued", time.perf_counter() - t0))
         winner = int(max(table, key=lambda t: (float(t[0]), -float(t[1])))[1])
+        marks.append(("metrics_on_host (steps finished)", time.perf_counter() - t0))
         timed_collective("broadcast_winner_arena", lambda: bcast(A.theta, winner))
+        marks.append(("winner_broadcast_enqueued", time.perf_counter() - t0))
         grid = {"nodes": world, "lr_grid": LR_GRID, "iterations": -(-world // len(LR_GRID)), "winner_rank": winner,
                 "winner_lr": LR_GRID[winner % len(LR_GRID)],
                 "collectives_in_timed_region": ["broadcast(start arena %.1f MB)" % (A.numel * 4 / 1e6),
@@ -1686,6 +1719,7 @@ def main():
         grid["collective_seconds_max_over_ranks"] = {name: max(r[1 + j] for r in per_rank) for j, (name, _, _) in enumerate(coll_ev)}
         grid["collective_seconds_rank0"] = {name: per_rank[0][1 + j] for j, (name, _, _) in enumerate(coll_ev)}
         grid["backend"] = "rccl" if backend == "nccl" else backend
+        grid["host_marks_s_rank0"] = {k: v for k, v in marks}
         grid["visible_devices"] = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES"))
     if not torch.isfinite(A.theta).all():
         raise SystemExit("non-finite parameters after the timed run")
@@ -1704,7 +1738,7 @@ def main():
         "config": {"workload": "EWC small_VGG9_cl_128_128, Tiny-ImageNet shapes (3x64x64, 20 classes), "
                                "batch 200: train step + Fisher step (BASELINE configs[1])",
                    "images_per_step": 2 * N, "batch": N,
-                   "parallelism": ("1 GPU" if world == 1 else
+                   "parallelism": ("1 GPU" if not multi else "1 GPU, communicator of one rank (dry run of the N > 1 path)" if force_dist else
                                    "%d grid nodes of the phase-1 LR grid, one per GPU (RCCL: start-model broadcast, metric "
                                    "all_gather, winner broadcast)" % world),
                    "algorithmic_gflop_per_step": 2 * N * step_fl / 1e9,
@@ -1772,15 +1806,15 @@ def main():
                                           **({"one_grid_with_the_layers_other_backward_launch": True,
                                               "one_grid_us_both_launches_with_transform_and_reduction": r["one_grid_us_both_launches"]}
                                              if r.get("one_grid") else {})} for r in rows]}
-        if world == 1 and not args.no_configs:
+        if not multi and not args.no_configs:
             del eng
             torch.cuda.empty_cache()
             out["configs"] = extra_configs(dev, N, args.config_steps)
             torch.cuda.empty_cache()
-        if world == 1 and not args.no_cpu_baseline:
+        if not multi and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, args.cpu_steps)
             out["config"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-        if world == 1 and not args.no_sweep:
+        if not multi and not args.no_sweep:
             try:
                 cb = out.get("cpu_baseline")
                 out["sweep"] = full_sweep(local_rank, cpu_threads=0 if args.no_cpu_baseline else cb["cores"],

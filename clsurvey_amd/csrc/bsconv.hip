@@ -416,9 +416,9 @@ __device__ __forceinline__ void bs_conv_body(
                         if (pw + PW <= OW) {
                             const int co = (k * OH + ph) * OW + pw;
                             typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-                            if constexpr (PW == 16) __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const clhip_u32x4*>(src), rs_code, co, 0, CLHIP_ST_AUX);
-                            else if constexpr (PW == 8) __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(src), rs_code, co, 0, CLHIP_ST_AUX);
-                            else __builtin_amdgcn_raw_buffer_store_b32(*reinterpret_cast<const unsigned*>(src), rs_code, co, 0, CLHIP_ST_AUX);
+                            if constexpr (PW == 16) __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const clhip_u32x4*>(src), rs_code, co, 0, 0);
+                            else if constexpr (PW == 8) __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(src), rs_code, co, 0, 0);
+                            else __builtin_amdgcn_raw_buffer_store_b32(*reinterpret_cast<const unsigned*>(src), rs_code, co, 0, 0);
                         } else {
                             for (int q = 0; q < PW && pw + q < OW; ++q) dst[q] = src[q];
                         }

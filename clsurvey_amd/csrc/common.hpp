@@ -75,8 +75,10 @@ __device__ __forceinline__ unsigned clhip_buf_load_u8(__amdgpu_buffer_rsrc_t r, 
 __device__ __forceinline__ void clhip_buf_store(float v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, CLHIP_ST_AUX);
 }
+// (arg-max bytes keep the default policy: written through, their 1 .. 16-byte pieces reach memory one by one — the pooling forward of
+// layer 2 wrote 19.0 MiB instead of 16.0, profiles/r06c_final_traffic.txt — and 3 MB of dirty lines cost nothing at the end of a kernel)
 __device__ __forceinline__ void clhip_buf_store_u8(uint8_t v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    __builtin_amdgcn_raw_buffer_store_b8(v, r, voff, soff, CLHIP_ST_AUX);
+    __builtin_amdgcn_raw_buffer_store_b8(v, r, voff, soff, 0);
 }
 __device__ __forceinline__ void clhip_buf_store4(float4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
     const clhip_u32x4 q = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};

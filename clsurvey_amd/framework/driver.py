@@ -543,7 +543,7 @@ def eval_all_models_all_tasks(args, manager, ds_paths, model_paths):
         return perf[manager.method.eval_name]
 
     out = {}
-    if world == 1:
+    if shard._solo(world):
         # eval.py:146-247 as it runs: a finished task is never re-evaluated outside overwrite mode (and ends the run), a
         # model whose evaluation fails ends its task's sequence (what was measured is kept), a task with no result at all
         # ends the run; debug mode writes nothing
@@ -675,7 +675,7 @@ def main(argv=None, method=None, dataset=None, train_node_factory=None):
     if args.shard:
         from . import shard
         rank, world = shard.init_from_env()
-        if world > 1:
+        if not shard._solo(world):
             # (the tree is named after the GLOBAL rank: under --methods two blocks both have a block rank 0)
             args.results_root = os.path.join(args.results_root, "rank%d" % shard.global_rank_world()[0])
             train_node_factory = train_node_factory or shard.sharded_grid_factory()

@@ -149,7 +149,7 @@ def init_from_env(backend=None):
     """torch.distributed.run contract: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment.  Returns
     (rank, world); a single process initialises nothing."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    if world <= 1 and _solo(1):
         return 0, 1
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -158,6 +158,12 @@ def init_from_env(backend=None):
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         dist.init_process_group(backend or ("nccl" if use_gpu else "gloo"), rank=int(os.environ["RANK"]), world_size=world)
     return rank_world()
+
+
+def _solo(world):
+    """A one-rank world needs no collective — unless CLHIP_SHARD_FORCE_COLLECTIVES=1 asks for them anyway (tests/test_shard_gpu.py:
+    every collective of this module issued over RCCL on a 1-GPU box, where a second rank cannot exist)."""
+    return world == 1 and os.environ.get("CLHIP_SHARD_FORCE_COLLECTIVES") != "1"
 
 
 def _dev():
@@ -180,7 +186,7 @@ def fill_factor(n_nodes, world):
 def gather_scalars(values):
     """values: {index: float} computed on this rank -> merged dict on every rank."""
     rank, world = rank_world()
-    if world == 1:
+    if _solo(world):
         return dict(values)
     n = torch.tensor([len(values)], dtype=torch.int64, device=_dev())
     counts = [torch.zeros_like(n) for _ in range(world)]
@@ -206,7 +212,7 @@ def gather_scalars(values):
 def broadcast_model(model, src=0):
     """Broadcast all parameters of `model` from rank src as ONE flat tensor (one RCCL broadcast)."""
     rank, world = rank_world()
-    if world == 1:
+    if _solo(world):
         return model
     params = [p.data for p in model.parameters()]
     flat = torch.cat([p.reshape(-1).to(_dev(), torch.float32) for p in params])
@@ -225,7 +231,7 @@ def broadcast_model(model, src=0):
 def broadcast_bytes(payload, src):
     """bytes on rank src (anything on the others) -> the same bytes everywhere; length first, then one uint8 tensor."""
     rank, world = rank_world()
-    if world == 1:
+    if _solo(world):
         return payload
     n = torch.tensor([len(payload) if rank == src else 0], dtype=torch.int64, device=_dev())
     with _timed("broadcast_s"):
@@ -247,7 +253,7 @@ def broadcast_files(directory, src, patterns=("*.pth.tar", "*.pth", "*.FLAG")):
     """The model / checkpoint files directly under `directory` on rank src appear under the same relative name in
     every rank's `directory` (which is a different absolute tree per rank).  Returns the file names."""
     rank, world = rank_world()
-    if world == 1:
+    if _solo(world):
         return []
     names = []
     if rank == src and os.path.isdir(directory):
@@ -278,7 +284,7 @@ def broadcast_object(obj, src=0):
 
 
 def barrier():
-    if rank_world()[1] > 1:
+    if not _solo(rank_world()[1]):
         dist.barrier(group=_G["group"])
 
 
@@ -292,7 +298,7 @@ def all_ok(ok, what=""):
     EVERY rank raises (a rank that failed alone would leave the others waiting in the next collective until the
     communicator times out, with no diagnostic)."""
     rank, world = rank_world()
-    if world > 1:
+    if not _solo(world):
         flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=_dev())
         with _timed("all_reduce_s"):
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=_G["group"])

@@ -52,6 +52,47 @@ def test_driver_shard_two_ranks(tmp_path):
     mp.spawn(_worker, args=(2, port, str(tmp_path), ndev), nprocs=2, join=True)
 
 
+def _worker_rccl_one_rank(rank, world, port, tmp):
+    """World size 1 over the REAL backend: every collective of the sharded driver (scalar gathers on device float64, model files as
+    device uint8, the ok-flag all_reduce(MIN), barriers, object broadcasts) goes through ProcessGroupNCCL = RCCL, with device tensors
+    on cuda:0 — what a 1-GPU box can check of the N > 1 path's use of the library (dtypes, devices, eager communicator set-up)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", CLHIP_SHARD_FORCE_COLLECTIVES="1")
+    torch.cuda.set_device(0)
+    import torch.distributed as dist
+    from clsurvey_amd.framework import driver, shard
+    from clsurvey_amd.methods import method as M
+    assert shard.init_from_env("nccl") == (0, 1)
+    assert dist.get_backend() == "nccl"
+    # the module's collectives one by one
+    assert shard.gather_scalars({3: 0.25, 1: 0.5}) == {1: 0.5, 3: 0.25}
+    assert shard.broadcast_bytes(b"model-bytes" * 1000, 0) == b"model-bytes" * 1000
+    assert shard.broadcast_object({"lr": 1e-3, "ok": True}, src=0) == {"lr": 1e-3, "ok": True}
+    shard.all_ok(True, "smoke")
+    shard.barrier()
+    t = torch.arange(8, dtype=torch.float32, device="cuda:0")
+    dist.broadcast(t, src=0)                                     # bench.py's arena broadcast
+    table = [torch.zeros(2, dtype=torch.float64, device="cuda:0")]
+    dist.all_gather(table, torch.tensor([0.5, 0.0], dtype=torch.float64, device="cuda:0"))      # bench.py's node metrics
+    assert float(table[0][0]) == 0.5
+    # ... and the driver itself, sharded over that one rank
+    common = ["small_VGG9_cl_128_128", "--lr_grid", "1e-2,3e-3", "--num_epochs", "4", "--batch_size", "40",
+              "--saving_freq", "100", "--results_root", tmp, "--synthetic", "2,4,160,40,40,32", "--shard", "--device", "cuda:0"]
+    driver.main(common + ["--method_name", "SI", "--runmode", "first_task_basemodel_dump"], method=M.parse("SI"))
+    out = driver.main(common + ["--method_name", "EWC", "--test", "--drop_margin", "0.05"], method=M.parse("EWC"))
+    assert out["manager"].previous_task_model_path.startswith(os.path.join(tmp, "rank0"))
+    assert sorted(out["results"]) == [0, 1] and len(out["manager"].grid_trace) == 2
+    assert shard.STATS.get("broadcast_calls", 0) > 0 and shard.STATS.get("all_gather_calls", 0) > 0
+    shard.barrier()
+    dist.destroy_process_group()
+
+
+def test_driver_shard_one_rank_over_rccl(tmp_path):
+    port = 29500 + (os.getpid() * 11 + 3) % 2000
+    mp.spawn(_worker_rccl_one_rank, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+
+
 def _worker_methods(rank, world, port, tmp, ndev):
     """`--shard --methods EWC,MAS` on 4 ranks: two blocks of two ranks, one method each."""
     sys.path.insert(0, ROOT)
