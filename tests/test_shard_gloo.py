@@ -311,3 +311,35 @@ def _worker_groups(rank, world, port, tmp):
 def test_method_groups_world4(tmp_path):
     port = 31500 + os.getpid() % 2000
     mp.spawn(_worker_groups, args=(4, port, str(tmp_path)), nprocs=4, join=True)
+
+
+def _worker_forced_world1(rank, world, port, tmp):
+    """CLHIP_SHARD_FORCE_COLLECTIVES=1: a one-rank world issues every collective instead of short-cutting it (the hook behind
+    tests/test_shard_gpu.py::test_driver_shard_one_rank_over_rccl, here over gloo) — and the sharded grid still decides as the
+    sequential rule does."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", CLHIP_SHARD_FORCE_COLLECTIVES="1")
+    from clsurvey_amd.framework import driver, shard
+    assert not shard._solo(1)
+    assert shard.init_from_env("gloo") == (0, 1) and dist.is_initialized()
+    before = dict(shard.STATS)
+    assert shard.gather_scalars({3: 0.25, 1: 0.5}) == {1: 0.5, 3: 0.25}
+    assert shard.broadcast_bytes(b"abc" * 100, 0) == b"abc" * 100
+    assert shard.broadcast_object({"k": [1, 2]}, src=0) == {"k": [1, 2]}
+    shard.all_ok(True, "forced")
+    shard.barrier()
+    assert shard.STATS["all_gather_calls"] > before["all_gather_calls"] and shard.STATS["broadcast_calls"] > before["broadcast_calls"]
+    assert shard.STATS["all_reduce_calls"] > before["all_reduce_calls"]
+    meth = _GridMethod(0)
+    mgr = driver.Manager(_DS(), meth, "prev", os.path.join(tmp, "rank0", "exp"), None)
+    args = _args()
+    best_lr, best_acc = driver.lr_grid_single_task(args, mgr, "all", train_node=shard.sharded_grid_factory()(args, mgr))
+    assert (best_lr, best_acc) == (5e-3, 0.9) and meth.trained == [1e-2, 5e-3, 1e-3, 5e-4, 1e-4]
+    dist.destroy_process_group()
+    del os.environ["CLHIP_SHARD_FORCE_COLLECTIVES"]
+    assert shard._solo(1)
+
+
+def test_forced_collectives_world1(tmp_path):
+    port = 29500 + (os.getpid() * 13 + 5) % 2000
+    mp.spawn(_worker_forced_world1, args=(1, port, str(tmp_path)), nprocs=1, join=True)

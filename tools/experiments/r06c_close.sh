@@ -32,3 +32,6 @@ head -10 $O/mfma_util_small.csv | cut -c1-150
 for k in bs_fwdpool bs_dgrad_unpool bs_wgrad_unpool; do bash tools/gpu_traffic.sh r06w/t_$k $k 200 64 64 32 3 2>&1 | grep -v amdgpu.ids | tee -a $O/traffic.txt; done
 timeout 200 python tools/alexnet_step.py 128 2>&1 | grep -v amdgpu.ids | tail -3 | tee $O/alexnet_step.txt
 echo "profiles: $SECONDS s"
+SECONDS=0
+CLHIP_BENCH_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29566 bench.py --gpus 1 --steps 20 --warmup 5 --no-sweep 2> $O/bench_rccl1.err > $O/bench_rccl1.json; echo "bench, one-rank RCCL communicator (dry run of the N > 1 path): $SECONDS s"
+tail -1 $O/bench_rccl1.json | cut -c1-900
