@@ -364,7 +364,7 @@ def mfma_busy_pmc(width, instance=None):
     when given; None when no profile is on file.  Read from the committed profile, not measured in this run."""
     import glob
     key = {"small_VGG9": "small", "base_VGG9": "base", "wide_VGG9": "wide"}.get(width, width)
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_mfma_util_%s.csv" % key)))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_mfma_util_%s.csv" % key)))      # (r06 < r06b < r06c: the newest sorts last)
     if not files:
         return None
     rows = {}
