@@ -658,7 +658,7 @@ class _PassCounter:
 # level the data sets.  Models start from torchvision's initialisation (models.py, VGGSlim.py / torchvision VGG: Kaiming
 # convolutions, N(0, 0.01) classifier), created by the driver's BaseModel as the reference's models/net.py:158-169 does.
 SWEEP_DATA = {"kind": "blobs", "noise": 0.5, "blobs": {"g": 8, "amp": 4.0, "noise_lr": 1.2, "q": 0.8}}
-PAIR = {"sizes": (2000, 500, 500), "epochs": 6, "batch": 50, "lr": "1e-2", "lam": 400.0}
+PAIR = {"sizes": (2000, 500, 500), "epochs": 4, "batch": 50, "lr": "1e-2", "lam": 400.0}
 
 
 def _pair_args(device):
