@@ -34,6 +34,7 @@
 //
 // Algorithmic FLOPs 2 * 9 * Cin * Cout * H * W * N; issued on the matrix pipe: 6x that, against the 2.5 PFLOP/s dense bf16 peak.
 #include "common.hpp"
+#include "bs_weight.hpp"
 #include <cstdlib>
 
 // Timing-only ablations (tools/experiments; results wrong by design; the product is built with 0): 1 no MFMAs, 2 no weight-operand
@@ -44,73 +45,20 @@
 
 namespace {
 
-typedef __bf16 bs_bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bs_bf16x2 __attribute__((ext_vector_type(2)));
-typedef float bs_f32x2 __attribute__((ext_vector_type(2)));
-
-constexpr int BS_BN = 64;            // output channels per block
-constexpr int BS_CK = 16;            // input channels per k-step (K of v_mfma_f32_32x32x16_bf16)
-
-// two floats -> two bf16 (round to nearest even), `lo` in bits 0..15: v_cvt_pk_bf16_f32
-__device__ __forceinline__ unsigned bs_pk(float lo, float hi) {
-    bs_f32x2 v = {lo, hi};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bs_bf16x2));
-}
-// a = a0 + a1 + a2 exactly (up to 2^-26 |a|): pieces of (a, b) packed pairwise
-__device__ __forceinline__ void bs_split2(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
-    p0 = bs_pk(a, b);
-    float ra = a - __uint_as_float(p0 << 16), rb = b - __uint_as_float(p0 & 0xffff0000u);
-    p1 = bs_pk(ra, rb);
-    ra -= __uint_as_float(p1 << 16);
-    rb -= __uint_as_float(p1 & 0xffff0000u);
-    p2 = bs_pk(ra, rb);
-}
-__device__ __forceinline__ void bs_split8(const float* v, clhip_u32x4& q0, clhip_u32x4& q1, clhip_u32x4& q2) {
-    unsigned a[4], b[4], c[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) bs_split2(v[2 * i], v[2 * i + 1], a[i], b[i], c[i]);
-    q0 = clhip_u32x4{a[0], a[1], a[2], a[3]};
-    q1 = clhip_u32x4{b[0], b[1], b[2], b[3]};
-    q2 = clhip_u32x4{c[0], c[1], c[2], c[3]};
-}
-
 // ---------------------------------------------------------------------------------------------------- weight image
 // img[nt][chunk][tap][piece][lane] (16 bytes each): lane l of the B operand of n tile nt holds output channel ko = 32 nt + (l & 31)
 // and input channels ci = 16 chunk + 8 (l >> 5) + e, e = 0..7, of tap (r, s) — MODE 0: w[ko][ci][r][s]; MODE 1 (backward-data: the
 // kernel's input channels are the layer's output channels): w[ci][ko][ks - 1 - r][ks - 1 - s].  Ko / Ci: channel counts as the KERNEL
-// sees them; ks x ks taps (3 x 3, or 5 x 5: AlexNet's second convolution, models/net.py:96-125).
+// sees them; ks x ks taps (3 x 3, or 5 x 5: AlexNet's second convolution, models/net.py:96-125).  The body (bs_weight_block) lives in
+// bs_weight.hpp: the plan executor builds these images and the Winograd U images of a pass in ONE launch (wino.hip,
+// clhip_internal_weight_images); this kernel serves the single-layer entry points.
 constexpr int BS_WT_JOBS = 24;
 struct BsWtJobs { int n; int pad; clhip_wino_wt j[BS_WT_JOBS]; int first[BS_WT_JOBS + 1]; };
 
 __global__ __launch_bounds__(256) void bs_weight_multi_kernel(BsWtJobs J) {
     int jb = 0;
     for (int i = 1; i < J.n; ++i) jb = ((int)blockIdx.x >= J.first[i]) ? i : jb;
-    const clhip_wino_wt& q = J.j[jb];
-    const int n_chunks = (q.Ci + BS_CK - 1) / BS_CK, n_nt = (q.Ko + 31) / 32;
-    const int ks = q.pad > 0 ? q.pad : 3, T = ks * ks;         // (clhip_wino_wt::pad carries the kernel size here: 0 = 3)
-    const int t = ((int)blockIdx.x - J.first[jb]) * 256 + threadIdx.x;
-    const int lane = t & 63;
-    int rest = t >> 6;
-    const int tap = rest % T;
-    rest /= T;
-    const int chunk = rest % n_chunks, nt = rest / n_chunks;
-    if (nt >= n_nt) return;
-    const int ko = nt * 32 + (lane & 31), ci0 = chunk * BS_CK + 8 * (lane >> 5);
-    float v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int ci = ci0 + e;
-        float x = 0.f;
-        if (ko < q.Ko && ci < q.Ci)
-            x = q.mode == 0 ? q.w[((size_t)ko * q.Ci + ci) * T + tap] : q.w[((size_t)ci * q.Ko + ko) * T + (T - 1 - tap)];
-        v[e] = x;
-    }
-    clhip_u32x4 p0, p1, p2;
-    bs_split8(v, p0, p1, p2);
-    clhip_u32x4* img = reinterpret_cast<clhip_u32x4*>(q.U) + ((size_t)(nt * n_chunks + chunk) * 3 * T + tap * 3) * 64 + lane;
-    img[0] = p0;
-    img[64] = p1;
-    img[128] = p2;
+    bs_weight_block(J.j[jb], (int)blockIdx.x - J.first[jb], (int)threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------- the convolution
@@ -682,9 +630,7 @@ int clhip_internal_bs_weights(const clhip_wino_wt* jobs, int n, hipStream_t s) {
             if (!q.w || !q.U || q.Ko <= 0 || q.Ci <= 0) return CLHIP_EINVAL;
             J.j[i] = q;
             J.first[i] = blocks;
-            const int ks = q.pad > 0 ? q.pad : 3;
-            const int total = ((q.Ko + 31) / 32) * ((q.Ci + BS_CK - 1) / BS_CK) * ks * ks * 64;
-            blocks += (total + 255) / 256;
+            blocks += bs_weight_blocks(q);
         }
         J.first[J.n] = blocks;
         hipLaunchKernelGGL(bs_weight_multi_kernel, dim3(blocks), dim3(256), 0, s, J);

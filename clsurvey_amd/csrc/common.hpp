@@ -156,6 +156,7 @@ int clhip_internal_convkk(int mode, const float* in, const float* w, const float
 // wino.hip: 3x3 convolution by Winograd F(2x2, 3x3) (forward / backward-data); see the file's header
 struct clhip_wino_wt { const float* w; float* U; int Ko, Ci, mode, pad; };
 int clhip_internal_wino_weights(const clhip_wino_wt* jobs, int n, hipStream_t s);
+int clhip_internal_weight_images(const clhip_wino_wt* wino_jobs, int n_wino, const clhip_wino_wt* bs_jobs, int n_bs, hipStream_t s);   // both kinds, one launch
 int clhip_internal_wino_conv_u(int mode, const float* in, const float* U, const float* bias, const float* mask_src, float* out,
                                uint8_t* pool_idx, int unpool, int N, int Cin, int Cout, int H, int W, int relu, hipStream_t s);
 bool clhip_internal_wino_ok(int Cin, int Cout, int H, int W);

@@ -575,9 +575,9 @@ static int wino_prepare(NetPlan* p, const float* params, char* base, bool fwd, b
         if (bwd && L.bs5_d)
             bsjobs.push_back(clhip_wino_wt{params + L.w_off, reinterpret_cast<float*>(base + p->off_wino + L.wino_ud), L.cin, L.cout, 1, 5});
     }
-    const int rc = clhip_internal_wino_weights(jobs.data(), (int)jobs.size(), s);
-    if (rc) return rc;
-    return clhip_internal_bs_weights(bsjobs.data(), (int)bsjobs.size(), s);      // (one launch each: Winograd U images, bf16-split images)
+    // (ONE launch for the Winograd U images and the bf16-split images of the pass when they fit one job table: a boundary between two
+    // launches of 5 - 7 us each costs as much as either)
+    return clhip_internal_weight_images(jobs.data(), (int)jobs.size(), bsjobs.data(), (int)bsjobs.size(), s);
 }
 
 static int net_forward_impl(void* handle, const float* params, const float* x, int N, void* ws, float* logits_out,

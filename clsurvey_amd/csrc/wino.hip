@@ -31,6 +31,7 @@
 //                           (even maps, 8 x 8 image pairs, odd maps 9..16 wide through row-packed tile rows)
 //   wino_wgrad_ps_kernel    weight gradient of layers with few stages per block: 32 x 32 tiles, pixel split, two blocks per CU
 #include "common.hpp"
+#include "bs_weight.hpp"
 #include <cstdlib>
 
 namespace {
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
 // The same for several (layer, mode) pairs in ONE launch: the plan executor transforms the weights of every Winograd layer of a
 // pass at its start (six ~5 us launches per pass of small_VGG9 were 3 % of the step).
 constexpr int WT_JOBS = 24;
-struct WtJobs { int n; int pad; clhip_wino_wt j[WT_JOBS]; int first[WT_JOBS + 1]; };
+struct WtJobs { int n; int pad; clhip_wino_wt j[WT_JOBS]; int first[WT_JOBS + 1]; };      // pad: bit i = job i is a bf16-split image (bs_weight.hpp)
 
 __device__ __forceinline__ void wino_weight_one(const float* __restrict__ w, float* __restrict__ U, int Ko, int Ci, int mode,
                                                 int n_chunks, int i) {
@@ -184,6 +185,10 @@ __global__ __launch_bounds__(256) void wino_weight_multi_kernel(WtJobs J) {
     int jb = 0;
     for (int i = 1; i < J.n; ++i) jb = ((int)blockIdx.x >= J.first[i]) ? i : jb;
     const clhip_wino_wt& q = J.j[jb];
+    if ((J.pad >> jb) & 1) {                 // (uniform per block) a bf16-split image of the same pass
+        bs_weight_block(q, (int)blockIdx.x - J.first[jb], (int)threadIdx.x);
+        return;
+    }
     const int n_chunks = (q.Ci + WCK - 1) / WCK;
     const int total = ((q.Ko + WKT - 1) / WKT) * n_chunks * WCK * WKT;
     const int i = ((int)blockIdx.x - J.first[jb]) * 256 + threadIdx.x;
@@ -1973,6 +1978,39 @@ int clhip_internal_wino_weights(const clhip_wino_wt* jobs, int n, hipStream_t s)
         hipLaunchKernelGGL(wino_weight_multi_kernel, dim3(blocks), dim3(256), 0, s, J);
         CLHIP_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+// Winograd U images (wj) AND bf16-split images (bj) of a pass in ONE launch when they fit one job table; otherwise (or when one kind
+// is absent) the launches of their own.  Same device code per job as the two launches: the images hold the same bits.
+int clhip_internal_weight_images(const clhip_wino_wt* wj, int nw, const clhip_wino_wt* bj, int nb, hipStream_t s) {
+    if (nw <= 0 || nb <= 0 || nw + nb > WT_JOBS) {
+        const int rc = clhip_internal_wino_weights(wj, nw, s);
+        if (rc) return rc;
+        return clhip_internal_bs_weights(bj, nb, s);
+    }
+    if (!wj || !bj) return CLHIP_EINVAL;
+    WtJobs J;
+    J.n = nw + nb;
+    J.pad = 0;
+    int blocks = 0;
+    for (int i = 0; i < J.n; ++i) {
+        const bool is_bs = i >= nw;
+        const clhip_wino_wt& q = is_bs ? bj[i - nw] : wj[i];
+        if (!q.w || !q.U || q.Ko <= 0 || q.Ci <= 0) return CLHIP_EINVAL;
+        J.j[i] = q;
+        J.first[i] = blocks;
+        if (is_bs) {
+            J.pad |= 1 << i;
+            blocks += bs_weight_blocks(q);
+        } else {
+            const int total = ((q.Ko + WKT - 1) / WKT) * ((q.Ci + WCK - 1) / WCK) * WCK * WKT;
+            blocks += (total + 255) / 256;
+        }
+    }
+    J.first[J.n] = blocks;
+    hipLaunchKernelGGL(wino_weight_multi_kernel, dim3(blocks), dim3(256), 0, s, J);
+    CLHIP_LAUNCH_CHECK();
     return 0;
 }
 
